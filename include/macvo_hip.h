@@ -1,0 +1,223 @@
+/*
+ * macvo_hip.h — C ABI of libmacvo_hip.so: the MI355X (gfx950) hot path of MAC-VO.
+ *
+ * Every entry point is what a binding for the reference's per-frame hot path would call
+ * (the reference is pure Python, so the "FFI" is ctypes — see INTEGRATION.md for the stub a
+ * maintainer adds on the reference side).  Each function cites the reference code it replaces
+ * (paths relative to the MAC-VO checkout).
+ *
+ * Conventions
+ *   - All data pointers are DEVICE pointers unless the parameter says "host".
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls only enqueue
+ *     work: no hidden synchronisation, no allocation, no host<->device copies.  The caller
+ *     owns every buffer and synchronises when it needs results.
+ *   - Return value: MV_OK (0) or a negative MV_ERR_* code; nothing throws.
+ *   - Tensors are dense row-major with the shapes given; N1 = H1*W1, N2 = H2*W2.
+ */
+#ifndef MACVO_HIP_H
+#define MACVO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mvStream_t;
+
+enum {
+    MV_OK = 0,
+    MV_ERR_INVALID_ARG = -1,
+    MV_ERR_UNSUPPORTED = -2,
+    MV_ERR_LAUNCH = -3,
+    MV_ERR_WORKSPACE = -4
+};
+
+enum { MV_F32 = 0, MV_F16 = 1, MV_BF16 = 2 };
+
+/* feature-map memory layouts accepted by mv_corr_volume */
+enum {
+    MV_LAYOUT_CHW = 0, /* [B, C, N]  (NCHW feature maps, as the reference hands them over) */
+    MV_LAYOUT_HWC = 1  /* [B, N, C]  (token-major / channels_last)                          */
+};
+
+/* library ABI version (bumped on any signature change) and a static description string */
+int mv_abi_version(void);
+const char* mv_error_string(int code);
+
+/* -------------------------------------------------------------------------------------------
+ * A5  all-pairs cost volume.
+ * Replaces FlowFormer `MemoryEncoder.corr` invoked at Module/Network/FlowFormerCov/flownet.py:26
+ * (`corr = einsum('bhid,bhjd->bhij')`, heads = 1, no 1/sqrt(d)) and the `.float()` at flownet.py:27.
+ *   out[b, i, j] = sum_c f1[b, c, i] * f2[b, c, j]          (== cost_maps [B*N1, 1, H2, W2] fp32)
+ * in_dtype MV_F32: exact fp32 (v_mfma_f32_32x32x2_f32, one rounding per product, k ascending).
+ * in_dtype MV_F16 / MV_BF16: 16-bit operands, fp32 accumulate, fp32 output (Fast mode).
+ * Requirements: C % 16 == 0.  f1/f2 16-byte aligned.
+ */
+int mv_corr_volume(const void* f1, const void* f2, float* out, int B, int C, int N1, int N2,
+                   int in_dtype, int layout, mvStream_t stream);
+
+/* -------------------------------------------------------------------------------------------
+ * A6  (2r+1)^2 bilinear window lookup in each query's own cost slice.
+ * Replaces FlowFormer `MemoryDecoder.encode_flow_token(cost_maps, coords1)` called at
+ * Module/Network/FlowFormerCov/covhead.py:92 ("MUST run in fp32", :91) =
+ * grid_sample(align_corners=True, padding_mode="zeros") on a [B*N1, 2r+1, 2r+1, 2] grid.
+ *   vol    [B*N1, H2, W2] fp32;  coords [B, 2, H1, W1] fp32 (channel 0 = x, 1 = y)
+ *   out    [B, (2r+1)^2, H1, W1] fp32; channel k = (2r+1)*i + j samples (x + i - r, y + j - r)
+ * Requirements: 1 <= radius <= 4.
+ */
+int mv_corr_lookup(const float* vol, const float* coords, float* out, int B, int H1, int W1,
+                   int H2, int W2, int radius, mvStream_t stream);
+
+/* -------------------------------------------------------------------------------------------
+ * A8/A2  frontend epilogue: network output -> the typed records of IStereoDepth.Output / IMatcher.Output.
+ * Replaces Module/Network/FlowFormerCov/flownet.py:44 (`exp(2*cov)`), Module/Frontend/Frontend.py:183-200
+ * (`inference_2_depth`, `inference_2_match`), Module/Frontend/StereoDepth.py:270-282 and
+ * Module/Frontend/Matching.py:28-40 (`from_partial_cov`).
+ *   flow [2, 2, H, W] fp32 (sample 0 = stereo pair, sample 1 = temporal pair)
+ *   logcov [2, 2, H, W] fp32 network log-sigma (cov = exp(2*logcov)); if cov_is_log == 0 it is already sigma^2
+ *   outputs (all [H*W] planes, any may be NULL to skip):
+ *   bl_fx = float(bl*fx), bl_fx_sq = float((bl*fx)**2), both evaluated in double by the caller exactly as
+ *   the reference's Python scalars are, then rounded once to fp32 (what torch does with a Python scalar)
+ *     disparity = |flow[0,0]|, disparity_cov = cov[0,0], depth = bl_fx * (1/disparity),
+ *     depth_cov = bl_fx_sq * ((disparity_cov * (1/d^2)) / d^2), bad_mask = flow[0,0] <= 0 (uint8),
+ *     match_flow [2,H,W] = flow[1], match_cov [3,H,W] = (cov[1,0], cov[1,1], 0)
+ */
+int mv_frontend_epilogue(const float* flow, const float* logcov, int cov_is_log, int H, int W,
+                         float bl_fx, float bl_fx_sq, float* disparity, float* disparity_cov,
+                         float* depth, float* depth_cov, uint8_t* bad_mask, float* match_flow,
+                         float* match_cov, mvStream_t stream);
+
+/* -------------------------------------------------------------------------------------------
+ * A10/A11 + MappingPointSelector  candidate generation for the covariance-aware keypoint selectors.
+ * Replaces the dense part of Module/KeypointSelector.py: CovAwareSelector_NoDepth.select_point :362-400,
+ * CovAwareSelector.select_point :260-327, MappingPointSelector.select_point :87-97 — quality map,
+ * kernel_size x kernel_size min-NMS (NaN-propagating, equality test), border mask, (nan)median*1.5
+ * thresholds with strict '<', optional validity masks, and torch.nonzero's row-major ordering.
+ * The CPU `torch.randperm` (:331,:404,:98) stays on the host so indices are bit-exact; use
+ * mv_kp_gather afterwards.
+ */
+enum { MV_KP_NODEPTH = 0, MV_KP_FULL = 1, MV_KP_MAPPING = 2 };
+
+typedef struct {
+    int32_t H, W;
+    int32_t mode;          /* MV_KP_* */
+    int32_t kernel_size;   /* odd, 1..15 (NMS window)            */
+    int32_t mask_width;    /* border exclusion in pixels (>= 1)  */
+    float max_depth;       /* FULL: z0 < max_depth & z1 < max_depth; MAPPING: z0 < max_depth */
+    float max_depth_cov;   /* FULL: min(max_depth_cov, 1.5*nanmedian); MAPPING: plain '<'    */
+    float max_match_cov;   /* NODEPTH/FULL: min(max_match_cov, 1.5*median)                   */
+} mvKpSelectParams;
+
+/* bytes of scratch mv_kp_select needs for an H x W image */
+size_t mv_kp_select_workspace_bytes(int H, int W);
+
+/*
+ *   flow_cov   [3, H, W] fp32 (uu, vv, uv) — required for NODEPTH, optional (may be NULL) for FULL
+ *   depth0/1, depth0_cov/1_cov [H, W] fp32 — FULL needs all four, MAPPING needs depth0 + depth0_cov
+ *   mask_a, mask_b [H, W] uint8 (0 = reject) or NULL — depth0_est.mask / match_est.mask
+ *   out_cand   [H*W] int32: linear indices v*W + u of the surviving pixels in row-major order
+ *   out_count  [4] int32: {n_candidates, n_nms, 0, 0}
+ *   out_stats  [4] fp32: {median_flow_q, thresh_flow_q, median_depth0_cov, thresh_depth0_cov}
+ */
+int mv_kp_select(const float* flow_cov, const float* depth0, const float* depth0_cov,
+                 const float* depth1, const float* depth1_cov, const uint8_t* mask_a,
+                 const uint8_t* mask_b, const mvKpSelectParams* params /* host */, void* workspace,
+                 size_t workspace_bytes, int32_t* out_cand, int32_t* out_count, float* out_stats,
+                 mvStream_t stream);
+
+/* selected[perm][..., 2:].roll(1, 1)  (KeypointSelector.py:331-332,404-405):
+ *   out_uv[k] = (cand[perm[k]] % W, cand[perm[k]] / W) as int64 (u, v) */
+int mv_kp_gather(const int32_t* cand, const int64_t* perm, int n_sel, int W, int64_t* out_uv,
+                 mvStream_t stream);
+
+/* -------------------------------------------------------------------------------------------
+ * A12  keypoint tracking + the scalar-map gathers of Odometry/MACVO.py:198-232 in one launch.
+ *   kp1 = kp0 + flow[:, v0, u0]; inbound = edge < u1 < W - edge & edge < v1 < H - edge (strict,
+ *   Utility/Point.py:5-13); gathers at kp0 (integer) and at kp1 truncated toward zero
+ *   (Module/Frontend/Frontend.py:117); match covariance read at the SOURCE pixel kp0 (:231).
+ * Outputs are written for every input keypoint (row order preserved); `inbound` says which rows the
+ * reference keeps.  kp0_uv int64 [N,2].  Planes are [H*W] fp32; match_cov is [3,H*W].
+ *   out_kp1 [N,2] fp32; out_inbound [N] uint8;
+ *   out_vals [N, 11] fp32 = {d0, disp0, sdisp0, sdd0, d1, disp1, sdisp1, sdd1, suu, svv, suv}
+ *   (for rows that are not inbound the kp1-side values are 0)
+ */
+int mv_kp_track(const int64_t* kp0_uv, int N, const float* match_flow, const float* match_cov,
+                const float* depth0, const float* disp0, const float* sdisp0, const float* sdd0,
+                const float* depth1, const float* disp1, const float* sdisp1, const float* sdd1,
+                int H, int W, int edge, float* out_kp1, uint8_t* out_inbound, float* out_vals,
+                mvStream_t stream);
+
+/* -------------------------------------------------------------------------------------------
+ * A13-A16  MAC-VO covariance model.
+ * Replaces Module/Covariance/Project2to3.py: MatchCovariance.estimate :124-181 (incl. the in-place
+ * clamp of flow_cov :131), Utility/Math.py:43-63 (gaussain_full_kernels), Covariance_2to3_full
+ * :377-423, create_3x3_matrix :426-433, and (optionally) the world-frame rotation
+ * cov_Tw = R cov R^T of Odometry/MACVO.py:273-281.
+ */
+typedef struct {
+    int32_t H, W;
+    int32_t kernel_size;       /* odd, <= 31 */
+    int32_t use_patch_var;     /* 1: weighted patch variance (flow_cov given or depth_cov NULL); 0: use depth_cov */
+    float fx, fy, cx, cy;
+    float min_flow_cov_sq;     /* config.min_flow_cov ** 2 (clamp applied to flow_cov[:, :2] IN PLACE) */
+    float min_depth_cov;
+} mvMatchCovParams;
+
+/*
+ *   depth_map [H, W] fp32; kp_uv [N, 2] fp32 (u, v) — patch centre = trunc(kp), (u - cx) uses the float
+ *   flow_cov [N, 3] fp32 in/out (clamped in place); depth_cov [N] fp32 or NULL
+ *   rot [9] fp64 row-major or NULL
+ *   out_cov [N, 9] fp64 NED order (z, x, y); out_cov_rot [N, 9] fp64 = R cov R^T or NULL
+ *   out_stats [N, 2] fp32 = (weighted mean depth, clamped variance) or NULL
+ */
+int mv_match_cov(const float* depth_map, const float* kp_uv, float* flow_cov,
+                 const float* depth_cov, const double* rot, const mvMatchCovParams* params /* host */,
+                 int N, double* out_cov, double* out_cov_rot, float* out_stats, mvStream_t stream);
+
+/* -------------------------------------------------------------------------------------------
+ * A17-A22  covariance-weighted two-frame pose-graph solve, batched over independent problems.
+ * Replaces TwoFrame_PGO._optimize (Module/Optimization/TwoFramePGO/Optimizer.py:81-102), the residual
+ * graphs + analytic Jacobians (Module/Optimization/TwoFramePGO/Graphs.py:33-231), LM_analytic.step
+ * (Module/Optimization/PyposeOptimizers.py:160-194) and the PyPose 0.6.8 pieces they call
+ * (Huber, FastTriggs, TrustRegion, PINV, StopOnPlateau, SE3 Exp/Act/Inv).  All arithmetic in fp64
+ * after the fp32 buffer construction the reference performs (Optimizer.py:84-85).
+ */
+enum { MV_GRAPH_ICP = 0, MV_GRAPH_REPROJ = 1, MV_GRAPH_DISP = 2 };
+
+typedef struct {
+    double huber_delta;  /* 0.1   */
+    double radius;       /* 1e3   (damping0 = 1/radius) */
+    double tr_high, tr_low, tr_up, tr_down, tr_factor, tr_min, tr_max; /* .5 1e-3 2 .5 .5 1e-6 1e16 */
+    double diag_min, diag_max; /* 1e-6 1e32 */
+    double decreasing;   /* 1e-5  */
+    double pinv_rcond;   /* 1e-15 */
+    int32_t reject;      /* 16    */
+    int32_t max_steps;   /* 10    */
+    int32_t patience;    /* 2     */
+    int32_t reserved;
+} mvLMParams;
+
+void mv_lm_default_params(mvLMParams* p /* host */);
+
+/*
+ * Problem p owns points [offsets[p], offsets[p+1]) of the concatenated per-point arrays.
+ *   offsets [nprob+1] int32; init_pose [nprob,7] fp32 (tx ty tz qx qy qz qw);
+ *   intrinsics [nprob,4] fp32 (fx fy cx cy); baseline [nprob] fp32
+ *   pos_Tw [Ntot,3] fp32; cov_Tw [Ntot,9] fp64 (ICP only, else may be NULL)
+ *   pixel2_uv [Ntot,2] fp32; pixel2_d [Ntot] fp32 (ICP); pixel2_disp, pixel2_disp_cov [Ntot] fp32 (DISP)
+ *   pixel2_uv_cov [Ntot,3] fp32 (REPROJ/DISP); obs2_covTc [Ntot,9] fp64 (ICP)
+ *   out_pose [nprob,7] fp64; out_info [nprob,4] fp64 = {final loss, outer steps, last reject_count, initial loss}
+ */
+int mv_pgo_solve(int nprob, const int32_t* offsets, int graph_type, const float* init_pose,
+                 const float* intrinsics, const float* baseline, const float* pos_Tw,
+                 const double* cov_Tw, const float* pixel2_uv, const float* pixel2_d,
+                 const float* pixel2_disp, const float* pixel2_disp_cov, const float* pixel2_uv_cov,
+                 const double* obs2_covTc, const mvLMParams* params /* host */, double* out_pose,
+                 double* out_info, mvStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MACVO_HIP_H */

@@ -1,0 +1,119 @@
+"""ctypes binding of ``libmacvo_hip.so`` (C ABI declared in ``include/macvo_hip.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C mac-vo_amd/csrc``.  There is no
+CPU fallback: if the library is missing or a symbol is absent, loading raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmacvo_hip.so")
+
+MV_OK = 0
+MV_F32, MV_F16, MV_BF16 = 0, 1, 2
+MV_LAYOUT_CHW, MV_LAYOUT_HWC = 0, 1
+MV_KP_NODEPTH, MV_KP_FULL, MV_KP_MAPPING = 0, 1, 2
+MV_GRAPH_ICP, MV_GRAPH_REPROJ, MV_GRAPH_DISP = 0, 1, 2
+ABI_VERSION = 1
+
+
+class mvKpSelectParams(C.Structure):
+    _fields_ = [
+        ("H", C.c_int32), ("W", C.c_int32), ("mode", C.c_int32), ("kernel_size", C.c_int32),
+        ("mask_width", C.c_int32), ("max_depth", C.c_float), ("max_depth_cov", C.c_float),
+        ("max_match_cov", C.c_float),
+    ]
+
+
+class mvMatchCovParams(C.Structure):
+    _fields_ = [
+        ("H", C.c_int32), ("W", C.c_int32), ("kernel_size", C.c_int32), ("use_patch_var", C.c_int32),
+        ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("min_flow_cov_sq", C.c_float), ("min_depth_cov", C.c_float),
+    ]
+
+
+class mvLMParams(C.Structure):
+    _fields_ = [
+        ("huber_delta", C.c_double), ("radius", C.c_double),
+        ("tr_high", C.c_double), ("tr_low", C.c_double), ("tr_up", C.c_double), ("tr_down", C.c_double),
+        ("tr_factor", C.c_double), ("tr_min", C.c_double), ("tr_max", C.c_double),
+        ("diag_min", C.c_double), ("diag_max", C.c_double), ("decreasing", C.c_double),
+        ("pinv_rcond", C.c_double),
+        ("reject", C.c_int32), ("max_steps", C.c_int32), ("patience", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+_P = C.c_void_p
+# name -> (restype, argtypes): every symbol include/macvo_hip.h declares
+SIGNATURES = {
+    "mv_abi_version": (C.c_int, []),
+    "mv_error_string": (C.c_char_p, [C.c_int]),
+    "mv_corr_volume": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mv_corr_lookup": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mv_frontend_epilogue": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                       _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mv_kp_select_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "mv_kp_select": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(mvKpSelectParams), _P, C.c_size_t,
+                               _P, _P, _P, _P]),
+    "mv_kp_gather": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
+    "mv_kp_track": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int,
+                              _P, _P, _P, _P]),
+    "mv_match_cov": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(mvMatchCovParams), C.c_int, _P, _P, _P, _P]),
+    "mv_lm_default_params": (None, [C.POINTER(mvLMParams)]),
+    "mv_pgo_solve": (C.c_int, [C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                               C.POINTER(mvLMParams), _P, _P, _P]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class MacvoHipError(RuntimeError):
+    pass
+
+
+def load(path: str | None = None) -> C.CDLL:
+    """Load (once) and type the shared library.  Raises if it is missing — there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        # libmacvo_hip.so needs libamdhip64.so.7: import torch first so that the HIP runtime PyTorch already
+        # loaded is the one the dynamic linker binds (one runtime per process -> shared streams/allocations).
+        import torch  # noqa: F401
+
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise MacvoHipError(
+                f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C mac-vo_amd/csrc` (no CPU fallback exists for the HIP hot path)"
+            )
+        try:
+            lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+        except OSError:
+            # no HIP runtime resolvable yet (e.g. CPU-only process): point the loader at ROCm's copy
+            for cand in ("/opt/rocm/lib/libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so"):
+                if os.path.exists(cand):
+                    C.CDLL(cand, mode=C.RTLD_GLOBAL)
+                    break
+            lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if lib.mv_abi_version() != ABI_VERSION:
+            raise MacvoHipError(f"ABI mismatch: library {lib.mv_abi_version()} != binding {ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != MV_OK:
+        msg = load().mv_error_string(code).decode()
+        raise MacvoHipError(f"{what} failed: {msg} ({code})")

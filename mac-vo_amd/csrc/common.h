@@ -1,0 +1,35 @@
+// Shared device/host helpers for libmacvo_hip (gfx950 / CDNA4 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "macvo_hip.h"
+
+#define MV_WAVE 64
+
+#define MV_CHECK_ARG(cond) \
+    do {                   \
+        if (!(cond)) return MV_ERR_INVALID_ARG; \
+    } while (0)
+
+static inline int mv_launch_status() {
+    return hipGetLastError() == hipSuccess ? MV_OK : MV_ERR_LAUNCH;
+}
+
+static inline int mv_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- wave-level reductions (64 lanes, butterfly so every lane ends with the result) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

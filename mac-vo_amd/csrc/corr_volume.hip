@@ -1,0 +1,519 @@
+// A5 — all-pairs cost volume  out[b,i,j] = sum_c f1[b,c,i] * f2[b,c,j]   
+//
+// Replaces FlowFormer MemoryEncoder.corr (einsum 'bhid,bhjd->bhij', heads = 1, no 1/sqrt(d)) called at
+// Module/Network/FlowFormerCov/flownet.py:26 and the `.float()` at :27.
+//
+// gfx950 design
+//   * fp32 inputs: exact-fp32 MFMA v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain, k ascending).  The NCHW
+//     feature map is K-major for BOTH operands ([C][N]), which is exactly the 32x32x2 A/B fragment order
+//     (lane l holds element [k = l>>5][i = l&31]) — no transposition anywhere: global float4 rows ->
+//     LDS [BK][128] -> conflict-free ds_read_b32 -> MFMA.  MFMA-bound (AI ~116 FLOP/B).
+//   * 16-bit inputs (Fast mode): v_mfma_f32_32x32x16_{f16,bf16}, fp32 accumulate, fp32 out — HBM-write bound.
+//   * 128x128 output tile per 256-thread workgroup (4 waves, 64x64 each = 2x2 MFMA blocks, 64 acc VGPRs),
+//     double-buffered LDS, register-staged global prefetch.
+//   * stores: each v_mfma C register row is 32 consecutive floats (128 B line) per half-wave.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BN = 128;
+
+// XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8); give each XCD a
+// contiguous band of tile rows so the f1 row-band and the streamed f2 tiles stay in that XCD's L2.
+__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int nwg = tiles_m * tiles_n;
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int lin = base + (id >> 3);
+    tm = lin / tiles_n;
+    tn = lin - tm * tiles_n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32, CHW ([C][N]) operands.  BK = 16.
+// ------------------------------------------------------------------------------------------------
+template <bool VEC4>
+__global__ __launch_bounds__(256) void corr_volume_f32_chw(const float* __restrict__ f1,
+                                                            const float* __restrict__ f2,
+                                                            float* __restrict__ out, int C, int N1, int N2,
+                                                            int tiles_m, int tiles_n) {
+    constexpr int BK = 16;
+    __shared__ __attribute__((aligned(16))) float sA[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float sB[2][BK][BN];
+
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    const int b = blockIdx.z;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const float* A = f1 + (size_t)b * C * N1;
+    const float* Bp = f2 + (size_t)b * C * N2;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // loader mapping: 16 rows x 128 cols per operand = 512 float4; thread t takes (row = t/32 + 8*p, col4 = (t%32)*4)
+    const int lrow = t >> 5;
+    const int lcol = (t & 31) * 4;
+
+    f32x4 ra[2], rb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int k = k0 + lrow + 8 * p;
+            const float* pa = A + (size_t)k * N1 + m0 + lcol;
+            const float* pb = Bp + (size_t)k * N2 + n0 + lcol;
+            if (VEC4) {
+                ra[p] = (m0 + lcol < N1) ? *reinterpret_cast<const f32x4*>(pa) : f32x4{0, 0, 0, 0};
+                rb[p] = (n0 + lcol < N2) ? *reinterpret_cast<const f32x4*>(pb) : f32x4{0, 0, 0, 0};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ra[p][e] = (m0 + lcol + e < N1) ? pa[e] : 0.f;
+                    rb[p][e] = (n0 + lcol + e < N2) ? pb[e] : 0.f;
+                }
+            }
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            *reinterpret_cast<f32x4*>(&sA[buf][lrow + 8 * p][lcol]) = ra[p];
+            *reinterpret_cast<f32x4*>(&sB[buf][lrow + 8 * p][lcol]) = rb[p];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+
+    const int nk = C / BK;
+    const int kh = lane >> 5;        // which k of the pair this lane feeds
+    const int li = lane & 31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[2], bb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = sA[buf][kk + kh][wm * 64 + i * 32 + li];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bb[j] = sB[buf][kk + kh][wn * 64 + j * 32 + li];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            sstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* O = out + (size_t)b * N1 * N2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (row < N1) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = n0 + wn * 64 + j * 32 + li;
+                    if (col < N2) __builtin_nontemporal_store(acc[i][j][r], &O[(size_t)row * N2 + col]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32, HWC ([N][C]) operands: same MFMA core; the loader transposes through LDS
+// (global float4 along C -> 4 scalar LDS stores into the K-major tile; row padding +1 keeps them conflict-light).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void corr_volume_f32_hwc(const float* __restrict__ f1,
+                                                            const float* __restrict__ f2,
+                                                            float* __restrict__ out, int C, int N1, int N2,
+                                                            int tiles_m, int tiles_n) {
+    constexpr int BK = 16;
+    constexpr int LD = BM + 4;  // padded leading dim (floats)
+    __shared__ __attribute__((aligned(16))) float sA[2][BK][LD];
+    __shared__ __attribute__((aligned(16))) float sB[2][BK][LD];
+
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    const int b = blockIdx.z;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const float* A = f1 + (size_t)b * N1 * C;
+    const float* Bp = f2 + (size_t)b * N2 * C;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // loader: tile = 128 rows x 16 k = 512 float4; thread t -> (row = t/4 + 64*p, k4 = (t%4)*4)
+    const int lrow = t >> 2;
+    const int lk = (t & 3) * 4;
+    f32x4 ra[2], rb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int ia = m0 + lrow + 64 * p, ib = n0 + lrow + 64 * p;
+            ra[p] = (ia < N1) ? *reinterpret_cast<const f32x4*>(A + (size_t)ia * C + k0 + lk) : f32x4{0, 0, 0, 0};
+            rb[p] = (ib < N2) ? *reinterpret_cast<const f32x4*>(Bp + (size_t)ib * C + k0 + lk) : f32x4{0, 0, 0, 0};
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sA[buf][lk + e][lrow + 64 * p] = ra[p][e];
+                sB[buf][lk + e][lrow + 64 * p] = rb[p][e];
+            }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    const int nk = C / BK;
+    const int kh = lane >> 5, li = lane & 31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[2], bb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = sA[buf][kk + kh][wm * 64 + i * 32 + li];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bb[j] = sB[buf][kk + kh][wn * 64 + j * 32 + li];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            sstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    float* O = out + (size_t)b * N1 * N2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (row < N1) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = n0 + wn * 64 + j * 32 + li;
+                    if (col < N2) __builtin_nontemporal_store(acc[i][j][r], &O[(size_t)row * N2 + col]);
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 16-bit operands (f16 / bf16), HWC ([N][C]): K is contiguous, which is the 32x32x16 fragment order
+// (lane l holds 8 consecutive k of row l&31, k-group l>>5).  BK = 64: a tile row is one 128-B line.
+// LDS tile [128 rows][64 k] 16-bit, 16-B chunks XOR-swizzled by (row & 7) so ds_read_b128 is conflict-free.
+// ------------------------------------------------------------------------------------------------
+template <bool IS_BF16>
+__global__ __launch_bounds__(256) void corr_volume_h_hwc(const uint16_t* __restrict__ f1,
+                                                          const uint16_t* __restrict__ f2,
+                                                          float* __restrict__ out, int C, int N1, int N2,
+                                                          int tiles_m, int tiles_n) {
+    constexpr int BK = 64;                  // 16-bit elements per tile row (128 B)
+    constexpr int CH = BK / 8;              // 16-byte chunks per row = 8
+    __shared__ __attribute__((aligned(16))) s16x8 sA[2][BM * CH];
+    __shared__ __attribute__((aligned(16))) s16x8 sB[2][BN * CH];
+
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    const int b = blockIdx.z;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const uint16_t* A = f1 + (size_t)b * N1 * C;
+    const uint16_t* Bp = f2 + (size_t)b * N2 * C;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // loader: 128 rows x 8 chunks = 1024 chunks per operand; thread t -> (row = t/8 + 32*p, chunk = t%8), p < 4
+    const int lrow = t >> 3, lch = t & 7;
+    s16x8 ra[4], rb[4];
+    const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int ia = m0 + lrow + 32 * p, ib = n0 + lrow + 32 * p;
+            ra[p] = (ia < N1) ? *reinterpret_cast<const s16x8*>(A + (size_t)ia * C + k0 + lch * 8) : zero;
+            rb[p] = (ib < N2) ? *reinterpret_cast<const s16x8*>(Bp + (size_t)ib * C + k0 + lch * 8) : zero;
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = lrow + 32 * p;
+            sA[buf][row * CH + (lch ^ (row & 7))] = ra[p];
+            sB[buf][row * CH + (lch ^ (row & 7))] = rb[p];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    const int nk = C / BK;
+    const int kh = lane >> 5, li = lane & 31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {   // 4 MFMA k-steps of 16
+            const int ch = ks * 2 + kh;          // 16-B chunk holding this lane's 8 k values
+            s16x8 a[2], bb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm * 64 + i * 32 + li;
+                a[i] = sA[buf][row * CH + (ch ^ (row & 7))];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wn * 64 + j * 32 + li;
+                bb[j] = sB[buf][row * CH + (ch ^ (row & 7))];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (IS_BF16)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, bb[j]), acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            __builtin_bit_cast(f16x8, a[i]), __builtin_bit_cast(f16x8, bb[j]), acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) {
+            sstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    float* O = out + (size_t)b * N1 * N2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (row < N1) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = n0 + wn * 64 + j * 32 + li;
+                    if (col < N2) __builtin_nontemporal_store(acc[i][j][r], &O[(size_t)row * N2 + col]);
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 16-bit operands, CHW ([C][N]): K-major.  The tile is staged K-major in LDS ([BK][128]) and each lane
+// assembles its 8-k fragment with 8 ds_read_u16 (column li, rows 8*kh .. 8*kh+7 of the k-step).
+// Compute is ~6% of the kernel at this size (HBM-write bound), so the scalar fragment gather is
+// acceptable for the layout the reference hands over; HWC is the fast path for 16-bit features.
+// ------------------------------------------------------------------------------------------------
+template <bool IS_BF16>
+__global__ __launch_bounds__(256) void corr_volume_h_chw(const uint16_t* __restrict__ f1,
+                                                          const uint16_t* __restrict__ f2,
+                                                          float* __restrict__ out, int C, int N1, int N2,
+                                                          int tiles_m, int tiles_n) {
+    constexpr int BK = 32;
+    constexpr int LD = BM + 8;  // 16-bit elements; +8 keeps 16-B alignment of row starts and skews banks
+    __shared__ __attribute__((aligned(16))) uint16_t sA[2][BK][LD];
+    __shared__ __attribute__((aligned(16))) uint16_t sB[2][BK][LD];
+
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    const int b = blockIdx.z;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const uint16_t* A = f1 + (size_t)b * C * N1;
+    const uint16_t* Bp = f2 + (size_t)b * C * N2;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // loader: 32 rows x 128 cols = 512 chunks of 8; thread t -> (row = t/16 + 16*p, col8 = (t%16)*8), p < 2
+    const int lrow = t >> 4, lcol = (t & 15) * 8;
+    const bool vec_ok = ((N1 & 7) == 0) && ((N2 & 7) == 0);
+    s16x8 ra[2], rb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int k = k0 + lrow + 16 * p;
+            const uint16_t* pa = A + (size_t)k * N1 + m0 + lcol;
+            const uint16_t* pb = Bp + (size_t)k * N2 + n0 + lcol;
+            if (vec_ok) {
+                const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                ra[p] = (m0 + lcol < N1) ? *reinterpret_cast<const s16x8*>(pa) : zero;
+                rb[p] = (n0 + lcol < N2) ? *reinterpret_cast<const s16x8*>(pb) : zero;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    ra[p][e] = (m0 + lcol + e < N1) ? (short)pa[e] : (short)0;
+                    rb[p][e] = (n0 + lcol + e < N2) ? (short)pb[e] : (short)0;
+                }
+            }
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            *reinterpret_cast<s16x8*>(&sA[buf][lrow + 16 * p][lcol]) = ra[p];
+            *reinterpret_cast<s16x8*>(&sB[buf][lrow + 16 * p][lcol]) = rb[p];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    const int nk = C / BK;
+    const int kh = lane >> 5, li = lane & 31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int kb = ks * 16 + kh * 8;
+            s16x8 a[2], bb[2];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i][e] = (short)sA[buf][kb + e][wm * 64 + i * 32 + li];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bb[j][e] = (short)sB[buf][kb + e][wn * 64 + j * 32 + li];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (IS_BF16)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, bb[j]), acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            __builtin_bit_cast(f16x8, a[i]), __builtin_bit_cast(f16x8, bb[j]), acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) {
+            sstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    float* O = out + (size_t)b * N1 * N2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (row < N1) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = n0 + wn * 64 + j * 32 + li;
+                    if (col < N2) __builtin_nontemporal_store(acc[i][j][r], &O[(size_t)row * N2 + col]);
+                }
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B, int C, int N1, int N2,
+                              int in_dtype, int layout, mvStream_t stream) {
+    MV_CHECK_ARG(f1 && f2 && out);
+    MV_CHECK_ARG(B > 0 && C > 0 && N1 > 0 && N2 > 0);
+    MV_CHECK_ARG(layout == MV_LAYOUT_CHW || layout == MV_LAYOUT_HWC);
+    MV_CHECK_ARG(((uintptr_t)f1 & 15) == 0 && ((uintptr_t)f2 & 15) == 0);
+    if (B > 65535) return MV_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles_m = mv_ceil_div(N1, BM), tiles_n = mv_ceil_div(N2, BN);
+    dim3 grid(tiles_m * tiles_n, 1, B), block(256);
+    if (in_dtype == MV_F32) {
+        if (C % 16) return MV_ERR_UNSUPPORTED;
+        const float* a = (const float*)f1;
+        const float* b = (const float*)f2;
+        if (layout == MV_LAYOUT_CHW) {
+            if ((N1 % 4 == 0) && (N2 % 4 == 0))
+                hipLaunchKernelGGL(corr_volume_f32_chw<true>, grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
+            else
+                hipLaunchKernelGGL(corr_volume_f32_chw<false>, grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
+        } else {
+            hipLaunchKernelGGL(corr_volume_f32_hwc, grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
+        }
+    } else if (in_dtype == MV_F16 || in_dtype == MV_BF16) {
+        const uint16_t* a = (const uint16_t*)f1;
+        const uint16_t* b = (const uint16_t*)f2;
+        const bool bf = in_dtype == MV_BF16;
+        if (layout == MV_LAYOUT_HWC) {
+            if (C % 64) return MV_ERR_UNSUPPORTED;
+            if (bf)
+                hipLaunchKernelGGL(corr_volume_h_hwc<true>, grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
+            else
+                hipLaunchKernelGGL(corr_volume_h_hwc<false>, grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
+        } else {
+            if (C % 32) return MV_ERR_UNSUPPORTED;
+            if (bf)
+                hipLaunchKernelGGL(corr_volume_h_chw<true>, grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
+            else
+                hipLaunchKernelGGL(corr_volume_h_chw<false>, grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
+        }
+    } else {
+        return MV_ERR_INVALID_ARG;
+    }
+    return mv_launch_status();
+}

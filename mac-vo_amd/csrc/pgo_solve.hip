@@ -1,0 +1,492 @@
+// A17-A22 — covariance-weighted two-frame pose-graph solve on SE(3), one 64-lane wave per problem
+// (SURVEY.md §8 A17-A22).
+//
+// Replaces, for the newest-frame pose (the only variable, Graphs.py:83):
+//   TwoFrame_PGO._optimize            Module/Optimization/TwoFramePGO/Optimizer.py:81-102
+//   residual graphs + analytic J      Module/Optimization/TwoFramePGO/Graphs.py:33-231
+//   LM_analytic.step                  Module/Optimization/PyposeOptimizers.py:160-194
+//   PyPose 0.6.8 Huber / FastTriggs / RobustModel.loss / TrustRegion / PINV / StopOnPlateau / SE3 add_
+//
+// What the reference materialises and this kernel does not:
+//   * the dense 3N x 3N block_diag weight (2.9 MB fp64 for N = 200, rebuilt every outer iteration):
+//     here each point applies its own 3x3 / 2x2 information block in registers;
+//   * J [3N,7] and the 7x600 @ 600x600 matmul: here J_i^T W_i J_i (21 unique entries), J_i^T W_i r_i (6),
+//     plus the UNWEIGHTED J^T J (21) and J^T r (6) that TrustRegion's quality ratio needs
+//     ((J D)^T (2R + J D) = 2 D^T J^T R + D^T J^T J D), are accumulated per lane and tree-reduced with
+//     wavefront butterflies — 55 fp64 values per build pass;
+//   * the dead 7th tangent column (clamped to 1e-6, b_7 = 0 => D_7 = 0) is dropped analytically;
+//     the 6x6 SPD system is solved by an in-register Cholesky instead of an SVD pseudo-inverse
+//     (identical up to fp64 roundoff whenever A is non-singular, which the diagonal clamp + multiplicative
+//     damping guarantee).
+// The whole <=10-step LM loop (with the inner reject/damp loop) runs on the device: one launch per batch of
+// problems, no host round trips.  Latency-bound for a single problem (report us/solve), throughput-bound
+// for large batches (report solves/s).
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+struct PgoArgs {
+    const int32_t* offsets;
+    const float* init_pose;
+    const float* intrinsics;
+    const float* baseline;
+    const float* pos_Tw;
+    const double* cov_Tw;
+    const float* pixel2_uv;
+    const float* pixel2_d;
+    const float* pixel2_disp;
+    const float* pixel2_disp_cov;
+    const float* pixel2_uv_cov;
+    const double* obs2_covTc;
+    double* out_pose;
+    double* out_info;
+};
+
+struct Pose {
+    double t[3];
+    double q[4];   // x y z w
+    double R[9];   // row-major rotation matrix of q
+};
+
+__device__ __forceinline__ void quat_to_R(Pose& P) {
+    const double x = P.q[0], y = P.q[1], z = P.q[2], w = P.q[3];
+    P.R[0] = 1 - 2 * (y * y + z * z); P.R[1] = 2 * (x * y - z * w);     P.R[2] = 2 * (x * z + y * w);
+    P.R[3] = 2 * (x * y + z * w);     P.R[4] = 1 - 2 * (x * x + z * z); P.R[5] = 2 * (y * z - x * w);
+    P.R[6] = 2 * (x * z - y * w);     P.R[7] = 2 * (y * z + x * w);     P.R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// PyPose SO3_Act: p + w*uv + qv x uv with uv = 2 (qv x p)
+__device__ __forceinline__ void quat_act(const double* q, const double* p, double* o) {
+    double uv0 = q[1] * p[2] - q[2] * p[1], uv1 = q[2] * p[0] - q[0] * p[2], uv2 = q[0] * p[1] - q[1] * p[0];
+    uv0 += uv0; uv1 += uv1; uv2 += uv2;
+    o[0] = p[0] + q[3] * uv0 + (q[1] * uv2 - q[2] * uv1);
+    o[1] = p[1] + q[3] * uv1 + (q[2] * uv0 - q[0] * uv2);
+    o[2] = p[2] + q[3] * uv2 + (q[0] * uv1 - q[1] * uv0);
+}
+
+// T <- Exp([rho, phi]) * T  (PyPose se3_Exp: t = Jl(phi) rho, q = so3_Exp(phi); SE3_Mul)
+__device__ void se3_left_update(Pose& P, const double* D) {
+    const double eps = 2.220446049250313e-16;
+    const double rho[3] = {D[0], D[1], D[2]}, phi[3] = {D[3], D[4], D[5]};
+    const double th2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
+    const double th = sqrt(th2);
+    double c1, c2, imag, real;
+    if (th > eps) {
+        c1 = (1.0 - cos(th)) / th2;
+        c2 = (th - sin(th)) / (th * th2);
+        imag = sin(0.5 * th) / th;
+        real = cos(0.5 * th);
+    } else {
+        const double th4 = th2 * th2;
+        c1 = 0.5 - th2 / 24.0;
+        c2 = 1.0 / 6.0 - th2 / 120.0;
+        imag = 0.5 - th2 / 48.0 + th4 / 3840.0;
+        real = 1.0 - th2 / 8.0 + th4 / 384.0;
+    }
+    // Jl rho = rho + c1 (phi x rho) + c2 (phi x (phi x rho))
+    const double k1[3] = {phi[1] * rho[2] - phi[2] * rho[1], phi[2] * rho[0] - phi[0] * rho[2], phi[0] * rho[1] - phi[1] * rho[0]};
+    const double k2[3] = {phi[1] * k1[2] - phi[2] * k1[1], phi[2] * k1[0] - phi[0] * k1[2], phi[0] * k1[1] - phi[1] * k1[0]};
+    const double te[3] = {rho[0] + c1 * k1[0] + c2 * k2[0], rho[1] + c1 * k1[1] + c2 * k2[1], rho[2] + c1 * k1[2] + c2 * k2[2]};
+    const double qe[4] = {phi[0] * imag, phi[1] * imag, phi[2] * imag, real};
+    // t' = te + qe.Act(t);  q' = qe * q
+    double rt[3];
+    quat_act(qe, P.t, rt);
+    const double a[3] = {qe[0], qe[1], qe[2]}, aw = qe[3];
+    const double b[3] = {P.q[0], P.q[1], P.q[2]}, bw = P.q[3];
+    const double nq[4] = {aw * b[0] + bw * a[0] + (a[1] * b[2] - a[2] * b[1]),
+                          aw * b[1] + bw * a[1] + (a[2] * b[0] - a[0] * b[2]),
+                          aw * b[2] + bw * a[2] + (a[0] * b[1] - a[1] * b[0]),
+                          aw * bw - (a[0] * b[0] + a[1] * b[1] + a[2] * b[2])};
+    P.t[0] = te[0] + rt[0]; P.t[1] = te[1] + rt[1]; P.t[2] = te[2] + rt[2];
+    P.q[0] = nq[0]; P.q[1] = nq[1]; P.q[2] = nq[2]; P.q[3] = nq[3];
+    quat_to_R(P);
+}
+
+__device__ __forceinline__ double huber(double x, double delta) {
+    const double sx = sqrt(x);
+    return (sx < delta) ? x : (2.0 * delta * sx - delta * delta);
+}
+
+// torch.linalg.pinv of the symmetric 2x2 [[a, c], [c, b]] (+ optional independent third singular value s3
+// of the block-diagonal 3x3) with relative cutoff rcond * sigma_max.
+__device__ __forceinline__ void pinv_sym2_blk(double a, double b, double c, double s3, bool has3, double rcond,
+                                              double& w00, double& w01, double& w11, double& w22) {
+    const double tr = a + b, df = a - b;
+    const double rad = sqrt(0.25 * df * df + c * c);
+    const double l1 = 0.5 * tr + rad, l2 = 0.5 * tr - rad;
+    double smax = fmax(fabs(l1), fabs(l2));
+    if (has3) smax = fmax(smax, fabs(s3));
+    const double cut = rcond * smax;
+    const bool k1 = fabs(l1) > cut, k2 = fabs(l2) > cut;
+    if (k1 && k2) {
+        const double det = a * b - c * c;
+        w00 = b / det; w01 = -c / det; w11 = a / det;
+    } else if (k1 || k2) {
+        const double l = k1 ? l1 : l2, lo = k1 ? l2 : l1;
+        const double s = 1.0 / (l * (l - lo));  // (A - lo I) / (l - lo) is the projector onto l's eigenvector
+        w00 = (a - lo) * s; w01 = c * s; w11 = (b - lo) * s;
+    } else {
+        w00 = w01 = w11 = 0.0;
+    }
+    w22 = (has3 && fabs(s3) > cut) ? 1.0 / s3 : 0.0;
+}
+
+// general 3x3 inverse by cofactors (== torch.pinverse for the well-conditioned fp64 covariances of the ICP graph)
+__device__ __forceinline__ void inv3(const double* m, double* o) {
+    const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    const double id = 1.0 / det;
+    o[0] = c00 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+// index of (j, k), j <= k, in the packed upper triangle of a 6x6
+__device__ __forceinline__ constexpr int tri(int j, int k) { return j * 6 - (j * (j - 1)) / 2 + (k - j); }
+
+struct Geometry {
+    double fx, fy, cx, cy, blfx;
+};
+
+// residual block of point i under pose P; returns |r|^2.  NR = 3 (ICP, DISP) or 2 (REPROJ).
+template <int GT>
+__device__ __forceinline__ double residual(const PgoArgs& a, const Geometry& g, const Pose& P, int i, double* r,
+                                           double* pc /* ICP: T*p_c ; else p_c = T^-1 p_w */) {
+    if (GT == MV_GRAPH_ICP) {
+        // points_Tc = pixel2point_NED(pixel2_uv, pixel2_d, K) built in fp32 (Graphs.py:49-51), then cast
+        const float u = a.pixel2_uv[2 * i], v = a.pixel2_uv[2 * i + 1], d = a.pixel2_d[i];
+        const float xe = ((u - (float)g.cx) * d) / (float)g.fx;
+        const float ye = ((v - (float)g.cy) * d) / (float)g.fy;
+        const double p[3] = {(double)d, (double)xe, (double)ye};
+        double rp[3];
+        quat_act(P.q, p, rp);
+        pc[0] = rp[0] + P.t[0]; pc[1] = rp[1] + P.t[1]; pc[2] = rp[2] + P.t[2];
+        r[0] = pc[0] - (double)a.pos_Tw[3 * i];
+        r[1] = pc[1] - (double)a.pos_Tw[3 * i + 1];
+        r[2] = pc[2] - (double)a.pos_Tw[3 * i + 2];
+        return r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    } else {
+        // p_c = T^-1 p_w : Inv = (-q^-1.Act(t), q^-1), Act = q^-1.Act(p_w) + t_inv
+        const double qi[4] = {-P.q[0], -P.q[1], -P.q[2], P.q[3]};
+        const double pw[3] = {(double)a.pos_Tw[3 * i], (double)a.pos_Tw[3 * i + 1], (double)a.pos_Tw[3 * i + 2]};
+        double ti[3], rp[3];
+        quat_act(qi, P.t, ti);
+        quat_act(qi, pw, rp);
+        pc[0] = rp[0] - ti[0]; pc[1] = rp[1] - ti[1]; pc[2] = rp[2] - ti[2];
+        // point2pixel_NED = homo2cart(p_EDN K^T): u = (fx Y + cx X) / X, v = (fy Z + cy X) / X
+        const double X = pc[0];
+        double den = fmax(fabs(X), 2.2250738585072014e-308);
+        den = (X >= 0.0) ? den : -den;
+        r[0] = (g.fx * pc[1] + g.cx * X) / den - (double)a.pixel2_uv[2 * i];
+        r[1] = (g.fy * pc[2] + g.cy * X) / den - (double)a.pixel2_uv[2 * i + 1];
+        double n2 = r[0] * r[0] + r[1] * r[1];
+        if (GT == MV_GRAPH_DISP) {
+            r[2] = (1.0 / X) * g.blfx - (double)a.pixel2_disp[i];
+            n2 += r[2] * r[2];
+        }
+        return n2;
+    }
+}
+
+template <int GT>
+__global__ __launch_bounds__(64) void pgo_solve_kernel(PgoArgs a, mvLMParams lm) {
+    constexpr int NR = (GT == MV_GRAPH_REPROJ) ? 2 : 3;
+    const int prob = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int beg = a.offsets[prob], end = a.offsets[prob + 1];
+
+    Geometry g;
+    g.fx = (double)a.intrinsics[4 * prob]; g.fy = (double)a.intrinsics[4 * prob + 1];
+    g.cx = (double)a.intrinsics[4 * prob + 2]; g.cy = (double)a.intrinsics[4 * prob + 3];
+    g.blfx = g.fx * (double)a.baseline[prob];  // K[0,0] * bl in fp64 of the fp32 buffers
+
+    Pose P;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) P.t[k] = (double)a.init_pose[7 * prob + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) P.q[k] = (double)a.init_pose[7 * prob + 3 + k];
+    quat_to_R(P);
+
+    double damping = 1.0 / lm.radius, tr_down = lm.tr_down;
+    double loss = 0.0, last = 0.0, loss0 = 0.0;
+    bool have_loss = false;
+    int steps = 0, patience_count = 0, reject_count = 0;
+    bool continual = true;
+
+    while (continual) {
+        // ------------------------------------------------------------------ build pass
+        double Aw[21], gw[6], Au[21], gu[6], loss_acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 21; ++k) { Aw[k] = 0.0; Au[k] = 0.0; }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { gw[k] = 0.0; gu[k] = 0.0; }
+
+        for (int i = beg + lane; i < end; i += 64) {
+            double r[3] = {0, 0, 0}, pc[3];
+            const double n2 = residual<GT>(a, g, P, i, r, pc);
+            loss_acc += huber(n2, lm.huber_delta);
+            // FastTriggs: s = sqrt(rho'(|r|^2)); both R and J are scaled by s => s^2 on every product
+            const double sn = sqrt(n2);
+            const double s2 = (sn < lm.huber_delta) ? 1.0 : (lm.huber_delta / sn);
+
+            double J[NR][6];
+            double W[NR][NR];
+            if (GT == MV_GRAPH_ICP) {
+                // J = [I, -skew(T p_c)]
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) J[rr][c] = 0.0;
+                J[0][0] = J[1][1] = J[2][2] = 1.0;
+                J[0][4] = pc[2];  J[0][5] = -pc[1];
+                J[1][3] = -pc[2]; J[1][5] = pc[0];
+                J[2][3] = pc[1];  J[2][4] = -pc[0];
+                // Sigma_i = R Sigma_obs R^T + Sigma_pt ; W_i = pinv(Sigma_i)
+                double So[9], Sp[9], T1[9], S[9], Wi[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { So[k] = a.obs2_covTc[9 * (size_t)i + k]; Sp[k] = a.cov_Tw[9 * (size_t)i + k]; }
+#pragma unroll
+                for (int x = 0; x < 3; ++x)
+#pragma unroll
+                    for (int y = 0; y < 3; ++y)
+                        T1[3 * x + y] = P.R[3 * x] * So[y] + P.R[3 * x + 1] * So[3 + y] + P.R[3 * x + 2] * So[6 + y];
+#pragma unroll
+                for (int x = 0; x < 3; ++x)
+#pragma unroll
+                    for (int y = 0; y < 3; ++y)
+                        S[3 * x + y] = (T1[3 * x] * P.R[3 * y] + T1[3 * x + 1] * P.R[3 * y + 1] + T1[3 * x + 2] * P.R[3 * y + 2]) + Sp[3 * x + y];
+                inv3(S, Wi);
+#pragma unroll
+                for (int x = 0; x < 3; ++x)
+#pragma unroll
+                    for (int y = 0; y < 3; ++y) W[x][y] = Wi[3 * x + y];
+            } else {
+                // G = d p_c / d delta = [-R^T, R^T skew(p_w)]   (3 x 6)
+                const double pw[3] = {(double)a.pos_Tw[3 * i], (double)a.pos_Tw[3 * i + 1], (double)a.pos_Tw[3 * i + 2]};
+                double G[3][6];
+#pragma unroll
+                for (int x = 0; x < 3; ++x) {
+                    const double rt0 = P.R[x], rt1 = P.R[3 + x], rt2 = P.R[6 + x];  // row x of R^T
+                    G[x][0] = -rt0; G[x][1] = -rt1; G[x][2] = -rt2;
+                    // R^T skew(p): col0 = R^T (0, pz, -py), col1 = R^T (-pz, 0, px), col2 = R^T (py, -px, 0)
+                    G[x][3] = rt1 * pw[2] - rt2 * pw[1];
+                    G[x][4] = -rt0 * pw[2] + rt2 * pw[0];
+                    G[x][5] = rt0 * pw[1] - rt1 * pw[0];
+                }
+                const double X = pc[0], Y = pc[1], Z = pc[2], X2 = X * X;
+                const double j00 = -g.fx * Y / X2, j01 = g.fx / X, j10 = -g.fy * Z / X2, j12 = g.fy / X;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    J[0][c] = j00 * G[0][c] + j01 * G[1][c];
+                    J[1][c] = j10 * G[0][c] + j12 * G[2][c];
+                }
+                double w00, w01, w11, w22;
+                const double suu = (double)a.pixel2_uv_cov[3 * i], svv = (double)a.pixel2_uv_cov[3 * i + 1],
+                             suv = (double)a.pixel2_uv_cov[3 * i + 2];
+                if (GT == MV_GRAPH_DISP) {
+                    const double jd = -g.blfx / X2;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) J[NR - 1][c] = jd * G[0][c];
+                    pinv_sym2_blk(suu, svv, suv, (double)a.pixel2_disp_cov[i], true, lm.pinv_rcond, w00, w01, w11, w22);
+                    W[0][NR - 1] = W[NR - 1][0] = W[1][NR - 1] = W[NR - 1][1] = 0.0;
+                    W[NR - 1][NR - 1] = w22;
+                } else {
+                    pinv_sym2_blk(suu, svv, suv, 0.0, false, lm.pinv_rcond, w00, w01, w11, w22);
+                }
+                W[0][0] = w00; W[0][1] = w01; W[1][0] = w01; W[1][1] = w11;
+            }
+            // accumulate s^2 J^T W J, s^2 J^T W r, s^2 J^T J, s^2 J^T r.
+            // reference: J_T = J^T @ weight ; A = J_T @ J ; b = -J_T @ R   (PyposeOptimizers.py:170-176)
+            double WJ[NR][6], Wr[NR];
+#pragma unroll
+            for (int x = 0; x < NR; ++x) {
+                double t = 0.0;
+#pragma unroll
+                for (int y = 0; y < NR; ++y) t += W[x][y] * r[y];
+                Wr[x] = t;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    double tj = 0.0;
+#pragma unroll
+                    for (int y = 0; y < NR; ++y) tj += W[x][y] * J[y][c];
+                    WJ[x][c] = tj;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                double gwj = 0.0, guj = 0.0;
+#pragma unroll
+                for (int x = 0; x < NR; ++x) { gwj += J[x][j] * Wr[x]; guj += J[x][j] * r[x]; }
+                gw[j] += s2 * gwj;
+                gu[j] += s2 * guj;
+#pragma unroll
+                for (int k = j; k < 6; ++k) {
+                    double aw = 0.0, au = 0.0;
+#pragma unroll
+                    for (int x = 0; x < NR; ++x) { aw += J[x][j] * WJ[x][k]; au += J[x][j] * J[x][k]; }
+                    Aw[tri(j, k)] += s2 * aw;
+                    Au[tri(j, k)] += s2 * au;
+                }
+            }
+        }
+        // wavefront tree reduce (every lane ends with the totals)
+#pragma unroll
+        for (int k = 0; k < 21; ++k) { Aw[k] = wave_sum(Aw[k]); Au[k] = wave_sum(Au[k]); }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { gw[k] = wave_sum(gw[k]); gu[k] = wave_sum(gu[k]); }
+        loss_acc = wave_sum(loss_acc);
+
+        if (!have_loss) { loss = loss_acc; loss0 = loss_acc; have_loss = true; }
+        last = loss;
+        reject_count = 0;
+
+        // A.diagonal().clamp_(min, max)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) Aw[tri(j, j)] = fmin(fmax(Aw[tri(j, j)], lm.diag_min), lm.diag_max);
+
+        // ------------------------------------------------------------------ inner damping / reject loop
+        while (last <= loss) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) Aw[tri(j, j)] += Aw[tri(j, j)] * damping;
+            // solve A D = b, b = -gw, by Cholesky (A = L L^T)
+            double L[6][6], D[6];
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                double d = Aw[tri(j, j)];
+#pragma unroll
+                for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+                ok = ok && (d > 0.0) && (d < INFINITY);
+                const double ljj = sqrt(d);
+                L[j][j] = ljj;
+#pragma unroll
+                for (int i2 = j + 1; i2 < 6; ++i2) {
+                    double s = Aw[tri(j, i2)];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) s -= L[i2][k] * L[j][k];
+                    L[i2][j] = s / ljj;
+                }
+            }
+            if (!ok) break;  // "Linear solver failed. Breaking optimization step..."
+            double yv[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                double s = -gw[j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) s -= L[j][k] * yv[k];
+                yv[j] = s / L[j][j];
+            }
+#pragma unroll
+            for (int j = 5; j >= 0; --j) {
+                double s = yv[j];
+#pragma unroll
+                for (int k = j + 1; k < 6; ++k) s -= L[k][j] * D[k];
+                D[j] = s / L[j][j];
+            }
+
+            const Pose P_prev = P;
+            se3_left_update(P, D);
+
+            // loss at the trial pose (RobustModel.loss: unweighted, uncorrected)
+            double la = 0.0;
+            for (int i = beg + lane; i < end; i += 64) {
+                double r[3] = {0, 0, 0}, pc[3];
+                la += huber(residual<GT>(a, g, P, i, r, pc), lm.huber_delta);
+            }
+            loss = wave_sum(la);
+
+            // TrustRegion.update: quality = (last - loss) / -((J D)^T (2 R + J D)) on the corrected, unweighted J, R
+            double dAd = 0.0, dg = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                dg += D[j] * gu[j];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) dAd += D[j] * D[k] * Au[(j <= k) ? tri(j, k) : tri(k, j)];
+            }
+            const double quality = (last - loss) / -(2.0 * dg + dAd);
+            double radius = 1.0 / damping;
+            if (quality > lm.tr_high) {
+                radius = lm.tr_up * radius;
+                tr_down = lm.tr_down;
+            } else if (quality > lm.tr_low) {
+                tr_down = lm.tr_down;
+            } else {
+                radius = radius * tr_down;
+                tr_down = tr_down * lm.tr_factor;
+            }
+            tr_down = fmax(lm.tr_min, fmin(tr_down, lm.tr_max));
+            radius = fmax(lm.tr_min, fmin(radius, lm.tr_max));
+            damping = 1.0 / radius;
+
+            if (last < loss && reject_count < lm.reject) {  // reject step
+                P = P_prev;
+                loss = last;
+                reject_count += 1;
+            } else {
+                break;
+            }
+        }
+
+        // ------------------------------------------------------------------ StopOnPlateau.step(loss)
+        steps += 1;
+        if (steps >= lm.max_steps) continual = false;
+        if ((last - loss) < lm.decreasing) patience_count += 1; else patience_count = 0;
+        if (patience_count >= lm.patience) continual = false;
+        if (reject_count >= lm.reject) continual = false;
+    }
+
+    if (lane == 0) {
+        double* o = a.out_pose + 7 * (size_t)prob;
+        o[0] = P.t[0]; o[1] = P.t[1]; o[2] = P.t[2];
+        o[3] = P.q[0]; o[4] = P.q[1]; o[5] = P.q[2]; o[6] = P.q[3];
+        double* inf = a.out_info + 4 * (size_t)prob;
+        inf[0] = loss; inf[1] = (double)steps; inf[2] = (double)reject_count; inf[3] = loss0;
+    }
+}
+
+}  // namespace
+
+extern "C" void mv_lm_default_params(mvLMParams* p) {
+    if (!p) return;
+    p->huber_delta = 0.1;
+    p->radius = 1e3;
+    p->tr_high = 0.5; p->tr_low = 1e-3; p->tr_up = 2.0; p->tr_down = 0.5; p->tr_factor = 0.5;
+    p->tr_min = 1e-6; p->tr_max = 1e16;
+    p->diag_min = 1e-6; p->diag_max = 1e32;
+    p->decreasing = 1e-5;
+    p->pinv_rcond = 1e-15;
+    p->reject = 16; p->max_steps = 10; p->patience = 2; p->reserved = 0;
+}
+
+extern "C" int mv_pgo_solve(int nprob, const int32_t* offsets, int graph_type, const float* init_pose,
+                            const float* intrinsics, const float* baseline, const float* pos_Tw, const double* cov_Tw,
+                            const float* pixel2_uv, const float* pixel2_d, const float* pixel2_disp,
+                            const float* pixel2_disp_cov, const float* pixel2_uv_cov, const double* obs2_covTc,
+                            const mvLMParams* params, double* out_pose, double* out_info, mvStream_t stream) {
+    MV_CHECK_ARG(nprob >= 0 && params);
+    if (nprob == 0) return MV_OK;
+    MV_CHECK_ARG(offsets && init_pose && intrinsics && baseline && pos_Tw && pixel2_uv && out_pose && out_info);
+    MV_CHECK_ARG(params->max_steps >= 1 && params->reject >= 0 && params->radius > 0 && params->huber_delta > 0);
+    PgoArgs a{offsets, init_pose, intrinsics, baseline, pos_Tw, cov_Tw, pixel2_uv, pixel2_d, pixel2_disp,
+              pixel2_disp_cov, pixel2_uv_cov, obs2_covTc, out_pose, out_info};
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(nprob), block(64);
+    switch (graph_type) {
+        case MV_GRAPH_ICP:
+            MV_CHECK_ARG(cov_Tw && obs2_covTc && pixel2_d);
+            hipLaunchKernelGGL(pgo_solve_kernel<MV_GRAPH_ICP>, grid, block, 0, s, a, *params);
+            break;
+        case MV_GRAPH_REPROJ:
+            MV_CHECK_ARG(pixel2_uv_cov);
+            hipLaunchKernelGGL(pgo_solve_kernel<MV_GRAPH_REPROJ>, grid, block, 0, s, a, *params);
+            break;
+        case MV_GRAPH_DISP:
+            MV_CHECK_ARG(pixel2_uv_cov && pixel2_disp && pixel2_disp_cov);
+            hipLaunchKernelGGL(pgo_solve_kernel<MV_GRAPH_DISP>, grid, block, 0, s, a, *params);
+            break;
+        default:
+            return MV_ERR_INVALID_ARG;
+    }
+    return mv_launch_status();
+}

@@ -1,0 +1,321 @@
+"""Torch-tensor front doors of the C ABI (``include/macvo_hip.h``).
+
+PyTorch is only the allocator / stream provider here: each function validates shapes, allocates the
+outputs, and hands raw device pointers plus the *current* HIP stream to ``libmacvo_hip.so``.  Nothing is
+computed in torch and there is no fallback path — a missing library or a non-GPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float32: L.MV_F32, torch.float16: L.MV_F16, torch.bfloat16: L.MV_BF16}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise L.MacvoHipError(f"{name}: expected a GPU tensor (the HIP hot path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise L.MacvoHipError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------- A5
+def corr_volume(f1: torch.Tensor, f2: torch.Tensor, layout: str = "chw", out: torch.Tensor | None = None) -> torch.Tensor:
+    """All-pairs cost volume (FlowFormer ``MemoryEncoder.corr``; call site flownet.py:26-27).
+
+    layout "chw": f1, f2 ``[B, C, H, W]`` (NCHW);  layout "hwc": ``[B, H, W, C]`` / ``[B, N, C]``.
+    Returns ``cost_maps [B*H1*W1, 1, H2, W2]`` float32 (layout "hwc" with 3-D inputs: ``[B*N1, 1, 1, N2]``).
+    """
+    lib = L.load()
+    if f1.dtype not in _DT or f1.dtype != f2.dtype:
+        raise L.MacvoHipError(f"corr_volume: unsupported dtypes {f1.dtype}/{f2.dtype}")
+    f1 = _req(f1, f1.dtype, "f1")
+    f2 = _req(f2, f2.dtype, "f2")
+    if layout == "chw":
+        B, Cc, H1, W1 = f1.shape
+        _, _, H2, W2 = f2.shape
+        lay = L.MV_LAYOUT_CHW
+    elif layout == "hwc":
+        if f1.dim() == 4:
+            B, H1, W1, Cc = f1.shape
+            _, H2, W2, _ = f2.shape
+        else:
+            B, N1_, Cc = f1.shape
+            H1, W1, H2, W2 = 1, N1_, 1, f2.shape[1]
+        lay = L.MV_LAYOUT_HWC
+    else:
+        raise ValueError(layout)
+    N1, N2 = H1 * W1, H2 * W2
+    if out is None:
+        out = torch.empty((B * N1, 1, H2, W2), dtype=torch.float32, device=f1.device)
+    L.check(lib.mv_corr_volume(f1.data_ptr(), f2.data_ptr(), out.data_ptr(), B, Cc, N1, N2, _DT[f1.dtype], lay,
+                               _stream()), "mv_corr_volume")
+    return out
+
+
+# ------------------------------------------------------------------------------------------- A6
+def corr_lookup(cost_maps: torch.Tensor, coords: torch.Tensor, radius: int = 4, out: torch.Tensor | None = None) -> torch.Tensor:
+    """``encode_flow_token(cost_maps, coords)`` (covhead.py:92): ``[B*N1,1,H2,W2]``, ``[B,2,H1,W1]`` -> ``[B,(2r+1)^2,H1,W1]``."""
+    lib = L.load()
+    cost_maps = _req(cost_maps, torch.float32, "cost_maps")
+    coords = _req(coords, torch.float32, "coords")
+    B, two, H1, W1 = coords.shape
+    assert two == 2
+    BN, _, H2, W2 = cost_maps.shape
+    if BN != B * H1 * W1:
+        raise L.MacvoHipError("corr_lookup: cost_maps / coords shape mismatch")
+    K = 2 * radius + 1
+    if out is None:
+        out = torch.empty((B, K * K, H1, W1), dtype=torch.float32, device=coords.device)
+    L.check(lib.mv_corr_lookup(cost_maps.data_ptr(), coords.data_ptr(), out.data_ptr(), B, H1, W1, H2, W2, radius,
+                               _stream()), "mv_corr_lookup")
+    return out
+
+
+# ------------------------------------------------------------------------------------------- A8 / A2
+@dataclass
+class FrontendMaps:
+    """The planes of IStereoDepth.Output / IMatcher.Output, each ``[1, C, H, W]`` float32 on the GPU."""
+    depth: torch.Tensor
+    depth_cov: torch.Tensor
+    disparity: torch.Tensor
+    disparity_cov: torch.Tensor
+    bad_mask: torch.Tensor | None
+    flow: torch.Tensor | None
+    flow_cov: torch.Tensor | None
+
+
+def frontend_epilogue(flow: torch.Tensor, cov: torch.Tensor, baseline: float, fx: float, cov_is_log: bool = True,
+                      enforce_positive_disparity: bool = False, want_match: bool = True) -> FrontendMaps:
+    """Network output ``flow, logcov [2,2,H,W]`` -> depth / match records (Frontend.py:183-200, flownet.py:44,
+    StereoDepth.py:270-282, Matching.py:28-40) in one launch.  ``baseline``/``fx`` are Python floats exactly as
+    ``frame.frame_baseline`` / ``frame.fx`` are in the reference."""
+    lib = L.load()
+    flow = _req(flow, torch.float32, "flow")
+    cov = _req(cov, torch.float32, "cov")
+    assert flow.shape == cov.shape and flow.shape[0] == 2 and flow.shape[1] == 2
+    _, _, H, W = flow.shape
+    dev = flow.device
+    mk = lambda c: torch.empty((1, c, H, W), dtype=torch.float32, device=dev)  # noqa: E731
+    disparity, disparity_cov, depth, depth_cov = mk(1), mk(1), mk(1), mk(1)
+    bad = torch.empty((1, 1, H, W), dtype=torch.bool, device=dev) if enforce_positive_disparity else None
+    mflow = mk(2) if want_match else None
+    mcov = mk(3) if want_match else None
+    bl_fx = float(baseline) * float(fx)            # python double product, rounded once to fp32 by ctypes
+    L.check(lib.mv_frontend_epilogue(flow.data_ptr(), cov.data_ptr(), int(cov_is_log), H, W, bl_fx, bl_fx ** 2,
+                                     disparity.data_ptr(), disparity_cov.data_ptr(), depth.data_ptr(),
+                                     depth_cov.data_ptr(), _ptr(bad), _ptr(mflow), _ptr(mcov), _stream()),
+            "mv_frontend_epilogue")
+    return FrontendMaps(depth, depth_cov, disparity, disparity_cov, bad, mflow, mcov)
+
+
+# ------------------------------------------------------------------------------------------- A10 / A11
+class KeypointCandidates:
+    """Device-side result of the dense selector stage; ``finish`` applies the reference's CPU randperm."""
+
+    def __init__(self, cand: torch.Tensor, count: torch.Tensor, stats: torch.Tensor, W: int):
+        self.cand, self.count, self.stats, self.W = cand, count, stats, W
+        self._n = None
+
+    @property
+    def n(self) -> int:
+        if self._n is None:
+            self._n = int(self.count[0].item())  # the one host sync of the selector (reference has two)
+        return self._n
+
+    def candidates_vu(self) -> torch.Tensor:
+        """``torch.nonzero(point_mask)[:, 2:]`` — (v, u) int64, row-major order."""
+        lin = self.cand[: self.n].long()
+        return torch.stack([lin // self.W, lin % self.W], dim=1)
+
+    def finish(self, numPoint: int) -> torch.Tensor:
+        """``selected[torch.randperm(n)[:numPoint]][..., 2:].roll(1, 1)`` (KeypointSelector.py:331-332,404-405).
+        The permutation comes from the global CPU generator exactly as in the reference."""
+        lib = L.load()
+        n = self.n
+        perm = torch.randperm(n)[:numPoint]
+        n_sel = perm.numel()
+        out = torch.empty((n_sel, 2), dtype=torch.int64, device=self.cand.device)
+        if n_sel:
+            perm_d = perm.to(self.cand.device, non_blocking=True)
+            L.check(lib.mv_kp_gather(self.cand.data_ptr(), perm_d.data_ptr(), n_sel, self.W, out.data_ptr(), _stream()),
+                    "mv_kp_gather")
+        return out
+
+
+_ws_cache: dict = {}
+
+
+def _kp_workspace(H: int, W: int, device) -> torch.Tensor:
+    key = (H, W, str(device))
+    ws = _ws_cache.get(key)
+    if ws is None:
+        nbytes = L.load().mv_kp_select_workspace_bytes(H, W)
+        ws = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def kp_select(mode: str, H: int, W: int, flow_cov: torch.Tensor | None = None, depth0: torch.Tensor | None = None,
+              depth0_cov: torch.Tensor | None = None, depth1: torch.Tensor | None = None,
+              depth1_cov: torch.Tensor | None = None, mask_a: torch.Tensor | None = None,
+              mask_b: torch.Tensor | None = None, kernel_size: int = 7, mask_width: int = 32,
+              max_depth: float = 0.0, max_depth_cov: float = 0.0, max_match_cov: float = 0.0) -> KeypointCandidates:
+    """Dense part of the covariance-aware selectors (KeypointSelector.py:87-97,260-327,362-400)."""
+    lib = L.load()
+    modes = {"nodepth": L.MV_KP_NODEPTH, "full": L.MV_KP_FULL, "mapping": L.MV_KP_MAPPING}
+    dev = None
+    ts = {}
+    for name, t in (("flow_cov", flow_cov), ("depth0", depth0), ("depth0_cov", depth0_cov), ("depth1", depth1),
+                    ("depth1_cov", depth1_cov)):
+        if t is not None:
+            t = _req(t, torch.float32, name)
+            dev = t.device
+        ts[name] = t
+    ms = {}
+    for name, t in (("mask_a", mask_a), ("mask_b", mask_b)):
+        if t is not None:
+            if t.dtype == torch.bool:
+                t = t.contiguous().view(torch.uint8)
+            t = _req(t, torch.uint8, name)
+        ms[name] = t
+    p = L.mvKpSelectParams(H, W, modes[mode], kernel_size, mask_width, max_depth, max_depth_cov, max_match_cov)
+    ws = _kp_workspace(H, W, dev)
+    cand = torch.empty((H * W,), dtype=torch.int32, device=dev)
+    count = torch.empty((4,), dtype=torch.int32, device=dev)
+    stats = torch.empty((4,), dtype=torch.float32, device=dev)
+    L.check(lib.mv_kp_select(_ptr(ts["flow_cov"]), _ptr(ts["depth0"]), _ptr(ts["depth0_cov"]), _ptr(ts["depth1"]),
+                             _ptr(ts["depth1_cov"]), _ptr(ms["mask_a"]), _ptr(ms["mask_b"]), C.byref(p),
+                             ws.data_ptr(), ws.numel() * 8, cand.data_ptr(), count.data_ptr(), stats.data_ptr(),
+                             _stream()), "mv_kp_select")
+    return KeypointCandidates(cand, count, stats, W)
+
+
+# ------------------------------------------------------------------------------------------- A12
+@dataclass
+class TrackedKeypoints:
+    kp1_uv: torch.Tensor      # [N,2] float32
+    inbound: torch.Tensor     # [N] bool
+    vals: torch.Tensor        # [N,11] float32: d0 disp0 sdisp0 sdd0 d1 disp1 sdisp1 sdd1 suu svv suv
+
+
+def kp_track(kp0_uv: torch.Tensor, flow: torch.Tensor, flow_cov: torch.Tensor | None, depth0: FrontendMaps | dict,
+             depth1: FrontendMaps | dict, edge: int) -> TrackedKeypoints:
+    """kp1 = kp0 + flow[kp0], strict border test, and all per-keypoint gathers (MACVO.py:198-232) in one launch."""
+    lib = L.load()
+    kp0_uv = _req(kp0_uv, torch.int64, "kp0_uv")
+    flow = _req(flow, torch.float32, "flow")
+    _, _, H, W = flow.shape
+    N = kp0_uv.shape[0]
+    dev = flow.device
+
+    def g(d, k):
+        v = d[k] if isinstance(d, dict) else getattr(d, k)
+        return None if v is None else _req(v, torch.float32, k)
+
+    d0 = [g(depth0, k) for k in ("depth", "disparity", "disparity_cov", "depth_cov")]
+    d1 = [g(depth1, k) for k in ("depth", "disparity", "disparity_cov", "depth_cov")]
+    fc = None if flow_cov is None else _req(flow_cov, torch.float32, "flow_cov")
+    kp1 = torch.empty((N, 2), dtype=torch.float32, device=dev)
+    inb = torch.empty((N,), dtype=torch.bool, device=dev)
+    vals = torch.empty((N, 11), dtype=torch.float32, device=dev)
+    L.check(lib.mv_kp_track(kp0_uv.data_ptr(), N, flow.data_ptr(), _ptr(fc), *[_ptr(t) for t in d0],
+                            *[_ptr(t) for t in d1], H, W, edge, kp1.data_ptr(), inb.data_ptr(), vals.data_ptr(),
+                            _stream()), "mv_kp_track")
+    return TrackedKeypoints(kp1, inb, vals)
+
+
+# ------------------------------------------------------------------------------------------- A13-A16
+def match_cov(depth_map: torch.Tensor, kp_uv: torch.Tensor, flow_cov: torch.Tensor, depth_cov: torch.Tensor | None,
+              fx: float, fy: float, cx: float, cy: float, kernel_size: int = 31, min_flow_cov: float = 0.25,
+              min_depth_cov: float = 0.05, use_patch_var: bool = True, rot: torch.Tensor | None = None,
+              want_stats: bool = False):
+    """MAC-VO covariance model (Project2to3.py:124-181,377-433; Math.py:43-63).  ``flow_cov [N,3]`` is clamped IN
+    PLACE like the reference.  Returns ``cov [N,3,3] float64`` (GPU) and, if ``rot [3,3] float64`` is given,
+    ``R cov R^T`` (MACVO.py:273-281)."""
+    lib = L.load()
+    depth_map = _req(depth_map, torch.float32, "depth_map")
+    H, W = depth_map.shape[-2:]
+    if kp_uv.dtype != torch.float32:
+        kp_uv = kp_uv.to(torch.float32)
+    kp_uv = _req(kp_uv, torch.float32, "kp_uv")
+    if flow_cov.dtype != torch.float32 or not flow_cov.is_contiguous() or not flow_cov.is_cuda:
+        raise L.MacvoHipError("match_cov: flow_cov must be a contiguous float32 GPU tensor (it is clamped in place)")
+    N = kp_uv.shape[0]
+    dev = depth_map.device
+    dc = None if depth_cov is None else _req(depth_cov, torch.float32, "depth_cov")
+    r = None if rot is None else _req(rot.to(dev), torch.float64, "rot")
+    out = torch.empty((N, 3, 3), dtype=torch.float64, device=dev)
+    out_rot = torch.empty((N, 3, 3), dtype=torch.float64, device=dev) if r is not None else None
+    stats = torch.empty((N, 2), dtype=torch.float32, device=dev) if want_stats else None
+    p = L.mvMatchCovParams(H, W, kernel_size, int(use_patch_var or dc is None), fx, fy, cx, cy, min_flow_cov ** 2,
+                           min_depth_cov)
+    L.check(lib.mv_match_cov(depth_map.data_ptr(), kp_uv.data_ptr(), flow_cov.data_ptr(), _ptr(dc), _ptr(r),
+                             C.byref(p), N, out.data_ptr(), _ptr(out_rot), _ptr(stats), _stream()), "mv_match_cov")
+    res = (out,)
+    if out_rot is not None:
+        res += (out_rot,)
+    if want_stats:
+        res += (stats,)
+    return res[0] if len(res) == 1 else res
+
+
+# ------------------------------------------------------------------------------------------- A17-A22
+def lm_default_params() -> L.mvLMParams:
+    p = L.mvLMParams()
+    L.load().mv_lm_default_params(C.byref(p))
+    return p
+
+
+@dataclass
+class PGOBatch:
+    """Concatenated per-point arrays of ``nprob`` independent two-frame problems (all GPU tensors)."""
+    offsets: torch.Tensor            # [nprob+1] int32
+    init_pose: torch.Tensor          # [nprob,7] float32
+    intrinsics: torch.Tensor         # [nprob,4] float32 (fx fy cx cy)
+    baseline: torch.Tensor           # [nprob] float32
+    pos_Tw: torch.Tensor             # [Ntot,3] float32
+    pixel2_uv: torch.Tensor          # [Ntot,2] float32
+    cov_Tw: torch.Tensor | None = None           # [Ntot,3,3] float64 (icp)
+    pixel2_d: torch.Tensor | None = None         # [Ntot] float32 (icp)
+    pixel2_disp: torch.Tensor | None = None      # [Ntot] float32 (disp)
+    pixel2_disp_cov: torch.Tensor | None = None  # [Ntot] float32 (disp)
+    pixel2_uv_cov: torch.Tensor | None = None    # [Ntot,3] float32 (reproj/disp)
+    obs2_covTc: torch.Tensor | None = None       # [Ntot,3,3] float64 (icp)
+
+
+_GRAPH = {"icp": L.MV_GRAPH_ICP, "reproj": L.MV_GRAPH_REPROJ, "disp": L.MV_GRAPH_DISP}
+
+
+def pgo_solve(batch: PGOBatch, graph_type: str = "disp", params: L.mvLMParams | None = None):
+    """Batched two-frame PGO (Optimizer.py:81-102 + PyposeOptimizers.py:160-194) -> (pose [nprob,7] f64, info [nprob,4] f64)."""
+    lib = L.load()
+    p = params or lm_default_params()
+    nprob = batch.init_pose.shape[0]
+    dev = batch.init_pose.device
+    f32 = lambda t, n: None if t is None else _req(t, torch.float32, n)  # noqa: E731
+    f64 = lambda t, n: None if t is None else _req(t, torch.float64, n)  # noqa: E731
+    out_pose = torch.empty((nprob, 7), dtype=torch.float64, device=dev)
+    out_info = torch.empty((nprob, 4), dtype=torch.float64, device=dev)
+    L.check(lib.mv_pgo_solve(nprob, _req(batch.offsets, torch.int32, "offsets").data_ptr(), _GRAPH[graph_type],
+                             f32(batch.init_pose, "init_pose").data_ptr(), f32(batch.intrinsics, "intrinsics").data_ptr(),
+                             f32(batch.baseline, "baseline").data_ptr(), f32(batch.pos_Tw, "pos_Tw").data_ptr(),
+                             _ptr(f64(batch.cov_Tw, "cov_Tw")), f32(batch.pixel2_uv, "pixel2_uv").data_ptr(),
+                             _ptr(f32(batch.pixel2_d, "pixel2_d")), _ptr(f32(batch.pixel2_disp, "pixel2_disp")),
+                             _ptr(f32(batch.pixel2_disp_cov, "pixel2_disp_cov")),
+                             _ptr(f32(batch.pixel2_uv_cov, "pixel2_uv_cov")), _ptr(f64(batch.obs2_covTc, "obs2_covTc")),
+                             C.byref(p), out_pose.data_ptr(), out_info.data_ptr(), _stream()), "mv_pgo_solve")
+    return out_pose, out_info

@@ -1,0 +1,150 @@
+"""GPU parity: HIP cost volume + window lookup vs the CPU oracle (oracle/corr.py)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _feats(B, C, H, W, seed, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(B, C, H, W, generator=g).to(dtype), torch.randn(B, C, H, W, generator=g).to(dtype)
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 8, 12), (2, 256, 16, 24), (1, 32, 7, 9), (1, 256, 60, 80)])
+def test_corr_volume_f32_chw(gpu, shape):
+    from macvo_amd import ops
+    from oracle import corr
+
+    B, C, H, W = shape
+    f1, f2 = _feats(B, C, H, W, seed=0)
+    ref64 = corr.corr_volume(f1, f2, torch.float64)
+    out = ops.corr_volume(f1.to(gpu), f2.to(gpu), layout="chw").cpu()
+    assert out.shape == (B * H * W, 1, H, W) and out.dtype == torch.float32
+    # fp32 fma chain over C products of N(0,1): tolerance 1e-5 relative to the row scale sqrt(C)
+    scale = float(C) ** 0.5
+    assert (out.double() - ref64).abs().max().item() <= 2e-5 * scale
+    # and not worse than a float32 einsum on the CPU
+    ref32 = corr.corr_volume(f1, f2, torch.float32)
+    assert (out.double() - ref64).abs().max() <= 4 * (ref32.double() - ref64).abs().max() + 1e-6
+
+
+def test_corr_volume_asymmetric_identity(gpu):
+    """A = I-like probe with asymmetric B catches transposed C writes (guide §3)."""
+    from macvo_amd import ops
+
+    C, H, W = 32, 4, 8  # N = 32 = C
+    N = H * W
+    f1 = torch.eye(C).reshape(1, C, H, W).contiguous()          # f1[c, i] = delta(c, i)
+    f2 = torch.arange(C * N, dtype=torch.float32).reshape(1, C, H, W) / 7.0
+    out = ops.corr_volume(f1.to(gpu), f2.to(gpu)).cpu().reshape(N, N)
+    assert torch.equal(out, f2.reshape(C, N))                    # out[i, j] = f2[i, j]
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 8, 12), (1, 256, 60, 80), (1, 48, 5, 7)])
+def test_corr_volume_f32_hwc(gpu, shape):
+    from macvo_amd import ops
+    from oracle import corr
+
+    B, C, H, W = shape
+    f1, f2 = _feats(B, C, H, W, seed=3)
+    ref64 = corr.corr_volume(f1, f2, torch.float64)
+    out = ops.corr_volume(f1.permute(0, 2, 3, 1).contiguous().to(gpu), f2.permute(0, 2, 3, 1).contiguous().to(gpu),
+                          layout="hwc").cpu()
+    assert (out.double() - ref64).abs().max().item() <= 2e-5 * float(C) ** 0.5
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("layout", ["chw", "hwc"])
+@pytest.mark.parametrize("shape", [(2, 64, 8, 12), (1, 256, 60, 80), (1, 128, 9, 11)])
+def test_corr_volume_16bit(gpu, dtype, layout, shape):
+    """Fast-mode path: 16-bit operands, fp32 accumulate.  Oracle = float64 einsum of the SAME rounded inputs;
+    tolerance = fp32 accumulation error only (1e-5 * sqrt(C) scale)."""
+    from macvo_amd import ops
+    from oracle import corr
+
+    B, C, H, W = shape
+    f1, f2 = _feats(B, C, H, W, seed=4, dtype=dtype)
+    ref64 = corr.corr_volume(f1, f2, torch.float64)
+    if layout == "chw":
+        out = ops.corr_volume(f1.to(gpu), f2.to(gpu), layout="chw")
+    else:
+        out = ops.corr_volume(f1.permute(0, 2, 3, 1).contiguous().to(gpu), f2.permute(0, 2, 3, 1).contiguous().to(gpu),
+                              layout="hwc")
+    assert (out.cpu().double() - ref64).abs().max().item() <= 2e-5 * float(C) ** 0.5
+
+
+def _coords(B, H, W, seed, spread=8.0):
+    from oracle import corr
+
+    g = torch.Generator().manual_seed(seed)
+    return corr.coords_grid(B, H, W) + (torch.rand(B, 2, H, W, generator=g) * 2 - 1) * spread
+
+
+@pytest.mark.parametrize("shape,radius", [((2, 8, 12), 4), ((1, 16, 24), 4), ((1, 7, 9), 3), ((2, 5, 6), 1), ((1, 9, 5), 2)])
+def test_corr_lookup_small(gpu, shape, radius):
+    from macvo_amd import ops
+    from oracle import corr
+
+    B, H, W = shape
+    g = torch.Generator().manual_seed(10)
+    vol = torch.randn(B * H * W, 1, H, W, generator=g) * 16
+    coords = _coords(B, H, W, seed=1)
+    ref = corr.corr_lookup(vol, coords, radius)
+    out = ops.corr_lookup(vol.to(gpu), coords.to(gpu), radius).cpu()
+    assert out.shape == ref.shape
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=2e-4)
+
+
+def test_corr_lookup_integer_coords_is_direct_indexing(gpu):
+    """At integer coordinates the lookup must reproduce direct indexing (with zero padding) up to the fp32
+    normalise/un-normalise round trip of grid_sample (<= 1e-5 relative)."""
+    from macvo_amd import ops
+    from oracle import corr
+
+    B, H, W, r = 1, 12, 16, 4
+    g = torch.Generator().manual_seed(11)
+    vol = torch.randn(B * H * W, 1, H, W, generator=g)
+    coords = corr.coords_grid(B, H, W)
+    out = ops.corr_lookup(vol.to(gpu), coords.to(gpu), r).cpu()
+    K = 2 * r + 1
+    exp = torch.zeros(B, K * K, H, W)
+    for y in range(H):
+        for x in range(W):
+            q = y * W + x
+            for i in range(K):
+                for j in range(K):
+                    xx, yy = x + i - r, y + j - r
+                    if 0 <= xx < W and 0 <= yy < H:
+                        exp[0, K * i + j, y, x] = vol[q, 0, yy, xx]
+    torch.testing.assert_close(out, exp, rtol=1e-4, atol=1e-4)
+
+
+def test_corr_lookup_full_size_12_iters(gpu):
+    """BASELINE size: 640x480 -> 60x80, B = 2, 12 successive coordinate sets (seeds 1..12, ~5% taps outside)."""
+    from macvo_amd import ops
+    from oracle import corr
+
+    B, H, W = 2, 60, 80
+    f1, f2 = _feats(B, 256, H, W, seed=0)
+    vol_d = ops.corr_volume(f1.to(gpu), f2.to(gpu))
+    vol = vol_d.cpu()
+    for it in range(1, 13):
+        coords = _coords(B, H, W, seed=it)
+        ref = corr.corr_lookup(vol, coords, 4)
+        out = ops.corr_lookup(vol_d, coords.to(gpu), 4).cpu()
+        torch.testing.assert_close(out, ref, rtol=1e-5, atol=2e-4)
+
+
+def test_corr_lookup_far_outside_and_nan(gpu):
+    """Coordinates far outside the slice give exact zeros (zero padding); NaN coordinates must not fault."""
+    from macvo_amd import ops
+    from oracle import corr
+
+    B, H, W = 1, 8, 8
+    vol = torch.ones(B * H * W, 1, H, W)
+    coords = corr.coords_grid(B, H, W) + 1000.0
+    out = ops.corr_lookup(vol.to(gpu), coords.to(gpu), 4).cpu()
+    assert torch.count_nonzero(out) == 0
+    coords[0, 0, 0, 0] = float("nan")
+    ops.corr_lookup(vol.to(gpu), coords.to(gpu), 4)
+    torch.cuda.synchronize()
