@@ -97,6 +97,8 @@ def test_match_cov(gpu, n, float_kp):
     fcov = torch.exp(2 * 0.5 * torch.randn(n, 3, generator=g))
     fcov[:, 2] = 0.2 * torch.randn(n, generator=g) * fcov[:, :2].min(dim=1).values   # PD off-diagonal
     fcov[:5, 0] = 0.01  # below the 0.0625 clamp
+    fcov[:5, 2] = 0.0
+    fcov[5, :] = torch.tensor([0.3, 0.3, 0.5])  # indefinite Sigma (det < 0): the reference yields NaN, so must we
     K = (320.0, 320.0, 320.0, 240.0)
     fc_ref = fcov.clone()
     ref, aux = covariance.match_covariance(kp, depth, None, fc_ref, *K, return_aux=True)
@@ -106,10 +108,11 @@ def test_match_cov(gpu, n, float_kp):
     assert out.dtype == torch.float64
     # in-place clamp of the caller's flow_cov, bit-exact
     assert torch.equal(fc_dev.cpu(), fc_ref)
-    torch.testing.assert_close(stats[:, 0].cpu(), aux["wavg"], rtol=2e-5, atol=1e-5)
-    torch.testing.assert_close(stats[:, 1].cpu(), aux["wvar"], rtol=2e-3, atol=1e-6)
-    torch.testing.assert_close(out.cpu(), ref, rtol=2e-3, atol=1e-7)
-    torch.testing.assert_close(out_rot.cpu(), covariance.rotate_covariance(R, out.cpu()), rtol=1e-12, atol=1e-14)
+    assert ref[5].isnan().any() and out[5].isnan().any()
+    torch.testing.assert_close(stats[:, 0].cpu(), aux["wavg"], rtol=2e-5, atol=1e-5, equal_nan=True)
+    torch.testing.assert_close(stats[:, 1].cpu(), aux["wvar"], rtol=2e-3, atol=1e-6, equal_nan=True)
+    torch.testing.assert_close(out.cpu(), ref, rtol=2e-3, atol=1e-7, equal_nan=True)
+    torch.testing.assert_close(out_rot.cpu(), covariance.rotate_covariance(R, out.cpu()), rtol=1e-12, atol=1e-14, equal_nan=True)
 
 
 def test_match_cov_given_depth_cov_and_nan(gpu):
