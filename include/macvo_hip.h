@@ -136,18 +136,41 @@ int mv_kp_gather(const int32_t* cand, const int64_t* perm, int n_sel, int W, int
  * A12  keypoint tracking + the scalar-map gathers of Odometry/MACVO.py:198-232 in one launch.
  *   kp1 = kp0 + flow[:, v0, u0]; inbound = edge < u1 < W - edge & edge < v1 < H - edge (strict,
  *   Utility/Point.py:5-13); gathers at kp0 (integer) and at kp1 truncated toward zero
- *   (Module/Frontend/Frontend.py:117); match covariance read at the SOURCE pixel kp0 (:231).
+ *   (Module/Frontend/Frontend.py:117); match covariance read at the SOURCE pixel kp0 (:231);
+ *   kp0 gets the constant sigma (match_cov_default, match_cov_default, 0) (:228-229).
  * Outputs are written for every input keypoint (row order preserved); `inbound` says which rows the
  * reference keeps.  kp0_uv int64 [N,2].  Planes are [H*W] fp32; match_cov is [3,H*W].
- *   out_kp1 [N,2] fp32; out_inbound [N] uint8;
- *   out_vals [N, 11] fp32 = {d0, disp0, sdisp0, sdd0, d1, disp1, sdisp1, sdd1, suu, svv, suv}
- *   (for rows that are not inbound the kp1-side values are 0)
+ *   out_kp0 [N,2] fp32 (= kp0 as float, or NULL); out_kp1 [N,2] fp32; out_inbound [N] uint8;
+ *   out_vals [11, N] fp32 (SoA rows) = d0, disp0, sdisp0, sdd0, d1, disp1, sdisp1, sdd1, suu, svv, suv
+ *   (for rows that are not inbound the kp1-side values are 0; absent maps give -1 like the reference)
+ *   out_sigma0, out_sigma1 [N,3] fp32 or NULL: (uu, vv, uv) of kp0 / of the match, ready for mv_match_cov
  */
 int mv_kp_track(const int64_t* kp0_uv, int N, const float* match_flow, const float* match_cov,
                 const float* depth0, const float* disp0, const float* sdisp0, const float* sdd0,
                 const float* depth1, const float* disp1, const float* sdisp1, const float* sdd1,
-                int H, int W, int edge, float* out_kp1, uint8_t* out_inbound, float* out_vals,
+                int H, int W, int edge, float match_cov_default, float* out_kp0, float* out_kp1,
+                uint8_t* out_inbound, float* out_vals, float* out_sigma0, float* out_sigma1,
                 mvStream_t stream);
+
+/* pixel2point_NED + world transform of Odometry/MACVO.py:240,273-281 (Utility/Point.py:15-17, pp.pixel2point):
+ *   pos_Tc[n] = (d, ((u-cx)*d)/fx, ((v-cy)*d)/fy)   (fp32, NED)          kp_uv [N,2] fp32
+ *   pos_Tw[n] = pose.Act(pos_Tc[n])                  (fp32, PyPose SO3_Act + t)  pose [7] fp32 device
+ *   rot [9] fp64 = pose.rotation().matrix().to(float64) (matrix evaluated in fp32 like PyPose, then widened)
+ * depth_vals[n * depth_stride] lets the caller pass a column of the mv_kp_track table directly.
+ * Any of pos_Tc / pos_Tw / rot may be NULL. */
+int mv_backproject(const float* kp_uv, const float* depth_vals, int depth_stride, float fx, float fy,
+                   float cx, float cy, const float* pose, int N, float* pos_Tc, float* pos_Tw,
+                   double* rot, mvStream_t stream);
+
+/* Observation filters of Module/OutlierFilter.py fused into one validity mask (row order kept, no compaction):
+ *   flags bit0 CovarianceSanityFilter :91-100 (no NaN/Inf in obs1_covTc / obs2_covTc)
+ *         bit1 SimpleDepthFilter :103-121 (min_depth <= d1, d2 <= max_depth)
+ *         bit2 LikelyFrontOfCamFilter :124-137 (d - 2*sqrt(sigma_d) > 0 for both observations)
+ *   inbound [N] uint8 or NULL (border test of mv_kp_track); vals = the [11, N] SoA table of mv_kp_track
+ *   valid [N] uint8; count [1] int32 = number of valid rows */
+int mv_obs_filter(const uint8_t* inbound, const double* cov1, const double* cov2, const float* vals,
+                  int flags, float min_depth, float max_depth, int N, uint8_t* valid, int32_t* count,
+                  mvStream_t stream);
 
 /* -------------------------------------------------------------------------------------------
  * A13-A16  MAC-VO covariance model.
@@ -208,14 +231,19 @@ void mv_lm_default_params(mvLMParams* p /* host */);
  *   pos_Tw [Ntot,3] fp32; cov_Tw [Ntot,9] fp64 (ICP only, else may be NULL)
  *   pixel2_uv [Ntot,2] fp32; pixel2_d [Ntot] fp32 (ICP); pixel2_disp, pixel2_disp_cov [Ntot] fp32 (DISP)
  *   pixel2_uv_cov [Ntot,3] fp32 (REPROJ/DISP); obs2_covTc [Ntot,9] fp64 (ICP)
+ *   valid [Ntot] uint8 or NULL: rows with 0 are skipped (the reference drops them from the map instead:
+ *     Odometry/MACVO.py:200-206 border filter, :269-270 outlier filter); min_points: a problem with fewer valid
+ *     rows is not optimised and returns init_pose with steps = 0 (lost track, MACVO.py:303-307; pass 0 to disable)
  *   out_pose [nprob,7] fp64; out_info [nprob,4] fp64 = {final loss, outer steps, last reject_count, initial loss}
+ *   out_pose_f32 [nprob,7] fp32 or NULL: `motion.float()` of write_graph_data (Optimizer.py:104-108)
  */
 int mv_pgo_solve(int nprob, const int32_t* offsets, int graph_type, const float* init_pose,
                  const float* intrinsics, const float* baseline, const float* pos_Tw,
                  const double* cov_Tw, const float* pixel2_uv, const float* pixel2_d,
                  const float* pixel2_disp, const float* pixel2_disp_cov, const float* pixel2_uv_cov,
-                 const double* obs2_covTc, const mvLMParams* params /* host */, double* out_pose,
-                 double* out_info, mvStream_t stream);
+                 const double* obs2_covTc, const uint8_t* valid, int min_points,
+                 const mvLMParams* params /* host */, double* out_pose, double* out_info,
+                 float* out_pose_f32, mvStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -53,8 +53,10 @@ __global__ __launch_bounds__(256) void kp_track_kernel(const int64_t* __restrict
                                                        const float* __restrict__ sdisp0, const float* __restrict__ sdd0,
                                                        const float* __restrict__ depth1, const float* __restrict__ disp1,
                                                        const float* __restrict__ sdisp1, const float* __restrict__ sdd1,
-                                                       int H, int W, int edge, float* __restrict__ out_kp1,
-                                                       uint8_t* __restrict__ out_inbound, float* __restrict__ out_vals) {
+                                                       int H, int W, int edge, float match_cov_default,
+                                                       float* __restrict__ out_kp0, float* __restrict__ out_kp1,
+                                                       uint8_t* __restrict__ out_inbound, float* __restrict__ out_vals,
+                                                       float* __restrict__ out_sigma0, float* __restrict__ out_sigma1) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const int plane = H * W;
@@ -65,27 +67,113 @@ __global__ __launch_bounds__(256) void kp_track_kernel(const int64_t* __restrict
     const float u1 = (float)u0 + match_flow[i0];
     const float v1 = (float)v0 + match_flow[plane + i0];
     const bool inb = ok0 && (u1 < (float)(W - edge)) && (u1 > (float)edge) && (v1 < (float)(H - edge)) && (v1 > (float)edge);
+    if (out_kp0) { out_kp0[2 * n] = (float)u0; out_kp0[2 * n + 1] = (float)v0; }
     out_kp1[2 * n] = u1;
     out_kp1[2 * n + 1] = v1;
     out_inbound[n] = inb;
-    float* o = out_vals + (size_t)n * 11;
-    o[0] = depth0[i0];
-    o[1] = disp0 ? disp0[i0] : -1.f;
-    o[2] = sdisp0 ? sdisp0[i0] : -1.f;
-    o[3] = sdd0 ? sdd0[i0] : -1.f;
+    float* o = out_vals + n;   // SoA: column k lives at out_vals[k * N + n]
+    o[0 * (size_t)N] = depth0[i0];
+    o[1 * (size_t)N] = disp0 ? disp0[i0] : -1.f;
+    o[2 * (size_t)N] = sdisp0 ? sdisp0[i0] : -1.f;
+    o[3 * (size_t)N] = sdd0 ? sdd0[i0] : -1.f;
     if (inb) {
         const int i1 = (int)v1 * W + (int)u1;  // .long(): truncation toward zero
-        o[4] = depth1[i1];
-        o[5] = disp1 ? disp1[i1] : -1.f;
-        o[6] = sdisp1 ? sdisp1[i1] : -1.f;
-        o[7] = sdd1 ? sdd1[i1] : -1.f;
+        o[4 * (size_t)N] = depth1[i1];
+        o[5 * (size_t)N] = disp1 ? disp1[i1] : -1.f;
+        o[6 * (size_t)N] = sdisp1 ? sdisp1[i1] : -1.f;
+        o[7 * (size_t)N] = sdd1 ? sdd1[i1] : -1.f;
     } else {
-        o[4] = o[5] = o[6] = o[7] = 0.f;
+        o[4 * (size_t)N] = o[5 * (size_t)N] = o[6 * (size_t)N] = o[7 * (size_t)N] = 0.f;
     }
     // match covariance is read at the SOURCE pixel kp0 (MACVO.py:231)
-    o[8] = match_cov ? match_cov[i0] : -1.f;
-    o[9] = match_cov ? match_cov[plane + i0] : -1.f;
-    o[10] = match_cov ? match_cov[2 * plane + i0] : -1.f;
+    const float suu = match_cov ? match_cov[i0] : -1.f;
+    const float svv = match_cov ? match_cov[plane + i0] : -1.f;
+    const float suv = match_cov ? match_cov[2 * plane + i0] : -1.f;
+    o[8 * (size_t)N] = suu; o[9 * (size_t)N] = svv; o[10 * (size_t)N] = suv;
+    if (out_sigma1) { out_sigma1[3 * n] = suu; out_sigma1[3 * n + 1] = svv; out_sigma1[3 * n + 2] = suv; }
+    // kp0 carries the constant quantisation sigma (MACVO.py:228-229)
+    if (out_sigma0) { out_sigma0[3 * n] = match_cov_default; out_sigma0[3 * n + 1] = match_cov_default; out_sigma0[3 * n + 2] = 0.f; }
+}
+
+
+// pp.SO3.matrix() in the pose dtype (fp32): columns are SO3_Act(q, e_i)  (PyPose: self.Act(I).T)
+__device__ __forceinline__ void quat_act_f32(const float* q, const float* p, float* o) {
+    float uv0 = q[1] * p[2] - q[2] * p[1], uv1 = q[2] * p[0] - q[0] * p[2], uv2 = q[0] * p[1] - q[1] * p[0];
+    uv0 += uv0; uv1 += uv1; uv2 += uv2;
+    o[0] = (p[0] + q[3] * uv0) + (q[1] * uv2 - q[2] * uv1);
+    o[1] = (p[1] + q[3] * uv1) + (q[2] * uv0 - q[0] * uv2);
+    o[2] = (p[2] + q[3] * uv2) + (q[0] * uv1 - q[1] * uv0);
+}
+
+__global__ __launch_bounds__(256) void backproject_kernel(const float* __restrict__ kp_uv,
+                                                          const float* __restrict__ depth_vals, int depth_stride,
+                                                          float fx, float fy, float cx, float cy,
+                                                          const float* __restrict__ pose, int N,
+                                                          float* __restrict__ pos_Tc, float* __restrict__ pos_Tw,
+                                                          double* __restrict__ rot) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    float t[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1};
+    if (pose) {
+        t[0] = pose[0]; t[1] = pose[1]; t[2] = pose[2];
+        q[0] = pose[3]; q[1] = pose[4]; q[2] = pose[5]; q[3] = pose[6];
+    }
+    if (n == 0 && rot && pose) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float e[3] = {c == 0 ? 1.f : 0.f, c == 1 ? 1.f : 0.f, c == 2 ? 1.f : 0.f};
+            float col[3];
+            quat_act_f32(q, e, col);
+            rot[0 * 3 + c] = (double)col[0];
+            rot[1 * 3 + c] = (double)col[1];
+            rot[2 * 3 + c] = (double)col[2];
+        }
+    }
+    if (n >= N) return;
+    // pixel2point_NED: pp.pixel2point -> (((u-cx)*d)/fx, ((v-cy)*d)/fy, d) rolled to (d, x, y)
+    const float u = kp_uv[2 * n], v = kp_uv[2 * n + 1], d = depth_vals[(size_t)n * depth_stride];
+    const float p[3] = {d, ((u - cx) * d) / fx, ((v - cy) * d) / fy};
+    if (pos_Tc) { pos_Tc[3 * n] = p[0]; pos_Tc[3 * n + 1] = p[1]; pos_Tc[3 * n + 2] = p[2]; }
+    if (pos_Tw) {
+        float r[3];
+        quat_act_f32(q, p, r);  // SE3 Act = SO3 Act + t
+        pos_Tw[3 * n] = r[0] + t[0]; pos_Tw[3 * n + 1] = r[1] + t[1]; pos_Tw[3 * n + 2] = r[2] + t[2];
+    }
+}
+
+__global__ __launch_bounds__(256) void obs_filter_kernel(const uint8_t* __restrict__ inbound,
+                                                         const double* __restrict__ cov1,
+                                                         const double* __restrict__ cov2,
+                                                         const float* __restrict__ vals, int flags,
+                                                         float min_depth, float max_depth, int N,
+                                                         uint8_t* __restrict__ valid, int32_t* __restrict__ count) {
+    // single workgroup: N <= a few thousand observations
+    __shared__ int total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    int local = 0;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        bool ok = inbound ? inbound[n] != 0 : true;
+        if (ok && (flags & 1)) {  // CovarianceSanityFilter (OutlierFilter.py:91-100)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const double a = cov1[(size_t)n * 9 + k], b = cov2[(size_t)n * 9 + k];
+                ok = ok && isfinite(a) && isfinite(b);
+            }
+        }
+        if (ok && (flags & 6)) {
+            const float d1 = vals[n], d2 = vals[4 * (size_t)N + n], c1 = vals[3 * (size_t)N + n], c2 = vals[7 * (size_t)N + n];
+            if (flags & 2)  // SimpleDepthFilter (:103-121)
+                ok = !((d1 < min_depth) || (d1 > max_depth) || (d2 < min_depth) || (d2 > max_depth));
+            if (ok && (flags & 4))  // LikelyFrontOfCamFilter (:124-137)
+                ok = ((d1 - sqrtf(c1) * 2.f) > 0.f) && ((d2 - sqrtf(c2) * 2.f) > 0.f);
+        }
+        valid[n] = ok;
+        local += ok;
+    }
+    local = wave_sum(local);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&total, local);
+    __syncthreads();
+    if (threadIdx.x == 0) count[0] = total;
 }
 
 }  // namespace
@@ -106,13 +194,37 @@ extern "C" int mv_frontend_epilogue(const float* flow, const float* logcov, int 
 extern "C" int mv_kp_track(const int64_t* kp0_uv, int N, const float* match_flow, const float* match_cov,
                            const float* depth0, const float* disp0, const float* sdisp0, const float* sdd0,
                            const float* depth1, const float* disp1, const float* sdisp1, const float* sdd1, int H,
-                           int W, int edge, float* out_kp1, uint8_t* out_inbound, float* out_vals,
+                           int W, int edge, float match_cov_default, float* out_kp0, float* out_kp1,
+                           uint8_t* out_inbound, float* out_vals, float* out_sigma0, float* out_sigma1,
                            mvStream_t stream) {
     MV_CHECK_ARG(N >= 0 && H > 0 && W > 0 && edge >= 0);
     if (N == 0) return MV_OK;
     MV_CHECK_ARG(kp0_uv && match_flow && depth0 && depth1 && out_kp1 && out_inbound && out_vals);
     hipLaunchKernelGGL(kp_track_kernel, dim3(mv_ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, kp0_uv, N,
                        match_flow, match_cov, depth0, disp0, sdisp0, sdd0, depth1, disp1, sdisp1, sdd1, H, W, edge,
-                       out_kp1, out_inbound, out_vals);
+                       match_cov_default, out_kp0, out_kp1, out_inbound, out_vals, out_sigma0, out_sigma1);
+    return mv_launch_status();
+}
+
+extern "C" int mv_backproject(const float* kp_uv, const float* depth_vals, int depth_stride, float fx, float fy,
+                              float cx, float cy, const float* pose, int N, float* pos_Tc, float* pos_Tw, double* rot,
+                              mvStream_t stream) {
+    MV_CHECK_ARG(N >= 0 && depth_stride >= 1);
+    MV_CHECK_ARG((!pos_Tw && !rot) || pose);
+    if (N == 0 && !rot) return MV_OK;
+    MV_CHECK_ARG(N == 0 || (kp_uv && depth_vals));
+    hipLaunchKernelGGL(backproject_kernel, dim3(N > 0 ? mv_ceil_div(N, 256) : 1), dim3(256), 0, (hipStream_t)stream,
+                       kp_uv, depth_vals, depth_stride, fx, fy, cx, cy, pose, N, pos_Tc, pos_Tw, rot);
+    return mv_launch_status();
+}
+
+extern "C" int mv_obs_filter(const uint8_t* inbound, const double* cov1, const double* cov2, const float* vals,
+                             int flags, float min_depth, float max_depth, int N, uint8_t* valid, int32_t* count,
+                             mvStream_t stream) {
+    MV_CHECK_ARG(N >= 0 && valid && count);
+    MV_CHECK_ARG(!(flags & 1) || (cov1 && cov2));
+    MV_CHECK_ARG(!(flags & 6) || vals);
+    hipLaunchKernelGGL(obs_filter_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, inbound, cov1, cov2, vals,
+                       flags, min_depth, max_depth, N, valid, count);
     return mv_launch_status();
 }

@@ -39,8 +39,11 @@ struct PgoArgs {
     const float* pixel2_disp_cov;
     const float* pixel2_uv_cov;
     const double* obs2_covTc;
+    const uint8_t* valid;
+    int min_points;
     double* out_pose;
     double* out_info;
+    float* out_pose_f32;
 };
 
 struct Pose {
@@ -214,6 +217,12 @@ __global__ __launch_bounds__(64) void pgo_solve_kernel(PgoArgs a, mvLMParams lm)
     int steps = 0, patience_count = 0, reject_count = 0;
     bool continual = true;
 
+    // Odometry/MACVO.py:303-307: fewer than min_num_point observations => no optimisation, pose stays at the prior
+    int n_valid = 0;
+    for (int i = beg + lane; i < end; i += 64) n_valid += (a.valid ? (a.valid[i] != 0) : 1);
+    n_valid = wave_sum(n_valid);
+    if (n_valid < a.min_points) continual = false;
+
     while (continual) {
         // ------------------------------------------------------------------ build pass
         double Aw[21], gw[6], Au[21], gu[6], loss_acc = 0.0;
@@ -223,6 +232,7 @@ __global__ __launch_bounds__(64) void pgo_solve_kernel(PgoArgs a, mvLMParams lm)
         for (int k = 0; k < 6; ++k) { gw[k] = 0.0; gu[k] = 0.0; }
 
         for (int i = beg + lane; i < end; i += 64) {
+            if (a.valid && !a.valid[i]) continue;
             double r[3] = {0, 0, 0}, pc[3];
             const double n2 = residual<GT>(a, g, P, i, r, pc);
             loss_acc += huber(n2, lm.huber_delta);
@@ -391,6 +401,7 @@ __global__ __launch_bounds__(64) void pgo_solve_kernel(PgoArgs a, mvLMParams lm)
             // loss at the trial pose (RobustModel.loss: unweighted, uncorrected)
             double la = 0.0;
             for (int i = beg + lane; i < end; i += 64) {
+                if (a.valid && !a.valid[i]) continue;
                 double r[3] = {0, 0, 0}, pc[3];
                 la += huber(residual<GT>(a, g, P, i, r, pc), lm.huber_delta);
             }
@@ -442,6 +453,11 @@ __global__ __launch_bounds__(64) void pgo_solve_kernel(PgoArgs a, mvLMParams lm)
         o[3] = P.q[0]; o[4] = P.q[1]; o[5] = P.q[2]; o[6] = P.q[3];
         double* inf = a.out_info + 4 * (size_t)prob;
         inf[0] = loss; inf[1] = (double)steps; inf[2] = (double)reject_count; inf[3] = loss0;
+        if (a.out_pose_f32) {
+            float* of = a.out_pose_f32 + 7 * (size_t)prob;  // write_graph_data: pose = motion.float()
+            of[0] = (float)P.t[0]; of[1] = (float)P.t[1]; of[2] = (float)P.t[2];
+            of[3] = (float)P.q[0]; of[4] = (float)P.q[1]; of[5] = (float)P.q[2]; of[6] = (float)P.q[3];
+        }
     }
 }
 
@@ -463,13 +479,14 @@ extern "C" int mv_pgo_solve(int nprob, const int32_t* offsets, int graph_type, c
                             const float* intrinsics, const float* baseline, const float* pos_Tw, const double* cov_Tw,
                             const float* pixel2_uv, const float* pixel2_d, const float* pixel2_disp,
                             const float* pixel2_disp_cov, const float* pixel2_uv_cov, const double* obs2_covTc,
-                            const mvLMParams* params, double* out_pose, double* out_info, mvStream_t stream) {
+                            const uint8_t* valid, int min_points, const mvLMParams* params, double* out_pose,
+                            double* out_info, float* out_pose_f32, mvStream_t stream) {
     MV_CHECK_ARG(nprob >= 0 && params);
     if (nprob == 0) return MV_OK;
     MV_CHECK_ARG(offsets && init_pose && intrinsics && baseline && pos_Tw && pixel2_uv && out_pose && out_info);
     MV_CHECK_ARG(params->max_steps >= 1 && params->reject >= 0 && params->radius > 0 && params->huber_delta > 0);
     PgoArgs a{offsets, init_pose, intrinsics, baseline, pos_Tw, cov_Tw, pixel2_uv, pixel2_d, pixel2_disp,
-              pixel2_disp_cov, pixel2_uv_cov, obs2_covTc, out_pose, out_info};
+              pixel2_disp_cov, pixel2_uv_cov, obs2_covTc, valid, min_points, out_pose, out_info, out_pose_f32};
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(nprob), block(64);
     switch (graph_type) {

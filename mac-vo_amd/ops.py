@@ -32,6 +32,14 @@ def _req(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _u8(t: torch.Tensor | None) -> torch.Tensor | None:
+    if t is None:
+        return None
+    if t.dtype == torch.bool:
+        t = t.contiguous().view(torch.uint8)
+    return _req(t, torch.uint8, "mask")
+
+
 # ------------------------------------------------------------------------------------------- A5
 def corr_volume(f1: torch.Tensor, f2: torch.Tensor, layout: str = "chw", out: torch.Tensor | None = None) -> torch.Tensor:
     """All-pairs cost volume (FlowFormer ``MemoryEncoder.corr``; call site flownet.py:26-27).
@@ -207,13 +215,16 @@ def kp_select(mode: str, H: int, W: int, flow_cov: torch.Tensor | None = None, d
 # ------------------------------------------------------------------------------------------- A12
 @dataclass
 class TrackedKeypoints:
+    kp0_uv: torch.Tensor      # [N,2] float32 (kp0 as float)
     kp1_uv: torch.Tensor      # [N,2] float32
     inbound: torch.Tensor     # [N] bool
-    vals: torch.Tensor        # [N,11] float32: d0 disp0 sdisp0 sdd0 d1 disp1 sdisp1 sdd1 suu svv suv
+    vals: torch.Tensor        # [11,N] float32 rows: d0 disp0 sdisp0 sdd0 d1 disp1 sdisp1 sdd1 suu svv suv
+    sigma0: torch.Tensor      # [N,3] float32 default sigma of kp0
+    sigma1: torch.Tensor      # [N,3] float32 match covariance (read at kp0)
 
 
 def kp_track(kp0_uv: torch.Tensor, flow: torch.Tensor, flow_cov: torch.Tensor | None, depth0: FrontendMaps | dict,
-             depth1: FrontendMaps | dict, edge: int) -> TrackedKeypoints:
+             depth1: FrontendMaps | dict, edge: int, match_cov_default: float = 0.25) -> TrackedKeypoints:
     """kp1 = kp0 + flow[kp0], strict border test, and all per-keypoint gathers (MACVO.py:198-232) in one launch."""
     lib = L.load()
     kp0_uv = _req(kp0_uv, torch.int64, "kp0_uv")
@@ -229,13 +240,16 @@ def kp_track(kp0_uv: torch.Tensor, flow: torch.Tensor, flow_cov: torch.Tensor | 
     d0 = [g(depth0, k) for k in ("depth", "disparity", "disparity_cov", "depth_cov")]
     d1 = [g(depth1, k) for k in ("depth", "disparity", "disparity_cov", "depth_cov")]
     fc = None if flow_cov is None else _req(flow_cov, torch.float32, "flow_cov")
+    kp0f = torch.empty((N, 2), dtype=torch.float32, device=dev)
     kp1 = torch.empty((N, 2), dtype=torch.float32, device=dev)
     inb = torch.empty((N,), dtype=torch.bool, device=dev)
-    vals = torch.empty((N, 11), dtype=torch.float32, device=dev)
+    vals = torch.empty((11, N), dtype=torch.float32, device=dev)
+    s0 = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    s1 = torch.empty((N, 3), dtype=torch.float32, device=dev)
     L.check(lib.mv_kp_track(kp0_uv.data_ptr(), N, flow.data_ptr(), _ptr(fc), *[_ptr(t) for t in d0],
-                            *[_ptr(t) for t in d1], H, W, edge, kp1.data_ptr(), inb.data_ptr(), vals.data_ptr(),
-                            _stream()), "mv_kp_track")
-    return TrackedKeypoints(kp1, inb, vals)
+                            *[_ptr(t) for t in d1], H, W, edge, match_cov_default, kp0f.data_ptr(), kp1.data_ptr(),
+                            inb.data_ptr(), vals.data_ptr(), s0.data_ptr(), s1.data_ptr(), _stream()), "mv_kp_track")
+    return TrackedKeypoints(kp0f, kp1, inb, vals, s0, s1)
 
 
 # ------------------------------------------------------------------------------------------- A13-A16
@@ -295,13 +309,16 @@ class PGOBatch:
     pixel2_disp_cov: torch.Tensor | None = None  # [Ntot] float32 (disp)
     pixel2_uv_cov: torch.Tensor | None = None    # [Ntot,3] float32 (reproj/disp)
     obs2_covTc: torch.Tensor | None = None       # [Ntot,3,3] float64 (icp)
+    valid: torch.Tensor | None = None            # [Ntot] bool/uint8: rows to use (None = all)
 
 
 _GRAPH = {"icp": L.MV_GRAPH_ICP, "reproj": L.MV_GRAPH_REPROJ, "disp": L.MV_GRAPH_DISP}
 
 
-def pgo_solve(batch: PGOBatch, graph_type: str = "disp", params: L.mvLMParams | None = None):
-    """Batched two-frame PGO (Optimizer.py:81-102 + PyposeOptimizers.py:160-194) -> (pose [nprob,7] f64, info [nprob,4] f64)."""
+def pgo_solve(batch: PGOBatch, graph_type: str = "disp", params: L.mvLMParams | None = None, min_points: int = 0,
+              out_pose_f32: torch.Tensor | None = None):
+    """Batched two-frame PGO (Optimizer.py:81-102 + PyposeOptimizers.py:160-194) -> (pose [nprob,7] f64, info [nprob,4] f64).
+    ``out_pose_f32`` (optional ``[nprob,7]`` float32 GPU tensor) receives ``motion.float()`` (Optimizer.py:104-108)."""
     lib = L.load()
     p = params or lm_default_params()
     nprob = batch.init_pose.shape[0]
@@ -317,5 +334,49 @@ def pgo_solve(batch: PGOBatch, graph_type: str = "disp", params: L.mvLMParams | 
                              _ptr(f32(batch.pixel2_d, "pixel2_d")), _ptr(f32(batch.pixel2_disp, "pixel2_disp")),
                              _ptr(f32(batch.pixel2_disp_cov, "pixel2_disp_cov")),
                              _ptr(f32(batch.pixel2_uv_cov, "pixel2_uv_cov")), _ptr(f64(batch.obs2_covTc, "obs2_covTc")),
-                             C.byref(p), out_pose.data_ptr(), out_info.data_ptr(), _stream()), "mv_pgo_solve")
+                             _ptr(_u8(batch.valid)), int(min_points), C.byref(p), out_pose.data_ptr(),
+                             out_info.data_ptr(), _ptr(out_pose_f32), _stream()), "mv_pgo_solve")
     return out_pose, out_info
+
+
+# ------------------------------------------------------------------------------------------- A12 tail / X1
+def backproject(kp_uv: torch.Tensor, depth_vals: torch.Tensor, K4: tuple, pose: torch.Tensor | None,
+                want_rot: bool = False):
+    """``pixel2point_NED`` (Point.py:15-17) + ``prev_pose.Act`` + ``rotation().matrix().double()`` (MACVO.py:240,273-281).
+    ``depth_vals`` may be a strided column view (e.g. ``tracked.vals[:, 0]``).  Returns (pos_Tc, pos_Tw | None, rot | None)."""
+    lib = L.load()
+    if kp_uv.dtype != torch.float32:
+        kp_uv = kp_uv.to(torch.float32)
+    kp_uv = _req(kp_uv, torch.float32, "kp_uv")
+    assert depth_vals.dtype == torch.float32 and depth_vals.is_cuda and depth_vals.dim() == 1
+    stride = depth_vals.stride(0) if depth_vals.numel() > 1 else 1
+    N = kp_uv.shape[0]
+    dev = kp_uv.device
+    pos_Tc = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    pos_Tw = torch.empty((N, 3), dtype=torch.float32, device=dev) if pose is not None else None
+    rot = torch.empty((3, 3), dtype=torch.float64, device=dev) if (want_rot and pose is not None) else None
+    pose_c = None if pose is None else _req(pose.reshape(-1), torch.float32, "pose")
+    L.check(lib.mv_backproject(kp_uv.data_ptr(), depth_vals.data_ptr(), int(stride), *[float(k) for k in K4],
+                               _ptr(pose_c), N, pos_Tc.data_ptr(), _ptr(pos_Tw), _ptr(rot), _stream()), "mv_backproject")
+    return pos_Tc, pos_Tw, rot
+
+
+FILTER_COV_SANITY, FILTER_SIMPLE_DEPTH, FILTER_FRONT_OF_CAM = 1, 2, 4
+
+
+def obs_filter(inbound: torch.Tensor | None, cov1: torch.Tensor | None, cov2: torch.Tensor | None,
+               vals: torch.Tensor | None, flags: int = FILTER_COV_SANITY, min_depth: float = 0.0,
+               max_depth: float = 0.0):
+    """Fused observation filters (OutlierFilter.py:91-137) -> (valid [N] bool, count [1] int32), both on the GPU."""
+    lib = L.load()
+    ref = inbound if inbound is not None else (cov1 if cov1 is not None else vals)
+    N = ref.shape[0]
+    dev = ref.device
+    valid = torch.empty((N,), dtype=torch.bool, device=dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    c1 = None if cov1 is None else _req(cov1, torch.float64, "cov1")
+    c2 = None if cov2 is None else _req(cov2, torch.float64, "cov2")
+    vv = None if vals is None else _req(vals, torch.float32, "vals")
+    L.check(lib.mv_obs_filter(_ptr(_u8(inbound)), _ptr(c1), _ptr(c2), _ptr(vv), flags, min_depth, max_depth, N,
+                              valid.data_ptr(), count.data_ptr(), _stream()), "mv_obs_filter")
+    return valid, count

@@ -1,0 +1,173 @@
+"""The per-frame hot path in the reference's call order (``Odometry/MACVO.py:173-311``), on one GPU.
+
+``HotPath.step`` is what ``MACVO.run_pair`` executes between "the learned layers produced feature maps /
+GRU updates" and "the optimised pose is written back", with every arithmetic step in the HIP kernels:
+
+    Frontend.estimate_pair   MACVO.py:182   corr volume (A5) -> 12 x window lookup (A6) -> epilogue (A8/A2)
+    KeypointSelector         MACVO.py:197   dense selector (A10/A11) + host randperm (bit-exact indices)
+    gathers / tracking       MACVO.py:198-232  kp_track (A12)
+    pixel2point_NED, world   MACVO.py:240,273-281  backproject (A12/A16)
+    ObsCovModel.estimate x2  MACVO.py:241-242  match_cov (A13-A16), world rotation fused
+    OutlierFilter.filter     MACVO.py:269   obs_filter (validity mask instead of row compaction)
+    Optimizer                MACVO.py:309-311  pgo_solve (A17-A22), pose written back in fp32 (A22)
+
+The learned FlowFormer layers (Twins encoder, cost-token transformer, GRU) are NOT part of this module: their
+outputs for a frame arrive as :class:`FrameInputs` already resident in HBM (the network "stays
+PyTorch-ROCm"; its source and weights are absent from the reference checkout).
+
+State carried between frames lives on the device: the previous frame's depth maps and the previous pose
+(StaticMotionModel: the prior of frame t is the optimised pose of frame t-1, MotionModel.py:134-142).
+The only host synchronisation per frame is the selector's candidate count (needed by ``torch.randperm``).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import torch
+
+from . import ops
+
+
+@dataclass
+class Camera:
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+    baseline: float
+    H: int
+    W: int
+
+    @property
+    def K4(self):
+        return (self.fx, self.fy, self.cx, self.cy)
+
+
+@dataclass
+class HotPathConfig:
+    """Values of ``Config/Experiment/MACVO/MACVO_Fast.yaml`` (:22-104) that touch the hot path."""
+    num_point: int = 200
+    edgewidth: int = 32
+    match_cov_default: float = 0.25
+    selector: str = "nodepth"            # CovAwareSelector_NoDepth | "full" = CovAwareSelector
+    kp_kernel_size: int = 7
+    kp_mask_width: int = 32
+    max_match_cov: float = 100.0
+    max_depth_cov: float = 250.0
+    max_depth: float | str = "auto"      # "auto" -> fx * baseline (KeypointSelector.py:263)
+    cov_kernel_size: int = 31
+    min_flow_cov: float = 0.25
+    min_depth_cov: float = 0.05
+    graph_type: str = "disp"
+    min_num_point: int = 10              # MACVO.py:64
+    filters: int = ops.FILTER_COV_SANITY  # CovarianceSanityFilter
+    filter_min_depth: float = 0.05
+    radius: int = 4
+    feature_layout: str = "chw"
+
+
+@dataclass
+class FrameInputs:
+    """What the learned layers hand to the hot path for one ``estimate_pair`` (all GPU-resident).
+
+    fmap1 / fmap2 : ``[2, C, H/8, W/8]`` (layout "chw") or ``[2, H/8, W/8, C]`` ("hwc"); pair 0 = stereo
+                    (L_t2 vs R_t2), pair 1 = temporal (L_t1 vs L_t2)  (Frontend.py:219-220)
+    coords        : ``[iters, 2, 2, H/8, W/8]`` fp32 — coords1 entering each decoder iteration (covhead.py:85-92)
+    flow, logcov  : ``[2, 2, H, W]`` fp32 — last upsampled flow / log-sigma predictions (covhead.py:140)
+    """
+    fmap1: torch.Tensor
+    fmap2: torch.Tensor
+    coords: torch.Tensor
+    flow: torch.Tensor
+    logcov: torch.Tensor
+
+
+@dataclass
+class FrameResult:
+    pose: torch.Tensor                 # [7] fp32 GPU — optimised pose of this frame (write_graph_data)
+    pose_f64: torch.Tensor | None      # [1,7] fp64 GPU
+    info: torch.Tensor | None          # [1,4] fp64 GPU {loss, steps, rejects, loss0}
+    kp0_uv: torch.Tensor | None        # [n,2] int64 GPU selected keypoints
+    n_valid: torch.Tensor | None       # [1] int32 GPU surviving observations
+    extras: dict = field(default_factory=dict)
+
+
+class HotPath:
+    def __init__(self, cam: Camera, cfg: HotPathConfig | None = None, device: str | torch.device = "cuda",
+                 keep_extras: bool = False):
+        self.cam, self.cfg = cam, cfg or HotPathConfig()
+        self.dev = torch.device(device)
+        self.keep_extras = keep_extras
+        self.lm = ops.lm_default_params()
+        self.maps_prev: ops.FrontendMaps | None = None
+        self.pose = torch.tensor([0, 0, 0, 0, 0, 0, 1], dtype=torch.float32, device=self.dev)
+        c = self.cfg
+        self._max_depth = cam.fx * cam.baseline if c.max_depth == "auto" else float(c.max_depth)
+        self._intr = torch.tensor([cam.K4], dtype=torch.float32, device=self.dev)
+        self._bl = torch.tensor([cam.baseline], dtype=torch.float32, device=self.dev)
+        self._vol = None
+        self._tok = None
+        self.last_tokens = None
+        # offsets table: row n = [0, n] (one problem of n points) — avoids an H2D copy per frame
+        m = self.cfg.num_point + 1
+        self._offs = torch.stack([torch.zeros(m, dtype=torch.int32), torch.arange(m, dtype=torch.int32)], 1).to(self.dev)
+
+    # ------------------------------------------------------------------ frontend part of the hot path
+    def frontend(self, x: FrameInputs) -> ops.FrontendMaps:
+        c = self.cfg
+        if self._vol is None or self._vol.shape[0] != x.fmap1.shape[0] * x.coords.shape[-1] * x.coords.shape[-2]:
+            self._vol = None
+        self._vol = ops.corr_volume(x.fmap1, x.fmap2, layout=c.feature_layout, out=self._vol)
+        for it in range(x.coords.shape[0]):
+            self._tok = ops.corr_lookup(self._vol, x.coords[it], c.radius, out=self._tok)
+        self.last_tokens = self._tok
+        return ops.frontend_epilogue(x.flow, x.logcov, self.cam.baseline, self.cam.fx, cov_is_log=True)
+
+    def initialize(self, x: FrameInputs, init_pose: torch.Tensor | None = None) -> None:
+        """Frame 0: ``MACVO.initialize`` (:158-171) — depth only, pose = prior."""
+        self.maps_prev = self.frontend(x)
+        if init_pose is not None:
+            self.pose = init_pose.to(self.dev, torch.float32).reshape(7).clone()
+
+    # ------------------------------------------------------------------ one run_pair
+    def step(self, x: FrameInputs) -> FrameResult:
+        assert self.maps_prev is not None, "call initialize() with the first frame"
+        c, cam = self.cfg, self.cam
+        maps0, maps1 = self.maps_prev, self.frontend(x)
+
+        if c.selector == "nodepth":
+            cands = ops.kp_select("nodepth", cam.H, cam.W, flow_cov=maps1.flow_cov, kernel_size=c.kp_kernel_size,
+                                  mask_width=c.kp_mask_width, max_match_cov=c.max_match_cov)
+        else:
+            cands = ops.kp_select("full", cam.H, cam.W, flow_cov=maps1.flow_cov, depth0=maps0.depth,
+                                  depth0_cov=maps0.depth_cov, depth1=maps1.depth, depth1_cov=maps1.depth_cov,
+                                  kernel_size=c.kp_kernel_size, mask_width=c.kp_mask_width, max_depth=self._max_depth,
+                                  max_depth_cov=c.max_depth_cov, max_match_cov=c.max_match_cov)
+        kp0 = cands.finish(c.num_point)          # host sync (count) + CPU randperm, as in the reference
+        n = kp0.shape[0]
+        if n == 0:
+            self.maps_prev = maps1
+            return FrameResult(self.pose, None, None, kp0, None)
+
+        tr = ops.kp_track(kp0, maps1.flow, maps1.flow_cov, maps0, maps1, c.edgewidth, c.match_cov_default)
+        pos0_Tc, pos_Tw, rot = ops.backproject(tr.kp0_uv, tr.vals[0], cam.K4, self.pose, want_rot=True)
+        cov0, cov0_w = ops.match_cov(maps0.depth, tr.kp0_uv, tr.sigma0, None, *cam.K4, kernel_size=c.cov_kernel_size,
+                                     min_flow_cov=c.min_flow_cov, min_depth_cov=c.min_depth_cov, rot=rot)
+        cov1 = ops.match_cov(maps1.depth, tr.kp1_uv, tr.sigma1, None, *cam.K4, kernel_size=c.cov_kernel_size,
+                             min_flow_cov=c.min_flow_cov, min_depth_cov=c.min_depth_cov)
+        valid, n_valid = ops.obs_filter(tr.inbound, cov0, cov1, tr.vals, c.filters, c.filter_min_depth, self._max_depth)
+
+        batch = ops.PGOBatch(
+            offsets=self._offs[n],
+            init_pose=self.pose.reshape(1, 7), intrinsics=self._intr, baseline=self._bl,
+            pos_Tw=pos_Tw, pixel2_uv=tr.kp1_uv, cov_Tw=cov0_w, pixel2_d=tr.vals[4], pixel2_disp=tr.vals[5],
+            pixel2_disp_cov=tr.vals[6], pixel2_uv_cov=tr.sigma1, obs2_covTc=cov1, valid=valid)
+        new_pose = torch.empty((1, 7), dtype=torch.float32, device=self.dev)
+        pose64, info = ops.pgo_solve(batch, c.graph_type, self.lm, min_points=c.min_num_point, out_pose_f32=new_pose)
+        self.pose = new_pose.reshape(7)
+        self.maps_prev = maps1
+        res = FrameResult(self.pose, pose64, info, kp0, n_valid)
+        if self.keep_extras:
+            res.extras = dict(tracked=tr, cov0=cov0, cov0_w=cov0_w, cov1=cov1, valid=valid, pos_Tw=pos_Tw,
+                              maps1=maps1, cands=cands)
+        return res

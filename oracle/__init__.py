@@ -28,4 +28,4 @@ Parity pinning status:
   "parity unpinned"; pinned instead to the mathematical definitions
   (``einsum`` / ``grid_sample(align_corners=True, zeros)``) the upstream code calls.
 """
-from . import se3, corr, frontend, selector, covariance, pgo  # noqa: F401
+from . import se3, corr, frontend, selector, covariance, pgo, pipeline  # noqa: F401

@@ -27,3 +27,98 @@ def keypoints(n=200, H=480, W=640, seed=5, border=32):
     u = torch.randint(border, W - border, (n,), generator=g)
     v = torch.randint(border, H - border, (n,), generator=g)
     return torch.stack([u, v], dim=1)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# S-e2e: a geometrically consistent synthetic stereo stream (planar scene, known SE3 trajectory)
+# ----------------------------------------------------------------------------------------------------------
+def _se3_exp(xi):
+    from oracle import se3
+
+    return se3.se3_exp(xi)
+
+
+def make_camera(H=480, W=640):
+    return dict(fx=320.0, fy=320.0, cx=W / 2.0, cy=H / 2.0, baseline=0.25, H=H, W=W)
+
+
+def make_sequence(n_frames=4, H=480, W=640, C=256, iters=12, seed=0, feat_dtype=torch.float32, pool=2,
+                  noise=0.3, device="cpu", closed_loop=False):
+    """Returns (cam dict, list of frame dicts, list of true poses [7] float64).
+
+    Frame dict keys = FrameInputs fields: fmap1, fmap2 [2,C,H/8,W/8]; coords [iters,2,2,H/8,W/8]; flow, logcov
+    [2,2,H,W].  flow[0,0] = -disparity of the frame (stereo pair), flow[1] = temporal flow (t-1 -> t) sampled on
+    frame t-1's pixel grid; both consistent with a planar scene and the true trajectory, plus noise ~ sigma.
+    The feature maps / lookup coordinates are random (their consumer, the GRU, is not part of the hot path); only
+    `pool` distinct sets are generated and cycled.
+    """
+    from oracle import se3
+
+    dev = torch.device(device)
+    g = torch.Generator().manual_seed(seed)
+    cam = make_camera(H, W)
+    fx, fy, cx, cy, bl = cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline"]
+    h8, w8 = H // 8, W // 8
+    if closed_loop:
+        # closed trajectory (bench): circle of radius 0.3 m in the image plane + small periodic rotation, so that
+        # frame 0 follows frame n-1 with the same inter-frame motion as every other pair
+        import math
+
+        poses = []
+        for t in range(n_frames):
+            th = 2 * math.pi * t / n_frames
+            xi = torch.tensor([0.05 * math.sin(th), 0.3 * math.cos(th), 0.3 * math.sin(th),
+                               0.01 * math.sin(th), 0.01 * math.cos(th), 0.01 * math.sin(2 * th)], dtype=torch.float64)
+            poses.append(se3.se3_exp(xi))
+    else:
+        # trajectory: smooth forward motion with small rotations
+        poses = [torch.tensor([0, 0, 0, 0, 0, 0, 1], dtype=torch.float64)]
+        for _ in range(n_frames - 1):
+            xi = torch.cat([torch.tensor([0.08, 0.0, 0.0]) + 0.02 * torch.randn(3, generator=g), 0.01 * torch.randn(3, generator=g)]).double()
+            poses.append(se3.se3_mul(poses[-1], se3.se3_exp(xi)))
+    # plane n . Pw = c in world NED (X forward): mostly fronto-parallel at ~12 m, tilted
+    nrm = torch.tensor([1.0, 0.15, -0.25], dtype=torch.float64)
+    nrm = nrm / nrm.norm()
+    cpl = 12.0
+    vs, us = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing="ij")
+    dirs = torch.stack([torch.ones_like(us), (us - cx) / fx, (vs - cy) / fy], dim=-1)  # [H,W,3] NED ray, X = 1
+
+    def depth_of(T):
+        R = se3.quat_to_matrix(T[3:])
+        rd = dirs @ R.T
+        return (cpl - (nrm * T[:3]).sum()) / (rd @ nrm)  # [H,W] depth along X_cam
+
+    pools = []
+    for _ in range(pool):
+        pools.append(dict(
+            fmap1=torch.randn(2, C, h8, w8, generator=g).to(feat_dtype).to(dev),
+            fmap2=torch.randn(2, C, h8, w8, generator=g).to(feat_dtype).to(dev),
+            coords=(torch.stack([torch.arange(w8).float()[None].expand(h8, w8), torch.arange(h8).float()[:, None].expand(h8, w8)])[None, None]
+                    + (torch.rand(iters, 2, 2, h8, w8, generator=g) * 2 - 1) * 8).to(dev),
+        ))
+    frames = []
+    z_prev = depth_of(poses[-1]) if closed_loop else None
+    for t in range(n_frames):
+        T = poses[t]
+        z = depth_of(T)
+        disp = fx * bl / z
+        logcov = (0.5 * torch.randn(2, 2, H, W, generator=g) - 0.7).float()
+        sig = torch.exp(logcov)
+        flow = torch.zeros(2, 2, H, W)
+        flow[0, 0] = -(disp.float() + noise * sig[0, 0] * torch.randn(H, W, generator=g))
+        flow[0, 1] = 0.01 * torch.randn(H, W, generator=g)
+        if t > 0 or closed_loop:
+            Tp = poses[t - 1]
+            Pc = dirs * z_prev[..., None]                                   # points in camera t-1
+            Pw = Pc @ se3.quat_to_matrix(Tp[3:]).T + Tp[:3]
+            Rt = se3.quat_to_matrix(T[3:])
+            P2 = (Pw - T[:3]) @ Rt                                           # R^T (Pw - t)
+            u2 = fx * P2[..., 1] / P2[..., 0] + cx
+            v2 = fy * P2[..., 2] / P2[..., 0] + cy
+            flow[1, 0] = (u2 - us).float() + noise * sig[1, 0] * torch.randn(H, W, generator=g)
+            flow[1, 1] = (v2 - vs).float() + noise * sig[1, 1] * torch.randn(H, W, generator=g)
+        fr = dict(pools[t % pool])
+        fr.update(flow=flow.to(dev), logcov=logcov.to(dev))
+        frames.append(fr)
+        z_prev = z
+    return cam, frames, poses

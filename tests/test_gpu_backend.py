@@ -171,12 +171,14 @@ def test_frontend_epilogue_and_track(gpu):
     assert torch.equal(inb, ref["inbound_mask"])
     assert 0 < int(inb.sum()) < 300
     assert torch.equal(tr.kp1_uv.cpu()[inb], ref["kp1_uv"])
-    v = tr.vals.cpu()[inb]
+    v = tr.vals.cpu().T[inb]
     assert torch.equal(v[:, 0], ref["kp0_d"]) and torch.equal(v[:, 4], ref["kp1_d"])
     assert torch.equal(v[:, 1], ref["kp0_disparity"][0]) and torch.equal(v[:, 5], ref["kp1_disparity"][0])
     assert torch.equal(v[:, 2], ref["kp0_sigma_disparity"][0]) and torch.equal(v[:, 6], ref["kp1_sigma_disparity"][0])
     assert torch.equal(v[:, 3], ref["kp0_sigma_dd"]) and torch.equal(v[:, 7], ref["kp1_sigma_dd"])
     assert torch.equal(v[:, 8:11], ref["kp1_sigma_uv"])
+    assert torch.equal(tr.sigma1.cpu()[inb], ref["kp1_sigma_uv"]) and torch.equal(tr.sigma0.cpu()[inb], ref["kp0_sigma_uv"])
+    assert torch.equal(tr.kp0_uv.cpu()[inb], ref["kp0_uv"].float())
 
 
 # ------------------------------------------------------------------------------- PGO
