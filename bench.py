@@ -43,7 +43,7 @@ def parse_args():
     ap.add_argument("--layout", choices=["chw", "hwc"], default="chw")
     ap.add_argument("--graph", choices=["disp", "reproj", "icp"], default="disp")
     ap.add_argument("--pool", type=int, default=24, help="distinct synthetic frames (closed trajectory) kept in HBM")
-    ap.add_argument("--cpu-frames", type=int, default=6, help="frames timed for the CPU baseline (rank 0, N=1 only)")
+    ap.add_argument("--cpu-frames", type=int, default=40, help="frames timed for the CPU baseline (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events around the volume kernel")
     return ap.parse_args()
@@ -174,7 +174,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.pipeline import OracleHotPath
 
-        cores = os.cpu_count() or 1
+        # 8 threads = what the reference's optimizer child uses (Optimization/Interface.py:254); more threads on a
+        # many-core host make the small float64 LM ops slower (fork/join dominated), measured 34 s/frame at 256 threads
+        cores = min(os.cpu_count() or 1, 8)
         torch.set_num_threads(cores)
         ora = OracleHotPath(cam, dict(graph_type=args.graph))
         cfr = [{k: (v.float() if v.dtype in (torch.float16, torch.bfloat16) else v) for k, v in fr.items()} for fr in frames_cpu]
@@ -187,7 +189,7 @@ def main():
         ora.step(cfr[1])  # warm-up (thread pools, first-call overheads)
         c0 = time.perf_counter()
         ncpu = 0
-        while ncpu < args.cpu_frames:
+        while ncpu < args.cpu_frames and (time.perf_counter() - c0) < 25.0:
             ora.step(cfr[(2 + ncpu) % args.pool])
             ncpu += 1
         csec = time.perf_counter() - c0
