@@ -1,0 +1,291 @@
+"""Drop-in plugins for ``Odometry/MACVO.py``: same interfaces, same YAML ``args`` as the reference classes they
+replace, every hot arithmetic step in the HIP kernels (``include/macvo_hip.h``).
+
+    reference class (Config ``type:``)        HIP plugin
+    ----------------------------------------  ----------------------------------
+    CovAwareSelector_NoDepth                  HIP_CovAwareSelector_NoDepth
+    CovAwareSelector                          HIP_CovAwareSelector
+    MappingPointSelector                      HIP_MappingPointSelector
+    MatchCovariance                           HIP_MatchCovariance
+    TwoFrame_PGO                              HIP_TwoFrame_PGO
+    (FlowFormerCov's volume / lookup)         install_flowformer_hooks(model)
+
+Select them by changing only the ``type:`` strings of ``Config/Experiment/MACVO/MACVO_Fast.yaml`` (see
+INTEGRATION.md); importing this module registers the classes (``SubclassRegistry`` semantics).
+There is no CPU fallback: ``device`` must be a GPU device string ("cuda" is the HIP device on ROCm).
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+
+import torch
+
+from . import ops
+from .interfaces import (GraphInput, GraphOutput, ICovariance2to3, IKeypointSelector, IOptimizer, _is_device)
+
+
+def _num(v) -> bool:
+    return isinstance(v, (int, float))
+
+
+# ----------------------------------------------------------------------------------------------- selectors
+class HIP_CovAwareSelector_NoDepth(IKeypointSelector):
+    """``CovAwareSelector_NoDepth`` (Module/KeypointSelector.py:349-416) on the GPU; bit-exact indices."""
+
+    def select_point(self, frame, numPoint: int, depth0_est, depth1_est, match_est) -> torch.Tensor:
+        dev = torch.device(self.config.device)
+        if match_est is None or match_est.cov is None:
+            return _grid_select(frame, numPoint, self.config.mask_width, dev)      # GridSelector fallback (:365-366)
+        fc = match_est.cov.to(dev)
+        H, W = fc.shape[-2:]
+        mask = None if match_est.mask is None else match_est.mask.to(dev)
+        cands = ops.kp_select("nodepth", H, W, flow_cov=fc, mask_b=mask, kernel_size=self.config.kernel_size,
+                              mask_width=self.config.mask_width, max_match_cov=float(self.config.max_match_cov))
+        return cands.finish(numPoint)
+
+    @classmethod
+    def is_valid_config(cls, config: SimpleNamespace | None) -> None:
+        cls._enforce_config_spec(config, {
+            "device": _is_device,
+            "mask_width": lambda m: isinstance(m, int) and m >= 0,
+            "kernel_size": lambda k: isinstance(k, int) and k > 0 and (k % 2 == 1),
+            "max_match_cov": lambda c: _num(c) and c > 0.0,
+        })
+
+
+class HIP_CovAwareSelector(IKeypointSelector):
+    """``CovAwareSelector`` (Module/KeypointSelector.py:250-346)."""
+
+    def select_point(self, frame, numPoint: int, depth0_est, depth1_est, match_est) -> torch.Tensor:
+        assert depth0_est.cov is not None and depth1_est.cov is not None
+        if self.config.max_depth == "auto":
+            self.config.max_depth = frame.fx * frame.frame_baseline               # written back like the reference
+        dev = torch.device(self.config.device)
+        d0, d0c = depth0_est.depth.to(dev), depth0_est.cov.to(dev)
+        d1, d1c = depth1_est.depth.to(dev), depth1_est.cov.to(dev)
+        fc = match_est.cov.to(dev) if (match_est is not None and match_est.cov is not None) else None
+        H, W = d0.shape[-2:]
+        ma = None if depth0_est.mask is None else depth0_est.mask.to(dev)
+        mb = None if (match_est is None or match_est.mask is None) else match_est.mask.to(dev)
+        cands = ops.kp_select("full", H, W, flow_cov=fc, depth0=d0, depth0_cov=d0c, depth1=d1, depth1_cov=d1c, mask_a=ma,
+                              mask_b=mb, kernel_size=self.config.kernel_size, mask_width=self.config.mask_width,
+                              max_depth=float(self.config.max_depth), max_depth_cov=float(self.config.max_depth_cov),
+                              max_match_cov=float(self.config.max_match_cov))
+        return cands.finish(numPoint)
+
+    @classmethod
+    def is_valid_config(cls, config: SimpleNamespace | None) -> None:
+        assert config is not None
+        cls._enforce_config_spec(config, {
+            "device": _is_device,
+            "mask_width": lambda m: isinstance(m, int) and m >= 0,
+            "max_depth": lambda d: (d == "auto") or (_num(d) and d > 0.0),
+            "kernel_size": lambda k: isinstance(k, int) and k > 0 and (k % 2 == 1),
+            "max_depth_cov": lambda c: _num(c) and c > 0.0,
+            "max_match_cov": lambda c: _num(c) and c > 0.0,
+        })
+
+
+class HIP_MappingPointSelector(IKeypointSelector):
+    """``MappingPointSelector`` (Module/KeypointSelector.py:78-100).  The reference's config has no ``device`` key;
+    the maps' own device is used."""
+
+    def select_point(self, frame, numPoint: int, depth0_est, depth1_est, match_est) -> torch.Tensor:
+        assert depth0_est.cov is not None
+        d0, d0c = depth0_est.depth, depth0_est.cov
+        if not d0.is_cuda:
+            d0, d0c = d0.cuda(), d0c.cuda()
+        H, W = d0.shape[-2:]
+        cands = ops.kp_select("mapping", H, W, depth0=d0, depth0_cov=d0c, mask_width=self.config.mask_width,
+                              max_depth=float(self.config.max_depth), max_depth_cov=float(self.config.max_depth_cov))
+        return cands.finish(numPoint)
+
+    @classmethod
+    def is_valid_config(cls, config: SimpleNamespace | None) -> None:
+        cls._enforce_config_spec(config, {
+            "max_depth": lambda v: isinstance(v, float),
+            "max_depth_cov": lambda v: isinstance(v, float),
+            "mask_width": lambda v: isinstance(v, int),
+        })
+
+
+def _grid_select(frame, numPoint: int, mask_width: int, dev) -> torch.Tensor:
+    """``GridSelector.select_point`` (Module/KeypointSelector.py:222-239) — the NoDepth selector's fallback when the
+    matcher gives no covariance.  Index arithmetic only (no float math), kept in torch."""
+    h, w = frame.height - 2 * mask_width, frame.width - 2 * mask_width
+    unit = max(1, int(math.sqrt(numPoint // 2)))
+    mesh_u, mesh_v = torch.meshgrid(torch.arange(0, h, h // unit, device=dev), torch.arange(0, w, w // (unit * 2), device=dev),
+                                    indexing="ij")
+    return torch.stack([mesh_v.flatten(), mesh_u.flatten()], dim=1) + mask_width
+
+
+# ----------------------------------------------------------------------------------------------- covariance
+class HIP_MatchCovariance(ICovariance2to3):
+    """``MatchCovariance`` (Module/Covariance/Project2to3.py:113-191).  Returns ``[N,3,3]`` float64 on the CPU like the
+    reference (its result is pushed straight into the CPU map, Odometry/MACVO.py:265-266) and clamps the caller's
+    ``flow_cov`` in place (Project2to3.py:131)."""
+
+    def estimate(self, frame, kp, depth_est, depth_cov, flow_cov) -> torch.Tensor:
+        return self.estimate_device(frame, kp, depth_est, depth_cov, flow_cov).cpu()
+
+    def estimate_device(self, frame, kp, depth_est, depth_cov, flow_cov, rot: torch.Tensor | None = None):
+        """Same as :meth:`estimate` but the result stays on the GPU (optionally also ``R cov R^T``)."""
+        dev = torch.device(self.config.device)
+        n = kp.size(0)
+        has_flow_cov = flow_cov is not None
+        if has_flow_cov:
+            work = flow_cov if (flow_cov.is_cuda and flow_cov.dtype == torch.float32 and flow_cov.is_contiguous()) \
+                else flow_cov.to(dev, torch.float32).contiguous()
+        else:
+            work = torch.full((n, 3), float(self.config.match_cov_default), dtype=torch.float32, device=dev)
+            work[:, 2] = 0.0
+        res = ops.match_cov(depth_est.depth.to(dev), kp.to(dev), work, None if depth_cov is None else depth_cov.to(dev),
+                            frame.fx, frame.fy, frame.cx, frame.cy, kernel_size=self.config.kernel_size,
+                            min_flow_cov=self.config.min_flow_cov, min_depth_cov=self.config.min_depth_cov,
+                            use_patch_var=(has_flow_cov or depth_cov is None), rot=rot)
+        if has_flow_cov and work is not flow_cov:
+            flow_cov.copy_(work)                                                   # keep the in-place side effect
+        return res
+
+    @classmethod
+    def is_valid_config(cls, config: SimpleNamespace | None) -> None:
+        cls._enforce_config_spec(config, {
+            "kernel_size": lambda k: isinstance(k, int) and k > 0 and (k % 2 == 1) and k <= 31,
+            "match_cov_default": lambda c: _num(c) and c > 0.0,
+            "min_flow_cov": lambda c: _num(c) and c > 0.0,
+            "min_depth_cov": lambda c: _num(c) and c > 0.0,
+            "device": _is_device,
+        })
+
+
+# ----------------------------------------------------------------------------------------------- optimizer
+def _bundle(x, key):
+    return x.data[key]
+
+
+class HIP_TwoFrame_PGO(IOptimizer[GraphInput, dict, GraphOutput]):
+    """``TwoFrame_PGO`` (Module/Optimization/TwoFramePGO/Optimizer.py:23-108) with the whole LM loop in one HIP launch.
+
+    ``parallel: true`` in the reference means "solve in a spawned CPU process while the GPU runs the next frame's
+    network" (Optimization/Interface.py:80-96).  Here the solve is a GPU kernel, so the overlap comes from a dedicated
+    HIP stream: ``start_optimize`` enqueues upload + solve + download on it and returns; ``write_map`` waits on the
+    completion event.  Results are identical in both modes.
+    """
+
+    def __init__(self, config: SimpleNamespace) -> None:
+        self.config = config
+        self.is_parallel_mode = bool(config.parallel)
+        self.context = self.init_context(config)
+        self.optimize_res = None
+        self.has_opt_job = False
+        self._pending = None
+
+    @staticmethod
+    def init_context(config) -> dict:
+        if config.autodiff:
+            raise ValueError("HIP_TwoFrame_PGO implements the analytic-Jacobian graphs only (autodiff: false)")
+        dev = torch.device("cuda" if config.device == "cpu" else config.device)   # the solve itself always runs on the GPU
+        return {"graph_type": config.graph_type, "device": dev, "lm": ops.lm_default_params(),
+                "stream": torch.cuda.Stream(device=dev) if config.parallel else None}
+
+    @classmethod
+    def is_valid_config(cls, config: SimpleNamespace | None) -> None:
+        cls._enforce_config_spec(config, {
+            "graph_type": lambda s: s in {"icp", "reproj", "disp"},
+            "device": lambda v: isinstance(v, str) and (v == "cpu" or "cuda" in v),
+            "vectorize": lambda b: isinstance(b, bool),
+            "parallel": lambda b: isinstance(b, bool),
+            "autodiff": lambda b: isinstance(b, bool),
+        })
+
+    def get_graph_data(self, global_map, frame_idx, observations=None, edges=None) -> GraphInput:
+        """Same gathers as the reference (Optimizer.py:24-38) through the map's own accessors."""
+        frame2opt = global_map.frames[frame_idx]
+        obs = global_map.get_frame2match(frame2opt)
+        pts = global_map.get_match2point(obs)
+        K = frame2opt.data["K"][0]
+        n = pts.data["pos_Tw"].shape[0]
+        return GraphInput(frame_idx, frame_idx - 1, frame2opt.data["pose"], frame2opt.data["baseline"], obs, pts, K,
+                          torch.zeros(n, dtype=torch.long), "cpu")
+
+    @staticmethod
+    def _launch(context: dict, g: GraphInput):
+        dev = context["device"]
+        obs, pts = g.observations, g.points
+        n = _bundle(pts, "pos_Tw").shape[0]
+        up = lambda t, dt: t.reshape(t.shape[0], -1).to(dev, dt, non_blocking=True).contiguous()  # noqa: E731
+        K = g.images_intrinsic
+        batch = ops.PGOBatch(
+            offsets=torch.tensor([0, n], dtype=torch.int32).to(dev, non_blocking=True),
+            init_pose=torch.as_tensor(g.init_motion).reshape(1, 7).to(dev, torch.float32, non_blocking=True),
+            intrinsics=torch.stack([K[0, 0], K[1, 1], K[0, 2], K[1, 2]]).reshape(1, 4).to(dev, torch.float32, non_blocking=True),
+            baseline=torch.as_tensor(g.baseline).reshape(1).to(dev, torch.float32, non_blocking=True),
+            pos_Tw=up(_bundle(pts, "pos_Tw"), torch.float32), pixel2_uv=up(_bundle(obs, "pixel2_uv"), torch.float32),
+            cov_Tw=up(_bundle(pts, "cov_Tw"), torch.float64), pixel2_d=up(_bundle(obs, "pixel2_d"), torch.float32).reshape(-1),
+            pixel2_disp=up(_bundle(obs, "pixel2_disp"), torch.float32).reshape(-1),
+            pixel2_disp_cov=up(_bundle(obs, "pixel2_disp_cov"), torch.float32).reshape(-1),
+            pixel2_uv_cov=up(_bundle(obs, "pixel2_uv_cov"), torch.float32), obs2_covTc=up(_bundle(obs, "obs2_covTc"), torch.float64))
+        pose, info = ops.pgo_solve(batch, context["graph_type"], context["lm"])
+        host = torch.empty((1, 7), dtype=torch.float64, pin_memory=True)
+        host.copy_(pose, non_blocking=True)
+        return host, info, batch
+
+    @staticmethod
+    def _optimize(context: dict, graph_data: GraphInput):
+        host, _, _keep = HIP_TwoFrame_PGO._launch(context, graph_data)
+        torch.cuda.current_stream().synchronize()
+        return context, GraphOutput(motion=host.clone(), frame_idx=graph_data.frame_idx, from_idx=graph_data.from_idx)
+
+    def start_optimize(self, graph_data: GraphInput) -> None:
+        self.has_opt_job = True
+        if not self.is_parallel_mode:
+            self.context, self.optimize_res = self._optimize(self.context, graph_data)
+            return
+        side = self.context["stream"]
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            host, info, keep = self._launch(self.context, graph_data)
+            done = torch.cuda.Event()
+            done.record(side)
+        self._pending = (host, done, graph_data, keep, info)
+
+    @property
+    def is_running(self) -> bool:
+        return self._pending is not None and not self._pending[1].query()
+
+    def get_result(self):
+        if self._pending is not None:
+            host, done, g, _keep, _ = self._pending
+            done.synchronize()
+            self.optimize_res = GraphOutput(motion=host.clone(), frame_idx=g.frame_idx, from_idx=g.from_idx)
+            self._pending = None
+            self.has_opt_job = False
+        return self.optimize_res
+
+    get_optimal = get_result
+
+    def write_map(self, global_map) -> None:
+        self.write_graph_data(self.get_result(), global_map)
+
+    def write_graph_data(self, result, global_map) -> None:
+        if result is None:
+            return
+        global_map.frames.data["pose"][result.frame_idx] = result.motion[0].double().cpu().float()  # Optimizer.py:104-108
+
+    def terminate(self) -> None:
+        self._pending = None
+
+
+# ----------------------------------------------------------------------------------------------- FlowFormer hooks
+def install_flowformer_hooks(model) -> None:
+    """Route FlowFormerCov's window lookup through the HIP kernel.
+
+    ``MemoryCovDecoder.forward`` calls ``self.encode_flow_token(cost_maps, flow_coords1)`` every decoder iteration
+    (Module/Network/FlowFormerCov/covhead.py:92); replacing that bound method is all it takes — signature and result
+    layout ([B, 81, H1, W1] fp32) are those of the upstream method.  The cost-volume build lives inside the (absent)
+    FlowFormer ``MemoryEncoder``; a maintainer replaces its ``einsum`` with ``ops.corr_volume(feat_s, feat_t)`` as
+    shown in INTEGRATION.md.
+    """
+    dec = model.memory_decoder
+    dec.encode_flow_token = lambda cost_maps, coords: ops.corr_lookup(cost_maps.float(), coords.float(), 4)

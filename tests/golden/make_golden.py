@@ -1,0 +1,249 @@
+#!/usr/bin/env python
+"""Generate golden vectors by RUNNING THE REAL REFERENCE MODULES (build container only: needs /root/reference).
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+What is executed from ``/root/reference`` (unmodified, imported in place):
+  * Module/KeypointSelector.py   CovAwareSelector, CovAwareSelector_NoDepth, MappingPointSelector
+  * Module/Covariance/Project2to3.py   MatchCovariance.estimate, Covariance_2to3_full
+  * Utility/Math.py   gaussain_full_kernels (eager: torch.compile is replaced by identity so results do not depend
+                      on inductor code generation)
+  * Module/Frontend/StereoDepth.py   disparity_to_depth, disparity_to_depth_cov;  Frontend.py retrieve_pixels;
+    Utility/Point.py filterPointsInRange
+  * Module/Optimization/TwoFramePGO/{Graphs,Optimizer}.py + PyposeOptimizers.py   TwoFrame_PGO._optimize with the
+    analytic graphs (icp / reproj / disp) — on top of tests/golden/pypose_shim.py (PyPose itself is not installable)
+
+Third-party packages the reference imports at module scope but that the hot path never calls (cv2, jaxtyping,
+typeguard, yacs, torchvision, evo, rerun, ...) are satisfied by inert placeholder modules.
+The GPU box has no /root/reference: tests only read the .npz files this script writes.
+"""
+from __future__ import annotations
+
+import hashlib
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from tests import synth  # noqa: E402
+from tests.golden import pypose_shim  # noqa: E402
+
+MISSING = {"cv2", "yacs", "evo", "rerun", "torchvision", "timm", "cupy", "xformers", "flow_vis", "h5py", "wandb", "onnx",
+           "tensorrt", "jaxtyping", "typeguard", "onnxruntime", "pycuda", "kornia", "numba", "open3d"}
+
+
+class _Dummy:
+    def __init__(self, *a, **k): pass
+    def __call__(self, *a, **k): return _Dummy()
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return _Dummy()
+    def __getitem__(self, k): return _Dummy()
+    def __class_getitem__(cls, k): return cls
+    def __iter__(self): return iter(())
+
+
+class _Sub:
+    def __getitem__(self, k): return object
+
+
+class _Anything(types.ModuleType):
+    __path__: list = []
+
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return type(k, (_Dummy,), {})
+
+
+class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, name, path, target=None):
+        if name.split(".")[0] in MISSING:
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+
+    def create_module(self, spec):
+        m = _Anything(spec.name)
+        if spec.name == "jaxtyping":
+            for k in ("Float32", "Bool", "Float", "Float64", "Int", "Int64", "UInt8", "Shaped"):
+                setattr(m, k, _Sub())
+            m.jaxtyped = lambda typechecker=None: (lambda c: c)
+        if spec.name == "typeguard":
+            m.typechecked = lambda f: f
+        return m
+
+    def exec_module(self, m):
+        pass
+
+
+def import_reference():
+    sys.meta_path.insert(0, _Finder())
+    pypose_shim.install()
+    torch.compile = lambda f=None, **kw: f  # OnCallCompiler -> eager
+    import Module.KeypointSelector as KS
+    import Module.Covariance.Project2to3 as P23
+    import Module.Frontend.StereoDepth as SD
+    import Module.Frontend.Frontend as FE
+    import Module.Optimization.TwoFramePGO.Optimizer as OPT
+    import Module.Optimization.TwoFramePGO.Graphs as GR
+    import Utility.Math as UM
+    import Utility.Point as UP
+    return SimpleNamespace(KS=KS, P23=P23, SD=SD, FE=FE, OPT=OPT, GR=GR, UM=UM, UP=UP)
+
+
+def sha(*tensors) -> str:
+    h = hashlib.sha256()
+    for t in tensors:
+        h.update(t.contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# ------------------------------------------------------------------------------------------------------------
+def gen_selectors(ref):
+    cases = {}
+    frame = SimpleNamespace(fx=320.0, frame_baseline=0.25, height=0, width=0)
+    # (name, H, W, seeds, nan_frac, store_inputs)
+    for name, H, W, nan_frac, store in (("small", 96, 136, 0.02, True), ("full", 480, 640, 0.003, False)):
+        fc = synth.flow_cov_maps(H, W, seed=2, nan_frac=nan_frac)
+        d0, d0c = synth.depth_maps(H, W, 3)
+        d1, d1c = synth.depth_maps(H, W, 4)
+        match = SimpleNamespace(cov=fc.clone(), mask=None)
+        dep0 = SimpleNamespace(depth=d0, cov=d0c, mask=None)
+        dep1 = SimpleNamespace(depth=d1, cov=d1c, mask=None)
+
+        cfg = SimpleNamespace(device="cpu", mask_width=16 if name == "small" else 32, kernel_size=7, max_match_cov=100.0)
+        sel = ref.KS.CovAwareSelector_NoDepth(cfg)
+        torch.manual_seed(1234)
+        px_nd = sel.select_point(frame, 200, dep0, dep1, match)
+
+        cfg2 = SimpleNamespace(device="cpu", mask_width=cfg.mask_width, max_depth="auto", kernel_size=7, max_depth_cov=250.0,
+                               max_match_cov=100.0)
+        sel2 = ref.KS.CovAwareSelector(cfg2)
+        torch.manual_seed(4321)
+        px_full = sel2.select_point(frame, 200, dep0, dep1, SimpleNamespace(cov=fc.clone(), mask=None))
+
+        cfg3 = SimpleNamespace(max_depth=20.0, max_depth_cov=0.2, mask_width=cfg.mask_width)
+        sel3 = ref.KS.MappingPointSelector(cfg3)
+        torch.manual_seed(7)
+        px_map = sel3.select_point(frame, 300, dep0, dep1, None)
+
+        cases[f"{name}_nodepth_px"] = px_nd
+        cases[f"{name}_full_px"] = px_full
+        cases[f"{name}_mapping_px"] = px_map
+        cases[f"{name}_meta"] = np.array([H, W, cfg.mask_width])
+        cases[f"{name}_sha"] = np.frombuffer(bytes.fromhex(sha(fc, d0, d0c, d1, d1c)), dtype=np.uint8)
+        if store:
+            cases.update({f"{name}_fc": fc, f"{name}_d0": d0, f"{name}_d0c": d0c, f"{name}_d1": d1, f"{name}_d1c": d1c})
+    save("selector", **cases)
+
+
+def gen_covariance(ref):
+    H, W, n = 120, 160, 48
+    depth, dcov = synth.depth_maps(H, W, 3)
+    kp = synth.keypoints(n, H, W, 5, border=20)
+    g = torch.Generator().manual_seed(8)
+    kpf = kp.float() + torch.rand(n, 2, generator=g)
+    fcov = torch.exp(2 * 0.5 * torch.randn(n, 3, generator=g))
+    fcov[:, 2] = 0.2 * torch.randn(n, generator=g) * fcov[:, :2].min(dim=1).values
+    fcov[:4, 0] = 0.01
+    fcov[:4, 2] = 0.0
+    frame = SimpleNamespace(fx=160.0, fy=150.0, cx=80.0, cy=60.0)
+    cfg = SimpleNamespace(kernel_size=31, match_cov_default=0.25, min_flow_cov=0.25, min_depth_cov=0.05, device="cpu")
+    model = ref.P23.MatchCovariance(cfg)
+    dest = SimpleNamespace(depth=depth, cov=dcov)
+    out = {"depth": depth, "dcov": dcov, "kp_int": kp, "kp_float": kpf, "flow_cov_in": fcov.clone(),
+           "K": np.array([frame.fx, frame.fy, frame.cx, frame.cy])}
+    fc1 = fcov.clone()
+    out["cov_int_flowcov"] = model.estimate(frame, kp, dest, None, fc1)           # kp1-style call (flow cov given)
+    out["flow_cov_after"] = fc1                                                      # in-place clamp
+    fc2 = fcov.clone()
+    out["cov_float_flowcov"] = model.estimate(frame, kpf, dest, None, fc2)
+    dc = dcov[0, 0, kp[:, 1], kp[:, 0]].contiguous()
+    out["depth_cov_kp"] = dc
+    out["cov_int_nodefault"] = model.estimate(frame, kp, dest, dc, None)            # flow_cov None -> given depth cov
+    s0 = torch.ones(n, 3) * 0.25
+    s0[:, 2] = 0
+    out["cov_int_default_sigma"] = model.estimate(frame, kp, dest, dc, s0)          # kp0-style call (MACVO.py:241)
+    # building blocks
+    cm = ref.P23.create_2x2_matrix([[fc1[:, 0], fc1[:, 2]], [fc1[:, 2], fc1[:, 1]]], n, torch.device("cpu"))
+    out["gauss_kernels"] = ref.UM.gaussain_full_kernels(cm, 31)[:6]
+    save("covariance", **out)
+
+
+def gen_frontend_bits(ref):
+    g = torch.Generator().manual_seed(21)
+    H, W = 64, 96
+    disp = torch.rand(1, 1, H, W, generator=g) * 40 + 0.5
+    dcov = torch.exp(torch.randn(1, 1, H, W, generator=g))
+    bl, fx = 0.25, 320.0
+    depth = ref.SD.disparity_to_depth(disp, bl, fx)
+    depth_cov = ref.SD.disparity_to_depth_cov(disp, dcov, bl, fx)
+    uv = torch.stack([torch.rand(50, generator=g) * (W - 1), torch.rand(50, generator=g) * (H - 1)], 1)
+    flow = torch.randn(1, 2, H, W, generator=g)
+    got = ref.FE.IFrontend.retrieve_pixels(uv, flow)
+    inr = ref.UP.filterPointsInRange(uv, (8, W - 8), (8, H - 8))
+    save("frontend_bits", disp=disp, dcov=dcov, depth=depth, depth_cov=depth_cov, uv=uv, flow=flow, retrieved=got,
+         in_range=inr, blfx=np.array([bl, fx]))
+
+
+def gen_pgo(ref):
+    """Run the reference's TwoFrame_PGO._optimize (analytic graphs) on seeded problems from oracle.pgo.make_synthetic_problem."""
+    from oracle import pgo as opgo
+
+    # Optimizer.py:83 evaluates torch.cuda.current_stream() even though the (inactive) Timer ignores it; there is
+    # no GPU in the build container, so hand it a placeholder
+    torch.cuda.current_stream = lambda *a, **k: None
+
+    cases = [dict(n=200, seed=6), dict(n=200, seed=7, outlier_frac=0.1), dict(n=37, seed=8),
+             dict(n=120, seed=10, trans_sigma=0.4, rot_sigma=0.08)]
+    out = {}
+    for gi, gname in enumerate(("icp", "reproj", "disp")):
+        cfg = SimpleNamespace(graph_type=gname, device="cpu", vectorize=True, parallel=False, autodiff=False)
+        ctx = ref.OPT.TwoFrame_PGO.init_context(cfg)
+        for ci, c in enumerate(cases):
+            prob, _ = opgo.make_synthetic_problem(**c)
+            obs = SimpleNamespace(data={
+                "pixel2_uv": prob.pixel2_uv, "pixel2_d": prob.pixel2_d, "pixel2_disp": prob.pixel2_disp,
+                "pixel2_disp_cov": prob.pixel2_disp_cov, "pixel2_uv_cov": prob.pixel2_uv_cov, "obs2_covTc": prob.obs2_covTc})
+            pts = SimpleNamespace(data={"pos_Tw": prob.pos_Tw, "cov_Tw": prob.cov_Tw})
+            n = prob.pos_Tw.shape[0]
+            gin = ref.GR.GraphInput(frame_idx=torch.tensor([1]), from_idx=torch.tensor([0]),
+                                    init_motion=pypose_shim.SE3(prob.init_pose.reshape(1, 7).clone()),
+                                    baseline=torch.tensor([prob.baseline], dtype=torch.float32), observations=obs, points=pts,
+                                    images_intrinsic=prob.K, edges_index=torch.zeros(n, dtype=torch.long), device="cpu")
+            _, gout = ref.OPT.TwoFrame_PGO._optimize(ctx, gin)
+            pose = gout.motion.detach().as_subclass(torch.Tensor).reshape(7).double()
+            out[f"{gname}_{ci}_pose"] = pose
+            out[f"{gname}_{ci}_case"] = np.array([c["n"], c["seed"], c.get("outlier_frac", 0.0), c.get("trans_sigma", 0.1), c.get("rot_sigma", 0.02)])
+    save("pgo", **out)
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "make_golden.py must run where /root/reference exists"
+    ref = import_reference()
+    gen_selectors(ref)
+    gen_covariance(ref)
+    gen_frontend_bits(ref)
+    gen_pgo(ref)

@@ -1,0 +1,67 @@
+"""GPU: HIP path vs golden vectors produced by the REAL reference modules (tests/golden/*.npz)."""
+import pytest
+import torch
+
+from tests.test_oracle_golden import _sel_inputs, load
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["small", "full"])
+def test_selectors_vs_reference_golden(gpu, name):
+    from macvo_amd import ops
+
+    z = load("selector")
+    H, W, mw, fc, d0, d0c, d1, d1c = _sel_inputs(z, name)
+    dv = lambda t: t.to(gpu)  # noqa: E731
+    torch.manual_seed(1234)
+    px = ops.kp_select("nodepth", H, W, flow_cov=dv(fc), kernel_size=7, mask_width=mw, max_match_cov=100.0).finish(200)
+    assert torch.equal(px.cpu(), z[f"{name}_nodepth_px"])
+    torch.manual_seed(4321)
+    px = ops.kp_select("full", H, W, flow_cov=dv(fc), depth0=dv(d0), depth0_cov=dv(d0c), depth1=dv(d1), depth1_cov=dv(d1c),
+                       kernel_size=7, mask_width=mw, max_depth=320.0 * 0.25, max_depth_cov=250.0, max_match_cov=100.0).finish(200)
+    assert torch.equal(px.cpu(), z[f"{name}_full_px"])
+    torch.manual_seed(7)
+    px = ops.kp_select("mapping", H, W, depth0=dv(d0), depth0_cov=dv(d0c), mask_width=mw, max_depth=20.0, max_depth_cov=0.2).finish(300)
+    assert torch.equal(px.cpu(), z[f"{name}_mapping_px"])
+
+
+def test_covariance_vs_reference_golden(gpu):
+    from macvo_amd import ops
+
+    z = load("covariance")
+    K = [float(v) for v in z["K"]]
+    depth = z["depth"].to(gpu)
+    fc = z["flow_cov_in"].clone().to(gpu)
+    out = ops.match_cov(depth, z["kp_int"].to(gpu), fc, None, *K)
+    assert torch.equal(fc.cpu(), z["flow_cov_after"])                         # in-place clamp, bit-exact
+    torch.testing.assert_close(out.cpu(), z["cov_int_flowcov"], rtol=2e-3, atol=1e-7)
+    out = ops.match_cov(depth, z["kp_float"].to(gpu), z["flow_cov_in"].clone().to(gpu), None, *K)
+    torch.testing.assert_close(out.cpu(), z["cov_float_flowcov"], rtol=2e-3, atol=1e-7)
+    s0 = torch.ones(z["kp_int"].shape[0], 3) * 0.25
+    s0[:, 2] = 0
+    out = ops.match_cov(depth, z["kp_int"].to(gpu), s0.to(gpu), z["depth_cov_kp"].to(gpu), *K, use_patch_var=True)
+    torch.testing.assert_close(out.cpu(), z["cov_int_default_sigma"], rtol=2e-3, atol=1e-7)
+    out = ops.match_cov(depth, z["kp_int"].to(gpu), s0.to(gpu), z["depth_cov_kp"].to(gpu), *K, use_patch_var=False)
+    torch.testing.assert_close(out.cpu(), z["cov_int_nodefault"], rtol=2e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("graph", ["icp", "reproj", "disp"])
+def test_pgo_vs_reference_golden(gpu, graph):
+    from macvo_amd import ops
+    from oracle import pgo, se3
+    from tests.test_gpu_backend import _to_batch
+
+    z = load("pgo")
+    probs, refs = [], []
+    ci = 0
+    while f"{graph}_{ci}_pose" in z:
+        n, seed, of, ts, rs = [float(v) for v in z[f"{graph}_{ci}_case"]]
+        probs.append(pgo.make_synthetic_problem(n=int(n), seed=int(seed), outlier_frac=of, trans_sigma=ts, rot_sigma=rs)[0])
+        refs.append(z[f"{graph}_{ci}_pose"])
+        ci += 1
+    pose, _ = ops.pgo_solve(_to_batch(probs, gpu), graph)
+    for k, ref in enumerate(refs):
+        dt, dr = se3.pose_error(ref, pose[k].cpu())
+        assert dt <= 1e-4 and dr <= 1e-4, (k, dt, dr)      # north_star tolerance
+        assert dt <= 1e-8 and dr <= 1e-8, (k, dt, dr)      # what is actually achieved

@@ -1,0 +1,94 @@
+"""CPU: pin the oracle (oracle/*.py) against golden vectors produced by the REAL reference modules
+(tests/golden/make_golden.py ran Module/KeypointSelector.py, Module/Covariance/Project2to3.py, Utility/Math.py,
+Module/Frontend/StereoDepth.py and Module/Optimization/TwoFramePGO/* from /root/reference in the build container)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import covariance, frontend, pgo, se3, selector
+from tests import synth
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return {k: torch.from_numpy(v) if v.dtype != np.uint8 or k.endswith("_px") else v for k, v in np.load(os.path.join(G, name + ".npz")).items()}
+
+
+def _sel_inputs(z, name):
+    H, W, mw = [int(v) for v in z[f"{name}_meta"]]
+    if f"{name}_fc" in z:
+        fc, d0, d0c, d1, d1c = (z[f"{name}_{k}"] for k in ("fc", "d0", "d0c", "d1", "d1c"))
+    else:  # regenerate from the seeds and check the checksum recorded at golden time
+        fc = synth.flow_cov_maps(H, W, seed=2, nan_frac=0.003)
+        d0, d0c = synth.depth_maps(H, W, 3)
+        d1, d1c = synth.depth_maps(H, W, 4)
+        h = hashlib.sha256()
+        for t in (fc, d0, d0c, d1, d1c):
+            h.update(t.contiguous().numpy().tobytes())
+        if h.digest() != bytes(np.asarray(z[f"{name}_sha"]).tobytes()):
+            pytest.skip("seeded inputs differ from the ones the golden was generated with (torch RNG changed)")
+    return H, W, mw, fc, d0, d0c, d1, d1c
+
+
+@pytest.mark.parametrize("name", ["small", "full"])
+def test_selectors_match_reference(name):
+    z = load("selector")
+    H, W, mw, fc, d0, d0c, d1, d1c = _sel_inputs(z, name)
+    torch.manual_seed(1234)
+    px, _, _ = selector.cov_aware_selector_nodepth(fc.clone(), 200, 7, mw, 100.0)
+    assert torch.equal(px, z[f"{name}_nodepth_px"])
+    torch.manual_seed(4321)
+    px, _, _ = selector.cov_aware_selector(d0, d0c, d1, d1c, fc.clone(), 200, 320.0 * 0.25, 7, mw, 250.0, 100.0)
+    assert torch.equal(px, z[f"{name}_full_px"])
+    torch.manual_seed(7)
+    px, _, _ = selector.mapping_point_selector(d0, d0c, 300, 20.0, 0.2, mw)
+    assert torch.equal(px, z[f"{name}_mapping_px"])
+
+
+def test_covariance_matches_reference():
+    z = load("covariance")
+    K = [float(v) for v in z["K"]]
+    depth = z["depth"]
+    fc = z["flow_cov_in"].clone()
+    out = covariance.match_covariance(z["kp_int"], depth, None, fc, *K)
+    assert torch.equal(out, z["cov_int_flowcov"]) and torch.equal(fc, z["flow_cov_after"])
+    out = covariance.match_covariance(z["kp_float"], depth, None, z["flow_cov_in"].clone(), *K)
+    assert torch.equal(out, z["cov_float_flowcov"])
+    out = covariance.match_covariance(z["kp_int"], depth, z["depth_cov_kp"], None, *K)
+    assert torch.equal(out, z["cov_int_nodefault"])
+    s0 = torch.ones(z["kp_int"].shape[0], 3) * 0.25
+    s0[:, 2] = 0
+    out = covariance.match_covariance(z["kp_int"], depth, z["depth_cov_kp"], s0, *K)
+    assert torch.equal(out, z["cov_int_default_sigma"])
+    fa = z["flow_cov_after"]
+    cm = covariance.create_2x2_matrix([[fa[:, 0], fa[:, 2]], [fa[:, 2], fa[:, 1]]], fa.shape[0], "cpu")
+    assert torch.equal(covariance.gaussain_full_kernels(cm, 31)[:6], z["gauss_kernels"])
+
+
+def test_frontend_bits_match_reference():
+    z = load("frontend_bits")
+    bl, fx = [float(v) for v in z["blfx"]]
+    assert torch.equal(frontend.disparity_to_depth(z["disp"], bl, fx), z["depth"])
+    assert torch.equal(frontend.disparity_to_depth_cov(z["disp"], z["dcov"], bl, fx), z["depth_cov"])
+    assert torch.equal(frontend.retrieve_pixels(z["uv"], z["flow"]), z["retrieved"])
+    H, W = z["flow"].shape[-2:]
+    assert torch.equal(frontend.filterPointsInRange(z["uv"], (8, W - 8), (8, H - 8)), z["in_range"].bool())
+
+
+@pytest.mark.parametrize("graph", ["icp", "reproj", "disp"])
+def test_pgo_matches_reference_in_tree_code(graph):
+    """Reference Graphs.py + LM_analytic.step + _optimize executed on the PyPose shim vs oracle.pgo.solve."""
+    z = load("pgo")
+    ci = 0
+    while f"{graph}_{ci}_pose" in z:
+        n, seed, of, ts, rs = [float(v) for v in z[f"{graph}_{ci}_case"]]
+        prob, _ = pgo.make_synthetic_problem(n=int(n), seed=int(seed), outlier_frac=of, trans_sigma=ts, rot_sigma=rs)
+        res = pgo.solve(prob, graph)
+        dt, dr = se3.pose_error(z[f"{graph}_{ci}_pose"], res.pose)
+        assert dt < 1e-9 and dr < 1e-9, (graph, ci, dt, dr)
+        ci += 1
+    assert ci >= 4
