@@ -19,20 +19,21 @@
 
 namespace {
 
-template <int R>
-__global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restrict__ vol,
+template <int R, int QPW>
+__global__ __launch_bounds__(64 * (32 / QPW)) void corr_lookup_kernel(const float* __restrict__ vol,
                                                            const float* __restrict__ coords,
                                                            float* __restrict__ out, int N1, int H2, int W2) {
     constexpr int K = 2 * R + 1;
     constexpr int KK = K * K;
     constexpr int BS = K + 3;            // staged block edge (12 for r = 4)
     constexpr int CELLS = BS * BS;       // 144
-    constexpr int QPW = 8;               // queries per wave
-    constexpr int QPB = 32;              // queries per workgroup
+    constexpr int QPB = 32;              // queries per workgroup (one 128-B output segment per channel)
+    constexpr int NWAVE = QPB / QPW;     // waves per workgroup, QPW queries each
+    constexpr int NTHR = 64 * NWAVE;
     constexpr int NLOAD = (QPW * CELLS + 63) / 64;  // 18 wave-wide loads
     constexpr int TAP_ROUNDS = (KK + 63) / 64;      // 2 for r = 4
 
-    __shared__ float blk[4][QPW * CELLS + 64];
+    __shared__ float blk[NWAVE][QPW * CELLS + 64];
     __shared__ float outs[KK][QPB + 1];
 
     const int b = blockIdx.y;
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
     const int slice = H2 * W2;
 
     // lane s < 8 owns query s of this wave: load its coords, derive the block origin
-    const int qmine = q0 + wave * QPW + (lane & 7);
+    const int qmine = q0 + wave * QPW + (lane & (QPW - 1));
     const bool qvalid = qmine < N1;
     float x = 0.f, y = 0.f;
     if (qvalid) {
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
         const int s = idx / CELLS;
         const int c = idx - s * CELLS;
         const int cy = c / BS, cx = c - cy * BS;
-        const int sbx = __shfl(bx, s & 7, 64), sby = __shfl(by, s & 7, 64);
+        const int sbx = __shfl(bx, s & (QPW - 1), 64), sby = __shfl(by, s & (QPW - 1), 64);
         const int q = q0 + wave * QPW + s;
         const int gx = sbx + cx, gy = sby + cy;
         const bool ok = (s < QPW) && (q < N1) && gx >= 0 && gx < W2 && gy >= 0 && gy < H2;
@@ -112,13 +113,25 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
     __syncthreads();
 
     // ---- transposed store: each channel row = 32 consecutive queries (128 B)
-    for (int idx = t; idx < KK * QPB; idx += 256) {
+    for (int idx = t; idx < KK * QPB; idx += NTHR) {
         const int k = idx >> 5, c = idx & 31;
         if (q0 + c < N1) out[((size_t)b * KK + k) * N1 + q0 + c] = outs[k][c];
     }
 }
 
 }  // namespace
+
+// queries-per-launch at or below which the 16-wave variant is used; MV_LOOKUP_SMALL=<n> overrides it for A/B runs
+// (tools/kernel_bench.py), e.g. 0 forces the 4-wave variant
+#include <stdlib.h>
+static int lookup_small_threshold() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MV_LOOKUP_SMALL");
+        v = e ? atoi(e) : 65536;
+    }
+    return v;
+}
 
 extern "C" int mv_corr_lookup(const float* vol, const float* coords, float* out, int B, int H1, int W1,
                               int H2, int W2, int radius, mvStream_t stream) {
@@ -127,13 +140,22 @@ extern "C" int mv_corr_lookup(const float* vol, const float* coords, float* out,
     if (radius < 1 || radius > 4) return MV_ERR_UNSUPPORTED;
     if (B > 65535) return MV_ERR_UNSUPPORTED;
     const int N1 = H1 * W1;
-    dim3 grid(mv_ceil_div(N1, 32), B), block(256);
+    dim3 grid(mv_ceil_div(N1, 32), B);
     hipStream_t s = (hipStream_t)stream;
+    // small launches (one frame: ~300 workgroups for 256 CUs) are latency-bound -> spread a workgroup's 32 queries
+    // over 16 waves; large batches are throughput-bound -> 8 queries per wave amortise the per-wave setup
+    const bool small = (size_t)B * N1 <= (size_t)lookup_small_threshold();
+#define MV_LOOKUP(R)                                                                                                  \
+    if (small)                                                                                                        \
+        hipLaunchKernelGGL((corr_lookup_kernel<R, 2>), grid, dim3(1024), 0, s, vol, coords, out, N1, H2, W2);         \
+    else                                                                                                              \
+        hipLaunchKernelGGL((corr_lookup_kernel<R, 8>), grid, dim3(256), 0, s, vol, coords, out, N1, H2, W2)
     switch (radius) {
-        case 1: hipLaunchKernelGGL(corr_lookup_kernel<1>, grid, block, 0, s, vol, coords, out, N1, H2, W2); break;
-        case 2: hipLaunchKernelGGL(corr_lookup_kernel<2>, grid, block, 0, s, vol, coords, out, N1, H2, W2); break;
-        case 3: hipLaunchKernelGGL(corr_lookup_kernel<3>, grid, block, 0, s, vol, coords, out, N1, H2, W2); break;
-        default: hipLaunchKernelGGL(corr_lookup_kernel<4>, grid, block, 0, s, vol, coords, out, N1, H2, W2); break;
+        case 1: MV_LOOKUP(1); break;
+        case 2: MV_LOOKUP(2); break;
+        case 3: MV_LOOKUP(3); break;
+        default: MV_LOOKUP(4); break;
     }
+#undef MV_LOOKUP
     return mv_launch_status();
 }

@@ -13,6 +13,7 @@
 //     double-buffered LDS, register-staged global prefetch.
 //   * stores: each v_mfma C register row is 32 consecutive floats (128 B line) per half-wave.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -27,9 +28,14 @@ constexpr int BN = 128;
 
 // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8); give each XCD a
 // contiguous band of tile rows so the f1 row-band and the streamed f2 tiles stay in that XCD's L2.
-__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int& tm, int& tn) {
+__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int& tm, int& tn, bool remap = true) {
     const int nwg = tiles_m * tiles_n;
     const int id = blockIdx.x;
+    if (!remap) {
+        tm = id / tiles_n;
+        tn = id - tm * tiles_n;
+        return;
+    }
     const int xcd = id & 7;
     const int q = nwg >> 3, r = nwg & 7;
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
@@ -38,20 +44,87 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int& tm, i
     tn = lin - tm * tiles_n;
 }
 
+
+// ---- shared pieces of the fp32 kernels -----------------------------------------------------------------
+// One K-tile (BK k values) of the 64x64 per-wave product from K-major LDS tiles sA/sB ([BK][LD] floats).
+// Fragments of k-pair kk+2 are fetched before the MFMAs of k-pair kk are issued, so the LDS latency sits
+// under 4 x 64 cycles of matrix work instead of in front of it.
+template <int BK, int LD>
+__device__ __forceinline__ void mfma_tile_f32(const float (*__restrict__ sA)[LD], const float (*__restrict__ sB)[LD],
+                                              int rowA, int rowB, int kh, f32x16 (&acc)[2][2]) {
+    float a[2][2], b[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a[0][i] = sA[kh][rowA + i * 32];
+        b[0][i] = sB[kh][rowB + i * 32];
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+        const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+        if (kk + 2 < BK) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[nxt][i] = sA[kk + 2 + kh][rowA + i * 32];
+                b[nxt][i] = sB[kk + 2 + kh][rowB + i * 32];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (hipcc otherwise sinks it back)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Interior tiles take the
+// unguarded path (one branch per workgroup instead of one per element).
+template <bool NT = true>
+__device__ __forceinline__ void store_tile(float* __restrict__ O, const f32x16 (&acc)[2][2], int row0, int col0,
+                                           int kh, int li, int N1, int N2, bool interior) {
+    if (interior) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* p = O + (size_t)(row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * N2 + col0 + li;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (NT) __builtin_nontemporal_store(acc[i][j][r], p + j * 32);
+                    else p[j * 32] = acc[i][j][r];
+                }
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < N1) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int col = col0 + j * 32 + li;
+                        if (col < N2) __builtin_nontemporal_store(acc[i][j][r], &O[(size_t)row * N2 + col]);
+                    }
+                }
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // fp32, CHW ([C][N]) operands.  BK = 16.
 // ------------------------------------------------------------------------------------------------
-template <bool VEC4>
+template <bool VEC4, int BK = 16, bool REMAP = true, bool NT = true, int ABLATE = 0>
 __global__ __launch_bounds__(256) void corr_volume_f32_chw(const float* __restrict__ f1,
                                                             const float* __restrict__ f2,
                                                             float* __restrict__ out, int C, int N1, int N2,
                                                             int tiles_m, int tiles_n) {
-    constexpr int BK = 16;
     __shared__ __attribute__((aligned(16))) float sA[2][BK][BM];
     __shared__ __attribute__((aligned(16))) float sB[2][BK][BN];
 
     int tm, tn;
-    tile_coords(tiles_m, tiles_n, tm, tn);
+    tile_coords(tiles_m, tiles_n, tm, tn, REMAP);
     const int b = blockIdx.z;
     const int m0 = tm * BM, n0 = tn * BN;
     const float* A = f1 + (size_t)b * C * N1;
@@ -61,14 +134,15 @@ __global__ __launch_bounds__(256) void corr_volume_f32_chw(const float* __restri
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // loader mapping: 16 rows x 128 cols per operand = 512 float4; thread t takes (row = t/32 + 8*p, col4 = (t%32)*4)
+    // loader mapping: BK rows x 128 cols per operand = BK*32 float4; thread t takes (row = t/32 + 8*p, col4 = (t%32)*4)
     const int lrow = t >> 5;
     const int lcol = (t & 31) * 4;
+    constexpr int NP = BK / 8;
 
-    f32x4 ra[2], rb[2];
+    f32x4 ra[NP], rb[NP];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const int k = k0 + lrow + 8 * p;
             const float* pa = A + (size_t)k * N1 + m0 + lcol;
             const float* pb = Bp + (size_t)k * N2 + n0 + lcol;
@@ -86,7 +160,7 @@ __global__ __launch_bounds__(256) void corr_volume_f32_chw(const float* __restri
     };
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < NP; ++p) {
             *reinterpret_cast<f32x4*>(&sA[buf][lrow + 8 * p][lcol]) = ra[p];
             *reinterpret_cast<f32x4*>(&sB[buf][lrow + 8 * p][lcol]) = rb[p];
         }
@@ -109,42 +183,21 @@ __global__ __launch_bounds__(256) void corr_volume_f32_chw(const float* __restri
     const int li = lane & 31;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * BK);
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float a[2], bb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = sA[buf][kk + kh][wm * 64 + i * 32 + li];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bb[j] = sB[buf][kk + kh][wn * 64 + j * 32 + li];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
+        if (ABLATE != 1 && kt + 1 < nk) gload((kt + 1) * BK);
+        mfma_tile_f32<BK, BM>(sA[buf], sB[buf], wm * 64 + li, wn * 64 + li, kh, acc);
+        if (ABLATE != 1 && kt + 1 < nk) {
             sstore(buf ^ 1);
             __syncthreads();
         }
     }
-
-    // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* O = out + (size_t)b * N1 * N2;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (row < N1) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = n0 + wn * 64 + j * 32 + li;
-                    if (col < N2) __builtin_nontemporal_store(acc[i][j][r], &O[(size_t)row * N2 + col]);
-                }
-            }
-        }
+    const bool interior = (m0 + BM <= N1) && (n0 + BN <= N2);
+    if (ABLATE == 2) {  // keep acc live, store one value per lane
+        float sum = 0.f;
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+        out[(size_t)b * N1 * N2 + (size_t)(m0 + wm * 64 + (lane >> 5)) * N2 + n0 + wn * 64 + li] = sum;
+        return;
     }
+    store_tile<NT>(out + (size_t)b * N1 * N2, acc, m0 + wm * 64, n0 + wn * 64, kh, li, N1, N2, interior);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -209,38 +262,14 @@ __global__ __launch_bounds__(256) void corr_volume_f32_hwc(const float* __restri
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload((kt + 1) * BK);
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float a[2], bb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = sA[buf][kk + kh][wm * 64 + i * 32 + li];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bb[j] = sB[buf][kk + kh][wn * 64 + j * 32 + li];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
-        }
+        mfma_tile_f32<BK, LD>(sA[buf], sB[buf], wm * 64 + li, wn * 64 + li, kh, acc);
         if (kt + 1 < nk) {
             sstore(buf ^ 1);
             __syncthreads();
         }
     }
-    float* O = out + (size_t)b * N1 * N2;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (row < N1) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = n0 + wn * 64 + j * 32 + li;
-                    if (col < N2) __builtin_nontemporal_store(acc[i][j][r], &O[(size_t)row * N2 + col]);
-                }
-            }
-        }
+    const bool interior = (m0 + BM <= N1) && (n0 + BN <= N2);
+    store_tile(out + (size_t)b * N1 * N2, acc, m0 + wm * 64, n0 + wn * 64, kh, li, N1, N2, interior);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -337,20 +366,8 @@ __global__ __launch_bounds__(256) void corr_volume_h_hwc(const uint16_t* __restr
             __syncthreads();
         }
     }
-    float* O = out + (size_t)b * N1 * N2;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (row < N1) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = n0 + wn * 64 + j * 32 + li;
-                    if (col < N2) __builtin_nontemporal_store(acc[i][j][r], &O[(size_t)row * N2 + col]);
-                }
-            }
-        }
+    const bool interior = (m0 + BM <= N1) && (n0 + BN <= N2);
+    store_tile(out + (size_t)b * N1 * N2, acc, m0 + wm * 64, n0 + wn * 64, kh, li, N1, N2, interior);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -455,20 +472,8 @@ __global__ __launch_bounds__(256) void corr_volume_h_chw(const uint16_t* __restr
             __syncthreads();
         }
     }
-    float* O = out + (size_t)b * N1 * N2;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (row < N1) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = n0 + wn * 64 + j * 32 + li;
-                    if (col < N2) __builtin_nontemporal_store(acc[i][j][r], &O[(size_t)row * N2 + col]);
-                }
-            }
-        }
+    const bool interior = (m0 + BM <= N1) && (n0 + BN <= N2);
+    store_tile(out + (size_t)b * N1 * N2, acc, m0 + wm * 64, n0 + wn * 64, kh, li, N1, N2, interior);
 }
 
 }  // namespace
@@ -488,7 +493,21 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
         const float* a = (const float*)f1;
         const float* b = (const float*)f2;
         if (layout == MV_LAYOUT_CHW) {
-            if ((N1 % 4 == 0) && (N2 % 4 == 0))
+            static int variant = -1;
+            if (variant < 0) { const char* e = getenv("MV_VOL_VARIANT"); variant = e ? atoi(e) : 0; }
+            if ((N1 % 4 == 0) && (N2 % 4 == 0) && variant == 1 && C % 32 == 0)
+                hipLaunchKernelGGL((corr_volume_f32_chw<true, 32>), grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
+            else if ((N1 % 4 == 0) && (N2 % 4 == 0) && variant == 2)
+                hipLaunchKernelGGL((corr_volume_f32_chw<true, 16, false>), grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
+            else if ((N1 % 4 == 0) && (N2 % 4 == 0) && variant == 3)
+                hipLaunchKernelGGL((corr_volume_f32_chw<true, 16, true, false>), grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
+            else if ((N1 % 4 == 0) && (N2 % 4 == 0) && variant == 4)
+                hipLaunchKernelGGL((corr_volume_f32_chw<true, 8>), grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
+            else if ((N1 % 4 == 0) && (N2 % 4 == 0) && variant == 5)
+                hipLaunchKernelGGL((corr_volume_f32_chw<true, 16, true, true, 1>), grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
+            else if ((N1 % 4 == 0) && (N2 % 4 == 0) && variant == 6)
+                hipLaunchKernelGGL((corr_volume_f32_chw<true, 16, true, true, 2>), grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
+            else if ((N1 % 4 == 0) && (N2 % 4 == 0))
                 hipLaunchKernelGGL(corr_volume_f32_chw<true>, grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
             else
                 hipLaunchKernelGGL(corr_volume_f32_chw<false>, grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);

@@ -8,13 +8,17 @@
 // -> optional validity masks -> torch.nonzero row-major candidate order.
 // The host keeps torch.randperm (global CPU generator) so selected indices are bit-exact.
 //
-// gfx950 design (HBM-bound at ~4-9 MB/frame, in practice launch/latency-bound):
-//   kernel 1 (grid of 64x16 tiles): quality tile + halo in LDS, NMS, one 64-bit __ballot word per
-//            64-pixel row segment (coalesced 8-B stores) for `nms` and for the threshold-independent
-//            part of the mask; the median populations are appended with one wave-aggregated atomic.
-//   kernel 2 (one 1024-thread workgroup): 4-pass 8-bit radix select (LDS histograms) for the lower
-//            median(s), thresholds, then an ordered stream compaction of the bit words
-//            (per-thread popcount -> workgroup exclusive scan -> in-order writes).
+// gfx950 design (4-9 MB of HBM traffic per frame; in practice launch/latency-bound, so: few launches, no
+// sparse gathers on the single-workgroup stage, one atomic per workgroup)
+//   kernel 1 (grid of 64x16 tiles, 256 threads): quality tile + halo in LDS, SEPARABLE NaN-propagating min
+//            (k + k LDS reads per pixel instead of k*k), equality test, one 64-bit __ballot word per 64-pixel row
+//            segment for the threshold-independent part of the mask.  Every NMS pixel also emits a 12-byte record
+//            {linear index | candidate flag, flow quality, depth0 variance}; a workgroup reserves its record range
+//            with ONE global atomic (LDS-aggregated), so there is no hot counter.
+//   kernel 2 (one 1024-thread workgroup, all accesses coalesced): lower (nan)median(s) of the record values by a
+//            3-pass 11/11/10-bit radix select with LDS histograms and a parallel bin search; thresholds; records
+//            failing a threshold clear their bit (atomicAnd); ordered stream compaction of the bit words
+//            (popcount -> workgroup scan -> in-order writes).
 // No host synchronisation inside; the caller reads back out_count when it needs n for randperm.
 #include "common.h"
 #include <math.h>
@@ -24,13 +28,14 @@ namespace {
 constexpr int TILE_W = 64;
 constexpr int TILE_H = 16;
 constexpr int MAX_R = 7;
+constexpr unsigned CAND_FLAG = 0x80000000u;
 
 struct KpWs {
-    unsigned long long* nms_bits;
     unsigned long long* cand_bits;
-    float* pop_a;   // flow-quality population  (q[nms])
-    float* pop_b;   // depth0_cov population    (depth0_cov[nms])
-    int* counters;  // [0] = population size
+    unsigned* rec_idx;  // linear index | CAND_FLAG
+    float* rec_q;       // flow quality of the NMS pixel      (population of the flow-cov median)
+    float* rec_d;       // depth0 variance of the NMS pixel   (population of the depth-cov median, FULL only)
+    int* counters;      // [0] = number of records (= NMS pixels)
 };
 
 __device__ __forceinline__ float flow_quality(const float* __restrict__ fc, int plane, int idx) {
@@ -39,13 +44,8 @@ __device__ __forceinline__ float flow_quality(const float* __restrict__ fc, int 
     return (c0 + c1) - 2.f * c2;
 }
 
-__device__ __forceinline__ float quality_at(int mode, const float* __restrict__ fc, const float* __restrict__ d0c,
-                                            const float* __restrict__ d1c, int plane, int idx) {
-    if (mode == MV_KP_NODEPTH) return flow_quality(fc, plane, idx);
-    float q = d0c[idx] + d1c[idx];
-    if (fc) q = q * flow_quality(fc, plane, idx);
-    return q;
-}
+// min that propagates NaN from either side (max_pool2d keeps a NaN once seen)
+__device__ __forceinline__ float nanmin(float a, float b) { return (a < b || a != a) ? a : b; }
 
 __global__ __launch_bounds__(256) void kp_nms_kernel(const float* __restrict__ fc, const float* __restrict__ d0,
                                                       const float* __restrict__ d0c, const float* __restrict__ d1,
@@ -54,12 +54,15 @@ __global__ __launch_bounds__(256) void kp_nms_kernel(const float* __restrict__ f
                                                       const uint8_t* __restrict__ mask_b, mvKpSelectParams p,
                                                       KpWs ws, int words_per_row) {
     __shared__ float tile[TILE_H + 2 * MAX_R][TILE_W + 2 * MAX_R + 1];
+    __shared__ float hmin[TILE_H + 2 * MAX_R][TILE_W + 1];
+    __shared__ int wg_count, wg_base;
     const int H = p.H, W = p.W, plane = H * W;
     const int r = p.kernel_size >> 1;
     const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
     const int tx = threadIdx.x, ty = threadIdx.y;  // tx = lane (0..63), ty = wave (0..3)
     const int tid = ty * 64 + tx;
     const bool mapping = p.mode == MV_KP_MAPPING;
+    if (tid == 0) wg_count = 0;
 
     if (!mapping) {
         const int tw = TILE_W + 2 * r, th = TILE_H + 2 * r;
@@ -67,12 +70,32 @@ __global__ __launch_bounds__(256) void kp_nms_kernel(const float* __restrict__ f
             const int ly = e / tw, lx = e - ly * tw;
             const int gx = x0 + lx - r, gy = y0 + ly - r;
             float q = INFINITY;  // out-of-image == -inf padding of max_pool2d(-q): never the minimum
-            if (gx >= 0 && gx < W && gy >= 0 && gy < H) q = quality_at(p.mode, fc, d0c, d1c, plane, gy * W + gx);
+            if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
+                const int idx = gy * W + gx;
+                if (p.mode == MV_KP_NODEPTH) {
+                    q = flow_quality(fc, plane, idx);
+                } else {
+                    q = d0c[idx] + d1c[idx];
+                    if (fc) q = q * flow_quality(fc, plane, idx);
+                }
+            }
             tile[ly][lx] = q;
         }
         __syncthreads();
+        // horizontal pass: hmin[ly][x] = nanmin over tile[ly][x .. x+2r]
+        for (int e = tid; e < th * TILE_W; e += 256) {
+            const int ly = e >> 6, lx = e & 63;
+            float m = tile[ly][lx];
+            for (int dx = 1; dx <= 2 * r; ++dx) m = nanmin(m, tile[ly][lx + dx]);
+            hmin[ly][lx] = m;
+        }
     }
+    __syncthreads();
 
+    bool nms_px[TILE_H / 4];
+    bool cand_px[TILE_H / 4];
+    float q_px[TILE_H / 4];
+    int my_nms = 0;
 #pragma unroll
     for (int it = 0; it < TILE_H / 4; ++it) {
         const int ly = ty * (TILE_H / 4) + it;
@@ -88,42 +111,44 @@ __global__ __launch_bounds__(256) void kp_nms_kernel(const float* __restrict__ f
                 cand = border && (d0[idx] < p.max_depth) && (d0c[idx] < p.max_depth_cov);
             } else {
                 q = tile[ly + r][tx + r];
-                float m = INFINITY;
-                bool has_nan = false;
-                for (int dy = 0; dy <= 2 * r; ++dy)
-                    for (int dx = 0; dx <= 2 * r; ++dx) {
-                        const float v = tile[ly + dy][tx + dx];
-                        has_nan |= (v != v);
-                        m = fminf(m, v);
-                    }
-                nms = !has_nan && (q == m);  // q NaN => has_nan
+                float m = hmin[ly][tx];
+                for (int dy = 1; dy <= 2 * r; ++dy) m = nanmin(m, hmin[ly + dy][tx]);
+                nms = (q == m);  // false whenever the window holds a NaN (m is NaN then) or q itself is NaN
                 cand = nms && border;
                 if (cand && p.mode == MV_KP_FULL) cand = (d0[idx] < p.max_depth) && (d1[idx] < p.max_depth);
             }
             if (cand && mask_a) cand = mask_a[idx] != 0;
             if (cand && mask_b) cand = mask_b[idx] != 0;
         }
-        const unsigned long long nms_word = __ballot(nms);
         const unsigned long long cand_word = __ballot(cand);
-        if (tx == 0 && gy < H) {
-            ws.nms_bits[(size_t)gy * words_per_row + blockIdx.x] = nms_word;
-            ws.cand_bits[(size_t)gy * words_per_row + blockIdx.x] = cand_word;
-        }
-        if (!mapping && nms_word) {
-            // wave-aggregated append of the median population(s); order is irrelevant for a median
-            const int cnt = __popcll(nms_word);
-            int base = 0;
-            if (tx == 0) base = atomicAdd(&ws.counters[0], cnt);
-            base = __shfl(base, 0, 64);
-            if (nms) {
-                const int rank = __popcll(nms_word & ((1ull << tx) - 1ull));
-                if (p.mode == MV_KP_NODEPTH) {
-                    ws.pop_a[base + rank] = q;
-                } else {
-                    if (fc) ws.pop_a[base + rank] = flow_quality(fc, plane, idx);
-                    ws.pop_b[base + rank] = d0c[idx];
-                }
+        if (tx == 0 && gy < H) ws.cand_bits[(size_t)gy * words_per_row + blockIdx.x] = cand_word;
+        nms_px[it] = nms;
+        cand_px[it] = cand;
+        q_px[it] = q;
+        my_nms += nms;
+    }
+    if (mapping) return;
+
+    // ---- records: LDS-aggregated reservation, one global atomic per workgroup
+    int my_off = 0;
+    if (my_nms) my_off = atomicAdd(&wg_count, my_nms);
+    __syncthreads();
+    if (tid == 0) wg_base = wg_count ? atomicAdd(&ws.counters[0], wg_count) : 0;
+    __syncthreads();
+    int pos = wg_base + my_off;
+#pragma unroll
+    for (int it = 0; it < TILE_H / 4; ++it) {
+        if (nms_px[it]) {
+            const int gx = x0 + tx, gy = y0 + ty * (TILE_H / 4) + it;
+            const int idx = gy * W + gx;
+            ws.rec_idx[pos] = (unsigned)idx | (cand_px[it] ? CAND_FLAG : 0u);
+            if (p.mode == MV_KP_NODEPTH) {
+                ws.rec_q[pos] = q_px[it];
+            } else {
+                ws.rec_q[pos] = fc ? flow_quality(fc, plane, idx) : 0.f;
+                ws.rec_d[pos] = d0c[idx];
             }
+            ++pos;
         }
     }
 }
@@ -139,11 +164,34 @@ __device__ __forceinline__ float key_float(unsigned k) {
     return __uint_as_float(u);
 }
 
-// Lower median ((m-1)/2-th smallest of the m non-NaN values) == torch.median / torch.nanmedian.
-// Whole workgroup participates; returns NaN when there is no non-NaN value.
-__device__ float block_nanmedian(const float* __restrict__ vals, int n, unsigned* hist /*[256]*/, int* sh /*[4]*/) {
+// workgroup exclusive scan of one int per thread (1024 threads = 16 waves); returns the exclusive prefix and the total
+__device__ __forceinline__ int block_exclusive_scan(int v, int* wave_tot /*[16] LDS*/, int& total) {
+    const int tid = threadIdx.x;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if ((tid & 63) >= o) incl += t;
+    }
+    __syncthreads();  // protect wave_tot reuse
+    if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+    __syncthreads();
+    int off = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int t = wave_tot[w];
+        if (w < (tid >> 6)) off += t;
+        total += t;
+    }
+    return off + incl - v;
+}
+
+// Lower median ((m-1)/2-th smallest of the m non-NaN values) == torch.median / torch.nanmedian of the population.
+// 3 radix passes (11 + 11 + 10 bits); the bin holding rank k is found with a workgroup scan (2 bins per thread).
+__device__ float block_nanmedian(const float* __restrict__ vals, int n, unsigned* hist /*[2048]*/, int* sh /*[4]*/,
+                                 int* wave_tot /*[16]*/) {
     const int tid = threadIdx.x, nt = blockDim.x;
-    // count NaNs
     if (tid == 0) sh[0] = 0;
     __syncthreads();
     int local_nan = 0;
@@ -152,115 +200,107 @@ __device__ float block_nanmedian(const float* __restrict__ vals, int n, unsigned
     if ((tid & 63) == 0 && local_nan) atomicAdd(&sh[0], local_nan);
     __syncthreads();
     const int m = n - sh[0];
-    __syncthreads();
     if (m <= 0) return NAN;
     int k = (m - 1) >> 1;
     unsigned prefix = 0, mask = 0;
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        for (int i = tid; i < 256; i += nt) hist[i] = 0;
+    const int shifts[3] = {21, 10, 0};
+    const int widths[3] = {11, 11, 10};
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = shifts[pass];
+        const unsigned bins = 1u << widths[pass];
+        for (int i = tid; i < 2048; i += nt) hist[i] = 0;
         __syncthreads();
         for (int i = tid; i < n; i += nt) {
             const unsigned key = float_key(vals[i]);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (bins - 1)], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            int acc = 0, bkt = 0;
-            for (; bkt < 256; ++bkt) {
-                const int c = (int)hist[bkt];
-                if (acc + c > k) break;
-                acc += c;
-            }
-            sh[1] = bkt;
-            sh[2] = k - acc;
+        const int c0 = (int)hist[2 * tid], c1 = (int)hist[2 * tid + 1];
+        int total;
+        const int excl = block_exclusive_scan(c0 + c1, wave_tot, total);
+        if (excl <= k && k < excl + c0 + c1) {  // exactly one thread
+            const bool second = k >= excl + c0;
+            sh[1] = 2 * tid + (second ? 1 : 0);
+            sh[2] = k - excl - (second ? c0 : 0);
         }
         __syncthreads();
         prefix |= ((unsigned)sh[1]) << shift;
-        mask |= 255u << shift;
+        mask |= (bins - 1) << shift;
         k = sh[2];
         __syncthreads();
     }
     return key_float(prefix);
 }
 
-__global__ __launch_bounds__(1024) void kp_compact_kernel(const float* __restrict__ fc,
-                                                           const float* __restrict__ d0c, mvKpSelectParams p,
-                                                           KpWs ws, int words_per_row, int32_t* __restrict__ out_cand,
-                                                           int32_t* __restrict__ out_count,
-                                                           float* __restrict__ out_stats) {
-    __shared__ unsigned hist[256];
+__global__ __launch_bounds__(1024) void kp_finish_kernel(mvKpSelectParams p, KpWs ws, int has_flow, int words_per_row,
+                                                          int32_t* __restrict__ out_cand,
+                                                          int32_t* __restrict__ out_count,
+                                                          float* __restrict__ out_stats) {
+    __shared__ unsigned hist[2048];
     __shared__ int sh[4];
     __shared__ int wave_tot[16];
     const int tid = threadIdx.x;
-    const int H = p.H, W = p.W, plane = H * W;
-    const int n_pop = (p.mode == MV_KP_MAPPING) ? 0 : ws.counters[0];
+    const int H = p.H, W = p.W;
+    const bool mapping = p.mode == MV_KP_MAPPING;
+    const int n_rec = mapping ? 0 : ws.counters[0];
 
     float med_f = NAN, thr_f = INFINITY, med_d = NAN, thr_d = INFINITY;
-    const bool use_f = (p.mode == MV_KP_NODEPTH) || (p.mode == MV_KP_FULL && fc != nullptr);
+    const bool use_f = (p.mode == MV_KP_NODEPTH) || (p.mode == MV_KP_FULL && has_flow);
     const bool use_d = (p.mode == MV_KP_FULL);
     if (use_f) {
-        med_f = block_nanmedian(ws.pop_a, n_pop, hist, sh);
+        med_f = block_nanmedian(ws.rec_q, n_rec, hist, sh, wave_tot);
         // python: min(max_match_cov, median * 1.5) in double, then the fp32 compare rounds it to fp32:
         // == fp32 min of fp32-rounded operands (rounding is monotonic; med*1.5 is exact in double).
         const float prod = med_f * 1.5f;
         thr_f = (prod < p.max_match_cov) ? prod : p.max_match_cov;  // python min(a, b): b if b < a else a
     }
     if (use_d) {
-        med_d = block_nanmedian(ws.pop_b, n_pop, hist, sh);
+        med_d = block_nanmedian(ws.rec_d, n_rec, hist, sh, wave_tot);
         const float prod = med_d * 1.5f;
         thr_d = (prod < p.max_depth_cov) ? prod : p.max_depth_cov;
     }
 
-    // ---- ordered compaction of the candidate words
+    // ---- candidates that fail a threshold clear their bit (records are contiguous: coalesced reads)
+    if (!mapping) {
+        for (int i = tid; i < n_rec; i += 1024) {
+            const unsigned ri = ws.rec_idx[i];
+            if (ri & CAND_FLAG) {
+                bool ok = true;
+                if (use_f) ok = ws.rec_q[i] < thr_f;
+                if (ok && use_d) ok = ws.rec_d[i] < thr_d;
+                if (!ok) {
+                    const int idx = (int)(ri & ~CAND_FLAG);
+                    const int row = idx / W, col = idx - row * W;
+                    atomicAnd(&ws.cand_bits[(size_t)row * words_per_row + (col >> 6)], ~(1ull << (col & 63)));
+                }
+            }
+        }
+        __threadfence();
+        __syncthreads();
+    }
+
+    // ---- ordered compaction of the candidate words (atomic loads: served by L2, where the atomics landed)
     const int n_words = H * words_per_row;
     const int per = (n_words + 1023) / 1024;
-    const int w_begin = tid * per, w_end = min(w_begin + per, n_words);
-
-    auto survives = [&](int idx) -> bool {
-        bool ok = true;
-        if (use_f) ok = flow_quality(fc, plane, idx) < thr_f;
-        if (ok && use_d) ok = d0c[idx] < thr_d;
-        return ok;
-    };
-
+    const int w_begin = min(tid * per, n_words), w_end = min(w_begin + per, n_words);
     int cnt = 0;
+    for (int w = w_begin; w < w_end; ++w)
+        cnt += __popcll(__hip_atomic_load(&ws.cand_bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    int total;
+    int pos = block_exclusive_scan(cnt, wave_tot, total);
     for (int w = w_begin; w < w_end; ++w) {
-        unsigned long long bits = ws.cand_bits[w];
+        unsigned long long bits = __hip_atomic_load(&ws.cand_bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int row = w / words_per_row, col0 = (w - row * words_per_row) * 64;
         while (bits) {
             const int bpos = __ffsll((long long)bits) - 1;
             bits &= bits - 1;
-            if (p.mode == MV_KP_MAPPING || survives(row * W + col0 + bpos)) ++cnt;
-        }
-    }
-    // workgroup exclusive scan of cnt
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o, 64);
-        if ((tid & 63) >= o) incl += v;
-    }
-    if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
-    __syncthreads();
-    int wave_off = 0, total = 0;
-    for (int w = 0; w < 16; ++w) {
-        if (w < (tid >> 6)) wave_off += wave_tot[w];
-        total += wave_tot[w];
-    }
-    int pos = wave_off + incl - cnt;
-    for (int w = w_begin; w < w_end; ++w) {
-        unsigned long long bits = ws.cand_bits[w];
-        const int row = w / words_per_row, col0 = (w - row * words_per_row) * 64;
-        while (bits) {
-            const int bpos = __ffsll((long long)bits) - 1;
-            bits &= bits - 1;
-            const int idx = row * W + col0 + bpos;
-            if (p.mode == MV_KP_MAPPING || survives(idx)) out_cand[pos++] = idx;
+            out_cand[pos++] = row * W + col0 + bpos;
         }
     }
     if (tid == 0) {
         out_count[0] = total;
-        out_count[1] = n_pop;
+        out_count[1] = n_rec;
         out_count[2] = 0;
         out_count[3] = 0;
         out_stats[0] = med_f;
@@ -287,7 +327,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 extern "C" size_t mv_kp_select_workspace_bytes(int H, int W) {
     if (H <= 0 || W <= 0) return 0;
     const size_t words = (size_t)H * mv_ceil_div(W, 64);
-    return 2 * align_up(words * 8, 256) + 2 * align_up((size_t)H * W * 4, 256) + 256;
+    return align_up(words * 8, 256) + 3 * align_up((size_t)H * W * 4, 256) + 256;
 }
 
 extern "C" int mv_kp_select(const float* flow_cov, const float* depth0, const float* depth0_cov,
@@ -316,25 +356,26 @@ extern "C" int mv_kp_select(const float* flow_cov, const float* depth0, const fl
 
     const int wpr = mv_ceil_div(p.W, 64);
     const size_t words = (size_t)p.H * wpr;
+    const size_t plane_bytes = align_up((size_t)p.H * p.W * 4, 256);
     char* base = (char*)workspace;
     KpWs ws;
-    ws.nms_bits = (unsigned long long*)base;
-    base += align_up(words * 8, 256);
     ws.cand_bits = (unsigned long long*)base;
     base += align_up(words * 8, 256);
-    ws.pop_a = (float*)base;
-    base += align_up((size_t)p.H * p.W * 4, 256);
-    ws.pop_b = (float*)base;
-    base += align_up((size_t)p.H * p.W * 4, 256);
+    ws.rec_idx = (unsigned*)base;
+    base += plane_bytes;
+    ws.rec_q = (float*)base;
+    base += plane_bytes;
+    ws.rec_d = (float*)base;
+    base += plane_bytes;
     ws.counters = (int*)base;
 
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(ws.counters, 0, 16, s) != hipSuccess) return MV_ERR_LAUNCH;
+    if (p.mode != MV_KP_MAPPING && hipMemsetAsync(ws.counters, 0, 16, s) != hipSuccess) return MV_ERR_LAUNCH;
     dim3 grid(wpr, mv_ceil_div(p.H, TILE_H)), block(64, 4);
     hipLaunchKernelGGL(kp_nms_kernel, grid, block, 0, s, flow_cov, depth0, depth0_cov, depth1, depth1_cov, mask_a,
                        mask_b, p, ws, wpr);
-    hipLaunchKernelGGL(kp_compact_kernel, dim3(1), dim3(1024), 0, s, flow_cov, depth0_cov, p, ws, wpr, out_cand,
-                       out_count, out_stats);
+    hipLaunchKernelGGL(kp_finish_kernel, dim3(1), dim3(1024), 0, s, p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count,
+                       out_stats);
     return mv_launch_status();
 }
 

@@ -12,12 +12,15 @@
 //     here each point applies its own 3x3 / 2x2 information block in registers;
 //   * J [3N,7] and the 7x600 @ 600x600 matmul: here J_i^T W_i J_i (21 unique entries), J_i^T W_i r_i (6),
 //     plus the UNWEIGHTED J^T J (21) and J^T r (6) that TrustRegion's quality ratio needs
-//     ((J D)^T (2R + J D) = 2 D^T J^T R + D^T J^T J D), are accumulated per lane and tree-reduced with
-//     wavefront butterflies — 55 fp64 values per build pass;
+//     ((J D)^T (2R + J D) = 2 D^T J^T R + D^T J^T J D), are accumulated per thread, tree-reduced inside each
+//     wavefront with DPP butterflies (quad_perm / row_half_mirror / row_mirror + 4 readlanes) and combined across
+//     the workgroup's 4 waves through a 4 x 55 fp64 LDS table — 55 fp64 values per build pass;
 //   * the dead 7th tangent column (clamped to 1e-6, b_7 = 0 => D_7 = 0) is dropped analytically;
 //     the 6x6 SPD system is solved by an in-register Cholesky instead of an SVD pseudo-inverse
 //     (identical up to fp64 roundoff whenever A is non-singular, which the diagonal clamp + multiplicative
 //     damping guarantee).
+// One 256-thread workgroup (4 waves) per problem: with N <= 256 every thread owns one point and keeps its
+// observation, world point and information matrix in registers for the whole solve (nothing is re-read).
 // The whole <=10-step LM loop (with the inner reject/damp loop) runs on the device: one launch per batch of
 // problems, no host round trips.  Latency-bound for a single problem (report us/solve), throughput-bound
 // for large batches (report solves/s).
@@ -51,6 +54,54 @@ struct Pose {
     double q[4];   // x y z w
     double R[9];   // row-major rotation matrix of q
 };
+
+
+// ---- fp64 wavefront sum with DPP (all lanes must be active); result is wave-uniform -----------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+    const long long o = ((long long)hi << 32) | (unsigned)lo;
+    return v + __builtin_bit_cast(double, o);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)b, lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]  : xor 1
+    v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]  : xor 2
+    v = dpp_add<0x141>(v);  // row_half_mirror      : other quad of the 8-lane half (all 4 lanes already equal)
+    v = dpp_add<0x140>(v);  // row_mirror           : other half of the 16-lane row
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
+constexpr int PGO_THREADS = 256;
+constexpr int PGO_WAVES = PGO_THREADS / 64;
+constexpr int NRED = 55;  // 21 + 6 + 21 + 6 + 1
+
+// workgroup sum of `n` per-thread values: DPP inside the wave, LDS table across the 4 waves; every thread gets all sums
+template <int N>
+__device__ __forceinline__ void block_sum(double (&v)[N], double (*__restrict__ tab)[NRED]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const double s = wave_sum_dpp(v[k]);
+        if (lane == 0) tab[wave][k] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double s = tab[0][k];
+#pragma unroll
+        for (int w = 1; w < PGO_WAVES; ++w) s += tab[w][k];
+        v[k] = s;
+    }
+    __syncthreads();
+}
 
 __device__ __forceinline__ void quat_to_R(Pose& P) {
     const double x = P.q[0], y = P.q[1], z = P.q[2], w = P.q[3];
@@ -152,52 +203,193 @@ struct Geometry {
     double fx, fy, cx, cy, blfx;
 };
 
-// residual block of point i under pose P; returns |r|^2.  NR = 3 (ICP, DISP) or 2 (REPROJ).
+
+// Everything a point contributes, gathered once (fp32 buffers widened to fp64 exactly as the reference's
+// `.to(torch.double)` does, Optimizer.py:84-85).
 template <int GT>
-__device__ __forceinline__ double residual(const PgoArgs& a, const Geometry& g, const Pose& P, int i, double* r,
-                                           double* pc /* ICP: T*p_c ; else p_c = T^-1 p_w */) {
+struct PointData {
+    bool valid;
+    double pw[3];      // pos_Tw
+    double obs[3];     // REPROJ/DISP: (u, v, disparity) ; ICP: points_Tc (pixel2point_NED evaluated in fp32)
+    double W[3][3];    // REPROJ/DISP: pinv(Sigma_i) (constant); ICP: unused
+    double So[9], Sp[9];  // ICP only: obs2_covTc, cov_Tw
+};
+
+template <int GT>
+__device__ __forceinline__ void load_point(const PgoArgs& a, const Geometry& g, const mvLMParams& lm, int i, bool in_range,
+                                           PointData<GT>& d) {
+    d.valid = in_range && (a.valid ? (a.valid[i] != 0) : true);
+    if (!d.valid) return;
+    d.pw[0] = (double)a.pos_Tw[3 * i]; d.pw[1] = (double)a.pos_Tw[3 * i + 1]; d.pw[2] = (double)a.pos_Tw[3 * i + 2];
     if (GT == MV_GRAPH_ICP) {
         // points_Tc = pixel2point_NED(pixel2_uv, pixel2_d, K) built in fp32 (Graphs.py:49-51), then cast
-        const float u = a.pixel2_uv[2 * i], v = a.pixel2_uv[2 * i + 1], d = a.pixel2_d[i];
-        const float xe = ((u - (float)g.cx) * d) / (float)g.fx;
-        const float ye = ((v - (float)g.cy) * d) / (float)g.fy;
-        const double p[3] = {(double)d, (double)xe, (double)ye};
+        const float u = a.pixel2_uv[2 * i], v = a.pixel2_uv[2 * i + 1], dd = a.pixel2_d[i];
+        d.obs[0] = (double)dd;
+        d.obs[1] = (double)(((u - (float)g.cx) * dd) / (float)g.fx);
+        d.obs[2] = (double)(((v - (float)g.cy) * dd) / (float)g.fy);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { d.So[k] = a.obs2_covTc[9 * (size_t)i + k]; d.Sp[k] = a.cov_Tw[9 * (size_t)i + k]; }
+    } else {
+        d.obs[0] = (double)a.pixel2_uv[2 * i]; d.obs[1] = (double)a.pixel2_uv[2 * i + 1];
+        const double suu = (double)a.pixel2_uv_cov[3 * i], svv = (double)a.pixel2_uv_cov[3 * i + 1],
+                     suv = (double)a.pixel2_uv_cov[3 * i + 2];
+        double w00, w01, w11, w22;
+        if (GT == MV_GRAPH_DISP) {
+            d.obs[2] = (double)a.pixel2_disp[i];
+            pinv_sym2_blk(suu, svv, suv, (double)a.pixel2_disp_cov[i], true, lm.pinv_rcond, w00, w01, w11, w22);
+        } else {
+            d.obs[2] = 0.0;
+            pinv_sym2_blk(suu, svv, suv, 0.0, false, lm.pinv_rcond, w00, w01, w11, w22);
+        }
+        d.W[0][0] = w00; d.W[0][1] = w01; d.W[1][0] = w01; d.W[1][1] = w11;
+        d.W[0][2] = d.W[2][0] = d.W[1][2] = d.W[2][1] = 0.0;
+        d.W[2][2] = w22;
+    }
+}
+
+// residual block under pose P; returns |r|^2.  pc = T*p_c (ICP) or p_c = T^-1 p_w (REPROJ/DISP).
+template <int GT>
+__device__ __forceinline__ double residual(const Geometry& g, const Pose& P, const PointData<GT>& d, double* r, double* pc) {
+    if (GT == MV_GRAPH_ICP) {
         double rp[3];
-        quat_act(P.q, p, rp);
+        quat_act(P.q, d.obs, rp);
         pc[0] = rp[0] + P.t[0]; pc[1] = rp[1] + P.t[1]; pc[2] = rp[2] + P.t[2];
-        r[0] = pc[0] - (double)a.pos_Tw[3 * i];
-        r[1] = pc[1] - (double)a.pos_Tw[3 * i + 1];
-        r[2] = pc[2] - (double)a.pos_Tw[3 * i + 2];
+        r[0] = pc[0] - d.pw[0]; r[1] = pc[1] - d.pw[1]; r[2] = pc[2] - d.pw[2];
         return r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
     } else {
         // p_c = T^-1 p_w : Inv = (-q^-1.Act(t), q^-1), Act = q^-1.Act(p_w) + t_inv
         const double qi[4] = {-P.q[0], -P.q[1], -P.q[2], P.q[3]};
-        const double pw[3] = {(double)a.pos_Tw[3 * i], (double)a.pos_Tw[3 * i + 1], (double)a.pos_Tw[3 * i + 2]};
         double ti[3], rp[3];
         quat_act(qi, P.t, ti);
-        quat_act(qi, pw, rp);
+        quat_act(qi, d.pw, rp);
         pc[0] = rp[0] - ti[0]; pc[1] = rp[1] - ti[1]; pc[2] = rp[2] - ti[2];
         // point2pixel_NED = homo2cart(p_EDN K^T): u = (fx Y + cx X) / X, v = (fy Z + cy X) / X
         const double X = pc[0];
         double den = fmax(fabs(X), 2.2250738585072014e-308);
         den = (X >= 0.0) ? den : -den;
-        r[0] = (g.fx * pc[1] + g.cx * X) / den - (double)a.pixel2_uv[2 * i];
-        r[1] = (g.fy * pc[2] + g.cy * X) / den - (double)a.pixel2_uv[2 * i + 1];
+        r[0] = (g.fx * pc[1] + g.cx * X) / den - d.obs[0];
+        r[1] = (g.fy * pc[2] + g.cy * X) / den - d.obs[1];
         double n2 = r[0] * r[0] + r[1] * r[1];
         if (GT == MV_GRAPH_DISP) {
-            r[2] = (1.0 / X) * g.blfx - (double)a.pixel2_disp[i];
+            r[2] = (1.0 / X) * g.blfx - d.obs[2];
             n2 += r[2] * r[2];
         }
         return n2;
     }
 }
 
+// One point's contribution to {A_w (21), g_w (6), A_u (21), g_u (6), loss (1)} = acc[55]
 template <int GT>
-__global__ __launch_bounds__(64) void pgo_solve_kernel(PgoArgs a, mvLMParams lm) {
+__device__ __forceinline__ void accumulate_point(const Geometry& g, const mvLMParams& lm, const Pose& P,
+                                                 const PointData<GT>& d, double (&acc)[NRED]) {
     constexpr int NR = (GT == MV_GRAPH_REPROJ) ? 2 : 3;
+    double r[3] = {0, 0, 0}, pc[3];
+    const double n2 = residual<GT>(g, P, d, r, pc);
+    acc[54] += huber(n2, lm.huber_delta);
+    // FastTriggs: s = sqrt(rho'(|r|^2)); both R and J are scaled by s => s^2 on every product
+    const double sn = sqrt(n2);
+    const double s2 = (sn < lm.huber_delta) ? 1.0 : (lm.huber_delta / sn);
+
+    double J[NR][6];
+    double W[NR][NR];
+    if (GT == MV_GRAPH_ICP) {
+        // J = [I, -skew(T p_c)]
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) J[rr][c] = 0.0;
+        J[0][0] = J[1][1] = J[2][2] = 1.0;
+        J[0][4] = pc[2];  J[0][5] = -pc[1];
+        J[1][3] = -pc[2]; J[1][5] = pc[0];
+        J[2][3] = pc[1];  J[2][4] = -pc[0];
+        // Sigma_i = R Sigma_obs R^T + Sigma_pt ; W_i = pinv(Sigma_i)   (Graphs.py:62-68, Optimizer.py:96-98)
+        double T1[9], S[9], Wi[9];
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int y = 0; y < 3; ++y)
+                T1[3 * x + y] = P.R[3 * x] * d.So[y] + P.R[3 * x + 1] * d.So[3 + y] + P.R[3 * x + 2] * d.So[6 + y];
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int y = 0; y < 3; ++y)
+                S[3 * x + y] = (T1[3 * x] * P.R[3 * y] + T1[3 * x + 1] * P.R[3 * y + 1] + T1[3 * x + 2] * P.R[3 * y + 2]) + d.Sp[3 * x + y];
+        inv3(S, Wi);
+#pragma unroll
+        for (int x = 0; x < NR; ++x)
+#pragma unroll
+            for (int y = 0; y < NR; ++y) W[x][y] = Wi[3 * x + y];
+    } else {
+        // G = d p_c / d delta = [-R^T, R^T skew(p_w)]   (3 x 6)
+        double G[3][6];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            const double rt0 = P.R[x], rt1 = P.R[3 + x], rt2 = P.R[6 + x];  // row x of R^T
+            G[x][0] = -rt0; G[x][1] = -rt1; G[x][2] = -rt2;
+            // R^T skew(p): col0 = R^T (0, pz, -py), col1 = R^T (-pz, 0, px), col2 = R^T (py, -px, 0)
+            G[x][3] = rt1 * d.pw[2] - rt2 * d.pw[1];
+            G[x][4] = -rt0 * d.pw[2] + rt2 * d.pw[0];
+            G[x][5] = rt0 * d.pw[1] - rt1 * d.pw[0];
+        }
+        const double X = pc[0], Y = pc[1], Z = pc[2], X2 = X * X;
+        const double j00 = -g.fx * Y / X2, j01 = g.fx / X, j10 = -g.fy * Z / X2, j12 = g.fy / X;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            J[0][c] = j00 * G[0][c] + j01 * G[1][c];
+            J[1][c] = j10 * G[0][c] + j12 * G[2][c];
+        }
+        if (GT == MV_GRAPH_DISP) {
+            const double jd = -g.blfx / X2;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) J[NR - 1][c] = jd * G[0][c];
+        }
+#pragma unroll
+        for (int x = 0; x < NR; ++x)
+#pragma unroll
+            for (int y = 0; y < NR; ++y) W[x][y] = d.W[x][y];
+    }
+    // reference: J_T = J^T @ weight ; A = J_T @ J ; b = -J_T @ R   (PyposeOptimizers.py:170-176)
+    double WJ[NR][6], Wr[NR];
+#pragma unroll
+    for (int x = 0; x < NR; ++x) {
+        double t = 0.0;
+#pragma unroll
+        for (int y = 0; y < NR; ++y) t += W[x][y] * r[y];
+        Wr[x] = t;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double tj = 0.0;
+#pragma unroll
+            for (int y = 0; y < NR; ++y) tj += W[x][y] * J[y][c];
+            WJ[x][c] = tj;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double gwj = 0.0, guj = 0.0;
+#pragma unroll
+        for (int x = 0; x < NR; ++x) { gwj += J[x][j] * Wr[x]; guj += J[x][j] * r[x]; }
+        acc[21 + j] += s2 * gwj;
+        acc[48 + j] += s2 * guj;
+#pragma unroll
+        for (int k = j; k < 6; ++k) {
+            double aw = 0.0, au = 0.0;
+#pragma unroll
+            for (int x = 0; x < NR; ++x) { aw += J[x][j] * WJ[x][k]; au += J[x][j] * J[x][k]; }
+            acc[tri(j, k)] += s2 * aw;
+            acc[27 + tri(j, k)] += s2 * au;
+        }
+    }
+}
+
+template <int GT>
+__global__ __launch_bounds__(PGO_THREADS) void pgo_solve_kernel(PgoArgs a, mvLMParams lm) {
+    __shared__ double red_tab[PGO_WAVES][NRED];
     const int prob = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
     const int beg = a.offsets[prob], end = a.offsets[prob + 1];
+    const int npts = end - beg;
+    const bool cached = npts <= PGO_THREADS;  // every thread owns (at most) one point for the whole solve
 
     Geometry g;
     g.fx = (double)a.intrinsics[4 * prob]; g.fy = (double)a.intrinsics[4 * prob + 1];
@@ -211,6 +403,10 @@ __global__ __launch_bounds__(64) void pgo_solve_kernel(PgoArgs a, mvLMParams lm)
     for (int k = 0; k < 4; ++k) P.q[k] = (double)a.init_pose[7 * prob + 3 + k];
     quat_to_R(P);
 
+    PointData<GT> mine;
+    mine.valid = false;
+    if (cached) load_point<GT>(a, g, lm, beg + tid, tid < npts, mine);
+
     double damping = 1.0 / lm.radius, tr_down = lm.tr_down;
     double loss = 0.0, last = 0.0, loss0 = 0.0;
     bool have_loss = false;
@@ -218,136 +414,38 @@ __global__ __launch_bounds__(64) void pgo_solve_kernel(PgoArgs a, mvLMParams lm)
     bool continual = true;
 
     // Odometry/MACVO.py:303-307: fewer than min_num_point observations => no optimisation, pose stays at the prior
-    int n_valid = 0;
-    for (int i = beg + lane; i < end; i += 64) n_valid += (a.valid ? (a.valid[i] != 0) : 1);
-    n_valid = wave_sum(n_valid);
-    if (n_valid < a.min_points) continual = false;
+    {
+        double nv[1] = {0.0};
+        if (cached) {
+            nv[0] = mine.valid ? 1.0 : 0.0;
+        } else {
+            for (int i = beg + tid; i < end; i += PGO_THREADS) nv[0] += (a.valid ? (a.valid[i] != 0) : 1) ? 1.0 : 0.0;
+        }
+        block_sum<1>(nv, red_tab);
+        if ((int)nv[0] < a.min_points) continual = false;
+    }
 
     while (continual) {
         // ------------------------------------------------------------------ build pass
-        double Aw[21], gw[6], Au[21], gu[6], loss_acc = 0.0;
+        double acc[NRED];
 #pragma unroll
-        for (int k = 0; k < 21; ++k) { Aw[k] = 0.0; Au[k] = 0.0; }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { gw[k] = 0.0; gu[k] = 0.0; }
-
-        for (int i = beg + lane; i < end; i += 64) {
-            if (a.valid && !a.valid[i]) continue;
-            double r[3] = {0, 0, 0}, pc[3];
-            const double n2 = residual<GT>(a, g, P, i, r, pc);
-            loss_acc += huber(n2, lm.huber_delta);
-            // FastTriggs: s = sqrt(rho'(|r|^2)); both R and J are scaled by s => s^2 on every product
-            const double sn = sqrt(n2);
-            const double s2 = (sn < lm.huber_delta) ? 1.0 : (lm.huber_delta / sn);
-
-            double J[NR][6];
-            double W[NR][NR];
-            if (GT == MV_GRAPH_ICP) {
-                // J = [I, -skew(T p_c)]
-#pragma unroll
-                for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) J[rr][c] = 0.0;
-                J[0][0] = J[1][1] = J[2][2] = 1.0;
-                J[0][4] = pc[2];  J[0][5] = -pc[1];
-                J[1][3] = -pc[2]; J[1][5] = pc[0];
-                J[2][3] = pc[1];  J[2][4] = -pc[0];
-                // Sigma_i = R Sigma_obs R^T + Sigma_pt ; W_i = pinv(Sigma_i)
-                double So[9], Sp[9], T1[9], S[9], Wi[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) { So[k] = a.obs2_covTc[9 * (size_t)i + k]; Sp[k] = a.cov_Tw[9 * (size_t)i + k]; }
-#pragma unroll
-                for (int x = 0; x < 3; ++x)
-#pragma unroll
-                    for (int y = 0; y < 3; ++y)
-                        T1[3 * x + y] = P.R[3 * x] * So[y] + P.R[3 * x + 1] * So[3 + y] + P.R[3 * x + 2] * So[6 + y];
-#pragma unroll
-                for (int x = 0; x < 3; ++x)
-#pragma unroll
-                    for (int y = 0; y < 3; ++y)
-                        S[3 * x + y] = (T1[3 * x] * P.R[3 * y] + T1[3 * x + 1] * P.R[3 * y + 1] + T1[3 * x + 2] * P.R[3 * y + 2]) + Sp[3 * x + y];
-                inv3(S, Wi);
-#pragma unroll
-                for (int x = 0; x < 3; ++x)
-#pragma unroll
-                    for (int y = 0; y < 3; ++y) W[x][y] = Wi[3 * x + y];
-            } else {
-                // G = d p_c / d delta = [-R^T, R^T skew(p_w)]   (3 x 6)
-                const double pw[3] = {(double)a.pos_Tw[3 * i], (double)a.pos_Tw[3 * i + 1], (double)a.pos_Tw[3 * i + 2]};
-                double G[3][6];
-#pragma unroll
-                for (int x = 0; x < 3; ++x) {
-                    const double rt0 = P.R[x], rt1 = P.R[3 + x], rt2 = P.R[6 + x];  // row x of R^T
-                    G[x][0] = -rt0; G[x][1] = -rt1; G[x][2] = -rt2;
-                    // R^T skew(p): col0 = R^T (0, pz, -py), col1 = R^T (-pz, 0, px), col2 = R^T (py, -px, 0)
-                    G[x][3] = rt1 * pw[2] - rt2 * pw[1];
-                    G[x][4] = -rt0 * pw[2] + rt2 * pw[0];
-                    G[x][5] = rt0 * pw[1] - rt1 * pw[0];
-                }
-                const double X = pc[0], Y = pc[1], Z = pc[2], X2 = X * X;
-                const double j00 = -g.fx * Y / X2, j01 = g.fx / X, j10 = -g.fy * Z / X2, j12 = g.fy / X;
-#pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    J[0][c] = j00 * G[0][c] + j01 * G[1][c];
-                    J[1][c] = j10 * G[0][c] + j12 * G[2][c];
-                }
-                double w00, w01, w11, w22;
-                const double suu = (double)a.pixel2_uv_cov[3 * i], svv = (double)a.pixel2_uv_cov[3 * i + 1],
-                             suv = (double)a.pixel2_uv_cov[3 * i + 2];
-                if (GT == MV_GRAPH_DISP) {
-                    const double jd = -g.blfx / X2;
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) J[NR - 1][c] = jd * G[0][c];
-                    pinv_sym2_blk(suu, svv, suv, (double)a.pixel2_disp_cov[i], true, lm.pinv_rcond, w00, w01, w11, w22);
-                    W[0][NR - 1] = W[NR - 1][0] = W[1][NR - 1] = W[NR - 1][1] = 0.0;
-                    W[NR - 1][NR - 1] = w22;
-                } else {
-                    pinv_sym2_blk(suu, svv, suv, 0.0, false, lm.pinv_rcond, w00, w01, w11, w22);
-                }
-                W[0][0] = w00; W[0][1] = w01; W[1][0] = w01; W[1][1] = w11;
-            }
-            // accumulate s^2 J^T W J, s^2 J^T W r, s^2 J^T J, s^2 J^T r.
-            // reference: J_T = J^T @ weight ; A = J_T @ J ; b = -J_T @ R   (PyposeOptimizers.py:170-176)
-            double WJ[NR][6], Wr[NR];
-#pragma unroll
-            for (int x = 0; x < NR; ++x) {
-                double t = 0.0;
-#pragma unroll
-                for (int y = 0; y < NR; ++y) t += W[x][y] * r[y];
-                Wr[x] = t;
-#pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    double tj = 0.0;
-#pragma unroll
-                    for (int y = 0; y < NR; ++y) tj += W[x][y] * J[y][c];
-                    WJ[x][c] = tj;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                double gwj = 0.0, guj = 0.0;
-#pragma unroll
-                for (int x = 0; x < NR; ++x) { gwj += J[x][j] * Wr[x]; guj += J[x][j] * r[x]; }
-                gw[j] += s2 * gwj;
-                gu[j] += s2 * guj;
-#pragma unroll
-                for (int k = j; k < 6; ++k) {
-                    double aw = 0.0, au = 0.0;
-#pragma unroll
-                    for (int x = 0; x < NR; ++x) { aw += J[x][j] * WJ[x][k]; au += J[x][j] * J[x][k]; }
-                    Aw[tri(j, k)] += s2 * aw;
-                    Au[tri(j, k)] += s2 * au;
-                }
+        for (int k = 0; k < NRED; ++k) acc[k] = 0.0;
+        if (cached) {
+            if (mine.valid) accumulate_point<GT>(g, lm, P, mine, acc);
+        } else {
+            for (int i = beg + tid; i < end; i += PGO_THREADS) {
+                PointData<GT> d;
+                load_point<GT>(a, g, lm, i, true, d);
+                if (d.valid) accumulate_point<GT>(g, lm, P, d, acc);
             }
         }
-        // wavefront tree reduce (every lane ends with the totals)
-#pragma unroll
-        for (int k = 0; k < 21; ++k) { Aw[k] = wave_sum(Aw[k]); Au[k] = wave_sum(Au[k]); }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { gw[k] = wave_sum(gw[k]); gu[k] = wave_sum(gu[k]); }
-        loss_acc = wave_sum(loss_acc);
+        block_sum<NRED>(acc, red_tab);
+        double* Aw = acc;
+        const double* gw = acc + 21;
+        const double* Au = acc + 27;
+        const double* gu = acc + 48;
 
-        if (!have_loss) { loss = loss_acc; loss0 = loss_acc; have_loss = true; }
+        if (!have_loss) { loss = acc[54]; loss0 = acc[54]; have_loss = true; }
         last = loss;
         reject_count = 0;
 
@@ -359,53 +457,65 @@ __global__ __launch_bounds__(64) void pgo_solve_kernel(PgoArgs a, mvLMParams lm)
         while (last <= loss) {
 #pragma unroll
             for (int j = 0; j < 6; ++j) Aw[tri(j, j)] += Aw[tri(j, j)] * damping;
-            // solve A D = b, b = -gw, by Cholesky (A = L L^T)
+            // solve A D = b, b = -gw, by Cholesky (A = L L^T); every thread solves redundantly (uniform control flow)
             double L[6][6], D[6];
             bool ok = true;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                double d = Aw[tri(j, j)];
+                double dd = Aw[tri(j, j)];
 #pragma unroll
-                for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
-                ok = ok && (d > 0.0) && (d < INFINITY);
-                const double ljj = sqrt(d);
+                for (int k = 0; k < j; ++k) dd -= L[j][k] * L[j][k];
+                ok = ok && (dd > 0.0) && (dd < INFINITY);
+                const double ljj = sqrt(dd);
+                const double inv = 1.0 / ljj;
                 L[j][j] = ljj;
 #pragma unroll
                 for (int i2 = j + 1; i2 < 6; ++i2) {
-                    double s = Aw[tri(j, i2)];
+                    double sacc = Aw[tri(j, i2)];
 #pragma unroll
-                    for (int k = 0; k < j; ++k) s -= L[i2][k] * L[j][k];
-                    L[i2][j] = s / ljj;
+                    for (int k = 0; k < j; ++k) sacc -= L[i2][k] * L[j][k];
+                    L[i2][j] = sacc * inv;
                 }
             }
             if (!ok) break;  // "Linear solver failed. Breaking optimization step..."
             double yv[6];
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                double s = -gw[j];
+                double sacc = -gw[j];
 #pragma unroll
-                for (int k = 0; k < j; ++k) s -= L[j][k] * yv[k];
-                yv[j] = s / L[j][j];
+                for (int k = 0; k < j; ++k) sacc -= L[j][k] * yv[k];
+                yv[j] = sacc / L[j][j];
             }
 #pragma unroll
             for (int j = 5; j >= 0; --j) {
-                double s = yv[j];
+                double sacc = yv[j];
 #pragma unroll
-                for (int k = j + 1; k < 6; ++k) s -= L[k][j] * D[k];
-                D[j] = s / L[j][j];
+                for (int k = j + 1; k < 6; ++k) sacc -= L[k][j] * D[k];
+                D[j] = sacc / L[j][j];
             }
 
             const Pose P_prev = P;
             se3_left_update(P, D);
 
             // loss at the trial pose (RobustModel.loss: unweighted, uncorrected)
-            double la = 0.0;
-            for (int i = beg + lane; i < end; i += 64) {
-                if (a.valid && !a.valid[i]) continue;
-                double r[3] = {0, 0, 0}, pc[3];
-                la += huber(residual<GT>(a, g, P, i, r, pc), lm.huber_delta);
+            double la[1] = {0.0};
+            if (cached) {
+                if (mine.valid) {
+                    double r[3] = {0, 0, 0}, pc[3];
+                    la[0] = huber(residual<GT>(g, P, mine, r, pc), lm.huber_delta);
+                }
+            } else {
+                for (int i = beg + tid; i < end; i += PGO_THREADS) {
+                    PointData<GT> d;
+                    load_point<GT>(a, g, lm, i, true, d);
+                    if (d.valid) {
+                        double r[3] = {0, 0, 0}, pc[3];
+                        la[0] += huber(residual<GT>(g, P, d, r, pc), lm.huber_delta);
+                    }
+                }
             }
-            loss = wave_sum(la);
+            block_sum<1>(la, red_tab);
+            loss = la[0];
 
             // TrustRegion.update: quality = (last - loss) / -((J D)^T (2 R + J D)) on the corrected, unweighted J, R
             double dAd = 0.0, dg = 0.0;
@@ -447,7 +557,7 @@ __global__ __launch_bounds__(64) void pgo_solve_kernel(PgoArgs a, mvLMParams lm)
         if (reject_count >= lm.reject) continual = false;
     }
 
-    if (lane == 0) {
+    if (tid == 0) {
         double* o = a.out_pose + 7 * (size_t)prob;
         o[0] = P.t[0]; o[1] = P.t[1]; o[2] = P.t[2];
         o[3] = P.q[0]; o[4] = P.q[1]; o[5] = P.q[2]; o[6] = P.q[3];
@@ -488,7 +598,7 @@ extern "C" int mv_pgo_solve(int nprob, const int32_t* offsets, int graph_type, c
     PgoArgs a{offsets, init_pose, intrinsics, baseline, pos_Tw, cov_Tw, pixel2_uv, pixel2_d, pixel2_disp,
               pixel2_disp_cov, pixel2_uv_cov, obs2_covTc, valid, min_points, out_pose, out_info, out_pose_f32};
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(nprob), block(64);
+    dim3 grid(nprob), block(PGO_THREADS);
     switch (graph_type) {
         case MV_GRAPH_ICP:
             MV_CHECK_ARG(cov_Tw && obs2_covTc && pixel2_d);

@@ -1,0 +1,108 @@
+#!/usr/bin/env python
+"""Stand-alone timing of individual C-ABI kernels on the GPU box (HIP events, median of N launches).
+
+    python tools/kernel_bench.py [volume_f32 volume_f16 lookup select cov pgo ...] [--iters 50]
+
+Used for A/B tuning and as the target of `rocprofv3 --pmc ...` runs (one kernel family per process).
+"""
+import argparse
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from macvo_amd import ops  # noqa: E402
+from tests import synth  # noqa: E402
+
+
+def timeit(fn, iters, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3)
+    return statistics.median(ts), min(ts)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="*", default=["volume_f32", "volume_f16", "lookup", "select", "cov", "pgo"])
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--H", type=int, default=480)
+    ap.add_argument("--W", type=int, default=640)
+    ap.add_argument("--B", type=int, default=2)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    H, W, B, C = a.H, a.W, a.B, 256
+    h8, w8 = H // 8, W // 8
+    n = h8 * w8
+    g = torch.Generator().manual_seed(0)
+    f1, f2 = torch.randn(B, C, h8, w8, generator=g).to(dev), torch.randn(B, C, h8, w8, generator=g).to(dev)
+    flops = B * 2.0 * n * n * C
+    vol = torch.empty((B * n, 1, h8, w8), dtype=torch.float32, device=dev)
+    for w in a.what:
+        if w == "volume_f32":
+            med, mn = timeit(lambda: ops.corr_volume(f1, f2, "chw", out=vol), a.iters)
+            print(f"volume_f32_chw  B={B} {med:8.1f} us (min {mn:.1f})  {flops / med / 1e6:7.1f} TFLOP/s  {flops / med / 1e6 / 157.3 * 100:.1f}% of f32 MFMA peak")
+            a1, a2 = f1.permute(0, 2, 3, 1).contiguous(), f2.permute(0, 2, 3, 1).contiguous()
+            med, mn = timeit(lambda: ops.corr_volume(a1, a2, "hwc", out=vol), a.iters)
+            print(f"volume_f32_hwc  B={B} {med:8.1f} us (min {mn:.1f})  {flops / med / 1e6:7.1f} TFLOP/s")
+        elif w == "volume_f16":
+            for dt in (torch.float16, torch.bfloat16):
+                a1, a2 = f1.permute(0, 2, 3, 1).contiguous().to(dt), f2.permute(0, 2, 3, 1).contiguous().to(dt)
+                byts = B * (2.0 * n * C * 2 + 4.0 * n * n)
+                med, mn = timeit(lambda: ops.corr_volume(a1, a2, "hwc", out=vol), a.iters)
+                print(f"volume_{str(dt)[6:]}_hwc B={B} {med:8.1f} us (min {mn:.1f})  {byts / med / 1e3:7.1f} GB/s  {byts / med / 1e3 / 8000 * 100:.1f}% of HBM peak")
+                c1, c2 = f1.to(dt), f2.to(dt)
+                med, mn = timeit(lambda: ops.corr_volume(c1, c2, "chw", out=vol), a.iters)
+                print(f"volume_{str(dt)[6:]}_chw B={B} {med:8.1f} us (min {mn:.1f})  {byts / med / 1e3:7.1f} GB/s")
+        elif w == "lookup":
+            ops.corr_volume(f1, f2, "chw", out=vol)
+            from oracle import corr
+
+            coords = (corr.coords_grid(B, h8, w8) + (torch.rand(B, 2, h8, w8, generator=g) * 2 - 1) * 8).to(dev)
+            tok = torch.empty((B, 81, h8, w8), dtype=torch.float32, device=dev)
+            byts = B * (n * 100 * 4 + n * 8 + n * 81 * 4.0)
+            med, mn = timeit(lambda: ops.corr_lookup(vol, coords, 4, out=tok), a.iters)
+            print(f"lookup r=4      B={B} {med:8.1f} us (min {mn:.1f})  {byts / med / 1e3:7.1f} GB/s algorithmic")
+        elif w == "select":
+            fc = synth.flow_cov_maps(H, W, 2).to(dev)
+            d0, d0c = [t.to(dev) for t in synth.depth_maps(H, W, 3)]
+            d1, d1c = [t.to(dev) for t in synth.depth_maps(H, W, 4)]
+            med, mn = timeit(lambda: ops.kp_select("nodepth", H, W, flow_cov=fc, kernel_size=7, mask_width=32, max_match_cov=100.0), a.iters)
+            print(f"kp_select nodepth    {med:8.1f} us (min {mn:.1f})")
+            med, mn = timeit(lambda: ops.kp_select("full", H, W, flow_cov=fc, depth0=d0, depth0_cov=d0c, depth1=d1, depth1_cov=d1c,
+                                                   kernel_size=7, mask_width=32, max_depth=80.0, max_depth_cov=250.0, max_match_cov=100.0), a.iters)
+            print(f"kp_select full       {med:8.1f} us (min {mn:.1f})")
+            med, mn = timeit(lambda: ops.kp_select("mapping", H, W, depth0=d0, depth0_cov=d0c, mask_width=32, max_depth=20.0, max_depth_cov=0.2), a.iters)
+            print(f"kp_select mapping    {med:8.1f} us (min {mn:.1f})")
+        elif w == "cov":
+            depth = synth.depth_maps(H, W, 3)[0].to(dev)
+            for npt in (200, 2000):
+                kp = synth.keypoints(npt, H, W, 5).float().to(dev)
+                fc = (torch.ones(npt, 3) * 0.25).to(dev)
+                med, mn = timeit(lambda: ops.match_cov(depth, kp, fc, None, 320.0, 320.0, 320.0, 240.0), a.iters)
+                print(f"match_cov N={npt:5d}    {med:8.1f} us (min {mn:.1f})")
+        elif w == "pgo":
+            from oracle import pgo
+            from tests.test_gpu_backend import _to_batch
+
+            for nprob in (1, 8, 256, 4096):
+                base = [pgo.make_synthetic_problem(n=200, seed=6 + k)[0] for k in range(min(nprob, 8))]
+                probs = [base[k % len(base)] for k in range(nprob)]
+                batch = _to_batch(probs, dev)
+                for gt in ("disp", "icp"):
+                    med, mn = timeit(lambda: ops.pgo_solve(batch, gt), max(5, a.iters // 5))
+                    print(f"pgo {gt:6s} nprob={nprob:5d} {med:9.1f} us (min {mn:.1f})  {nprob / med * 1e6:10.0f} solves/s")
+
+
+if __name__ == "__main__":
+    main()
