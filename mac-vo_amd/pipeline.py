@@ -99,7 +99,10 @@ class HotPath:
         self.dev = torch.device(device)
         self.keep_extras = keep_extras
         self.lm = ops.lm_default_params()
-        self.maps_prev: ops.FrontendMaps | None = None
+        self.maps_prev_for_next: ops.FrontendMaps | None = None   # depth maps of the newest frontend'ed frame
+        self._side = torch.cuda.Stream(device=self.dev)
+        self._pgo_done = None
+        self._pgo_keep = None
         self.pose = torch.tensor([0, 0, 0, 0, 0, 0, 1], dtype=torch.float32, device=self.dev)
         c = self.cfg
         self._max_depth = cam.fx * cam.baseline if c.max_depth == "auto" else float(c.max_depth)
@@ -125,16 +128,17 @@ class HotPath:
 
     def initialize(self, x: FrameInputs, init_pose: torch.Tensor | None = None) -> None:
         """Frame 0: ``MACVO.initialize`` (:158-171) — depth only, pose = prior."""
-        self.maps_prev = self.frontend(x)
+        self.maps_prev_for_next = self.frontend(x)
         if init_pose is not None:
             self.pose = init_pose.to(self.dev, torch.float32).reshape(7).clone()
 
-    # ------------------------------------------------------------------ one run_pair
-    def step(self, x: FrameInputs) -> FrameResult:
-        assert self.maps_prev is not None, "call initialize() with the first frame"
+    # ------------------------------------------------------------------ one run_pair, in two halves
+    def enqueue_frontend(self, x: FrameInputs) -> "_Pending":
+        """Everything of a frame that does not depend on the previous pose: volume, lookups, epilogue and the dense
+        selector stage.  Only enqueues work; the candidate count travels to a pinned host word behind an event, so a
+        later ``finish`` waits for THIS frame's selector and not for whatever was queued after it."""
         c, cam = self.cfg, self.cam
-        maps0, maps1 = self.maps_prev, self.frontend(x)
-
+        maps0, maps1 = self.maps_prev_for_next, self.frontend(x)
         if c.selector == "nodepth":
             cands = ops.kp_select("nodepth", cam.H, cam.W, flow_cov=maps1.flow_cov, kernel_size=c.kp_kernel_size,
                                   mask_width=c.kp_mask_width, max_match_cov=c.max_match_cov)
@@ -143,10 +147,28 @@ class HotPath:
                                   depth0_cov=maps0.depth_cov, depth1=maps1.depth, depth1_cov=maps1.depth_cov,
                                   kernel_size=c.kp_kernel_size, mask_width=c.kp_mask_width, max_depth=self._max_depth,
                                   max_depth_cov=c.max_depth_cov, max_match_cov=c.max_match_cov)
-        kp0 = cands.finish(c.num_point)          # host sync (count) + CPU randperm, as in the reference
+        host_count = torch.empty((4,), dtype=torch.int32, pin_memory=True)
+        host_count.copy_(cands.count, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.maps_prev_for_next = maps1
+        return _Pending(maps0, maps1, cands, host_count, ev)
+
+    def finish(self, pend: "_Pending", pose_sink: torch.Tensor | None = None) -> FrameResult:
+        """Host randperm (bit-exact indices) + the pose-dependent half: tracking, back-projection, covariances, filter,
+        PGO.  The solve runs on a side stream (the GPU analogue of the reference's optimizer child process,
+        Optimization/Interface.py:80-96): the next frame's frontend overlaps it, the next frame's back-projection
+        waits for it."""
+        c, cam = self.cfg, self.cam
+        maps0, maps1, cands = pend.maps0, pend.maps1, pend.cands
+        pend.event.synchronize()
+        cands._n = int(pend.host_count[0])
+        kp0 = cands.finish(c.num_point)          # CPU randperm from the global generator, as in the reference
         n = kp0.shape[0]
+        main = torch.cuda.current_stream()
+        if self._pgo_done is not None:
+            main.wait_event(self._pgo_done)       # self.pose of the previous frame is produced on the side stream
         if n == 0:
-            self.maps_prev = maps1
             return FrameResult(self.pose, None, None, kp0, None)
 
         tr = ops.kp_track(kp0, maps1.flow, maps1.flow_cov, maps0, maps1, c.edgewidth, c.match_cov_default)
@@ -158,16 +180,65 @@ class HotPath:
         valid, n_valid = ops.obs_filter(tr.inbound, cov0, cov1, tr.vals, c.filters, c.filter_min_depth, self._max_depth)
 
         batch = ops.PGOBatch(
-            offsets=self._offs[n],
-            init_pose=self.pose.reshape(1, 7), intrinsics=self._intr, baseline=self._bl,
+            offsets=self._offs[n], init_pose=self.pose.reshape(1, 7), intrinsics=self._intr, baseline=self._bl,
             pos_Tw=pos_Tw, pixel2_uv=tr.kp1_uv, cov_Tw=cov0_w, pixel2_d=tr.vals[4], pixel2_disp=tr.vals[5],
             pixel2_disp_cov=tr.vals[6], pixel2_uv_cov=tr.sigma1, obs2_covTc=cov1, valid=valid)
-        new_pose = torch.empty((1, 7), dtype=torch.float32, device=self.dev)
-        pose64, info = ops.pgo_solve(batch, c.graph_type, self.lm, min_points=c.min_num_point, out_pose_f32=new_pose)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        side = self._side
+        side.wait_event(ready)
+        with torch.cuda.stream(side):
+            new_pose = torch.empty((1, 7), dtype=torch.float32, device=self.dev)
+            pose64, info = ops.pgo_solve(batch, c.graph_type, self.lm, min_points=c.min_num_point, out_pose_f32=new_pose)
+            if pose_sink is not None:
+                pose_sink.copy_(new_pose.reshape(7), non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(side)
+        self._pgo_done = done
+        self._pgo_keep = (batch, tr, cov0, cov1, maps0)   # inputs of the in-flight solve stay referenced until replaced
         self.pose = new_pose.reshape(7)
-        self.maps_prev = maps1
         res = FrameResult(self.pose, pose64, info, kp0, n_valid)
         if self.keep_extras:
             res.extras = dict(tracked=tr, cov0=cov0, cov0_w=cov0_w, cov1=cov1, valid=valid, pos_Tw=pos_Tw,
                               maps1=maps1, cands=cands)
         return res
+
+    def step(self, x: FrameInputs) -> FrameResult:
+        """One ``run_pair`` start to finish (no cross-frame overlap); results are valid on the current stream."""
+        assert self.maps_prev_for_next is not None, "call initialize() with the first frame"
+        res = self.finish(self.enqueue_frontend(x))
+        self.sync_pose()
+        return res
+
+    def sync_pose(self) -> None:
+        """Make the current stream wait for the in-flight solve (needed before reading ``self.pose`` there)."""
+        if self._pgo_done is not None:
+            torch.cuda.current_stream().wait_event(self._pgo_done)
+
+    def run(self, frames, pose_sink: torch.Tensor | None = None):
+        """Software-pipelined stream: frame t+1's frontend is enqueued before frame t's host-side randperm, so the GPU
+        never idles on the selector's host round trip.  Yields a FrameResult per frame (same results as ``step``)."""
+        it = iter(frames)
+        try:
+            nxt = self.enqueue_frontend(next(it))
+        except StopIteration:
+            return
+        i = 0
+        while nxt is not None:
+            cur = nxt
+            try:
+                nxt = self.enqueue_frontend(next(it))
+            except StopIteration:
+                nxt = None
+            yield self.finish(cur, None if pose_sink is None else pose_sink[i])
+            i += 1
+        self.sync_pose()
+
+
+@dataclass
+class _Pending:
+    maps0: "ops.FrontendMaps"
+    maps1: "ops.FrontendMaps"
+    cands: "ops.KeypointCandidates"
+    host_count: torch.Tensor
+    event: "torch.cuda.Event"

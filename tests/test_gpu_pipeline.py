@@ -50,3 +50,26 @@ def test_sequence_matches_oracle(gpu, H, W, graph, selector):
         assert et < 0.05 and er < 0.01, (t, et, er)
         # keep both pipelines on the same prior so that fp32-level covariance differences cannot compound
         hot.pose = ro["pose"].to(gpu)
+
+
+def test_pipelined_run_equals_stepwise(gpu):
+    """HotPath.run (cross-frame software pipelining + side-stream PGO) must give exactly the poses of step()."""
+    from macvo_amd.pipeline import Camera, HotPath, HotPathConfig
+
+    n_frames = 7
+    cam, frames, _ = synth.make_sequence(n_frames, 240, 320, C=64, iters=2, seed=5)
+    ins = [_to_inputs(f, gpu) for f in frames]
+    a = HotPath(Camera(**cam), HotPathConfig(), gpu)
+    a.initialize(ins[0])
+    torch.manual_seed(77)
+    poses_a = []
+    for t in range(1, n_frames):
+        poses_a.append(a.step(ins[t]).pose.clone())
+    b = HotPath(Camera(**cam), HotPathConfig(), gpu)
+    b.initialize(ins[0])
+    sink = torch.zeros(n_frames - 1, 7, device=gpu)
+    torch.manual_seed(77)
+    kps = [r.kp0_uv for r in b.run(ins[1:], pose_sink=sink)]
+    torch.cuda.synchronize()
+    assert len(kps) == n_frames - 1
+    assert torch.equal(sink, torch.stack(poses_a))
