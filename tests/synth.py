@@ -2,23 +2,36 @@
 import torch
 
 
+def _exact_lognormal_like(shape, g, lo_exp=-4, n_exp=8):
+    """Positive floats with a log-uniform-ish spread built from integer draws and exact fp32 arithmetic only
+    ((1 + r1/1024) * 2^(r2 + lo_exp)), so that the same seed gives bit-identical tensors on any CPU (torch.randn /
+    exp go through ISA-specific vector math and are NOT bit-reproducible across hosts)."""
+    r1 = torch.randint(0, 1024, shape, generator=g).float()
+    r2 = torch.randint(0, n_exp, shape, generator=g).float()
+    return (1.0 + r1 / 1024.0) * torch.exp2(r2 + lo_exp)
+
+
 def flow_cov_maps(H=480, W=640, seed=2, nan_frac=0.0):
-    """S-sel: sigma_uu, sigma_vv = exp(2 N(0, .5)), sigma_uv = 0  -> [1,3,H,W] float32."""
+    """S-sel: sigma_uu, sigma_vv spread over ~2 decades, sigma_uv = 0  -> [1,3,H,W] float32 (bit-reproducible)."""
     g = torch.Generator().manual_seed(seed)
-    c = torch.exp(2 * 0.5 * torch.randn(1, 2, H, W, generator=g))
+    c = _exact_lognormal_like((1, 2, H, W), g)
     fc = torch.cat([c, torch.zeros(1, 1, H, W)], dim=1)
     if nan_frac > 0:
-        m = torch.rand(1, 1, H, W, generator=g) < nan_frac
+        m = torch.randint(0, 1 << 20, (1, 1, H, W), generator=g) < int(nan_frac * (1 << 20))
         fc[:, 0:1][m] = float("nan")
     return fc
 
 
 def depth_maps(H=480, W=640, seed=3):
-    """depth ~ U(1, 60) smooth-ish plane + noise; depth cov = (z^2/80)^2 * exp(N(0,.3)) -> two [1,1,H,W]."""
+    """Tilted plane 3..58 m plus +-1/16 m quantised noise; depth cov = (z^2/80)^2 * spread * 1e-2 -> two [1,1,H,W]
+    (integer draws + exact fp32 arithmetic: bit-reproducible across hosts)."""
     g = torch.Generator().manual_seed(seed)
-    ys, xs = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
-    z = (3 + 40 * ys + 15 * xs)[None, None] + 0.05 * torch.randn(1, 1, H, W, generator=g)
-    zc = (z ** 2 / 80) ** 2 * torch.exp(0.3 * torch.randn(1, 1, H, W, generator=g)) * 1e-2
+    ys = (torch.arange(H, dtype=torch.int64)[:, None] * 40 * 1024 // H).float() / 1024.0
+    xs = (torch.arange(W, dtype=torch.int64)[None, :] * 15 * 1024 // W).float() / 1024.0
+    noise = (torch.randint(0, 129, (1, 1, H, W), generator=g).float() - 64.0) / 1024.0
+    z = (3.0 + ys + xs)[None, None] + noise
+    spread = _exact_lognormal_like((1, 1, H, W), g, lo_exp=-2, n_exp=3)
+    zc = (z * z / 80.0) * (z * z / 80.0) * spread * 0.0078125
     return z.float(), zc.float()
 
 
