@@ -60,7 +60,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also exercises RCCL at world = 1)
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -122,6 +122,9 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    if dist is not None:  # warm the collectives used in / around the timed region (RCCL sets channels up lazily)
+        gather_poses(torch.zeros((args.steps, 7), dtype=torch.float32, device=dev), dist)
+        dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=dev), op=dist.ReduceOp.MAX)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()

@@ -24,7 +24,7 @@ def gather_poses(poses: torch.Tensor, dist=None, lengths: torch.Tensor | None = 
     (two-phase: gather lengths, pad to the max, gather payload).  Returns ``[world, T_max, 7]``; with no process
     group it is ``poses[None]``.
     """
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return poses[None]
     world = dist.get_world_size()
     T = torch.tensor([poses.shape[0]], dtype=torch.int64, device=poses.device)
