@@ -34,7 +34,13 @@ enum {
     MV_ERR_WORKSPACE = -4
 };
 
-enum { MV_F32 = 0, MV_F16 = 1, MV_BF16 = 2 };
+enum {
+    MV_F32 = 0,        /* fp32 operands, exact fp32 MFMA (bitwise an fmaf chain)                               */
+    MV_F16 = 1,
+    MV_BF16 = 2,
+    MV_BF16X3 = 3      /* fp32 operands pre-split by mv_split_bf16x3 into 3 bf16 planes; 6 bf16 MFMA products, fp32
+                          accumulate: fp32-class accuracy (dropped terms O(2^-24)), not bitwise; layout HWC only     */
+};
 
 /* feature-map memory layouts accepted by mv_corr_volume */
 enum {
@@ -53,10 +59,16 @@ const char* mv_error_string(int code);
  *   out[b, i, j] = sum_c f1[b, c, i] * f2[b, c, j]          (== cost_maps [B*N1, 1, H2, W2] fp32)
  * in_dtype MV_F32: exact fp32 (v_mfma_f32_32x32x2_f32, one rounding per product, k ascending).
  * in_dtype MV_F16 / MV_BF16: 16-bit operands, fp32 accumulate, fp32 output (Fast mode).
+ * in_dtype MV_BF16X3: f1/f2 are the [3][B][N][C] bf16 planes written by mv_split_bf16x3 from fp32 features
+ *   (x = hi + mid + lo); the product is rebuilt from the 6 bf16 MFMA products with i + j <= 2.  The reference runs
+ *   this GEMM in TF32/fp16 (Module/Frontend/Frontend.py:275-278), so this mode is at least as precise as its own.
  * Requirements: C % 16 == 0.  f1/f2 16-byte aligned.
  */
 int mv_corr_volume(const void* f1, const void* f2, float* out, int B, int C, int N1, int N2,
                    int in_dtype, int layout, mvStream_t stream);
+
+/* fp32 -> three bf16 planes (hi, mid, lo; residuals exact): planes[3][n] (uint16 bf16 bits), n % 4 == 0. */
+int mv_split_bf16x3(const float* x, void* planes, size_t n, mvStream_t stream);
 
 /* -------------------------------------------------------------------------------------------
  * A6  (2r+1)^2 bilinear window lookup in each query's own cost slice.

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmacvo_hip.so")
 
 MV_OK = 0
-MV_F32, MV_F16, MV_BF16 = 0, 1, 2
+MV_F32, MV_F16, MV_BF16, MV_BF16X3 = 0, 1, 2, 3
 MV_LAYOUT_CHW, MV_LAYOUT_HWC = 0, 1
 MV_KP_NODEPTH, MV_KP_FULL, MV_KP_MAPPING = 0, 1, 2
 MV_GRAPH_ICP, MV_GRAPH_REPROJ, MV_GRAPH_DISP = 0, 1, 2
@@ -53,6 +53,7 @@ SIGNATURES = {
     "mv_abi_version": (C.c_int, []),
     "mv_error_string": (C.c_char_p, [C.c_int]),
     "mv_corr_volume": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mv_split_bf16x3": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "mv_corr_lookup": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv_frontend_epilogue": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                        _P, _P, _P, _P, _P, _P, _P, _P]),

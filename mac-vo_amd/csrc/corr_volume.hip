@@ -115,7 +115,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ O, const f32x16 (
 // ------------------------------------------------------------------------------------------------
 // fp32, CHW ([C][N]) operands.  BK = 16.
 // ------------------------------------------------------------------------------------------------
-template <bool VEC4, int BK = 16, bool REMAP = true, bool NT = true, int ABLATE = 0>
+template <bool VEC4, int BK = 16, bool REMAP = true, bool NT = true>
 __global__ __launch_bounds__(256) void corr_volume_f32_chw(const float* __restrict__ f1,
                                                             const float* __restrict__ f2,
                                                             float* __restrict__ out, int C, int N1, int N2,
@@ -183,20 +183,14 @@ __global__ __launch_bounds__(256) void corr_volume_f32_chw(const float* __restri
     const int li = lane & 31;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (ABLATE != 1 && kt + 1 < nk) gload((kt + 1) * BK);
+        if (kt + 1 < nk) gload((kt + 1) * BK);
         mfma_tile_f32<BK, BM>(sA[buf], sB[buf], wm * 64 + li, wn * 64 + li, kh, acc);
-        if (ABLATE != 1 && kt + 1 < nk) {
+        if (kt + 1 < nk) {
             sstore(buf ^ 1);
             __syncthreads();
         }
     }
     const bool interior = (m0 + BM <= N1) && (n0 + BN <= N2);
-    if (ABLATE == 2) {  // keep acc live, store one value per lane
-        float sum = 0.f;
-        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
-        out[(size_t)b * N1 * N2 + (size_t)(m0 + wm * 64 + (lane >> 5)) * N2 + n0 + wn * 64 + li] = sum;
-        return;
-    }
     store_tile<NT>(out + (size_t)b * N1 * N2, acc, m0 + wm * 64, n0 + wn * 64, kh, li, N1, N2, interior);
 }
 
@@ -267,6 +261,128 @@ __global__ __launch_bounds__(256) void corr_volume_f32_hwc(const float* __restri
             sstore(buf ^ 1);
             __syncthreads();
         }
+    }
+    const bool interior = (m0 + BM <= N1) && (n0 + BN <= N2);
+    store_tile(out + (size_t)b * N1 * N2, acc, m0 + wm * 64, n0 + wn * 64, kh, li, N1, N2, interior);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// fp32 operands, HWC ([N][C]), bf16x3 SPLIT: each fp32 value is split on the fly into three bf16 pieces
+// (x = hi + mid + lo, 8 + 8 + 8 significant bits, exact residuals) and the fp32 product a*b is rebuilt from the six
+// bf16 MFMA products with i + j <= 2  (a0b2, a1b1, a2b0, a0b1, a1b0, a0b0 — smallest first), accumulated in fp32.
+// Dropped terms are O(2^-24 |a||b|): fp32-class accuracy at 6/16 of the fp32-MFMA cycle cost (gfx950 has no
+// TF32/xf32 MFMA; the reference itself runs this GEMM in TF32 or fp16, Module/Frontend/Frontend.py:275-278).
+// LDS: six [128][32] bf16 tiles (3 pieces x 2 operands, 48 KB), 16-B chunks XOR-swizzled by (row>>2)&3.
+// ------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// pre-pass: x[n] fp32 -> planes[3][n] bf16 (hi, mid, lo), x = hi + mid + lo up to 2^-24 |x|, residuals exact in fp32
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, uint16_t* __restrict__ planes, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        s16x4 h, m, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const __bf16 hb = (__bf16)v[e];
+            const float r1 = v[e] - (float)hb;
+            const __bf16 mb = (__bf16)r1;
+            const float r2 = r1 - (float)mb;
+            const __bf16 lb = (__bf16)r2;
+            h[e] = __builtin_bit_cast(short, hb);
+            m[e] = __builtin_bit_cast(short, mb);
+            l[e] = __builtin_bit_cast(short, lb);
+        }
+        reinterpret_cast<s16x4*>(planes)[i] = h;
+        reinterpret_cast<s16x4*>(planes + n4 * 4)[i] = m;
+        reinterpret_cast<s16x4*>(planes + 2 * n4 * 4)[i] = l;
+    }
+}
+
+// GEMM over pre-split planes: operands are [3][B][N][C] bf16 (piece-major).  Per K-tile of 32 the six [128][32] bf16
+// tiles (3 pieces x 2 operands, 48 KB, single buffer, register prefetch of the next tile) feed 6 x 4 x 2 = 48 MFMAs per
+// wave; 3 workgroups per CU interleave their load / MFMA phases.  No VALU work besides addressing.
+__global__ __launch_bounds__(256) void corr_volume_bf16x3_hwc(const uint16_t* __restrict__ p1,
+                                                               const uint16_t* __restrict__ p2,
+                                                               float* __restrict__ out, int C, int N1, int N2, int Bn,
+                                                               int tiles_m, int tiles_n) {
+    constexpr int BK = 32;
+    constexpr int CH = BK / 8;                   // 16-B chunks per row = 4
+    constexpr int TILE = BM * CH;                // s16x8 elements per [128][32] tile
+    __shared__ __attribute__((aligned(16))) s16x8 smem[6 * TILE];
+
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    const int b = blockIdx.z;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const size_t plane1 = (size_t)Bn * N1 * C, plane2 = (size_t)Bn * N2 * C;
+    const uint16_t* A = p1 + (size_t)b * N1 * C;
+    const uint16_t* Bp = p2 + (size_t)b * N2 * C;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kh = lane >> 5, li = lane & 31;
+
+    // loader: per tile 128 rows x 4 chunks = 512 chunks; thread t -> (row = t/4 + 64*p, chunk = t%4), p < 2
+    const int lrow = t >> 2, lch = t & 3;
+    s16x8 r[6][2];
+    const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int ia = m0 + lrow + 64 * p, ib = n0 + lrow + 64 * p;
+                r[pc][p] = (ia < N1) ? *reinterpret_cast<const s16x8*>(A + pc * plane1 + (size_t)ia * C + k0 + lch * 8) : zero;
+                r[3 + pc][p] = (ib < N2) ? *reinterpret_cast<const s16x8*>(Bp + pc * plane2 + (size_t)ib * C + k0 + lch * 8) : zero;
+            }
+    };
+    auto swz = [](int row, int c) { return row * CH + (c ^ ((row >> 2) & 3)); };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int tl = 0; tl < 6; ++tl)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) smem[tl * TILE + swz(lrow + 64 * p, lch)] = r[tl][p];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    const int nk = C / BK;
+    gload(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        sstore();
+        __syncthreads();
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int c = ks * 2 + kh;
+            bf16x8 a[3][2], bb[3][2];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[pc][i] = __builtin_bit_cast(bf16x8, smem[pc * TILE + swz(wm * 64 + i * 32 + li, c)]);
+                    bb[pc][i] = __builtin_bit_cast(bf16x8, smem[(3 + pc) * TILE + swz(wn * 64 + i * 32 + li, c)]);
+                }
+            // smallest products first: (a0,b2) (a1,b1) (a2,b0) (a0,b1) (a1,b0) (a0,b0)
+            constexpr int PA[6] = {0, 1, 2, 0, 1, 0};
+            constexpr int PB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], bb[PB[q]][j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
     }
     const bool interior = (m0 + BM <= N1) && (n0 + BN <= N2);
     store_tile(out + (size_t)b * N1 * N2, acc, m0 + wm * 64, n0 + wn * 64, kh, li, N1, N2, interior);
@@ -493,27 +609,18 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
         const float* a = (const float*)f1;
         const float* b = (const float*)f2;
         if (layout == MV_LAYOUT_CHW) {
-            static int variant = -1;
-            if (variant < 0) { const char* e = getenv("MV_VOL_VARIANT"); variant = e ? atoi(e) : 0; }
-            if ((N1 % 4 == 0) && (N2 % 4 == 0) && variant == 1 && C % 32 == 0)
-                hipLaunchKernelGGL((corr_volume_f32_chw<true, 32>), grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
-            else if ((N1 % 4 == 0) && (N2 % 4 == 0) && variant == 2)
-                hipLaunchKernelGGL((corr_volume_f32_chw<true, 16, false>), grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
-            else if ((N1 % 4 == 0) && (N2 % 4 == 0) && variant == 3)
-                hipLaunchKernelGGL((corr_volume_f32_chw<true, 16, true, false>), grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
-            else if ((N1 % 4 == 0) && (N2 % 4 == 0) && variant == 4)
-                hipLaunchKernelGGL((corr_volume_f32_chw<true, 8>), grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
-            else if ((N1 % 4 == 0) && (N2 % 4 == 0) && variant == 5)
-                hipLaunchKernelGGL((corr_volume_f32_chw<true, 16, true, true, 1>), grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
-            else if ((N1 % 4 == 0) && (N2 % 4 == 0) && variant == 6)
-                hipLaunchKernelGGL((corr_volume_f32_chw<true, 16, true, true, 2>), grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
-            else if ((N1 % 4 == 0) && (N2 % 4 == 0))
+            if ((N1 % 4 == 0) && (N2 % 4 == 0))
                 hipLaunchKernelGGL(corr_volume_f32_chw<true>, grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
             else
                 hipLaunchKernelGGL(corr_volume_f32_chw<false>, grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
         } else {
             hipLaunchKernelGGL(corr_volume_f32_hwc, grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
         }
+    } else if (in_dtype == MV_BF16X3) {
+        // f1 / f2 = planes produced by mv_split_bf16x3: [3][B][N][C] bf16
+        if (layout != MV_LAYOUT_HWC || (C % 32)) return MV_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(corr_volume_bf16x3_hwc, grid, block, 0, s, (const uint16_t*)f1, (const uint16_t*)f2, out, C, N1,
+                           N2, B, tiles_m, tiles_n);
     } else if (in_dtype == MV_F16 || in_dtype == MV_BF16) {
         const uint16_t* a = (const uint16_t*)f1;
         const uint16_t* b = (const uint16_t*)f2;
@@ -534,5 +641,14 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
     } else {
         return MV_ERR_INVALID_ARG;
     }
+    return mv_launch_status();
+}
+
+extern "C" int mv_split_bf16x3(const float* x, void* planes, size_t n, mvStream_t stream) {
+    MV_CHECK_ARG(x && planes && n > 0 && (n % 4) == 0);
+    MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)planes & 7) == 0);
+    const size_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(split3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)planes, n4);
     return mv_launch_status();
 }

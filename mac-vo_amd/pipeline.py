@@ -64,6 +64,7 @@ class HotPathConfig:
     filter_min_depth: float = 0.05
     radius: int = 4
     feature_layout: str = "chw"
+    volume_precision: str = "exact"      # "exact" fp32 MFMA | "split3" bf16x3 (fp32 features in layout "hwc")
 
 
 @dataclass
@@ -120,7 +121,7 @@ class HotPath:
         c = self.cfg
         if self._vol is None or self._vol.shape[0] != x.fmap1.shape[0] * x.coords.shape[-1] * x.coords.shape[-2]:
             self._vol = None
-        self._vol = ops.corr_volume(x.fmap1, x.fmap2, layout=c.feature_layout, out=self._vol)
+        self._vol = ops.corr_volume(x.fmap1, x.fmap2, layout=c.feature_layout, out=self._vol, precision=c.volume_precision)
         for it in range(x.coords.shape[0]):
             self._tok = ops.corr_lookup(self._vol, x.coords[it], c.radius, out=self._tok)
         self.last_tokens = self._tok

@@ -53,6 +53,29 @@ def test_corr_volume_f32_hwc(gpu, shape):
     assert (out.double() - ref64).abs().max().item() <= 2e-5 * float(C) ** 0.5
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 8, 12), (1, 256, 60, 80), (1, 96, 5, 7), (1, 256, 16, 24)])
+def test_corr_volume_f32_split3(gpu, shape):
+    """bf16x3 split mode: fp32 operands rebuilt from six bf16 MFMA products.  Same tolerance as the exact fp32 path
+    (2e-5 * sqrt(C) absolute vs a float64 einsum) — i.e. fp32-class accuracy, far tighter than the TF32/fp16 the
+    reference runs this GEMM in (Frontend.py:275-278)."""
+    from macvo_amd import ops
+    from oracle import corr
+
+    B, C, H, W = shape
+    f1, f2 = _feats(B, C, H, W, seed=5)
+    f1[0, :, 0, 0] *= 1e3       # wide dynamic range within a row
+    f2[0, :, 0, 1] *= 1e-3
+    ref64 = corr.corr_volume(f1, f2, torch.float64)
+    a1, a2 = f1.permute(0, 2, 3, 1).contiguous().to(gpu), f2.permute(0, 2, 3, 1).contiguous().to(gpu)
+    out = ops.corr_volume(a1, a2, layout="hwc", precision="split3").cpu()
+    err = (out.double() - ref64).abs()
+    scale = (f1.double().abs().reshape(B, C, -1).permute(0, 2, 1).unsqueeze(2) * f2.double().abs().reshape(B, C, -1).permute(0, 2, 1).unsqueeze(1)).sum(-1)
+    assert (err / scale.reshape(err.shape).clamp_min(1e-30)).max().item() <= 1e-6     # relative to sum |a||b|
+    exact = ops.corr_volume(a1, a2, layout="hwc").cpu()
+    e_exact = (exact.double() - ref64).abs()
+    assert err.max() <= 1.5 * e_exact.max() + 1e-6                                     # no worse than the exact fp32 path
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("layout", ["chw", "hwc"])
 @pytest.mark.parametrize("shape", [(2, 64, 8, 12), (1, 256, 60, 80), (1, 128, 9, 11)])

@@ -55,6 +55,8 @@ def main():
             a1, a2 = f1.permute(0, 2, 3, 1).contiguous(), f2.permute(0, 2, 3, 1).contiguous()
             med, mn = timeit(lambda: ops.corr_volume(a1, a2, "hwc", out=vol), a.iters)
             print(f"volume_f32_hwc  B={B} {med:8.1f} us (min {mn:.1f})  {flops / med / 1e6:7.1f} TFLOP/s")
+            med, mn = timeit(lambda: ops.corr_volume(a1, a2, "hwc", out=vol, precision="split3"), a.iters)
+            print(f"volume_split3_hwc B={B} {med:6.1f} us (min {mn:.1f})  {flops / med / 1e6:7.1f} TFLOP/s algorithmic")
         elif w == "volume_f16":
             for dt in (torch.float16, torch.bfloat16):
                 a1, a2 = f1.permute(0, 2, 3, 1).contiguous().to(dt), f2.permute(0, 2, 3, 1).contiguous().to(dt)
