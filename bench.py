@@ -154,6 +154,15 @@ def main():
     flops_per_launch = pairs * 2.0 * n_q * n_q * C                       # 2*N^2*C per pair
     esz = 4 if args.feat_dtype == "f32" else 2
     bytes_per_launch = pairs * (2.0 * n_q * C * esz + 4.0 * n_q * n_q)   # read f1,f2 + write fp32 volume
+    # HBM traffic of the dominant kernel from a committed rocprofv3 --pmc pass over the same launch configuration
+    # (scripts/pmc_gpu.sh -> profiles/r01_pmc_corr_volume.json; PMC passes cannot be mixed into this run)
+    traffic = None
+    try:
+        if H == 480 and W == 640 and C == 256 and args.feat_dtype == "f32" and args.volume_precision == "exact":
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_corr_volume.json")))
+            traffic = pm["corr_volume_f32_" + args.layout]["_derived"]["traffic_bytes_per_launch"]
+    except Exception:  # noqa: BLE001
+        traffic = None
     roofline = None
     if vol_events:
         ms = [a.elapsed_time(b) for a, b in vol_events]
@@ -169,7 +178,7 @@ def main():
         elif args.feat_dtype == "f32":
             ach = flops_per_launch / avg_s / 1e12
             roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                         "kernel": "corr_volume_f32_" + args.layout, "avg_launch_us": round(avg_s * 1e6, 2),
                         "launches": len(ms), "algorithmic_flops_per_launch": flops_per_launch,
                         "algorithmic_bytes_per_launch": bytes_per_launch}
