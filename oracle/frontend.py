@@ -115,3 +115,12 @@ def upsample_flow(flow: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     up = torch.sum(mask * up, dim=2)
     up = up.permute(0, 1, 4, 2, 5, 3)
     return up.reshape(N, C, 8 * H, 8 * W)
+
+
+def upsample_and_epilogue(flow8: torch.Tensor, mask_flow: torch.Tensor, cov8: torch.Tensor, mask_cov: torch.Tensor):
+    """Last decoder iteration's tail (``covhead.py:119-140`` + ``flownet.py:44``): convex-upsample the 1/8-res flow with
+    ``0.25 * up_mask`` already applied by the caller for the flow branch (:121) and the cov branch's mask as produced
+    by ``CovUpdateBlock`` (0.25 applied inside, :41); returns ``(flow_up, exp(2 * cov_up))``."""
+    flow_up = upsample_flow(flow8, mask_flow)
+    cov_up = upsample_flow(cov8, mask_cov)
+    return flow_up, torch.exp(cov_up * 2)
