@@ -102,6 +102,17 @@ int mv_frontend_epilogue(const float* flow, const float* logcov, int cov_is_log,
                          float* match_cov, mvStream_t stream);
 
 /* -------------------------------------------------------------------------------------------
+ * §8(f) rank 1  convex 8x upsampling (RAFT / FlowFormer `upsample_flow`), optionally fused with exp(2*x).
+ * Replaces MemoryDecoder.upsample_flow at Module/Network/FlowFormerCov/covhead.py:124-126,133-135 (in-tree twin
+ * Module/Network/PWCNet/pwc_cov/gru.py:40-52) and, with exp2_out = 1, the exp(2*cov) of flownet.py:44.
+ *   flow [B, 2, h, w] fp32 (1/8 resolution);  mask [B, 576, h, w] fp32 (channel = tap*64 + sy*8 + sx)
+ *   out  [B, 2, 8h, 8w] fp32 = sum_tap softmax_tap(mask_scale * mask) * (8 * flow at the tap's 3x3 neighbour, zero pad)
+ *   mask_scale: 0.25 for the flow branch (covhead.py:121), 1.0 for the log-sigma branch (scaled inside CovUpdateBlock :41)
+ */
+int mv_convex_upsample(const float* flow, const float* mask, float* out, int B, int h, int w,
+                       float mask_scale, int exp2_out, mvStream_t stream);
+
+/* -------------------------------------------------------------------------------------------
  * A10/A11 + MappingPointSelector  candidate generation for the covariance-aware keypoint selectors.
  * Replaces the dense part of Module/KeypointSelector.py: CovAwareSelector_NoDepth.select_point :362-400,
  * CovAwareSelector.select_point :260-327, MappingPointSelector.select_point :87-97 — quality map,

@@ -57,6 +57,7 @@ SIGNATURES = {
     "mv_corr_lookup": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv_frontend_epilogue": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                        _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mv_convex_upsample": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P]),
     "mv_kp_select_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mv_kp_select": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(mvKpSelectParams), _P, C.c_size_t,
                                _P, _P, _P, _P]),

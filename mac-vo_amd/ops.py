@@ -145,6 +145,20 @@ def frontend_epilogue(flow: torch.Tensor, cov: torch.Tensor, baseline: float, fx
     return FrontendMaps(depth, depth_cov, disparity, disparity_cov, bad, mflow, mcov)
 
 
+def convex_upsample(flow8: torch.Tensor, mask: torch.Tensor, mask_scale: float = 1.0, exp2_out: bool = False) -> torch.Tensor:
+    """RAFT / FlowFormer ``upsample_flow`` (covhead.py:124-126,133-135): ``[B,2,h,w], [B,576,h,w] -> [B,2,8h,8w]``;
+    ``exp2_out`` fuses the ``exp(2 * cov)`` of flownet.py:44."""
+    lib = L.load()
+    flow8 = _req(flow8, torch.float32, "flow8")
+    mask = _req(mask, torch.float32, "mask")
+    B, two, h, w = flow8.shape
+    assert two == 2 and mask.shape == (B, 576, h, w)
+    out = torch.empty((B, 2, 8 * h, 8 * w), dtype=torch.float32, device=flow8.device)
+    L.check(lib.mv_convex_upsample(flow8.data_ptr(), mask.data_ptr(), out.data_ptr(), B, h, w, float(mask_scale),
+                                   int(exp2_out), _stream()), "mv_convex_upsample")
+    return out
+
+
 # ------------------------------------------------------------------------------------------- A10 / A11
 class KeypointCandidates:
     """Device-side result of the dense selector stage; ``finish`` applies the reference's CPU randperm."""

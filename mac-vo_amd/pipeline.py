@@ -79,8 +79,14 @@ class FrameInputs:
     fmap1: torch.Tensor
     fmap2: torch.Tensor
     coords: torch.Tensor
-    flow: torch.Tensor
-    logcov: torch.Tensor
+    flow: torch.Tensor | None = None
+    logcov: torch.Tensor | None = None
+    # alternative to flow/logcov: the last decoder iteration's 1/8-resolution fields and convex
+    # upsampling masks (covhead.py:119-135); the hot path then runs mv_convex_upsample (+ fused exp(2*cov)) itself
+    flow8: torch.Tensor | None = None        # [2, 2, H/8, W/8]  coords1 - coords0
+    cov8: torch.Tensor | None = None         # [2, 2, H/8, W/8]  cov_coords1 - cov_coords0
+    up_mask: torch.Tensor | None = None      # [2, 576, H/8, W/8] flow branch mask BEFORE the 0.25 scale (:121)
+    cov_mask: torch.Tensor | None = None     # [2, 576, H/8, W/8] log-sigma branch mask (0.25 already applied, :41)
 
 
 @dataclass
@@ -125,6 +131,10 @@ class HotPath:
         for it in range(x.coords.shape[0]):
             self._tok = ops.corr_lookup(self._vol, x.coords[it], c.radius, out=self._tok)
         self.last_tokens = self._tok
+        if x.flow8 is not None:
+            flow = ops.convex_upsample(x.flow8, x.up_mask, mask_scale=0.25)
+            cov = ops.convex_upsample(x.cov8, x.cov_mask, mask_scale=1.0, exp2_out=True)     # exp(2*cov) fused
+            return ops.frontend_epilogue(flow, cov, self.cam.baseline, self.cam.fx, cov_is_log=False)
         return ops.frontend_epilogue(x.flow, x.logcov, self.cam.baseline, self.cam.fx, cov_is_log=True)
 
     def initialize(self, x: FrameInputs, init_pose: torch.Tensor | None = None) -> None:

@@ -37,10 +37,15 @@ class OracleHotPath:
         vol = corr.corr_volume(f1, f2, torch.float32)
         for it in range(x["coords"].shape[0]):
             self.last_tokens = corr.corr_lookup(vol, x["coords"][it], self.cfg["radius"])
-        cov = torch.exp(x["logcov"] * 2)                                               # flownet.py:44
-        depth, depth_cov, disp, disp_cov, _ = frontend.inference_2_depth(x["flow"][0:1], cov[0:1], self.cam["baseline"], self.cam["fx"])
+        if x.get("flow8") is not None:                                                 # covhead.py:119-135
+            flow = frontend.upsample_flow(x["flow8"], 0.25 * x["up_mask"])
+            cov = torch.exp(frontend.upsample_flow(x["cov8"], x["cov_mask"]) * 2)
+        else:
+            flow = x["flow"]
+            cov = torch.exp(x["logcov"] * 2)                                           # flownet.py:44
+        depth, depth_cov, disp, disp_cov, _ = frontend.inference_2_depth(flow[0:1], cov[0:1], self.cam["baseline"], self.cam["fx"])
         return dict(depth=depth, cov=depth_cov, disparity=disp, disparity_uncertainty=disp_cov,
-                    flow=x["flow"][1:2], flow_cov=frontend.from_partial_cov(cov[1:2]))
+                    flow=flow[1:2], flow_cov=frontend.from_partial_cov(cov[1:2]))
 
     def initialize(self, x: dict, init_pose=None):
         self.maps_prev = self.frontend(x)

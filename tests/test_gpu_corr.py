@@ -171,3 +171,26 @@ def test_corr_lookup_far_outside_and_nan(gpu):
     coords[0, 0, 0, 0] = float("nan")
     ops.corr_lookup(vol.to(gpu), coords.to(gpu), 4)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B,h,w", [(2, 60, 80), (1, 7, 9), (3, 16, 24)])
+def test_convex_upsample(gpu, B, h, w):
+    """§8(f) rank 1: convex 8x upsampling vs the oracle (softmax over 9 taps of unfold(8*flow)); exp(2x) fused variant."""
+    from macvo_amd import ops
+    from oracle import frontend
+
+    g = torch.Generator().manual_seed(31)
+    flow8 = torch.randn(B, 2, h, w, generator=g) * 3
+    mask = torch.randn(B, 576, h, w, generator=g) * 4
+    ref = frontend.upsample_flow(flow8, 0.25 * mask)
+    out = ops.convex_upsample(flow8.to(gpu), mask.to(gpu), mask_scale=0.25).cpu()
+    assert out.shape == (B, 2, 8 * h, 8 * w)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=2e-5)
+    cov8 = torch.randn(B, 2, h, w, generator=g) * 0.05
+    ref2 = torch.exp(frontend.upsample_flow(cov8, mask) * 2)
+    out2 = ops.convex_upsample(cov8.to(gpu), mask.to(gpu), mask_scale=1.0, exp2_out=True).cpu()
+    torch.testing.assert_close(out2, ref2, rtol=2e-5, atol=1e-6)
+    # convexity: a constant field is reproduced exactly in the interior (weights sum to 1)
+    const = torch.full((1, 2, h, w), 0.5)
+    up = ops.convex_upsample(const.to(gpu), mask[:1].to(gpu)).cpu()
+    assert (up[..., 8:-8, 8:-8] - 4.0).abs().max() < 1e-5

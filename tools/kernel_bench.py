@@ -75,6 +75,12 @@ def main():
             byts = B * (n * 100 * 4 + n * 8 + n * 81 * 4.0)
             med, mn = timeit(lambda: ops.corr_lookup(vol, coords, 4, out=tok), a.iters)
             print(f"lookup r=4      B={B} {med:8.1f} us (min {mn:.1f})  {byts / med / 1e3:7.1f} GB/s algorithmic")
+        elif w == "upsample":
+            fl = torch.randn(B, 2, h8, w8, generator=g).to(dev)
+            mk = torch.randn(B, 576, h8, w8, generator=g).to(dev)
+            byts = B * (578 * n * 4 + 2 * 64 * n * 4.0)
+            med, mn = timeit(lambda: ops.convex_upsample(fl, mk, 0.25), a.iters)
+            print(f"convex_upsample B={B} {med:8.1f} us (min {mn:.1f})  {byts / med / 1e3:7.1f} GB/s  {byts / med / 1e3 / 8000 * 100:.1f}% of HBM peak")
         elif w == "select":
             fc = synth.flow_cov_maps(H, W, 2).to(dev)
             d0, d0c = [t.to(dev) for t in synth.depth_maps(H, W, 3)]
