@@ -79,13 +79,17 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
     return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
-constexpr int PGO_THREADS = 256;
-constexpr int PGO_WAVES = PGO_THREADS / 64;
 constexpr int NRED = 55;  // 21 + 6 + 21 + 6 + 1
 
-// workgroup sum of `n` per-thread values: DPP inside the wave, LDS table across the 4 waves; every thread gets all sums
-template <int N>
+// workgroup sum of `n` per-thread values: DPP inside the wave, LDS table across the NW waves; every thread gets all sums.
+// NW = 1 (throughput variant, one wave per problem) needs no LDS and no barrier at all.
+template <int N, int NW>
 __device__ __forceinline__ void block_sum(double (&v)[N], double (*__restrict__ tab)[NRED]) {
+    if (NW == 1) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = wave_sum_dpp(v[k]);
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -97,7 +101,7 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double (*__restrict__ 
     for (int k = 0; k < N; ++k) {
         double s = tab[0][k];
 #pragma unroll
-        for (int w = 1; w < PGO_WAVES; ++w) s += tab[w][k];
+        for (int w = 1; w < NW; ++w) s += tab[w][k];
         v[k] = s;
     }
     __syncthreads();
@@ -126,7 +130,15 @@ __device__ void se3_left_update(Pose& P, const double* D) {
     const double th2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
     const double th = sqrt(th2);
     double c1, c2, imag, real;
-    if (th > eps) {
+    if (th2 < 1.0e-2) {
+        // |phi| < 0.1 rad (every LM step but a wild first one): Taylor series, truncation error < 3e-16 relative —
+        // below the cancellation noise of PyPose's own closed forms at these angles — and no fp64 sin/cos calls
+        const double h2 = 0.25 * th2;  // (theta/2)^2
+        c1 = 0.5 - th2 * (1.0 / 24.0 - th2 * (1.0 / 720.0 - th2 * (1.0 / 40320.0 - th2 * (1.0 / 3628800.0))));
+        c2 = 1.0 / 6.0 - th2 * (1.0 / 120.0 - th2 * (1.0 / 5040.0 - th2 * (1.0 / 362880.0 - th2 * (1.0 / 39916800.0))));
+        imag = 0.5 * (1.0 - h2 * (1.0 / 6.0 - h2 * (1.0 / 120.0 - h2 * (1.0 / 5040.0 - h2 * (1.0 / 362880.0)))));
+        real = 1.0 - h2 * (0.5 - h2 * (1.0 / 24.0 - h2 * (1.0 / 720.0 - h2 * (1.0 / 40320.0 - h2 * (1.0 / 3628800.0)))));
+    } else if (th > eps) {
         c1 = (1.0 - cos(th)) / th2;
         c2 = (th - sin(th)) / (th * th2);
         imag = sin(0.5 * th) / th;
@@ -382,9 +394,10 @@ __device__ __forceinline__ void accumulate_point(const Geometry& g, const mvLMPa
     }
 }
 
-template <int GT>
-__global__ __launch_bounds__(PGO_THREADS) void pgo_solve_kernel(PgoArgs a, mvLMParams lm) {
-    __shared__ double red_tab[PGO_WAVES][NRED];
+template <int GT, int NW>
+__global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParams lm) {
+    constexpr int PGO_THREADS = 64 * NW;
+    __shared__ double red_tab[NW][NRED];
     const int prob = blockIdx.x;
     const int tid = threadIdx.x;
     const int beg = a.offsets[prob], end = a.offsets[prob + 1];
@@ -421,7 +434,7 @@ __global__ __launch_bounds__(PGO_THREADS) void pgo_solve_kernel(PgoArgs a, mvLMP
         } else {
             for (int i = beg + tid; i < end; i += PGO_THREADS) nv[0] += (a.valid ? (a.valid[i] != 0) : 1) ? 1.0 : 0.0;
         }
-        block_sum<1>(nv, red_tab);
+        block_sum<1, NW>(nv, red_tab);
         if ((int)nv[0] < a.min_points) continual = false;
     }
 
@@ -439,7 +452,7 @@ __global__ __launch_bounds__(PGO_THREADS) void pgo_solve_kernel(PgoArgs a, mvLMP
                 if (d.valid) accumulate_point<GT>(g, lm, P, d, acc);
             }
         }
-        block_sum<NRED>(acc, red_tab);
+        block_sum<NRED, NW>(acc, red_tab);
         double* Aw = acc;
         const double* gw = acc + 21;
         const double* Au = acc + 27;
@@ -514,7 +527,7 @@ __global__ __launch_bounds__(PGO_THREADS) void pgo_solve_kernel(PgoArgs a, mvLMP
                     }
                 }
             }
-            block_sum<1>(la, red_tab);
+            block_sum<1, NW>(la, red_tab);
             loss = la[0];
 
             // TrustRegion.update: quality = (last - loss) / -((J D)^T (2 R + J D)) on the corrected, unweighted J, R
@@ -598,22 +611,29 @@ extern "C" int mv_pgo_solve(int nprob, const int32_t* offsets, int graph_type, c
     PgoArgs a{offsets, init_pose, intrinsics, baseline, pos_Tw, cov_Tw, pixel2_uv, pixel2_d, pixel2_disp,
               pixel2_disp_cov, pixel2_uv_cov, obs2_covTc, valid, min_points, out_pose, out_info, out_pose_f32};
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(nprob), block(PGO_THREADS);
+    // latency variant (4 waves per problem, one point per thread in registers) for small batches; throughput variant
+    // (1 wave per problem, 4x more problems resident per CU) once the batch alone fills the chip
+    const bool wide = nprob < 512;
+    dim3 grid(nprob), block(wide ? 256 : 64);
+#define MV_PGO(G)                                                                             \
+    if (wide) hipLaunchKernelGGL((pgo_solve_kernel<G, 4>), grid, block, 0, s, a, *params);    \
+    else hipLaunchKernelGGL((pgo_solve_kernel<G, 1>), grid, block, 0, s, a, *params)
     switch (graph_type) {
         case MV_GRAPH_ICP:
             MV_CHECK_ARG(cov_Tw && obs2_covTc && pixel2_d);
-            hipLaunchKernelGGL(pgo_solve_kernel<MV_GRAPH_ICP>, grid, block, 0, s, a, *params);
+            MV_PGO(MV_GRAPH_ICP);
             break;
         case MV_GRAPH_REPROJ:
             MV_CHECK_ARG(pixel2_uv_cov);
-            hipLaunchKernelGGL(pgo_solve_kernel<MV_GRAPH_REPROJ>, grid, block, 0, s, a, *params);
+            MV_PGO(MV_GRAPH_REPROJ);
             break;
         case MV_GRAPH_DISP:
             MV_CHECK_ARG(pixel2_uv_cov && pixel2_disp && pixel2_disp_cov);
-            hipLaunchKernelGGL(pgo_solve_kernel<MV_GRAPH_DISP>, grid, block, 0, s, a, *params);
+            MV_PGO(MV_GRAPH_DISP);
             break;
         default:
             return MV_ERR_INVALID_ARG;
     }
+#undef MV_PGO
     return mv_launch_status();
 }
