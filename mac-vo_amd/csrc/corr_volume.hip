@@ -11,7 +11,13 @@
 //   * 16-bit inputs (Fast mode): v_mfma_f32_32x32x16_{f16,bf16}, fp32 accumulate, fp32 out — HBM-write bound.
 //   * 128x128 output tile per 256-thread workgroup (4 waves, 64x64 each = 2x2 MFMA blocks, 64 acc VGPRs),
 //     double-buffered LDS, register-staged global prefetch.
-//   * stores: each v_mfma C register row is 32 consecutive floats (128 B line) per half-wave.
+//   * stores: each v_mfma C register row is 32 consecutive floats = one full 128-B line per half-wave and instruction.
+//     (Measured alternative: swapping the MFMA operands gives each lane 4 consecutive columns -> 16 dwordx4 stores
+//     instead of 64 dword stores per wave, but every instruction then writes 32 B into 32 different lines: the
+//     16-bit kernel went 59 -> 112 us, the fp32 kernel 250 -> 279 us.  Full-line stores win.  An LDS-staged epilogue
+//     with dwordx4 stores of whole 256-B row segments measured the same as the direct one (59 us), so the 16-bit
+//     kernel's distance to the 27-30 us of a pure 184-MB fill is not store-instruction count; BK 32 vs 64 and nt vs
+//     plain stores are also within noise.)
 #include "common.h"
 #include <stdlib.h>
 
@@ -111,6 +117,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ O, const f32x16 (
             }
     }
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // fp32, CHW ([C][N]) operands.  BK = 16.
@@ -393,13 +400,17 @@ __global__ __launch_bounds__(256) void corr_volume_bf16x3_hwc(const uint16_t* __
 // (lane l holds 8 consecutive k of row l&31, k-group l>>5).  BK = 64: a tile row is one 128-B line.
 // LDS tile [128 rows][64 k] 16-bit, 16-B chunks XOR-swizzled by (row & 7) so ds_read_b128 is conflict-free.
 // ------------------------------------------------------------------------------------------------
-template <bool IS_BF16>
+template <bool IS_BF16, int BK, bool NT = true>
 __global__ __launch_bounds__(256) void corr_volume_h_hwc(const uint16_t* __restrict__ f1,
                                                           const uint16_t* __restrict__ f2,
                                                           float* __restrict__ out, int C, int N1, int N2,
                                                           int tiles_m, int tiles_n) {
-    constexpr int BK = 64;                  // 16-bit elements per tile row (128 B)
-    constexpr int CH = BK / 8;              // 16-byte chunks per row = 8
+    // BK 16-bit elements per tile row: 64 -> one 128-B line per row, 64 KB LDS, 2 workgroups / CU;
+    //                                  32 -> half lines, 32 KB LDS, 4 workgroups / CU (more loads in flight: the kernel
+    //                                  is latency-bound, its MFMA work is ~1 us per workgroup)
+    constexpr int CH = BK / 8;              // 16-byte chunks per row
+    constexpr int RPP = 256 / CH;           // rows covered per loader pass
+    constexpr int NPASS = BM / RPP;
     __shared__ __attribute__((aligned(16))) s16x8 sA[2][BM * CH];
     __shared__ __attribute__((aligned(16))) s16x8 sB[2][BN * CH];
 
@@ -414,24 +425,25 @@ __global__ __launch_bounds__(256) void corr_volume_h_hwc(const uint16_t* __restr
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // loader: 128 rows x 8 chunks = 1024 chunks per operand; thread t -> (row = t/8 + 32*p, chunk = t%8), p < 4
-    const int lrow = t >> 3, lch = t & 7;
-    s16x8 ra[4], rb[4];
+    const int lrow = t / CH, lch = t % CH;
+    s16x8 ra[NPASS], rb[NPASS];
     const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int ia = m0 + lrow + 32 * p, ib = n0 + lrow + 32 * p;
+        for (int p = 0; p < NPASS; ++p) {
+            const int ia = m0 + lrow + RPP * p, ib = n0 + lrow + RPP * p;
             ra[p] = (ia < N1) ? *reinterpret_cast<const s16x8*>(A + (size_t)ia * C + k0 + lch * 8) : zero;
             rb[p] = (ib < N2) ? *reinterpret_cast<const s16x8*>(Bp + (size_t)ib * C + k0 + lch * 8) : zero;
         }
     };
+    // conflict-free ds_read_b128: a 16-lane service group must hit 16 distinct 16-B slots of the 256-B bank row
+    auto swz = [](int row, int c) { return row * CH + (c ^ (CH == 8 ? (row & 7) : ((row >> 2) & 3))); };
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int row = lrow + 32 * p;
-            sA[buf][row * CH + (lch ^ (row & 7))] = ra[p];
-            sB[buf][row * CH + (lch ^ (row & 7))] = rb[p];
+        for (int p = 0; p < NPASS; ++p) {
+            const int row = lrow + RPP * p;
+            sA[buf][swz(row, lch)] = ra[p];
+            sB[buf][swz(row, lch)] = rb[p];
         }
     };
 
@@ -452,19 +464,13 @@ __global__ __launch_bounds__(256) void corr_volume_h_hwc(const uint16_t* __restr
         const int buf = kt & 1;
         if (kt + 1 < nk) gload((kt + 1) * BK);
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {   // 4 MFMA k-steps of 16
+        for (int ks = 0; ks < BK / 16; ++ks) {   // MFMA k-steps of 16
             const int ch = ks * 2 + kh;          // 16-B chunk holding this lane's 8 k values
             s16x8 a[2], bb[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = wm * 64 + i * 32 + li;
-                a[i] = sA[buf][row * CH + (ch ^ (row & 7))];
-            }
+            for (int i = 0; i < 2; ++i) a[i] = sA[buf][swz(wm * 64 + i * 32 + li, ch)];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = wn * 64 + j * 32 + li;
-                bb[j] = sB[buf][row * CH + (ch ^ (row & 7))];
-            }
+            for (int j = 0; j < 2; ++j) bb[j] = sB[buf][swz(wn * 64 + j * 32 + li, ch)];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -483,7 +489,7 @@ __global__ __launch_bounds__(256) void corr_volume_h_hwc(const uint16_t* __restr
         }
     }
     const bool interior = (m0 + BM <= N1) && (n0 + BN <= N2);
-    store_tile(out + (size_t)b * N1 * N2, acc, m0 + wm * 64, n0 + wn * 64, kh, li, N1, N2, interior);
+    store_tile<NT>(out + (size_t)b * N1 * N2, acc, m0 + wm * 64, n0 + wn * 64, kh, li, N1, N2, interior);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -626,11 +632,16 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
         const uint16_t* b = (const uint16_t*)f2;
         const bool bf = in_dtype == MV_BF16;
         if (layout == MV_LAYOUT_HWC) {
-            if (C % 64) return MV_ERR_UNSUPPORTED;
-            if (bf)
-                hipLaunchKernelGGL(corr_volume_h_hwc<true>, grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
-            else
-                hipLaunchKernelGGL(corr_volume_h_hwc<false>, grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
+            if (C % 32) return MV_ERR_UNSUPPORTED;
+            static int hbk = -1;
+            if (hbk < 0) { const char* e = getenv("MV_H_BK"); hbk = e ? atoi(e) : 32; }
+            if (hbk == 64 && (C % 64) == 0) {
+                if (bf) hipLaunchKernelGGL((corr_volume_h_hwc<true, 64>), grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
+                else hipLaunchKernelGGL((corr_volume_h_hwc<false, 64>), grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
+            } else {
+                if (bf) hipLaunchKernelGGL((corr_volume_h_hwc<true, 32>), grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
+                else hipLaunchKernelGGL((corr_volume_h_hwc<false, 32>), grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
+            }
         } else {
             if (C % 32) return MV_ERR_UNSUPPORTED;
             if (bf)
