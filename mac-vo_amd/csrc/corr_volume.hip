@@ -46,8 +46,16 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int& tm, i
     const int q = nwg >> 3, r = nwg & 7;
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     const int lin = base + (id >> 3);
-    tm = lin / tiles_n;
-    tn = lin - tm * tiles_n;
+    // inside an XCD's contiguous range, walk "super-rows" of RG tile rows column by column: consecutive workgroups share
+    // one f2 column tile (128 KB) and cycle through RG f1 row tiles (RG x 128 KB), which fits the 4 MB L2 with room to
+    // spare, instead of streaming all of f2 (4.9 MB > L2) once per tile row
+    constexpr int RG = 5;
+    const int per_sr = RG * tiles_n;
+    const int sr = lin / per_sr;
+    const int within = lin - sr * per_sr;
+    const int rows = min(RG, tiles_m - sr * RG);
+    tn = within / rows;
+    tm = sr * RG + (within - tn * rows);
 }
 
 

@@ -221,9 +221,12 @@ extern "C" int mv_backproject(const float* kp_uv, const float* depth_vals, int d
 extern "C" int mv_obs_filter(const uint8_t* inbound, const double* cov1, const double* cov2, const float* vals,
                              int flags, float min_depth, float max_depth, int N, uint8_t* valid, int32_t* count,
                              mvStream_t stream) {
-    MV_CHECK_ARG(N >= 0 && valid && count);
-    MV_CHECK_ARG(!(flags & 1) || (cov1 && cov2));
-    MV_CHECK_ARG(!(flags & 6) || vals);
+    MV_CHECK_ARG(N >= 0 && count);
+    if (N > 0) {
+        MV_CHECK_ARG(valid);
+        MV_CHECK_ARG(!(flags & 1) || (cov1 && cov2));
+        MV_CHECK_ARG(!(flags & 6) || vals);
+    }
     hipLaunchKernelGGL(obs_filter_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, inbound, cov1, cov2, vals,
                        flags, min_depth, max_depth, N, valid, count);
     return mv_launch_status();
