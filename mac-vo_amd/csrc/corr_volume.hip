@@ -17,7 +17,8 @@
 //     16-bit kernel went 59 -> 112 us, the fp32 kernel 250 -> 279 us.  Full-line stores win.  An LDS-staged epilogue
 //     with dwordx4 stores of whole 256-B row segments measured the same as the direct one (59 us), so the 16-bit
 //     kernel's distance to the 27-30 us of a pure 184-MB fill is not store-instruction count; BK 32 vs 64 and nt vs
-//     plain stores are also within noise.)
+//     plain stores are also within noise.  An LDS-free fp32 variant (fragments straight from global memory with an
+//     8- or 16-deep register ring, no barriers) measured 395 / 628 us vs 250 us: the LDS tile is worth keeping.)
 #include "common.h"
 #include <stdlib.h>
 
@@ -208,6 +209,7 @@ __global__ __launch_bounds__(256) void corr_volume_f32_chw(const float* __restri
     const bool interior = (m0 + BM <= N1) && (n0 + BN <= N2);
     store_tile<NT>(out + (size_t)b * N1 * N2, acc, m0 + wm * 64, n0 + wn * 64, kh, li, N1, N2, interior);
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // fp32, HWC ([N][C]) operands: same MFMA core; the loader transposes through LDS

@@ -87,6 +87,9 @@ class FrameInputs:
     cov8: torch.Tensor | None = None         # [2, 2, H/8, W/8]  cov_coords1 - cov_coords0
     up_mask: torch.Tensor | None = None      # [2, 576, H/8, W/8] flow branch mask BEFORE the 0.25 scale (:121)
     cov_mask: torch.Tensor | None = None     # [2, 576, H/8, W/8] log-sigma branch mask (0.25 already applied, :41)
+    # event recorded by whoever produced fmap1/fmap2 (None = already complete, e.g. resident inputs): the volume GEMM
+    # runs on its own stream and must not start before its operands exist
+    ready: "torch.cuda.Event | None" = None
 
 
 @dataclass
@@ -107,7 +110,10 @@ class HotPath:
         self.keep_extras = keep_extras
         self.lm = ops.lm_default_params()
         self.maps_prev_for_next: ops.FrontendMaps | None = None   # depth maps of the newest frontend'ed frame
-        self._side = torch.cuda.Stream(device=self.dev)
+        self._side = torch.cuda.Stream(device=self.dev)      # PGO stream
+        self._back = torch.cuda.Stream(device=self.dev)      # pose-dependent half of a frame (tracking .. filter)
+        self._perm_pinned = [torch.empty((max(self.cfg.num_point, 1),), dtype=torch.int64, pin_memory=True) for _ in range(4)]
+        self._perm_slot = 0
         self._pgo_done = None
         self._pgo_keep = None
         self.pose = torch.tensor([0, 0, 0, 0, 0, 0, 1], dtype=torch.float32, device=self.dev)
@@ -115,7 +121,10 @@ class HotPath:
         self._max_depth = cam.fx * cam.baseline if c.max_depth == "auto" else float(c.max_depth)
         self._intr = torch.tensor([cam.K4], dtype=torch.float32, device=self.dev)
         self._bl = torch.tensor([cam.baseline], dtype=torch.float32, device=self.dev)
-        self._vol = None
+        self._vols = [None, None]                 # double-buffered cost volumes (184 MB each @640x480, B = 2)
+        self._vol_free = [None, None]             # event: the last reader (lookups) of that buffer has finished
+        self._vol_idx = 0
+        self._vol_stream = torch.cuda.Stream(device=self.dev)
         self._tok = None
         self.last_tokens = None
         # offsets table: row n = [0, n] (one problem of n points) — avoids an H2D copy per frame
@@ -125,11 +134,33 @@ class HotPath:
     # ------------------------------------------------------------------ frontend part of the hot path
     def frontend(self, x: FrameInputs) -> ops.FrontendMaps:
         c = self.cfg
-        if self._vol is None or self._vol.shape[0] != x.fmap1.shape[0] * x.coords.shape[-1] * x.coords.shape[-2]:
-            self._vol = None
-        self._vol = ops.corr_volume(x.fmap1, x.fmap2, layout=c.feature_layout, out=self._vol, precision=c.volume_precision)
+        # The MFMA-bound volume GEMM of THIS frame runs on its own stream and overlaps the latency-bound decoder-side
+        # work (lookups, selector, backend) of the PREVIOUS frame that is still queued on the main stream — the two
+        # frontends are independent (Frontend.py:219-224).  Two volume buffers alternate; a buffer is rewritten only
+        # after the lookups that read it have finished.
+        main = torch.cuda.current_stream()
+        k = self._vol_idx
+        self._vol_idx ^= 1
+        n_rows = x.fmap1.shape[0] * x.coords.shape[-1] * x.coords.shape[-2]
+        if self._vols[k] is not None and self._vols[k].shape[0] != n_rows:
+            self._vols[k] = None
+        vs = self._vol_stream
+        if x.ready is not None:
+            vs.wait_event(x.ready)            # producer of the feature maps (the encoder) signals readiness
+        if self._vol_free[k] is not None:
+            vs.wait_event(self._vol_free[k])
+        with torch.cuda.stream(vs):
+            self._vols[k] = ops.corr_volume(x.fmap1, x.fmap2, layout=c.feature_layout, out=self._vols[k],
+                                            precision=c.volume_precision)
+            vol_done = torch.cuda.Event()
+            vol_done.record(vs)
+        main.wait_event(vol_done)
+        vol = self._vols[k]
         for it in range(x.coords.shape[0]):
-            self._tok = ops.corr_lookup(self._vol, x.coords[it], c.radius, out=self._tok)
+            self._tok = ops.corr_lookup(vol, x.coords[it], c.radius, out=self._tok)
+        free = torch.cuda.Event()
+        free.record(main)
+        self._vol_free[k] = free
         self.last_tokens = self._tok
         if x.flow8 is not None:
             flow = ops.convex_upsample(x.flow8, x.up_mask, mask_scale=0.25)
@@ -174,29 +205,33 @@ class HotPath:
         maps0, maps1, cands = pend.maps0, pend.maps1, pend.cands
         pend.event.synchronize()
         cands._n = int(pend.host_count[0])
-        kp0 = cands.finish(c.num_point)          # CPU randperm from the global generator, as in the reference
-        n = kp0.shape[0]
-        main = torch.cuda.current_stream()
-        if self._pgo_done is not None:
-            main.wait_event(self._pgo_done)       # self.pose of the previous frame is produced on the side stream
-        if n == 0:
-            return FrameResult(self.pose, None, None, kp0, None)
+        back, side = self._back, self._side
+        # The backend runs on its own stream: it must not queue behind the NEXT frame's decoder-side work that
+        # enqueue_frontend already put on the main stream (that work waits for the next volume GEMM).
+        back.wait_event(pend.event)
+        with torch.cuda.stream(back):
+            self._perm_slot = (self._perm_slot + 1) % len(self._perm_pinned)
+            kp0 = cands.finish(c.num_point, staging=self._perm_pinned[self._perm_slot])  # CPU randperm, as the reference
+            n = kp0.shape[0]
+            if self._pgo_done is not None:
+                back.wait_event(self._pgo_done)   # self.pose of the previous frame is produced on the PGO stream
+            if n == 0:
+                return FrameResult(self.pose, None, None, kp0, None)
 
-        tr = ops.kp_track(kp0, maps1.flow, maps1.flow_cov, maps0, maps1, c.edgewidth, c.match_cov_default)
-        pos0_Tc, pos_Tw, rot = ops.backproject(tr.kp0_uv, tr.vals[0], cam.K4, self.pose, want_rot=True)
-        cov0, cov0_w = ops.match_cov(maps0.depth, tr.kp0_uv, tr.sigma0, None, *cam.K4, kernel_size=c.cov_kernel_size,
-                                     min_flow_cov=c.min_flow_cov, min_depth_cov=c.min_depth_cov, rot=rot)
-        cov1 = ops.match_cov(maps1.depth, tr.kp1_uv, tr.sigma1, None, *cam.K4, kernel_size=c.cov_kernel_size,
-                             min_flow_cov=c.min_flow_cov, min_depth_cov=c.min_depth_cov)
-        valid, n_valid = ops.obs_filter(tr.inbound, cov0, cov1, tr.vals, c.filters, c.filter_min_depth, self._max_depth)
+            tr = ops.kp_track(kp0, maps1.flow, maps1.flow_cov, maps0, maps1, c.edgewidth, c.match_cov_default)
+            pos0_Tc, pos_Tw, rot = ops.backproject(tr.kp0_uv, tr.vals[0], cam.K4, self.pose, want_rot=True)
+            cov0, cov0_w = ops.match_cov(maps0.depth, tr.kp0_uv, tr.sigma0, None, *cam.K4, kernel_size=c.cov_kernel_size,
+                                         min_flow_cov=c.min_flow_cov, min_depth_cov=c.min_depth_cov, rot=rot)
+            cov1 = ops.match_cov(maps1.depth, tr.kp1_uv, tr.sigma1, None, *cam.K4, kernel_size=c.cov_kernel_size,
+                                 min_flow_cov=c.min_flow_cov, min_depth_cov=c.min_depth_cov)
+            valid, n_valid = ops.obs_filter(tr.inbound, cov0, cov1, tr.vals, c.filters, c.filter_min_depth, self._max_depth)
 
-        batch = ops.PGOBatch(
-            offsets=self._offs[n], init_pose=self.pose.reshape(1, 7), intrinsics=self._intr, baseline=self._bl,
-            pos_Tw=pos_Tw, pixel2_uv=tr.kp1_uv, cov_Tw=cov0_w, pixel2_d=tr.vals[4], pixel2_disp=tr.vals[5],
-            pixel2_disp_cov=tr.vals[6], pixel2_uv_cov=tr.sigma1, obs2_covTc=cov1, valid=valid)
-        ready = torch.cuda.Event()
-        ready.record(main)
-        side = self._side
+            batch = ops.PGOBatch(
+                offsets=self._offs[n], init_pose=self.pose.reshape(1, 7), intrinsics=self._intr, baseline=self._bl,
+                pos_Tw=pos_Tw, pixel2_uv=tr.kp1_uv, cov_Tw=cov0_w, pixel2_d=tr.vals[4], pixel2_disp=tr.vals[5],
+                pixel2_disp_cov=tr.vals[6], pixel2_uv_cov=tr.sigma1, obs2_covTc=cov1, valid=valid)
+            ready = torch.cuda.Event()
+            ready.record(back)
         side.wait_event(ready)
         with torch.cuda.stream(side):
             new_pose = torch.empty((1, 7), dtype=torch.float32, device=self.dev)
@@ -206,7 +241,7 @@ class HotPath:
             done = torch.cuda.Event()
             done.record(side)
         self._pgo_done = done
-        self._pgo_keep = (batch, tr, cov0, cov1, maps0)   # inputs of the in-flight solve stay referenced until replaced
+        self._pgo_keep = (self._pgo_keep[1] if self._pgo_keep else None, (batch, tr, cov0, cov1, maps0, maps1, kp0, pos0_Tc, cands, pend))  # keep 2 frames of cross-stream tensors alive
         self.pose = new_pose.reshape(7)
         res = FrameResult(self.pose, pose64, info, kp0, n_valid)
         if self.keep_extras:

@@ -134,6 +134,7 @@ def test_hot_path_survives_frame_without_keypoints(gpu):
     frames[1]["logcov"] = torch.full_like(frames[1]["logcov"], float("nan"))   # selector finds nothing on frame 1
     hot = HotPath(Camera(**cam), HotPathConfig(kp_mask_width=16, edgewidth=16), gpu)
     ins = [FrameInputs(**{k: v.to(gpu) for k, v in f.items()}) for f in frames]
+    torch.cuda.synchronize()
     hot.initialize(ins[0])
     p0 = hot.pose.clone()
     r1 = hot.step(ins[1])

@@ -10,7 +10,10 @@ pytestmark = pytest.mark.gpu
 def _to_inputs(fr, dev):
     from macvo_amd.pipeline import FrameInputs
 
-    return FrameInputs(**{k: v.to(dev) for k, v in fr.items()})
+    x = FrameInputs(**{k: v.to(dev) for k, v in fr.items()})
+    x.ready = torch.cuda.Event()
+    x.ready.record()
+    return x
 
 
 @pytest.mark.parametrize("H,W,graph,selector", [(480, 640, "disp", "nodepth"), (240, 320, "icp", "full"), (240, 320, "reproj", "nodepth")])
@@ -93,7 +96,12 @@ def test_sequence_with_convex_upsample_path(gpu):
         fr["logcov"] = None
     ora = OracleHotPath(cam, {})
     hot = HotPath(Camera(**cam), HotPathConfig(), gpu)
-    dv = lambda fr: __import__("macvo_amd.pipeline", fromlist=["FrameInputs"]).FrameInputs(**{k: (None if v is None else v.to(gpu)) for k, v in fr.items()})  # noqa: E731
+    def dv(fr):
+        from macvo_amd.pipeline import FrameInputs
+
+        x = FrameInputs(**{k: (None if v is None else v.to(gpu)) for k, v in fr.items()})
+        torch.cuda.synchronize()
+        return x
     ora.initialize(frames[0])
     hot.initialize(dv(frames[0]))
     for t in range(1, n_frames):
