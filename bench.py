@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--pool", type=int, default=24, help="distinct synthetic frames (closed trajectory) kept in HBM")
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames timed for the CPU baseline (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graphs", action="store_true", help="replay the decoder-side segment (12 lookups + epilogue + selector) as a hipGraph (measured slower than eager launches on ROCm 7.2: 2.46 k vs 2.60 k fps)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events around the volume kernel")
     return ap.parse_args()
 
@@ -91,8 +92,11 @@ def main():
             cache[k] = t.to(dev)
         return cache[k]
 
-    frames = [FrameInputs(**{k: to_dev(v) for k, v in fr.items()}) for fr in frames_cpu]
-    hot = HotPath(Camera(**cam), HotPathConfig(graph_type=args.graph, feature_layout=args.layout, volume_precision=args.volume_precision), dev)
+    use_graphs = args.graphs
+    assert args.pool % 6 == 0 or not use_graphs, "--pool must be a multiple of 6 with graphs (one graph per resident frame)"
+    frames = [FrameInputs(static=True, **{k: to_dev(v) for k, v in fr.items()}) for fr in frames_cpu]
+    hot = HotPath(Camera(**cam), HotPathConfig(graph_type=args.graph, feature_layout=args.layout,
+                                               volume_precision=args.volume_precision, use_graphs=use_graphs), dev)
     torch.manual_seed(1234 + rank)  # the selector consumes the global CPU generator (reference behaviour)
 
     # ---- per-launch HIP events around the dominant kernel (cost volume), on the launch stream
@@ -115,6 +119,11 @@ def main():
 
     hot.initialize(frames[0])
     t_idx = 1
+    if use_graphs:
+        # setup (untimed, before the warm-up): one pass over the resident frames captures their decoder-side hipGraphs
+        for _ in hot.run(frames[(t_idx + k) % args.pool] for k in range(args.pool)):
+            pass
+        t_idx += args.pool
     poses = torch.zeros((args.steps, 7), dtype=torch.float32, device=dev)
     for _ in hot.run(frames[(t_idx + k) % args.pool] for k in range(args.warmup)):
         pass
@@ -238,6 +247,7 @@ def main():
             "config": {"workload": f"configs[1]: single MI355X, {W}x{H} synthetic stereo, HIP correlation volume + GN backend, 1-seq stream per GPU",
                        "per_step": f"2 cost volumes [{n_q}x{C}x{n_q}] + {args.iters}x2 9x9 lookups + epilogue + CovAwareSelector_NoDepth(200) + 2x MatchCovariance(31x31) + TwoFrame_PGO({args.graph})",
                        "feature_dtype": args.feat_dtype, "feature_layout": args.layout, "volume_precision": args.volume_precision,
+                       "hip_graphs": use_graphs,
                        "excluded": "learned FlowFormer layers (source + weights absent from the reference checkout)",
                        "parallelism": f"{world} independent sequence(s), one per GPU; one all_gather of poses"},
             "roofline": roofline,

@@ -33,8 +33,14 @@ __global__ __launch_bounds__(64 * (32 / QPW)) void corr_lookup_kernel(const floa
     constexpr int NLOAD = (QPW * CELLS + 63) / 64;  // 18 wave-wide loads
     constexpr int TAP_ROUNDS = (KK + 63) / 64;      // 2 for r = 4
 
-    __shared__ float blk[NWAVE][QPW * CELLS + 64];
-    __shared__ float outs[KK][QPB + 1];
+    // one LDS region, two lives: staged cell blocks (read by the tap phase), then the transposed outputs.  Keeping the
+    // footprint at max(22.5, 10.7) KB lets a lookup workgroup co-reside with four 32-KB volume-GEMM workgroups on a CU
+    // (the pipeline runs the next frame's GEMM on another stream while this frame's lookups execute).
+    constexpr int BLK_FLOATS = NWAVE * (QPW * CELLS + 64);
+    constexpr int OUT_FLOATS = KK * (QPB + 1);
+    __shared__ float smem[BLK_FLOATS > OUT_FLOATS ? BLK_FLOATS : OUT_FLOATS];
+    float (*blk)[QPW * CELLS + 64] = reinterpret_cast<float (*)[QPW * CELLS + 64]>(smem);
+    float (*outs)[QPB + 1] = reinterpret_cast<float (*)[QPB + 1]>(smem);
 
     const int b = blockIdx.y;
     const int q0 = blockIdx.x * QPB;
@@ -75,6 +81,7 @@ __global__ __launch_bounds__(64 * (32 / QPW)) void corr_lookup_kernel(const floa
     // ---- taps: lane -> (i, j); replay RAFT normalise + ATen unnormalise + bilinear weights in fp32
     const float wm1 = (float)(W2 - 1), hm1 = (float)(H2 - 1);
     const float sx = wm1 / 2.f, sy = hm1 / 2.f;
+    float res[TAP_ROUNDS][QPW];
 #pragma unroll
     for (int tr = 0; tr < TAP_ROUNDS; ++tr) {
         const int tap = tr * 64 + lane;
@@ -106,8 +113,17 @@ __global__ __launch_bounds__(64 * (32 / QPW)) void corr_lookup_kernel(const floa
                 r0 = r0 + vne * (so * w);
                 r0 = r0 + vsw * (n * e);
                 r0 = r0 + vse * (n * w);
-                outs[tap][wave * QPW + s] = r0;
+                res[tr][s] = r0;
             }
+        }
+    }
+    __syncthreads();   // every wave is done reading the staged blocks: the region becomes the output transpose buffer
+#pragma unroll
+    for (int tr = 0; tr < TAP_ROUNDS; ++tr) {
+        const int tap = tr * 64 + lane;
+        if (tap < KK) {
+#pragma unroll
+            for (int s = 0; s < QPW; ++s) outs[tap][wave * QPW + s] = res[tr][s];
         }
     }
     __syncthreads();

@@ -35,9 +35,10 @@ constexpr int BN = 128;
 
 // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8); give each XCD a
 // contiguous band of tile rows so the f1 row-band and the streamed f2 tiles stay in that XCD's L2.
-__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int& tm, int& tn, bool remap = true) {
+__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int& tm, int& tn, bool remap = true,
+                                            int vid = -1) {
     const int nwg = tiles_m * tiles_n;
-    const int id = blockIdx.x;
+    const int id = vid >= 0 ? vid : (int)blockIdx.x;
     if (!remap) {
         tm = id / tiles_n;
         tn = id - tm * tiles_n;
@@ -130,86 +131,103 @@ __device__ __forceinline__ void store_tile(float* __restrict__ O, const f32x16 (
 
 // ------------------------------------------------------------------------------------------------
 // fp32, CHW ([C][N]) operands.  BK = 16.
+//
+// PERSIST form (opt-in, see persistent_grid()): the grid is k workgroups per CU (768 on MI355X, a multiple of 8 so that
+// "id % 8 == XCD" keeps holding) and each workgroup strides over the B * tiles_m * tiles_n tiles.  The whole grid is
+// resident from the first microsecond, so the hardware workgroup dispatcher is never parked on this kernel, and the
+// small latency-bound kernels that the pipeline runs on other streams (window lookups, selector, backend, PGO of the
+// neighbouring frames) are dispatched into the spare wave slots / LDS while the GEMM runs.  With the classic
+// one-tile-per-workgroup grid (2888 workgroups for 1024 slots) a concurrently launched 8-us lookup kernel was measured
+// to finish only when the GEMM had drained (140 us) — head-of-line blocking in the dispatcher, not lack of resources.
 // ------------------------------------------------------------------------------------------------
-template <bool VEC4, int BK = 16, bool REMAP = true, bool NT = true>
+template <bool VEC4, bool PERSIST>
 __global__ __launch_bounds__(256) void corr_volume_f32_chw(const float* __restrict__ f1,
                                                             const float* __restrict__ f2,
                                                             float* __restrict__ out, int C, int N1, int N2,
-                                                            int tiles_m, int tiles_n) {
+                                                            int tiles_m, int tiles_n, int batches) {
+    constexpr int BK = 16;
+    constexpr int NP = BK / 8;
     __shared__ __attribute__((aligned(16))) float sA[2][BK][BM];
     __shared__ __attribute__((aligned(16))) float sB[2][BK][BN];
-
-    int tm, tn;
-    tile_coords(tiles_m, tiles_n, tm, tn, REMAP);
-    const int b = blockIdx.z;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const float* A = f1 + (size_t)b * C * N1;
-    const float* Bp = f2 + (size_t)b * C * N2;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-
+    const int kh = lane >> 5;        // which k of the pair this lane feeds
+    const int li = lane & 31;
     // loader mapping: BK rows x 128 cols per operand = BK*32 float4; thread t takes (row = t/32 + 8*p, col4 = (t%32)*4)
     const int lrow = t >> 5;
     const int lcol = (t & 31) * 4;
-    constexpr int NP = BK / 8;
+    const int nk = C / BK;
+    const int per_batch = tiles_m * tiles_n;
+    const int total = PERSIST ? per_batch * batches : 1;
 
-    f32x4 ra[NP], rb[NP];
-    auto gload = [&](int k0) {
+    for (int work = PERSIST ? (int)blockIdx.x : 0; work < total; work += PERSIST ? (int)gridDim.x : 1) {
+        int tm, tn, b;
+        if (PERSIST) {
+            // batch-major split keeps "virtual id % 8 == XCD": gridDim.x is a multiple of 8
+            b = work / per_batch;
+            tile_coords(tiles_m, tiles_n, tm, tn, true, work - b * per_batch);
+        } else {
+            b = blockIdx.z;
+            tile_coords(tiles_m, tiles_n, tm, tn);
+        }
+        const int m0 = tm * BM, n0 = tn * BN;
+        const float* A = f1 + (size_t)b * C * N1;
+        const float* Bp = f2 + (size_t)b * C * N2;
+
+        f32x4 ra[NP], rb[NP];
+        auto gload = [&](int k0) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int k = k0 + lrow + 8 * p;
-            const float* pa = A + (size_t)k * N1 + m0 + lcol;
-            const float* pb = Bp + (size_t)k * N2 + n0 + lcol;
-            if (VEC4) {
-                ra[p] = (m0 + lcol < N1) ? *reinterpret_cast<const f32x4*>(pa) : f32x4{0, 0, 0, 0};
-                rb[p] = (n0 + lcol < N2) ? *reinterpret_cast<const f32x4*>(pb) : f32x4{0, 0, 0, 0};
-            } else {
+            for (int p = 0; p < NP; ++p) {
+                const int k = k0 + lrow + 8 * p;
+                const float* pa = A + (size_t)k * N1 + m0 + lcol;
+                const float* pb = Bp + (size_t)k * N2 + n0 + lcol;
+                if (VEC4) {
+                    ra[p] = (m0 + lcol < N1) ? *reinterpret_cast<const f32x4*>(pa) : f32x4{0, 0, 0, 0};
+                    rb[p] = (n0 + lcol < N2) ? *reinterpret_cast<const f32x4*>(pb) : f32x4{0, 0, 0, 0};
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ra[p][e] = (m0 + lcol + e < N1) ? pa[e] : 0.f;
-                    rb[p][e] = (n0 + lcol + e < N2) ? pb[e] : 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                        ra[p][e] = (m0 + lcol + e < N1) ? pa[e] : 0.f;
+                        rb[p][e] = (n0 + lcol + e < N2) ? pb[e] : 0.f;
+                    }
                 }
             }
-        }
-    };
-    auto sstore = [&](int buf) {
+        };
+        auto sstore = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            *reinterpret_cast<f32x4*>(&sA[buf][lrow + 8 * p][lcol]) = ra[p];
-            *reinterpret_cast<f32x4*>(&sB[buf][lrow + 8 * p][lcol]) = rb[p];
-        }
-    };
+            for (int p = 0; p < NP; ++p) {
+                *reinterpret_cast<f32x4*>(&sA[buf][lrow + 8 * p][lcol]) = ra[p];
+                *reinterpret_cast<f32x4*>(&sB[buf][lrow + 8 * p][lcol]) = rb[p];
+            }
+        };
 
-    f32x16 acc[2][2];
+        f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    gload(0);
-    sstore(0);
-    __syncthreads();
-
-    const int nk = C / BK;
-    const int kh = lane >> 5;        // which k of the pair this lane feeds
-    const int li = lane & 31;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * BK);
-        mfma_tile_f32<BK, BM>(sA[buf], sB[buf], wm * 64 + li, wn * 64 + li, kh, acc);
-        if (kt + 1 < nk) {
-            sstore(buf ^ 1);
-            __syncthreads();
+        gload(0);
+        if (PERSIST) __syncthreads();   // the previous tile's last K-step may still be reading buffer 0/1
+        sstore(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) gload((kt + 1) * BK);
+            mfma_tile_f32<BK, BM>(sA[buf], sB[buf], wm * 64 + li, wn * 64 + li, kh, acc);
+            if (kt + 1 < nk) {
+                sstore(buf ^ 1);
+                __syncthreads();
+            }
         }
+        const bool interior = (m0 + BM <= N1) && (n0 + BN <= N2);
+        store_tile(out + (size_t)b * N1 * N2, acc, m0 + wm * 64, n0 + wn * 64, kh, li, N1, N2, interior);
     }
-    const bool interior = (m0 + BM <= N1) && (n0 + BN <= N2);
-    store_tile<NT>(out + (size_t)b * N1 * N2, acc, m0 + wm * 64, n0 + wn * 64, kh, li, N1, N2, interior);
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // fp32, HWC ([N][C]) operands: same MFMA core; the loader transposes through LDS
@@ -610,6 +628,24 @@ __global__ __launch_bounds__(256) void corr_volume_h_chw(const uint16_t* __restr
 
 }  // namespace
 
+// Persistent-grid size of the fp32 GEMM: 3 workgroups per CU (queried once), rounded down to a multiple of 8 (XCDs).
+// Opt-in: MV_VOL_PERSIST_WG_PER_CU=<k> (default 0 = classic one-tile-per-workgroup grid, which measured the same GEMM
+// time; on the round-1 test system the expected cross-stream overlap did not materialise either way — lookups launched
+// beside the GEMM ran ~3x slower and finished after it — so the simpler grid stays the default).
+static int persistent_grid() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MV_VOL_PERSIST_WG_PER_CU");
+        const int per_cu = e ? atoi(e) : 0;
+        int dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        v = (per_cu * cus) / 8 * 8;
+    }
+    return v;
+}
+
 extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B, int C, int N1, int N2,
                               int in_dtype, int layout, mvStream_t stream) {
     MV_CHECK_ARG(f1 && f2 && out);
@@ -625,10 +661,18 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
         const float* a = (const float*)f1;
         const float* b = (const float*)f2;
         if (layout == MV_LAYOUT_CHW) {
-            if ((N1 % 4 == 0) && (N2 % 4 == 0))
-                hipLaunchKernelGGL(corr_volume_f32_chw<true>, grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
-            else
-                hipLaunchKernelGGL(corr_volume_f32_chw<false>, grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
+            if ((N1 % 4 == 0) && (N2 % 4 == 0)) {
+                const int pg = persistent_grid();
+                if (pg > 0 && tiles_m * tiles_n * B > pg)
+                    hipLaunchKernelGGL((corr_volume_f32_chw<true, true>), dim3(pg), block, 0, s, a, b, out, C, N1, N2,
+                                       tiles_m, tiles_n, B);
+                else
+                    hipLaunchKernelGGL((corr_volume_f32_chw<true, false>), grid, block, 0, s, a, b, out, C, N1, N2,
+                                       tiles_m, tiles_n, B);
+            } else {
+                hipLaunchKernelGGL((corr_volume_f32_chw<false, false>), grid, block, 0, s, a, b, out, C, N1, N2, tiles_m,
+                                   tiles_n, B);
+            }
         } else {
             hipLaunchKernelGGL(corr_volume_f32_hwc, grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
         }

@@ -64,6 +64,7 @@ class HotPathConfig:
     filter_min_depth: float = 0.05
     radius: int = 4
     feature_layout: str = "chw"
+    use_graphs: bool = False             # hipGraph-replay the decoder-side segment for inputs marked `static`
     volume_precision: str = "exact"      # "exact" fp32 MFMA | "split3" bf16x3 (fp32 features in layout "hwc")
 
 
@@ -90,6 +91,9 @@ class FrameInputs:
     # event recorded by whoever produced fmap1/fmap2 (None = already complete, e.g. resident inputs): the volume GEMM
     # runs on its own stream and must not start before its operands exist
     ready: "torch.cuda.Event | None" = None
+    # promise that every tensor above lives at a fixed address for the lifetime of the HotPath (e.g. the static output
+    # buffers of a graph-captured network, as in the reference's CUDAGraph frontend): allows hipGraph replay
+    static: bool = False
 
 
 @dataclass
@@ -110,10 +114,12 @@ class HotPath:
         self.keep_extras = keep_extras
         self.lm = ops.lm_default_params()
         self.maps_prev_for_next: ops.FrontendMaps | None = None   # depth maps of the newest frontend'ed frame
-        self._side = torch.cuda.Stream(device=self.dev)      # PGO stream
-        self._back = torch.cuda.Stream(device=self.dev)      # pose-dependent half of a frame (tracking .. filter)
+        self._side = torch.cuda.Stream(device=self.dev, priority=-1)      # PGO stream
+        self._back = torch.cuda.Stream(device=self.dev, priority=-1)      # pose-dependent half of a frame (tracking .. filter)
         self._perm_pinned = [torch.empty((max(self.cfg.num_point, 1),), dtype=torch.int64, pin_memory=True) for _ in range(4)]
         self._perm_slot = 0
+        self._graphs: dict = {}                   # (id(inputs), slot) -> captured decoder-side segment
+        self._frame_no = 0
         self._pgo_done = None
         self._pgo_keep = None
         self.pose = torch.tensor([0, 0, 0, 0, 0, 0, 1], dtype=torch.float32, device=self.dev)
@@ -124,7 +130,9 @@ class HotPath:
         self._vols = [None, None]                 # double-buffered cost volumes (184 MB each @640x480, B = 2)
         self._vol_free = [None, None]             # event: the last reader (lookups) of that buffer has finished
         self._vol_idx = 0
-        self._vol_stream = torch.cuda.Stream(device=self.dev)
+        # the GEMM stream gets the LOWEST priority: whenever CU slots free up, the small latency-bound kernels of the other
+        # streams (lookups, selector, backend, PGO) should be dispatched first and the GEMM fills whatever is left
+        self._vol_stream = torch.cuda.Stream(device=self.dev, priority=0)
         self._tok = None
         self.last_tokens = None
         # offsets table: row n = [0, n] (one problem of n points) — avoids an H2D copy per frame
@@ -132,15 +140,16 @@ class HotPath:
         self._offs = torch.stack([torch.zeros(m, dtype=torch.int32), torch.arange(m, dtype=torch.int32)], 1).to(self.dev)
 
     # ------------------------------------------------------------------ frontend part of the hot path
-    def frontend(self, x: FrameInputs) -> ops.FrontendMaps:
+    def _volume(self, x: FrameInputs):
+        """The MFMA-bound volume GEMM of THIS frame runs on its own stream and overlaps the latency-bound decoder-side
+        work (lookups, selector, backend) of the PREVIOUS frame that is still queued on the other streams — the two
+        frontends are independent (Frontend.py:219-224).  Two volume buffers alternate; a buffer is rewritten only
+        after the lookups that read it have finished."""
         c = self.cfg
-        # The MFMA-bound volume GEMM of THIS frame runs on its own stream and overlaps the latency-bound decoder-side
-        # work (lookups, selector, backend) of the PREVIOUS frame that is still queued on the main stream — the two
-        # frontends are independent (Frontend.py:219-224).  Two volume buffers alternate; a buffer is rewritten only
-        # after the lookups that read it have finished.
         main = torch.cuda.current_stream()
-        k = self._vol_idx
-        self._vol_idx ^= 1
+        slot = self._frame_no % 6
+        self._frame_no += 1
+        k = slot & 1
         n_rows = x.fmap1.shape[0] * x.coords.shape[-1] * x.coords.shape[-2]
         if self._vols[k] is not None and self._vols[k].shape[0] != n_rows:
             self._vols[k] = None
@@ -155,22 +164,66 @@ class HotPath:
             vol_done = torch.cuda.Event()
             vol_done.record(vs)
         main.wait_event(vol_done)
-        vol = self._vols[k]
+        return self._vols[k], k, slot
+
+    def _decoder_side(self, x: FrameInputs, vol: torch.Tensor, with_selector: bool):
+        """12 x window lookup + (convex upsampling) + epilogue + dense selector stage: everything between the volume and
+        the host's randperm.  Pure enqueue (graph-capturable)."""
+        c, cam = self.cfg, self.cam
+        tok = None
         for it in range(x.coords.shape[0]):
-            self._tok = ops.corr_lookup(vol, x.coords[it], c.radius, out=self._tok)
-        free = torch.cuda.Event()
-        free.record(main)
-        self._vol_free[k] = free
-        self.last_tokens = self._tok
+            tok = ops.corr_lookup(vol, x.coords[it], c.radius, out=tok)
         if x.flow8 is not None:
             flow = ops.convex_upsample(x.flow8, x.up_mask, mask_scale=0.25)
             cov = ops.convex_upsample(x.cov8, x.cov_mask, mask_scale=1.0, exp2_out=True)     # exp(2*cov) fused
-            return ops.frontend_epilogue(flow, cov, self.cam.baseline, self.cam.fx, cov_is_log=False)
-        return ops.frontend_epilogue(x.flow, x.logcov, self.cam.baseline, self.cam.fx, cov_is_log=True)
+            maps = ops.frontend_epilogue(flow, cov, cam.baseline, cam.fx, cov_is_log=False)
+        else:
+            maps = ops.frontend_epilogue(x.flow, x.logcov, cam.baseline, cam.fx, cov_is_log=True)
+        cands = None
+        if with_selector:
+            cands = ops.kp_select("nodepth", cam.H, cam.W, flow_cov=maps.flow_cov, kernel_size=c.kp_kernel_size,
+                                  mask_width=c.kp_mask_width, max_match_cov=c.max_match_cov)
+        return tok, maps, cands
+
+    def frontend(self, x: FrameInputs, with_selector: bool = False):
+        """volume -> decoder side; returns (maps, cands | None, host_count | None).  With ``use_graphs`` and a ``static``
+        input the decoder side is one hipGraph replay (12 lookups + epilogue + selector + count copy = 17 nodes)."""
+        c = self.cfg
+        vol, k, slot = self._volume(x)
+        main = torch.cuda.current_stream()
+        graphable = c.use_graphs and x.static and with_selector and c.selector == "nodepth"
+        host_count = None
+        if graphable:
+            key = (id(x), slot)
+            g = self._graphs.get(key)
+            if g is None:
+                # eager warm-up (lazy initialisations must not happen under capture), then capture
+                self._decoder_side(x, vol, True)
+                hc = torch.empty((4,), dtype=torch.int32, pin_memory=True)
+                main.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    tok, maps, cands = self._decoder_side(x, vol, True)
+                    hc.copy_(cands.count, non_blocking=True)
+                g = (graph, tok, maps, cands, hc, x, vol)
+                self._graphs[key] = g
+            graph, tok, maps, cands, host_count = g[:5]
+            graph.replay()
+            cands._n = None
+        else:
+            tok, maps, cands = self._decoder_side(x, vol, with_selector and c.selector == "nodepth")
+            if cands is not None:
+                host_count = torch.empty((4,), dtype=torch.int32, pin_memory=True)
+                host_count.copy_(cands.count, non_blocking=True)
+        free = torch.cuda.Event()
+        free.record(main)
+        self._vol_free[k] = free
+        self.last_tokens = tok
+        return maps, cands, host_count
 
     def initialize(self, x: FrameInputs, init_pose: torch.Tensor | None = None) -> None:
         """Frame 0: ``MACVO.initialize`` (:158-171) — depth only, pose = prior."""
-        self.maps_prev_for_next = self.frontend(x)
+        self.maps_prev_for_next = self.frontend(x)[0]
         if init_pose is not None:
             self.pose = init_pose.to(self.dev, torch.float32).reshape(7).clone()
 
@@ -180,17 +233,15 @@ class HotPath:
         selector stage.  Only enqueues work; the candidate count travels to a pinned host word behind an event, so a
         later ``finish`` waits for THIS frame's selector and not for whatever was queued after it."""
         c, cam = self.cfg, self.cam
-        maps0, maps1 = self.maps_prev_for_next, self.frontend(x)
-        if c.selector == "nodepth":
-            cands = ops.kp_select("nodepth", cam.H, cam.W, flow_cov=maps1.flow_cov, kernel_size=c.kp_kernel_size,
-                                  mask_width=c.kp_mask_width, max_match_cov=c.max_match_cov)
-        else:
+        maps0 = self.maps_prev_for_next
+        maps1, cands, host_count = self.frontend(x, with_selector=True)
+        if cands is None:   # CovAwareSelector needs the previous frame's depth maps: eager, after the frontend
             cands = ops.kp_select("full", cam.H, cam.W, flow_cov=maps1.flow_cov, depth0=maps0.depth,
                                   depth0_cov=maps0.depth_cov, depth1=maps1.depth, depth1_cov=maps1.depth_cov,
                                   kernel_size=c.kp_kernel_size, mask_width=c.kp_mask_width, max_depth=self._max_depth,
                                   max_depth_cov=c.max_depth_cov, max_match_cov=c.max_match_cov)
-        host_count = torch.empty((4,), dtype=torch.int32, pin_memory=True)
-        host_count.copy_(cands.count, non_blocking=True)
+            host_count = torch.empty((4,), dtype=torch.int32, pin_memory=True)
+            host_count.copy_(cands.count, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.maps_prev_for_next = maps1

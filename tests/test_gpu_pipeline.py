@@ -117,3 +117,26 @@ def test_sequence_with_convex_upsample_path(gpu):
             dt, dr = se3.pose_error(ro["pose"].double(), rh.pose.cpu().double())
             assert dt <= 1e-4 and dr <= 1e-4, (t, dt, dr)
         hot.pose = ro["pose"].to(gpu)
+
+
+def test_graph_replay_equals_eager(gpu):
+    """use_graphs: the decoder-side segment replayed as a hipGraph must give the same keypoints and poses as eager."""
+    from macvo_amd.pipeline import Camera, FrameInputs, HotPath, HotPathConfig
+
+    n_pool, n_steps = 6, 14
+    cam, frames, _ = synth.make_sequence(n_pool, 240, 320, C=64, iters=3, seed=11, closed_loop=True)
+    ins = [FrameInputs(static=True, **{k: v.to(gpu) for k, v in f.items()}) for f in frames]
+    torch.cuda.synchronize()
+    outs = []
+    for use_graphs in (False, True):
+        hot = HotPath(Camera(**cam), HotPathConfig(use_graphs=use_graphs), gpu)
+        hot.initialize(ins[0])
+        sink = torch.zeros(n_steps, 7, device=gpu)
+        torch.manual_seed(5)
+        kps = [r.kp0_uv.clone() for r in hot.run((ins[(1 + k) % n_pool] for k in range(n_steps)), pose_sink=sink)]
+        torch.cuda.synchronize()
+        outs.append((sink.clone(), kps))
+        if use_graphs:
+            assert len(hot._graphs) == n_pool
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
