@@ -133,7 +133,8 @@ typedef struct {
     float max_match_cov;   /* NODEPTH/FULL: min(max_match_cov, 1.5*median)                   */
 } mvKpSelectParams;
 
-/* bytes of scratch mv_kp_select needs for an H x W image */
+/* bytes of scratch mv_kp_select needs for an H x W image.  The workspace must be ZERO-FILLED once after allocation;
+ * every call leaves its internal counters zeroed again, so it can be reused call after call (on one stream). */
 size_t mv_kp_select_workspace_bytes(int H, int W);
 
 /*
@@ -221,6 +222,14 @@ typedef struct {
 int mv_match_cov(const float* depth_map, const float* kp_uv, float* flow_cov,
                  const float* depth_cov, const double* rot, const mvMatchCovParams* params /* host */,
                  int N, double* out_cov, double* out_cov_rot, float* out_stats, mvStream_t stream);
+
+/* Both ObsCovModel.estimate calls of one frame (Odometry/MACVO.py:241-242) in ONE launch: set 0 = kp0 on the previous
+ * frame's depth map (+ optional world rotation, :273-281), set 1 = kp1 on the current depth map.  Same arithmetic as
+ * two mv_match_cov calls with use_patch_var = 1 (both flow_cov arrays are clamped in place). */
+int mv_match_cov_pair(const float* depth_map0, const float* kp_uv0, float* flow_cov0, const double* rot0,
+                      double* out_cov0, double* out_cov_rot0, const float* depth_map1, const float* kp_uv1,
+                      float* flow_cov1, double* out_cov1, const mvMatchCovParams* params /* host */, int N,
+                      mvStream_t stream);
 
 /* -------------------------------------------------------------------------------------------
  * A17-A22  covariance-weighted two-frame pose-graph solve, batched over independent problems.

@@ -65,6 +65,7 @@ SIGNATURES = {
     "mv_kp_track": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int,
                               C.c_float, _P, _P, _P, _P, _P, _P, _P]),
     "mv_match_cov": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(mvMatchCovParams), C.c_int, _P, _P, _P, _P]),
+    "mv_match_cov_pair": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(mvMatchCovParams), C.c_int, _P]),
     "mv_lm_default_params": (None, [C.POINTER(mvLMParams)]),
     "mv_pgo_solve": (C.c_int, [C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int,
                                C.POINTER(mvLMParams), _P, _P, _P, _P]),

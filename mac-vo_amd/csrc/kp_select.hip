@@ -299,6 +299,7 @@ __global__ __launch_bounds__(1024) void kp_finish_kernel(mvKpSelectParams p, KpW
         }
     }
     if (tid == 0) {
+        ws.counters[0] = 0;   // leave the record counter clean for the next call (no per-call memset launch)
         out_count[0] = total;
         out_count[1] = n_rec;
         out_count[2] = 0;
@@ -370,7 +371,8 @@ extern "C" int mv_kp_select(const float* flow_cov, const float* depth0, const fl
     ws.counters = (int*)base;
 
     hipStream_t s = (hipStream_t)stream;
-    if (p.mode != MV_KP_MAPPING && hipMemsetAsync(ws.counters, 0, 16, s) != hipSuccess) return MV_ERR_LAUNCH;
+    // ws.counters must be zero on entry: the caller zero-fills the workspace once after allocating it, and every
+    // call leaves it zeroed again (kp_finish_kernel) — this saves a 5-us fill launch per frame.
     dim3 grid(wpr, mv_ceil_div(p.H, TILE_H)), block(64, 4);
     hipLaunchKernelGGL(kp_nms_kernel, grid, block, 0, s, flow_cov, depth0, depth0_cov, depth1, depth1_cov, mask_a,
                        mask_b, p, ws, wpr);

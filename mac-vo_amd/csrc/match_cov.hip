@@ -23,15 +23,30 @@ constexpr int MAX_TAPS_PER_LANE = (MAX_K * MAX_K + 63) / 64;  // 16
 
 __device__ __forceinline__ float clamp_min_nanprop(float x, float m) { return (x < m) ? m : x; }  // torch.clamp(min=)
 
-__global__ __launch_bounds__(256) void match_cov_kernel(const float* __restrict__ depth_map,
-                                                         const float* __restrict__ kp_uv, float* __restrict__ flow_cov,
-                                                         const float* __restrict__ depth_cov,
-                                                         const double* __restrict__ rot, mvMatchCovParams p, int N,
-                                                         double* __restrict__ out_cov, double* __restrict__ out_cov_rot,
-                                                         float* __restrict__ out_stats) {
+struct CovSet {
+    const float* depth_map;
+    const float* kp_uv;
+    float* flow_cov;
+    const float* depth_cov;
+    const double* rot;
+    double* out_cov;
+    double* out_cov_rot;
+    float* out_stats;
+};
+
+__global__ __launch_bounds__(256) void match_cov_kernel(CovSet s0, CovSet s1, mvMatchCovParams p, int N) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;  // whole wave exits together
+    const CovSet& S = blockIdx.y ? s1 : s0;   // the frame's two keypoint sets (kp0 on depth0, kp1 on depth1) share a launch
+    const float* __restrict__ depth_map = S.depth_map;
+    const float* __restrict__ kp_uv = S.kp_uv;
+    float* __restrict__ flow_cov = S.flow_cov;
+    const float* __restrict__ depth_cov = S.depth_cov;
+    const double* __restrict__ rot = S.rot;
+    double* __restrict__ out_cov = S.out_cov;
+    double* __restrict__ out_cov_rot = S.out_cov_rot;
+    float* __restrict__ out_stats = S.out_stats;
 
     const float u = kp_uv[2 * n], v = kp_uv[2 * n + 1];
     const int iu = (int)u, iv = (int)v;  // .long(): truncation toward zero
@@ -145,7 +160,24 @@ extern "C" int mv_match_cov(const float* depth_map, const float* kp_uv, float* f
     if (p.kernel_size > MAX_K) return MV_ERR_UNSUPPORTED;
     MV_CHECK_ARG(p.use_patch_var || depth_cov);
     MV_CHECK_ARG(!out_cov_rot || rot);
-    hipLaunchKernelGGL(match_cov_kernel, dim3(mv_ceil_div(N, 4)), dim3(256), 0, (hipStream_t)stream, depth_map, kp_uv,
-                       flow_cov, depth_cov, rot, p, N, out_cov, out_cov_rot, out_stats);
+    const CovSet s0{depth_map, kp_uv, flow_cov, depth_cov, rot, out_cov, out_cov_rot, out_stats};
+    hipLaunchKernelGGL(match_cov_kernel, dim3(mv_ceil_div(N, 4), 1), dim3(256), 0, (hipStream_t)stream, s0, s0, p, N);
+    return mv_launch_status();
+}
+
+extern "C" int mv_match_cov_pair(const float* depth_map0, const float* kp_uv0, float* flow_cov0, const double* rot0,
+                                 double* out_cov0, double* out_cov_rot0, const float* depth_map1, const float* kp_uv1,
+                                 float* flow_cov1, double* out_cov1, const mvMatchCovParams* params, int N,
+                                 mvStream_t stream) {
+    MV_CHECK_ARG(params && N >= 0);
+    if (N == 0) return MV_OK;
+    MV_CHECK_ARG(depth_map0 && kp_uv0 && flow_cov0 && out_cov0 && depth_map1 && kp_uv1 && flow_cov1 && out_cov1);
+    const mvMatchCovParams p = *params;
+    MV_CHECK_ARG(p.H > 0 && p.W > 0 && p.kernel_size >= 1 && (p.kernel_size & 1) && p.use_patch_var);
+    if (p.kernel_size > MAX_K) return MV_ERR_UNSUPPORTED;
+    MV_CHECK_ARG(!out_cov_rot0 || rot0);
+    const CovSet s0{depth_map0, kp_uv0, flow_cov0, nullptr, rot0, out_cov0, out_cov_rot0, nullptr};
+    const CovSet s1{depth_map1, kp_uv1, flow_cov1, nullptr, nullptr, out_cov1, nullptr, nullptr};
+    hipLaunchKernelGGL(match_cov_kernel, dim3(mv_ceil_div(N, 4), 2), dim3(256), 0, (hipStream_t)stream, s0, s1, p, N);
     return mv_launch_status();
 }

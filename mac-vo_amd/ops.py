@@ -212,7 +212,7 @@ def _kp_workspace(H: int, W: int, device) -> torch.Tensor:
     ws = _ws_cache.get(key)
     if ws is None:
         nbytes = L.load().mv_kp_select_workspace_bytes(H, W)
-        ws = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=device)
+        ws = torch.zeros((nbytes + 7) // 8, dtype=torch.int64, device=device)   # must start zeroed (see header)
         _ws_cache[key] = ws
     return ws
 
@@ -325,6 +325,31 @@ def match_cov(depth_map: torch.Tensor, kp_uv: torch.Tensor, flow_cov: torch.Tens
     if want_stats:
         res += (stats,)
     return res[0] if len(res) == 1 else res
+
+
+def match_cov_pair(depth0: torch.Tensor, kp0_uv: torch.Tensor, sigma0: torch.Tensor, depth1: torch.Tensor,
+                   kp1_uv: torch.Tensor, sigma1: torch.Tensor, fx: float, fy: float, cx: float, cy: float,
+                   rot: torch.Tensor | None = None, kernel_size: int = 31, min_flow_cov: float = 0.25,
+                   min_depth_cov: float = 0.05):
+    """Both covariance-model calls of a frame (MACVO.py:241-242) in one launch -> (cov0, cov0_world | None, cov1)."""
+    lib = L.load()
+    d0, d1 = _req(depth0, torch.float32, "depth0"), _req(depth1, torch.float32, "depth1")
+    H, W = d0.shape[-2:]
+    k0, k1 = _req(kp0_uv, torch.float32, "kp0_uv"), _req(kp1_uv, torch.float32, "kp1_uv")
+    for t_, nm in ((sigma0, "sigma0"), (sigma1, "sigma1")):
+        if t_.dtype != torch.float32 or not t_.is_contiguous() or not t_.is_cuda:
+            raise L.MacvoHipError(f"match_cov_pair: {nm} must be a contiguous float32 GPU tensor (clamped in place)")
+    N, dev = k0.shape[0], d0.device
+    assert k1.shape[0] == N
+    r = None if rot is None else _req(rot.to(dev), torch.float64, "rot")
+    c0 = torch.empty((N, 3, 3), dtype=torch.float64, device=dev)
+    c1 = torch.empty((N, 3, 3), dtype=torch.float64, device=dev)
+    c0w = torch.empty((N, 3, 3), dtype=torch.float64, device=dev) if r is not None else None
+    p = L.mvMatchCovParams(H, W, kernel_size, 1, fx, fy, cx, cy, min_flow_cov ** 2, min_depth_cov)
+    L.check(lib.mv_match_cov_pair(d0.data_ptr(), k0.data_ptr(), sigma0.data_ptr(), _ptr(r), c0.data_ptr(), _ptr(c0w),
+                                  d1.data_ptr(), k1.data_ptr(), sigma1.data_ptr(), c1.data_ptr(), C.byref(p), N, _stream()),
+            "mv_match_cov_pair")
+    return c0, c0w, c1
 
 
 # ------------------------------------------------------------------------------------------- A17-A22

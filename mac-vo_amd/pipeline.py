@@ -271,10 +271,9 @@ class HotPath:
 
             tr = ops.kp_track(kp0, maps1.flow, maps1.flow_cov, maps0, maps1, c.edgewidth, c.match_cov_default)
             pos0_Tc, pos_Tw, rot = ops.backproject(tr.kp0_uv, tr.vals[0], cam.K4, self.pose, want_rot=True)
-            cov0, cov0_w = ops.match_cov(maps0.depth, tr.kp0_uv, tr.sigma0, None, *cam.K4, kernel_size=c.cov_kernel_size,
-                                         min_flow_cov=c.min_flow_cov, min_depth_cov=c.min_depth_cov, rot=rot)
-            cov1 = ops.match_cov(maps1.depth, tr.kp1_uv, tr.sigma1, None, *cam.K4, kernel_size=c.cov_kernel_size,
-                                 min_flow_cov=c.min_flow_cov, min_depth_cov=c.min_depth_cov)
+            cov0, cov0_w, cov1 = ops.match_cov_pair(maps0.depth, tr.kp0_uv, tr.sigma0, maps1.depth, tr.kp1_uv, tr.sigma1,
+                                                    *cam.K4, rot=rot, kernel_size=c.cov_kernel_size,
+                                                    min_flow_cov=c.min_flow_cov, min_depth_cov=c.min_depth_cov)
             valid, n_valid = ops.obs_filter(tr.inbound, cov0, cov1, tr.vals, c.filters, c.filter_min_depth, self._max_depth)
 
             batch = ops.PGOBatch(

@@ -115,6 +115,30 @@ def test_match_cov(gpu, n, float_kp):
     torch.testing.assert_close(out_rot.cpu(), covariance.rotate_covariance(R, out.cpu()), rtol=1e-12, atol=1e-14, equal_nan=True)
 
 
+def test_match_cov_pair_equals_two_calls(gpu):
+    from macvo_amd import ops
+
+    H, W, n = 240, 320, 150
+    d0, _ = synth.depth_maps(H, W, 3)
+    d1, _ = synth.depth_maps(H, W, 4)
+    g = torch.Generator().manual_seed(3)
+    k0 = synth.keypoints(n, H, W, 5).float()
+    k1 = k0 + torch.rand(n, 2, generator=g) * 3
+    s0 = torch.ones(n, 3) * 0.25
+    s0[:, 2] = 0
+    s1 = torch.rand(n, 3, generator=g) * 0.5
+    s1[:, 2] = 0
+    K = (160.0, 160.0, 160.0, 120.0)
+    R = torch.linalg.qr(torch.randn(3, 3, generator=g, dtype=torch.float64))[0].to(gpu)
+    a0, a1 = s0.clone().to(gpu), s1.clone().to(gpu)
+    c0, c0w = ops.match_cov(d0.to(gpu), k0.to(gpu), a0, None, *K, rot=R)
+    c1 = ops.match_cov(d1.to(gpu), k1.to(gpu), a1, None, *K)
+    b0, b1 = s0.clone().to(gpu), s1.clone().to(gpu)
+    p0, p0w, p1 = ops.match_cov_pair(d0.to(gpu), k0.to(gpu), b0, d1.to(gpu), k1.to(gpu), b1, *K, rot=R)
+    assert torch.equal(p0, c0) and torch.equal(p0w, c0w) and torch.equal(p1, c1)
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)
+
+
 def test_match_cov_given_depth_cov_and_nan(gpu):
     """depth_cov branch (flow_cov None in the reference == default sigma, use given variance) and NaN propagation."""
     from macvo_amd import ops
