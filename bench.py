@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames timed for the CPU baseline (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graphs", action="store_true", help="replay the decoder-side segment (12 lookups + epilogue + selector) as a hipGraph (measured slower than eager launches on ROCm 7.2: 2.46 k vs 2.60 k fps)")
+    ap.add_argument("--driver", choices=["native", "python"], default="native",
+                    help="host-side frame sequencing: the C++ driver (mv_frame_pipe_*) or the Python loop over the per-op entry points")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events around the volume kernel")
     return ap.parse_args()
 
@@ -72,7 +74,7 @@ def main():
 
     from macvo_amd import ops
     from macvo_amd.distributed import gather_poses
-    from macvo_amd.pipeline import Camera, FrameInputs, HotPath, HotPathConfig
+    from macvo_amd.pipeline import Camera, FrameInputs, HotPath, HotPathConfig, NativeHotPath
     from tests import synth
 
     H, W, C = args.height, args.width, args.channels
@@ -95,8 +97,11 @@ def main():
     use_graphs = args.graphs
     assert args.pool % 6 == 0 or not use_graphs, "--pool must be a multiple of 6 with graphs (one graph per resident frame)"
     frames = [FrameInputs(static=True, **{k: to_dev(v) for k, v in fr.items()}) for fr in frames_cpu]
-    hot = HotPath(Camera(**cam), HotPathConfig(graph_type=args.graph, feature_layout=args.layout,
-                                               volume_precision=args.volume_precision, use_graphs=use_graphs), dev)
+    native = args.driver == "native"
+    assert not (native and use_graphs), "--graphs belongs to the Python driver"
+    hot = (NativeHotPath if native else HotPath)(
+        Camera(**cam), HotPathConfig(graph_type=args.graph, feature_layout=args.layout,
+                                     volume_precision=args.volume_precision, use_graphs=use_graphs), dev)
     torch.manual_seed(1234 + rank)  # the selector consumes the global CPU generator (reference behaviour)
 
     # ---- per-launch HIP events around the dominant kernel (cost volume), on the launch stream
@@ -114,7 +119,7 @@ def main():
         vol_events.append((e0, e1))
         return out
 
-    if not args.no_kernel_events:
+    if not args.no_kernel_events and not native:
         ops.corr_volume = timed_corr_volume
 
     hot.initialize(frames[0])
@@ -140,6 +145,8 @@ def main():
     barrier()
     torch.cuda.synchronize()
     record["on"] = True
+    if native and not args.no_kernel_events:
+        hot.time_volume(args.steps)   # HIP-event pairs around the volume GEMM, recorded by the driver on its GEMM stream
     t0 = time.perf_counter()
     # software-pipelined stream (frame t+1's frontend is queued before frame t's host randperm); K full run_pairs
     for _ in hot.run((frames[(t_idx + k) % args.pool] for k in range(args.steps)), pose_sink=poses):
@@ -173,8 +180,10 @@ def main():
     except Exception:  # noqa: BLE001
         traffic = None
     roofline = None
+    if native and not args.no_kernel_events:
+        vol_events = hot.volume_times_ms()
     if vol_events:
-        ms = [a.elapsed_time(b) for a, b in vol_events]
+        ms = vol_events if native else [a.elapsed_time(b) for a, b in vol_events]
         avg_s = sum(ms) / len(ms) / 1e3
         if args.feat_dtype == "f32" and args.volume_precision == "split3":
             ach = flops_per_launch / avg_s / 1e12
@@ -247,7 +256,7 @@ def main():
             "config": {"workload": f"configs[1]: single MI355X, {W}x{H} synthetic stereo, HIP correlation volume + GN backend, 1-seq stream per GPU",
                        "per_step": f"2 cost volumes [{n_q}x{C}x{n_q}] + {args.iters}x2 9x9 lookups + epilogue + CovAwareSelector_NoDepth(200) + 2x MatchCovariance(31x31) + TwoFrame_PGO({args.graph})",
                        "feature_dtype": args.feat_dtype, "feature_layout": args.layout, "volume_precision": args.volume_precision,
-                       "hip_graphs": use_graphs,
+                       "hip_graphs": use_graphs, "host_driver": args.driver,
                        "excluded": "learned FlowFormer layers (source + weights absent from the reference checkout)",
                        "parallelism": f"{world} independent sequence(s), one per GPU; one all_gather of poses"},
             "roofline": roofline,

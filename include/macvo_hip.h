@@ -277,6 +277,91 @@ int mv_pgo_solve(int nprob, const int32_t* offsets, int graph_type, const float*
                  const mvLMParams* params /* host */, double* out_pose, double* out_info,
                  float* out_pose_f32, mvStream_t stream);
 
+/* -------------------------------------------------------------------------------------------
+ * Native per-frame driver: the host-side sequencing of one `MACVO.run_pair` (Odometry/MACVO.py:173-311) and
+ * `FlowFormerCovFrontend.estimate_pair` (Module/Frontend/Frontend.py:215-232) for the hot path, as two host calls per
+ * frame instead of ~30 (a Python loop over the entry points above is interpreter-bound at ~370 us/frame, more than the
+ * GPU work).  Internally: 4 HIP streams (volume GEMM | lookups+epilogue+selector | tracking..filter | LM solve),
+ * rotating buffer slots carved out of ONE caller-provided device arena, events for every cross-stream hazard.
+ *
+ * Call order (frame 0 = MACVO.initialize :158-171, depth only):
+ *     mv_frame_pipe_enqueue(p, &in0, s, 0);
+ *     mv_frame_pipe_enqueue(p, &in1, s, 1);
+ *     loop t = 1..: mv_frame_pipe_enqueue(p, &in[t+1], s, 1);          // next frame's frontend first (software pipeline)
+ *                   mv_frame_pipe_wait_candidates(p, &n);                // host blocks on frame t's selector only
+ *                   perm = torch.randperm(n)[:num_point]                 // stays on the host CPU: bit-exact indices
+ *                   mv_frame_pipe_finish(p, perm, n_sel, pose_sink);     // backend + solve of frame t
+ * At most two tracked frames may be in flight (enqueued, not finished).
+ */
+typedef struct mvFramePipe mvFramePipe;
+
+typedef struct {
+    int32_t H, W;              /* image size, multiples of 8 */
+    int32_t C;                 /* feature channels (% 16 == 0) */
+    int32_t pairs;             /* volume batch; must be 2: pair 0 stereo, pair 1 temporal (Frontend.py:219-220) */
+    int32_t iters;             /* decoder iterations = window lookups per frame (12) */
+    int32_t radius;            /* lookup radius (4) */
+    int32_t feat_dtype;        /* MV_F32 | MV_F16 | MV_BF16 */
+    int32_t layout;            /* MV_LAYOUT_* of the feature maps */
+    int32_t volume_split3;     /* 1: fp32 HWC features, split on the device and multiplied as bf16x3 */
+    int32_t selector_mode;     /* MV_KP_NODEPTH | MV_KP_FULL */
+    int32_t kp_kernel_size, kp_mask_width;
+    int32_t num_point;         /* keypoints per frame (200) */
+    int32_t edgewidth;         /* strict border of the tracked keypoints (32) */
+    int32_t min_num_point;     /* fewer valid observations -> pose not optimised (MACVO.py:64,303-307) */
+    int32_t graph_type;        /* MV_GRAPH_* */
+    int32_t filters;           /* mv_obs_filter flags */
+    int32_t cov_kernel_size;   /* 31 */
+    float fx, fy, cx, cy, baseline;
+    float bl_fx, bl_fx_sq;     /* baseline*fx and its square, rounded once from double (StereoDepth.py:270-282) */
+    float match_cov_default, max_match_cov, max_depth_cov, max_depth;
+    float min_flow_cov_sq, min_depth_cov, filter_min_depth;
+    float reserved;
+    mvLMParams lm;
+} mvFramePipeConfig;
+
+/* what the learned layers hand over for one estimate_pair (device pointers, fp32 unless noted) */
+typedef struct {
+    const void* fmap1;      /* [pairs, C, H/8, W/8] (CHW) or [pairs, H/8, W/8, C] (HWC), feat_dtype */
+    const void* fmap2;
+    const float* coords;    /* [iters, pairs, 2, H/8, W/8]: coords1 entering each decoder iteration (covhead.py:85-92) */
+    const float* flow;      /* [pairs, 2, H, W] last upsampled flow        } either these two ...            */
+    const float* logcov;    /* [pairs, 2, H, W] last upsampled log-sigma   }                                  */
+    const float* flow8;     /* [pairs, 2, H/8, W/8]   } ... or the 1/8-resolution fields + convex-upsampling */
+    const float* cov8;      /* [pairs, 2, H/8, W/8]   }     masks of the last iteration (covhead.py:119-135); */
+    const float* up_mask;   /* [pairs, 576, H/8, W/8] }     up_mask BEFORE its 0.25 scale, cov_mask after      */
+    const float* cov_mask;  /* [pairs, 576, H/8, W/8] }                                                       */
+} mvFrameInputs;
+
+/* buffers reported by mv_frame_pipe_buffer (element counts, not bytes) */
+enum {
+    MV_FB_VOLUME = 0, MV_FB_TOKENS, MV_FB_DISPARITY, MV_FB_DISPARITY_COV, MV_FB_DEPTH, MV_FB_DEPTH_COV, MV_FB_MATCH_FLOW,
+    MV_FB_MATCH_COV, MV_FB_CAND, MV_FB_COUNT, MV_FB_STATS,                       /* frontend side: age counts enqueued frames */
+    MV_FB_KP0, MV_FB_KP0F, MV_FB_KP1, MV_FB_INBOUND, MV_FB_VALS, MV_FB_SIGMA0, MV_FB_SIGMA1, MV_FB_POS_TC, MV_FB_POS_TW,
+    MV_FB_ROT, MV_FB_COV0, MV_FB_COV0W, MV_FB_COV1, MV_FB_VALID, MV_FB_NVALID, MV_FB_POSE64, MV_FB_INFO,   /* backend side */
+    MV_FB_POSE                                                                   /* fp32 [7]; age 0 = newest solve's output */
+};
+
+size_t mv_frame_pipe_arena_bytes(const mvFramePipeConfig* cfg);           /* 0 = invalid configuration */
+/* arena: device memory, 256-byte aligned, >= mv_frame_pipe_arena_bytes; must outlive the pipe */
+int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, size_t arena_bytes, mvFramePipe** out);
+void mv_frame_pipe_destroy(mvFramePipe* p);
+int mv_frame_pipe_set_pose(mvFramePipe* p, const float* pose7_host);      /* prior of the next frame (blocking) */
+/* frontend half of a frame; inputs must be complete on `in_stream` (an event is recorded there) and stay untouched
+ * until the frame's lookups ran.  with_selector = 0 for the very first frame. */
+int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_stream, int with_selector);
+int mv_frame_pipe_wait_candidates(mvFramePipe* p, int32_t* n_cand);       /* oldest unfinished frame; blocks the host */
+/* perm_host: int64[n_sel] = randperm(n_cand)[:num_point]; pose_sink: device fp32[7] or NULL (copy of the new pose) */
+int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, int n_sel, float* pose_sink);
+/* block_host != 0: wait for all four streams; else make `stream` wait for everything enqueued so far */
+int mv_frame_pipe_sync(mvFramePipe* p, mvStream_t stream, int block_host);
+/* measurement hook (bench.py roofline): record a HIP-event pair around each of the next max_launches volume GEMMs on the
+ * stream they run on (0 = off; restarts the count), and read the elapsed milliseconds back (blocks on that stream) */
+int mv_frame_pipe_time_volume(mvFramePipe* p, int max_launches);
+int mv_frame_pipe_volume_times(mvFramePipe* p, float* ms, int cap, int* n);
+/* where a result lives inside the arena; age 0 = newest frame that passed that stage, 1 = the one before */
+int mv_frame_pipe_buffer(mvFramePipe* p, int which, int age, void** ptr, size_t* count);
+
 #ifdef __cplusplus
 }
 #endif

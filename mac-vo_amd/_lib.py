@@ -47,6 +47,26 @@ class mvLMParams(C.Structure):
     ]
 
 
+class mvFramePipeConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "H", "W", "C", "pairs", "iters", "radius", "feat_dtype", "layout", "volume_split3", "selector_mode",
+        "kp_kernel_size", "kp_mask_width", "num_point", "edgewidth", "min_num_point", "graph_type", "filters",
+        "cov_kernel_size")] + [(n, C.c_float) for n in (
+        "fx", "fy", "cx", "cy", "baseline", "bl_fx", "bl_fx_sq", "match_cov_default", "max_match_cov", "max_depth_cov",
+        "max_depth", "min_flow_cov_sq", "min_depth_cov", "filter_min_depth", "reserved")] + [("lm", mvLMParams)]
+
+
+class mvFrameInputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("fmap1", "fmap2", "coords", "flow", "logcov", "flow8", "cov8", "up_mask",
+                                          "cov_mask")]
+
+
+# mv_frame_pipe_buffer ids (enum order of the header)
+FB_NAMES = ("VOLUME", "TOKENS", "DISPARITY", "DISPARITY_COV", "DEPTH", "DEPTH_COV", "MATCH_FLOW", "MATCH_COV", "CAND",
+            "COUNT", "STATS", "KP0", "KP0F", "KP1", "INBOUND", "VALS", "SIGMA0", "SIGMA1", "POS_TC", "POS_TW", "ROT", "COV0",
+            "COV0W", "COV1", "VALID", "NVALID", "POSE64", "INFO", "POSE")
+FB = {n: i for i, n in enumerate(FB_NAMES)}
+
 _P = C.c_void_p
 # name -> (restype, argtypes): every symbol include/macvo_hip.h declares
 SIGNATURES = {
@@ -72,6 +92,17 @@ SIGNATURES = {
     "mv_backproject": (C.c_int, [_P, _P, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_int,
                                  _P, _P, _P, _P]),
     "mv_obs_filter": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P, _P]),
+    "mv_frame_pipe_arena_bytes": (C.c_size_t, [C.POINTER(mvFramePipeConfig)]),
+    "mv_frame_pipe_create": (C.c_int, [C.POINTER(mvFramePipeConfig), _P, C.c_size_t, C.POINTER(_P)]),
+    "mv_frame_pipe_destroy": (None, [_P]),
+    "mv_frame_pipe_set_pose": (C.c_int, [_P, _P]),
+    "mv_frame_pipe_enqueue": (C.c_int, [_P, C.POINTER(mvFrameInputs), _P, C.c_int]),
+    "mv_frame_pipe_wait_candidates": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "mv_frame_pipe_finish": (C.c_int, [_P, _P, C.c_int, _P]),
+    "mv_frame_pipe_sync": (C.c_int, [_P, _P, C.c_int]),
+    "mv_frame_pipe_time_volume": (C.c_int, [_P, C.c_int]),
+    "mv_frame_pipe_volume_times": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
+    "mv_frame_pipe_buffer": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),
 }
 
 _lib = None

@@ -5,41 +5,50 @@
 // delta[i][j] = (dy[i], dx[j]) added to (x, y)  =>  channel k = K*i + j samples (x + i - r, y + j - r),
 // bilinear_sampler = grid_sample(align_corners=True, zeros) after normalising by (W2-1), (H2-1).
 //
-// gfx950 design (HBM/L2 gather-bound, ~0.7 KB useful per query)
-//   * a 256-thread workgroup owns 32 consecutive queries of one batch item; each wave owns 8 of them.
-//   * staging: the wave gathers, for its 8 queries, the (K+3)^2 cell block that covers every tap
-//     (block origin floor(x)-r-1: one spare cell each side absorbs the fp32 normalise/un-normalise
-//     round trip) with all 18 wave-wide loads in flight at once (row segments of 48 B per query),
-//     zero-filling out-of-image cells (= zero padding) -> LDS.
-//   * compute: lane = tap (81 of 128... of 64x2), per-tap fp32 arithmetic replays grid_sample's exactly
-//     (true division, same op order) so results match the ATen CPU kernel to rounding.
-//   * output [B, K*K, H1, W1] is channel-major: results are transposed through LDS so every channel row
-//     is written as one 128-B segment of 32 consecutive queries.
+// gfx950 design.  One frame's lookup (9600 queries) is ~4 MB of traffic: neither HBM nor the texture path is the
+// limit, the VALU instruction stream of the few resident waves is (measured: launch floor 3.4 us, staging + stores
+// +1.6 us, and the per-tap coordinate arithmetic of a lane-per-tap formulation another +3.5 us).  Hence:
+//   * a wave owns QPW queries; a workgroup QPB of them (QPB consecutive queries = one contiguous output segment per
+//     channel).
+//   * staging: per query the (K+3)^2 cell block that covers every tap (block origin floor(x)-r-1: one spare cell each
+//     side absorbs the fp32 normalise/un-normalise round trip) is fetched with lane = (row-in-group, column): the
+//     lane's (row, column) split is computed once, the query origin is wave-uniform (readlane -> SGPR), so a load costs
+//     a handful of VALU ops; all loads are issued before LDS is touched; out-of-image cells are zero (= zero padding).
+//   * per-AXIS coordinate math: RAFT's normalise + ATen's un-normalise + floor/weights depend only on (query, i) for x
+//     and (query, j) for y: 2K values per query instead of 2*K*K.  Lanes [0, 2K) of an "axis pass" evaluate them for one
+//     query, the next 2K lanes for the next query, ... (true division, same fp32 op order as grid_sample), and the tap
+//     phase fetches its (weight, cell) pair per axis with ds_bpermute.  Results are bit-identical to the per-tap form.
+//   * taps: lane = tap (K*K of them in ceil(K*K/64) rounds): 4 LDS reads + the ATen bilinear sum.
+//   * output [B, K*K, H1, W1] is channel-major: results are transposed through LDS (aliasing the staging buffer) so
+//     every channel row is written as one QPB*4-byte segment.
 #include "common.h"
 
 namespace {
 
-template <int R, int QPW>
-__global__ __launch_bounds__(64 * (32 / QPW)) void corr_lookup_kernel(const float* __restrict__ vol,
-                                                           const float* __restrict__ coords,
-                                                           float* __restrict__ out, int N1, int H2, int W2) {
+template <int R, int QPW, int QPB>
+__global__ __launch_bounds__(64 * (QPB / QPW)) void corr_lookup_kernel(const float* __restrict__ vol,
+                                                                        const float* __restrict__ coords,
+                                                                        float* __restrict__ out, int N1, int H2, int W2) {
     constexpr int K = 2 * R + 1;
     constexpr int KK = K * K;
     constexpr int BS = K + 3;            // staged block edge (12 for r = 4)
     constexpr int CELLS = BS * BS;       // 144
-    constexpr int QPB = 32;              // queries per workgroup (one 128-B output segment per channel)
     constexpr int NWAVE = QPB / QPW;     // waves per workgroup, QPW queries each
     constexpr int NTHR = 64 * NWAVE;
-    constexpr int NLOAD = (QPW * CELLS + 63) / 64;  // 18 wave-wide loads
+    constexpr int RPR = 64 / BS;         // block rows one wave-wide load covers (5 for r = 4)
+    constexpr int LPR = RPR * BS;        // active lanes of such a load (60)
+    constexpr int NROUND = (BS + RPR - 1) / RPR;    // loads per query (3)
     constexpr int TAP_ROUNDS = (KK + 63) / 64;      // 2 for r = 4
+    constexpr int QPA = 64 / (2 * K);               // queries one axis pass covers (3 for r = 4)
+    constexpr int APASS = (QPW + QPA - 1) / QPA;
+    static_assert(QPW <= 32 && (QPW & (QPW - 1)) == 0 && QPB % QPW == 0, "bad lookup tiling");
 
-    // one LDS region, two lives: staged cell blocks (read by the tap phase), then the transposed outputs.  Keeping the
-    // footprint at max(22.5, 10.7) KB lets a lookup workgroup co-reside with four 32-KB volume-GEMM workgroups on a CU
-    // (the pipeline runs the next frame's GEMM on another stream while this frame's lookups execute).
-    constexpr int BLK_FLOATS = NWAVE * (QPW * CELLS + 64);
+    // one LDS region, two lives: staged cell blocks (read by the tap phase), then the transposed outputs
+    constexpr int BLK_STRIDE = QPW * CELLS;
+    constexpr int BLK_FLOATS = NWAVE * BLK_STRIDE;
     constexpr int OUT_FLOATS = KK * (QPB + 1);
     __shared__ float smem[BLK_FLOATS > OUT_FLOATS ? BLK_FLOATS : OUT_FLOATS];
-    float (*blk)[QPW * CELLS + 64] = reinterpret_cast<float (*)[QPW * CELLS + 64]>(smem);
+    float* blk = smem + (threadIdx.x >> 6) * BLK_STRIDE;
     float (*outs)[QPB + 1] = reinterpret_cast<float (*)[QPB + 1]>(smem);
 
     const int b = blockIdx.y;
@@ -47,11 +56,10 @@ __global__ __launch_bounds__(64 * (32 / QPW)) void corr_lookup_kernel(const floa
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int slice = H2 * W2;
 
-    // lane s < 8 owns query s of this wave: load its coords, derive the block origin
+    // lane s < QPW owns query s of this wave: load its coords, derive the block origin
     const int qmine = q0 + wave * QPW + (lane & (QPW - 1));
-    const bool qvalid = qmine < N1;
     float x = 0.f, y = 0.f;
-    if (qvalid) {
+    if (qmine < N1) {
         x = coords[((size_t)b * 2 + 0) * N1 + qmine];
         y = coords[((size_t)b * 2 + 1) * N1 + qmine];
     }
@@ -60,27 +68,55 @@ __global__ __launch_bounds__(64 * (32 / QPW)) void corr_lookup_kernel(const floa
     const int bx = ((xc == xc) ? (int)floorf(xc) : 0) - R - 1;
     const int by = ((yc == yc) ? (int)floorf(yc) : 0) - R - 1;
 
-    // ---- stage 8 x 144 cells: issue every load before touching LDS
-    float v[NLOAD];
+    // ---- stage QPW x CELLS cells: issue every load before touching LDS
+    const int cyl = lane / BS, cxl = lane - cyl * BS;
+    float v[QPW][NROUND];
 #pragma unroll
-    for (int r = 0; r < NLOAD; ++r) {
-        const int idx = r * 64 + lane;
-        const int s = idx / CELLS;
-        const int c = idx - s * CELLS;
-        const int cy = c / BS, cx = c - cy * BS;
-        const int sbx = __shfl(bx, s & (QPW - 1), 64), sby = __shfl(by, s & (QPW - 1), 64);
+    for (int s = 0; s < QPW; ++s) {
+        const int sbx = __builtin_amdgcn_readlane(bx, s), sby = __builtin_amdgcn_readlane(by, s);
         const int q = q0 + wave * QPW + s;
-        const int gx = sbx + cx, gy = sby + cy;
-        const bool ok = (s < QPW) && (q < N1) && gx >= 0 && gx < W2 && gy >= 0 && gy < H2;
-        v[r] = ok ? vol[((size_t)b * N1 + q) * slice + gy * W2 + gx] : 0.f;
-    }
+        const float* __restrict__ base = vol + ((size_t)b * N1 + q) * slice;
+        const int gx = sbx + cxl;
+        const bool okx = lane < LPR && q < N1 && gx >= 0 && gx < W2;
 #pragma unroll
-    for (int r = 0; r < NLOAD; ++r) blk[wave][r * 64 + lane] = v[r];
+        for (int k = 0; k < NROUND; ++k) {
+            const int row = k * RPR + cyl, gy = sby + row;
+            const bool ok = okx && row < BS && gy >= 0 && gy < H2;
+            v[s][k] = ok ? base[gy * W2 + gx] : 0.f;
+        }
+    }
+
+    // ---- per-axis coordinate math (overlaps the loads in flight): lane -> (query sq of the pass, axis, offset)
+    const float wm1 = (float)(W2 - 1), hm1 = (float)(H2 - 1);
+    const int asq = lane / (2 * K), aa = lane - asq * (2 * K);
+    const bool a_is_y = aa >= K;
+    const int aoff = (a_is_y ? aa - K : aa) - R;
+    const float adim = a_is_y ? hm1 : wm1;
+    float ax_w[APASS];
+    int ax_c[APASS];   // clamped cell offset in the block | (1 << 8) when the tap's 2-cell span lies inside the block
+#pragma unroll
+    for (int ps = 0; ps < APASS; ++ps) {
+        const int s = ps * QPA + asq;   // lanes with s >= QPW compute garbage nobody reads
+        const float qx = __shfl(x, s, 64), qy = __shfl(y, s, 64);
+        const int obx = __shfl(bx, s, 64), oby = __shfl(by, s, 64);
+        const float cs = (a_is_y ? qy : qx) + (float)aoff;
+        const float g = (2.f * cs) / adim - 1.f;          // RAFT bilinear_sampler normalisation
+        const float ic = (g + 1.f) * (adim / 2.f);        // ATen grid_sampler_unnormalize, align_corners=True
+        const float f0 = floorf(ic);
+        ax_w[ps] = ic - f0;
+        const int c = (int)fminf(fmaxf(f0, -2.0e6f), 2.0e6f) - (a_is_y ? oby : obx);
+        const bool inb = c >= 0 && c <= BS - 2;
+        ax_c[ps] = min(max(c, 0), BS - 2) | (inb ? 256 : 0);
+    }
+
+#pragma unroll
+    for (int s = 0; s < QPW; ++s)
+#pragma unroll
+        for (int k = 0; k < NROUND; ++k)
+            if (lane < LPR && k * LPR + lane < CELLS) blk[s * CELLS + k * LPR + lane] = v[s][k];
     __syncthreads();
 
-    // ---- taps: lane -> (i, j); replay RAFT normalise + ATen unnormalise + bilinear weights in fp32
-    const float wm1 = (float)(W2 - 1), hm1 = (float)(H2 - 1);
-    const float sx = wm1 / 2.f, sy = hm1 / 2.f;
+    // ---- taps: lane -> (i, j)
     float res[TAP_ROUNDS][QPW];
 #pragma unroll
     for (int tr = 0; tr < TAP_ROUNDS; ++tr) {
@@ -88,33 +124,21 @@ __global__ __launch_bounds__(64 * (32 / QPW)) void corr_lookup_kernel(const floa
         const int ti = tap / K, tj = tap - ti * K;
 #pragma unroll
         for (int s = 0; s < QPW; ++s) {
-            const float qx = __shfl(x, s, 64), qy = __shfl(y, s, 64);
-            const int sbx = __shfl(bx, s, 64), sby = __shfl(by, s, 64);
-            if (tap < KK) {
-                const float xs = qx + (float)(ti - R);
-                const float ys = qy + (float)(tj - R);
-                const float xg = (2.f * xs) / wm1 - 1.f;
-                const float yg = (2.f * ys) / hm1 - 1.f;
-                const float ix = (xg + 1.f) * sx;
-                const float iy = (yg + 1.f) * sy;
-                const float fx0 = floorf(ix), fy0 = floorf(iy);
-                const float w = ix - fx0, e = 1.f - w;
-                const float n = iy - fy0, so = 1.f - n;
-                int cx = (int)fminf(fmaxf(fx0, -2.0e6f), 2.0e6f) - sbx;
-                int cy = (int)fminf(fmaxf(fy0, -2.0e6f), 2.0e6f) - sby;
-                const bool inblk = cx >= 0 && cx <= BS - 2 && cy >= 0 && cy <= BS - 2;
-                cx = min(max(cx, 0), BS - 2);
-                cy = min(max(cy, 0), BS - 2);
-                const float* p = &blk[wave][s * CELLS + cy * BS + cx];
-                const float vnw = inblk ? p[0] : 0.f, vne = inblk ? p[1] : 0.f;
-                const float vsw = inblk ? p[BS] : 0.f, vse = inblk ? p[BS + 1] : 0.f;
-                // ATen: (nw_val*nw + ne_val*ne) + sw_val*sw + se_val*se with nw = s*e, ne = s*w, sw = n*e, se = n*w
-                float r0 = vnw * (so * e);
-                r0 = r0 + vne * (so * w);
-                r0 = r0 + vsw * (n * e);
-                r0 = r0 + vse * (n * w);
-                res[tr][s] = r0;
-            }
+            const int ps = s / QPA, sq = s - ps * QPA;
+            const int srcx = sq * 2 * K + ti, srcy = sq * 2 * K + K + tj;
+            const float w = __shfl(ax_w[ps], srcx, 64), n = __shfl(ax_w[ps], srcy, 64);
+            const int pcx = __shfl(ax_c[ps], srcx, 64), pcy = __shfl(ax_c[ps], srcy, 64);
+            const bool inblk = ((pcx & pcy) & 256) != 0;
+            const float* p = &blk[s * CELLS + (pcy & 255) * BS + (pcx & 255)];
+            const float e = 1.f - w, so = 1.f - n;
+            const float vnw = inblk ? p[0] : 0.f, vne = inblk ? p[1] : 0.f;
+            const float vsw = inblk ? p[BS] : 0.f, vse = inblk ? p[BS + 1] : 0.f;
+            // ATen: (nw_val*nw + ne_val*ne) + sw_val*sw + se_val*se with nw = s*e, ne = s*w, sw = n*e, se = n*w
+            float r0 = vnw * (so * e);
+            r0 = r0 + vne * (so * w);
+            r0 = r0 + vsw * (n * e);
+            r0 = r0 + vse * (n * w);
+            res[tr][s] = r0;
         }
     }
     __syncthreads();   // every wave is done reading the staged blocks: the region becomes the output transpose buffer
@@ -128,9 +152,9 @@ __global__ __launch_bounds__(64 * (32 / QPW)) void corr_lookup_kernel(const floa
     }
     __syncthreads();
 
-    // ---- transposed store: each channel row = 32 consecutive queries (128 B)
+    // ---- transposed store: each channel row = QPB consecutive queries
     for (int idx = t; idx < KK * QPB; idx += NTHR) {
-        const int k = idx >> 5, c = idx & 31;
+        const int k = idx / QPB, c = idx - k * QPB;
         if (q0 + c < N1) out[((size_t)b * KK + k) * N1 + q0 + c] = outs[k][c];
     }
 }
@@ -156,16 +180,18 @@ extern "C" int mv_corr_lookup(const float* vol, const float* coords, float* out,
     if (radius < 1 || radius > 4) return MV_ERR_UNSUPPORTED;
     if (B > 65535) return MV_ERR_UNSUPPORTED;
     const int N1 = H1 * W1;
-    dim3 grid(mv_ceil_div(N1, 32), B);
     hipStream_t s = (hipStream_t)stream;
-    // small launches (one frame: ~300 workgroups for 256 CUs) are latency-bound -> spread a workgroup's 32 queries
-    // over 16 waves; large batches are throughput-bound -> 8 queries per wave amortise the per-wave setup
+    // small launches (one frame: 9600 queries for 256 CUs) are latency-bound -> 16-query workgroups of 8 waves (600
+    // workgroups, 5.96 us vs 7.15 us for 32-query ones); large batches (B = 32: 58.5 us, ~2.4 TB/s) are throughput-bound ->
+    // 4 queries per wave amortise the per-wave setup, 32-query (128-B) output segments
     const bool small = (size_t)B * N1 <= (size_t)lookup_small_threshold();
 #define MV_LOOKUP(R)                                                                                                  \
     if (small)                                                                                                        \
-        hipLaunchKernelGGL((corr_lookup_kernel<R, 2>), grid, dim3(1024), 0, s, vol, coords, out, N1, H2, W2);         \
+        hipLaunchKernelGGL((corr_lookup_kernel<R, 2, 16>), dim3(mv_ceil_div(N1, 16), B), dim3(512), 0, s, vol, coords, \
+                           out, N1, H2, W2);                                                                          \
     else                                                                                                              \
-        hipLaunchKernelGGL((corr_lookup_kernel<R, 8>), grid, dim3(256), 0, s, vol, coords, out, N1, H2, W2)
+        hipLaunchKernelGGL((corr_lookup_kernel<R, 4, 32>), dim3(mv_ceil_div(N1, 32), B), dim3(512), 0, s, vol, coords, \
+                           out, N1, H2, W2)
     switch (radius) {
         case 1: MV_LOOKUP(1); break;
         case 2: MV_LOOKUP(2); break;

@@ -1,0 +1,525 @@
+// Native per-frame driver: one MACVO.run_pair of kernel launches per host call (SURVEY.md §8 A1-A22 call order)
+//
+// Replaces the host-side sequencing of Odometry/MACVO.py:173-311 (run_pair) + Module/Frontend/Frontend.py:215-232
+// (estimate_pair) for the hot path.  The reference issues ~150 tiny torch ops per frame from Python; a Python loop over
+// this library's own entry points still costs ~370 us of interpreter / ctypes time per frame, which is MORE than the
+// ~330 us of GPU work (measured: the frame rate did not move when the volume GEMM got 4x faster).  Here the whole
+// enqueue side is C++: ~30 launches per frame at 2-3 us each, two host calls per frame.
+//
+// Four HIP streams (created here, independent of the caller's):
+//   vol    the MFMA-bound cost-volume GEMM of frame t+1 (double-buffered volumes)
+//   main   decoder side of a frame: 12 window lookups, (convex upsampling,) epilogue, dense selector, count -> host
+//   back   pose-dependent half of frame t: perm H2D, gather, tracking, back-projection, covariances, filter
+//   side   the LM solve (the GPU analogue of the reference's optimizer child process, Optimization/Interface.py:80-96)
+// Frame t+1's frontend is enqueued before frame t's `finish`, so the selector's host round trip (candidate count ->
+// torch.randperm on the CPU, kept for bit-exact indices -> permutation back) never idles the GPU.
+//
+// Memory: every device buffer lives in ONE caller-provided arena (a torch tensor in the Python host), carved up here;
+// mv_frame_pipe_buffer reports where each piece is so the host can view results without copies.  Slots rotate so a
+// stage never overwrites data a still-running stage of another stream reads (maps x3, everything else x2) and the
+// cross-stream hazards are closed with events (see `enqueue` / `finish`).
+#include "common.h"
+#include <deque>
+#include <vector>
+#include <new>
+#include <string.h>
+
+#define MV_HIP(call)                                   \
+    do {                                               \
+        if ((call) != hipSuccess) return MV_ERR_LAUNCH; \
+    } while (0)
+#define MV_TRY(call)               \
+    do {                           \
+        const int rc_ = (call);    \
+        if (rc_ != MV_OK) return rc_; \
+    } while (0)
+
+namespace {
+
+constexpr int N_MAPS = 3, N_PERM = 4, N_INEV = 8;
+
+struct Maps {
+    float *disparity, *disparity_cov, *depth, *depth_cov, *match_flow, *match_cov;
+    uint8_t* bad_mask;
+};
+
+struct Backend {
+    int64_t *perm, *kp0;
+    float *kp0f, *kp1, *vals, *sigma0, *sigma1, *pos_Tc, *pos_Tw;
+    uint8_t *inbound, *valid;
+    double *rot, *cov0, *cov0w, *cov1, *pose64, *info;
+    int32_t* n_valid;
+    int n_sel;
+};
+
+struct Pending {
+    int maps, maps_prev, cand;
+    bool has_cand;
+};
+
+struct Carver {   // bump allocator over the arena (or a size counter when base == nullptr)
+    char* base;
+    size_t off = 0;
+    template <typename T>
+    T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+}  // namespace
+
+struct mvFramePipe {
+    mvFramePipeConfig c;
+    int plane, h8, w8, n8, KK;
+    char* arena;
+    size_t arena_bytes;
+    // device buffers
+    float* vol[2];
+    float* tok[2];
+    void* planes[2];   // bf16x3 split planes of fmap1 / fmap2 (volume_split3)
+    float *up_flow, *up_cov;
+    Maps maps[N_MAPS];
+    void* kp_ws;
+    size_t kp_ws_bytes;
+    int32_t* cand[2];
+    int32_t* count[2];
+    float* stats[2];
+    Backend be[2];
+    float* pose[3];
+    float *intr, *bl;
+    int32_t* offs;   // row n = {0, n}
+    // host
+    int32_t* h_count[2];      // pinned
+    int64_t* h_perm[N_PERM];  // pinned
+    // streams / events
+    hipStream_t s_vol, s_main, s_back, s_side;
+    hipEvent_t e_in[N_INEV], e_vol_done[2], e_vol_free[2], e_cand[2], e_backend[2], e_pgo, e_perm[N_PERM];
+    bool vol_free_valid[2], backend_valid[2], pgo_valid, perm_valid[N_PERM];
+    // state
+    long n_enq, n_fin;
+    int pose_cur;
+    int newest_maps;
+    std::deque<Pending> pending;
+    // optional timing of the dominant kernel (bench.py roofline): event pairs around each volume GEMM on its stream
+    std::vector<hipEvent_t> tv0, tv1;
+    int n_timed, timed_cap;
+};
+
+static size_t carve(mvFramePipe* p, char* base) {
+    const mvFramePipeConfig& c = p->c;
+    Carver a{base};
+    const size_t plane = p->plane, n8 = p->n8, B = c.pairs, N = c.num_point > 0 ? c.num_point : 1;
+    for (int k = 0; k < 2; ++k) p->vol[k] = a.take<float>(B * n8 * n8);
+    for (int k = 0; k < 2; ++k) p->tok[k] = a.take<float>(B * p->KK * n8);
+    for (int k = 0; k < 2; ++k) p->planes[k] = c.volume_split3 ? (void*)a.take<uint16_t>(3 * B * n8 * c.C) : nullptr;
+    p->up_flow = a.take<float>(B * 2 * plane);
+    p->up_cov = a.take<float>(B * 2 * plane);
+    for (int k = 0; k < N_MAPS; ++k) {
+        Maps& m = p->maps[k];
+        m.disparity = a.take<float>(plane);
+        m.disparity_cov = a.take<float>(plane);
+        m.depth = a.take<float>(plane);
+        m.depth_cov = a.take<float>(plane);
+        m.match_flow = a.take<float>(2 * plane);
+        m.match_cov = a.take<float>(3 * plane);
+        m.bad_mask = a.take<uint8_t>(plane);
+    }
+    p->kp_ws_bytes = mv_kp_select_workspace_bytes(c.H, c.W);
+    p->kp_ws = a.take<char>(p->kp_ws_bytes);
+    for (int k = 0; k < 2; ++k) {
+        p->cand[k] = a.take<int32_t>(plane);
+        p->count[k] = a.take<int32_t>(4);
+        p->stats[k] = a.take<float>(4);
+        Backend& b = p->be[k];
+        b.perm = a.take<int64_t>(N);
+        b.kp0 = a.take<int64_t>(2 * N);
+        b.kp0f = a.take<float>(2 * N);
+        b.kp1 = a.take<float>(2 * N);
+        b.vals = a.take<float>(11 * N);
+        b.sigma0 = a.take<float>(3 * N);
+        b.sigma1 = a.take<float>(3 * N);
+        b.pos_Tc = a.take<float>(3 * N);
+        b.pos_Tw = a.take<float>(3 * N);
+        b.inbound = a.take<uint8_t>(N);
+        b.valid = a.take<uint8_t>(N);
+        b.rot = a.take<double>(9);
+        b.cov0 = a.take<double>(9 * N);
+        b.cov0w = a.take<double>(9 * N);
+        b.cov1 = a.take<double>(9 * N);
+        b.pose64 = a.take<double>(7);
+        b.info = a.take<double>(4);
+        b.n_valid = a.take<int32_t>(1);
+    }
+    for (int k = 0; k < 3; ++k) p->pose[k] = a.take<float>(7);
+    p->intr = a.take<float>(4);
+    p->bl = a.take<float>(1);
+    p->offs = a.take<int32_t>(2 * (N + 1));
+    return (a.off + 255) & ~(size_t)255;
+}
+
+static int check_config(const mvFramePipeConfig* c) {
+    MV_CHECK_ARG(c);
+    MV_CHECK_ARG(c->H > 0 && c->W > 0 && c->H % 8 == 0 && c->W % 8 == 0);
+    MV_CHECK_ARG(c->C > 0 && c->C % 16 == 0 && c->pairs == 2 && c->iters >= 0);
+    MV_CHECK_ARG(c->radius >= 1 && c->radius <= 4);
+    MV_CHECK_ARG(c->selector_mode == MV_KP_NODEPTH || c->selector_mode == MV_KP_FULL);
+    MV_CHECK_ARG(c->num_point >= 0 && c->edgewidth >= 0 && c->min_num_point >= 0);
+    MV_CHECK_ARG(c->graph_type >= MV_GRAPH_ICP && c->graph_type <= MV_GRAPH_DISP);
+    MV_CHECK_ARG(!c->volume_split3 || (c->feat_dtype == MV_F32 && c->layout == MV_LAYOUT_HWC));
+    return MV_OK;
+}
+
+extern "C" size_t mv_frame_pipe_arena_bytes(const mvFramePipeConfig* cfg) {
+    if (check_config(cfg) != MV_OK) return 0;
+    mvFramePipe tmp{};
+    tmp.c = *cfg;
+    tmp.plane = cfg->H * cfg->W;
+    tmp.h8 = cfg->H / 8;
+    tmp.w8 = cfg->W / 8;
+    tmp.n8 = tmp.h8 * tmp.w8;
+    tmp.KK = (2 * cfg->radius + 1) * (2 * cfg->radius + 1);
+    return carve(&tmp, nullptr);
+}
+
+extern "C" void mv_frame_pipe_destroy(mvFramePipe* p) {
+    if (!p) return;
+    (void)hipStreamSynchronize(p->s_vol);
+    (void)hipStreamSynchronize(p->s_main);
+    (void)hipStreamSynchronize(p->s_back);
+    (void)hipStreamSynchronize(p->s_side);
+    auto ev = [](hipEvent_t e) { if (e) (void)hipEventDestroy(e); };
+    for (auto e : p->e_in) ev(e);
+    for (int k = 0; k < 2; ++k) { ev(p->e_vol_done[k]); ev(p->e_vol_free[k]); ev(p->e_cand[k]); ev(p->e_backend[k]); }
+    ev(p->e_pgo);
+    for (auto e : p->e_perm) ev(e);
+    for (auto e : p->tv0) ev(e);
+    for (auto e : p->tv1) ev(e);
+    for (int k = 0; k < 2; ++k) if (p->h_count[k]) (void)hipHostFree(p->h_count[k]);
+    for (auto h : p->h_perm) if (h) (void)hipHostFree(h);
+    if (p->s_vol) (void)hipStreamDestroy(p->s_vol);
+    if (p->s_main) (void)hipStreamDestroy(p->s_main);
+    if (p->s_back) (void)hipStreamDestroy(p->s_back);
+    if (p->s_side) (void)hipStreamDestroy(p->s_side);
+    delete p;
+}
+
+static int create_impl(mvFramePipe* p) {
+    const mvFramePipeConfig& c = p->c;
+    int lo = 0, hi = 0;
+    MV_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));   // hi = numerically lowest = highest priority
+    // the GEMM and the decoder side run at normal priority; the short pose-dependent kernels go first when slots free up
+    MV_HIP(hipStreamCreateWithPriority(&p->s_vol, hipStreamNonBlocking, 0));
+    MV_HIP(hipStreamCreateWithPriority(&p->s_main, hipStreamNonBlocking, 0));
+    MV_HIP(hipStreamCreateWithPriority(&p->s_back, hipStreamNonBlocking, hi));
+    MV_HIP(hipStreamCreateWithPriority(&p->s_side, hipStreamNonBlocking, hi));
+    auto mk = [](hipEvent_t* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming); };
+    for (auto& e : p->e_in) MV_HIP(mk(&e));
+    for (int k = 0; k < 2; ++k) {
+        MV_HIP(mk(&p->e_vol_done[k]));
+        MV_HIP(mk(&p->e_vol_free[k]));
+        MV_HIP(mk(&p->e_cand[k]));
+        MV_HIP(mk(&p->e_backend[k]));
+        MV_HIP(hipHostMalloc((void**)&p->h_count[k], 4 * sizeof(int32_t), hipHostMallocDefault));
+    }
+    MV_HIP(mk(&p->e_pgo));
+    const size_t N = c.num_point > 0 ? c.num_point : 1;
+    for (int k = 0; k < N_PERM; ++k) {
+        MV_HIP(mk(&p->e_perm[k]));
+        MV_HIP(hipHostMalloc((void**)&p->h_perm[k], N * sizeof(int64_t), hipHostMallocDefault));
+    }
+    // constants: selector workspace zeroed once (mv_kp_select leaves it zeroed), identity pose, PGO scalars, offsets table
+    MV_HIP(hipMemsetAsync(p->kp_ws, 0, p->kp_ws_bytes, p->s_main));
+    const float ident[7] = {0, 0, 0, 0, 0, 0, 1};
+    const float intr[4] = {c.fx, c.fy, c.cx, c.cy};
+    MV_HIP(hipMemcpyAsync(p->pose[0], ident, sizeof(ident), hipMemcpyHostToDevice, p->s_main));
+    MV_HIP(hipMemcpyAsync(p->intr, intr, sizeof(intr), hipMemcpyHostToDevice, p->s_main));
+    MV_HIP(hipMemcpyAsync(p->bl, &c.baseline, sizeof(float), hipMemcpyHostToDevice, p->s_main));
+    int32_t* offs = new (std::nothrow) int32_t[2 * (N + 1)];
+    if (!offs) return MV_ERR_WORKSPACE;
+    for (size_t n = 0; n <= N; ++n) { offs[2 * n] = 0; offs[2 * n + 1] = (int32_t)n; }
+    const hipError_t e = hipMemcpyAsync(p->offs, offs, 2 * (N + 1) * sizeof(int32_t), hipMemcpyHostToDevice, p->s_main);
+    const hipError_t e2 = hipStreamSynchronize(p->s_main);
+    delete[] offs;
+    MV_HIP(e);
+    MV_HIP(e2);
+    return MV_OK;
+}
+
+extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, size_t arena_bytes, mvFramePipe** out) {
+    MV_CHECK_ARG(out && arena);
+    MV_TRY(check_config(cfg));
+    mvFramePipe* p = new (std::nothrow) mvFramePipe{};
+    if (!p) return MV_ERR_WORKSPACE;
+    p->c = *cfg;
+    p->plane = cfg->H * cfg->W;
+    p->h8 = cfg->H / 8;
+    p->w8 = cfg->W / 8;
+    p->n8 = p->h8 * p->w8;
+    p->KK = (2 * cfg->radius + 1) * (2 * cfg->radius + 1);
+    p->arena = (char*)arena;
+    p->arena_bytes = arena_bytes;
+    if (((uintptr_t)arena & 255) != 0 || carve(p, p->arena) > arena_bytes) {
+        delete p;
+        return MV_ERR_WORKSPACE;
+    }
+    p->newest_maps = -1;
+    const int rc = create_impl(p);
+    if (rc != MV_OK) {
+        mv_frame_pipe_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return MV_OK;
+}
+
+extern "C" int mv_frame_pipe_set_pose(mvFramePipe* p, const float* pose7_host) {
+    MV_CHECK_ARG(p && pose7_host);
+    if (p->pgo_valid) MV_HIP(hipEventSynchronize(p->e_pgo));
+    MV_HIP(hipMemcpy(p->pose[p->pose_cur], pose7_host, 7 * sizeof(float), hipMemcpyHostToDevice));
+    return MV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ frontend half
+extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_stream, int with_selector) {
+    MV_CHECK_ARG(p && in && in->fmap1 && in->fmap2);
+    const mvFramePipeConfig& c = p->c;
+    MV_CHECK_ARG(c.iters == 0 || in->coords);
+    const bool up = in->flow8 != nullptr;
+    MV_CHECK_ARG(up ? (in->cov8 && in->up_mask && in->cov_mask) : (in->flow && in->logcov));
+    const long f = p->n_enq;
+    const int k = (int)(f & 1), m = (int)(f % N_MAPS);
+    MV_CHECK_ARG(!with_selector || p->newest_maps >= 0);   // a tracked frame needs the previous frame's maps
+    MV_CHECK_ARG(!with_selector || p->pending.size() < 2);  // slot rotation covers two tracked frames in flight
+    const int B = c.pairs;
+
+    // inputs were produced on the caller's stream
+    hipEvent_t e_in = p->e_in[f % N_INEV];
+    MV_HIP(hipEventRecord(e_in, (hipStream_t)in_stream));
+
+    // ---- volume GEMM (own stream; a buffer is rewritten only after the lookups that read it have finished)
+    MV_HIP(hipStreamWaitEvent(p->s_vol, e_in, 0));
+    if (p->vol_free_valid[k]) MV_HIP(hipStreamWaitEvent(p->s_vol, p->e_vol_free[k], 0));
+    const bool timed = p->n_timed < p->timed_cap;
+    if (timed) MV_HIP(hipEventRecord(p->tv0[p->n_timed], p->s_vol));
+    if (c.volume_split3) {
+        const size_t nel = (size_t)B * p->n8 * c.C;
+        MV_TRY(mv_split_bf16x3((const float*)in->fmap1, p->planes[0], nel, p->s_vol));
+        MV_TRY(mv_split_bf16x3((const float*)in->fmap2, p->planes[1], nel, p->s_vol));
+        MV_TRY(mv_corr_volume(p->planes[0], p->planes[1], p->vol[k], B, c.C, p->n8, p->n8, MV_BF16X3, MV_LAYOUT_HWC, p->s_vol));
+    } else {
+        MV_TRY(mv_corr_volume(in->fmap1, in->fmap2, p->vol[k], B, c.C, p->n8, p->n8, c.feat_dtype, c.layout, p->s_vol));
+    }
+    if (timed) MV_HIP(hipEventRecord(p->tv1[p->n_timed++], p->s_vol));
+    MV_HIP(hipEventRecord(p->e_vol_done[k], p->s_vol));
+
+    // ---- decoder side
+    hipStream_t s = p->s_main;
+    MV_HIP(hipStreamWaitEvent(s, e_in, 0));
+    MV_HIP(hipStreamWaitEvent(s, p->e_vol_done[k], 0));
+    const size_t coord_stride = (size_t)B * 2 * p->n8;
+    for (int it = 0; it < c.iters; ++it)
+        MV_TRY(mv_corr_lookup(p->vol[k], in->coords + it * coord_stride, p->tok[it & 1], B, p->h8, p->w8, p->h8, p->w8,
+                              c.radius, s));
+    MV_HIP(hipEventRecord(p->e_vol_free[k], s));
+    p->vol_free_valid[k] = true;
+
+    // maps slot m and candidate slot k were last read by the backend of frame f - 2 (f - 3 for the maps) on `back`
+    if (p->backend_valid[k]) MV_HIP(hipStreamWaitEvent(s, p->e_backend[k], 0));
+    if (p->backend_valid[k ^ 1]) MV_HIP(hipStreamWaitEvent(s, p->e_backend[k ^ 1], 0));
+    Maps& mp = p->maps[m];
+    if (up) {
+        MV_TRY(mv_convex_upsample(in->flow8, in->up_mask, p->up_flow, B, p->h8, p->w8, 0.25f, 0, s));
+        MV_TRY(mv_convex_upsample(in->cov8, in->cov_mask, p->up_cov, B, p->h8, p->w8, 1.0f, 1, s));
+        MV_TRY(mv_frontend_epilogue(p->up_flow, p->up_cov, 0, c.H, c.W, c.bl_fx, c.bl_fx_sq, mp.disparity, mp.disparity_cov,
+                                    mp.depth, mp.depth_cov, nullptr, mp.match_flow, mp.match_cov, s));
+    } else {
+        MV_TRY(mv_frontend_epilogue(in->flow, in->logcov, 1, c.H, c.W, c.bl_fx, c.bl_fx_sq, mp.disparity, mp.disparity_cov,
+                                    mp.depth, mp.depth_cov, nullptr, mp.match_flow, mp.match_cov, s));
+    }
+    Pending pd{m, p->newest_maps, k, with_selector != 0};
+    if (with_selector) {
+        mvKpSelectParams sp{c.H, c.W, c.selector_mode, c.kp_kernel_size, c.kp_mask_width, c.max_depth, c.max_depth_cov,
+                            c.max_match_cov};
+        if (c.selector_mode == MV_KP_NODEPTH) {
+            MV_TRY(mv_kp_select(mp.match_cov, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &sp, p->kp_ws,
+                                p->kp_ws_bytes, p->cand[k], p->count[k], p->stats[k], s));
+        } else {
+            const Maps& m0 = p->maps[pd.maps_prev];
+            MV_TRY(mv_kp_select(mp.match_cov, m0.depth, m0.depth_cov, mp.depth, mp.depth_cov, nullptr, nullptr, &sp,
+                                p->kp_ws, p->kp_ws_bytes, p->cand[k], p->count[k], p->stats[k], s));
+        }
+        MV_HIP(hipMemcpyAsync(p->h_count[k], p->count[k], 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        MV_HIP(hipEventRecord(p->e_cand[k], s));
+        p->pending.push_back(pd);
+    }
+    p->newest_maps = m;
+    p->n_enq = f + 1;
+    return MV_OK;
+}
+
+extern "C" int mv_frame_pipe_wait_candidates(mvFramePipe* p, int32_t* n_cand) {
+    MV_CHECK_ARG(p && n_cand && !p->pending.empty());
+    const Pending& pd = p->pending.front();
+    MV_HIP(hipEventSynchronize(p->e_cand[pd.cand]));
+    *n_cand = p->h_count[pd.cand][0];
+    return MV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ pose-dependent half
+extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, int n_sel, float* pose_sink) {
+    MV_CHECK_ARG(p && !p->pending.empty());
+    const mvFramePipeConfig& c = p->c;
+    MV_CHECK_ARG(n_sel >= 0 && n_sel <= c.num_point && (n_sel == 0 || perm_host));
+    const Pending pd = p->pending.front();
+    p->pending.pop_front();
+    const long g = p->n_fin;
+    const int k = (int)(g & 1);
+    Backend& b = p->be[k];
+    b.n_sel = n_sel;
+    p->n_fin = g + 1;
+    hipStream_t s = p->s_back;
+    if (n_sel == 0) {   // nothing to track: the pose stays at the motion-model prior (MACVO.py:303-307)
+        if (pose_sink) {
+            if (p->pgo_valid) MV_HIP(hipStreamWaitEvent(p->s_side, p->e_pgo, 0));
+            MV_HIP(hipMemcpyAsync(pose_sink, p->pose[p->pose_cur], 7 * sizeof(float), hipMemcpyDeviceToDevice, p->s_side));
+            MV_HIP(hipEventRecord(p->e_pgo, p->s_side));
+            p->pgo_valid = true;
+        }
+        return MV_OK;
+    }
+    const Maps &m0 = p->maps[pd.maps_prev], &m1 = p->maps[pd.maps];
+
+    // permutation -> pinned slot -> device
+    const int ps = (int)(g % N_PERM);
+    if (p->perm_valid[ps]) MV_HIP(hipEventSynchronize(p->e_perm[ps]));   // long done; keeps the slot reuse provably safe
+    memcpy(p->h_perm[ps], perm_host, (size_t)n_sel * sizeof(int64_t));
+    MV_HIP(hipStreamWaitEvent(s, p->e_cand[pd.cand], 0));
+    MV_HIP(hipMemcpyAsync(b.perm, p->h_perm[ps], (size_t)n_sel * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    MV_HIP(hipEventRecord(p->e_perm[ps], s));
+    p->perm_valid[ps] = true;
+    MV_TRY(mv_kp_gather(p->cand[pd.cand], b.perm, n_sel, c.W, b.kp0, s));
+    // the previous pose is produced by the previous solve; this also orders us after the solve of frame g - 2, the last
+    // reader of this backend slot
+    if (p->pgo_valid) MV_HIP(hipStreamWaitEvent(s, p->e_pgo, 0));
+    const float* pose = p->pose[p->pose_cur];
+    MV_TRY(mv_kp_track(b.kp0, n_sel, m1.match_flow, m1.match_cov, m0.depth, m0.disparity, m0.disparity_cov, m0.depth_cov,
+                       m1.depth, m1.disparity, m1.disparity_cov, m1.depth_cov, c.H, c.W, c.edgewidth, c.match_cov_default,
+                       b.kp0f, b.kp1, b.inbound, b.vals, b.sigma0, b.sigma1, s));
+    MV_TRY(mv_backproject(b.kp0f, b.vals, 1, c.fx, c.fy, c.cx, c.cy, pose, n_sel, b.pos_Tc, b.pos_Tw, b.rot, s));
+    mvMatchCovParams cp{c.H, c.W, c.cov_kernel_size, 1, c.fx, c.fy, c.cx, c.cy, c.min_flow_cov_sq, c.min_depth_cov};
+    MV_TRY(mv_match_cov_pair(m0.depth, b.kp0f, b.sigma0, b.rot, b.cov0, b.cov0w, m1.depth, b.kp1, b.sigma1, b.cov1, &cp,
+                             n_sel, s));
+    MV_TRY(mv_obs_filter(b.inbound, b.cov0, b.cov1, b.vals, c.filters, c.filter_min_depth, c.max_depth, n_sel, b.valid,
+                         b.n_valid, s));
+    MV_HIP(hipEventRecord(p->e_backend[k], s));
+    p->backend_valid[k] = true;
+
+    // ---- LM solve on the side stream; the optimised pose becomes the next frame's prior (StaticMotionModel)
+    hipStream_t ss = p->s_side;
+    MV_HIP(hipStreamWaitEvent(ss, p->e_backend[k], 0));
+    const int nxt = (p->pose_cur + 1) % 3;
+    const size_t N = (size_t)n_sel;
+    MV_TRY(mv_pgo_solve(1, p->offs + 2 * N, c.graph_type, pose, p->intr, p->bl, b.pos_Tw, b.cov0w, b.kp1, b.vals + 4 * N,
+                        b.vals + 5 * N, b.vals + 6 * N, b.sigma1, b.cov1, b.valid, c.min_num_point, &c.lm, b.pose64, b.info,
+                        p->pose[nxt], ss));
+    if (pose_sink)
+        MV_HIP(hipMemcpyAsync(pose_sink, p->pose[nxt], 7 * sizeof(float), hipMemcpyDeviceToDevice, ss));
+    MV_HIP(hipEventRecord(p->e_pgo, ss));
+    p->pgo_valid = true;
+    p->pose_cur = nxt;
+    return MV_OK;
+}
+
+extern "C" int mv_frame_pipe_sync(mvFramePipe* p, mvStream_t stream, int block_host) {
+    MV_CHECK_ARG(p);
+    if (block_host) {
+        MV_HIP(hipStreamSynchronize(p->s_vol));
+        MV_HIP(hipStreamSynchronize(p->s_main));
+        MV_HIP(hipStreamSynchronize(p->s_back));
+        MV_HIP(hipStreamSynchronize(p->s_side));
+        return MV_OK;
+    }
+    // make `stream` wait for everything enqueued so far
+    hipEvent_t e;
+    MV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipStream_t all[4] = {p->s_vol, p->s_main, p->s_back, p->s_side};
+    int rc = MV_OK;
+    for (hipStream_t q : all) {
+        if (hipEventRecord(e, q) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, e, 0) != hipSuccess) rc = MV_ERR_LAUNCH;
+    }
+    (void)hipEventDestroy(e);
+    return rc;
+}
+
+extern "C" int mv_frame_pipe_time_volume(mvFramePipe* p, int max_launches) {
+    MV_CHECK_ARG(p && max_launches >= 0 && max_launches <= (1 << 20));
+    while ((int)p->tv0.size() < max_launches) {
+        hipEvent_t a, b;
+        MV_HIP(hipEventCreate(&a));
+        p->tv0.push_back(a);
+        MV_HIP(hipEventCreate(&b));
+        p->tv1.push_back(b);
+    }
+    p->n_timed = 0;
+    p->timed_cap = max_launches;
+    return MV_OK;
+}
+
+extern "C" int mv_frame_pipe_volume_times(mvFramePipe* p, float* ms, int cap, int* n) {
+    MV_CHECK_ARG(p && n && cap >= 0 && (cap == 0 || ms));
+    MV_HIP(hipStreamSynchronize(p->s_vol));
+    const int m = p->n_timed < cap ? p->n_timed : cap;
+    for (int i = 0; i < m; ++i) MV_HIP(hipEventElapsedTime(&ms[i], p->tv0[i], p->tv1[i]));
+    *n = m;
+    return MV_OK;
+}
+
+extern "C" int mv_frame_pipe_buffer(mvFramePipe* p, int which, int age, void** ptr, size_t* count) {
+    MV_CHECK_ARG(p && ptr && count && age >= 0);
+    const mvFramePipeConfig& c = p->c;
+    const size_t plane = p->plane;
+    *ptr = nullptr;
+    *count = 0;
+    // frontend-side buffers: age 0 = the newest enqueued frame; backend-side: age 0 = the newest finished frame
+    const long f = p->n_enq - 1 - age, g = p->n_fin - 1 - age;
+    auto front = [&](int depth) { return f >= 0 && age < depth; };
+    auto back = [&]() { return g >= 0 && age < 2; };
+    const Backend* b = back() ? &p->be[g & 1] : nullptr;
+    const size_t N = b ? (size_t)b->n_sel : 0;
+    switch (which) {
+        case MV_FB_VOLUME: if (!front(2)) break; *ptr = p->vol[f & 1]; *count = (size_t)c.pairs * p->n8 * p->n8; return MV_OK;
+        case MV_FB_TOKENS: if (!front(1) || c.iters == 0) break; *ptr = p->tok[(c.iters - 1) & 1]; *count = (size_t)c.pairs * p->KK * p->n8; return MV_OK;
+        case MV_FB_DISPARITY: if (!front(N_MAPS)) break; *ptr = p->maps[f % N_MAPS].disparity; *count = plane; return MV_OK;
+        case MV_FB_DISPARITY_COV: if (!front(N_MAPS)) break; *ptr = p->maps[f % N_MAPS].disparity_cov; *count = plane; return MV_OK;
+        case MV_FB_DEPTH: if (!front(N_MAPS)) break; *ptr = p->maps[f % N_MAPS].depth; *count = plane; return MV_OK;
+        case MV_FB_DEPTH_COV: if (!front(N_MAPS)) break; *ptr = p->maps[f % N_MAPS].depth_cov; *count = plane; return MV_OK;
+        case MV_FB_MATCH_FLOW: if (!front(N_MAPS)) break; *ptr = p->maps[f % N_MAPS].match_flow; *count = 2 * plane; return MV_OK;
+        case MV_FB_MATCH_COV: if (!front(N_MAPS)) break; *ptr = p->maps[f % N_MAPS].match_cov; *count = 3 * plane; return MV_OK;
+        case MV_FB_CAND: if (!front(2)) break; *ptr = p->cand[f & 1]; *count = plane; return MV_OK;
+        case MV_FB_COUNT: if (!front(2)) break; *ptr = p->count[f & 1]; *count = 4; return MV_OK;
+        case MV_FB_STATS: if (!front(2)) break; *ptr = p->stats[f & 1]; *count = 4; return MV_OK;
+        case MV_FB_KP0: if (!b) break; *ptr = b->kp0; *count = 2 * N; return MV_OK;
+        case MV_FB_KP0F: if (!b) break; *ptr = b->kp0f; *count = 2 * N; return MV_OK;
+        case MV_FB_KP1: if (!b) break; *ptr = b->kp1; *count = 2 * N; return MV_OK;
+        case MV_FB_INBOUND: if (!b) break; *ptr = b->inbound; *count = N; return MV_OK;
+        case MV_FB_VALS: if (!b) break; *ptr = b->vals; *count = 11 * N; return MV_OK;
+        case MV_FB_SIGMA0: if (!b) break; *ptr = b->sigma0; *count = 3 * N; return MV_OK;
+        case MV_FB_SIGMA1: if (!b) break; *ptr = b->sigma1; *count = 3 * N; return MV_OK;
+        case MV_FB_POS_TC: if (!b) break; *ptr = b->pos_Tc; *count = 3 * N; return MV_OK;
+        case MV_FB_POS_TW: if (!b) break; *ptr = b->pos_Tw; *count = 3 * N; return MV_OK;
+        case MV_FB_ROT: if (!b) break; *ptr = b->rot; *count = 9; return MV_OK;
+        case MV_FB_COV0: if (!b) break; *ptr = b->cov0; *count = 9 * N; return MV_OK;
+        case MV_FB_COV0W: if (!b) break; *ptr = b->cov0w; *count = 9 * N; return MV_OK;
+        case MV_FB_COV1: if (!b) break; *ptr = b->cov1; *count = 9 * N; return MV_OK;
+        case MV_FB_VALID: if (!b) break; *ptr = b->valid; *count = N; return MV_OK;
+        case MV_FB_NVALID: if (!b) break; *ptr = b->n_valid; *count = 1; return MV_OK;
+        case MV_FB_POSE64: if (!b) break; *ptr = b->pose64; *count = 7; return MV_OK;
+        case MV_FB_INFO: if (!b) break; *ptr = b->info; *count = 4; return MV_OK;
+        case MV_FB_POSE: if (age > 1) break; *ptr = p->pose[(p->pose_cur + 3 - age) % 3]; *count = 7; return MV_OK;
+        default: break;
+    }
+    return MV_ERR_INVALID_ARG;
+}

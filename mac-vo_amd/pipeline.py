@@ -338,3 +338,245 @@ class _Pending:
     cands: "ops.KeypointCandidates"
     host_count: torch.Tensor
     event: "torch.cuda.Event"
+
+
+# ====================================================================================== native driver (default)
+class _NativeResult:
+    """Result of one natively driven frame.  Every tensor is a VIEW into the pipe's arena: valid until two more
+    frames have been finished (slots rotate); clone what must live longer."""
+
+    def __init__(self, hp: "NativeHotPath", n_sel: int, n_cand: int, age_fix: int):
+        self._hp, self.n_sel, self.n_cand = hp, n_sel, n_cand
+        self._fin = hp._n_fin          # finish counter at creation: views are resolved against it
+        self.pose = hp.pose
+        self.extras: dict = {}
+
+    def _age(self) -> int:
+        age = self._hp._n_fin - self._fin
+        if age > 1:
+            raise ops.L.MacvoHipError("this frame's buffers were recycled (results are views; clone them earlier)")
+        return age
+
+    def _b(self, name, dtype, shape):
+        return self._hp._view(name, self._age(), dtype, shape)
+
+    @property
+    def kp0_uv(self):
+        return self._b("KP0", torch.int64, (self.n_sel, 2))
+
+    @property
+    def n_valid(self):
+        return self._b("NVALID", torch.int32, (1,)) if self.n_sel else None
+
+    @property
+    def pose_f64(self):
+        return self._b("POSE64", torch.float64, (1, 7)) if self.n_sel else None
+
+    @property
+    def info(self):
+        return self._b("INFO", torch.float64, (1, 4)) if self.n_sel else None
+
+
+class NativeHotPath:
+    """Same contract as :class:`HotPath`, but the per-frame sequencing (streams, events, buffer rotation, ~30 launches)
+    runs in C++ (``mv_frame_pipe_*``, csrc/frame_pipe.hip): two host calls per frame instead of ~30 Python-level ones.
+    The Python loop was interpreter-bound (~370 us/frame, more than the GPU work); kernels, launch order and arguments
+    are identical, so results are bit-identical to :class:`HotPath` (tests/test_gpu_native.py)."""
+
+    def __init__(self, cam: Camera, cfg: HotPathConfig | None = None, device: str | torch.device = "cuda",
+                 keep_extras: bool = False):
+        self.cam, self.cfg = cam, cfg or HotPathConfig()
+        self.dev = torch.device(device)
+        self.keep_extras = keep_extras
+        self.lm = ops.lm_default_params()
+        self._pipe = None
+        self._arena = None
+        self._views: dict = {}
+        self._n_fin = 0
+        self._n_enq = 0
+        self._pending: list = []
+        self._init_pose = None
+        self._ncand = ops.C.c_int32(0)
+        self._ptr = ops.C.c_void_p()
+        self._cnt = ops.C.c_size_t()
+
+    # ------------------------------------------------------------------ construction (needs the first input's shapes)
+    def _create(self, x: FrameInputs) -> None:
+        L, C = ops.L, ops.C
+        c, cam = self.cfg, self.cam
+        lib = L.load()
+        hwc = c.feature_layout == "hwc"
+        pairs = x.fmap1.shape[0]
+        chans = x.fmap1.shape[-1] if hwc else x.fmap1.shape[1]
+        dt = {torch.float32: L.MV_F32, torch.float16: L.MV_F16, torch.bfloat16: L.MV_BF16}[x.fmap1.dtype]
+        bl_fx = float(cam.baseline) * float(cam.fx)
+        max_depth = cam.fx * cam.baseline if c.max_depth == "auto" else float(c.max_depth)
+        pc = L.mvFramePipeConfig(
+            H=cam.H, W=cam.W, C=chans, pairs=pairs, iters=x.coords.shape[0], radius=c.radius, feat_dtype=dt,
+            layout=L.MV_LAYOUT_HWC if hwc else L.MV_LAYOUT_CHW, volume_split3=int(c.volume_precision == "split3"),
+            selector_mode=L.MV_KP_NODEPTH if c.selector == "nodepth" else L.MV_KP_FULL,
+            kp_kernel_size=c.kp_kernel_size, kp_mask_width=c.kp_mask_width, num_point=c.num_point, edgewidth=c.edgewidth,
+            min_num_point=c.min_num_point, graph_type=ops._GRAPH[c.graph_type], filters=c.filters,
+            cov_kernel_size=c.cov_kernel_size, fx=cam.fx, fy=cam.fy, cx=cam.cx, cy=cam.cy, baseline=cam.baseline,
+            bl_fx=bl_fx, bl_fx_sq=bl_fx ** 2, match_cov_default=c.match_cov_default, max_match_cov=c.max_match_cov,
+            max_depth_cov=c.max_depth_cov, max_depth=max_depth, min_flow_cov_sq=c.min_flow_cov ** 2,
+            min_depth_cov=c.min_depth_cov, filter_min_depth=c.filter_min_depth, reserved=0.0, lm=self.lm)
+        nbytes = lib.mv_frame_pipe_arena_bytes(C.byref(pc))
+        if nbytes == 0:
+            raise L.MacvoHipError("mv_frame_pipe_arena_bytes: invalid configuration")
+        self._arena = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.dev)
+        self._base = (self._arena.data_ptr() + 255) & ~255
+        pipe = C.c_void_p()
+        L.check(lib.mv_frame_pipe_create(C.byref(pc), self._base, nbytes, C.byref(pipe)), "mv_frame_pipe_create")
+        self._pipe, self._lib, self._pc = pipe, lib, pc
+        if self._init_pose is not None:
+            self._set_pose(self._init_pose)
+
+    def __del__(self):
+        if getattr(self, "_pipe", None):
+            self._lib.mv_frame_pipe_destroy(self._pipe)
+            self._pipe = None
+
+    def _set_pose(self, pose: torch.Tensor) -> None:
+        host = pose.detach().to("cpu", torch.float32).reshape(7).contiguous()
+        ops.L.check(self._lib.mv_frame_pipe_set_pose(self._pipe, host.data_ptr()), "mv_frame_pipe_set_pose")
+
+    def _view(self, name: str, age: int, dtype: torch.dtype, shape: tuple) -> torch.Tensor:
+        ops.L.check(self._lib.mv_frame_pipe_buffer(self._pipe, ops.L.FB[name], age, ops.C.byref(self._ptr),
+                                                   ops.C.byref(self._cnt)), f"mv_frame_pipe_buffer({name})")
+        key = (self._ptr.value, dtype, shape)
+        v = self._views.get(key)
+        if v is None:
+            off = self._ptr.value - self._arena.data_ptr()
+            n = 1
+            for s in shape:
+                n *= s
+            assert n <= self._cnt.value or n == 0, (name, shape, self._cnt.value)
+            v = self._arena[off: off + n * torch.empty((), dtype=dtype).element_size()].view(dtype).view(shape)
+            if len(self._views) > 256:
+                self._views.clear()
+            self._views[key] = v
+        return v
+
+    @property
+    def pose(self) -> torch.Tensor:
+        """fp32 ``[7]`` view of the newest solve's output (valid on a stream after :meth:`sync_pose`)."""
+        return self._view("POSE", 0, torch.float32, (7,))
+
+    @pose.setter
+    def pose(self, value: torch.Tensor) -> None:
+        """Override the prior of the next frame (blocking; e.g. an external motion model)."""
+        if self._pipe is None:
+            self._init_pose = value
+        else:
+            self._set_pose(value)
+
+    @property
+    def last_tokens(self) -> torch.Tensor:
+        """Window-lookup output of the newest frame's last decoder iteration ``[pairs, (2r+1)^2, H/8, W/8]``."""
+        k = 2 * self.cfg.radius + 1
+        return self._view("TOKENS", 0, torch.float32, (self._pc.pairs, k * k, self.cam.H // 8, self.cam.W // 8))
+
+    def maps(self, age: int = 0) -> "ops.FrontendMaps":
+        H, W = self.cam.H, self.cam.W
+        v = lambda n, c: self._view(n, age, torch.float32, (1, c, H, W))  # noqa: E731
+        return ops.FrontendMaps(v("DEPTH", 1), v("DEPTH_COV", 1), v("DISPARITY", 1), v("DISPARITY_COV", 1), None,
+                                v("MATCH_FLOW", 2), v("MATCH_COV", 3))
+
+    # ------------------------------------------------------------------ frame API
+    def _inputs(self, x: FrameInputs):
+        st = getattr(x, "_native_struct", None)
+        if st is not None and x.static:
+            return st
+        c = self.cfg
+        q = lambda t, dt=torch.float32: None if t is None else ops._req(t, dt, "frame input").data_ptr()  # noqa: E731
+        st = ops.L.mvFrameInputs(q(x.fmap1, x.fmap1.dtype), q(x.fmap2, x.fmap2.dtype), q(x.coords), q(x.flow), q(x.logcov),
+                                 q(x.flow8), q(x.cov8), q(x.up_mask), q(x.cov_mask))
+        if x.flow8 is not None:
+            st.flow, st.logcov = None, None
+        x._native_struct = st
+        return st
+
+    def _enqueue(self, x: FrameInputs, with_selector: bool) -> None:
+        if self._pipe is None:
+            self._create(x)
+        if x.ready is not None:
+            torch.cuda.current_stream().wait_event(x.ready)
+        ops.L.check(self._lib.mv_frame_pipe_enqueue(self._pipe, ops.C.byref(self._inputs(x)), ops._stream(),
+                                                    int(with_selector)), "mv_frame_pipe_enqueue")
+        self._n_enq += 1
+
+    def initialize(self, x: FrameInputs, init_pose: torch.Tensor | None = None) -> None:
+        """Frame 0: ``MACVO.initialize`` (:158-171) — depth only, pose = prior."""
+        self._init_pose = init_pose
+        self._enqueue(x, False)
+
+    def enqueue_frontend(self, x: FrameInputs):
+        assert self._n_enq >= 1, "call initialize() with the first frame"
+        self._enqueue(x, True)
+        return x
+
+    def finish(self, pend=None, pose_sink: torch.Tensor | None = None) -> _NativeResult:
+        L, lib = ops.L, self._lib
+        L.check(lib.mv_frame_pipe_wait_candidates(self._pipe, ops.C.byref(self._ncand)), "mv_frame_pipe_wait_candidates")
+        n = self._ncand.value
+        perm = torch.randperm(n)[: self.cfg.num_point]            # global CPU generator, exactly as the reference
+        n_sel = perm.numel()
+        L.check(lib.mv_frame_pipe_finish(self._pipe, perm.data_ptr() if n_sel else None, n_sel,
+                                         None if pose_sink is None else pose_sink.data_ptr()), "mv_frame_pipe_finish")
+        self._n_fin += 1
+        res = _NativeResult(self, n_sel, n, 0)
+        if self.keep_extras and n_sel:
+            b = lambda nm, dt, sh: self._view(nm, 0, dt, sh)  # noqa: E731
+            f32, f64 = torch.float32, torch.float64
+            tr = ops.TrackedKeypoints(b("KP0F", f32, (n_sel, 2)), b("KP1", f32, (n_sel, 2)),
+                                      b("INBOUND", torch.bool, (n_sel,)), b("VALS", f32, (11, n_sel)),
+                                      b("SIGMA0", f32, (n_sel, 3)), b("SIGMA1", f32, (n_sel, 3)))
+            res.extras = dict(tracked=tr, cov0=b("COV0", f64, (n_sel, 3, 3)), cov0_w=b("COV0W", f64, (n_sel, 3, 3)),
+                              cov1=b("COV1", f64, (n_sel, 3, 3)), valid=b("VALID", torch.bool, (n_sel,)),
+                              pos_Tw=b("POS_TW", f32, (n_sel, 3)), n_cand=n)
+        return res
+
+    def step(self, x: FrameInputs) -> _NativeResult:
+        """One ``run_pair`` start to finish (no cross-frame overlap); results are valid on the current stream."""
+        self.enqueue_frontend(x)
+        res = self.finish()
+        self.sync_pose()
+        return res
+
+    def sync_pose(self) -> None:
+        """Make the current stream wait for everything the pipe has enqueued (solve included)."""
+        if self._pipe is not None:
+            ops.L.check(self._lib.mv_frame_pipe_sync(self._pipe, ops._stream(), 0), "mv_frame_pipe_sync")
+
+    def time_volume(self, max_launches: int) -> None:
+        """Record a HIP-event pair around each of the next ``max_launches`` volume GEMMs (on the stream they run on)."""
+        ops.L.check(self._lib.mv_frame_pipe_time_volume(self._pipe, int(max_launches)), "mv_frame_pipe_time_volume")
+
+    def volume_times_ms(self) -> list:
+        cap = self._pc_timed = 1 << 16
+        buf = (ops.C.c_float * cap)()
+        n = ops.C.c_int(0)
+        ops.L.check(self._lib.mv_frame_pipe_volume_times(self._pipe, buf, cap, ops.C.byref(n)), "mv_frame_pipe_volume_times")
+        return list(buf[: n.value])
+
+    def synchronize(self) -> None:
+        if self._pipe is not None:
+            ops.L.check(self._lib.mv_frame_pipe_sync(self._pipe, None, 1), "mv_frame_pipe_sync")
+
+    def run(self, frames, pose_sink: torch.Tensor | None = None):
+        """Software-pipelined stream (frame t+1's frontend is enqueued before frame t's host randperm)."""
+        it = iter(frames)
+        try:
+            self.enqueue_frontend(next(it))
+        except StopIteration:
+            return
+        i, more = 0, True
+        while more:
+            try:
+                self.enqueue_frontend(next(it))
+            except StopIteration:
+                more = False
+            yield self.finish(None, None if pose_sink is None else pose_sink[i])
+            i += 1
+        self.sync_pose()

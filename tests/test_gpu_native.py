@@ -1,0 +1,144 @@
+"""The native frame driver (mv_frame_pipe_*, csrc/frame_pipe.hip) must reproduce the Python-sequenced HotPath bit for bit:
+same kernels, same launch arguments, only the host side differs."""
+import pytest
+import torch
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(frames, dev, hwc=False, **kw):
+    from macvo_amd.pipeline import FrameInputs
+
+    out = []
+    for fr in frames:
+        d = {k: (None if v is None else v.to(dev)) for k, v in fr.items()}
+        if hwc:
+            d["fmap1"] = d["fmap1"].permute(0, 2, 3, 1).contiguous()
+            d["fmap2"] = d["fmap2"].permute(0, 2, 3, 1).contiguous()
+        out.append(FrameInputs(**d, **kw))
+    torch.cuda.synchronize()
+    return out
+
+
+def _pair(cam, cfg_kw, dev):
+    from macvo_amd.pipeline import Camera, HotPath, HotPathConfig, NativeHotPath
+
+    return (HotPath(Camera(**cam), HotPathConfig(**cfg_kw), dev, keep_extras=True),
+            NativeHotPath(Camera(**cam), HotPathConfig(**cfg_kw), dev, keep_extras=True))
+
+
+@pytest.mark.parametrize("H,W,graph,selector", [(480, 640, "disp", "nodepth"), (240, 320, "icp", "full"),
+                                                (240, 320, "reproj", "nodepth")])
+def test_native_step_equals_python_step(gpu, H, W, graph, selector):
+    n_frames = 6
+    cam, frames, _ = synth.make_sequence(n_frames, H, W, C=64, iters=3, seed=21)
+    ins = _inputs(frames, gpu)
+    py, nat = _pair(cam, dict(graph_type=graph, selector=selector), gpu)
+    py.initialize(ins[0])
+    nat.initialize(ins[0])
+    for t in range(1, n_frames):
+        torch.manual_seed(300 + t)
+        a = py.step(ins[t])
+        torch.manual_seed(300 + t)
+        b = nat.step(ins[t])
+        torch.cuda.synchronize()
+        assert torch.equal(py.last_tokens, nat.last_tokens)
+        ma, mb = py.maps_prev_for_next, nat.maps()
+        for f in ("depth", "depth_cov", "disparity", "disparity_cov", "flow", "flow_cov"):
+            assert torch.equal(getattr(ma, f), getattr(mb, f), ), f
+        assert torch.equal(a.kp0_uv, b.kp0_uv), t
+        assert torch.equal(a.n_valid, b.n_valid)
+        for k in ("cov0", "cov0_w", "cov1", "valid", "pos_Tw"):
+            assert torch.equal(a.extras[k], b.extras[k]), k
+        for f in ("kp0_uv", "kp1_uv", "inbound", "vals", "sigma0", "sigma1"):
+            assert torch.equal(getattr(a.extras["tracked"], f), getattr(b.extras["tracked"], f)), f
+        assert torch.equal(a.pose_f64, b.pose_f64) and torch.equal(a.info, b.info)
+        assert torch.equal(a.pose, b.pose), t
+
+
+def test_native_pipelined_run_equals_python_run(gpu):
+    n_pool, n_steps = 6, 25
+    cam, frames, _ = synth.make_sequence(n_pool, 240, 320, C=64, iters=3, seed=11, closed_loop=True)
+    ins = _inputs(frames, gpu, static=True)
+    py, nat = _pair(cam, {}, gpu)
+    outs = []
+    for hp in (py, nat):
+        hp.keep_extras = False
+        hp.initialize(ins[0])
+        sink = torch.zeros(n_steps, 7, device=gpu)
+        torch.manual_seed(5)
+        kps = []
+        for r in hp.run((ins[(1 + k) % n_pool] for k in range(n_steps)), pose_sink=sink):
+            hp.sync_pose()            # results live on the pipe's own streams: order the current stream after them
+            kps.append(r.kp0_uv.clone())
+        torch.cuda.synchronize()
+        outs.append((sink.clone(), kps))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert len(outs[1][1]) == n_steps and all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+    assert outs[1][0].abs().sum() > 0
+
+
+def test_native_upsample_path_and_split3(gpu):
+    H, W, n_frames = 240, 320, 4
+    cam, frames, _ = synth.make_sequence(n_frames, H, W, C=64, iters=2, seed=9)
+    g = torch.Generator().manual_seed(2)
+    for fr in frames:
+        fr["flow8"] = torch.nn.functional.avg_pool2d(fr["flow"], 8) / 8.0
+        fr["cov8"] = torch.nn.functional.avg_pool2d(fr["logcov"], 8) / 8.0
+        fr["up_mask"] = torch.randn(2, 576, H // 8, W // 8, generator=g)
+        fr["cov_mask"] = torch.randn(2, 576, H // 8, W // 8, generator=g) * 0.25
+        fr["flow"] = None
+        fr["logcov"] = None
+    ins = _inputs(frames, gpu, hwc=True)
+    py, nat = _pair(cam, dict(feature_layout="hwc", volume_precision="split3"), gpu)
+    py.initialize(ins[0])
+    nat.initialize(ins[0])
+    for t in range(1, n_frames):
+        torch.manual_seed(40 + t)
+        a = py.step(ins[t])
+        torch.manual_seed(40 + t)
+        b = nat.step(ins[t])
+        torch.cuda.synchronize()
+        assert torch.equal(py.last_tokens, nat.last_tokens)
+        assert torch.equal(a.kp0_uv, b.kp0_uv) and torch.equal(a.pose, b.pose)
+
+
+def test_native_no_candidates_keeps_the_prior(gpu):
+    from macvo_amd.pipeline import Camera, HotPathConfig, NativeHotPath
+
+    cam, frames, _ = synth.make_sequence(3, 240, 320, C=64, iters=1, seed=4)
+    ins = _inputs(frames, gpu)
+    nat = NativeHotPath(Camera(**cam), HotPathConfig(max_match_cov=0.0), gpu)   # quality < 0 never holds: no candidates
+    prior = torch.tensor([0.5, -0.25, 0.125, 0, 0, 0, 1.0])
+    nat.initialize(ins[0], init_pose=prior)
+    sink = torch.zeros(2, 7, device=gpu)
+    res = list(nat.run(ins[1:], pose_sink=sink))
+    torch.cuda.synchronize()
+    assert [r.n_sel for r in res] == [0, 0] and [r.n_cand for r in res] == [0, 0]
+    assert torch.equal(sink.cpu(), prior.expand(2, 7)) and torch.equal(nat.pose.cpu(), prior)
+    assert res[-1].n_valid is None and res[-1].kp0_uv.shape == (0, 2)
+
+
+def test_native_errors_are_loud(gpu):
+    from macvo_amd import _lib as L
+    from macvo_amd.pipeline import Camera, HotPathConfig, NativeHotPath
+
+    cam, frames, _ = synth.make_sequence(4, 240, 320, C=64, iters=1, seed=4)
+    ins = _inputs(frames, gpu)
+    nat = NativeHotPath(Camera(**cam), HotPathConfig(), gpu)
+    nat.initialize(ins[0])
+    with pytest.raises(L.MacvoHipError):
+        nat.finish()                              # nothing pending
+    nat.enqueue_frontend(ins[1])
+    nat.enqueue_frontend(ins[2])
+    with pytest.raises(L.MacvoHipError):
+        nat.enqueue_frontend(ins[3])              # more than two tracked frames in flight
+    r1 = nat.finish()
+    nat.finish()
+    nat.enqueue_frontend(ins[3])
+    nat.finish()
+    with pytest.raises(L.MacvoHipError):
+        r1.kp0_uv                                 # recycled two finishes ago
+    nat.synchronize()
