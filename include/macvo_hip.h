@@ -38,8 +38,11 @@ enum {
     MV_F32 = 0,        /* fp32 operands, exact fp32 MFMA (bitwise an fmaf chain)                               */
     MV_F16 = 1,
     MV_BF16 = 2,
-    MV_BF16X3 = 3      /* fp32 operands pre-split by mv_split_bf16x3 into 3 bf16 planes; 6 bf16 MFMA products, fp32
+    MV_BF16X3 = 3,     /* fp32 operands pre-split by mv_split_bf16x3 into 3 bf16 planes; 6 bf16 MFMA products, fp32
                           accumulate: fp32-class accuracy (dropped terms O(2^-24)), not bitwise; layout HWC only     */
+    MV_BF16X2 = 4      /* the same planes, but only the two leading pieces (16 significant bits) and the 3 products
+                          a0b1 + a1b0 + a0b0: relative error ~2^-16, finer than TF32 — the class the reference's fast
+                          frontend runs this GEMM in (allow_tf32, Module/Frontend/Frontend.py:275-277); layout HWC only */
 };
 
 /* feature-map memory layouts accepted by mv_corr_volume */
@@ -303,7 +306,7 @@ typedef struct {
     int32_t radius;            /* lookup radius (4) */
     int32_t feat_dtype;        /* MV_F32 | MV_F16 | MV_BF16 */
     int32_t layout;            /* MV_LAYOUT_* of the feature maps */
-    int32_t volume_split3;     /* 1: fp32 HWC features, split on the device and multiplied as bf16x3 */
+    int32_t volume_split;      /* 0 | 3 | 2: fp32 HWC features split on the device, multiplied as MV_BF16X3 / MV_BF16X2 */
     int32_t selector_mode;     /* MV_KP_NODEPTH | MV_KP_FULL */
     int32_t kp_kernel_size, kp_mask_width;
     int32_t num_point;         /* keypoints per frame (200) */

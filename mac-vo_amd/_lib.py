@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmacvo_hip.so")
 
 MV_OK = 0
-MV_F32, MV_F16, MV_BF16, MV_BF16X3 = 0, 1, 2, 3
+MV_F32, MV_F16, MV_BF16, MV_BF16X3, MV_BF16X2 = 0, 1, 2, 3, 4
 MV_LAYOUT_CHW, MV_LAYOUT_HWC = 0, 1
 MV_KP_NODEPTH, MV_KP_FULL, MV_KP_MAPPING = 0, 1, 2
 MV_GRAPH_ICP, MV_GRAPH_REPROJ, MV_GRAPH_DISP = 0, 1, 2
@@ -49,7 +49,7 @@ class mvLMParams(C.Structure):
 
 class mvFramePipeConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
-        "H", "W", "C", "pairs", "iters", "radius", "feat_dtype", "layout", "volume_split3", "selector_mode",
+        "H", "W", "C", "pairs", "iters", "radius", "feat_dtype", "layout", "volume_split", "selector_mode",
         "kp_kernel_size", "kp_mask_width", "num_point", "edgewidth", "min_num_point", "graph_type", "filters",
         "cov_kernel_size")] + [(n, C.c_float) for n in (
         "fx", "fy", "cx", "cy", "baseline", "bl_fx", "bl_fx_sq", "match_cov_default", "max_match_cov", "max_depth_cov",

@@ -337,6 +337,10 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
 // GEMM over pre-split planes: operands are [3][B][N][C] bf16 (piece-major).  Per K-tile of 32 the six [128][32] bf16
 // tiles (3 pieces x 2 operands, 48 KB, single buffer, register prefetch of the next tile) feed 6 x 4 x 2 = 48 MFMAs per
 // wave; 3 workgroups per CU interleave their load / MFMA phases.  No VALU work besides addressing.
+// NP = 3: all six products (fp32-class).  NP = 2: only the two leading pieces of each operand (16 significant bits, finer
+// than TF32's 11) and the three products a0b1, a1b0, a0b0 — the precision class the reference's own fast frontend runs
+// this GEMM in (allow_tf32 / matmul precision "medium", Module/Frontend/Frontend.py:275-277); 32 KB LDS, 4 workgroups / CU.
+template <int NP>
 __global__ __launch_bounds__(256) void corr_volume_bf16x3_hwc(const uint16_t* __restrict__ p1,
                                                                const uint16_t* __restrict__ p2,
                                                                float* __restrict__ out, int C, int N1, int N2, int Bn,
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(256) void corr_volume_bf16x3_hwc(const uint16_t* __
     constexpr int BK = 32;
     constexpr int CH = BK / 8;                   // 16-B chunks per row = 4
     constexpr int TILE = BM * CH;                // s16x8 elements per [128][32] tile
-    __shared__ __attribute__((aligned(16))) s16x8 smem[6 * TILE];
+    __shared__ __attribute__((aligned(16))) s16x8 smem[2 * NP * TILE];
 
     int tm, tn;
     tile_coords(tiles_m, tiles_n, tm, tn);
@@ -361,22 +365,22 @@ __global__ __launch_bounds__(256) void corr_volume_bf16x3_hwc(const uint16_t* __
 
     // loader: per tile 128 rows x 4 chunks = 512 chunks; thread t -> (row = t/4 + 64*p, chunk = t%4), p < 2
     const int lrow = t >> 2, lch = t & 3;
-    s16x8 r[6][2];
+    s16x8 r[2 * NP][2];
     const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
+        for (int pc = 0; pc < NP; ++pc)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int ia = m0 + lrow + 64 * p, ib = n0 + lrow + 64 * p;
                 r[pc][p] = (ia < N1) ? *reinterpret_cast<const s16x8*>(A + pc * plane1 + (size_t)ia * C + k0 + lch * 8) : zero;
-                r[3 + pc][p] = (ib < N2) ? *reinterpret_cast<const s16x8*>(Bp + pc * plane2 + (size_t)ib * C + k0 + lch * 8) : zero;
+                r[NP + pc][p] = (ib < N2) ? *reinterpret_cast<const s16x8*>(Bp + pc * plane2 + (size_t)ib * C + k0 + lch * 8) : zero;
             }
     };
     auto swz = [](int row, int c) { return row * CH + (c ^ ((row >> 2) & 3)); };
     auto sstore = [&]() {
 #pragma unroll
-        for (int tl = 0; tl < 6; ++tl)
+        for (int tl = 0; tl < 2 * NP; ++tl)
 #pragma unroll
             for (int p = 0; p < 2; ++p) smem[tl * TILE + swz(lrow + 64 * p, lch)] = r[tl][p];
     };
@@ -398,19 +402,20 @@ __global__ __launch_bounds__(256) void corr_volume_bf16x3_hwc(const uint16_t* __
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             const int c = ks * 2 + kh;
-            bf16x8 a[3][2], bb[3][2];
+            bf16x8 a[NP][2], bb[NP][2];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc)
+            for (int pc = 0; pc < NP; ++pc)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     a[pc][i] = __builtin_bit_cast(bf16x8, smem[pc * TILE + swz(wm * 64 + i * 32 + li, c)]);
-                    bb[pc][i] = __builtin_bit_cast(bf16x8, smem[(3 + pc) * TILE + swz(wn * 64 + i * 32 + li, c)]);
+                    bb[pc][i] = __builtin_bit_cast(bf16x8, smem[(NP + pc) * TILE + swz(wn * 64 + i * 32 + li, c)]);
                 }
             // smallest products first: (a0,b2) (a1,b1) (a2,b0) (a0,b1) (a1,b0) (a0,b0)
-            constexpr int PA[6] = {0, 1, 2, 0, 1, 0};
-            constexpr int PB[6] = {2, 1, 0, 1, 0, 0};
+            constexpr int NQ = NP == 3 ? 6 : 3;
+            constexpr int PA[6] = {NP == 3 ? 0 : 0, 1, NP == 3 ? 2 : 0, 0, 1, 0};
+            constexpr int PB[6] = {NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0, 0};
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
+            for (int q = 0; q < NQ; ++q)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -679,8 +684,13 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
     } else if (in_dtype == MV_BF16X3) {
         // f1 / f2 = planes produced by mv_split_bf16x3: [3][B][N][C] bf16
         if (layout != MV_LAYOUT_HWC || (C % 32)) return MV_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(corr_volume_bf16x3_hwc, grid, block, 0, s, (const uint16_t*)f1, (const uint16_t*)f2, out, C, N1,
-                           N2, B, tiles_m, tiles_n);
+        hipLaunchKernelGGL(corr_volume_bf16x3_hwc<3>, grid, block, 0, s, (const uint16_t*)f1, (const uint16_t*)f2, out, C,
+                           N1, N2, B, tiles_m, tiles_n);
+    } else if (in_dtype == MV_BF16X2) {
+        // same planes, only the two leading pieces are read
+        if (layout != MV_LAYOUT_HWC || (C % 32)) return MV_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(corr_volume_bf16x3_hwc<2>, grid, block, 0, s, (const uint16_t*)f1, (const uint16_t*)f2, out, C,
+                           N1, N2, B, tiles_m, tiles_n);
     } else if (in_dtype == MV_F16 || in_dtype == MV_BF16) {
         const uint16_t* a = (const uint16_t*)f1;
         const uint16_t* b = (const uint16_t*)f2;

@@ -114,7 +114,7 @@ static size_t carve(mvFramePipe* p, char* base) {
     const size_t plane = p->plane, n8 = p->n8, B = c.pairs, N = c.num_point > 0 ? c.num_point : 1;
     for (int k = 0; k < 2; ++k) p->vol[k] = a.take<float>(B * n8 * n8);
     for (int k = 0; k < 2; ++k) p->tok[k] = a.take<float>(B * p->KK * n8);
-    for (int k = 0; k < 2; ++k) p->planes[k] = c.volume_split3 ? (void*)a.take<uint16_t>(3 * B * n8 * c.C) : nullptr;
+    for (int k = 0; k < 2; ++k) p->planes[k] = c.volume_split ? (void*)a.take<uint16_t>(3 * B * n8 * c.C) : nullptr;
     p->up_flow = a.take<float>(B * 2 * plane);
     p->up_cov = a.take<float>(B * 2 * plane);
     for (int k = 0; k < N_MAPS; ++k) {
@@ -168,7 +168,8 @@ static int check_config(const mvFramePipeConfig* c) {
     MV_CHECK_ARG(c->selector_mode == MV_KP_NODEPTH || c->selector_mode == MV_KP_FULL);
     MV_CHECK_ARG(c->num_point >= 0 && c->edgewidth >= 0 && c->min_num_point >= 0);
     MV_CHECK_ARG(c->graph_type >= MV_GRAPH_ICP && c->graph_type <= MV_GRAPH_DISP);
-    MV_CHECK_ARG(!c->volume_split3 || (c->feat_dtype == MV_F32 && c->layout == MV_LAYOUT_HWC));
+    MV_CHECK_ARG(c->volume_split == 0 || c->volume_split == 2 || c->volume_split == 3);
+    MV_CHECK_ARG(!c->volume_split || (c->feat_dtype == MV_F32 && c->layout == MV_LAYOUT_HWC));
     return MV_OK;
 }
 
@@ -304,11 +305,12 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
     if (p->vol_free_valid[k]) MV_HIP(hipStreamWaitEvent(p->s_vol, p->e_vol_free[k], 0));
     const bool timed = p->n_timed < p->timed_cap;
     if (timed) MV_HIP(hipEventRecord(p->tv0[p->n_timed], p->s_vol));
-    if (c.volume_split3) {
+    if (c.volume_split) {
         const size_t nel = (size_t)B * p->n8 * c.C;
         MV_TRY(mv_split_bf16x3((const float*)in->fmap1, p->planes[0], nel, p->s_vol));
         MV_TRY(mv_split_bf16x3((const float*)in->fmap2, p->planes[1], nel, p->s_vol));
-        MV_TRY(mv_corr_volume(p->planes[0], p->planes[1], p->vol[k], B, c.C, p->n8, p->n8, MV_BF16X3, MV_LAYOUT_HWC, p->s_vol));
+        MV_TRY(mv_corr_volume(p->planes[0], p->planes[1], p->vol[k], B, c.C, p->n8, p->n8,
+                              c.volume_split == 2 ? MV_BF16X2 : MV_BF16X3, MV_LAYOUT_HWC, p->s_vol));
     } else {
         MV_TRY(mv_corr_volume(in->fmap1, in->fmap2, p->vol[k], B, c.C, p->n8, p->n8, c.feat_dtype, c.layout, p->s_vol));
     }

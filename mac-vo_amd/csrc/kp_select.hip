@@ -25,6 +25,13 @@
 
 namespace {
 
+#ifdef MV_KP_PROFILE
+__device__ long long g_kp_stamps[16];
+#define KP_STAMP(i) do { if (threadIdx.x == 0) g_kp_stamps[i] = wall_clock64(); } while (0)
+#else
+#define KP_STAMP(i)
+#endif
+
 constexpr int TILE_W = 64;
 constexpr int TILE_H = 16;
 constexpr int MAX_R = 7;
@@ -32,7 +39,7 @@ constexpr unsigned CAND_FLAG = 0x80000000u;
 
 struct KpWs {
     unsigned long long* cand_bits;
-    unsigned* rec_idx;  // linear index | CAND_FLAG
+    unsigned* rec_idx;  // (candidate-word index << 6 | bit) | CAND_FLAG: where this NMS pixel's bit lives in cand_bits
     float* rec_q;       // flow quality of the NMS pixel      (population of the flow-cov median)
     float* rec_d;       // depth0 variance of the NMS pixel   (population of the depth-cov median, FULL only)
     int* counters;      // [0] = number of records (= NMS pixels)
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256) void kp_nms_kernel(const float* __restrict__ f
         if (nms_px[it]) {
             const int gx = x0 + tx, gy = y0 + ty * (TILE_H / 4) + it;
             const int idx = gy * W + gx;
-            ws.rec_idx[pos] = (unsigned)idx | (cand_px[it] ? CAND_FLAG : 0u);
+            ws.rec_idx[pos] = (unsigned)(((gy * words_per_row + blockIdx.x) << 6) | tx) | (cand_px[it] ? CAND_FLAG : 0u);
             if (p.mode == MV_KP_NODEPTH) {
                 ws.rec_q[pos] = q_px[it];
             } else {
@@ -164,8 +171,19 @@ __device__ __forceinline__ float key_float(unsigned k) {
     return __uint_as_float(u);
 }
 
-// workgroup exclusive scan of one int per thread (1024 threads = 16 waves); returns the exclusive prefix and the total
-__device__ __forceinline__ int block_exclusive_scan(int v, int* wave_tot /*[16] LDS*/, int& total) {
+#ifndef MV_KP_FINISH_THREADS
+#define MV_KP_FINISH_THREADS 1024
+#endif
+constexpr int FIN_NT = MV_KP_FINISH_THREADS;         // threads of the single finishing workgroup
+constexpr int MAX_REC = 16384;                       // records the fast path keeps in registers
+constexpr int LDS_WORDS = 5120;                      // candidate bit words the fast path keeps in LDS (40 KB): 640 x 512
+constexpr int RANK_CAP = 256;                        // bucket size at which selection switches to direct ranking
+constexpr unsigned NAN_KEY = 0xFFFFFFFFu;
+
+// workgroup exclusive scan of one int per thread; returns the exclusive prefix and the total
+template <int NT>
+__device__ __forceinline__ int block_exclusive_scan(int v, int* wave_tot /*[NT/64] LDS*/, int& total) {
+    constexpr int NW = NT / 64;
     const int tid = threadIdx.x;
     int incl = v;
 #pragma unroll
@@ -179,7 +197,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* wave_tot /*[16] 
     int off = 0;
     total = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) {
+    for (int w = 0; w < NW; ++w) {
         const int t = wave_tot[w];
         if (w < (tid >> 6)) off += t;
         total += t;
@@ -187,110 +205,248 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* wave_tot /*[16] 
     return off + incl - v;
 }
 
-// Lower median ((m-1)/2-th smallest of the m non-NaN values) == torch.median / torch.nanmedian of the population.
-// 3 radix passes (11 + 11 + 10 bits); the bin holding rank k is found with a workgroup scan (2 bins per thread).
-__device__ float block_nanmedian(const float* __restrict__ vals, int n, unsigned* hist /*[2048]*/, int* sh /*[4]*/,
-                                 int* wave_tot /*[16]*/) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    if (tid == 0) sh[0] = 0;
-    __syncthreads();
-    int local_nan = 0;
-    for (int i = tid; i < n; i += nt) local_nan += (vals[i] != vals[i]);
-    local_nan = wave_sum(local_nan);
-    if ((tid & 63) == 0 && local_nan) atomicAdd(&sh[0], local_nan);
-    __syncthreads();
-    const int m = n - sh[0];
-    if (m <= 0) return NAN;
-    int k = (m - 1) >> 1;
-    unsigned prefix = 0, mask = 0;
-    const int shifts[3] = {21, 10, 0};
-    const int widths[3] = {11, 11, 10};
+template <int NT, bool CACHED, typename F>
+__device__ __forceinline__ void for_each_key(const float* __restrict__ vals, int n, const unsigned (&keys)[MAX_REC / NT],
+                                             F&& f) {
+    const int tid = threadIdx.x;
+    if (CACHED) {
+        const int nr = (n + NT - 1) / NT;   // register slots that hold data (uniform)
 #pragma unroll
-    for (int pass = 0; pass < 3; ++pass) {
-        const int shift = shifts[pass];
-        const unsigned bins = 1u << widths[pass];
-        for (int i = tid; i < 2048; i += nt) hist[i] = 0;
-        __syncthreads();
-        for (int i = tid; i < n; i += nt) {
-            const unsigned key = float_key(vals[i]);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (bins - 1)], 1u);
-        }
-        __syncthreads();
-        const int c0 = (int)hist[2 * tid], c1 = (int)hist[2 * tid + 1];
-        int total;
-        const int excl = block_exclusive_scan(c0 + c1, wave_tot, total);
-        if (excl <= k && k < excl + c0 + c1) {  // exactly one thread
-            const bool second = k >= excl + c0;
-            sh[1] = 2 * tid + (second ? 1 : 0);
-            sh[2] = k - excl - (second ? c0 : 0);
-        }
-        __syncthreads();
-        prefix |= ((unsigned)sh[1]) << shift;
-        mask |= (bins - 1) << shift;
-        k = sh[2];
-        __syncthreads();
+        for (int r = 0; r < MAX_REC / NT; ++r)
+            if (r < nr && r * NT + tid < n) f(keys[r]);
+    } else {
+        for (int i = tid; i < n; i += NT) f(float_key(vals[i]));
     }
-    return key_float(prefix);
 }
 
-__global__ __launch_bounds__(1024) void kp_finish_kernel(mvKpSelectParams p, KpWs ws, int has_flow, int words_per_row,
-                                                          int32_t* __restrict__ out_cand,
-                                                          int32_t* __restrict__ out_count,
-                                                          float* __restrict__ out_stats) {
-    __shared__ unsigned hist[2048];
-    __shared__ int sh[4];
-    __shared__ int wave_tot[16];
+struct MedianLds {
+    unsigned hist[2048];
+    unsigned lst[RANK_CAP];
+    unsigned red_lo[16], red_hi[16];
+    int red_cnt[16];
+    int wave_tot[16];
+    int sh[4];
+    unsigned res;
+};
+
+// Lower median ((m-1)/2-th smallest of the m non-NaN values) == torch.median / torch.nanmedian of the population, by
+// bucket refinement on the order-preserving keys: [lo, hi] starts as the population's own range (so the 2048 linear
+// buckets are spread over the values that exist: no hot histogram bin, unlike a fixed sign/exponent digit), the bucket
+// holding rank k becomes the next range, and as soon as that bucket holds <= 256 keys they are ranked directly.
+// Typical cost: one min/max reduction, one histogram pass, one scan, one tiny ranking step.  The population is read
+// from registers (CACHED: thread t holds keys t, t + NT, ...) or re-read from global memory (any size).
+template <int NT, bool CACHED>
+__device__ float block_nanmedian(const float* __restrict__ vals, int n, const unsigned (&keys)[MAX_REC / NT],
+                                 MedianLds& L) {
+    constexpr int NW = NT / 64, BPT = 2048 / NT;
+    const int tid = threadIdx.x;
+    unsigned lo = NAN_KEY, hi = 0u;
+    int cnt = 0;
+    for_each_key<NT, CACHED>(vals, n, keys, [&](unsigned k) {
+        if (k != NAN_KEY) {
+            lo = min(lo, k);
+            hi = max(hi, k);
+            ++cnt;
+        }
+    });
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, (unsigned)__shfl_xor((int)lo, o, 64));
+        hi = max(hi, (unsigned)__shfl_xor((int)hi, o, 64));
+        cnt += __shfl_xor(cnt, o, 64);
+    }
+    __syncthreads();   // L may still be in use by a previous call
+    if ((tid & 63) == 0) {
+        L.red_lo[tid >> 6] = lo;
+        L.red_hi[tid >> 6] = hi;
+        L.red_cnt[tid >> 6] = cnt;
+    }
+    __syncthreads();
+    cnt = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        lo = min(lo, L.red_lo[w]);
+        hi = max(hi, L.red_hi[w]);
+        cnt += L.red_cnt[w];
+    }
+    if (cnt <= 0) return NAN;
+    int k = (cnt - 1) >> 1;
+    for (;;) {   // every quantity below is workgroup-uniform
+        if (lo == hi) return key_float(lo);
+        const unsigned span = hi - lo;
+        const int s = max(0, 32 - __clz((int)span) - 11);   // (span >> s) < 2048
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) L.hist[j * NT + tid] = 0;
+        if (tid == 0) L.sh[3] = 0;
+        __syncthreads();
+        for_each_key<NT, CACHED>(vals, n, keys, [&](unsigned kk) {
+            if (kk >= lo && kk <= hi) atomicAdd(&L.hist[(kk - lo) >> s], 1u);
+        });
+        __syncthreads();
+        int c[BPT], sum = 0;
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) {
+            c[j] = (int)L.hist[tid * BPT + j];
+            sum += c[j];
+        }
+        int total;
+        const int excl = block_exclusive_scan<NT>(sum, L.wave_tot, total);
+        if (excl <= k && k < excl + sum) {  // exactly one thread owns the bucket of rank k
+            int before = excl;
+#pragma unroll
+            for (int j = 0; j < BPT; ++j) {
+                if (k >= before && k < before + c[j]) {
+                    L.sh[0] = tid * BPT + j;
+                    L.sh[1] = c[j];
+                    L.sh[2] = k - before;
+                }
+                before += c[j];
+            }
+        }
+        __syncthreads();
+        const unsigned b = (unsigned)L.sh[0];
+        const int cb = L.sh[1];
+        k = L.sh[2];
+        const unsigned nlo = lo + (b << s);
+        const unsigned w = s ? ((1u << s) - 1u) : 0u;
+        const unsigned nhi = (hi - nlo < w) ? hi : nlo + w;
+        if (cb <= RANK_CAP) {
+            for_each_key<NT, CACHED>(vals, n, keys, [&](unsigned kk) {
+                if (kk >= nlo && kk <= nhi) L.lst[atomicAdd(&L.sh[3], 1)] = kk;
+            });
+            __syncthreads();
+            for (int i = tid; i < cb; i += NT) {
+                const unsigned e = L.lst[i];
+                int rank = 0;
+                for (int j = 0; j < cb; ++j) {
+                    const unsigned o = L.lst[j];
+                    rank += (o < e) || (o == e && j < i);
+                }
+                if (rank == k) L.res = e;
+            }
+            __syncthreads();
+            return key_float(L.res);
+        }
+        lo = nlo;
+        hi = nhi;
+        __syncthreads();   // sh / hist are rewritten by the next round
+    }
+}
+
+// One workgroup of NT threads.  FAST (n_rec <= 16384 and H * words_per_row <= LDS_WORDS, e.g. 640x480): every global
+// array is read exactly once with all loads in flight (records -> registers, candidate words -> registers -> LDS), the
+// threshold pass clears bits with LDS atomics and the compaction reads LDS.  Otherwise the same steps run against
+// global memory.  Few fat threads on purpose: the work is a few thousand elements on ONE compute unit, where every
+// wave-level instruction costs 4 cycles and per-wave fixed costs (scans, loop control) multiply with the wave count.
+template <int NT, bool FAST>
+__device__ __forceinline__ void kp_finish_body(const mvKpSelectParams& p, const KpWs& ws, int has_flow, int words_per_row,
+                                               int32_t* __restrict__ out_cand, int32_t* __restrict__ out_count,
+                                               float* __restrict__ out_stats, int n_rec, MedianLds& L,
+                                               unsigned long long* lds_words) {
+    constexpr int RPT = MAX_REC / NT, WPT = LDS_WORDS / NT;
     const int tid = threadIdx.x;
     const int H = p.H, W = p.W;
     const bool mapping = p.mode == MV_KP_MAPPING;
-    const int n_rec = mapping ? 0 : ws.counters[0];
-
-    float med_f = NAN, thr_f = INFINITY, med_d = NAN, thr_d = INFINITY;
     const bool use_f = (p.mode == MV_KP_NODEPTH) || (p.mode == MV_KP_FULL && has_flow);
     const bool use_d = (p.mode == MV_KP_FULL);
+    const int n_words = H * words_per_row;
+
+    // FAST: every global read of this kernel is issued here, before anything waits: the record arrays are read for all
+    // register slots without knowing n_rec yet (they are plane-sized, so the reads stay inside the workspace), the
+    // candidate words go to registers and are parked in LDS only after the medians
+    unsigned kq[RPT], kd[RPT], ridx[RPT];
+    unsigned long long wreg[WPT];
+    KP_STAMP(0);
+    if (FAST) {
+        const int cap = H * W;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int i = min(r * NT + tid, cap - 1);
+            ridx[r] = mapping ? 0u : ws.rec_idx[i];
+            kq[r] = use_f ? __float_as_uint(ws.rec_q[i]) : 0u;
+            kd[r] = use_d ? __float_as_uint(ws.rec_d[i]) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const int w = j * NT + tid;
+            wreg[j] = w < n_words ? ws.cand_bits[w] : 0ull;
+        }
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const bool live = r * NT + tid < n_rec;
+            ridx[r] = live ? ridx[r] : 0u;
+            kq[r] = live ? float_key(__uint_as_float(kq[r])) : NAN_KEY;
+            kd[r] = live ? float_key(__uint_as_float(kd[r])) : NAN_KEY;
+        }
+    }
+
+    float med_f = NAN, thr_f = INFINITY, med_d = NAN, thr_d = INFINITY;
+    KP_STAMP(1);
     if (use_f) {
-        med_f = block_nanmedian(ws.rec_q, n_rec, hist, sh, wave_tot);
+        med_f = block_nanmedian<NT, FAST>(ws.rec_q, n_rec, kq, L);
         // python: min(max_match_cov, median * 1.5) in double, then the fp32 compare rounds it to fp32:
         // == fp32 min of fp32-rounded operands (rounding is monotonic; med*1.5 is exact in double).
         const float prod = med_f * 1.5f;
         thr_f = (prod < p.max_match_cov) ? prod : p.max_match_cov;  // python min(a, b): b if b < a else a
     }
     if (use_d) {
-        med_d = block_nanmedian(ws.rec_d, n_rec, hist, sh, wave_tot);
+        med_d = block_nanmedian<NT, FAST>(ws.rec_d, n_rec, kd, L);
         const float prod = med_d * 1.5f;
         thr_d = (prod < p.max_depth_cov) ? prod : p.max_depth_cov;
     }
 
-    // ---- candidates that fail a threshold clear their bit (records are contiguous: coalesced reads)
-    if (!mapping) {
-        for (int i = tid; i < n_rec; i += 1024) {
-            const unsigned ri = ws.rec_idx[i];
-            if (ri & CAND_FLAG) {
-                bool ok = true;
-                if (use_f) ok = ws.rec_q[i] < thr_f;
-                if (ok && use_d) ok = ws.rec_d[i] < thr_d;
-                if (!ok) {
-                    const int idx = (int)(ri & ~CAND_FLAG);
-                    const int row = idx / W, col = idx - row * W;
-                    atomicAnd(&ws.cand_bits[(size_t)row * words_per_row + (col >> 6)], ~(1ull << (col & 63)));
-                }
-            }
-        }
-        __threadfence();
+    KP_STAMP(2);
+    if (FAST) {
+#pragma unroll
+        for (int j = 0; j < WPT; ++j)
+            if (j * NT + tid < n_words) lds_words[j * NT + tid] = wreg[j];
         __syncthreads();
     }
+    // ---- candidates that fail a threshold clear their bit (the cached keys are mapped back to the exact floats; a NaN
+    //      comes back as a NaN, so the fp32 `<` behaves as on the original values)
+    if (!mapping) {
+        if (FAST) {
+            const int nr = (n_rec + NT - 1) / NT;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                if (r < nr && (ridx[r] & CAND_FLAG)) {
+                    bool ok = true;
+                    if (use_f) ok = key_float(kq[r]) < thr_f;
+                    if (ok && use_d) ok = key_float(kd[r]) < thr_d;
+                    if (!ok) atomicAnd(&lds_words[(ridx[r] & ~CAND_FLAG) >> 6], ~(1ull << (ridx[r] & 63)));
+                }
+            }
+            __syncthreads();
+        } else {
+            for (int i = tid; i < n_rec; i += NT) {
+                const unsigned ri = ws.rec_idx[i];
+                if (ri & CAND_FLAG) {
+                    bool ok = true;
+                    if (use_f) ok = ws.rec_q[i] < thr_f;
+                    if (ok && use_d) ok = ws.rec_d[i] < thr_d;
+                    if (!ok) atomicAnd(&ws.cand_bits[(ri & ~CAND_FLAG) >> 6], ~(1ull << (ri & 63)));
+                }
+            }
+            __threadfence();
+            __syncthreads();
+        }
+    }
 
-    // ---- ordered compaction of the candidate words (atomic loads: served by L2, where the atomics landed)
-    const int n_words = H * words_per_row;
-    const int per = (n_words + 1023) / 1024;
+    KP_STAMP(3);
+    // ---- ordered compaction of the candidate words: thread t owns words [t * per, (t + 1) * per)
+    const int per = (n_words + NT - 1) / NT;
     const int w_begin = min(tid * per, n_words), w_end = min(w_begin + per, n_words);
+    auto word = [&](int w) -> unsigned long long {
+        if (FAST) return lds_words[w];
+        return __hip_atomic_load(&ws.cand_bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // L2, where the atomics landed
+    };
     int cnt = 0;
-    for (int w = w_begin; w < w_end; ++w)
-        cnt += __popcll(__hip_atomic_load(&ws.cand_bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    for (int w = w_begin; w < w_end; ++w) cnt += __popcll(word(w));
     int total;
-    int pos = block_exclusive_scan(cnt, wave_tot, total);
+    int pos = block_exclusive_scan<NT>(cnt, L.wave_tot, total);
+    KP_STAMP(4);
     for (int w = w_begin; w < w_end; ++w) {
-        unsigned long long bits = __hip_atomic_load(&ws.cand_bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long bits = word(w);
         const int row = w / words_per_row, col0 = (w - row * words_per_row) * 64;
         while (bits) {
             const int bpos = __ffsll((long long)bits) - 1;
@@ -298,6 +454,7 @@ __global__ __launch_bounds__(1024) void kp_finish_kernel(mvKpSelectParams p, KpW
             out_cand[pos++] = row * W + col0 + bpos;
         }
     }
+    KP_STAMP(5);
     if (tid == 0) {
         ws.counters[0] = 0;   // leave the record counter clean for the next call (no per-call memset launch)
         out_count[0] = total;
@@ -309,6 +466,19 @@ __global__ __launch_bounds__(1024) void kp_finish_kernel(mvKpSelectParams p, KpW
         out_stats[2] = med_d;
         out_stats[3] = thr_d;
     }
+}
+
+__global__ __launch_bounds__(FIN_NT) void kp_finish_kernel(mvKpSelectParams p, KpWs ws, int has_flow, int words_per_row,
+                                                            int32_t* __restrict__ out_cand,
+                                                            int32_t* __restrict__ out_count,
+                                                            float* __restrict__ out_stats) {
+    __shared__ MedianLds L;
+    __shared__ unsigned long long lds_words[LDS_WORDS];
+    const int n_rec = p.mode == MV_KP_MAPPING ? 0 : ws.counters[0];
+    if (n_rec <= MAX_REC && p.H * words_per_row <= LDS_WORDS)
+        kp_finish_body<FIN_NT, true>(p, ws, has_flow, words_per_row, out_cand, out_count, out_stats, n_rec, L, lds_words);
+    else
+        kp_finish_body<FIN_NT, false>(p, ws, has_flow, words_per_row, out_cand, out_count, out_stats, n_rec, L, lds_words);
 }
 
 __global__ void kp_gather_kernel(const int32_t* __restrict__ cand, const int64_t* __restrict__ perm, int n_sel,
@@ -376,7 +546,7 @@ extern "C" int mv_kp_select(const float* flow_cov, const float* depth0, const fl
     dim3 grid(wpr, mv_ceil_div(p.H, TILE_H)), block(64, 4);
     hipLaunchKernelGGL(kp_nms_kernel, grid, block, 0, s, flow_cov, depth0, depth0_cov, depth1, depth1_cov, mask_a,
                        mask_b, p, ws, wpr);
-    hipLaunchKernelGGL(kp_finish_kernel, dim3(1), dim3(1024), 0, s, p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count,
+    hipLaunchKernelGGL(kp_finish_kernel, dim3(1), dim3(FIN_NT), 0, s, p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count,
                        out_stats);
     return mv_launch_status();
 }

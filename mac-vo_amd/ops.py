@@ -53,8 +53,9 @@ def corr_volume(f1: torch.Tensor, f2: torch.Tensor, layout: str = "chw", out: to
     """All-pairs cost volume (FlowFormer ``MemoryEncoder.corr``; call site flownet.py:26-27).
 
     layout "chw": f1, f2 ``[B, C, H, W]`` (NCHW);  layout "hwc": ``[B, H, W, C]`` / ``[B, N, C]``.
-    precision (fp32 inputs only): "exact" = fp32 MFMA (bitwise fmaf chain); "split3" = bf16x3 split, fp32-class
-    accuracy, ~2.5x faster (layout "hwc" only).
+    precision (fp32 inputs only): "exact" = fp32 MFMA (bitwise fmaf chain); "split3" = bf16x3 split (6 products), fp32-class
+    accuracy; "split2" = two leading pieces, 3 products, relative error ~2^-16 (finer than TF32, the class the
+    reference's fast frontend allows itself) — both layout "hwc" only.
     Returns ``cost_maps [B*H1*W1, 1, H2, W2]`` float32 (layout "hwc" with 3-D inputs: ``[B*N1, 1, 1, N2]``).
     """
     lib = L.load()
@@ -81,14 +82,14 @@ def corr_volume(f1: torch.Tensor, f2: torch.Tensor, layout: str = "chw", out: to
         out = torch.empty((B * N1, 1, H2, W2), dtype=torch.float32, device=f1.device)
     dt = _DT[f1.dtype]
     p1, p2 = f1, f2
-    if precision == "split3":
+    if precision in ("split3", "split2"):
         if f1.dtype != torch.float32 or lay != L.MV_LAYOUT_HWC:
-            raise L.MacvoHipError("corr_volume: precision='split3' needs float32 inputs in layout 'hwc'")
+            raise L.MacvoHipError(f"corr_volume: precision='{precision}' needs float32 inputs in layout 'hwc'")
         p1 = torch.empty((3,) + tuple(f1.shape), dtype=torch.bfloat16, device=f1.device)
         p2 = torch.empty((3,) + tuple(f2.shape), dtype=torch.bfloat16, device=f2.device)
         L.check(lib.mv_split_bf16x3(f1.data_ptr(), p1.data_ptr(), f1.numel(), _stream()), "mv_split_bf16x3")
         L.check(lib.mv_split_bf16x3(f2.data_ptr(), p2.data_ptr(), f2.numel(), _stream()), "mv_split_bf16x3")
-        dt = L.MV_BF16X3
+        dt = L.MV_BF16X3 if precision == "split3" else L.MV_BF16X2
     elif precision != "exact":
         raise ValueError(precision)
     L.check(lib.mv_corr_volume(p1.data_ptr(), p2.data_ptr(), out.data_ptr(), B, Cc, N1, N2, dt, lay, _stream()),

@@ -65,7 +65,8 @@ class HotPathConfig:
     radius: int = 4
     feature_layout: str = "chw"
     use_graphs: bool = False             # hipGraph-replay the decoder-side segment for inputs marked `static`
-    volume_precision: str = "exact"      # "exact" fp32 MFMA | "split3" bf16x3 (fp32 features in layout "hwc")
+    volume_precision: str = "exact"      # "exact" fp32 MFMA | "split3" bf16x3, fp32-class | "split2" 3 products, finer
+                                         # than TF32 (the reference's own fast-frontend class); splits need layout "hwc"
 
 
 @dataclass
@@ -413,7 +414,7 @@ class NativeHotPath:
         max_depth = cam.fx * cam.baseline if c.max_depth == "auto" else float(c.max_depth)
         pc = L.mvFramePipeConfig(
             H=cam.H, W=cam.W, C=chans, pairs=pairs, iters=x.coords.shape[0], radius=c.radius, feat_dtype=dt,
-            layout=L.MV_LAYOUT_HWC if hwc else L.MV_LAYOUT_CHW, volume_split3=int(c.volume_precision == "split3"),
+            layout=L.MV_LAYOUT_HWC if hwc else L.MV_LAYOUT_CHW, volume_split={"exact": 0, "split3": 3, "split2": 2}[c.volume_precision],
             selector_mode=L.MV_KP_NODEPTH if c.selector == "nodepth" else L.MV_KP_FULL,
             kp_kernel_size=c.kp_kernel_size, kp_mask_width=c.kp_mask_width, num_point=c.num_point, edgewidth=c.edgewidth,
             min_num_point=c.min_num_point, graph_type=ops._GRAPH[c.graph_type], filters=c.filters,

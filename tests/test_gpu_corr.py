@@ -76,6 +76,29 @@ def test_corr_volume_f32_split3(gpu, shape):
     assert err.max() <= 1.5 * e_exact.max() + 1e-6                                     # no worse than the exact fp32 path
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 8, 12), (1, 256, 60, 80), (1, 96, 5, 7)])
+def test_corr_volume_f32_split2(gpu, shape):
+    """Two leading bf16 pieces, three products: the relative error (vs sum |a||b|) must stay below 2^-15 — 16x finer
+    than TF32 (2^-11), the precision the reference's fast frontend runs this GEMM in (Frontend.py:275-277)."""
+    from macvo_amd import ops
+    from oracle import corr
+
+    B, C, H, W = shape
+    f1, f2 = _feats(B, C, H, W, seed=6)
+    f1[0, :, 0, 0] *= 1e3
+    f2[0, :, 0, 1] *= 1e-3
+    ref64 = corr.corr_volume(f1, f2, torch.float64)
+    a1, a2 = f1.permute(0, 2, 3, 1).contiguous().to(gpu), f2.permute(0, 2, 3, 1).contiguous().to(gpu)
+    out = ops.corr_volume(a1, a2, layout="hwc", precision="split2").cpu()
+    err = (out.double() - ref64).abs()
+    scale = (f1.double().abs().reshape(B, C, -1).permute(0, 2, 1).unsqueeze(2) * f2.double().abs().reshape(B, C, -1).permute(0, 2, 1).unsqueeze(1)).sum(-1)
+    rel = (err / scale.reshape(err.shape).clamp_min(1e-30)).max().item()
+    assert rel <= 2.0 ** -15, rel
+    # and it is a genuinely different (coarser) mode than split3
+    fine = ops.corr_volume(a1, a2, layout="hwc", precision="split3").cpu()
+    assert (fine.double() - ref64).abs().max() <= err.max()
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("layout", ["chw", "hwc"])
 @pytest.mark.parametrize("shape", [(2, 64, 8, 12), (1, 256, 60, 80), (1, 128, 9, 11)])
