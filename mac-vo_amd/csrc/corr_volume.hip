@@ -20,6 +20,7 @@
 //     plain stores are also within noise.  An LDS-free fp32 variant (fragments straight from global memory with an
 //     8- or 16-deep register ring, no barriers) measured 395 / 628 us vs 250 us: the LDS tile is worth keeping.)
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -176,33 +177,6 @@ __global__ __launch_bounds__(256) void corr_volume_f32_chw(const float* __restri
         const float* A = f1 + (size_t)b * C * N1;
         const float* Bp = f2 + (size_t)b * C * N2;
 
-        f32x4 ra[NP], rb[NP];
-        auto gload = [&](int k0) {
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                const int k = k0 + lrow + 8 * p;
-                const float* pa = A + (size_t)k * N1 + m0 + lcol;
-                const float* pb = Bp + (size_t)k * N2 + n0 + lcol;
-                if (VEC4) {
-                    ra[p] = (m0 + lcol < N1) ? *reinterpret_cast<const f32x4*>(pa) : f32x4{0, 0, 0, 0};
-                    rb[p] = (n0 + lcol < N2) ? *reinterpret_cast<const f32x4*>(pb) : f32x4{0, 0, 0, 0};
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        ra[p][e] = (m0 + lcol + e < N1) ? pa[e] : 0.f;
-                        rb[p][e] = (n0 + lcol + e < N2) ? pb[e] : 0.f;
-                    }
-                }
-            }
-        };
-        auto sstore = [&](int buf) {
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                *reinterpret_cast<f32x4*>(&sA[buf][lrow + 8 * p][lcol]) = ra[p];
-                *reinterpret_cast<f32x4*>(&sB[buf][lrow + 8 * p][lcol]) = rb[p];
-            }
-        };
-
         f32x16 acc[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -211,17 +185,91 @@ __global__ __launch_bounds__(256) void corr_volume_f32_chw(const float* __restri
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        gload(0);
-        if (PERSIST) __syncthreads();   // the previous tile's last K-step may still be reading buffer 0/1
-        sstore(0);
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < nk) gload((kt + 1) * BK);
-            mfma_tile_f32<BK, BM>(sA[buf], sB[buf], wm * 64 + li, wn * 64 + li, kh, acc);
-            if (kt + 1 < nk) {
-                sstore(buf ^ 1);
+        if (VEC4 && (nk & 1) == 0) {
+            // 2-deep global prefetch, register staged: the loads of tile kt+2 are issued while tile kt is multiplied, so the
+            // wait in front of the LDS store of tile kt+1 is vmcnt(4) — the younger loads stay in flight across the
+            // barrier — instead of the vmcnt(0) drain of the 1-deep form (measured 216.8 -> 207.7 us).  For hipcc to count
+            // them the loads must be branch-free: columns past the edge are clamped to the last valid float4 (they only
+            // feed output rows / columns that are never stored) and the last two issues re-read the final tile.
+            const float* pa = A + min(m0 + lcol, N1 - 4);
+            const float* pb = Bp + min(n0 + lcol, N2 - 4);
+            const int klast = C - BK;
+            f32x4 ra[2][NP], rb[2][NP];
+            auto gload = [&](auto SET, int k0) {
+                constexpr int S = decltype(SET)::value;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int k = k0 + lrow + 8 * p;
+                    ra[S][p] = *reinterpret_cast<const f32x4*>(pa + (size_t)k * N1);
+                    rb[S][p] = *reinterpret_cast<const f32x4*>(pb + (size_t)k * N2);
+                }
+            };
+            auto sstore = [&](auto SET, int buf) {
+                constexpr int S = decltype(SET)::value;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    *reinterpret_cast<f32x4*>(&sA[buf][lrow + 8 * p][lcol]) = ra[S][p];
+                    *reinterpret_cast<f32x4*>(&sB[buf][lrow + 8 * p][lcol]) = rb[S][p];
+                }
+            };
+            using S0 = std::integral_constant<int, 0>;
+            using S1 = std::integral_constant<int, 1>;
+            gload(S0{}, 0);
+            gload(S1{}, BK);
+            if (PERSIST) __syncthreads();   // the previous tile's last K-step may still be reading buffer 0/1
+            sstore(S0{}, 0);
+            __syncthreads();
+            for (int kt = 0; kt < nk; kt += 2) {
+                // even step: tile kt in LDS buffer 0, tile kt+1 in register set 1
+                gload(S0{}, min((kt + 2) * BK, klast));
+                mfma_tile_f32<BK, BM>(sA[0], sB[0], wm * 64 + li, wn * 64 + li, kh, acc);
+                sstore(S1{}, 1);
                 __syncthreads();
+                // odd step: tile kt+1 in LDS buffer 1, tile kt+2 in register set 0
+                gload(S1{}, min((kt + 3) * BK, klast));
+                mfma_tile_f32<BK, BM>(sA[1], sB[1], wm * 64 + li, wn * 64 + li, kh, acc);
+                sstore(S0{}, 0);
+                __syncthreads();
+            }
+        } else {
+            f32x4 ra[NP], rb[NP];
+            auto gload = [&](int k0) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int k = k0 + lrow + 8 * p;
+                    const float* pa = A + (size_t)k * N1 + m0 + lcol;
+                    const float* pb = Bp + (size_t)k * N2 + n0 + lcol;
+                    if (VEC4) {
+                        ra[p] = (m0 + lcol < N1) ? *reinterpret_cast<const f32x4*>(pa) : f32x4{0, 0, 0, 0};
+                        rb[p] = (n0 + lcol < N2) ? *reinterpret_cast<const f32x4*>(pb) : f32x4{0, 0, 0, 0};
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            ra[p][e] = (m0 + lcol + e < N1) ? pa[e] : 0.f;
+                            rb[p][e] = (n0 + lcol + e < N2) ? pb[e] : 0.f;
+                        }
+                    }
+                }
+            };
+            auto sstore = [&](int buf) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    *reinterpret_cast<f32x4*>(&sA[buf][lrow + 8 * p][lcol]) = ra[p];
+                    *reinterpret_cast<f32x4*>(&sB[buf][lrow + 8 * p][lcol]) = rb[p];
+                }
+            };
+            gload(0);
+            if (PERSIST) __syncthreads();   // the previous tile's last K-step may still be reading buffer 0/1
+            sstore(0);
+            __syncthreads();
+            for (int kt = 0; kt < nk; ++kt) {
+                const int buf = kt & 1;
+                if (kt + 1 < nk) gload((kt + 1) * BK);
+                mfma_tile_f32<BK, BM>(sA[buf], sB[buf], wm * 64 + li, wn * 64 + li, kh, acc);
+                if (kt + 1 < nk) {
+                    sstore(buf ^ 1);
+                    __syncthreads();
+                }
             }
         }
         const bool interior = (m0 + BM <= N1) && (n0 + BN <= N2);

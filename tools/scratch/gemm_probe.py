@@ -1,0 +1,24 @@
+import ctypes as C, os, sys, statistics, torch
+lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgemm_probe.so"))
+lib.gemm_probe_launch.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]
+B, N, Cc = 2, 4800, 256
+f1 = torch.randn(B, Cc, N, device="cuda"); f2 = torch.randn(B, Cc, N, device="cuda"); out = torch.empty(B, N, N, device="cuda")
+fl = B * 2.0 * N * N * Cc
+modes = [int(a) for a in sys.argv[1:]] or [0, 16]
+def run(mode, n):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): rc = lib.gemm_probe_launch(f1.data_ptr(), f2.data_ptr(), out.data_ptr(), B, Cc, N, mode, None)
+    e1.record(); torch.cuda.synchronize()
+    assert rc == 0, (mode, rc)
+    return e0.elapsed_time(e1) * 1e3 / n
+for m in modes: run(m, 20)          # warm-up (clocks, code objects)
+lib.gemm_probe_launch(f1.data_ptr(), f2.data_ptr(), out.data_ptr(), B, Cc, N, 0, None); torch.cuda.synchronize(); ref = out.clone()
+res = {m: [] for m in modes}
+for r in range(7):
+    for m in modes: res[m].append(run(m, 10))
+for m in modes:
+    out.zero_(); lib.gemm_probe_launch(f1.data_ptr(), f2.data_ptr(), out.data_ptr(), B, Cc, N, m, None); torch.cuda.synchronize()
+    ok = torch.equal(out, ref)
+    md, mn = statistics.median(res[m]), min(res[m])
+    print(f"mode {m:3d}: median {md:7.1f} us ({fl / md / 1e6:6.1f} TF)  min {mn:7.1f} us ({fl / mn / 1e6:6.1f} TF)  bitwise==mode0: {ok}")
