@@ -281,6 +281,17 @@ int mv_pgo_solve(int nprob, const int32_t* offsets, int graph_type, const float*
                  float* out_pose_f32, mvStream_t stream);
 
 /* -------------------------------------------------------------------------------------------
+ * A23  PWC-Net local correlation, forward (the reference's only hand-written CUDA kernel; non-default matcher path).
+ * Replaces `FunctionCorrelation(tenFirst, tenSecond)` = `_FunctionCorrelation.forward`
+ * (Module/Network/PWCNet/pwc/correlation.py:277-325; kernels :8-33 rearrange, :35-103 updateOutput):
+ *   out[b, 9*(dy+4)+(dx+4), y, x] = (1/C) * sum_c first[b,c,y,x] * second[b,c,y+dy,x+dx],  dx,dy in [-4,4], zero padded.
+ * first, second: [B, C, H, W] fp32 contiguous (NCHW, as the reference asserts :283-284); out: [B, 81, H, W] fp32.
+ * Callers: pwc_model.py:178-233 (five pyramid levels), pwc_model_tartanvo.py:231,259, RAFTCov.py:7.
+ */
+int mv_local_corr81(const float* first, const float* second, float* out, int B, int C, int H, int W,
+                    mvStream_t stream);
+
+/* -------------------------------------------------------------------------------------------
  * Native per-frame driver: the host-side sequencing of one `MACVO.run_pair` (Odometry/MACVO.py:173-311) and
  * `FlowFormerCovFrontend.estimate_pair` (Module/Frontend/Frontend.py:215-232) for the hot path, as two host calls per
  * frame instead of ~30 (a Python loop over the entry points above is interpreter-bound at ~370 us/frame, more than the

@@ -97,6 +97,23 @@ def corr_volume(f1: torch.Tensor, f2: torch.Tensor, layout: str = "chw", out: to
     return out
 
 
+# ------------------------------------------------------------------------------------------- A23
+def local_corr81(first: torch.Tensor, second: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """PWC-Net ``FunctionCorrelation(tenFirst, tenSecond)`` forward (pwc/correlation.py:277-325): ``[B,C,H,W]`` x2 ->
+    ``[B,81,H,W]``, channel ``9*(dy+4)+(dx+4)`` = mean over C of ``first[y,x] * second[y+dy,x+dx]``, zero padded."""
+    lib = L.load()
+    first = _req(first, torch.float32, "first")
+    second = _req(second, torch.float32, "second")
+    if first.shape != second.shape or first.dim() != 4:
+        raise L.MacvoHipError("local_corr81: first / second must be [B,C,H,W] tensors of the same shape")
+    B, Cc, H, W = first.shape
+    if out is None:
+        out = torch.empty((B, 81, H, W), dtype=torch.float32, device=first.device)
+    L.check(lib.mv_local_corr81(first.data_ptr(), second.data_ptr(), out.data_ptr(), B, Cc, H, W, _stream()),
+            "mv_local_corr81")
+    return out
+
+
 # ------------------------------------------------------------------------------------------- A6
 def corr_lookup(cost_maps: torch.Tensor, coords: torch.Tensor, radius: int = 4, out: torch.Tensor | None = None) -> torch.Tensor:
     """``encode_flow_token(cost_maps, coords)`` (covhead.py:92): ``[B*N1,1,H2,W2]``, ``[B,2,H1,W1]`` -> ``[B,(2r+1)^2,H1,W1]``."""

@@ -289,3 +289,20 @@ def install_flowformer_hooks(model) -> None:
     """
     dec = model.memory_decoder
     dec.encode_flow_token = lambda cost_maps, coords: ops.corr_lookup(cost_maps.float(), coords.float(), 4)
+
+
+def FunctionCorrelation(tenFirst, tenSecond):
+    """Drop-in for ``Module/Network/PWCNet/pwc/correlation.py:372-373`` (forward / inference only — the gradient kernels
+    :105-233 are training code): same argument names, same contiguity asserts (:283-284), HIP kernel underneath.  Patch
+    with ``Module.Network.PWCNet.pwc.correlation.FunctionCorrelation = macvo_amd.plugins.FunctionCorrelation``."""
+    import torch
+
+    from . import ops
+
+    assert tenFirst.is_contiguous()
+    assert tenSecond.is_contiguous()
+    if not tenFirst.is_cuda:
+        raise NotImplementedError()          # as the reference (:323-324): there is no CPU path
+    if torch.is_grad_enabled() and (tenFirst.requires_grad or tenSecond.requires_grad):
+        raise NotImplementedError("macvo_amd FunctionCorrelation is forward-only; wrap the call in torch.no_grad()")
+    return ops.local_corr81(tenFirst.float(), tenSecond.float())

@@ -111,3 +111,39 @@ def corr_lookup_naive(cost_maps: torch.Tensor, coords: torch.Tensor, radius: int
                     acc[b] += torch.where(ok[b], v * w[b], torch.zeros_like(v))
             out[:, K * i + j] = acc
     return out.reshape(B, K * K, H1, W1)
+
+
+def local_corr81(first: torch.Tensor, second: torch.Tensor, accum_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """PWC-Net local correlation, forward: ``_FunctionCorrelation.forward`` (Module/Network/PWCNet/pwc/correlation.py:277-325)
+    = ``kernel_Correlation_rearrange`` (:8-33, zero padding by 4) + ``kernel_Correlation_updateOutput`` (:35-103):
+
+        out[b, 9*(s2p+4) + (s2o+4), y, x] = sum_c first[b,c,y,x] * second[b,c,y+s2p,x+s2o] / C      (:73-74,:99-101)
+
+    with ``s2o = top_channel % 9 - 4`` the x offset and ``s2p = top_channel / 9 - 4`` the y offset.  PARITY UNPINNED: the
+    reference kernel is CUDA-only (cupy; the CPU branch raises NotImplementedError, :323-324) and its tests hold no
+    vectors for it, so this restates the arithmetic definition; the reference's own summation order (32 strided partial
+    sums, serial reduce by lane 0, :76-96) differs from any other order at fp32 rounding level only.
+    """
+    B, C, H, W = first.shape
+    a = first.to(accum_dtype)
+    b = torch.nn.functional.pad(second.to(accum_dtype), (4, 4, 4, 4))
+    out = torch.empty((B, 81, H, W), dtype=accum_dtype)
+    for k in range(81):
+        s2o, s2p = k % 9 - 4, k // 9 - 4
+        out[:, k] = (a * b[:, :, 4 + s2p: 4 + s2p + H, 4 + s2o: 4 + s2o + W]).sum(dim=1) / C
+    return out
+
+
+def local_corr81_naive(first: torch.Tensor, second: torch.Tensor) -> torch.Tensor:
+    """Per-pixel loops in float64 written directly from the kernel's index arithmetic (:47-101); tiny inputs only."""
+    B, C, H, W = first.shape
+    out = torch.zeros((B, 81, H, W), dtype=torch.float64)
+    f, s = first.double(), second.double()
+    for b in range(B):
+        for y in range(H):
+            for x in range(W):
+                for k in range(81):
+                    x2, y2 = x + k % 9 - 4, y + k // 9 - 4
+                    if 0 <= x2 < W and 0 <= y2 < H:
+                        out[b, k, y, x] = (f[b, :, y, x] * s[b, :, y2, x2]).sum() / C
+    return out

@@ -217,3 +217,39 @@ def test_convex_upsample(gpu, B, h, w):
     const = torch.full((1, 2, h, w), 0.5)
     up = ops.convex_upsample(const.to(gpu), mask[:1].to(gpu)).cpu()
     assert (up[..., 8:-8, 8:-8] - 4.0).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 112, 160), (2, 196, 7, 10), (1, 128, 14, 20), (2, 96, 28, 40), (1, 64, 56, 80),
+                                   (1, 16, 33, 47), (1, 3, 5, 5), (3, 8, 1, 1)])
+def test_local_corr81(gpu, shape):
+    """PWC-Net 81-channel local correlation (§8(f) rank 3) at the pyramid shapes of pwc_model.py:178-233 for a 640x448
+    input, plus ragged / degenerate sizes.  Oracle = the definition in float64; tolerance = fp32 accumulation over C
+    (1e-6 relative to (1/C) * sum |a||b|)."""
+    from macvo_amd import ops
+    from oracle import corr
+
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(C + H)
+    a, b = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+    ref = corr.local_corr81(a, b, torch.float64)
+    out = ops.local_corr81(a.to(gpu), b.to(gpu)).cpu()
+    assert out.shape == (B, 81, H, W)
+    scale = corr.local_corr81(a.abs(), b.abs(), torch.float64)
+    err = (out.double() - ref).abs()
+    assert (err <= 1e-6 * scale + 1e-30).all(), float((err / scale.clamp_min(1e-30)).max())
+    # zero padding: displacement (-4,-4) at the top-left pixel reads outside the image
+    assert out[:, 0, 0, 0].abs().max() == 0
+
+
+def test_function_correlation_drop_in(gpu):
+    from macvo_amd import plugins
+    from oracle import corr
+
+    a, b = torch.randn(1, 32, 20, 24), torch.randn(1, 32, 20, 24)
+    with torch.no_grad():
+        out = plugins.FunctionCorrelation(tenFirst=a.to(gpu), tenSecond=b.to(gpu))
+    torch.testing.assert_close(out.cpu(), corr.local_corr81(a, b), rtol=1e-4, atol=1e-5)
+    with pytest.raises(NotImplementedError):
+        plugins.FunctionCorrelation(tenFirst=a, tenSecond=b)        # CPU: same behaviour as the reference
+    with pytest.raises(AssertionError):
+        plugins.FunctionCorrelation(tenFirst=a.to(gpu).transpose(2, 3), tenSecond=b.to(gpu))

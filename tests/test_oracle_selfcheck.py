@@ -116,3 +116,16 @@ def test_huber_and_fast_triggs_definitions():
     s = math.sqrt(0.1 / 0.5)
     assert Rc[0].tolist() == pytest.approx(R[0].tolist()) and Rc[1].tolist() == pytest.approx((R[1] * s).tolist())
     assert Jc[:3].eq(1).all() and Jc[3:].allclose(torch.full((3, 7), s, dtype=torch.float64))
+
+
+def test_local_corr81_matches_index_arithmetic():
+    """oracle.corr.local_corr81 (vectorised) vs per-pixel loops written from the reference kernel's index arithmetic."""
+    from oracle import corr
+
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.randn(2, 5, 6, 7, generator=g), torch.randn(2, 5, 6, 7, generator=g)
+    fast = corr.local_corr81(a, b, torch.float64)
+    slow = corr.local_corr81_naive(a, b)
+    torch.testing.assert_close(fast, slow, rtol=1e-12, atol=1e-12)
+    # channel 40 is the zero displacement: mean over C of first * second
+    torch.testing.assert_close(fast[:, 40], (a.double() * b.double()).mean(1), rtol=1e-12, atol=1e-12)

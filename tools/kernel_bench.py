@@ -75,6 +75,14 @@ def main():
             byts = B * (n * 100 * 4 + n * 8 + n * 81 * 4.0)
             med, mn = timeit(lambda: ops.corr_lookup(vol, coords, 4, out=tok), a.iters)
             print(f"lookup r=4      B={B} {med:8.1f} us (min {mn:.1f})  {byts / med / 1e3:7.1f} GB/s algorithmic")
+        elif w == "localcorr":
+            # PWC pyramid levels of a 640x448 input (pwc_model.py:178-233): (C, H, W)
+            for (cc, hh, ww) in ((196, 7, 10), (128, 14, 20), (96, 28, 40), (64, 56, 80), (32, 112, 160)):
+                a1, a2 = torch.randn(1, cc, hh, ww, generator=g).to(dev), torch.randn(1, cc, hh, ww, generator=g).to(dev)
+                o = torch.empty(1, 81, hh, ww, device=dev)
+                med, mn = timeit(lambda: ops.local_corr81(a1, a2, out=o), a.iters)
+                fl = 2.0 * 81 * cc * hh * ww
+                print(f"local_corr81 C={cc:3d} {hh}x{ww:<3d} {med:7.1f} us (min {mn:.1f})  {fl / med / 1e3:8.1f} GFLOP/s")
         elif w == "upsample":
             fl = torch.randn(B, 2, h8, w8, generator=g).to(dev)
             mk = torch.randn(B, 576, h8, w8, generator=g).to(dev)
