@@ -135,3 +135,49 @@ def make_sequence(n_frames=4, H=480, W=640, C=256, iters=12, seed=0, feat_dtype=
         frames.append(fr)
         z_prev = z
     return cam, frames, poses
+
+
+def tartanair_sequence(C=32, iters=1):
+    """The reference's own unit-test asset as hot-path inputs (tests/golden/tartanair_p000.npz, built by
+    tests/golden/make_tartanair_fixture.py from Scripts/UnitTest/assets/test_sequence/TartanAir2_abs_P000): ground-truth
+    depth -> disparity (stereo sample), ground-truth optical flow t-1 -> t (temporal sample), ground-truth NED poses.
+
+    The log-sigma maps are synthetic and deterministic (integer arithmetic only): a small texture so that the 7x7 NMS has
+    isolated minima, plus +3 where the flow is flagged invalid (occlusion / out of view) or the depth is sky, so the
+    covariance-aware selector avoids those pixels exactly as it avoids high-uncertainty pixels of the real network.
+    Returns (cam dict, frame dicts, poses [n,7] float64).
+    """
+    import os
+
+    import numpy as np
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tartanair_p000.npz"))
+    depth = torch.from_numpy(z["depth"])                               # [n,H,W] f32
+    flow = (torch.from_numpy(z["flow_u16"].astype(np.float32)) - 32768.0) / 64.0   # [n-1,2,H,W], exact
+    fmask = torch.from_numpy(z["flow_mask"])                           # [n-1,H,W] 0 = valid
+    poses = torch.from_numpy(z["poses"])
+    fx, fy, cx, cy = [float(v) for v in z["K"]]
+    bl = float(z["baseline"])
+    n, H, W = depth.shape
+    cam = dict(fx=fx, fy=fy, cx=cx, cy=cy, baseline=bl, H=H, W=W)
+    g = torch.Generator().manual_seed(7)
+    h8, w8 = H // 8, W // 8
+    pool = dict(fmap1=torch.randn(2, C, h8, w8, generator=g), fmap2=torch.randn(2, C, h8, w8, generator=g),
+                coords=(torch.stack([torch.arange(w8).float()[None].expand(h8, w8), torch.arange(h8).float()[:, None].expand(h8, w8)])[None, None]
+                        + (torch.rand(iters, 2, 2, h8, w8, generator=g) * 2 - 1) * 4))
+    vs, us = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    tex = (((us * 7 + vs * 13 + (us * vs) % 11) % 17).float() - 8.0) / 64.0        # exact multiples of 1/64 in [-1/8, 1/8]
+    frames = []
+    for t in range(n):
+        fl = torch.zeros(2, 2, H, W)
+        fl[0, 0] = -(fx * bl) / depth[t]                                # stereo sample: disparity (the frontend takes |.|)
+        lc = torch.full((2, 2, H, W), -1.0) + tex
+        lc[0] = lc[0] + 3.0 * (depth[t] > 100.0).float()
+        if t > 0:
+            fl[1] = flow[t - 1]
+            bad = (fmask[t - 1] != 0) | (depth[t - 1] > 100.0)
+            lc[1] = lc[1] + 3.0 * bad.float()
+        fr = dict(pool)
+        fr.update(flow=fl, logcov=lc)
+        frames.append(fr)
+    return cam, frames, poses
