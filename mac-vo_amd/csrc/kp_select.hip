@@ -175,8 +175,6 @@ __device__ __forceinline__ float key_float(unsigned k) {
 #define MV_KP_FINISH_THREADS 1024
 #endif
 constexpr int FIN_NT = MV_KP_FINISH_THREADS;         // threads of the single finishing workgroup
-constexpr int MAX_REC = 16384;                       // records the fast path keeps in registers
-constexpr int LDS_WORDS = 5120;                      // candidate bit words the fast path keeps in LDS (40 KB): 640 x 512
 constexpr int RANK_CAP = 256;                        // bucket size at which selection switches to direct ranking
 constexpr unsigned NAN_KEY = 0xFFFFFFFFu;
 
@@ -205,14 +203,13 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* wave_tot /*[NT/6
     return off + incl - v;
 }
 
-template <int NT, bool CACHED, typename F>
-__device__ __forceinline__ void for_each_key(const float* __restrict__ vals, int n, const unsigned (&keys)[MAX_REC / NT],
-                                             F&& f) {
+template <int NT, bool CACHED, int RPT, typename F>
+__device__ __forceinline__ void for_each_key(const float* __restrict__ vals, int n, const unsigned (&keys)[RPT], F&& f) {
     const int tid = threadIdx.x;
     if (CACHED) {
         const int nr = (n + NT - 1) / NT;   // register slots that hold data (uniform)
 #pragma unroll
-        for (int r = 0; r < MAX_REC / NT; ++r)
+        for (int r = 0; r < RPT; ++r)
             if (r < nr && r * NT + tid < n) f(keys[r]);
     } else {
         for (int i = tid; i < n; i += NT) f(float_key(vals[i]));
@@ -235,14 +232,13 @@ struct MedianLds {
 // holding rank k becomes the next range, and as soon as that bucket holds <= 256 keys they are ranked directly.
 // Typical cost: one min/max reduction, one histogram pass, one scan, one tiny ranking step.  The population is read
 // from registers (CACHED: thread t holds keys t, t + NT, ...) or re-read from global memory (any size).
-template <int NT, bool CACHED>
-__device__ float block_nanmedian(const float* __restrict__ vals, int n, const unsigned (&keys)[MAX_REC / NT],
-                                 MedianLds& L) {
+template <int NT, bool CACHED, int RPT>
+__device__ float block_nanmedian(const float* __restrict__ vals, int n, const unsigned (&keys)[RPT], MedianLds& L) {
     constexpr int NW = NT / 64, BPT = 2048 / NT;
     const int tid = threadIdx.x;
     unsigned lo = NAN_KEY, hi = 0u;
     int cnt = 0;
-    for_each_key<NT, CACHED>(vals, n, keys, [&](unsigned k) {
+    for_each_key<NT, CACHED, RPT>(vals, n, keys, [&](unsigned k) {
         if (k != NAN_KEY) {
             lo = min(lo, k);
             hi = max(hi, k);
@@ -279,7 +275,7 @@ __device__ float block_nanmedian(const float* __restrict__ vals, int n, const un
         for (int j = 0; j < BPT; ++j) L.hist[j * NT + tid] = 0;
         if (tid == 0) L.sh[3] = 0;
         __syncthreads();
-        for_each_key<NT, CACHED>(vals, n, keys, [&](unsigned kk) {
+        for_each_key<NT, CACHED, RPT>(vals, n, keys, [&](unsigned kk) {
             if (kk >= lo && kk <= hi) atomicAdd(&L.hist[(kk - lo) >> s], 1u);
         });
         __syncthreads();
@@ -311,7 +307,7 @@ __device__ float block_nanmedian(const float* __restrict__ vals, int n, const un
         const unsigned w = s ? ((1u << s) - 1u) : 0u;
         const unsigned nhi = (hi - nlo < w) ? hi : nlo + w;
         if (cb <= RANK_CAP) {
-            for_each_key<NT, CACHED>(vals, n, keys, [&](unsigned kk) {
+            for_each_key<NT, CACHED, RPT>(vals, n, keys, [&](unsigned kk) {
                 if (kk >= nlo && kk <= nhi) L.lst[atomicAdd(&L.sh[3], 1)] = kk;
             });
             __syncthreads();
@@ -333,28 +329,28 @@ __device__ float block_nanmedian(const float* __restrict__ vals, int n, const un
     }
 }
 
-// One workgroup of NT threads.  FAST (n_rec <= 16384 and H * words_per_row <= LDS_WORDS, e.g. 640x480): every global
+// One workgroup of NT threads.  FAST (n_rec <= RPT * NT and H * words_per_row <= WPT * NT): every global
 // array is read exactly once with all loads in flight (records -> registers, candidate words -> registers -> LDS), the
 // threshold pass clears bits with LDS atomics and the compaction reads LDS.  Otherwise the same steps run against
 // global memory.  Few fat threads on purpose: the work is a few thousand elements on ONE compute unit, where every
 // wave-level instruction costs 4 cycles and per-wave fixed costs (scans, loop control) multiply with the wave count.
-template <int NT, bool FAST>
+template <int NT, bool FAST, int RPT, int WPT, bool USE_D>
 __device__ __forceinline__ void kp_finish_body(const mvKpSelectParams& p, const KpWs& ws, int has_flow, int words_per_row,
                                                int32_t* __restrict__ out_cand, int32_t* __restrict__ out_count,
                                                float* __restrict__ out_stats, int n_rec, MedianLds& L,
                                                unsigned long long* lds_words) {
-    constexpr int RPT = MAX_REC / NT, WPT = LDS_WORDS / NT;
+    constexpr int RD = USE_D ? RPT : 1;   // the depth-variance keys only exist in FULL mode
     const int tid = threadIdx.x;
     const int H = p.H, W = p.W;
     const bool mapping = p.mode == MV_KP_MAPPING;
     const bool use_f = (p.mode == MV_KP_NODEPTH) || (p.mode == MV_KP_FULL && has_flow);
-    const bool use_d = (p.mode == MV_KP_FULL);
+    const bool use_d = USE_D && (p.mode == MV_KP_FULL);
     const int n_words = H * words_per_row;
 
     // FAST: every global read of this kernel is issued here, before anything waits: the record arrays are read for all
     // register slots without knowing n_rec yet (they are plane-sized, so the reads stay inside the workspace), the
     // candidate words go to registers and are parked in LDS only after the medians
-    unsigned kq[RPT], kd[RPT], ridx[RPT];
+    unsigned kq[RPT], kd[RD], ridx[RPT];
     unsigned long long wreg[WPT];
     KP_STAMP(0);
     if (FAST) {
@@ -364,7 +360,7 @@ __device__ __forceinline__ void kp_finish_body(const mvKpSelectParams& p, const 
             const int i = min(r * NT + tid, cap - 1);
             ridx[r] = mapping ? 0u : ws.rec_idx[i];
             kq[r] = use_f ? __float_as_uint(ws.rec_q[i]) : 0u;
-            kd[r] = use_d ? __float_as_uint(ws.rec_d[i]) : 0u;
+            if (USE_D) kd[r] = use_d ? __float_as_uint(ws.rec_d[i]) : 0u;
         }
 #pragma unroll
         for (int j = 0; j < WPT; ++j) {
@@ -376,21 +372,21 @@ __device__ __forceinline__ void kp_finish_body(const mvKpSelectParams& p, const 
             const bool live = r * NT + tid < n_rec;
             ridx[r] = live ? ridx[r] : 0u;
             kq[r] = live ? float_key(__uint_as_float(kq[r])) : NAN_KEY;
-            kd[r] = live ? float_key(__uint_as_float(kd[r])) : NAN_KEY;
+            if (USE_D) kd[r] = live ? float_key(__uint_as_float(kd[r])) : NAN_KEY;
         }
     }
 
     float med_f = NAN, thr_f = INFINITY, med_d = NAN, thr_d = INFINITY;
     KP_STAMP(1);
     if (use_f) {
-        med_f = block_nanmedian<NT, FAST>(ws.rec_q, n_rec, kq, L);
+        med_f = block_nanmedian<NT, FAST, RPT>(ws.rec_q, n_rec, kq, L);
         // python: min(max_match_cov, median * 1.5) in double, then the fp32 compare rounds it to fp32:
         // == fp32 min of fp32-rounded operands (rounding is monotonic; med*1.5 is exact in double).
         const float prod = med_f * 1.5f;
         thr_f = (prod < p.max_match_cov) ? prod : p.max_match_cov;  // python min(a, b): b if b < a else a
     }
     if (use_d) {
-        med_d = block_nanmedian<NT, FAST>(ws.rec_d, n_rec, kd, L);
+        med_d = block_nanmedian<NT, FAST, RD>(ws.rec_d, n_rec, kd, L);
         const float prod = med_d * 1.5f;
         thr_d = (prod < p.max_depth_cov) ? prod : p.max_depth_cov;
     }
@@ -412,7 +408,7 @@ __device__ __forceinline__ void kp_finish_body(const mvKpSelectParams& p, const 
                 if (r < nr && (ridx[r] & CAND_FLAG)) {
                     bool ok = true;
                     if (use_f) ok = key_float(kq[r]) < thr_f;
-                    if (ok && use_d) ok = key_float(kd[r]) < thr_d;
+                    if (USE_D) { if (ok && use_d) ok = key_float(kd[USE_D ? r : 0]) < thr_d; }
                     if (!ok) atomicAnd(&lds_words[(ridx[r] & ~CAND_FLAG) >> 6], ~(1ull << (ridx[r] & 63)));
                 }
             }
@@ -468,17 +464,41 @@ __device__ __forceinline__ void kp_finish_body(const mvKpSelectParams& p, const 
     }
 }
 
+// RPT register slots per thread for the records, WPT for the candidate words (kept in dynamic LDS: WPT * NT * 8 bytes).
+// <16, 5> covers 640x480-class images (40 KB), <24, 15> up to 1280x768 (120 KB of the 160 KB LDS; 24 slots keep the
+// kernel inside 128 VGPRs without scratch).
+template <int RPT, int WPT, bool USE_D>
 __global__ __launch_bounds__(FIN_NT) void kp_finish_kernel(mvKpSelectParams p, KpWs ws, int has_flow, int words_per_row,
                                                             int32_t* __restrict__ out_cand,
                                                             int32_t* __restrict__ out_count,
                                                             float* __restrict__ out_stats) {
     __shared__ MedianLds L;
-    __shared__ unsigned long long lds_words[LDS_WORDS];
+    extern __shared__ unsigned long long lds_words[];
     const int n_rec = p.mode == MV_KP_MAPPING ? 0 : ws.counters[0];
-    if (n_rec <= MAX_REC && p.H * words_per_row <= LDS_WORDS)
-        kp_finish_body<FIN_NT, true>(p, ws, has_flow, words_per_row, out_cand, out_count, out_stats, n_rec, L, lds_words);
+    if (n_rec <= RPT * FIN_NT && p.H * words_per_row <= WPT * FIN_NT)
+        kp_finish_body<FIN_NT, true, RPT, WPT, USE_D>(p, ws, has_flow, words_per_row, out_cand, out_count, out_stats, n_rec,
+                                                      L, lds_words);
     else
-        kp_finish_body<FIN_NT, false>(p, ws, has_flow, words_per_row, out_cand, out_count, out_stats, n_rec, L, lds_words);
+        kp_finish_body<FIN_NT, false, RPT, WPT, USE_D>(p, ws, has_flow, words_per_row, out_cand, out_count, out_stats,
+                                                       n_rec, L, lds_words);
+}
+
+template <int RPT, int WPT, bool USE_D>
+static int launch_finish(const mvKpSelectParams& p, const KpWs& ws, int has_flow, int wpr, int32_t* out_cand,
+                         int32_t* out_count, float* out_stats, hipStream_t s) {
+    const size_t dyn = (size_t)WPT * FIN_NT * sizeof(unsigned long long);
+    if (dyn > 48 * 1024) {
+        static bool raised = false;   // per instantiation
+        if (!raised) {
+            if (hipFuncSetAttribute((const void*)kp_finish_kernel<RPT, WPT, USE_D>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)dyn) != hipSuccess)
+                return MV_ERR_LAUNCH;
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL((kp_finish_kernel<RPT, WPT, USE_D>), dim3(1), dim3(FIN_NT), dyn, s, p, ws, has_flow, wpr, out_cand,
+                       out_count, out_stats);
+    return MV_OK;
 }
 
 __global__ void kp_gather_kernel(const int32_t* __restrict__ cand, const int64_t* __restrict__ perm, int n_sel,
@@ -546,8 +566,14 @@ extern "C" int mv_kp_select(const float* flow_cov, const float* depth0, const fl
     dim3 grid(wpr, mv_ceil_div(p.H, TILE_H)), block(64, 4);
     hipLaunchKernelGGL(kp_nms_kernel, grid, block, 0, s, flow_cov, depth0, depth0_cov, depth1, depth1_cov, mask_a,
                        mask_b, p, ws, wpr);
-    hipLaunchKernelGGL(kp_finish_kernel, dim3(1), dim3(FIN_NT), 0, s, p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count,
-                       out_stats);
+    const bool big = (size_t)p.H * wpr > 5 * (size_t)FIN_NT;
+    const bool full = p.mode == MV_KP_FULL;
+    int rc;
+    if (big) rc = full ? launch_finish<24, 15, true>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, s)
+                       : launch_finish<24, 15, false>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, s);
+    else rc = full ? launch_finish<16, 5, true>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, s)
+                   : launch_finish<16, 5, false>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, s);
+    if (rc != MV_OK) return rc;
     return mv_launch_status();
 }
 
