@@ -45,7 +45,7 @@ def parse_args():
                     help="fp32 features: exact fp32 MFMA (default) or bf16x3 split (fp32-class accuracy; needs --layout hwc)")
     ap.add_argument("--graph", choices=["disp", "reproj", "icp"], default="disp")
     ap.add_argument("--pool", type=int, default=24, help="distinct synthetic frames (closed trajectory) kept in HBM")
-    ap.add_argument("--cpu-frames", type=int, default=40, help="frames timed for the CPU baseline (rank 0, N=1 only)")
+    ap.add_argument("--cpu-frames", type=int, default=120, help="frames timed for the CPU baseline (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graphs", action="store_true", help="replay the decoder-side segment (12 lookups + epilogue + selector) as a hipGraph (measured slower than eager launches on ROCm 7.2: 2.46 k vs 2.60 k fps)")
     ap.add_argument("--driver", choices=["native", "python"], default="native",

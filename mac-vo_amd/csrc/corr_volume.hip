@@ -33,6 +33,9 @@ namespace {
 
 constexpr int BM = 128;
 constexpr int BN = 128;
+#ifdef MV_VOL_RG_RUNTIME
+__constant__ int g_rg = 5;   // experiment knob: tile rows per super-row (scratch builds only)
+#endif
 
 // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8); give each XCD a
 // contiguous band of tile rows so the f1 row-band and the streamed f2 tiles stay in that XCD's L2.
@@ -50,9 +53,15 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int& tm, i
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     const int lin = base + (id >> 3);
     // inside an XCD's contiguous range, walk "super-rows" of RG tile rows column by column: consecutive workgroups share
-    // one f2 column tile (128 KB) and cycle through RG f1 row tiles (RG x 128 KB), which fits the 4 MB L2 with room to
-    // spare, instead of streaming all of f2 (4.9 MB > L2) once per tile row
-    constexpr int RG = 5;
+    // one f2 column tile (128 KB) and cycle through RG f1 row tiles (RG x 128 KB = 1.3 MB, resident in the 4 MB L2).
+    // With RG = 10 a super-row holds 380 tiles = two XCDs' worth (361 per pair / 8 ... 180 each), i.e. the XCDs tile the
+    // output 4 x 2: each reads 1/4 of f1 and 1/2 of f2 instead of 1/8 and all of it (HBM/fabric fetches 100 -> ~60 MB;
+    // the run time does not depend on RG — the GEMM is not read-bound)
+#ifdef MV_VOL_RG_RUNTIME
+    const int RG = g_rg;
+#else
+    constexpr int RG = 10;
+#endif
     const int per_sr = RG * tiles_n;
     const int sr = lin / per_sr;
     const int within = lin - sr * per_sr;

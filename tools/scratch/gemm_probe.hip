@@ -1,4 +1,5 @@
 // scratch: which part of the fp32 volume GEMM costs the 33 % between 105 and 156 TFLOP/s?  (knock-out variants)
+#define MV_VOL_RG_RUNTIME 1
 #include "../../mac-vo_amd/csrc/corr_volume.hip"
 namespace {
 template <int MODE>   // 1 = no epilogue store, 2 = no global loads, 4 = no ds_write + barrier, 8 = no LDS fragment reads
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(256) void probe_gemm_glds(const float* __restrict__
 }
 }  // namespace
 
+extern "C" int gemm_probe_set_rg(int rg) { return hipMemcpyToSymbol(HIP_SYMBOL(g_rg), &rg, sizeof(int)) == hipSuccess ? 0 : 1; }
 extern "C" int gemm_probe_launch(const float* f1, const float* f2, float* out, int B, int C, int N, int mode, void* stream) {
     const int tm = (N + BM - 1) / BM;
     dim3 grid(tm * tm, 1, B), block(256);
