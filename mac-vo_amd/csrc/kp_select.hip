@@ -73,11 +73,16 @@ __global__ __launch_bounds__(256) void kp_nms_kernel(const float* __restrict__ f
 
     if (!mapping) {
         const int tw = TILE_W + 2 * r, th = TILE_H + 2 * r;
-        for (int e = tid; e < tw * th; e += 256) {
+        // stage the quality tile + halo: all global loads of a thread are issued before the first LDS store
+        constexpr int NST = ((TILE_W + 2 * MAX_R) * (TILE_H + 2 * MAX_R) + 255) / 256;   // 9 for the 78 x 30 maximum
+        float qv[NST];
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int e = i * 256 + tid;
             const int ly = e / tw, lx = e - ly * tw;
             const int gx = x0 + lx - r, gy = y0 + ly - r;
             float q = INFINITY;  // out-of-image == -inf padding of max_pool2d(-q): never the minimum
-            if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
+            if (e < tw * th && gx >= 0 && gx < W && gy >= 0 && gy < H) {
                 const int idx = gy * W + gx;
                 if (p.mode == MV_KP_NODEPTH) {
                     q = flow_quality(fc, plane, idx);
@@ -86,7 +91,13 @@ __global__ __launch_bounds__(256) void kp_nms_kernel(const float* __restrict__ f
                     if (fc) q = q * flow_quality(fc, plane, idx);
                 }
             }
-            tile[ly][lx] = q;
+            qv[i] = q;
+        }
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int e = i * 256 + tid;
+            const int ly = e / tw, lx = e - ly * tw;
+            if (e < tw * th) tile[ly][lx] = qv[i];
         }
         __syncthreads();
         // horizontal pass: hmin[ly][x] = nanmin over tile[ly][x .. x+2r]
@@ -140,7 +151,11 @@ __global__ __launch_bounds__(256) void kp_nms_kernel(const float* __restrict__ f
     int my_off = 0;
     if (my_nms) my_off = atomicAdd(&wg_count, my_nms);
     __syncthreads();
+#ifdef MV_KP_FAKE_ATOMIC
+    if (tid == 0) wg_base = (blockIdx.y * gridDim.x + blockIdx.x) * 16;   // timing experiment only (wrong results)
+#else
     if (tid == 0) wg_base = wg_count ? atomicAdd(&ws.counters[0], wg_count) : 0;
+#endif
     __syncthreads();
     int pos = wg_base + my_off;
 #pragma unroll
