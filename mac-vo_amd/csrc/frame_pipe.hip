@@ -13,6 +13,10 @@
 //   side   the LM solve (the GPU analogue of the reference's optimizer child process, Optimization/Interface.py:80-96)
 // Frame t+1's frontend is enqueued before frame t's `finish`, so the selector's host round trip (candidate count ->
 // torch.randperm on the CPU, kept for bit-exact indices -> permutation back) never idles the GPU.
+// Stream layouts measured on the bench (ms / frame): this one 0.3235; even / odd frames each entirely on their own
+// frontend stream (no event between GEMM and lookups) 0.337 — the next frame's GEMM then collides with more of the
+// latency-bound kernels and both stretch; ONE frontend stream for everything 0.373 — the ~3 us launch-to-launch gaps of
+// the 15 small kernels are no longer hidden under the next GEMM.
 //
 // Memory: every device buffer lives in ONE caller-provided arena (a torch tensor in the Python host), carved up here;
 // mv_frame_pipe_buffer reports where each piece is so the host can view results without copies.  Slots rotate so a
@@ -107,6 +111,15 @@ struct mvFramePipe {
     std::vector<hipEvent_t> tv0, tv1;
     int n_timed, timed_cap;
 };
+
+// cross-stream dependency; when the event has already fired no barrier packet is queued at all (every
+// hipStreamWaitEvent costs the waiting queue a few microseconds even for a long-fired event)
+static int wait_if_pending(hipStream_t s, hipEvent_t e) {
+    const hipError_t q = hipEventQuery(e);
+    if (q == hipSuccess) return MV_OK;
+    if (q != hipErrorNotReady) return MV_ERR_LAUNCH;
+    return hipStreamWaitEvent(s, e, 0) == hipSuccess ? MV_OK : MV_ERR_LAUNCH;
+}
 
 static size_t carve(mvFramePipe* p, char* base) {
     const mvFramePipeConfig& c = p->c;
@@ -301,8 +314,8 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
     MV_HIP(hipEventRecord(e_in, (hipStream_t)in_stream));
 
     // ---- volume GEMM (own stream; a buffer is rewritten only after the lookups that read it have finished)
-    MV_HIP(hipStreamWaitEvent(p->s_vol, e_in, 0));
-    if (p->vol_free_valid[k]) MV_HIP(hipStreamWaitEvent(p->s_vol, p->e_vol_free[k], 0));
+    MV_TRY(wait_if_pending(p->s_vol, e_in));
+    if (p->vol_free_valid[k]) MV_TRY(wait_if_pending(p->s_vol, p->e_vol_free[k]));
     const bool timed = p->n_timed < p->timed_cap;
     if (timed) MV_HIP(hipEventRecord(p->tv0[p->n_timed], p->s_vol));
     if (c.volume_split) {
@@ -319,8 +332,7 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
 
     // ---- decoder side
     hipStream_t s = p->s_main;
-    MV_HIP(hipStreamWaitEvent(s, e_in, 0));
-    MV_HIP(hipStreamWaitEvent(s, p->e_vol_done[k], 0));
+    MV_HIP(hipStreamWaitEvent(s, p->e_vol_done[k], 0));   // also orders `s` after e_in (the GEMM stream waited for it)
     const size_t coord_stride = (size_t)B * 2 * p->n8;
     for (int it = 0; it < c.iters; ++it)
         MV_TRY(mv_corr_lookup(p->vol[k], in->coords + it * coord_stride, p->tok[it & 1], B, p->h8, p->w8, p->h8, p->w8,
@@ -329,8 +341,8 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
     p->vol_free_valid[k] = true;
 
     // maps slot m and candidate slot k were last read by the backend of frame f - 2 (f - 3 for the maps) on `back`
-    if (p->backend_valid[k]) MV_HIP(hipStreamWaitEvent(s, p->e_backend[k], 0));
-    if (p->backend_valid[k ^ 1]) MV_HIP(hipStreamWaitEvent(s, p->e_backend[k ^ 1], 0));
+    // (the newest backend event covers the older one: same stream)
+    if (p->n_fin > 0 && p->backend_valid[(p->n_fin - 1) & 1]) MV_TRY(wait_if_pending(s, p->e_backend[(p->n_fin - 1) & 1]));
     Maps& mp = p->maps[m];
     if (up) {
         MV_TRY(mv_convex_upsample(in->flow8, in->up_mask, p->up_flow, B, p->h8, p->w8, 0.25f, 0, s));
@@ -398,14 +410,14 @@ extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, in
     const int ps = (int)(g % N_PERM);
     if (p->perm_valid[ps]) MV_HIP(hipEventSynchronize(p->e_perm[ps]));   // long done; keeps the slot reuse provably safe
     memcpy(p->h_perm[ps], perm_host, (size_t)n_sel * sizeof(int64_t));
-    MV_HIP(hipStreamWaitEvent(s, p->e_cand[pd.cand], 0));
+    MV_TRY(wait_if_pending(s, p->e_cand[pd.cand]));   // fired: the host has just read this frame's count
     MV_HIP(hipMemcpyAsync(b.perm, p->h_perm[ps], (size_t)n_sel * sizeof(int64_t), hipMemcpyHostToDevice, s));
     MV_HIP(hipEventRecord(p->e_perm[ps], s));
     p->perm_valid[ps] = true;
     MV_TRY(mv_kp_gather(p->cand[pd.cand], b.perm, n_sel, c.W, b.kp0, s));
     // the previous pose is produced by the previous solve; this also orders us after the solve of frame g - 2, the last
     // reader of this backend slot
-    if (p->pgo_valid) MV_HIP(hipStreamWaitEvent(s, p->e_pgo, 0));
+    if (p->pgo_valid) MV_TRY(wait_if_pending(s, p->e_pgo));
     const float* pose = p->pose[p->pose_cur];
     MV_TRY(mv_kp_track(b.kp0, n_sel, m1.match_flow, m1.match_cov, m0.depth, m0.disparity, m0.disparity_cov, m0.depth_cov,
                        m1.depth, m1.disparity, m1.disparity_cov, m1.depth_cov, c.H, c.W, c.edgewidth, c.match_cov_default,
