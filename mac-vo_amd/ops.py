@@ -154,7 +154,8 @@ def frontend_epilogue(flow: torch.Tensor, cov: torch.Tensor, baseline: float, fx
     lib = L.load()
     flow = _req(flow, torch.float32, "flow")
     cov = _req(cov, torch.float32, "cov")
-    assert flow.shape == cov.shape and flow.shape[0] == 2 and flow.shape[1] == 2
+    assert flow.shape == cov.shape and flow.shape[1] == 2
+    assert flow.shape[0] == 2 or (flow.shape[0] == 1 and not want_match), "sample 0 = stereo pair, sample 1 = temporal pair"
     _, _, H, W = flow.shape
     dev = flow.device
     mk = lambda c: torch.empty((1, c, H, W), dtype=torch.float32, device=dev)  # noqa: E731

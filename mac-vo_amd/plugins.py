@@ -8,6 +8,7 @@ replace, every hot arithmetic step in the HIP kernels (``include/macvo_hip.h``).
     MappingPointSelector                      HIP_MappingPointSelector
     MatchCovariance                           HIP_MatchCovariance
     TwoFrame_PGO                              HIP_TwoFrame_PGO
+    FlowFormerCovFrontend                     HIP_FlowFormerCovFrontend  (network stays PyTorch; lookups + epilogue in HIP)
     (FlowFormerCov's volume / lookup)         install_flowformer_hooks(model)
 
 Select them by changing only the ``type:`` strings of ``Config/Experiment/MACVO/MACVO_Fast.yaml`` (see
@@ -22,7 +23,8 @@ from types import SimpleNamespace
 import torch
 
 from . import ops
-from .interfaces import (GraphInput, GraphOutput, ICovariance2to3, IKeypointSelector, IOptimizer, _is_device)
+from .interfaces import (GraphInput, GraphOutput, ICovariance2to3, IFrontend, IKeypointSelector, IMatcher, IOptimizer,
+                         IStereoDepth, _is_device)
 
 
 def _num(v) -> bool:
@@ -275,6 +277,95 @@ class HIP_TwoFrame_PGO(IOptimizer[GraphInput, dict, GraphOutput]):
 
     def terminate(self) -> None:
         self._pending = None
+
+
+# ----------------------------------------------------------------------------------------------- IFrontend
+class HIP_FlowFormerCovFrontend(IFrontend):
+    """``FlowFormerCovFrontend`` (Module/Frontend/Frontend.py:143-262) with the hot path in HIP: same YAML args, same call
+    structure (``estimate_pair`` concatenates ``A = [L_t2, L_t1]``, ``B = [R_t2, L_t2]`` :219-220, one ``model.inference``,
+    ``.float()``), but the window lookups of the network run through ``mv_corr_lookup`` (``install_flowformer_hooks``) and
+    ``inference_2_depth`` + ``inference_2_match`` (:183-200: abs, disparity_to_depth(_cov), from_partial_cov) are ONE
+    ``mv_frontend_epilogue`` launch instead of ~8 elementwise kernels.
+
+    The network itself stays PyTorch: it is built exactly as the reference does (:147-158) when the FlowFormer package is
+    importable; a host that constructs the model itself passes it as ``config.model`` (anything with
+    ``inference(imageA, imageB) -> (flow [B,2,H,W], cov = exp(2*log_sigma) [B,2,H,W])``, flownet.py:35-44)."""
+
+    def __init__(self, config: SimpleNamespace):
+        super().__init__(config)
+        model = getattr(config, "model", None)
+        if model is None:
+            try:
+                from Module.Network.FlowFormer.configs.submission import get_cfg
+                from Module.Network.FlowFormerCov import build_flowformer
+                from Utility.Utils import reflect_torch_dtype
+            except Exception as e:  # noqa: BLE001
+                raise ImportError(
+                    "HIP_FlowFormerCovFrontend: the FlowFormer network (Module/Network/FlowFormer, the MAC-VO/S_FlowFormer "
+                    "submodule) is not importable; initialise the submodule or pass a constructed network as config.model"
+                ) from e
+            cfg = get_cfg()
+            cfg.latentcostformer.decoder_depth = self.config.decoder_depth
+            model = build_flowformer(cfg, reflect_torch_dtype(config.enc_dtype), reflect_torch_dtype(config.dec_dtype))
+            ckpt = torch.load(self.config.weight, map_location=self.config.device, weights_only=True)
+            model.eval()
+            model.to(self.config.device)
+            model.load_ddp_state_dict(ckpt)
+        if hasattr(model, "memory_decoder"):
+            install_flowformer_hooks(model)
+        self.model = model
+
+    @property
+    def provide_cov(self) -> tuple[bool, bool]:
+        return True, True
+
+    def _infer(self, input_A: torch.Tensor, input_B: torch.Tensor):
+        input_A = input_A.to(device=self.config.device)
+        input_B = input_B.to(device=self.config.device)
+        est_flow, est_cov = self.model.inference(input_A, input_B)
+        return est_flow.float().contiguous(), est_cov.float().contiguous()
+
+    def _depth_record(self, maps) -> "IStereoDepth.Output":
+        return IStereoDepth.Output(depth=maps.depth, cov=maps.depth_cov, disparity=maps.disparity,
+                                   disparity_uncertainty=maps.disparity_cov, mask=maps.bad_mask)
+
+    @torch.inference_mode()
+    def estimate_depth(self, frame) -> "IStereoDepth.Output":
+        flow, cov = self._infer(frame.imageL, frame.imageR)
+        maps = ops.frontend_epilogue(flow[0:1], cov[0:1], frame.frame_baseline, frame.fx, cov_is_log=False,
+                                     enforce_positive_disparity=self.config.enforce_positive_disparity, want_match=False)
+        return self._depth_record(maps)
+
+    @torch.inference_mode()
+    def estimate_pair(self, frame_t1, frame_t2):
+        flow, cov = self._infer(torch.cat([frame_t2.imageL, frame_t1.imageL], dim=0),
+                                torch.cat([frame_t2.imageR, frame_t2.imageL], dim=0))
+        maps = ops.frontend_epilogue(flow[0:2], cov[0:2], frame_t2.frame_baseline, frame_t2.fx, cov_is_log=False,
+                                     enforce_positive_disparity=self.config.enforce_positive_disparity)
+        return self._depth_record(maps), IMatcher.Output(flow=maps.flow, cov=maps.flow_cov, mask=None)
+
+    @torch.inference_mode()
+    def estimate_triplet(self, frame_t1, frame_t2):
+        flow, cov = self._infer(torch.cat([frame_t1.imageL, frame_t2.imageL, frame_t1.imageL], dim=0),
+                                torch.cat([frame_t1.imageL, frame_t2.imageR, frame_t2.imageL], dim=0))
+        # NB the reference feeds (L_t1, L_t1) as the first pair (:237-238) — kept as is
+        pos = self.config.enforce_positive_disparity
+        m1 = ops.frontend_epilogue(flow[0:1], cov[0:1], frame_t1.frame_baseline, frame_t1.fx, cov_is_log=False,
+                                   enforce_positive_disparity=pos, want_match=False)
+        m2 = ops.frontend_epilogue(flow[1:3], cov[1:3], frame_t2.frame_baseline, frame_t2.fx, cov_is_log=False,
+                                   enforce_positive_disparity=pos)
+        return self._depth_record(m1), self._depth_record(m2), IMatcher.Output(flow=m2.flow, cov=m2.flow_cov, mask=None)
+
+    @classmethod
+    def is_valid_config(cls, config: SimpleNamespace | None) -> None:
+        cls._enforce_config_spec(config, {
+            "weight": lambda s: isinstance(s, str),
+            "device": lambda s: isinstance(s, str) and ("cuda" in s),      # the HIP hot path has no CPU fallback
+            "dec_dtype": lambda b: isinstance(b, str) and b in ("fp32", "fp16", "bf16"),
+            "enc_dtype": lambda b: isinstance(b, str) and b in ("fp32", "fp16", "bf16"),
+            "enforce_positive_disparity": lambda b: isinstance(b, bool),
+            "decoder_depth": lambda v: isinstance(v, int),
+        })
 
 
 # ----------------------------------------------------------------------------------------------- FlowFormer hooks

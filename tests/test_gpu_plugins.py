@@ -130,3 +130,66 @@ def test_hip_selector_plugins(gpu):
     px = s3.select_point(frame, 500, dep0, dep1, match)
     torch.manual_seed(7)
     assert torch.equal(px.cpu(), selector.mapping_point_selector(d0, d0c, 500, 20.0, 0.2, 32)[0])
+
+
+def test_frontend_plugin_matches_reference_records(gpu):
+    """HIP_FlowFormerCovFrontend with an injected network stub: estimate_pair / estimate_depth / estimate_triplet must
+    return what FlowFormerCovFrontend.inference_2_depth / _2_match (Frontend.py:183-200) would, bit for bit."""
+    from types import SimpleNamespace
+
+    from macvo_amd import plugins
+    from oracle import frontend as ofr
+
+    H, W = 64, 96
+    g = torch.Generator().manual_seed(0)
+
+    class Net:
+        def __init__(self):
+            self.calls = []
+
+        def inference(self, a, b):
+            self.calls.append((a.clone(), b.clone()))
+            n = a.shape[0]
+            gg = torch.Generator().manual_seed(100 + n)
+            flow = (torch.randn(n, 2, H, W, generator=gg) * 8).to(a.device)
+            flow[0, 0, 0, :5] = torch.tensor([0.0, -0.0, 1e-30, -3.5, 2.0])       # zero / negative disparities
+            cov = torch.exp(2 * (0.5 * torch.randn(n, 2, H, W, generator=gg) - 0.7)).to(a.device)
+            return flow.half(), cov.half()                                       # the plugin must .float() them
+
+    def frame(seed):
+        gg = torch.Generator().manual_seed(seed)
+        return SimpleNamespace(imageL=torch.rand(1, 3, H, W, generator=gg), imageR=torch.rand(1, 3, H, W, generator=gg),
+                               frame_baseline=0.25, fx=320.0)
+
+    net = Net()
+    cfg = SimpleNamespace(weight="", device="cuda", dec_dtype="fp32", enc_dtype="fp32", enforce_positive_disparity=True,
+                          decoder_depth=12, model=net)
+    fe = plugins.HIP_FlowFormerCovFrontend(cfg)
+    assert fe.provide_cov == (True, True)
+    f1, f2 = frame(1), frame(2)
+
+    def check_depth(out, flow, cov, fr):
+        d, dc, disp, dispc, bad = ofr.inference_2_depth(flow, cov, fr.frame_baseline, fr.fx, enforce_positive_disparity=True)
+        assert torch.equal(out.disparity.cpu(), disp) and torch.equal(out.disparity_uncertainty.cpu(), dispc)
+        assert torch.equal(out.depth.cpu(), d, ) and torch.equal(out.cov.cpu(), dc)
+        assert torch.equal(out.mask.cpu(), bad)
+
+    depth2, match = fe.estimate_pair(f1, f2)
+    a, b = net.calls[-1]
+    assert torch.equal(a.cpu(), torch.cat([f2.imageL, f1.imageL])) and torch.equal(b.cpu(), torch.cat([f2.imageR, f2.imageL]))
+    flow, cov = [t.float().cpu() for t in Net().inference(a, b)]
+    check_depth(depth2, flow[0:1], cov[0:1], f2)
+    assert torch.equal(match.flow.cpu(), flow[1:2]) and torch.equal(match.cov.cpu()[:, :2], cov[1:2])
+    assert match.cov.shape == (1, 3, H, W) and match.cov[:, 2].abs().max() == 0 and match.mask is None
+
+    d1 = fe.estimate_depth(f1)
+    flow, cov = [t.float().cpu() for t in Net().inference(*net.calls[-1])]
+    check_depth(d1, flow[0:1], cov[0:1], f1)
+
+    t1, t2, m12 = fe.estimate_triplet(f1, f2)
+    a, b = net.calls[-1]
+    assert a.shape[0] == 3 and torch.equal(b.cpu(), torch.cat([f1.imageL, f2.imageR, f2.imageL]))
+    flow, cov = [t.float().cpu() for t in Net().inference(a, b)]
+    check_depth(t1, flow[0:1], cov[0:1], f1)
+    check_depth(t2, flow[1:2], cov[1:2], f2)
+    assert torch.equal(m12.flow.cpu(), flow[2:3]) and torch.equal(m12.cov.cpu()[:, :2], cov[2:3])

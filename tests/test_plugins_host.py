@@ -57,3 +57,19 @@ def test_retrieve_pixels_contract():
     got = I.IFrontend.retrieve_pixels(uv, m)
     assert got.shape == (3, 2) and torch.equal(got[:, 0], m[0, :, 2, 1]) and torch.equal(got[:, 1], m[0, :, 0, 4])
     assert I.IFrontend.retrieve_pixels(uv, None) is None
+
+
+def test_frontend_plugin_registers_and_explains_missing_network():
+    from types import SimpleNamespace
+
+    from macvo_amd import plugins
+    from macvo_amd.interfaces import IFrontend
+
+    assert IFrontend.get_class("HIP_FlowFormerCovFrontend") is plugins.HIP_FlowFormerCovFrontend
+    good = SimpleNamespace(weight="w.pth", device="cuda", dec_dtype="fp32", enc_dtype="fp16", enforce_positive_disparity=False,
+                           decoder_depth=12)
+    plugins.HIP_FlowFormerCovFrontend.is_valid_config(good)
+    with pytest.raises(Exception):
+        plugins.HIP_FlowFormerCovFrontend.is_valid_config(SimpleNamespace(**{**vars(good), "device": "cpu"}))
+    with pytest.raises(ImportError, match="S_FlowFormer"):
+        plugins.HIP_FlowFormerCovFrontend(good)      # FlowFormer source is an empty submodule in the reference checkout
