@@ -97,3 +97,46 @@ def test_gloo_world2_pose_gather(tmp_path):
                          capture_output=True, text=True, env=env, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("OK") == 2
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """No CPU fallback: a missing libmacvo_hip.so must raise and name the build command (fresh interpreter: load() caches)."""
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path.insert(0, %r); import macvo_amd; from macvo_amd import _lib as L\n"
+            "try:\n    L.load(%r)\nexcept L.MacvoHipError as e:\n    assert 'no CPU fallback' in str(e) and 'make -C' in str(e); print('LOUD')\n"
+            % (ROOT, str(tmp_path / "libmacvo_hip.so")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "LOUD" in out.stdout, out.stderr[-2000:]
+
+
+def test_frame_pipe_config_validation_without_gpu():
+    """mv_frame_pipe_arena_bytes is pure host code: sizes the arena and rejects invalid configurations with 0."""
+    import ctypes as C
+
+    from macvo_amd import _lib as L
+
+    lib = L.load()
+    lm = L.mvLMParams()
+    lib.mv_lm_default_params(C.byref(lm))
+
+    def cfg(**kw):
+        d = dict(H=480, W=640, C=256, pairs=2, iters=12, radius=4, feat_dtype=L.MV_F32, layout=L.MV_LAYOUT_CHW, volume_split=0,
+                 selector_mode=L.MV_KP_NODEPTH, kp_kernel_size=7, kp_mask_width=32, num_point=200, edgewidth=32,
+                 min_num_point=10, graph_type=L.MV_GRAPH_DISP, filters=1, cov_kernel_size=31, fx=320.0, fy=320.0, cx=320.0,
+                 cy=240.0, baseline=0.25, bl_fx=80.0, bl_fx_sq=6400.0, match_cov_default=0.25, max_match_cov=100.0,
+                 max_depth_cov=250.0, max_depth=80.0, min_flow_cov_sq=0.0625, min_depth_cov=0.05, filter_min_depth=0.05,
+                 reserved=0.0, lm=lm)
+        d.update(kw)
+        return L.mvFramePipeConfig(**d)
+
+    n = lib.mv_frame_pipe_arena_bytes(C.byref(cfg()))
+    vol = 2 * 4800 * 4800 * 4
+    assert 2 * vol < n < 2 * vol + 100e6 and n % 256 == 0            # two volumes + ~57 MB of maps / scratch
+    assert lib.mv_frame_pipe_arena_bytes(C.byref(cfg(H=720, W=1280))) > 2 * 2 * 14400 * 14400 * 4
+    for bad in (dict(H=481), dict(C=100), dict(pairs=3), dict(radius=5), dict(selector_mode=L.MV_KP_MAPPING),
+                dict(graph_type=7), dict(volume_split=2), dict(volume_split=4, layout=L.MV_LAYOUT_HWC)):
+        assert lib.mv_frame_pipe_arena_bytes(C.byref(cfg(**bad))) == 0, bad
+    assert lib.mv_frame_pipe_arena_bytes(C.byref(cfg(volume_split=2, layout=L.MV_LAYOUT_HWC))) > n   # split planes added
+    assert lib.mv_error_string(-4).decode() == "workspace too small"
