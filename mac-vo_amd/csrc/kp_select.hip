@@ -516,6 +516,48 @@ static int launch_finish(const mvKpSelectParams& p, const KpWs& ws, int has_flow
     return MV_OK;
 }
 
+// ---- MappingPointSelector: no medians, but typically 10^5 candidates.  The single finishing workgroup would emit ~150
+// indices per thread one after the other (40 us at 640x480, 115 us at 720p); instead: one workgroup scans the per-word
+// popcounts, then one WAVE per 64-pixel word emits its set bits (rank by popcount of the lower bits).
+__global__ __launch_bounds__(1024) void kp_map_scan_kernel(const unsigned long long* __restrict__ cand_bits, int n_words,
+                                                            int* __restrict__ word_off, int32_t* __restrict__ out_count,
+                                                            float* __restrict__ out_stats) {
+    __shared__ int wave_tot[16];
+    const int tid = threadIdx.x;
+    const int per = (n_words + 1023) / 1024;
+    const int w_begin = min(tid * per, n_words), w_end = min(w_begin + per, n_words);
+    int cnt = 0;
+    for (int w = w_begin; w < w_end; ++w) cnt += __popcll(cand_bits[w]);
+    int total;
+    int pos = block_exclusive_scan<1024>(cnt, wave_tot, total);
+    for (int w = w_begin; w < w_end; ++w) {
+        word_off[w] = pos;
+        pos += __popcll(cand_bits[w]);
+    }
+    if (tid == 0) {
+        out_count[0] = total;
+        out_count[1] = out_count[2] = out_count[3] = 0;
+        out_stats[0] = NAN;
+        out_stats[1] = INFINITY;
+        out_stats[2] = NAN;
+        out_stats[3] = INFINITY;
+    }
+}
+
+__global__ __launch_bounds__(256) void kp_map_emit_kernel(const unsigned long long* __restrict__ cand_bits,
+                                                           const int* __restrict__ word_off, int n_words, int words_per_row,
+                                                           int W, int32_t* __restrict__ out_cand) {
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_words) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long bits = cand_bits[w];
+    if ((bits >> lane) & 1ull) {
+        const int rank = __popcll(bits & ((1ull << lane) - 1ull));
+        const int row = w / words_per_row, col0 = (w - row * words_per_row) * 64;
+        out_cand[word_off[w] + rank] = row * W + col0 + lane;
+    }
+}
+
 __global__ void kp_gather_kernel(const int32_t* __restrict__ cand, const int64_t* __restrict__ perm, int n_sel,
                                  int W, int64_t* __restrict__ out_uv) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -581,6 +623,14 @@ extern "C" int mv_kp_select(const float* flow_cov, const float* depth0, const fl
     dim3 grid(wpr, mv_ceil_div(p.H, TILE_H)), block(64, 4);
     hipLaunchKernelGGL(kp_nms_kernel, grid, block, 0, s, flow_cov, depth0, depth0_cov, depth1, depth1_cov, mask_a,
                        mask_b, p, ws, wpr);
+    if (p.mode == MV_KP_MAPPING) {
+        const int n_words = p.H * wpr;
+        int* word_off = (int*)ws.rec_idx;   // record arrays are unused in this mode
+        hipLaunchKernelGGL(kp_map_scan_kernel, dim3(1), dim3(1024), 0, s, ws.cand_bits, n_words, word_off, out_count, out_stats);
+        hipLaunchKernelGGL(kp_map_emit_kernel, dim3(mv_ceil_div(n_words, 4)), dim3(256), 0, s, ws.cand_bits, word_off, n_words,
+                           wpr, p.W, out_cand);
+        return mv_launch_status();
+    }
     const bool big = (size_t)p.H * wpr > 5 * (size_t)FIN_NT;
     const bool full = p.mode == MV_KP_FULL;
     int rc;
