@@ -140,3 +140,36 @@ def test_frame_pipe_config_validation_without_gpu():
         assert lib.mv_frame_pipe_arena_bytes(C.byref(cfg(**bad))) == 0, bad
     assert lib.mv_frame_pipe_arena_bytes(C.byref(cfg(volume_split=2, layout=L.MV_LAYOUT_HWC))) > n   # split planes added
     assert lib.mv_error_string(-4).decode() == "workspace too small"
+
+
+def test_header_is_plain_c_and_layouts_match_ctypes(tmp_path):
+    """gcc -std=c99 -pedantic compiles a C consumer of include/macvo_hip.h, links libmacvo_hip.so and runs host-only entry
+    points; the struct sizes / offsets it prints must equal what the ctypes Structures in mac-vo_amd/_lib.py lay out."""
+    import ctypes as C
+    import shutil
+
+    from macvo_amd import _lib as L
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    L.load()
+    exe = tmp_path / "abi_probe"
+    libdir = os.path.join(ROOT, "mac-vo_amd")
+    rocm = "/opt/rocm/lib"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c_abi", "abi_probe.c"), "-o", str(exe), "-L", libdir, "-lmacvo_hip",
+           f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{rocm}", f"-Wl,-rpath-link,{rocm}"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    kv = {k.strip().split(" ")[-1] if k.startswith("sizeof") else k.strip(): v for k, v in re.findall(r"([A-Za-z_][\w ]*?)=(\S+)", out.stdout)}
+    assert kv["abi"] == str(L.ABI_VERSION)
+    assert int(kv["mvLMParams"]) == C.sizeof(L.mvLMParams)
+    assert int(kv["mvFramePipeConfig"]) == C.sizeof(L.mvFramePipeConfig)
+    assert int(kv["mvFrameInputs"]) == C.sizeof(L.mvFrameInputs)
+    assert int(kv["mvKpSelectParams"]) == C.sizeof(L.mvKpSelectParams)
+    assert int(kv["mvMatchCovParams"]) == C.sizeof(L.mvMatchCovParams)
+    assert int(kv["offsetof lm"]) == L.mvFramePipeConfig.lm.offset and int(kv["fx"]) == L.mvFramePipeConfig.fx.offset
+    assert int(kv["arena"]) > 2 * 4800 * 4800 * 4 * 2 and int(kv["MV_FB_POSE"]) == L.FB["POSE"] and int(kv["MV_BF16X2"]) == L.MV_BF16X2
+    assert "steps=10" in out.stdout and "reject=16" in out.stdout and "err=unsupported" in out.stdout
