@@ -226,6 +226,18 @@ int mv_match_cov(const float* depth_map, const float* kp_uv, float* flow_cov,
                  const float* depth_cov, const double* rot, const mvMatchCovParams* params /* host */,
                  int N, double* out_cov, double* out_cov_rot, float* out_stats, mvStream_t stream);
 
+/* Dense-mapping tail of run_pair (Odometry/MACVO.py:313-337, `mapping: true`): for the map pixels chosen by
+ * MappingPointSelector (mv_kp_select MV_KP_MAPPING + mv_kp_gather, 2000 per frame) gather depth (:317) and its variance
+ * (:320), pixel2point_NED (:318), prev_pose.Act (:334), the constant match sigma (:322-323) and optionally the colour
+ * (imageL*255 -> uint8, :326-328).  The covariance of these points is one mv_match_cov call on out_uv / out_sigma
+ * (:324 — note the reference stores it UNROTATED, in the camera frame).
+ *   uv [N,2] int64; depth, depth_cov [H*W] fp32; image [3,H,W] fp32 in [0,1] or NULL; pose fp32[7] (device)
+ *   out_uv [N,2], out_d [N], out_sdd [N], out_sigma [N,3], out_Tc [N,3], out_Tw [N,3] fp32, out_color [N,3] uint8 (NULL ok) */
+int mv_map_points(const int64_t* uv, int N, const float* depth, const float* depth_cov, const float* image, int H, int W,
+                  float fx, float fy, float cx, float cy, const float* pose, float match_cov_default, float* out_uv,
+                  float* out_d, float* out_sdd, float* out_sigma, float* out_Tc, float* out_Tw, uint8_t* out_color,
+                  mvStream_t stream);
+
 /* Both ObsCovModel.estimate calls of one frame (Odometry/MACVO.py:241-242) in ONE launch: set 0 = kp0 on the previous
  * frame's depth map (+ optional world rotation, :273-281), set 1 = kp1 on the current depth map.  Same arithmetic as
  * two mv_match_cov calls with use_patch_var = 1 (both flow_cov arrays are clamped in place). */

@@ -92,6 +92,8 @@ SIGNATURES = {
     "mv_backproject": (C.c_int, [_P, _P, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_int,
                                  _P, _P, _P, _P]),
     "mv_obs_filter": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P, _P]),
+    "mv_map_points": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _P,
+                                C.c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mv_local_corr81": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv_frame_pipe_arena_bytes": (C.c_size_t, [C.POINTER(mvFramePipeConfig)]),
     "mv_frame_pipe_create": (C.c_int, [C.POINTER(mvFramePipeConfig), _P, C.c_size_t, C.POINTER(_P)]),

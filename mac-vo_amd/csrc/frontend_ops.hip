@@ -140,6 +140,46 @@ __global__ __launch_bounds__(256) void backproject_kernel(const float* __restric
     }
 }
 
+// Dense-mapping tail of run_pair (Odometry/MACVO.py:315-325,334): per selected map pixel gather depth and depth variance,
+// back-project (pixel2point_NED), move to the world with the previous pose, and emit the constant match sigma.
+__global__ __launch_bounds__(256) void map_points_kernel(const int64_t* __restrict__ uv, int N,
+                                                          const float* __restrict__ depth, const float* __restrict__ depth_cov,
+                                                          const float* __restrict__ image, int H, int W, float fx, float fy,
+                                                          float cx, float cy, const float* __restrict__ pose,
+                                                          float match_cov_default, float* __restrict__ out_uv,
+                                                          float* __restrict__ out_d, float* __restrict__ out_sdd,
+                                                          float* __restrict__ out_sigma, float* __restrict__ out_Tc,
+                                                          float* __restrict__ out_Tw, uint8_t* __restrict__ out_color) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int u = (int)uv[2 * n], v = (int)uv[2 * n + 1];
+    const bool ok = u >= 0 && u < W && v >= 0 && v < H;
+    const int i = ok ? v * W + u : 0;
+    const float d = depth[i];
+    const float uf = (float)u, vf = (float)v;
+    out_uv[2 * n] = uf;
+    out_uv[2 * n + 1] = vf;
+    if (out_d) out_d[n] = d;
+    if (out_sdd) out_sdd[n] = depth_cov ? depth_cov[i] : -1.f;
+    if (out_sigma) { out_sigma[3 * n] = match_cov_default; out_sigma[3 * n + 1] = match_cov_default; out_sigma[3 * n + 2] = 0.f; }
+    const float pc[3] = {d, ((uf - cx) * d) / fx, ((vf - cy) * d) / fy};
+    if (out_Tc) { out_Tc[3 * n] = pc[0]; out_Tc[3 * n + 1] = pc[1]; out_Tc[3 * n + 2] = pc[2]; }
+    if (out_Tw) {
+        const float q[4] = {pose[3], pose[4], pose[5], pose[6]};
+        float r[3];
+        quat_act_f32(q, pc, r);
+        out_Tw[3 * n] = r[0] + pose[0]; out_Tw[3 * n + 1] = r[1] + pose[1]; out_Tw[3 * n + 2] = r[2] + pose[2];
+    }
+    if (out_color && image) {   // (imageL * 255).to(uint8): truncation toward zero of a [0,1] float (MACVO.py:327-328)
+        const size_t plane = (size_t)H * W;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float x = image[c * plane + i] * 255.f;
+            out_color[3 * n + c] = (uint8_t)(int)x;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void obs_filter_kernel(const uint8_t* __restrict__ inbound,
                                                          const double* __restrict__ cov1,
                                                          const double* __restrict__ cov2,
@@ -229,5 +269,19 @@ extern "C" int mv_obs_filter(const uint8_t* inbound, const double* cov1, const d
     }
     hipLaunchKernelGGL(obs_filter_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, inbound, cov1, cov2, vals,
                        flags, min_depth, max_depth, N, valid, count);
+    return mv_launch_status();
+}
+
+extern "C" int mv_map_points(const int64_t* uv, int N, const float* depth, const float* depth_cov, const float* image, int H,
+                             int W, float fx, float fy, float cx, float cy, const float* pose, float match_cov_default,
+                             float* out_uv, float* out_d, float* out_sdd, float* out_sigma, float* out_Tc, float* out_Tw,
+                             uint8_t* out_color, mvStream_t stream) {
+    MV_CHECK_ARG(N >= 0 && H > 0 && W > 0);
+    if (N == 0) return MV_OK;
+    MV_CHECK_ARG(uv && depth && out_uv);
+    MV_CHECK_ARG(!out_Tw || pose);
+    hipLaunchKernelGGL(map_points_kernel, dim3(mv_ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, uv, N, depth, depth_cov,
+                       image, H, W, fx, fy, cx, cy, pose, match_cov_default, out_uv, out_d, out_sdd, out_sigma, out_Tc, out_Tw,
+                       out_color);
     return mv_launch_status();
 }

@@ -445,6 +445,41 @@ def backproject(kp_uv: torch.Tensor, depth_vals: torch.Tensor, K4: tuple, pose: 
     return pos_Tc, pos_Tw, rot
 
 
+@dataclass
+class MapPoints:
+    """Dense map points of one frame (MACVO.py:313-337): camera-frame covariance is UNROTATED, as the reference stores it."""
+    uv: torch.Tensor            # [N,2] float32 (integer-valued pixel coordinates)
+    depth: torch.Tensor         # [N]
+    sigma_dd: torch.Tensor      # [N]  depth variance at the pixel
+    pos_Tc: torch.Tensor        # [N,3]
+    pos_Tw: torch.Tensor        # [N,3]
+    cov_Tc: torch.Tensor        # [N,3,3] float64
+    color: torch.Tensor | None  # [N,3] uint8
+
+
+def map_points(uv: torch.Tensor, depth: torch.Tensor, depth_cov: torch.Tensor, K4: tuple, pose: torch.Tensor,
+               image: torch.Tensor | None = None, match_cov_default: float = 0.25, kernel_size: int = 31,
+               min_flow_cov: float = 0.25, min_depth_cov: float = 0.05) -> MapPoints:
+    """Everything ``run_pair`` does for the dense map after the selector (MACVO.py:317-334) in two launches."""
+    lib = L.load()
+    uv = _req(uv, torch.int64, "uv")
+    depth = _req(depth, torch.float32, "depth")
+    depth_cov = _req(depth_cov, torch.float32, "depth_cov")
+    H, W = depth.shape[-2:]
+    N, dev = uv.shape[0], depth.device
+    img = None if image is None else _req(image.reshape(3, H, W), torch.float32, "image")
+    f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)  # noqa: E731
+    uvf, d, sdd, sig, Tc, Tw = f(N, 2), f(N), f(N), f(N, 3), f(N, 3), f(N, 3)
+    col = torch.empty((N, 3), dtype=torch.uint8, device=dev) if img is not None else None
+    pose_c = _req(pose.reshape(-1), torch.float32, "pose")
+    L.check(lib.mv_map_points(uv.data_ptr(), N, depth.data_ptr(), depth_cov.data_ptr(), _ptr(img), H, W,
+                              *[float(k) for k in K4], pose_c.data_ptr(), float(match_cov_default), uvf.data_ptr(),
+                              d.data_ptr(), sdd.data_ptr(), sig.data_ptr(), Tc.data_ptr(), Tw.data_ptr(), _ptr(col), _stream()),
+            "mv_map_points")
+    cov = match_cov(depth, uvf, sig, sdd, *K4, kernel_size=kernel_size, min_flow_cov=min_flow_cov, min_depth_cov=min_depth_cov)
+    return MapPoints(uvf, d, sdd, Tc, Tw, cov, col)
+
+
 FILTER_COV_SANITY, FILTER_SIMPLE_DEPTH, FILTER_FRONT_OF_CAM = 1, 2, 4
 
 

@@ -65,6 +65,11 @@ class HotPathConfig:
     radius: int = 4
     feature_layout: str = "chw"
     use_graphs: bool = False             # hipGraph-replay the decoder-side segment for inputs marked `static`
+    mapping: bool = False                # dense-mapping tail of run_pair (MACVO.py:313-337; `mapping: true` in MACVO_Fast)
+    map_num_point: int = 2000            # :315
+    map_max_depth: float = 5.0           # MappingPointSelector args (Config/Experiment/MACVO/MACVO_Fast.yaml)
+    map_max_depth_cov: float = 0.005
+    map_mask_width: int = 32
     volume_precision: str = "exact"      # "exact" fp32 MFMA | "split3" bf16x3, fp32-class | "split2" 3 products, finer
                                          # than TF32 (the reference's own fast-frontend class); splits need layout "hwc"
 
@@ -92,6 +97,8 @@ class FrameInputs:
     # event recorded by whoever produced fmap1/fmap2 (None = already complete, e.g. resident inputs): the volume GEMM
     # runs on its own stream and must not start before its operands exist
     ready: "torch.cuda.Event | None" = None
+    # previous LEFT image [1|-,3,H,W] in [0,1] for the map-point colours (MACVO.py:326-328); optional, mapping mode only
+    image: torch.Tensor | None = None
     # promise that every tensor above lives at a fixed address for the lifetime of the HotPath (e.g. the static output
     # buffers of a graph-captured network, as in the reference's CUDAGraph frontend): allows hipGraph replay
     static: bool = False
@@ -105,6 +112,7 @@ class FrameResult:
     kp0_uv: torch.Tensor | None        # [n,2] int64 GPU selected keypoints
     n_valid: torch.Tensor | None       # [1] int32 GPU surviving observations
     extras: dict = field(default_factory=dict)
+    map_points: "ops.MapPoints | None" = None   # mapping mode: the frame's dense map points (valid after sync_pose())
 
 
 class HotPath:
@@ -123,6 +131,8 @@ class HotPath:
         self._frame_no = 0
         self._pgo_done = None
         self._pgo_keep = None
+        self._map_done = None
+        self._prev_image = None
         self.pose = torch.tensor([0, 0, 0, 0, 0, 0, 1], dtype=torch.float32, device=self.dev)
         c = self.cfg
         self._max_depth = cam.fx * cam.baseline if c.max_depth == "auto" else float(c.max_depth)
@@ -225,6 +235,7 @@ class HotPath:
     def initialize(self, x: FrameInputs, init_pose: torch.Tensor | None = None) -> None:
         """Frame 0: ``MACVO.initialize`` (:158-171) — depth only, pose = prior."""
         self.maps_prev_for_next = self.frontend(x)[0]
+        self._prev_image = x.image
         if init_pose is not None:
             self.pose = init_pose.to(self.dev, torch.float32).reshape(7).clone()
 
@@ -243,10 +254,19 @@ class HotPath:
                                   max_depth_cov=c.max_depth_cov, max_match_cov=c.max_match_cov)
             host_count = torch.empty((4,), dtype=torch.int32, pin_memory=True)
             host_count.copy_(cands.count, non_blocking=True)
+        cands_m = host_count_m = None
+        if c.mapping:   # MappingPointSelector works on the PREVIOUS frame's depth maps (KeypointSelector.py:87-97): count travels with the other one
+            cands_m = ops.kp_select("mapping", cam.H, cam.W, depth0=maps0.depth, depth0_cov=maps0.depth_cov,
+                                    mask_width=c.map_mask_width, max_depth=c.map_max_depth, max_depth_cov=c.map_max_depth_cov)
+            host_count_m = torch.empty((4,), dtype=torch.int32, pin_memory=True)
+            host_count_m.copy_(cands_m.count, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.maps_prev_for_next = maps1
-        return _Pending(maps0, maps1, cands, host_count, ev)
+        pend = _Pending(maps0, maps1, cands, host_count, ev)
+        pend.cands_m, pend.host_count_m, pend.image0 = cands_m, host_count_m, self._prev_image
+        self._prev_image = x.image
+        return pend
 
     def finish(self, pend: "_Pending", pose_sink: torch.Tensor | None = None) -> FrameResult:
         """Host randperm (bit-exact indices) + the pose-dependent half: tracking, back-projection, covariances, filter,
@@ -291,10 +311,24 @@ class HotPath:
                 pose_sink.copy_(new_pose.reshape(7), non_blocking=True)
             done = torch.cuda.Event()
             done.record(side)
+        map_pts = None
+        if c.mapping:
+            # the reference maps only when tracking succeeded (:303-307) and then draws its second randperm of the frame
+            ready.synchronize()
+            if int(n_valid.item()) >= c.min_num_point:
+                pend.cands_m._n = int(pend.host_count_m[0])
+                with torch.cuda.stream(back):
+                    muv = pend.cands_m.finish(c.map_num_point)
+                    map_pts = ops.map_points(muv, maps0.depth, maps0.depth_cov, cam.K4, batch.init_pose, image=pend.image0,
+                                             match_cov_default=c.match_cov_default, kernel_size=c.cov_kernel_size,
+                                             min_flow_cov=c.min_flow_cov, min_depth_cov=c.min_depth_cov)
+                    self._map_done = torch.cuda.Event()
+                    self._map_done.record(back)
         self._pgo_done = done
         self._pgo_keep = (self._pgo_keep[1] if self._pgo_keep else None, (batch, tr, cov0, cov1, maps0, maps1, kp0, pos0_Tc, cands, pend))  # keep 2 frames of cross-stream tensors alive
         self.pose = new_pose.reshape(7)
         res = FrameResult(self.pose, pose64, info, kp0, n_valid)
+        res.map_points = map_pts
         if self.keep_extras:
             res.extras = dict(tracked=tr, cov0=cov0, cov0_w=cov0_w, cov1=cov1, valid=valid, pos_Tw=pos_Tw,
                               maps1=maps1, cands=cands)
@@ -311,6 +345,8 @@ class HotPath:
         """Make the current stream wait for the in-flight solve (needed before reading ``self.pose`` there)."""
         if self._pgo_done is not None:
             torch.cuda.current_stream().wait_event(self._pgo_done)
+        if getattr(self, "_map_done", None) is not None:
+            torch.cuda.current_stream().wait_event(self._map_done)
 
     def run(self, frames, pose_sink: torch.Tensor | None = None):
         """Software-pipelined stream: frame t+1's frontend is enqueued before frame t's host-side randperm, so the GPU
@@ -339,6 +375,9 @@ class _Pending:
     cands: "ops.KeypointCandidates"
     host_count: torch.Tensor
     event: "torch.cuda.Event"
+    cands_m: "ops.KeypointCandidates | None" = None     # mapping mode
+    host_count_m: torch.Tensor | None = None
+    image0: torch.Tensor | None = None
 
 
 # ====================================================================================== native driver (default)

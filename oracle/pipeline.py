@@ -24,12 +24,14 @@ class OracleHotPath:
         self.cam = cam
         d = dict(num_point=200, edgewidth=32, match_cov_default=0.25, selector="nodepth", kp_kernel_size=7,
                  kp_mask_width=32, max_match_cov=100.0, max_depth_cov=250.0, max_depth="auto", cov_kernel_size=31,
-                 min_flow_cov=0.25, min_depth_cov=0.05, graph_type="disp", min_num_point=10, radius=4)
+                 min_flow_cov=0.25, min_depth_cov=0.05, graph_type="disp", min_num_point=10, radius=4,
+                 mapping=False, map_num_point=2000, map_max_depth=5.0, map_max_depth_cov=0.005, map_mask_width=32)
         d.update(cfg or {})
         self.cfg = d
         self.maps_prev = None
         self.pose = torch.tensor([0, 0, 0, 0, 0, 0, 1], dtype=torch.float32)
         self.last_tokens = None
+        self._prev_image = None
         self.timing: dict = {}
 
     def frontend(self, x: dict) -> dict:
@@ -49,6 +51,7 @@ class OracleHotPath:
 
     def initialize(self, x: dict, init_pose=None):
         self.maps_prev = self.frontend(x)
+        self._prev_image = x.get("image")
         if init_pose is not None:
             self.pose = init_pose.float().reshape(7).clone()
 
@@ -83,6 +86,7 @@ class OracleHotPath:
         cov_Tw = covariance.rotate_covariance(R, cov0)
         n = int(mask.sum())
         out = dict(kp0_uv=kp0_all, n_valid=n)
+        prev_pose = self.pose.clone()
         if n >= c["min_num_point"]:
             prob = pgo.PGOProblem(init_pose=self.pose.clone(), K=Km, baseline=cam["baseline"], pos_Tw=pos_Tw[mask],
                                   cov_Tw=cov_Tw[mask], pixel2_uv=kp1[mask], pixel2_d=tr["kp1_d"][mask].unsqueeze(-1),
@@ -91,7 +95,21 @@ class OracleHotPath:
             res = pgo.solve(prob, c["graph_type"])
             self.pose = res.pose.float()                                               # write_graph_data
             out.update(pose_f64=res.pose, steps=res.steps, loss=res.loss)
+            if c["mapping"]:                                                           # MACVO.py:313-337 (skipped when lost, :303-307)
+                muv, _, _ = selector.mapping_point_selector(maps0["depth"], maps0["cov"], c["map_num_point"], c["map_max_depth"],
+                                                            c["map_max_depth_cov"], c["map_mask_width"])
+                md = frontend.retrieve_pixels(muv, maps0["depth"]).squeeze(0)
+                m_Tc = frontend.pixel2point_NED(muv, md, Km)
+                m_sdd = frontend.retrieve_pixels(muv, maps0["cov"]).squeeze(0)
+                m_suv = torch.ones((muv.shape[0], 3)) * c["match_cov_default"]
+                m_suv[..., 2] = 0.
+                m_cov = covariance.match_covariance(muv, maps0["depth"], m_sdd, m_suv, *K4, **mc)   # stored unrotated (:324,334)
+                out["map"] = dict(uv=muv, depth=md, sigma_dd=m_sdd, pos_Tc=m_Tc, pos_Tw=se3.se3_act(prev_pose, m_Tc), cov_Tc=m_cov)
+                if self._prev_image is not None:                                   # frame0.stereo.imageL (:327)
+                    img = self._prev_image.reshape(1, 3, H, W)
+                    out["map"]["color"] = (img[..., muv[..., 1], muv[..., 0]].squeeze(0).T * 255).to(torch.uint8)
         out["pose"] = self.pose
         out.update(cov0=cov0, cov1=cov1, cov_Tw=cov_Tw, pos_Tw=pos_Tw, mask=mask, tracked=tr)
         self.maps_prev = maps1
+        self._prev_image = x.get("image")
         return out

@@ -140,3 +140,42 @@ def test_graph_replay_equals_eager(gpu):
             assert len(hot._graphs) == n_pool
     assert torch.equal(outs[0][0], outs[1][0])
     assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+
+
+def test_dense_mapping_tail_matches_oracle(gpu):
+    """`mapping: true` (MACVO_Fast.yaml): MappingPointSelector(2000) on the previous frame's depth + the covariance model on
+    those points + world positions (MACVO.py:313-337).  Selected map pixels must be the oracle's bit for bit (second
+    randperm of the frame on the shared CPU generator), values to fp32 rounding; keypoints / poses unchanged."""
+    from macvo_amd.pipeline import Camera, FrameInputs, HotPath, HotPathConfig
+    from oracle.pipeline import OracleHotPath
+
+    H, W, n_frames = 240, 320, 4
+    cam, frames, _ = synth.make_sequence(n_frames, H, W, C=64, iters=1, seed=23)
+    g = torch.Generator().manual_seed(1)
+    for fr in frames:
+        fr["image"] = torch.rand(1, 3, H, W, generator=g)
+    # the synthetic plane sits at ~12 m with sigma_z^2 ~ 1e-2: widen the selector's gates so that it has candidates
+    mcfg = dict(mapping=True, map_max_depth=13.0, map_max_depth_cov=0.5, map_num_point=500)
+    ora = OracleHotPath(cam, mcfg)
+    hot = HotPath(Camera(**cam), HotPathConfig(**mcfg), gpu)
+    ins = [FrameInputs(**{k: v.to(gpu) for k, v in fr.items()}) for fr in frames]
+    torch.cuda.synchronize()
+    ora.initialize(frames[0])
+    hot.initialize(ins[0])
+    for t in range(1, n_frames):
+        torch.manual_seed(70 + t)
+        ro = ora.step(frames[t])
+        torch.manual_seed(70 + t)
+        rh = hot.step(ins[t])
+        torch.cuda.synchronize()
+        assert torch.equal(rh.kp0_uv.cpu(), ro["kp0_uv"])
+        m, mo = rh.map_points, ro["map"]
+        assert m is not None and m.uv.shape[0] == 500
+        assert torch.equal(m.uv.cpu().long(), mo["uv"]), t                       # identical map pixels
+        assert torch.equal(m.depth.cpu(), mo["depth"])
+        torch.testing.assert_close(m.sigma_dd.cpu(), mo["sigma_dd"], rtol=1e-5, atol=0)   # exp(2*cov): expf ulp on the device
+        torch.testing.assert_close(m.pos_Tc.cpu(), mo["pos_Tc"], rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(m.pos_Tw.cpu(), mo["pos_Tw"], rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(m.cov_Tc.cpu(), mo["cov_Tc"], rtol=2e-3, atol=1e-7)
+        assert torch.equal(m.color.cpu(), mo["color"])
+        hot.pose = ro["pose"].to(gpu)
