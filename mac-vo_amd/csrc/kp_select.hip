@@ -10,15 +10,22 @@
 //
 // gfx950 design (4-9 MB of HBM traffic per frame; in practice launch/latency-bound, so: few launches, no
 // sparse gathers on the single-workgroup stage, one atomic per workgroup)
-//   kernel 1 (grid of 64x16 tiles, 256 threads): quality tile + halo in LDS, SEPARABLE NaN-propagating min
-//            (k + k LDS reads per pixel instead of k*k), equality test, one 64-bit __ballot word per 64-pixel row
-//            segment for the threshold-independent part of the mask.  Every NMS pixel also emits a 12-byte record
-//            {linear index | candidate flag, flow quality, depth0 variance}; a workgroup reserves its record range
-//            with ONE global atomic (LDS-aggregated), so there is no hot counter.
-//   kernel 2 (one 1024-thread workgroup, all accesses coalesced): lower (nan)median(s) of the record values by a
-//            3-pass 11/11/10-bit radix select with LDS histograms and a parallel bin search; thresholds; records
-//            failing a threshold clear their bit (atomicAnd); ordered stream compaction of the bit words
-//            (popcount -> workgroup scan -> in-order writes).
+//   kernel 1 (grid of 64x16 tiles, 256 threads): quality tile + halo in LDS (all global loads of a thread in flight
+//            before the first LDS store), SEPARABLE NaN-propagating min (k + k LDS reads per pixel instead of k*k),
+//            equality test, one 64-bit __ballot word per 64-pixel row segment for the threshold-independent part of
+//            the mask.  Every NMS pixel also emits a 12-byte record {bit address | candidate flag, flow quality,
+//            depth0 variance}; a workgroup reserves its record range with ONE global atomic (LDS-aggregated).  That
+//            atomic is the kernel's longest dependency (measured: ~6 of its 13 us are 300 workgroups waiting for the
+//            return value of a same-address device-scope atomic); removing it needs per-workgroup record regions and a
+//            re-indexing pass in kernel 2 that costs about half of what it saves — left as is.
+//   kernel 2 (one 1024-thread workgroup; 256 / 512 threads measured 3x / 1.4x slower): every global read is issued
+//            up front (records -> registers, candidate words -> registers -> dynamic LDS); lower (nan)median(s) by
+//            BUCKET REFINEMENT on order-preserving keys (min/max -> 2048 linear buckets over the population's own range
+//            -> direct ranking once the bucket holds <= 256 keys: one histogram pass in the common case, no hot bin);
+//            records failing a threshold clear their bit with an LDS atomicAnd; ordered stream compaction of the bit
+//            words (popcount -> workgroup scan -> in-order writes); the record counter is left zeroed for the next
+//            call.  23.5 us (3-pass radix select re-reading global memory) -> 11.7 us.
+//   MAPPING mode (no medians, ~10^5 candidates): kernel 1, a one-workgroup popcount scan, and a wave-per-word emit.
 // No host synchronisation inside; the caller reads back out_count when it needs n for randperm.
 #include "common.h"
 #include <math.h>
