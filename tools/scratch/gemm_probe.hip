@@ -198,12 +198,125 @@ __global__ __launch_bounds__(256) void probe_gemm_glds(const float* __restrict__
 }
 }  // namespace
 
+namespace {
+// 160 x 128 tile (4800 = 30 x 160: 2280 tiles = 8.9 per CU -> 9, 99 % balanced, vs 11.28 -> 12, 94 %, for 128 x 128):
+// 4 waves side by side along N, each 160 x 32 = 5 MFMA blocks; 2-deep register prefetch as the shipped kernel
+constexpr int BM2 = 160;
+template <int MODE>
+__global__ __launch_bounds__(256, 3) void probe_gemm_160(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                      float* __restrict__ out, int C, int N1, int N2, int tiles_m, int tiles_n) {
+    constexpr int BK = 16;
+    __shared__ __attribute__((aligned(16))) float sA[2][BK][BM2];
+    __shared__ __attribute__((aligned(16))) float sB[2][BK][BN];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, kh = lane >> 5, li = lane & 31;
+    const int nk = C / BK;
+    int tm, tn;
+    const int b = blockIdx.z;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * BM2, n0 = tn * BN;
+    // loader: A tile = 16 rows x 40 float4 (640), B tile = 16 rows x 32 float4 (512)
+    const int arow[3] = {t / 40, (t + 256) / 40, (t + 512) / 40};
+    const int acol[3] = {(t % 40) * 4, ((t + 256) % 40) * 4, ((t + 512) % 40) * 4};
+    const bool a3 = t + 512 < 640;
+    const int brow = t >> 5, bcol = (t & 31) * 4;
+    const float* Ab = f1 + (size_t)b * C * N1;
+    const float* Bb = f2 + (size_t)b * C * N2 + min(n0 + bcol, N2 - 4);
+    const float* pa[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) pa[j] = Ab + (size_t)(j == 2 && !a3 ? 0 : arow[j]) * N1 + min(m0 + acol[j], N1 - 4);
+    const int klast = C - BK;
+    f32x4 ra[2][3], rb[2][2];
+    auto gload = [&](auto SET, int k0) {
+        constexpr int S = decltype(SET)::value;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ra[S][j] = *reinterpret_cast<const f32x4*>(pa[j] + (size_t)k0 * N1);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) rb[S][p] = *reinterpret_cast<const f32x4*>(Bb + (size_t)(k0 + brow + 8 * p) * N2);
+    };
+    auto sstore = [&](auto SET, int buf) {
+        constexpr int S = decltype(SET)::value;
+        *reinterpret_cast<f32x4*>(&sA[buf][arow[0]][acol[0]]) = ra[S][0];
+        *reinterpret_cast<f32x4*>(&sA[buf][arow[1]][acol[1]]) = ra[S][1];
+        if (a3) *reinterpret_cast<f32x4*>(&sA[buf][arow[2]][acol[2]]) = ra[S][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) *reinterpret_cast<f32x4*>(&sB[buf][brow + 8 * p][bcol]) = rb[S][p];
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    f32x16 acc[5];
+    for (int i = 0; i < 5; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    auto mma = [&](int buf) {
+        float a[2][5], bb[2];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) a[0][i] = sA[buf][kh][i * 32 + li];
+        bb[0] = sB[buf][kh][wave * 32 + li];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+            if (kk + 2 < BK) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) a[nxt][i] = sA[buf][kk + 2 + kh][i * 32 + li];
+                bb[nxt] = sB[buf][kk + 2 + kh][wave * 32 + li];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], bb[cur], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    gload(S0{}, 0);
+    gload(S1{}, BK);
+    sstore(S0{}, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        gload(S0{}, min((kt + 2) * BK, klast));
+        mma(0);
+        sstore(S1{}, 1);
+        __syncthreads();
+        gload(S1{}, min((kt + 3) * BK, klast));
+        mma(1);
+        sstore(S0{}, 0);
+        __syncthreads();
+    }
+    if (MODE & 1) {
+        float s = 0.f;
+        for (int i = 0; i < 5; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+        if (s == 123.456f) out[0] = s;
+    } else {
+        float* O = out + (size_t)b * N1 * N2;
+        const int col = n0 + wave * 32 + li;
+        if (m0 + BM2 <= N1 && n0 + BN <= N2) {   // interior tile: no per-element guards
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_nontemporal_store(acc[i][r], O + (size_t)(m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * N2 + col);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (row < N1 && col < N2) __builtin_nontemporal_store(acc[i][r], &O[(size_t)row * N2 + col]);
+                }
+        }
+    }
+}
+}  // namespace
+
 extern "C" int gemm_probe_set_rg(int rg) { return hipMemcpyToSymbol(HIP_SYMBOL(g_rg), &rg, sizeof(int)) == hipSuccess ? 0 : 1; }
 extern "C" int gemm_probe_launch(const float* f1, const float* f2, float* out, int B, int C, int N, int mode, void* stream) {
     const int tm = (N + BM - 1) / BM;
     dim3 grid(tm * tm, 1, B), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define L(M) case M: hipLaunchKernelGGL(probe_gemm<M>, grid, block, 0, s, f1, f2, out, C, N, N, tm, tm); break
+    if (mode == 30 || mode == 31) {
+        const int tm2 = (N + BM2 - 1) / BM2;
+        dim3 g2(tm2 * tm, 1, B);
+        if (mode == 30) hipLaunchKernelGGL(probe_gemm_160<0>, g2, block, 0, s, f1, f2, out, C, N, N, tm2, tm);
+        else hipLaunchKernelGGL(probe_gemm_160<1>, g2, block, 0, s, f1, f2, out, C, N, N, tm2, tm);
+        return hipGetLastError() == hipSuccess ? 0 : 1;
+    }
     if (mode == 20) { hipLaunchKernelGGL((probe_gemm_glds<3, false>), grid, block, 0, s, f1, f2, out, C, N, N, tm, tm); return hipGetLastError() == hipSuccess ? 0 : 1; }
     if (mode == 21) { hipLaunchKernelGGL((probe_gemm_glds<3, true>), grid, block, 0, s, f1, f2, out, C, N, N, tm, tm); return hipGetLastError() == hipSuccess ? 0 : 1; }
     if (mode == 22) { hipLaunchKernelGGL((probe_gemm_glds<4, false>), grid, block, 0, s, f1, f2, out, C, N, N, tm, tm); return hipGetLastError() == hipSuccess ? 0 : 1; }
