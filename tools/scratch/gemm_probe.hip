@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void probe_gemm(const float* __restrict__ f1, 
 namespace {
 // 2-deep global prefetch, register staged: loads of tile kt+2 are issued while tile kt is multiplied; the wait before the
 // LDS store of tile kt+1 is vmcnt(4) (the 4 younger loads stay in flight) instead of vmcnt(0)
+__constant__ int g_stagger = 4;
 template <int MODE>
 __global__ __launch_bounds__(256) void probe_gemm_pf2(const float* __restrict__ f1, const float* __restrict__ f2,
                                                       float* __restrict__ out, int C, int N1, int N2, int tiles_m, int tiles_n) {
@@ -111,6 +112,13 @@ __global__ __launch_bounds__(256) void probe_gemm_pf2(const float* __restrict__ 
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
+    if (MODE & 2) {   // experiment: phase-shift the first wave of workgroups so that tile completions (store bursts) spread out
+        const int lin = blockIdx.z * gridDim.x + blockIdx.x;
+        if (lin < 1024) {
+            const int q = lin >> 8;                      // 0..3: presumably the slot index on its CU
+            for (int i = 0; i < q * g_stagger; ++i) __builtin_amdgcn_s_sleep(127);   // 127 * 64 clk = 3.4 us each
+        }
+    }
     f32x16 acc[2][2];
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     // nk is even (C % 32 == 0).  Loads are issued UNCONDITIONALLY (the last two re-read the final tile): with no branch
@@ -304,6 +312,7 @@ __global__ __launch_bounds__(256, 3) void probe_gemm_160(const float* __restrict
 }
 }  // namespace
 
+extern "C" int gemm_probe_set_stagger(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_stagger), &v, sizeof(int)) == hipSuccess ? 0 : 1; }
 extern "C" int gemm_probe_set_rg(int rg) { return hipMemcpyToSymbol(HIP_SYMBOL(g_rg), &rg, sizeof(int)) == hipSuccess ? 0 : 1; }
 extern "C" int gemm_probe_launch(const float* f1, const float* f2, float* out, int B, int C, int N, int mode, void* stream) {
     const int tm = (N + BM - 1) / BM;
@@ -320,6 +329,7 @@ extern "C" int gemm_probe_launch(const float* f1, const float* f2, float* out, i
     if (mode == 20) { hipLaunchKernelGGL((probe_gemm_glds<3, false>), grid, block, 0, s, f1, f2, out, C, N, N, tm, tm); return hipGetLastError() == hipSuccess ? 0 : 1; }
     if (mode == 21) { hipLaunchKernelGGL((probe_gemm_glds<3, true>), grid, block, 0, s, f1, f2, out, C, N, N, tm, tm); return hipGetLastError() == hipSuccess ? 0 : 1; }
     if (mode == 22) { hipLaunchKernelGGL((probe_gemm_glds<4, false>), grid, block, 0, s, f1, f2, out, C, N, N, tm, tm); return hipGetLastError() == hipSuccess ? 0 : 1; }
+    if (mode == 18) { hipLaunchKernelGGL(probe_gemm_pf2<2>, grid, block, 0, s, f1, f2, out, C, N, N, tm, tm); return hipGetLastError() == hipSuccess ? 0 : 1; }
     if (mode == 16) { hipLaunchKernelGGL(probe_gemm_pf2<0>, grid, block, 0, s, f1, f2, out, C, N, N, tm, tm); return hipGetLastError() == hipSuccess ? 0 : 1; }
     if (mode == 17) { hipLaunchKernelGGL(probe_gemm_pf2<1>, grid, block, 0, s, f1, f2, out, C, N, N, tm, tm); return hipGetLastError() == hipSuccess ? 0 : 1; }
     switch (mode) { L(0); L(1); L(2); L(3); L(4); L(5); L(6); L(7); L(8); L(9); L(15); L(14); L(12); L(10); L(11); L(13); default: return 2; }
