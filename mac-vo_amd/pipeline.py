@@ -426,6 +426,11 @@ class NativeHotPath:
     def __init__(self, cam: Camera, cfg: HotPathConfig | None = None, device: str | torch.device = "cuda",
                  keep_extras: bool = False):
         self.cam, self.cfg = cam, cfg or HotPathConfig()
+        if self.cfg.mapping:
+            raise ops.L.MacvoHipError("the dense-mapping tail (mapping=True) is sequenced by pipeline.HotPath only: its cost is "
+                                      "the host-side torch.randperm(n ~ 1e5), which the native driver cannot hide")
+        if self.cfg.use_graphs:
+            raise ops.L.MacvoHipError("use_graphs belongs to the Python-sequenced pipeline.HotPath")
         self.dev = torch.device(device)
         self.keep_extras = keep_extras
         self.lm = ops.lm_default_params()
