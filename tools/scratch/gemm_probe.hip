@@ -144,6 +144,13 @@ __global__ __launch_bounds__(256) void probe_gemm_pf2(const float* __restrict__ 
         float s = 0.f;
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
         if (s == 123.456f) out[0] = s;
+    } else if (MODE & 4) {
+        // same store instructions, but every workgroup writes into its XCD-local 64 KB slot of a 2 MB window: stays in L2
+        float* O = out + (size_t)(blockIdx.x & 31) * 16384;
+        store_tile<false>(O, acc, wm * 64, wn * 64, kh, li, 128, 128, true);
+    } else if (MODE & 8) {
+        const bool interior = (m0 + BM <= N1) && (n0 + BN <= N2);
+        store_tile<false>(out + (size_t)b * N1 * N2, acc, m0 + wm * 64, n0 + wn * 64, kh, li, N1, N2, interior);
     } else {
         const bool interior = (m0 + BM <= N1) && (n0 + BN <= N2);
         store_tile(out + (size_t)b * N1 * N2, acc, m0 + wm * 64, n0 + wn * 64, kh, li, N1, N2, interior);
@@ -329,6 +336,8 @@ extern "C" int gemm_probe_launch(const float* f1, const float* f2, float* out, i
     if (mode == 20) { hipLaunchKernelGGL((probe_gemm_glds<3, false>), grid, block, 0, s, f1, f2, out, C, N, N, tm, tm); return hipGetLastError() == hipSuccess ? 0 : 1; }
     if (mode == 21) { hipLaunchKernelGGL((probe_gemm_glds<3, true>), grid, block, 0, s, f1, f2, out, C, N, N, tm, tm); return hipGetLastError() == hipSuccess ? 0 : 1; }
     if (mode == 22) { hipLaunchKernelGGL((probe_gemm_glds<4, false>), grid, block, 0, s, f1, f2, out, C, N, N, tm, tm); return hipGetLastError() == hipSuccess ? 0 : 1; }
+    if (mode == 40) { hipLaunchKernelGGL(probe_gemm_pf2<4>, grid, block, 0, s, f1, f2, out, C, N, N, tm, tm); return hipGetLastError() == hipSuccess ? 0 : 1; }
+    if (mode == 41) { hipLaunchKernelGGL(probe_gemm_pf2<8>, grid, block, 0, s, f1, f2, out, C, N, N, tm, tm); return hipGetLastError() == hipSuccess ? 0 : 1; }
     if (mode == 18) { hipLaunchKernelGGL(probe_gemm_pf2<2>, grid, block, 0, s, f1, f2, out, C, N, N, tm, tm); return hipGetLastError() == hipSuccess ? 0 : 1; }
     if (mode == 16) { hipLaunchKernelGGL(probe_gemm_pf2<0>, grid, block, 0, s, f1, f2, out, C, N, N, tm, tm); return hipGetLastError() == hipSuccess ? 0 : 1; }
     if (mode == 17) { hipLaunchKernelGGL(probe_gemm_pf2<1>, grid, block, 0, s, f1, f2, out, C, N, N, tm, tm); return hipGetLastError() == hipSuccess ? 0 : 1; }
