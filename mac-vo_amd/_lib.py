@@ -128,7 +128,7 @@ def load(path: str | None = None) -> C.CDLL:
         # loaded is the one the dynamic linker binds (one runtime per process -> shared streams/allocations).
         import torch  # noqa: F401
 
-        p = path or LIB_PATH
+        p = path or os.environ.get("MACVO_HIP_LIB") or LIB_PATH   # MACVO_HIP_LIB: A/B a differently built library
         if not os.path.exists(p):
             raise MacvoHipError(
                 f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(64 * (QPB / QPW)) void corr_lookup_kernel(const flo
     float* blk = smem + (threadIdx.x >> 6) * BLK_STRIDE;
     float (*outs)[QPB + 1] = reinterpret_cast<float (*)[QPB + 1]>(smem);
 
+    MV_SMALL_KERNEL_PRIO();
     const int b = blockIdx.y;
     const int q0 = blockIdx.x * QPB;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
