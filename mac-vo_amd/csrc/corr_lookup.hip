@@ -186,8 +186,13 @@ extern "C" int mv_corr_lookup(const float* vol, const float* coords, float* out,
     // workgroups, 5.96 us vs 7.15 us for 32-query ones); large batches (B = 32: 58.5 us, ~2.4 TB/s) are throughput-bound ->
     // 4 queries per wave amortise the per-wave setup, 32-query (128-B) output segments
     const bool small = (size_t)B * N1 <= (size_t)lookup_small_threshold();
+    static int small_qpb = -1;   // MV_LOOKUP_QPB=8: 256-thread workgroups of 8 queries (A/B knob for the co-running case)
+    if (small_qpb < 0) { const char* e = getenv("MV_LOOKUP_QPB"); small_qpb = (e && atoi(e) == 8) ? 8 : 16; }
 #define MV_LOOKUP(R)                                                                                                  \
-    if (small)                                                                                                        \
+    if (small && small_qpb == 8)                                                                                      \
+        hipLaunchKernelGGL((corr_lookup_kernel<R, 2, 8>), dim3(mv_ceil_div(N1, 8), B), dim3(256), 0, s, vol, coords,  \
+                           out, N1, H2, W2);                                                                          \
+    else if (small)                                                                                                   \
         hipLaunchKernelGGL((corr_lookup_kernel<R, 2, 16>), dim3(mv_ceil_div(N1, 16), B), dim3(512), 0, s, vol, coords, \
                            out, N1, H2, W2);                                                                          \
     else                                                                                                              \
