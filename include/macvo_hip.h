@@ -385,6 +385,8 @@ int mv_frame_pipe_sync(mvFramePipe* p, mvStream_t stream, int block_host);
  * stream they run on (0 = off; restarts the count), and read the elapsed milliseconds back (blocks on that stream) */
 int mv_frame_pipe_time_volume(mvFramePipe* p, int max_launches);
 int mv_frame_pipe_volume_times(mvFramePipe* p, float* ms, int cap, int* n);
+/* per timed frame: {GEMM start, GEMM end, last lookup done, selector done} in ms since the first timed GEMM start */
+int mv_frame_pipe_timeline(mvFramePipe* p, float* ms, int cap_frames, int* n);
 /* where a result lives inside the arena; age 0 = newest frame that passed that stage, 1 = the one before */
 int mv_frame_pipe_buffer(mvFramePipe* p, int which, int age, void** ptr, size_t* count);
 

@@ -110,7 +110,7 @@ struct mvFramePipe {
     int newest_maps;
     std::deque<Pending> pending;
     // optional timing of the dominant kernel (bench.py roofline): event pairs around each volume GEMM on its stream
-    std::vector<hipEvent_t> tv0, tv1;
+    std::vector<hipEvent_t> tv0, tv1, tv2, tv3;   // GEMM start / end, last lookup done, selector done (timeline hook)
     int n_timed, timed_cap;
 };
 
@@ -213,6 +213,8 @@ extern "C" void mv_frame_pipe_destroy(mvFramePipe* p) {
     for (auto e : p->e_perm) ev(e);
     for (auto e : p->tv0) ev(e);
     for (auto e : p->tv1) ev(e);
+    for (auto e : p->tv2) ev(e);
+    for (auto e : p->tv3) ev(e);
     for (int k = 0; k < 2; ++k) if (p->h_count[k]) (void)hipHostFree(p->h_count[k]);
     for (auto h : p->h_perm) if (h) (void)hipHostFree(h);
     if (p->s_vol) (void)hipStreamDestroy(p->s_vol);
@@ -364,6 +366,7 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
     } else {
         MV_TRY(mv_corr_volume(in->fmap1, in->fmap2, p->vol[k], B, c.C, p->n8, p->n8, c.feat_dtype, c.layout, p->s_vol));
     }
+    const int ti = p->n_timed;
     if (timed) MV_HIP(hipEventRecord(p->tv1[p->n_timed++], p->s_vol));
 
     // ---- decoder side on `main`, overlapping the next frame's GEMM.  (MV_PIPE_LOOKUPS_ON=vol keeps the lookups on the
@@ -379,6 +382,7 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
                                   c.radius, s));
         MV_HIP(hipEventRecord(p->e_vol_free[k], s));
         p->vol_free_valid[k] = true;
+        if (timed) MV_HIP(hipEventRecord(p->tv2[ti], s));
     } else {
         for (int it = 0; it < c.iters; ++it)
             MV_TRY(mv_corr_lookup(p->vol[k], in->coords + it * coord_stride, p->tok[it & 1], B, p->h8, p->w8, p->h8, p->w8,
@@ -415,6 +419,7 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
         }
         MV_HIP(hipMemcpyAsync(p->h_count[k], p->count[k], 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         MV_HIP(hipEventRecord(p->e_cand[k], s));
+        if (timed) MV_HIP(hipEventRecord(p->tv3[ti], s));
         p->pending.push_back(pd);
     }
     p->newest_maps = m;
@@ -524,6 +529,11 @@ extern "C" int mv_frame_pipe_time_volume(mvFramePipe* p, int max_launches) {
         p->tv0.push_back(a);
         MV_HIP(hipEventCreate(&b));
         p->tv1.push_back(b);
+        hipEvent_t c2, c3;
+        MV_HIP(hipEventCreate(&c2));
+        p->tv2.push_back(c2);
+        MV_HIP(hipEventCreate(&c3));
+        p->tv3.push_back(c3);
     }
     p->n_timed = 0;
     p->timed_cap = max_launches;
@@ -535,6 +545,22 @@ extern "C" int mv_frame_pipe_volume_times(mvFramePipe* p, float* ms, int cap, in
     MV_HIP(hipStreamSynchronize(p->s_vol));
     const int m = p->n_timed < cap ? p->n_timed : cap;
     for (int i = 0; i < m; ++i) MV_HIP(hipEventElapsedTime(&ms[i], p->tv0[i], p->tv1[i]));
+    *n = m;
+    return MV_OK;
+}
+
+// timeline of the timed frames: for frame i, ms[4*i + {0,1,2,3}] = GEMM start, GEMM end, last lookup done, selector done,
+// all relative to the first timed GEMM start (blocks until everything enqueued so far has finished)
+extern "C" int mv_frame_pipe_timeline(mvFramePipe* p, float* ms, int cap_frames, int* n) {
+    MV_CHECK_ARG(p && n && cap_frames >= 0 && (cap_frames == 0 || ms));
+    MV_HIP(hipStreamSynchronize(p->s_vol));
+    MV_HIP(hipStreamSynchronize(p->s_main));
+    const int m = p->n_timed < cap_frames ? p->n_timed : cap_frames;
+    for (int i = 0; i < m; ++i) {
+        hipEvent_t evs[4] = {p->tv0[i], p->tv1[i], p->tv2[i], p->tv3[i]};
+        for (int j = 0; j < 4; ++j)
+            if (hipEventElapsedTime(&ms[4 * i + j], p->tv0[0], evs[j]) != hipSuccess) ms[4 * i + j] = -1.f;
+    }
     *n = m;
     return MV_OK;
 }

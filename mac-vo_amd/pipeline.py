@@ -605,6 +605,14 @@ class NativeHotPath:
         ops.L.check(self._lib.mv_frame_pipe_volume_times(self._pipe, buf, cap, ops.C.byref(n)), "mv_frame_pipe_volume_times")
         return list(buf[: n.value])
 
+    def timeline_ms(self) -> list:
+        """[(GEMM start, GEMM end, last lookup done, selector done)] per timed frame, ms since the first timed GEMM start."""
+        cap = 1 << 14
+        buf = (ops.C.c_float * (4 * cap))()
+        n = ops.C.c_int(0)
+        ops.L.check(self._lib.mv_frame_pipe_timeline(self._pipe, buf, cap, ops.C.byref(n)), "mv_frame_pipe_timeline")
+        return [tuple(buf[4 * i: 4 * i + 4]) for i in range(n.value)]
+
     def synchronize(self) -> None:
         if self._pipe is not None:
             ops.L.check(self._lib.mv_frame_pipe_sync(self._pipe, None, 1), "mv_frame_pipe_sync")
