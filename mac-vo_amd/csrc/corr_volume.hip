@@ -708,6 +708,14 @@ static int persistent_grid() {
     return v;
 }
 
+// MV_VOL_EXTRA_LDS=<bytes> of unused dynamic LDS per workgroup: 12288 drops the GEMM from 4 to 3 workgroups per CU, leaving
+// registers / LDS / wave slots for the latency-bound kernels of the other streams (A/B knob, default 0)
+static unsigned gemm_extra_lds() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MV_VOL_EXTRA_LDS"); v = e ? atoi(e) : 0; }
+    return (unsigned)v;
+}
+
 extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B, int C, int N1, int N2,
                               int in_dtype, int layout, mvStream_t stream) {
     MV_CHECK_ARG(f1 && f2 && out);
@@ -729,7 +737,7 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
                     hipLaunchKernelGGL((corr_volume_f32_chw<true, true>), dim3(pg), block, 0, s, a, b, out, C, N1, N2,
                                        tiles_m, tiles_n, B);
                 else
-                    hipLaunchKernelGGL((corr_volume_f32_chw<true, false>), grid, block, 0, s, a, b, out, C, N1, N2,
+                    hipLaunchKernelGGL((corr_volume_f32_chw<true, false>), grid, block, gemm_extra_lds(), s, a, b, out, C, N1, N2,
                                        tiles_m, tiles_n, B);
             } else {
                 hipLaunchKernelGGL((corr_volume_f32_chw<false, false>), grid, block, 0, s, a, b, out, C, N1, N2, tiles_m,

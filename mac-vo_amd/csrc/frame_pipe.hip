@@ -259,7 +259,23 @@ static int create_impl(mvFramePipe* p) {
         MV_HIP(hipExtStreamCreateWithCUMask(&p->s_back, words, small));
         MV_HIP(hipExtStreamCreateWithCUMask(&p->s_side, words, small));
     } else {
-        MV_HIP(hipStreamCreateWithPriority(&p->s_vol, hipStreamNonBlocking, 0));
+        // MV_PIPE_GEMM_RESERVE=<n> (default 0): mask the GEMM's stream off n compute units so that kernels which cannot be
+        // placed beside four 104-register GEMM waves per SIMD (the selector's finishing workgroup, the LM solve) always find
+        // a free CU.  Measured: the selector then finishes 80 us earlier, but ANY CU mask costs the GEMM 12 % (218 -> 248 us,
+        // independent of n = 2, 4, 8 — presumably the round-robin workgroup -> XCD assignment its tile order relies on is
+        // lost), so the frame gets slower (0.354 vs 0.320 ms).
+        int reserve = 0;
+        {
+            const char* e = getenv("MV_PIPE_GEMM_RESERVE");
+            if (e) reserve = atoi(e);
+        }
+        if (reserve > 0 && reserve < n_cu && n_cu <= 1024) {
+            uint32_t big[32] = {0};
+            for (int i = 0; i < n_cu - reserve; ++i) big[i >> 5] |= 1u << (i & 31);
+            MV_HIP(hipExtStreamCreateWithCUMask(&p->s_vol, (uint32_t)((n_cu + 31) / 32), big));
+        } else {
+            MV_HIP(hipStreamCreateWithPriority(&p->s_vol, hipStreamNonBlocking, 0));
+        }
         MV_HIP(hipStreamCreateWithPriority(&p->s_main, hipStreamNonBlocking, 0));
         MV_HIP(hipStreamCreateWithPriority(&p->s_back, hipStreamNonBlocking, hi));
         MV_HIP(hipStreamCreateWithPriority(&p->s_side, hipStreamNonBlocking, hi));

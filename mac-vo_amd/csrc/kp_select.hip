@@ -196,7 +196,7 @@ __device__ __forceinline__ float key_float(unsigned k) {
 #ifndef MV_KP_FINISH_THREADS
 #define MV_KP_FINISH_THREADS 1024
 #endif
-constexpr int FIN_NT = MV_KP_FINISH_THREADS;         // threads of the single finishing workgroup
+
 constexpr int RANK_CAP = 256;                        // bucket size at which selection switches to direct ranking
 constexpr unsigned NAN_KEY = 0xFFFFFFFFu;
 
@@ -414,63 +414,101 @@ __device__ __forceinline__ void kp_finish_body(const mvKpSelectParams& p, const 
     }
 
     KP_STAMP(2);
+    const int per = (n_words + NT - 1) / NT;   // thread t owns the contiguous words [t * per, (t + 1) * per) in the compaction
+    unsigned long long cw[WPT];                // FAST: those words, after the clears
     if (FAST) {
-#pragma unroll
-        for (int j = 0; j < WPT; ++j)
-            if (j * NT + tid < n_words) lds_words[j * NT + tid] = wreg[j];
-        __syncthreads();
-    }
-    // ---- candidates that fail a threshold clear their bit (the cached keys are mapped back to the exact floats; a NaN
-    //      comes back as a NaN, so the fp32 `<` behaves as on the original values)
-    if (!mapping) {
-        if (FAST) {
+        // The words pass through LDS in NPASS chunks (park -> atomic clears -> read back contiguous): the kernel then needs
+        // <= 20 KB of LDS beside its 9 KB of median scratch instead of 40-120 KB.  That matters because this single workgroup
+        // is launched while the NEXT frame's volume GEMM owns the chip (four 32-KB workgroups per CU = 128 of 160 KB): with a
+        // 50-KB footprint it could not be placed until that GEMM's grid had drained, and the candidate count — which the host
+        // needs before it can enqueue the frame after — arrived ~200 us late (unprofiled timeline).
+        constexpr int NPASS = WPT > 5 * 1024 / NT ? 8 : 2;   // 2 chunks for 640x480-class images, 8 for the large variant
+        constexpr int TPP = NT / NPASS;        // threads whose contiguous ranges make up one chunk
+        unsigned fail = 0;                     // bit r: candidate record in slot r fails a threshold
+        if (!mapping) {
             const int nr = (n_rec + NT - 1) / NT;
 #pragma unroll
             for (int r = 0; r < RPT; ++r) {
                 if (r < nr && (ridx[r] & CAND_FLAG)) {
+                    // cached keys are mapped back to the exact floats (a NaN comes back as a NaN): fp32 `<` as on the originals
                     bool ok = true;
                     if (use_f) ok = key_float(kq[r]) < thr_f;
                     if (USE_D) { if (ok && use_d) ok = key_float(kd[USE_D ? r : 0]) < thr_d; }
-                    if (!ok) atomicAnd(&lds_words[(ridx[r] & ~CAND_FLAG) >> 6], ~(1ull << (ridx[r] & 63)));
+                    if (!ok) fail |= 1u << r;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) cw[i] = 0ull;
+#pragma unroll 1
+        for (int h = 0; h < NPASS; ++h) {
+            const int wlo = h * TPP * per, whi = min(wlo + TPP * per, n_words);
+#pragma unroll
+            for (int j = 0; j < WPT; ++j) {
+                const int w = j * NT + tid;
+                if (w >= wlo && w < whi) lds_words[w - wlo] = wreg[j];
+            }
+            __syncthreads();
+            if (fail) {
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) {
+                    const int w = (int)((ridx[r] & ~CAND_FLAG) >> 6);
+                    if (((fail >> r) & 1u) && w >= wlo && w < whi) atomicAnd(&lds_words[w - wlo], ~(1ull << (ridx[r] & 63)));
                 }
             }
             __syncthreads();
-        } else {
-            for (int i = tid; i < n_rec; i += NT) {
-                const unsigned ri = ws.rec_idx[i];
-                if (ri & CAND_FLAG) {
-                    bool ok = true;
-                    if (use_f) ok = ws.rec_q[i] < thr_f;
-                    if (ok && use_d) ok = ws.rec_d[i] < thr_d;
-                    if (!ok) atomicAnd(&ws.cand_bits[(ri & ~CAND_FLAG) >> 6], ~(1ull << (ri & 63)));
+            if (tid / TPP == h) {
+#pragma unroll
+                for (int i = 0; i < WPT; ++i) {
+                    const int w = tid * per + i;
+                    if (i < per && w < whi) cw[i] = lds_words[w - wlo];
                 }
             }
-            __threadfence();
             __syncthreads();
         }
+    } else if (!mapping) {
+        for (int i = tid; i < n_rec; i += NT) {
+            const unsigned ri = ws.rec_idx[i];
+            if (ri & CAND_FLAG) {
+                bool ok = true;
+                if (use_f) ok = ws.rec_q[i] < thr_f;
+                if (ok && use_d) ok = ws.rec_d[i] < thr_d;
+                if (!ok) atomicAnd(&ws.cand_bits[(ri & ~CAND_FLAG) >> 6], ~(1ull << (ri & 63)));
+            }
+        }
+        __threadfence();
+        __syncthreads();
     }
 
     KP_STAMP(3);
-    // ---- ordered compaction of the candidate words: thread t owns words [t * per, (t + 1) * per)
-    const int per = (n_words + NT - 1) / NT;
+    // ---- ordered compaction of the candidate words
     const int w_begin = min(tid * per, n_words), w_end = min(w_begin + per, n_words);
-    auto word = [&](int w) -> unsigned long long {
-        if (FAST) return lds_words[w];
-        return __hip_atomic_load(&ws.cand_bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // L2, where the atomics landed
-    };
     int cnt = 0;
-    for (int w = w_begin; w < w_end; ++w) cnt += __popcll(word(w));
+    if (FAST) {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) cnt += __popcll(cw[i]);
+    } else {
+        for (int w = w_begin; w < w_end; ++w)   // atomic loads: served by L2, where the atomics landed
+            cnt += __popcll(__hip_atomic_load(&ws.cand_bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
     int total;
     int pos = block_exclusive_scan<NT>(cnt, L.wave_tot, total);
     KP_STAMP(4);
-    for (int w = w_begin; w < w_end; ++w) {
-        unsigned long long bits = word(w);
+    auto emit = [&](unsigned long long bits, int w) {
         const int row = w / words_per_row, col0 = (w - row * words_per_row) * 64;
         while (bits) {
             const int bpos = __ffsll((long long)bits) - 1;
             bits &= bits - 1;
             out_cand[pos++] = row * W + col0 + bpos;
         }
+    };
+    if (FAST) {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            if (cw[i]) emit(cw[i], w_begin + i);
+    } else {
+        for (int w = w_begin; w < w_end; ++w)
+            emit(__hip_atomic_load(&ws.cand_bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), w);
     }
     KP_STAMP(5);
     if (tid == 0) {
@@ -486,39 +524,29 @@ __device__ __forceinline__ void kp_finish_body(const mvKpSelectParams& p, const 
     }
 }
 
-// RPT register slots per thread for the records, WPT for the candidate words (kept in dynamic LDS: WPT * NT * 8 bytes).
-// <16, 5> covers 640x480-class images (40 KB), <24, 15> up to 1280x768 (120 KB of the 160 KB LDS; 24 slots keep the
-// kernel inside 128 VGPRs without scratch).
-template <int RPT, int WPT, bool USE_D>
-__global__ __launch_bounds__(FIN_NT) void kp_finish_kernel(mvKpSelectParams p, KpWs ws, int has_flow, int words_per_row,
-                                                            int32_t* __restrict__ out_cand,
-                                                            int32_t* __restrict__ out_count,
-                                                            float* __restrict__ out_stats) {
+// RPT register slots per thread for the records, WPT for the candidate words (which pass through dynamic LDS in chunks).
+// <16, 5> covers 640x480-class images (2 chunks of 20 KB), <24, 15> up to 1280x768 (8 chunks of 15 KB; 24 slots keep
+// the kernel inside 128 VGPRs without scratch).
+template <int NT, int RPT, int WPT, bool USE_D>
+__global__ __launch_bounds__(NT) void kp_finish_kernel(mvKpSelectParams p, KpWs ws, int has_flow, int words_per_row,
+                                                        int32_t* __restrict__ out_cand, int32_t* __restrict__ out_count,
+                                                        float* __restrict__ out_stats) {
     __shared__ MedianLds L;
     extern __shared__ unsigned long long lds_words[];
     const int n_rec = p.mode == MV_KP_MAPPING ? 0 : ws.counters[0];
-    if (n_rec <= RPT * FIN_NT && p.H * words_per_row <= WPT * FIN_NT)
-        kp_finish_body<FIN_NT, true, RPT, WPT, USE_D>(p, ws, has_flow, words_per_row, out_cand, out_count, out_stats, n_rec,
-                                                      L, lds_words);
+    if (n_rec <= RPT * NT && p.H * words_per_row <= WPT * NT)
+        kp_finish_body<NT, true, RPT, WPT, USE_D>(p, ws, has_flow, words_per_row, out_cand, out_count, out_stats, n_rec, L,
+                                                  lds_words);
     else
-        kp_finish_body<FIN_NT, false, RPT, WPT, USE_D>(p, ws, has_flow, words_per_row, out_cand, out_count, out_stats,
-                                                       n_rec, L, lds_words);
+        kp_finish_body<NT, false, RPT, WPT, USE_D>(p, ws, has_flow, words_per_row, out_cand, out_count, out_stats, n_rec, L,
+                                                   lds_words);
 }
 
-template <int RPT, int WPT, bool USE_D>
+template <int NT, int RPT, int WPT, bool USE_D>
 static int launch_finish(const mvKpSelectParams& p, const KpWs& ws, int has_flow, int wpr, int32_t* out_cand,
                          int32_t* out_count, float* out_stats, hipStream_t s) {
-    const size_t dyn = (size_t)WPT * FIN_NT * sizeof(unsigned long long);
-    if (dyn > 48 * 1024) {
-        static bool raised = false;   // per instantiation
-        if (!raised) {
-            if (hipFuncSetAttribute((const void*)kp_finish_kernel<RPT, WPT, USE_D>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)dyn) != hipSuccess)
-                return MV_ERR_LAUNCH;
-            raised = true;
-        }
-    }
-    hipLaunchKernelGGL((kp_finish_kernel<RPT, WPT, USE_D>), dim3(1), dim3(FIN_NT), dyn, s, p, ws, has_flow, wpr, out_cand,
+    const size_t dyn = (size_t)WPT * (NT / (WPT > 5 * 1024 / NT ? 8 : 2)) * sizeof(unsigned long long);   // one chunk of words
+    hipLaunchKernelGGL((kp_finish_kernel<NT, RPT, WPT, USE_D>), dim3(1), dim3(NT), dyn, s, p, ws, has_flow, wpr, out_cand,
                        out_count, out_stats);
     return MV_OK;
 }
@@ -638,13 +666,18 @@ extern "C" int mv_kp_select(const float* flow_cov, const float* depth0, const fl
                            wpr, p.W, out_cand);
         return mv_launch_status();
     }
-    const bool big = (size_t)p.H * wpr > 5 * (size_t)FIN_NT;
+    const bool big = (size_t)p.H * wpr > 5 * (size_t)1024;
     const bool full = p.mode == MV_KP_FULL;
     int rc;
-    if (big) rc = full ? launch_finish<24, 15, true>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, s)
-                       : launch_finish<24, 15, false>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, s);
-    else rc = full ? launch_finish<16, 5, true>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, s)
-                   : launch_finish<16, 5, false>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, s);
+    static int small_nt = -1;   // MV_KP_FINISH_SMALL_NT=512: 8-wave finishing workgroup (fits beside a 3-per-CU GEMM)
+    if (small_nt < 0) { const char* e = getenv("MV_KP_FINISH_SMALL_NT"); small_nt = (e && atoi(e) == 512) ? 512 : 1024; }
+    if (big) rc = full ? launch_finish<1024, 24, 15, true>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, s)
+                       : launch_finish<1024, 24, 15, false>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, s);
+    else if (small_nt == 512)
+        rc = full ? launch_finish<512, 16, 10, true>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, s)
+                  : launch_finish<512, 16, 10, false>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, s);
+    else rc = full ? launch_finish<1024, 16, 5, true>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, s)
+                   : launch_finish<1024, 16, 5, false>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, s);
     if (rc != MV_OK) return rc;
     return mv_launch_status();
 }
