@@ -164,3 +164,31 @@ def test_native_long_stream_is_race_free(gpu):
     assert torch.isfinite(sinks[1]).all()
     bad = (sinks[0] != sinks[1]).any(dim=1).nonzero().flatten()
     assert bad.numel() == 0, f"first mismatching frames: {bad[:10].tolist()}"
+
+
+def test_native_measurement_hooks(gpu):
+    """mv_frame_pipe_time_volume / _volume_times / _timeline: HIP events the driver records on its own streams (bench.py's
+    roofline leg and the unprofiled timeline of DESIGN.md §5)."""
+    n_pool = 6
+    cam, frames, _ = synth.make_sequence(n_pool, 240, 320, C=64, iters=2, seed=3, closed_loop=True)
+    ins = _inputs(frames, gpu, static=True)
+    _, nat = _pair(cam, {}, gpu)
+    nat.initialize(ins[0])
+    torch.manual_seed(1)
+    for _ in nat.run(ins[(1 + k) % n_pool] for k in range(4)):
+        pass
+    nat.time_volume(5)
+    for _ in nat.run(ins[(5 + k) % n_pool] for k in range(8)):
+        pass
+    ms = nat.volume_times_ms()
+    assert len(ms) == 5 and all(0.0 < t < 50.0 for t in ms)            # only the first 5 GEMMs after arming are timed
+    tl = nat.timeline_ms()
+    assert len(tl) == 5
+    for i, (g0, g1, lk, sel) in enumerate(tl):
+        assert g0 <= g1 <= lk <= sel, (i, g0, g1, lk, sel)                 # GEMM -> its lookups -> its selector
+        assert abs((g1 - g0) - ms[i]) < 1e-3
+    assert all(tl[i + 1][0] >= tl[i][1] for i in range(4))                 # GEMMs are serial on their stream
+    nat.time_volume(0)
+    for _ in nat.run(ins[(13 + k) % n_pool] for k in range(2)):
+        pass
+    assert nat.volume_times_ms() == []
