@@ -9,6 +9,7 @@ replace, every hot arithmetic step in the HIP kernels (``include/macvo_hip.h``).
     MatchCovariance                           HIP_MatchCovariance
     TwoFrame_PGO                              HIP_TwoFrame_PGO
     FlowFormerCovFrontend                     HIP_FlowFormerCovFrontend  (network stays PyTorch; lookups + epilogue in HIP)
+    CUDAGraph_FlowFormerCovFrontend           HIP_CUDAGraph_FlowFormerCovFrontend  (same, inference replayed as a hipGraph)
     (FlowFormerCov's volume / lookup)         install_flowformer_hooks(model)
 
 Select them by changing only the ``type:`` strings of ``Config/Experiment/MACVO/MACVO_Fast.yaml`` (see
@@ -366,6 +367,58 @@ class HIP_FlowFormerCovFrontend(IFrontend):
             "enforce_positive_disparity": lambda b: isinstance(b, bool),
             "decoder_depth": lambda v: isinstance(v, int),
         })
+
+
+class HIP_CUDAGraph_FlowFormerCovFrontend(HIP_FlowFormerCovFrontend):
+    """``CUDAGraph_FlowFormerCovFrontend`` (Module/Frontend/Frontend.py:264-353): the joint stereo + temporal inference of
+    ``estimate_pair`` is captured once (3 warm-up runs on a side stream, then ``torch.cuda.graph`` = a hipGraph on ROCm)
+    and replayed per frame on static input buffers; outputs are cloned (:344-347).  The HIP window lookups installed by
+    ``install_flowformer_hooks`` are plain stream launches through the C ABI, so they are captured with the network's own
+    kernels; the depth / match epilogue stays one ``mv_frontend_epilogue`` launch after the replay.  ``estimate_depth`` and
+    ``estimate_triplet`` are inherited (eager), as in the reference."""
+
+    def __init__(self, config: SimpleNamespace):
+        super().__init__(config)
+        assert "cuda" in self.config.device.lower(), "HIP_CUDAGraph_FlowFormerCovFrontend can only run on a GPU device."
+        self.cuda_graph = None
+        torch.backends.cuda.matmul.allow_tf32 = True          # the reference's settings (:275-277)
+        torch.backends.cudnn.allow_tf32 = True
+        torch.set_float32_matmul_precision("medium")
+
+    def cuda_graph_estimate(self, inp_A: torch.Tensor, inp_B: torch.Tensor):
+        if self.cuda_graph is None:
+            static_A, static_B = torch.empty_like(inp_A, device="cuda"), torch.empty_like(inp_B, device="cuda")
+            static_A.copy_(inp_A)
+            static_B.copy_(inp_B)
+            out_val = out_cov = None
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    out_val, out_cov = self.model.inference(static_A, static_B)
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_flow, static_cov = self.model.inference(static_A, static_B)
+            self.cuda_graph = SimpleNamespace(graph=graph, shape=inp_A.shape, input_A=static_A, input_B=static_B,
+                                              flow=static_flow, flow_cov=static_cov)
+            return out_val, out_cov
+        g = self.cuda_graph
+        assert inp_A.shape == g.shape, f"Input shape mismatch for graph replay: {inp_A.shape} != {g.shape}"
+        g.input_A.copy_(inp_A)
+        g.input_B.copy_(inp_B)
+        g.graph.replay()
+        return g.flow.clone(), g.flow_cov.clone()
+
+    @torch.inference_mode()
+    def estimate_pair(self, frame_t1, frame_t2):
+        input_A = torch.cat([frame_t2.imageL, frame_t1.imageL], dim=0).to(device=self.config.device)
+        input_B = torch.cat([frame_t2.imageR, frame_t2.imageL], dim=0).to(device=self.config.device)
+        est_flow, est_cov = self.cuda_graph_estimate(input_A, input_B)
+        flow, cov = est_flow.float().contiguous(), est_cov.float().contiguous()
+        maps = ops.frontend_epilogue(flow[0:2], cov[0:2], frame_t2.frame_baseline, frame_t2.fx, cov_is_log=False,
+                                     enforce_positive_disparity=self.config.enforce_positive_disparity)
+        return self._depth_record(maps), IMatcher.Output(flow=maps.flow, cov=maps.flow_cov, mask=None)
 
 
 # ----------------------------------------------------------------------------------------------- FlowFormer hooks

@@ -193,3 +193,44 @@ def test_frontend_plugin_matches_reference_records(gpu):
     check_depth(t1, flow[0:1], cov[0:1], f1)
     check_depth(t2, flow[1:2], cov[1:2], f2)
     assert torch.equal(m12.flow.cpu(), flow[2:3]) and torch.equal(m12.cov.cpu()[:, :2], cov[2:3])
+
+
+def test_graph_frontend_plugin_replays_hip_lookups(gpu):
+    """HIP_CUDAGraph_FlowFormerCovFrontend: the network stub calls the HIP window lookup (a ctypes launch on the current
+    stream) among ordinary torch ops; captured once and replayed, it must give the eager plugin's outputs for new inputs."""
+    from types import SimpleNamespace
+
+    from macvo_amd import ops, plugins
+
+    H, W = 64, 96
+    h8, w8 = H // 8, W // 8
+
+    class Net:
+        def __init__(self):
+            g = torch.Generator().manual_seed(0)
+            self.vol = torch.randn(2 * h8 * w8, 1, h8, w8, generator=g).to(gpu)
+            self.base = torch.stack(torch.meshgrid(torch.arange(w8), torch.arange(h8), indexing="xy")).float()[None].to(gpu)
+
+        def inference(self, a, b):
+            shift = torch.nn.functional.avg_pool2d(a - b, 8)[:, :2]                         # [2,2,h8,w8], depends on the inputs
+            tok = ops.corr_lookup(self.vol, (self.base + shift).contiguous(), 4)           # HIP kernel inside the model
+            flow = torch.nn.functional.interpolate(tok[:, :2], size=(H, W), mode="bilinear") * 4 + 1.5
+            cov = torch.exp(torch.nn.functional.interpolate(tok[:, 2:4], size=(H, W), mode="bilinear").clamp(-3, 1))
+            return flow, cov
+
+    def frame(seed):
+        gg = torch.Generator().manual_seed(seed)
+        return SimpleNamespace(imageL=torch.rand(1, 3, H, W, generator=gg), imageR=torch.rand(1, 3, H, W, generator=gg),
+                               frame_baseline=0.25, fx=320.0)
+
+    mk = lambda cls: cls(SimpleNamespace(weight="", device="cuda", dec_dtype="fp32", enc_dtype="fp32",        # noqa: E731
+                                         enforce_positive_disparity=False, decoder_depth=12, model=Net()))
+    eager, graphed = mk(plugins.HIP_FlowFormerCovFrontend), mk(plugins.HIP_CUDAGraph_FlowFormerCovFrontend)
+    frames = [frame(s) for s in range(5)]
+    for t in range(1, 5):                                  # call 1 builds the graph, calls 2-4 replay it
+        d_e, m_e = eager.estimate_pair(frames[t - 1], frames[t])
+        d_g, m_g = graphed.estimate_pair(frames[t - 1], frames[t])
+        torch.cuda.synchronize()
+        assert torch.equal(d_e.depth, d_g.depth) and torch.equal(d_e.cov, d_g.cov), t
+        assert torch.equal(m_e.flow, m_g.flow) and torch.equal(m_e.cov, m_g.cov), t
+    assert graphed.cuda_graph is not None and tuple(graphed.cuda_graph.shape) == (2, 3, H, W)

@@ -66,6 +66,7 @@ def test_frontend_plugin_registers_and_explains_missing_network():
     from macvo_amd.interfaces import IFrontend
 
     assert IFrontend.get_class("HIP_FlowFormerCovFrontend") is plugins.HIP_FlowFormerCovFrontend
+    assert IFrontend.get_class("HIP_CUDAGraph_FlowFormerCovFrontend") is plugins.HIP_CUDAGraph_FlowFormerCovFrontend
     good = SimpleNamespace(weight="w.pth", device="cuda", dec_dtype="fp32", enc_dtype="fp16", enforce_positive_disparity=False,
                            decoder_depth=12)
     plugins.HIP_FlowFormerCovFrontend.is_valid_config(good)
