@@ -103,14 +103,16 @@ def track_keypoints(kp0_uv: torch.Tensor, flow: torch.Tensor, cov3: torch.Tensor
     return out
 
 
-def upsample_flow(flow: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+def upsample_flow(flow: torch.Tensor, mask: torch.Tensor, scale: float = 8) -> torch.Tensor:
     """FlowFormer/RAFT convex 8x upsampling (call sites ``covhead.py:124-126,133-135``; in-tree twin
     ``Module/Network/PWCNet/pwc_cov/gru.py:40-52``): softmax over 9 taps of the 3x3 neighbourhood of
-    ``8*flow``; ``[N,2,H,W],[N,576,H,W] -> [N,2,8H,8W]``."""
+    ``8*flow``; ``[N,2,H,W],[N,576,H,W] -> [N,2,8H,8W]``.  ``scale``: RAFT/FlowFormer multiply the coarse flow by 8;
+    the in-tree PWC twin multiplies by its kernel size (3) — with ``scale=3`` this function IS that twin, which is how it
+    is pinned (tests/golden/upsample.npz)."""
     N, C, H, W = flow.shape
     mask = mask.view(N, 1, 9, 8, 8, H, W)
     mask = torch.softmax(mask, dim=2)
-    up = torch.nn.functional.unfold(8 * flow, [3, 3], padding=1)
+    up = torch.nn.functional.unfold(scale * flow, [3, 3], padding=1)
     up = up.view(N, C, 9, 1, 1, H, W)
     up = torch.sum(mask * up, dim=2)
     up = up.permute(0, 1, 4, 2, 5, 3)

@@ -240,6 +240,33 @@ def gen_pgo(ref):
     save("pgo", **out)
 
 
+def gen_upsample():
+    """The in-tree twin of FlowFormer's convex upsampling: GaussianGRU.upsample_flow (Module/Network/PWCNet/pwc_cov/gru.py:40-52),
+    executed unmodified (module loaded by path; its only sibling import is the torch-only attention.py)."""
+    import importlib.util
+    import types
+
+    base = os.path.join(REF, "Module/Network/PWCNet/pwc_cov") + "/"
+    pkg = types.ModuleType("pwc_cov_pkg")
+    pkg.__path__ = [base]
+    sys.modules["pwc_cov_pkg"] = pkg
+    mods = {}
+    for name in ("attention", "gru"):
+        spec = importlib.util.spec_from_file_location(f"pwc_cov_pkg.{name}", base + name + ".py")
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[f"pwc_cov_pkg.{name}"] = m
+        spec.loader.exec_module(m)
+        mods[name] = m
+    out = {}
+    for ci, (n, h, w, seed) in enumerate([(2, 6, 7, 0), (1, 8, 9, 1), (3, 1, 1, 2)]):
+        g = torch.Generator().manual_seed(seed)
+        flow = torch.randn(n, 2, h, w, generator=g) * 4
+        mask = torch.randn(n, 576, h, w, generator=g) * 2
+        out[f"c{ci}_flow"], out[f"c{ci}_mask"] = flow, mask
+        out[f"c{ci}_out"] = mods["gru"].GaussianGRU.upsample_flow(SimpleNamespace(kernel_size=3), flow, mask)
+    save("upsample", **out)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "make_golden.py must run where /root/reference exists"
     ref = import_reference()
@@ -247,3 +274,4 @@ if __name__ == "__main__":
     gen_covariance(ref)
     gen_frontend_bits(ref)
     gen_pgo(ref)
+    gen_upsample()

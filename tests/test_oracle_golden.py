@@ -92,3 +92,21 @@ def test_pgo_matches_reference_in_tree_code(graph):
         assert dt < 1e-9 and dr < 1e-9, (graph, ci, dt, dr)
         ci += 1
     assert ci >= 4
+
+
+def test_upsample_flow_is_the_in_tree_twin():
+    """oracle.frontend.upsample_flow vs the reference's own GaussianGRU.upsample_flow (PWCNet/pwc_cov/gru.py:40-52, run
+    unmodified by make_golden.py): the twin scales the coarse flow by its kernel size (3) where RAFT / FlowFormer use 8 —
+    same code path in the oracle with ``scale=3`` — and the result must be bit-identical."""
+    import os
+
+    import numpy as np
+
+    from oracle import frontend
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "upsample.npz"))
+    for ci in range(3):
+        flow, mask, out = [torch.from_numpy(z[f"c{ci}_{k}"]) for k in ("flow", "mask", "out")]
+        assert torch.equal(frontend.upsample_flow(flow, mask, scale=3), out), ci
+        # and the RAFT scaling is the same linear map: 8/3 of it up to the rounding of the two multiplications
+        torch.testing.assert_close(frontend.upsample_flow(flow, mask), out * (8.0 / 3.0), rtol=1e-5, atol=1e-5)
