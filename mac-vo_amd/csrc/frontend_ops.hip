@@ -189,7 +189,11 @@ __global__ __launch_bounds__(256) void obs_filter_kernel(const uint8_t* __restri
     // single workgroup: N <= a few thousand observations
     __shared__ int total;
     if (threadIdx.x == 0) total = 0;
-    __syncthreads();
+    // LikelyFrontOfCamFilter: if ANY pixel1_d_cov is the -1 placeholder the filter lets every row pass (:133-136)
+    int has_placeholder = 0;
+    if (flags & 4)
+        for (int n = threadIdx.x; n < N; n += blockDim.x) has_placeholder |= (vals[3 * (size_t)N + n] == -1.f);
+    const bool front_off = __syncthreads_or(has_placeholder) != 0;
     int local = 0;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         bool ok = inbound ? inbound[n] != 0 : true;
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256) void obs_filter_kernel(const uint8_t* __restri
             const float d1 = vals[n], d2 = vals[4 * (size_t)N + n], c1 = vals[3 * (size_t)N + n], c2 = vals[7 * (size_t)N + n];
             if (flags & 2)  // SimpleDepthFilter (:103-121)
                 ok = !((d1 < min_depth) || (d1 > max_depth) || (d2 < min_depth) || (d2 > max_depth));
-            if (ok && (flags & 4))  // LikelyFrontOfCamFilter (:124-137)
+            if (ok && (flags & 4) && !front_off)  // LikelyFrontOfCamFilter (:124-141)
                 ok = ((d1 - sqrtf(c1) * 2.f) > 0.f) && ((d2 - sqrtf(c2) * 2.f) > 0.f);
         }
         valid[n] = ok;

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import torch
 
-from . import corr, covariance, frontend, pgo, se3, selector
+from . import corr, covariance, filters, frontend, pgo, se3, selector
 
 
 def rotation_matrix_f32(pose: torch.Tensor) -> torch.Tensor:
@@ -79,8 +79,7 @@ class OracleHotPath:
         cov0 = covariance.match_covariance(kp0, maps0["depth"], tr["kp0_sigma_dd"], tr["kp0_sigma_uv"], *K4, **mc)
         cov1 = covariance.match_covariance(kp1, maps1["depth"], tr["kp1_sigma_dd"], tr["kp1_sigma_uv"], *K4, **mc)
         # CovarianceSanityFilter (OutlierFilter.py:91-100)
-        bad = cov0.isnan().any(dim=[-1, -2]) | cov0.isinf().any(dim=[-1, -2]) | cov1.isnan().any(dim=[-1, -2]) | cov1.isinf().any(dim=[-1, -2])
-        mask = ~bad
+        mask = filters.covariance_sanity(cov0, cov1)
         R = rotation_matrix_f32(self.pose)
         pos_Tw = se3.se3_act(self.pose, pos0_Tc)                                      # fp32 (MACVO.py:277)
         cov_Tw = covariance.rotate_covariance(R, cov0)

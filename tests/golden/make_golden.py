@@ -240,6 +240,43 @@ def gen_pgo(ref):
     save("pgo", **out)
 
 
+def gen_filters():
+    """The real observation filters (Module/OutlierFilter.py:91-145) on seeded rows with NaN / inf covariances, depths around
+    the gates and variances around the 2-sigma front-of-camera test (one variant carries the -1 "no covariance" placeholder)."""
+    import Module.OutlierFilter as OF
+
+    n = 96
+    g = torch.Generator().manual_seed(11)
+    cov1 = torch.eye(3, dtype=torch.float64).repeat(n, 1, 1) * (0.1 + torch.rand(n, 1, 1, generator=g, dtype=torch.float64))
+    cov2 = cov1.clone() * 2
+    cov1[3, 0, 1] = float("nan")
+    cov2[7, 2, 2] = float("inf")
+    cov1[11, 1, 1] = float("-inf")
+    cov2[12, 0, 0] = float("nan")
+    d1 = torch.rand(n, 1, generator=g) * 12
+    d2 = torch.rand(n, 1, generator=g) * 12
+    d1[20], d2[21], d1[22], d2[23] = 0.05, 0.05, 10.0, 10.0                       # exactly on the gates (strict compares)
+    c1 = (torch.rand(n, 1, generator=g) * 3) ** 2
+    c2 = (torch.rand(n, 1, generator=g) * 3) ** 2
+    c1[30] = (d1[30] / 2) ** 2                                                     # d - 2*sqrt(c) == 0 -> rejected (strict >)
+    c2[31] = float("nan")
+    out = dict(cov1=cov1, cov2=cov2, d1=d1, d2=d2, c1=c1, c2=c2)
+    for tag, cc1 in (("", c1), ("_placeholder", torch.where(torch.arange(n)[:, None] == 40, torch.tensor(-1.0), c1))):
+        class _Bundle:          # the two things the filters use of a TensorBundle: .data[...] and len()
+            data = {"obs1_covTc": cov1, "obs2_covTc": cov2, "pixel1_d": d1, "pixel2_d": d2, "pixel1_d_cov": cc1,
+                    "pixel2_d_cov": c2}
+
+            def __len__(self):
+                return n
+
+        vals = _Bundle()
+        dev = torch.device("cpu")
+        out["sanity" + tag] = OF.CovarianceSanityFilter(SimpleNamespace()).filter(vals, dev)
+        out["depth" + tag] = OF.SimpleDepthFilter(SimpleNamespace(min_depth=0.05, max_depth=10.0)).filter(vals, dev)
+        out["front" + tag] = OF.LikelyFrontOfCamFilter(SimpleNamespace()).filter(vals, dev)
+    save("filters", **out)
+
+
 def gen_upsample():
     """The in-tree twin of FlowFormer's convex upsampling: GaussianGRU.upsample_flow (Module/Network/PWCNet/pwc_cov/gru.py:40-52),
     executed unmodified (module loaded by path; its only sibling import is the torch-only attention.py)."""
@@ -275,3 +312,4 @@ if __name__ == "__main__":
     gen_frontend_bits(ref)
     gen_pgo(ref)
     gen_upsample()
+    gen_filters()

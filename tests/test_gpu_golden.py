@@ -65,3 +65,36 @@ def test_pgo_vs_reference_golden(gpu, graph):
         dt, dr = se3.pose_error(ref, pose[k].cpu())
         assert dt <= 1e-4 and dr <= 1e-4, (k, dt, dr)      # north_star tolerance
         assert dt <= 1e-8 and dr <= 1e-8, (k, dt, dr)      # what is actually achieved
+
+
+def test_obs_filter_vs_reference_classes(gpu):
+    """mv_obs_filter (flags 1 / 2 / 4 and their combinations) vs the masks the REAL filter classes produced
+    (tests/golden/filters.npz): NaN / +-inf covariances, depths exactly on the gates, the 2-sigma test at equality, a NaN
+    variance, and the -1 "no covariance" placeholder that switches LikelyFrontOfCamFilter off for every row."""
+    import os
+
+    import numpy as np
+
+    from macvo_amd import ops
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "filters.npz"))
+    T = lambda k: torch.from_numpy(z[k])  # noqa: E731
+    n = T("d1").shape[0]
+    for tag in ("", "_placeholder"):
+        c1 = T("c1").clone()
+        if tag:
+            c1[40] = -1.0
+        vals = torch.zeros(11, n)
+        vals[0], vals[3], vals[4], vals[7] = T("d1")[:, 0], c1[:, 0], T("d2")[:, 0], T("c2")[:, 0]
+        masks = {1: T("sanity" + tag), 2: T("depth" + tag), 4: T("front" + tag)}
+        for flags in (1, 2, 4, 3, 5, 6, 7):
+            want = torch.ones(n, dtype=torch.bool)
+            for bit, m in masks.items():
+                if flags & bit:
+                    want &= m
+            valid, count = ops.obs_filter(None, T("cov1").to(gpu), T("cov2").to(gpu), vals.to(gpu), flags, 0.05, 10.0)
+            assert torch.equal(valid.cpu(), want), (tag, flags)
+            assert int(count.item()) == int(want.sum())
+        inb = torch.arange(n) % 3 != 0
+        valid, _ = ops.obs_filter(inb.to(gpu), T("cov1").to(gpu), T("cov2").to(gpu), vals.to(gpu), 7, 0.05, 10.0)
+        assert torch.equal(valid.cpu(), inb & masks[1] & masks[2] & masks[4])

@@ -110,3 +110,23 @@ def test_upsample_flow_is_the_in_tree_twin():
         assert torch.equal(frontend.upsample_flow(flow, mask, scale=3), out), ci
         # and the RAFT scaling is the same linear map: 8/3 of it up to the rounding of the two multiplications
         torch.testing.assert_close(frontend.upsample_flow(flow, mask), out * (8.0 / 3.0), rtol=1e-5, atol=1e-5)
+
+
+def test_observation_filters_vs_reference_classes():
+    """oracle.filters vs the real CovarianceSanityFilter / SimpleDepthFilter / LikelyFrontOfCamFilter (OutlierFilter.py)."""
+    import os
+
+    import numpy as np
+
+    from oracle import filters as F
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "filters.npz"))
+    T = lambda k: torch.from_numpy(z[k])  # noqa: E731
+    for tag in ("", "_placeholder"):
+        c1 = T("c1").clone()
+        if tag:
+            c1[40] = -1.0
+        assert torch.equal(F.covariance_sanity(T("cov1"), T("cov2")), T("sanity" + tag))
+        assert torch.equal(F.simple_depth(T("d1"), T("d2"), 0.05, 10.0), T("depth" + tag))
+        assert torch.equal(F.likely_front_of_cam(T("d1"), c1, T("d2"), T("c2")), T("front" + tag))
+    assert 0 < int(T("front").sum()) < 96 and int(T("front_placeholder").sum()) == 96
