@@ -156,6 +156,17 @@ else:
         def __init__(self, config: SimpleNamespace):
             self.config = config
 
+        @property
+        @abstractmethod
+        def provide_cov(self) -> bool: ...
+
+        @abstractmethod
+        def forward(self, frame_t1, frame_t2) -> "IMatcher.Output": ...
+
+        def estimate(self, frame_t1, frame_t2) -> "IMatcher.Output":      # Matching.py:68-70
+            with torch.no_grad(), torch.inference_mode():
+                return self.forward(frame_t1, frame_t2)
+
     class IFrontend(ABC, ConfigurablePlugin):
         def __init__(self, config: SimpleNamespace):
             self.config = config

@@ -10,6 +10,7 @@ replace, every hot arithmetic step in the HIP kernels (``include/macvo_hip.h``).
     TwoFrame_PGO                              HIP_TwoFrame_PGO
     FlowFormerCovFrontend                     HIP_FlowFormerCovFrontend  (network stays PyTorch; lookups + epilogue in HIP)
     CUDAGraph_FlowFormerCovFrontend           HIP_CUDAGraph_FlowFormerCovFrontend  (same, inference replayed as a hipGraph)
+    FlowFormerCovDepth / FlowFormerCovMatcher HIP_FlowFormerCovDepth / HIP_FlowFormerCovMatcher  (for FrontendCompose configs)
     (FlowFormerCov's volume / lookup)         install_flowformer_hooks(model)
 
 Select them by changing only the ``type:`` strings of ``Config/Experiment/MACVO/MACVO_Fast.yaml`` (see
@@ -367,6 +368,80 @@ class HIP_FlowFormerCovFrontend(IFrontend):
             "enforce_positive_disparity": lambda b: isinstance(b, bool),
             "decoder_depth": lambda v: isinstance(v, int),
         })
+
+
+def _build_flowformer_cov(config: SimpleNamespace, who: str):
+    """The network exactly as the reference builds it (StereoDepth.py:143-157, Matching.py:161-176) — or ``config.model``."""
+    model = getattr(config, "model", None)
+    if model is None:
+        try:
+            from Module.Network.FlowFormer.configs.submission import get_cfg
+            from Module.Network.FlowFormerCov import build_flowformer
+            from Utility.Utils import reflect_torch_dtype
+        except Exception as e:  # noqa: BLE001
+            raise ImportError(f"{who}: the FlowFormer network (Module/Network/FlowFormer, the MAC-VO/S_FlowFormer submodule) is "
+                              "not importable; initialise the submodule or pass a constructed network as config.model") from e
+        model = build_flowformer(get_cfg(), reflect_torch_dtype(config.enc_dtype), reflect_torch_dtype(config.dec_dtype))
+        model.load_ddp_state_dict(torch.load(config.weight, weights_only=True))
+        model.to(config.device)
+        model.eval()
+    if hasattr(model, "memory_decoder"):
+        install_flowformer_hooks(model)
+    return model
+
+
+_FF_COV_SPEC = {
+    "weight": lambda s: isinstance(s, str),
+    "device": lambda s: isinstance(s, str) and ("cuda" in s),              # the HIP hot path has no CPU fallback
+    "enc_dtype": lambda s: s in {"fp16", "bf16", "fp32"},
+    "dec_dtype": lambda s: s in {"fp16", "bf16", "fp32"},
+}
+
+
+class HIP_FlowFormerCovDepth(IStereoDepth):
+    """``FlowFormerCovDepth`` (Module/Frontend/StereoDepth.py:138-184), the ``IStereoDepth`` of ``FrontendCompose`` configs:
+    network in PyTorch (its window lookups through ``mv_corr_lookup``), ``abs`` + ``disparity_to_depth(_cov)`` (:168-171) in
+    one ``mv_frontend_epilogue`` launch."""
+
+    def __init__(self, config: SimpleNamespace):
+        super().__init__(config)
+        self.model = _build_flowformer_cov(config, "HIP_FlowFormerCovDepth")
+
+    @property
+    def provide_cov(self) -> bool:
+        return True
+
+    @torch.inference_mode()
+    def estimate(self, frame) -> "IStereoDepth.Output":
+        est_flow, est_cov = self.model.inference(frame.imageL.to(self.config.device), frame.imageR.to(self.config.device))
+        m = ops.frontend_epilogue(est_flow.float().contiguous()[0:1], est_cov.float().contiguous()[0:1], frame.frame_baseline,
+                                  frame.fx, cov_is_log=False, want_match=False)
+        return IStereoDepth.Output(depth=m.depth, cov=m.depth_cov, disparity=m.disparity, disparity_uncertainty=m.disparity_cov)
+
+    @classmethod
+    def is_valid_config(cls, config: SimpleNamespace | None) -> None:
+        cls._enforce_config_spec(config, _FF_COV_SPEC)
+
+
+class HIP_FlowFormerCovMatcher(IMatcher):
+    """``FlowFormerCovMatcher`` (Module/Frontend/Matching.py:157-197): network in PyTorch with the HIP window lookups;
+    ``from_partial_cov`` (:34-40) pads the two variance channels with a zero sigma_uv plane."""
+
+    def __init__(self, config: SimpleNamespace):
+        super().__init__(config)
+        self.model = _build_flowformer_cov(config, "HIP_FlowFormerCovMatcher")
+
+    @property
+    def provide_cov(self) -> bool:
+        return True
+
+    def forward(self, frame_t1, frame_t2) -> "IMatcher.Output":
+        flow, flow_cov = self.model.inference(frame_t1.imageL.to(self.config.device), frame_t2.imageL.to(self.config.device))
+        return IMatcher.Output.from_partial_cov(flow=flow, cov=flow_cov)
+
+    @classmethod
+    def is_valid_config(cls, config: SimpleNamespace | None) -> None:
+        cls._enforce_config_spec(config, _FF_COV_SPEC)
 
 
 class HIP_CUDAGraph_FlowFormerCovFrontend(HIP_FlowFormerCovFrontend):

@@ -234,3 +234,41 @@ def test_graph_frontend_plugin_replays_hip_lookups(gpu):
         assert torch.equal(d_e.depth, d_g.depth) and torch.equal(d_e.cov, d_g.cov), t
         assert torch.equal(m_e.flow, m_g.flow) and torch.equal(m_e.cov, m_g.cov), t
     assert graphed.cuda_graph is not None and tuple(graphed.cuda_graph.shape) == (2, 3, H, W)
+
+
+def test_depth_and_matcher_plugins(gpu):
+    """HIP_FlowFormerCovDepth / HIP_FlowFormerCovMatcher (the FrontendCompose pieces) vs the reference formulas."""
+    from types import SimpleNamespace
+
+    from macvo_amd import plugins
+    from macvo_amd.interfaces import IMatcher, IStereoDepth
+    from oracle import frontend as ofr
+
+    H, W = 48, 64
+
+    class Net:
+        def inference(self, a, b):
+            gg = torch.Generator().manual_seed(int(a.sum().item() * 1000) % 1000)
+            flow = (torch.randn(a.shape[0], 2, H, W, generator=gg) * 6).to(a.device)
+            cov = torch.exp(torch.randn(a.shape[0], 2, H, W, generator=gg)).to(a.device)
+            return flow, cov
+
+    def frame(seed):
+        gg = torch.Generator().manual_seed(seed)
+        return SimpleNamespace(imageL=torch.rand(1, 3, H, W, generator=gg), imageR=torch.rand(1, 3, H, W, generator=gg),
+                               frame_baseline=0.25, fx=320.0)
+
+    cfg = lambda: SimpleNamespace(weight="", device="cuda", enc_dtype="fp32", dec_dtype="fp32", model=Net())  # noqa: E731
+    assert IStereoDepth.get_class("HIP_FlowFormerCovDepth") is plugins.HIP_FlowFormerCovDepth
+    assert IMatcher.get_class("HIP_FlowFormerCovMatcher") is plugins.HIP_FlowFormerCovMatcher
+    dep, mat = plugins.HIP_FlowFormerCovDepth(cfg()), plugins.HIP_FlowFormerCovMatcher(cfg())
+    f1, f2 = frame(1), frame(2)
+    out = dep.estimate(f1)
+    flow, cov = [t.cpu() for t in Net().inference(f1.imageL.to(gpu), f1.imageR.to(gpu))]
+    d, dc, disp, dispc, _ = ofr.inference_2_depth(flow, cov, 0.25, 320.0)
+    assert torch.equal(out.depth.cpu(), d) and torch.equal(out.cov.cpu(), dc)
+    assert torch.equal(out.disparity.cpu(), disp) and torch.equal(out.disparity_uncertainty.cpu(), dispc) and out.mask is None
+    m = mat.estimate(f1, f2)
+    flow, cov = [t.cpu() for t in Net().inference(f1.imageL.to(gpu), f2.imageL.to(gpu))]
+    assert torch.equal(m.flow.cpu(), flow) and torch.equal(m.cov.cpu(), ofr.from_partial_cov(cov)) and m.mask is None
+    assert dep.provide_cov and mat.provide_cov
