@@ -151,7 +151,7 @@ def main():
     # software-pipelined stream (frame t+1's frontend is queued before frame t's host randperm); K full run_pairs
     for _ in hot.run((frames[(t_idx + k) % args.pool] for k in range(args.steps)), pose_sink=poses):
         pass
-    all_poses = gather_poses(poses, dist)  # the one collective of the job (no-op for N = 1)
+    all_poses, _ = gather_poses(poses, dist)  # the one collective of the job (no-op for N = 1)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()

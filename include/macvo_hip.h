@@ -266,7 +266,10 @@ typedef struct {
     int32_t reject;      /* 16    */
     int32_t max_steps;   /* 10    */
     int32_t patience;    /* 2     */
-    int32_t reserved;
+    int32_t stop_on_reject; /* 1: StopOnPlateau ends the outer loop when the last step's reject_count >= this value
+                             * (PyPose 0.6.x scheduler: `if optimizer.reject_count > 0` => 1, the default; `reject` (16)
+                             * = "only after the maximum number of rejections"; 0 = rejections never stop the loop).
+                             * PyPose is un-vendored (requirements.txt:1) => from memory, hence a named knob. */
 } mvLMParams;
 
 void mv_lm_default_params(mvLMParams* p /* host */);

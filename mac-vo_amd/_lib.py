@@ -43,7 +43,7 @@ class mvLMParams(C.Structure):
         ("tr_factor", C.c_double), ("tr_min", C.c_double), ("tr_max", C.c_double),
         ("diag_min", C.c_double), ("diag_max", C.c_double), ("decreasing", C.c_double),
         ("pinv_rcond", C.c_double),
-        ("reject", C.c_int32), ("max_steps", C.c_int32), ("patience", C.c_int32), ("reserved", C.c_int32),
+        ("reject", C.c_int32), ("max_steps", C.c_int32), ("patience", C.c_int32), ("stop_on_reject", C.c_int32),
     ]
 
 

@@ -567,7 +567,7 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
         if (steps >= lm.max_steps) continual = false;
         if ((last - loss) < lm.decreasing) patience_count += 1; else patience_count = 0;
         if (patience_count >= lm.patience) continual = false;
-        if (reject_count >= lm.reject) continual = false;
+        if (lm.stop_on_reject > 0 && reject_count >= lm.stop_on_reject) continual = false;
     }
 
     if (tid == 0) {
@@ -595,7 +595,7 @@ extern "C" void mv_lm_default_params(mvLMParams* p) {
     p->diag_min = 1e-6; p->diag_max = 1e32;
     p->decreasing = 1e-5;
     p->pinv_rcond = 1e-15;
-    p->reject = 16; p->max_steps = 10; p->patience = 2; p->reserved = 0;
+    p->reject = 16; p->max_steps = 10; p->patience = 2; p->stop_on_reject = 1;
 }
 
 extern "C" int mv_pgo_solve(int nprob, const int32_t* offsets, int graph_type, const float* init_pose,
@@ -607,7 +607,7 @@ extern "C" int mv_pgo_solve(int nprob, const int32_t* offsets, int graph_type, c
     MV_CHECK_ARG(nprob >= 0 && params);
     if (nprob == 0) return MV_OK;
     MV_CHECK_ARG(offsets && init_pose && intrinsics && baseline && pos_Tw && pixel2_uv && out_pose && out_info);
-    MV_CHECK_ARG(params->max_steps >= 1 && params->reject >= 0 && params->radius > 0 && params->huber_delta > 0);
+    MV_CHECK_ARG(params->max_steps >= 1 && params->reject >= 0 && params->stop_on_reject >= 0 && params->radius > 0 && params->huber_delta > 0);
     PgoArgs a{offsets, init_pose, intrinsics, baseline, pos_Tw, cov_Tw, pixel2_uv, pixel2_d, pixel2_disp,
               pixel2_disp_cov, pixel2_uv_cov, obs2_covTc, valid, min_points, out_pose, out_info, out_pose_f32};
     hipStream_t s = (hipStream_t)stream;

@@ -17,30 +17,47 @@ def shard_sequences(n_sequences: int, rank: int, world: int) -> list[int]:
     return [s for s in range(n_sequences) if s % world == rank]
 
 
-def gather_poses(poses: torch.Tensor, dist=None, lengths: torch.Tensor | None = None) -> torch.Tensor:
-    """All-gather per-rank pose tracks.
+def gather_tracks(poses: torch.Tensor, time_ns: torch.Tensor | None = None, dist=None):
+    """All-gather per-rank trajectories: ``poses [T,7]`` fp32 + ``time_ns [T]`` int64 + ``T``.
 
-    poses ``[T, 7]`` (same T on every rank -> one all_gather_into_tensor) or ragged with ``lengths`` given
-    (two-phase: gather lengths, pad to the max, gather payload).  Returns ``[world, T_max, 7]``; with no process
-    group it is ``poses[None]``.
+    Two phases, both tiny: (1) all_gather of the track lengths, (2) ONE all_gather of a ``[T_max, 9]`` fp32 payload
+    (7 pose floats + the int64 timestamp carried as two 32-bit words), rows beyond a rank's own T zero-padded.  Ragged
+    tracks are therefore always safe; the lengths come back so callers can strip the padding.
+    Returns ``(poses [world, T_max, 7] fp32, time_ns [world, T_max] int64, lengths [world] int64)``; without a process
+    group the inputs are returned with a leading dimension of 1.
     """
+    assert poses.dim() == 2 and poses.shape[1] == 7 and poses.dtype == torch.float32, "poses must be [T,7] float32"
+    T = poses.shape[0]
+    dev = poses.device
+    if time_ns is None:
+        time_ns = torch.zeros((T,), dtype=torch.int64, device=dev)
+    assert time_ns.shape == (T,) and time_ns.dtype == torch.int64, "time_ns must be [T] int64"
     if dist is None or not dist.is_initialized():
-        return poses[None]
+        return poses[None], time_ns[None], torch.tensor([T], dtype=torch.int64, device=dev)
     world = dist.get_world_size()
-    T = torch.tensor([poses.shape[0]], dtype=torch.int64, device=poses.device)
-    if lengths is not None:
-        all_T = [torch.zeros_like(T) for _ in range(world)]
-        dist.all_gather(all_T, T)
-        t_max = int(torch.stack(all_T).max().item())
-        if poses.shape[0] < t_max:
-            pad = torch.zeros((t_max - poses.shape[0], poses.shape[1]), dtype=poses.dtype, device=poses.device)
-            poses = torch.cat([poses, pad], dim=0)
-    poses = poses.contiguous()
-    out = torch.empty((world,) + tuple(poses.shape), dtype=poses.dtype, device=poses.device)
-    if poses.is_cuda:
-        dist.all_gather_into_tensor(out, poses)
-    else:  # gloo: list form
-        parts = [torch.empty_like(poses) for _ in range(world)]
-        dist.all_gather(parts, poses)
-        out = torch.stack(parts)
-    return out
+    mine = torch.tensor([T], dtype=torch.int64, device=dev)
+    lengths = torch.empty((world,), dtype=torch.int64, device=dev)
+    _all_gather(dist, lengths, mine)
+    t_max = int(lengths.max().item())
+    payload = torch.zeros((t_max, 9), dtype=torch.float32, device=dev)
+    payload[:T, :7] = poses
+    payload[:T, 7:] = time_ns.contiguous().view(torch.float32).view(T, 2)     # bit pattern, not a conversion
+    out = torch.empty((world, t_max, 9), dtype=torch.float32, device=dev)
+    _all_gather(dist, out, payload)
+    ts = out[:, :, 7:].contiguous().view(torch.int64).view(world, t_max)
+    return out[:, :, :7].contiguous(), ts, lengths
+
+
+def _all_gather(dist, out: torch.Tensor, mine: torch.Tensor) -> None:
+    if mine.is_cuda:   # RCCL over xGMI (backend "nccl")
+        dist.all_gather_into_tensor(out, mine.contiguous())
+    else:              # gloo: list form
+        parts = [torch.empty_like(mine) for _ in range(out.shape[0])]
+        dist.all_gather(parts, mine.contiguous())
+        out.copy_(torch.stack(parts).view_as(out))
+
+
+def gather_poses(poses: torch.Tensor, dist=None, time_ns: torch.Tensor | None = None):
+    """``gather_tracks`` returning ``(poses [world, T_max, 7], lengths [world])`` (padding rows are zero)."""
+    p, _, lengths = gather_tracks(poses, time_ns, dist)
+    return p, lengths

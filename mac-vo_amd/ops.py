@@ -227,7 +227,9 @@ _ws_cache: dict = {}
 
 
 def _kp_workspace(H: int, W: int, device) -> torch.Tensor:
-    key = (H, W, str(device))
+    # one workspace per (shape, device, STREAM): the kernel needs its counters zero on entry and leaves them zero, so two
+    # launches may share a workspace only when they are ordered, i.e. on the same stream
+    key = (H, W, str(device), _stream())
     ws = _ws_cache.get(key)
     if ws is None:
         nbytes = L.load().mv_kp_select_workspace_bytes(H, W)
@@ -488,9 +490,11 @@ def obs_filter(inbound: torch.Tensor | None, cov1: torch.Tensor | None, cov2: to
                max_depth: float = 0.0):
     """Fused observation filters (OutlierFilter.py:91-137) -> (valid [N] bool, count [1] int32), both on the GPU."""
     lib = L.load()
-    ref = inbound if inbound is not None else (cov1 if cov1 is not None else vals)
-    N = ref.shape[0]
-    dev = ref.device
+    sizes = [t.shape[0] for t in (inbound, cov1, cov2) if t is not None] + ([vals.shape[1]] if vals is not None else [])
+    if not sizes or any(n != sizes[0] for n in sizes):
+        raise L.MacvoHipError(f"obs_filter: inbound [N], cov1/cov2 [N,3,3] and vals [11,N] must agree on N (got {sizes})")
+    N = sizes[0]
+    dev = next(t for t in (inbound, cov1, cov2, vals) if t is not None).device
     valid = torch.empty((N,), dtype=torch.bool, device=dev)
     count = torch.empty((1,), dtype=torch.int32, device=dev)
     c1 = None if cov1 is None else _req(cov1, torch.float64, "cov1")

@@ -146,7 +146,8 @@ class HIP_MatchCovariance(ICovariance2to3):
             work[:, 2] = 0.0
         res = ops.match_cov(depth_est.depth.to(dev), kp.to(dev), work, None if depth_cov is None else depth_cov.to(dev),
                             frame.fx, frame.fy, frame.cx, frame.cy, kernel_size=self.config.kernel_size,
-                            min_flow_cov=self.config.min_flow_cov, min_depth_cov=self.config.min_depth_cov,
+                            min_flow_cov=self.config.min_flow_cov if has_flow_cov else 0.0,   # clamp only a GIVEN flow_cov (Project2to3.py:128-135)
+                            min_depth_cov=self.config.min_depth_cov,
                             use_patch_var=(has_flow_cov or depth_cov is None), rot=rot)
         if has_flow_cov and work is not flow_cov:
             flow_cov.copy_(work)                                                   # keep the in-place side effect

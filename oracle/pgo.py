@@ -49,6 +49,10 @@ class LMParams:
     patience: int = 2
     decreasing: float = 1e-5
     pinv_rcond: float = 1e-15         # torch.linalg.pinv default rcond for the PINV solver / weights
+    # StopOnPlateau's reaction to rejected steps (PyPose is un-vendored => restated from memory, hence a knob):
+    #   1  (default) PyPose 0.6.x scheduler.py: ``if optimizer.reject_count > 0: stop``
+    #   16 (= reject) stop only when the inner loop exhausted its rejections;  0: rejections never stop the loop
+    stop_on_reject: int = 1
 
 
 @dataclass
@@ -73,6 +77,7 @@ class PGOResult:
     loss: float
     steps: int
     history: list = field(default_factory=list)
+    reject_count: int = 0            # of the LAST LM step (what StopOnPlateau sees)
 
 
 # --------------------------------------------------------------------------- PyPose pieces
@@ -261,10 +266,10 @@ def solve(prob: PGOProblem, graph_type: int | str = "disp", params: LMParams | N
             patience_count = 0
         if patience_count >= p.patience:
             continual = False
-        if st.reject_count >= p.reject:
+        if p.stop_on_reject > 0 and st.reject_count >= p.stop_on_reject:
             continual = False
         hist.append((float(loss), st.reject_count, st.damping))
-    return PGOResult(pose=g.T.clone(), loss=float(st.loss), steps=steps, history=hist)
+    return PGOResult(pose=g.T.clone(), loss=float(st.loss), steps=steps, history=hist, reject_count=st.reject_count)
 
 
 # --------------------------------------------------------------------------- synthetic problems (SURVEY §8(d) S-pgo)

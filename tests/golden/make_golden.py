@@ -216,27 +216,42 @@ def gen_pgo(ref):
     # no GPU in the build container, so hand it a placeholder
     torch.cuda.current_stream = lambda *a, **k: None
 
+    # cases 4-6 are chosen to ENTER the reject loop mid-solve (bad prior: 5 rejections in the first LM step of
+    # reproj / disp; heavy outliers), cases 0-3 mostly reject only at convergence (16 rejections in the last step)
     cases = [dict(n=200, seed=6), dict(n=200, seed=7, outlier_frac=0.1), dict(n=37, seed=8),
-             dict(n=120, seed=10, trans_sigma=0.4, rot_sigma=0.08)]
+             dict(n=120, seed=10, trans_sigma=0.4, rot_sigma=0.08),
+             dict(n=200, seed=11, trans_sigma=1.0, rot_sigma=0.3, outlier_frac=0.3),
+             dict(n=60, seed=12, trans_sigma=2.0, rot_sigma=0.5),
+             dict(n=200, seed=13, outlier_frac=0.5)]
     out = {}
-    for gi, gname in enumerate(("icp", "reproj", "disp")):
-        cfg = SimpleNamespace(graph_type=gname, device="cpu", vectorize=True, parallel=False, autodiff=False)
-        ctx = ref.OPT.TwoFrame_PGO.init_context(cfg)
-        for ci, c in enumerate(cases):
-            prob, _ = opgo.make_synthetic_problem(**c)
-            obs = SimpleNamespace(data={
-                "pixel2_uv": prob.pixel2_uv, "pixel2_d": prob.pixel2_d, "pixel2_disp": prob.pixel2_disp,
-                "pixel2_disp_cov": prob.pixel2_disp_cov, "pixel2_uv_cov": prob.pixel2_uv_cov, "obs2_covTc": prob.obs2_covTc})
-            pts = SimpleNamespace(data={"pos_Tw": prob.pos_Tw, "cov_Tw": prob.cov_Tw})
-            n = prob.pos_Tw.shape[0]
-            gin = ref.GR.GraphInput(frame_idx=torch.tensor([1]), from_idx=torch.tensor([0]),
-                                    init_motion=pypose_shim.SE3(prob.init_pose.reshape(1, 7).clone()),
-                                    baseline=torch.tensor([prob.baseline], dtype=torch.float32), observations=obs, points=pts,
-                                    images_intrinsic=prob.K, edges_index=torch.zeros(n, dtype=torch.long), device="cpu")
-            _, gout = ref.OPT.TwoFrame_PGO._optimize(ctx, gin)
-            pose = gout.motion.detach().as_subclass(torch.Tensor).reshape(7).double()
-            out[f"{gname}_{ci}_pose"] = pose
-            out[f"{gname}_{ci}_case"] = np.array([c["n"], c["seed"], c.get("outlier_frac", 0.0), c.get("trans_sigma", 0.1), c.get("rot_sigma", 0.02)])
+    SOP = pypose_shim.StopOnPlateau
+    # both readings of StopOnPlateau's reject rule (see pypose_shim.StopOnPlateau): "" = threshold 1 (default),
+    # "_r16" = threshold = optimizer.reject
+    for tag, thr in (("", 1), ("_r16", 16)):
+        SOP.STOP_ON_REJECT = thr
+        for gi, gname in enumerate(("icp", "reproj", "disp")):
+            cfg = SimpleNamespace(graph_type=gname, device="cpu", vectorize=True, parallel=False, autodiff=False)
+            ctx = ref.OPT.TwoFrame_PGO.init_context(cfg)
+            for ci, c in enumerate(cases):
+                prob, _ = opgo.make_synthetic_problem(**c)
+                obs = SimpleNamespace(data={
+                    "pixel2_uv": prob.pixel2_uv, "pixel2_d": prob.pixel2_d, "pixel2_disp": prob.pixel2_disp,
+                    "pixel2_disp_cov": prob.pixel2_disp_cov, "pixel2_uv_cov": prob.pixel2_uv_cov, "obs2_covTc": prob.obs2_covTc})
+                pts = SimpleNamespace(data={"pos_Tw": prob.pos_Tw, "cov_Tw": prob.cov_Tw})
+                n = prob.pos_Tw.shape[0]
+                gin = ref.GR.GraphInput(frame_idx=torch.tensor([1]), from_idx=torch.tensor([0]),
+                                        init_motion=pypose_shim.SE3(prob.init_pose.reshape(1, 7).clone()),
+                                        baseline=torch.tensor([prob.baseline], dtype=torch.float32), observations=obs, points=pts,
+                                        images_intrinsic=prob.K, edges_index=torch.zeros(n, dtype=torch.long), device="cpu")
+                _, gout = ref.OPT.TwoFrame_PGO._optimize(ctx, gin)
+                pose = gout.motion.detach().as_subclass(torch.Tensor).reshape(7).double()
+                sch = SOP.last_instance
+                out[f"{gname}_{ci}_pose{tag}"] = pose
+                # {outer LM steps, reject_count of the last step, final robust loss, max reject_count over the steps}
+                out[f"{gname}_{ci}_stats{tag}"] = np.array([sch.steps, sch.optimizer.reject_count, float(sch.optimizer.loss),
+                                                            max(sch.reject_hist)], dtype=np.float64)
+                out[f"{gname}_{ci}_case"] = np.array([c["n"], c["seed"], c.get("outlier_frac", 0.0), c.get("trans_sigma", 0.1), c.get("rot_sigma", 0.02)])
+    SOP.STOP_ON_REJECT = 1
     save("pgo", **out)
 
 

@@ -252,16 +252,27 @@ class _Optimizer(Optimizer):
 
 
 class StopOnPlateau:
+    # reaction to rejected LM steps — restated from memory of pypose/optim/scheduler.py (0.6.x):
+    #     if hasattr(self.optimizer, 'reject_count'):
+    #         if self.optimizer.reject_count > 0: self._continual = False   # "Maximum rejected steps reached"
+    # => threshold 1.  The golden generator also runs the alternative reading (threshold = optimizer.reject, i.e. stop
+    # only after the maximum number of rejections) and stores both; 0 disables the rule.
+    STOP_ON_REJECT = 1
+    last_instance = None    # the generator reads steps / reject_count of the scheduler `_optimize` created
+
     def __init__(self, optimizer, steps, patience=5, decreasing=1e-3, verbose=False):
         self.optimizer, self.max_steps, self.steps = optimizer, steps, 0
         self.patience, self.patience_count, self.decreasing = patience, 0, decreasing
         self._continual = True
+        StopOnPlateau.last_instance = self
+        self.reject_hist = []
 
     def continual(self):
         return self._continual
 
     def step(self, loss):
         self.steps += 1
+        self.reject_hist.append(int(getattr(self.optimizer, "reject_count", 0)))
         if self.steps >= self.max_steps:
             self._continual = False
         if (self.optimizer.last - loss) < self.decreasing:
@@ -270,7 +281,8 @@ class StopOnPlateau:
             self.patience_count = 0
         if self.patience_count >= self.patience:
             self._continual = False
-        if hasattr(self.optimizer, "reject_count") and self.optimizer.reject_count >= self.optimizer.reject:
+        thr = StopOnPlateau.STOP_ON_REJECT
+        if thr > 0 and hasattr(self.optimizer, "reject_count") and self.optimizer.reject_count >= thr:
             self._continual = False
 
 

@@ -71,18 +71,22 @@ def test_shard_sequences():
 WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r)
-from macvo_amd.distributed import gather_poses
+from macvo_amd.distributed import gather_poses, gather_tracks
 rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 T = 5 + rank                                   # ragged: rank r tracked 5 + r frames
 poses = torch.full((T, 7), float(rank)) + torch.arange(T)[:, None]
-out = gather_poses(poses, dist, lengths=torch.tensor([T]))
+stamps = (1 << 40) * (rank + 1) + torch.arange(T, dtype=torch.int64) * 33_333_333     # needs all 64 bits
+out, ts, lengths = gather_tracks(poses, stamps, dist)
 assert out.shape == (world, 5 + world - 1, 7), out.shape
+assert lengths.tolist() == [5 + r for r in range(world)]
 for r in range(world):
-    assert torch.equal(out[r, : 5 + r], torch.full((5 + r, 7), float(r)) + torch.arange(5 + r)[:, None])
-    assert out[r, 5 + r:].abs().sum() == 0
-same = gather_poses(torch.full((4, 7), float(rank)), dist)
-assert same.shape == (world, 4, 7) and all(float(same[r].mean()) == r for r in range(world))
+    n = int(lengths[r])
+    assert torch.equal(out[r, :n], torch.full((n, 7), float(r)) + torch.arange(n)[:, None])
+    assert torch.equal(ts[r, :n], (1 << 40) * (r + 1) + torch.arange(n, dtype=torch.int64) * 33_333_333)
+    assert out[r, n:].abs().sum() == 0 and ts[r, n:].abs().sum() == 0
+same, ln = gather_poses(torch.full((4, 7), float(rank)), dist)
+assert same.shape == (world, 4, 7) and all(float(same[r].mean()) == r for r in range(world)) and ln.tolist() == [4] * world
 dist.destroy_process_group()
 print("OK", rank)
 '''

@@ -47,24 +47,37 @@ def test_covariance_vs_reference_golden(gpu):
 
 
 @pytest.mark.parametrize("graph", ["icp", "reproj", "disp"])
-def test_pgo_vs_reference_golden(gpu, graph):
+@pytest.mark.parametrize("variant", ["", "_r16"])
+def test_pgo_vs_reference_golden(gpu, graph, variant):
+    """mv_pgo_solve vs the reference's in-tree optimizer code run on the PyPose shim (pgo.npz): pose, number of outer LM
+    steps, reject_count of the last step and final loss, for both readings of StopOnPlateau's reject rule
+    (``mvLMParams.stop_on_reject`` = 1, the default, and = 16).  Cases 4-6 enter the reject loop mid-solve."""
     from macvo_amd import ops
     from oracle import pgo, se3
     from tests.test_gpu_backend import _to_batch
 
     z = load("pgo")
-    probs, refs = [], []
+    probs, refs, stats = [], [], []
     ci = 0
-    while f"{graph}_{ci}_pose" in z:
+    while f"{graph}_{ci}_pose{variant}" in z:
         n, seed, of, ts, rs = [float(v) for v in z[f"{graph}_{ci}_case"]]
         probs.append(pgo.make_synthetic_problem(n=int(n), seed=int(seed), outlier_frac=of, trans_sigma=ts, rot_sigma=rs)[0])
-        refs.append(z[f"{graph}_{ci}_pose"])
+        refs.append(z[f"{graph}_{ci}_pose{variant}"])
+        stats.append(z[f"{graph}_{ci}_stats{variant}"])
         ci += 1
-    pose, _ = ops.pgo_solve(_to_batch(probs, gpu), graph)
+    assert ci >= 7
+    lm = ops.lm_default_params()
+    assert lm.stop_on_reject == 1
+    lm.stop_on_reject = 1 if variant == "" else 16
+    pose, info = ops.pgo_solve(_to_batch(probs, gpu), graph, lm)
+    info = info.cpu()
     for k, ref in enumerate(refs):
         dt, dr = se3.pose_error(ref, pose[k].cpu())
         assert dt <= 1e-4 and dr <= 1e-4, (k, dt, dr)      # north_star tolerance
         assert dt <= 1e-8 and dr <= 1e-8, (k, dt, dr)      # what is actually achieved
+        steps, rej, loss, _ = [float(v) for v in stats[k]]
+        assert int(info[k, 1]) == int(steps) and int(info[k, 2]) == int(rej), (k, info[k].tolist(), stats[k].tolist())
+        assert abs(float(info[k, 0]) - loss) <= 1e-8 * max(1.0, abs(loss))
 
 
 def test_obs_filter_vs_reference_classes(gpu):

@@ -80,18 +80,41 @@ def test_frontend_bits_match_reference():
 
 
 @pytest.mark.parametrize("graph", ["icp", "reproj", "disp"])
-def test_pgo_matches_reference_in_tree_code(graph):
-    """Reference Graphs.py + LM_analytic.step + _optimize executed on the PyPose shim vs oracle.pgo.solve."""
+@pytest.mark.parametrize("variant", ["", "_r16"])
+def test_pgo_matches_reference_in_tree_code(graph, variant):
+    """Reference Graphs.py + LM_analytic.step + _optimize executed on the PyPose shim vs oracle.pgo.solve: pose, number
+    of outer LM steps, reject_count of the last step, final loss — for both readings of StopOnPlateau's reject rule
+    (``LMParams.stop_on_reject`` 1 = default, 16)."""
     z = load("pgo")
-    ci = 0
-    while f"{graph}_{ci}_pose" in z:
+    params = pgo.LMParams(stop_on_reject=1 if variant == "" else 16)
+    ci, mid_rejects = 0, 0
+    while f"{graph}_{ci}_pose{variant}" in z:
         n, seed, of, ts, rs = [float(v) for v in z[f"{graph}_{ci}_case"]]
         prob, _ = pgo.make_synthetic_problem(n=int(n), seed=int(seed), outlier_frac=of, trans_sigma=ts, rot_sigma=rs)
-        res = pgo.solve(prob, graph)
-        dt, dr = se3.pose_error(z[f"{graph}_{ci}_pose"], res.pose)
+        res = pgo.solve(prob, graph, params)
+        dt, dr = se3.pose_error(z[f"{graph}_{ci}_pose{variant}"], res.pose)
         assert dt < 1e-9 and dr < 1e-9, (graph, ci, dt, dr)
+        steps, rej, loss, max_rej = [float(v) for v in z[f"{graph}_{ci}_stats{variant}"]]
+        assert res.steps == int(steps) and res.reject_count == int(rej), (graph, ci, res.steps, steps, res.reject_count, rej)
+        assert abs(res.loss - loss) <= 1e-9 * max(1.0, abs(loss))
+        assert max(h[1] for h in res.history) == int(max_rej)
+        mid_rejects += int(0 < max_rej < 16)
         ci += 1
-    assert ci >= 4
+    assert ci >= 7
+
+
+def test_pgo_goldens_take_the_reject_branch():
+    """The goldens must exercise LM_analytic's reject loop (PyposeOptimizers.py:187-191): steps that are rejected a few
+    times and then accepted (where the two StopOnPlateau readings differ), and steps that exhaust all 16 rejections."""
+    z = load("pgo")
+    some, full, differ = 0, 0, 0
+    for graph in ("icp", "reproj", "disp"):
+        for ci in range(7):
+            a, b = z[f"{graph}_{ci}_stats"], z[f"{graph}_{ci}_stats_r16"]
+            some += int(0 < float(b[3]) < 16 or 0 < float(a[3]) < 16)
+            full += int(float(b[3]) == 16)
+            differ += int(float(a[0]) != float(b[0]))
+    assert some >= 2 and full >= 6 and differ >= 2, (some, full, differ)
 
 
 def test_upsample_flow_is_the_in_tree_twin():
