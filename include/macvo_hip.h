@@ -51,6 +51,9 @@ enum {
     MV_LAYOUT_HWC = 1  /* [B, N, C]  (token-major / channels_last)                          */
 };
 
+/* most independent sequences ("lanes") one lane-batched launch / one frame pipe can carry (batch-32 frames = 32 lanes) */
+#define MV_MAX_LANES 64
+
 /* library ABI version (bumped on any signature change) and a static description string */
 int mv_abi_version(void);
 const char* mv_error_string(int code);
@@ -307,6 +310,46 @@ int mv_local_corr81(const float* first, const float* second, float* out, int B, 
                     mvStream_t stream);
 
 /* -------------------------------------------------------------------------------------------
+ * Lane-batched variants: the same kernels over `lanes` INDEPENDENT frames (sequences) in ONE launch.  This is the
+ * reference's batching point (Module/Frontend/Frontend.py:219-224 concatenates pairs along the batch axis) carried through
+ * the rest of run_pair, for BASELINE configs[4] (batch-32 frames per GPU).  Layout rule: every argument gains a leading
+ * [lanes] dimension (maps [lanes, ch, H, W]; per-keypoint tables [lanes, cap, .] with `cap` rows of capacity per lane of
+ * which n_live[l] are live — n_live is a HOST int32[lanes], travels as a kernel argument), EXCEPT the SoA value table of
+ * mv_kp_track, which is [11, lanes, cap] so that each of its rows is one concatenated per-point column that mv_pgo_solve
+ * takes directly (problem l = rows [l*cap, (l+1)*cap), dead rows masked by `valid`, which mv_obs_filter_lanes zeroes).
+ * The plain entry points above are these with lanes = 1, cap = N.  MV_KP_MAPPING supports lanes = 1 only. */
+int mv_frontend_epilogue_lanes(const float* flow, const float* logcov, int cov_is_log, int H, int W, float bl_fx,
+                               float bl_fx_sq, float* disparity, float* disparity_cov, float* depth, float* depth_cov,
+                               uint8_t* bad_mask, float* match_flow, float* match_cov, int lanes, mvStream_t stream);
+/* workspace: lanes consecutive copies of mv_kp_select_workspace_bytes(H, W), zero-filled once */
+int mv_kp_select_lanes(const float* flow_cov, const float* depth0, const float* depth0_cov, const float* depth1,
+                       const float* depth1_cov, const uint8_t* mask_a, const uint8_t* mask_b,
+                       const mvKpSelectParams* params /* host */, void* workspace, size_t workspace_bytes,
+                       int32_t* out_cand /* [lanes, H*W] */, int32_t* out_count /* [lanes, 4] */,
+                       float* out_stats /* [lanes, 4] */, int lanes, mvStream_t stream);
+int mv_kp_gather_lanes(const int32_t* cand, size_t cand_lane_stride, const int64_t* perm /* [lanes, cap] */, int lanes,
+                       const int32_t* n_live /* host */, int cap, int W, int64_t* out_uv /* [lanes, cap, 2] */,
+                       mvStream_t stream);
+int mv_kp_track_lanes(const int64_t* kp0_uv, int lanes, const int32_t* n_live /* host */, int cap, const float* match_flow,
+                      const float* match_cov, const float* depth0, const float* disp0, const float* sdisp0,
+                      const float* sdd0, const float* depth1, const float* disp1, const float* sdisp1, const float* sdd1,
+                      int H, int W, int edge, float match_cov_default, float* out_kp0, float* out_kp1,
+                      uint8_t* out_inbound, float* out_vals /* [11, lanes, cap] */, float* out_sigma0, float* out_sigma1,
+                      mvStream_t stream);
+/* depth of lane l, row n = depth_vals[l * depth_lane_stride + n * depth_stride]; pose [lanes, 7]; rot [lanes, 9] */
+int mv_backproject_lanes(const float* kp_uv, const float* depth_vals, int depth_stride, size_t depth_lane_stride, float fx,
+                         float fy, float cx, float cy, const float* pose, int lanes, const int32_t* n_live /* host */,
+                         int cap, float* pos_Tc, float* pos_Tw, double* rot, mvStream_t stream);
+int mv_match_cov_pair_lanes(const float* depth_map0, const float* kp_uv0, float* flow_cov0, const double* rot0,
+                            double* out_cov0, double* out_cov_rot0, const float* depth_map1, const float* kp_uv1,
+                            float* flow_cov1, double* out_cov1, const mvMatchCovParams* params /* host */, int lanes,
+                            const int32_t* n_live /* host */, int cap, mvStream_t stream);
+/* vals = the [11, lanes, cap] table; valid [lanes, cap] (rows >= n_live[l] are written 0); count [lanes] */
+int mv_obs_filter_lanes(const uint8_t* inbound, const double* cov1, const double* cov2, const float* vals, int flags,
+                        float min_depth, float max_depth, int lanes, const int32_t* n_live /* host */, int cap,
+                        uint8_t* valid, int32_t* count, mvStream_t stream);
+
+/* -------------------------------------------------------------------------------------------
  * Native per-frame driver: the host-side sequencing of one `MACVO.run_pair` (Odometry/MACVO.py:173-311) and
  * `FlowFormerCovFrontend.estimate_pair` (Module/Frontend/Frontend.py:215-232) for the hot path, as two host calls per
  * frame instead of ~30 (a Python loop over the entry points above is interpreter-bound at ~370 us/frame, more than the
@@ -321,13 +364,19 @@ int mv_local_corr81(const float* first, const float* second, float* out, int B, 
  *                   perm = torch.randperm(n)[:num_point]                 // stays on the host CPU: bit-exact indices
  *                   mv_frame_pipe_finish(p, perm, n_sel, pose_sink);     // backend + solve of frame t
  * At most two tracked frames may be in flight (enqueued, not finished).
+ *
+ * Lanes (BASELINE configs[4], "batch-32 frames per GPU"): with pairs = 2 * lanes the pipe advances `lanes` INDEPENDENT
+ * sequences in lock-step through the same launches — one volume GEMM of 2 * lanes pairs (pair 2l = lane l's stereo pair,
+ * 2l + 1 its temporal pair, the batch axis of Frontend.py:219-220), lane-batched lookups / epilogue / selector / backend
+ * kernels, and ONE mv_pgo_solve over `lanes` problems.  Every input of mvFrameInputs and every reported buffer then has
+ * the leading dimension scaled by `lanes`; wait_candidates / finish / set_pose take per-lane arrays.
  */
 typedef struct mvFramePipe mvFramePipe;
 
 typedef struct {
     int32_t H, W;              /* image size, multiples of 8 */
     int32_t C;                 /* feature channels (% 16 == 0) */
-    int32_t pairs;             /* volume batch; must be 2: pair 0 stereo, pair 1 temporal (Frontend.py:219-220) */
+    int32_t pairs;             /* volume batch = 2 * lanes (<= 2 * MV_MAX_LANES): pair 2l stereo, 2l + 1 temporal of lane l */
     int32_t iters;             /* decoder iterations = window lookups per frame (12) */
     int32_t radius;            /* lookup radius (4) */
     int32_t feat_dtype;        /* MV_F32 | MV_F16 | MV_BF16 */
@@ -362,26 +411,28 @@ typedef struct {
     const float* cov_mask;  /* [pairs, 576, H/8, W/8] }                                                       */
 } mvFrameInputs;
 
-/* buffers reported by mv_frame_pipe_buffer (element counts, not bytes) */
+/* buffers reported by mv_frame_pipe_buffer (element counts, not bytes); each has a leading [lanes] dimension, per-keypoint
+ * tables are [lanes, num_point, .] (a lane's live rows = its n_sel), MV_FB_VALS is [11, lanes, num_point] */
 enum {
     MV_FB_VOLUME = 0, MV_FB_TOKENS, MV_FB_DISPARITY, MV_FB_DISPARITY_COV, MV_FB_DEPTH, MV_FB_DEPTH_COV, MV_FB_MATCH_FLOW,
     MV_FB_MATCH_COV, MV_FB_CAND, MV_FB_COUNT, MV_FB_STATS,                       /* frontend side: age counts enqueued frames */
     MV_FB_KP0, MV_FB_KP0F, MV_FB_KP1, MV_FB_INBOUND, MV_FB_VALS, MV_FB_SIGMA0, MV_FB_SIGMA1, MV_FB_POS_TC, MV_FB_POS_TW,
     MV_FB_ROT, MV_FB_COV0, MV_FB_COV0W, MV_FB_COV1, MV_FB_VALID, MV_FB_NVALID, MV_FB_POSE64, MV_FB_INFO,   /* backend side */
-    MV_FB_POSE                                                                   /* fp32 [7]; age 0 = newest solve's output */
+    MV_FB_POSE                                                                   /* fp32 [lanes, 7]; age 0 = newest solve's output */
 };
 
 size_t mv_frame_pipe_arena_bytes(const mvFramePipeConfig* cfg);           /* 0 = invalid configuration */
 /* arena: device memory, 256-byte aligned, >= mv_frame_pipe_arena_bytes; must outlive the pipe */
 int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, size_t arena_bytes, mvFramePipe** out);
 void mv_frame_pipe_destroy(mvFramePipe* p);
-int mv_frame_pipe_set_pose(mvFramePipe* p, const float* pose7_host);      /* prior of the next frame (blocking) */
+int mv_frame_pipe_set_pose(mvFramePipe* p, const float* pose7_host);      /* [lanes, 7] host: priors of the next frame (blocking) */
 /* frontend half of a frame; inputs must be complete on `in_stream` (an event is recorded there) and stay untouched
  * until the frame's lookups ran.  with_selector = 0 for the very first frame. */
 int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_stream, int with_selector);
-int mv_frame_pipe_wait_candidates(mvFramePipe* p, int32_t* n_cand);       /* oldest unfinished frame; blocks the host */
-/* perm_host: int64[n_sel] = randperm(n_cand)[:num_point]; pose_sink: device fp32[7] or NULL (copy of the new pose) */
-int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, int n_sel, float* pose_sink);
+int mv_frame_pipe_wait_candidates(mvFramePipe* p, int32_t* n_cand /* [lanes] host */);   /* oldest unfinished frame; blocks the host */
+/* perm_host: int64 [lanes, num_point], row l = randperm(n_cand[l])[:num_point] (n_sel[l] entries used); n_sel: int32 [lanes]
+ * host; pose_sink: device fp32 [lanes, 7] or NULL (copy of the new poses) */
+int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, const int32_t* n_sel, float* pose_sink);
 /* block_host != 0: wait for all four streams; else make `stream` wait for everything enqueued so far */
 int mv_frame_pipe_sync(mvFramePipe* p, mvStream_t stream, int block_host);
 /* measurement hook (bench.py roofline): record a HIP-event pair around each of the next max_launches volume GEMMs on the

@@ -6,6 +6,11 @@
 
 #define MV_WAVE 64
 
+// live rows per lane of a lane-batched launch (kernel argument, passed by value: no H2D copy, no device table)
+struct mvLaneCounts {
+    int32_t n[MV_MAX_LANES];
+};
+
 #define MV_CHECK_ARG(cond) \
     do {                   \
         if (!(cond)) return MV_ERR_INVALID_ARG; \

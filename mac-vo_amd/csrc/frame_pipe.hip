@@ -48,13 +48,13 @@ struct Maps {
     uint8_t* bad_mask;
 };
 
-struct Backend {
+struct Backend {   // every table is [lanes, cap = num_point, ...]; rows beyond a lane's n_sel are dead (valid = 0)
     int64_t *perm, *kp0;
     float *kp0f, *kp1, *vals, *sigma0, *sigma1, *pos_Tc, *pos_Tw;
     uint8_t *inbound, *valid;
     double *rot, *cov0, *cov0w, *cov1, *pose64, *info;
     int32_t* n_valid;
-    int n_sel;
+    int32_t n_sel[MV_MAX_LANES];
 };
 
 struct Pending {
@@ -79,6 +79,7 @@ struct Carver {   // bump allocator over the arena (or a size counter when base 
 struct mvFramePipe {
     mvFramePipeConfig c;
     int plane, h8, w8, n8, KK;
+    int lanes;   // independent sequences batched through every launch (= pairs / 2)
     char* arena;
     size_t arena_bytes;
     // device buffers
@@ -93,9 +94,9 @@ struct mvFramePipe {
     int32_t* count[2];
     float* stats[2];
     Backend be[2];
-    float* pose[3];
-    float *intr, *bl;
-    int32_t* offs;   // row n = {0, n}
+    float* pose[3];   // [lanes, 7]
+    float *intr, *bl;   // [lanes, 4], [lanes]
+    int32_t* offs;    // [lanes + 1]: lane l owns rows [l * cap, (l + 1) * cap) of the backend tables
     // host
     int32_t* h_count[2];      // pinned
     int64_t* h_perm[N_PERM];  // pinned
@@ -126,59 +127,61 @@ static int wait_if_pending(hipStream_t s, hipEvent_t e) {
 static size_t carve(mvFramePipe* p, char* base) {
     const mvFramePipeConfig& c = p->c;
     Carver a{base};
+    const size_t L = p->lanes;
     const size_t plane = p->plane, n8 = p->n8, B = c.pairs, N = c.num_point > 0 ? c.num_point : 1;
     for (int k = 0; k < 2; ++k) p->vol[k] = a.take<float>(B * n8 * n8);
     for (int k = 0; k < 2; ++k) p->tok[k] = a.take<float>(B * p->KK * n8);
     for (int k = 0; k < 2; ++k) p->planes[k] = c.volume_split ? (void*)a.take<uint16_t>(3 * B * n8 * c.C) : nullptr;
     p->up_flow = a.take<float>(B * 2 * plane);
     p->up_cov = a.take<float>(B * 2 * plane);
-    for (int k = 0; k < N_MAPS; ++k) {
+    for (int k = 0; k < N_MAPS; ++k) {   // every map is [lanes, ch, H, W]
         Maps& m = p->maps[k];
-        m.disparity = a.take<float>(plane);
-        m.disparity_cov = a.take<float>(plane);
-        m.depth = a.take<float>(plane);
-        m.depth_cov = a.take<float>(plane);
-        m.match_flow = a.take<float>(2 * plane);
-        m.match_cov = a.take<float>(3 * plane);
-        m.bad_mask = a.take<uint8_t>(plane);
+        m.disparity = a.take<float>(L * plane);
+        m.disparity_cov = a.take<float>(L * plane);
+        m.depth = a.take<float>(L * plane);
+        m.depth_cov = a.take<float>(L * plane);
+        m.match_flow = a.take<float>(L * 2 * plane);
+        m.match_cov = a.take<float>(L * 3 * plane);
+        m.bad_mask = a.take<uint8_t>(L * plane);
     }
-    p->kp_ws_bytes = mv_kp_select_workspace_bytes(c.H, c.W);
+    p->kp_ws_bytes = L * mv_kp_select_workspace_bytes(c.H, c.W);
     p->kp_ws = a.take<char>(p->kp_ws_bytes);
     for (int k = 0; k < 2; ++k) {
-        p->cand[k] = a.take<int32_t>(plane);
-        p->count[k] = a.take<int32_t>(4);
-        p->stats[k] = a.take<float>(4);
+        p->cand[k] = a.take<int32_t>(L * plane);
+        p->count[k] = a.take<int32_t>(L * 4);
+        p->stats[k] = a.take<float>(L * 4);
         Backend& b = p->be[k];
-        b.perm = a.take<int64_t>(N);
-        b.kp0 = a.take<int64_t>(2 * N);
-        b.kp0f = a.take<float>(2 * N);
-        b.kp1 = a.take<float>(2 * N);
-        b.vals = a.take<float>(11 * N);
-        b.sigma0 = a.take<float>(3 * N);
-        b.sigma1 = a.take<float>(3 * N);
-        b.pos_Tc = a.take<float>(3 * N);
-        b.pos_Tw = a.take<float>(3 * N);
-        b.inbound = a.take<uint8_t>(N);
-        b.valid = a.take<uint8_t>(N);
-        b.rot = a.take<double>(9);
-        b.cov0 = a.take<double>(9 * N);
-        b.cov0w = a.take<double>(9 * N);
-        b.cov1 = a.take<double>(9 * N);
-        b.pose64 = a.take<double>(7);
-        b.info = a.take<double>(4);
-        b.n_valid = a.take<int32_t>(1);
+        b.perm = a.take<int64_t>(L * N);
+        b.kp0 = a.take<int64_t>(L * 2 * N);
+        b.kp0f = a.take<float>(L * 2 * N);
+        b.kp1 = a.take<float>(L * 2 * N);
+        b.vals = a.take<float>(L * 11 * N);
+        b.sigma0 = a.take<float>(L * 3 * N);
+        b.sigma1 = a.take<float>(L * 3 * N);
+        b.pos_Tc = a.take<float>(L * 3 * N);
+        b.pos_Tw = a.take<float>(L * 3 * N);
+        b.inbound = a.take<uint8_t>(L * N);
+        b.valid = a.take<uint8_t>(L * N);
+        b.rot = a.take<double>(L * 9);
+        b.cov0 = a.take<double>(L * 9 * N);
+        b.cov0w = a.take<double>(L * 9 * N);
+        b.cov1 = a.take<double>(L * 9 * N);
+        b.pose64 = a.take<double>(L * 7);
+        b.info = a.take<double>(L * 4);
+        b.n_valid = a.take<int32_t>(L);
     }
-    for (int k = 0; k < 3; ++k) p->pose[k] = a.take<float>(7);
-    p->intr = a.take<float>(4);
-    p->bl = a.take<float>(1);
-    p->offs = a.take<int32_t>(2 * (N + 1));
+    for (int k = 0; k < 3; ++k) p->pose[k] = a.take<float>(L * 7);
+    p->intr = a.take<float>(L * 4);
+    p->bl = a.take<float>(L);
+    p->offs = a.take<int32_t>(L + 1);
     return (a.off + 255) & ~(size_t)255;
 }
 
 static int check_config(const mvFramePipeConfig* c) {
     MV_CHECK_ARG(c);
     MV_CHECK_ARG(c->H > 0 && c->W > 0 && c->H % 8 == 0 && c->W % 8 == 0);
-    MV_CHECK_ARG(c->C > 0 && c->C % 16 == 0 && c->pairs == 2 && c->iters >= 0);
+    MV_CHECK_ARG(c->C > 0 && c->C % 16 == 0 && c->iters >= 0);
+    MV_CHECK_ARG(c->pairs >= 2 && c->pairs % 2 == 0 && c->pairs / 2 <= MV_MAX_LANES);   // lane l = pairs 2l (stereo), 2l + 1 (temporal)
     MV_CHECK_ARG(c->radius >= 1 && c->radius <= 4);
     MV_CHECK_ARG(c->selector_mode == MV_KP_NODEPTH || c->selector_mode == MV_KP_FULL);
     MV_CHECK_ARG(c->num_point >= 0 && c->edgewidth >= 0 && c->min_num_point >= 0);
@@ -197,6 +200,7 @@ extern "C" size_t mv_frame_pipe_arena_bytes(const mvFramePipeConfig* cfg) {
     tmp.w8 = cfg->W / 8;
     tmp.n8 = tmp.h8 * tmp.w8;
     tmp.KK = (2 * cfg->radius + 1) * (2 * cfg->radius + 1);
+    tmp.lanes = cfg->pairs / 2;
     return carve(&tmp, nullptr);
 }
 
@@ -287,29 +291,29 @@ static int create_impl(mvFramePipe* p) {
         MV_HIP(mk(&p->e_vol_free[k]));
         MV_HIP(mk(&p->e_cand[k]));
         MV_HIP(mk(&p->e_backend[k]));
-        MV_HIP(hipHostMalloc((void**)&p->h_count[k], 4 * sizeof(int32_t), hipHostMallocDefault));
+        MV_HIP(hipHostMalloc((void**)&p->h_count[k], (size_t)p->lanes * 4 * sizeof(int32_t), hipHostMallocDefault));
     }
     MV_HIP(mk(&p->e_pgo));
     const size_t N = c.num_point > 0 ? c.num_point : 1;
     for (int k = 0; k < N_PERM; ++k) {
         MV_HIP(mk(&p->e_perm[k]));
-        MV_HIP(hipHostMalloc((void**)&p->h_perm[k], N * sizeof(int64_t), hipHostMallocDefault));
+        MV_HIP(hipHostMalloc((void**)&p->h_perm[k], (size_t)p->lanes * N * sizeof(int64_t), hipHostMallocDefault));
     }
     // constants: selector workspace zeroed once (mv_kp_select leaves it zeroed), identity pose, PGO scalars, offsets table
     MV_HIP(hipMemsetAsync(p->kp_ws, 0, p->kp_ws_bytes, p->s_main));
-    const float ident[7] = {0, 0, 0, 0, 0, 0, 1};
-    const float intr[4] = {c.fx, c.fy, c.cx, c.cy};
-    MV_HIP(hipMemcpyAsync(p->pose[0], ident, sizeof(ident), hipMemcpyHostToDevice, p->s_main));
-    MV_HIP(hipMemcpyAsync(p->intr, intr, sizeof(intr), hipMemcpyHostToDevice, p->s_main));
-    MV_HIP(hipMemcpyAsync(p->bl, &c.baseline, sizeof(float), hipMemcpyHostToDevice, p->s_main));
-    int32_t* offs = new (std::nothrow) int32_t[2 * (N + 1)];
-    if (!offs) return MV_ERR_WORKSPACE;
-    for (size_t n = 0; n <= N; ++n) { offs[2 * n] = 0; offs[2 * n + 1] = (int32_t)n; }
-    const hipError_t e = hipMemcpyAsync(p->offs, offs, 2 * (N + 1) * sizeof(int32_t), hipMemcpyHostToDevice, p->s_main);
-    const hipError_t e2 = hipStreamSynchronize(p->s_main);
-    delete[] offs;
-    MV_HIP(e);
-    MV_HIP(e2);
+    const int L = p->lanes;
+    std::vector<float> ident((size_t)L * 7, 0.f), intr((size_t)L * 4), bl((size_t)L, c.baseline);
+    std::vector<int32_t> offs((size_t)L + 1);
+    for (int l = 0; l < L; ++l) {
+        ident[7 * l + 6] = 1.f;
+        intr[4 * l] = c.fx; intr[4 * l + 1] = c.fy; intr[4 * l + 2] = c.cx; intr[4 * l + 3] = c.cy;
+    }
+    for (int l = 0; l <= L; ++l) offs[l] = (int32_t)(l * N);
+    MV_HIP(hipMemcpyAsync(p->pose[0], ident.data(), ident.size() * sizeof(float), hipMemcpyHostToDevice, p->s_main));
+    MV_HIP(hipMemcpyAsync(p->intr, intr.data(), intr.size() * sizeof(float), hipMemcpyHostToDevice, p->s_main));
+    MV_HIP(hipMemcpyAsync(p->bl, bl.data(), bl.size() * sizeof(float), hipMemcpyHostToDevice, p->s_main));
+    MV_HIP(hipMemcpyAsync(p->offs, offs.data(), offs.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->s_main));
+    MV_HIP(hipStreamSynchronize(p->s_main));   // the host vectors die here
     return MV_OK;
 }
 
@@ -324,6 +328,7 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
     p->w8 = cfg->W / 8;
     p->n8 = p->h8 * p->w8;
     p->KK = (2 * cfg->radius + 1) * (2 * cfg->radius + 1);
+    p->lanes = cfg->pairs / 2;
     p->arena = (char*)arena;
     p->arena_bytes = arena_bytes;
     if (((uintptr_t)arena & 255) != 0 || carve(p, p->arena) > arena_bytes) {
@@ -347,7 +352,7 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
 extern "C" int mv_frame_pipe_set_pose(mvFramePipe* p, const float* pose7_host) {
     MV_CHECK_ARG(p && pose7_host);
     if (p->pgo_valid) MV_HIP(hipEventSynchronize(p->e_pgo));
-    MV_HIP(hipMemcpy(p->pose[p->pose_cur], pose7_host, 7 * sizeof(float), hipMemcpyHostToDevice));
+    MV_HIP(hipMemcpy(p->pose[p->pose_cur], pose7_host, (size_t)p->lanes * 7 * sizeof(float), hipMemcpyHostToDevice));
     return MV_OK;
 }
 
@@ -415,25 +420,27 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
     if (up) {
         MV_TRY(mv_convex_upsample(in->flow8, in->up_mask, p->up_flow, B, p->h8, p->w8, 0.25f, 0, s));
         MV_TRY(mv_convex_upsample(in->cov8, in->cov_mask, p->up_cov, B, p->h8, p->w8, 1.0f, 1, s));
-        MV_TRY(mv_frontend_epilogue(p->up_flow, p->up_cov, 0, c.H, c.W, c.bl_fx, c.bl_fx_sq, mp.disparity, mp.disparity_cov,
-                                    mp.depth, mp.depth_cov, nullptr, mp.match_flow, mp.match_cov, s));
+        MV_TRY(mv_frontend_epilogue_lanes(p->up_flow, p->up_cov, 0, c.H, c.W, c.bl_fx, c.bl_fx_sq, mp.disparity,
+                                          mp.disparity_cov, mp.depth, mp.depth_cov, nullptr, mp.match_flow, mp.match_cov,
+                                          p->lanes, s));
     } else {
-        MV_TRY(mv_frontend_epilogue(in->flow, in->logcov, 1, c.H, c.W, c.bl_fx, c.bl_fx_sq, mp.disparity, mp.disparity_cov,
-                                    mp.depth, mp.depth_cov, nullptr, mp.match_flow, mp.match_cov, s));
+        MV_TRY(mv_frontend_epilogue_lanes(in->flow, in->logcov, 1, c.H, c.W, c.bl_fx, c.bl_fx_sq, mp.disparity,
+                                          mp.disparity_cov, mp.depth, mp.depth_cov, nullptr, mp.match_flow, mp.match_cov,
+                                          p->lanes, s));
     }
     Pending pd{m, p->newest_maps, k, with_selector != 0};
     if (with_selector) {
         mvKpSelectParams sp{c.H, c.W, c.selector_mode, c.kp_kernel_size, c.kp_mask_width, c.max_depth, c.max_depth_cov,
                             c.max_match_cov};
         if (c.selector_mode == MV_KP_NODEPTH) {
-            MV_TRY(mv_kp_select(mp.match_cov, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &sp, p->kp_ws,
-                                p->kp_ws_bytes, p->cand[k], p->count[k], p->stats[k], s));
+            MV_TRY(mv_kp_select_lanes(mp.match_cov, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &sp, p->kp_ws,
+                                      p->kp_ws_bytes, p->cand[k], p->count[k], p->stats[k], p->lanes, s));
         } else {
             const Maps& m0 = p->maps[pd.maps_prev];
-            MV_TRY(mv_kp_select(mp.match_cov, m0.depth, m0.depth_cov, mp.depth, mp.depth_cov, nullptr, nullptr, &sp,
-                                p->kp_ws, p->kp_ws_bytes, p->cand[k], p->count[k], p->stats[k], s));
+            MV_TRY(mv_kp_select_lanes(mp.match_cov, m0.depth, m0.depth_cov, mp.depth, mp.depth_cov, nullptr, nullptr, &sp,
+                                      p->kp_ws, p->kp_ws_bytes, p->cand[k], p->count[k], p->stats[k], p->lanes, s));
         }
-        MV_HIP(hipMemcpyAsync(p->h_count[k], p->count[k], 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        MV_HIP(hipMemcpyAsync(p->h_count[k], p->count[k], (size_t)p->lanes * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         MV_HIP(hipEventRecord(p->e_cand[k], s));
         if (timed) MV_HIP(hipEventRecord(p->tv3[ti], s));
         p->pending.push_back(pd);
@@ -447,27 +454,34 @@ extern "C" int mv_frame_pipe_wait_candidates(mvFramePipe* p, int32_t* n_cand) {
     MV_CHECK_ARG(p && n_cand && !p->pending.empty());
     const Pending& pd = p->pending.front();
     MV_HIP(hipEventSynchronize(p->e_cand[pd.cand]));
-    *n_cand = p->h_count[pd.cand][0];
+    for (int l = 0; l < p->lanes; ++l) n_cand[l] = p->h_count[pd.cand][4 * l];
     return MV_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ pose-dependent half
-extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, int n_sel, float* pose_sink) {
-    MV_CHECK_ARG(p && !p->pending.empty());
+extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, const int32_t* n_sel, float* pose_sink) {
+    MV_CHECK_ARG(p && n_sel && !p->pending.empty());
     const mvFramePipeConfig& c = p->c;
-    MV_CHECK_ARG(n_sel >= 0 && n_sel <= c.num_point && (n_sel == 0 || perm_host));
+    const int L = p->lanes, cap = c.num_point > 0 ? c.num_point : 1;
+    int n_max = 0;
+    for (int l = 0; l < L; ++l) {
+        MV_CHECK_ARG(n_sel[l] >= 0 && n_sel[l] <= c.num_point);
+        n_max = n_sel[l] > n_max ? n_sel[l] : n_max;
+    }
+    MV_CHECK_ARG(n_max == 0 || perm_host);
     const Pending pd = p->pending.front();
     p->pending.pop_front();
     const long g = p->n_fin;
     const int k = (int)(g & 1);
     Backend& b = p->be[k];
-    b.n_sel = n_sel;
+    for (int l = 0; l < L; ++l) b.n_sel[l] = n_sel[l];
     p->n_fin = g + 1;
     hipStream_t s = p->s_back;
-    if (n_sel == 0) {   // nothing to track: the pose stays at the motion-model prior (MACVO.py:303-307)
+    if (n_max == 0) {   // nothing to track in any lane: the poses stay at the motion-model prior (MACVO.py:303-307)
         if (pose_sink) {
             if (p->pgo_valid) MV_HIP(hipStreamWaitEvent(p->s_side, p->e_pgo, 0));
-            MV_HIP(hipMemcpyAsync(pose_sink, p->pose[p->pose_cur], 7 * sizeof(float), hipMemcpyDeviceToDevice, p->s_side));
+            MV_HIP(hipMemcpyAsync(pose_sink, p->pose[p->pose_cur], (size_t)L * 7 * sizeof(float), hipMemcpyDeviceToDevice,
+                                  p->s_side));
             MV_HIP(hipEventRecord(p->e_pgo, p->s_side));
             p->pgo_valid = true;
         }
@@ -475,41 +489,46 @@ extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, in
     }
     const Maps &m0 = p->maps[pd.maps_prev], &m1 = p->maps[pd.maps];
 
-    // permutation -> pinned slot -> device
+    // permutations [lanes, cap] -> pinned slot -> device (ONE copy; rows beyond a lane's n_sel are never read)
     const int ps = (int)(g % N_PERM);
     if (p->perm_valid[ps]) MV_HIP(hipEventSynchronize(p->e_perm[ps]));   // long done; keeps the slot reuse provably safe
-    memcpy(p->h_perm[ps], perm_host, (size_t)n_sel * sizeof(int64_t));
+    for (int l = 0; l < L; ++l)
+        memcpy(p->h_perm[ps] + (size_t)l * cap, perm_host + (size_t)l * cap, (size_t)n_sel[l] * sizeof(int64_t));
     MV_TRY(wait_if_pending(s, p->e_cand[pd.cand]));   // fired: the host has just read this frame's count
-    MV_HIP(hipMemcpyAsync(b.perm, p->h_perm[ps], (size_t)n_sel * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    const size_t perm_bytes = ((size_t)(L - 1) * cap + n_sel[L - 1]) * sizeof(int64_t);
+    MV_HIP(hipMemcpyAsync(b.perm, p->h_perm[ps], perm_bytes, hipMemcpyHostToDevice, s));
     MV_HIP(hipEventRecord(p->e_perm[ps], s));
     p->perm_valid[ps] = true;
-    MV_TRY(mv_kp_gather(p->cand[pd.cand], b.perm, n_sel, c.W, b.kp0, s));
+    MV_TRY(mv_kp_gather_lanes(p->cand[pd.cand], (size_t)p->plane, b.perm, L, b.n_sel, cap, c.W, b.kp0, s));
     // the previous pose is produced by the previous solve; this also orders us after the solve of frame g - 2, the last
     // reader of this backend slot
     if (p->pgo_valid) MV_TRY(wait_if_pending(s, p->e_pgo));
     const float* pose = p->pose[p->pose_cur];
-    MV_TRY(mv_kp_track(b.kp0, n_sel, m1.match_flow, m1.match_cov, m0.depth, m0.disparity, m0.disparity_cov, m0.depth_cov,
-                       m1.depth, m1.disparity, m1.disparity_cov, m1.depth_cov, c.H, c.W, c.edgewidth, c.match_cov_default,
-                       b.kp0f, b.kp1, b.inbound, b.vals, b.sigma0, b.sigma1, s));
-    MV_TRY(mv_backproject(b.kp0f, b.vals, 1, c.fx, c.fy, c.cx, c.cy, pose, n_sel, b.pos_Tc, b.pos_Tw, b.rot, s));
+    MV_TRY(mv_kp_track_lanes(b.kp0, L, b.n_sel, cap, m1.match_flow, m1.match_cov, m0.depth, m0.disparity, m0.disparity_cov,
+                             m0.depth_cov, m1.depth, m1.disparity, m1.disparity_cov, m1.depth_cov, c.H, c.W, c.edgewidth,
+                             c.match_cov_default, b.kp0f, b.kp1, b.inbound, b.vals, b.sigma0, b.sigma1, s));
+    MV_TRY(mv_backproject_lanes(b.kp0f, b.vals, 1, (size_t)cap, c.fx, c.fy, c.cx, c.cy, pose, L, b.n_sel, cap, b.pos_Tc,
+                                b.pos_Tw, b.rot, s));
     mvMatchCovParams cp{c.H, c.W, c.cov_kernel_size, 1, c.fx, c.fy, c.cx, c.cy, c.min_flow_cov_sq, c.min_depth_cov};
-    MV_TRY(mv_match_cov_pair(m0.depth, b.kp0f, b.sigma0, b.rot, b.cov0, b.cov0w, m1.depth, b.kp1, b.sigma1, b.cov1, &cp,
-                             n_sel, s));
-    MV_TRY(mv_obs_filter(b.inbound, b.cov0, b.cov1, b.vals, c.filters, c.filter_min_depth, c.max_depth, n_sel, b.valid,
-                         b.n_valid, s));
+    MV_TRY(mv_match_cov_pair_lanes(m0.depth, b.kp0f, b.sigma0, b.rot, b.cov0, b.cov0w, m1.depth, b.kp1, b.sigma1, b.cov1, &cp,
+                                   L, b.n_sel, cap, s));
+    MV_TRY(mv_obs_filter_lanes(b.inbound, b.cov0, b.cov1, b.vals, c.filters, c.filter_min_depth, c.max_depth, L, b.n_sel, cap,
+                               b.valid, b.n_valid, s));
     MV_HIP(hipEventRecord(p->e_backend[k], s));
     p->backend_valid[k] = true;
 
-    // ---- LM solve on the side stream; the optimised pose becomes the next frame's prior (StaticMotionModel)
+    // ---- LM solves of all lanes in ONE launch on the side stream (problem l = rows [l * cap, (l + 1) * cap), dead rows
+    // masked by `valid`); the optimised poses become the next frame's priors (StaticMotionModel)
     hipStream_t ss = p->s_side;
     MV_HIP(hipStreamWaitEvent(ss, p->e_backend[k], 0));
     const int nxt = (p->pose_cur + 1) % 3;
-    const size_t N = (size_t)n_sel;
-    MV_TRY(mv_pgo_solve(1, p->offs + 2 * N, c.graph_type, pose, p->intr, p->bl, b.pos_Tw, b.cov0w, b.kp1, b.vals + 4 * N,
-                        b.vals + 5 * N, b.vals + 6 * N, b.sigma1, b.cov1, b.valid, c.min_num_point, &c.lm, b.pose64, b.info,
+    const size_t N = (size_t)cap;
+    const size_t LN = (size_t)L * N;   // value table is [11, lanes, cap]: each of its rows is one concatenated per-point column
+    MV_TRY(mv_pgo_solve(L, p->offs, c.graph_type, pose, p->intr, p->bl, b.pos_Tw, b.cov0w, b.kp1, b.vals + 4 * LN,
+                        b.vals + 5 * LN, b.vals + 6 * LN, b.sigma1, b.cov1, b.valid, c.min_num_point, &c.lm, b.pose64, b.info,
                         p->pose[nxt], ss));
     if (pose_sink)
-        MV_HIP(hipMemcpyAsync(pose_sink, p->pose[nxt], 7 * sizeof(float), hipMemcpyDeviceToDevice, ss));
+        MV_HIP(hipMemcpyAsync(pose_sink, p->pose[nxt], (size_t)L * 7 * sizeof(float), hipMemcpyDeviceToDevice, ss));
     MV_HIP(hipEventRecord(p->e_pgo, ss));
     p->pgo_valid = true;
     p->pose_cur = nxt;
@@ -584,7 +603,7 @@ extern "C" int mv_frame_pipe_timeline(mvFramePipe* p, float* ms, int cap_frames,
 extern "C" int mv_frame_pipe_buffer(mvFramePipe* p, int which, int age, void** ptr, size_t* count) {
     MV_CHECK_ARG(p && ptr && count && age >= 0);
     const mvFramePipeConfig& c = p->c;
-    const size_t plane = p->plane;
+    const size_t L = p->lanes, plane = L * p->plane;   // every buffer has a leading [lanes] dimension (VALS: [11, lanes, cap])
     *ptr = nullptr;
     *count = 0;
     // frontend-side buffers: age 0 = the newest enqueued frame; backend-side: age 0 = the newest finished frame
@@ -592,7 +611,7 @@ extern "C" int mv_frame_pipe_buffer(mvFramePipe* p, int which, int age, void** p
     auto front = [&](int depth) { return f >= 0 && age < depth; };
     auto back = [&]() { return g >= 0 && age < 2; };
     const Backend* b = back() ? &p->be[g & 1] : nullptr;
-    const size_t N = b ? (size_t)b->n_sel : 0;
+    const size_t N = L * (size_t)(c.num_point > 0 ? c.num_point : 1);   // capacity rows (a lane's live rows: its n_sel)
     switch (which) {
         case MV_FB_VOLUME: if (!front(2)) break; *ptr = p->vol[f & 1]; *count = (size_t)c.pairs * p->n8 * p->n8; return MV_OK;
         case MV_FB_TOKENS: if (!front(1) || c.iters == 0) break; *ptr = p->tok[(c.iters - 1) & 1]; *count = (size_t)c.pairs * p->KK * p->n8; return MV_OK;
@@ -603,8 +622,8 @@ extern "C" int mv_frame_pipe_buffer(mvFramePipe* p, int which, int age, void** p
         case MV_FB_MATCH_FLOW: if (!front(N_MAPS)) break; *ptr = p->maps[f % N_MAPS].match_flow; *count = 2 * plane; return MV_OK;
         case MV_FB_MATCH_COV: if (!front(N_MAPS)) break; *ptr = p->maps[f % N_MAPS].match_cov; *count = 3 * plane; return MV_OK;
         case MV_FB_CAND: if (!front(2)) break; *ptr = p->cand[f & 1]; *count = plane; return MV_OK;
-        case MV_FB_COUNT: if (!front(2)) break; *ptr = p->count[f & 1]; *count = 4; return MV_OK;
-        case MV_FB_STATS: if (!front(2)) break; *ptr = p->stats[f & 1]; *count = 4; return MV_OK;
+        case MV_FB_COUNT: if (!front(2)) break; *ptr = p->count[f & 1]; *count = 4 * L; return MV_OK;
+        case MV_FB_STATS: if (!front(2)) break; *ptr = p->stats[f & 1]; *count = 4 * L; return MV_OK;
         case MV_FB_KP0: if (!b) break; *ptr = b->kp0; *count = 2 * N; return MV_OK;
         case MV_FB_KP0F: if (!b) break; *ptr = b->kp0f; *count = 2 * N; return MV_OK;
         case MV_FB_KP1: if (!b) break; *ptr = b->kp1; *count = 2 * N; return MV_OK;
@@ -614,15 +633,15 @@ extern "C" int mv_frame_pipe_buffer(mvFramePipe* p, int which, int age, void** p
         case MV_FB_SIGMA1: if (!b) break; *ptr = b->sigma1; *count = 3 * N; return MV_OK;
         case MV_FB_POS_TC: if (!b) break; *ptr = b->pos_Tc; *count = 3 * N; return MV_OK;
         case MV_FB_POS_TW: if (!b) break; *ptr = b->pos_Tw; *count = 3 * N; return MV_OK;
-        case MV_FB_ROT: if (!b) break; *ptr = b->rot; *count = 9; return MV_OK;
+        case MV_FB_ROT: if (!b) break; *ptr = b->rot; *count = 9 * L; return MV_OK;
         case MV_FB_COV0: if (!b) break; *ptr = b->cov0; *count = 9 * N; return MV_OK;
         case MV_FB_COV0W: if (!b) break; *ptr = b->cov0w; *count = 9 * N; return MV_OK;
         case MV_FB_COV1: if (!b) break; *ptr = b->cov1; *count = 9 * N; return MV_OK;
         case MV_FB_VALID: if (!b) break; *ptr = b->valid; *count = N; return MV_OK;
-        case MV_FB_NVALID: if (!b) break; *ptr = b->n_valid; *count = 1; return MV_OK;
-        case MV_FB_POSE64: if (!b) break; *ptr = b->pose64; *count = 7; return MV_OK;
-        case MV_FB_INFO: if (!b) break; *ptr = b->info; *count = 4; return MV_OK;
-        case MV_FB_POSE: if (age > 1) break; *ptr = p->pose[(p->pose_cur + 3 - age) % 3]; *count = 7; return MV_OK;
+        case MV_FB_NVALID: if (!b) break; *ptr = b->n_valid; *count = L; return MV_OK;
+        case MV_FB_POSE64: if (!b) break; *ptr = b->pose64; *count = 7 * L; return MV_OK;
+        case MV_FB_INFO: if (!b) break; *ptr = b->info; *count = 4 * L; return MV_OK;
+        case MV_FB_POSE: if (age > 1) break; *ptr = p->pose[(p->pose_cur + 3 - age) % 3]; *count = 7 * L; return MV_OK;
         default: break;
     }
     return MV_ERR_INVALID_ARG;

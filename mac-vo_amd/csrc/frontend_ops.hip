@@ -17,6 +17,16 @@ __global__ __launch_bounds__(256) void frontend_epilogue_kernel(
     float bl_fx_sq, float* __restrict__ disparity, float* __restrict__ disparity_cov, float* __restrict__ depth,
     float* __restrict__ depth_cov, uint8_t* __restrict__ bad_mask, float* __restrict__ match_flow,
     float* __restrict__ match_cov) {
+    // lane-batched (blockIdx.y = lane): inputs [lanes, 2, 2, H, W], every output [lanes, ch, H, W]
+    const size_t lo = (size_t)blockIdx.y * plane;
+    flow += 4 * lo; logcov += 4 * lo;
+    if (disparity) disparity += lo;
+    if (disparity_cov) disparity_cov += lo;
+    if (depth) depth += lo;
+    if (depth_cov) depth_cov += lo;
+    if (bad_mask) bad_mask += lo;
+    if (match_flow) match_flow += 2 * lo;
+    if (match_cov) match_cov += 3 * lo;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
         // sample 0 (stereo pair): flow[0,0] -> disparity, cov[0,0] -> disparity variance
         const float fx0 = flow[i];
@@ -46,7 +56,10 @@ __global__ __launch_bounds__(256) void frontend_epilogue_kernel(
     }
 }
 
-__global__ __launch_bounds__(256) void kp_track_kernel(const int64_t* __restrict__ kp0_uv, int N,
+// Lane-batched: blockIdx.y = lane; every per-keypoint table is [lanes, ..., cap] with `cap` rows of capacity per lane of
+// which cnt.n[lane] are live (rows beyond are left untouched); every map is [lanes, ch, H, W].  lanes = 1, cap = N is the
+// plain single-frame call.
+__global__ __launch_bounds__(256) void kp_track_kernel(const int64_t* __restrict__ kp0_uv, int N, mvLaneCounts cnt,
                                                        const float* __restrict__ match_flow,
                                                        const float* __restrict__ match_cov,
                                                        const float* __restrict__ depth0, const float* __restrict__ disp0,
@@ -58,8 +71,28 @@ __global__ __launch_bounds__(256) void kp_track_kernel(const int64_t* __restrict
                                                        uint8_t* __restrict__ out_inbound, float* __restrict__ out_vals,
                                                        float* __restrict__ out_sigma0, float* __restrict__ out_sigma1) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+    const int lane = blockIdx.y;
+    if (n >= cnt.n[lane]) return;
     const int plane = H * W;
+    {
+        const size_t lp = (size_t)lane * plane, ln = (size_t)lane * N;
+        kp0_uv += 2 * ln;
+        match_flow += 2 * lp;
+        if (match_cov) match_cov += 3 * lp;
+        depth0 += lp; depth1 += lp;
+        if (disp0) disp0 += lp;
+        if (sdisp0) sdisp0 += lp;
+        if (sdd0) sdd0 += lp;
+        if (disp1) disp1 += lp;
+        if (sdisp1) sdisp1 += lp;
+        if (sdd1) sdd1 += lp;
+        if (out_kp0) out_kp0 += 2 * ln;
+        out_kp1 += 2 * ln;
+        out_inbound += ln;
+        out_vals += ln;   // SoA table [11, lanes, cap]: row stride = lanes * cap
+        if (out_sigma0) out_sigma0 += 3 * ln;
+        if (out_sigma1) out_sigma1 += 3 * ln;
+    }
     const int u0 = (int)kp0_uv[2 * n], v0 = (int)kp0_uv[2 * n + 1];
     const bool ok0 = u0 >= 0 && u0 < W && v0 >= 0 && v0 < H;
     const int i0 = ok0 ? v0 * W + u0 : 0;
@@ -71,25 +104,26 @@ __global__ __launch_bounds__(256) void kp_track_kernel(const int64_t* __restrict
     out_kp1[2 * n] = u1;
     out_kp1[2 * n + 1] = v1;
     out_inbound[n] = inb;
-    float* o = out_vals + n;   // SoA: column k lives at out_vals[k * N + n]
-    o[0 * (size_t)N] = depth0[i0];
-    o[1 * (size_t)N] = disp0 ? disp0[i0] : -1.f;
-    o[2 * (size_t)N] = sdisp0 ? sdisp0[i0] : -1.f;
-    o[3 * (size_t)N] = sdd0 ? sdd0[i0] : -1.f;
+    float* o = out_vals + n;   // SoA: column k of lane l lives at out_vals[(k * lanes + l) * N + n]
+    const size_t vs = (size_t)gridDim.y * N;
+    o[0 * vs] = depth0[i0];
+    o[1 * vs] = disp0 ? disp0[i0] : -1.f;
+    o[2 * vs] = sdisp0 ? sdisp0[i0] : -1.f;
+    o[3 * vs] = sdd0 ? sdd0[i0] : -1.f;
     if (inb) {
         const int i1 = (int)v1 * W + (int)u1;  // .long(): truncation toward zero
-        o[4 * (size_t)N] = depth1[i1];
-        o[5 * (size_t)N] = disp1 ? disp1[i1] : -1.f;
-        o[6 * (size_t)N] = sdisp1 ? sdisp1[i1] : -1.f;
-        o[7 * (size_t)N] = sdd1 ? sdd1[i1] : -1.f;
+        o[4 * vs] = depth1[i1];
+        o[5 * vs] = disp1 ? disp1[i1] : -1.f;
+        o[6 * vs] = sdisp1 ? sdisp1[i1] : -1.f;
+        o[7 * vs] = sdd1 ? sdd1[i1] : -1.f;
     } else {
-        o[4 * (size_t)N] = o[5 * (size_t)N] = o[6 * (size_t)N] = o[7 * (size_t)N] = 0.f;
+        o[4 * vs] = o[5 * vs] = o[6 * vs] = o[7 * vs] = 0.f;
     }
     // match covariance is read at the SOURCE pixel kp0 (MACVO.py:231)
     const float suu = match_cov ? match_cov[i0] : -1.f;
     const float svv = match_cov ? match_cov[plane + i0] : -1.f;
     const float suv = match_cov ? match_cov[2 * plane + i0] : -1.f;
-    o[8 * (size_t)N] = suu; o[9 * (size_t)N] = svv; o[10 * (size_t)N] = suv;
+    o[8 * vs] = suu; o[9 * vs] = svv; o[10 * vs] = suv;
     if (out_sigma1) { out_sigma1[3 * n] = suu; out_sigma1[3 * n + 1] = svv; out_sigma1[3 * n + 2] = suv; }
     // kp0 carries the constant quantisation sigma (MACVO.py:228-229)
     if (out_sigma0) { out_sigma0[3 * n] = match_cov_default; out_sigma0[3 * n + 1] = match_cov_default; out_sigma0[3 * n + 2] = 0.f; }
@@ -108,10 +142,23 @@ __device__ __forceinline__ void quat_act_f32(const float* q, const float* p, flo
 __global__ __launch_bounds__(256) void backproject_kernel(const float* __restrict__ kp_uv,
                                                           const float* __restrict__ depth_vals, int depth_stride,
                                                           float fx, float fy, float cx, float cy,
-                                                          const float* __restrict__ pose, int N,
+                                                          const float* __restrict__ pose, int cap, mvLaneCounts cnt,
+                                                          size_t depth_lane_stride,
                                                           float* __restrict__ pos_Tc, float* __restrict__ pos_Tw,
                                                           double* __restrict__ rot) {
+    // lane-batched (blockIdx.y = lane): kp_uv / pos_* are [lanes, cap, .], pose [lanes, 7], rot [lanes, 9]
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = blockIdx.y;
+    const int N = cnt.n[lane];
+    {
+        const size_t ln = (size_t)lane * cap;
+        if (kp_uv) kp_uv += 2 * ln;
+        if (depth_vals) depth_vals += (size_t)lane * depth_lane_stride;
+        if (pose) pose += 7 * lane;
+        if (pos_Tc) pos_Tc += 3 * ln;
+        if (pos_Tw) pos_Tw += 3 * ln;
+        if (rot) rot += 9 * lane;
+    }
     float t[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1};
     if (pose) {
         t[0] = pose[0]; t[1] = pose[1]; t[2] = pose[2];
@@ -184,15 +231,28 @@ __global__ __launch_bounds__(256) void obs_filter_kernel(const uint8_t* __restri
                                                          const double* __restrict__ cov1,
                                                          const double* __restrict__ cov2,
                                                          const float* __restrict__ vals, int flags,
-                                                         float min_depth, float max_depth, int N,
+                                                         float min_depth, float max_depth, int cap, mvLaneCounts cnt,
                                                          uint8_t* __restrict__ valid, int32_t* __restrict__ count) {
-    // single workgroup: N <= a few thousand observations
+    // one workgroup per lane (blockIdx.x): N <= a few thousand observations.  Tables are [lanes, ., cap]; rows in
+    // [n_live, cap) are written as invalid so that a capacity-strided solve (mv_pgo_solve with static offsets) skips them.
+    const int lane = blockIdx.x;
+    const int N = cnt.n[lane];
+    {
+        const size_t ln = (size_t)lane * cap;
+        if (inbound) inbound += ln;
+        if (cov1) cov1 += 9 * ln;
+        if (cov2) cov2 += 9 * ln;
+        if (vals) vals += ln;   // SoA table [11, lanes, cap]
+        valid += ln;
+        count += lane;
+    }
+    const size_t vs = (size_t)gridDim.x * cap;
     __shared__ int total;
     if (threadIdx.x == 0) total = 0;
     // LikelyFrontOfCamFilter: if ANY pixel1_d_cov is the -1 placeholder the filter lets every row pass (:133-136)
     int has_placeholder = 0;
     if (flags & 4)
-        for (int n = threadIdx.x; n < N; n += blockDim.x) has_placeholder |= (vals[3 * (size_t)N + n] == -1.f);
+        for (int n = threadIdx.x; n < N; n += blockDim.x) has_placeholder |= (vals[3 * vs + n] == -1.f);
     const bool front_off = __syncthreads_or(has_placeholder) != 0;
     int local = 0;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
@@ -205,7 +265,7 @@ __global__ __launch_bounds__(256) void obs_filter_kernel(const uint8_t* __restri
             }
         }
         if (ok && (flags & 6)) {
-            const float d1 = vals[n], d2 = vals[4 * (size_t)N + n], c1 = vals[3 * (size_t)N + n], c2 = vals[7 * (size_t)N + n];
+            const float d1 = vals[n], d2 = vals[4 * vs + n], c1 = vals[3 * vs + n], c2 = vals[7 * vs + n];
             if (flags & 2)  // SimpleDepthFilter (:103-121)
                 ok = !((d1 < min_depth) || (d1 > max_depth) || (d2 < min_depth) || (d2 > max_depth));
             if (ok && (flags & 4) && !front_off)  // LikelyFrontOfCamFilter (:124-141)
@@ -214,6 +274,7 @@ __global__ __launch_bounds__(256) void obs_filter_kernel(const uint8_t* __restri
         valid[n] = ok;
         local += ok;
     }
+    for (int n = N + threadIdx.x; n < cap; n += blockDim.x) valid[n] = 0;
     local = wave_sum(local);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(&total, local);
     __syncthreads();
@@ -222,16 +283,54 @@ __global__ __launch_bounds__(256) void obs_filter_kernel(const uint8_t* __restri
 
 }  // namespace
 
+static inline int check_lanes(int lanes, const int32_t* n_live, int cap, mvLaneCounts& c, int& n_max) {
+    MV_CHECK_ARG(lanes >= 1 && lanes <= MV_MAX_LANES && n_live && cap >= 0);
+    n_max = 0;
+    for (int l = 0; l < lanes; ++l) {
+        MV_CHECK_ARG(n_live[l] >= 0 && n_live[l] <= cap);
+        c.n[l] = n_live[l];
+        n_max = n_live[l] > n_max ? n_live[l] : n_max;
+    }
+    return MV_OK;
+}
+
+extern "C" int mv_frontend_epilogue_lanes(const float* flow, const float* logcov, int cov_is_log, int H, int W,
+                                          float bl_fx, float bl_fx_sq, float* disparity, float* disparity_cov,
+                                          float* depth, float* depth_cov, uint8_t* bad_mask, float* match_flow,
+                                          float* match_cov, int lanes, mvStream_t stream) {
+    MV_CHECK_ARG(flow && logcov && H > 0 && W > 0 && lanes >= 1 && lanes <= MV_MAX_LANES);
+    const int plane = H * W;
+    const int blocks = min(mv_ceil_div(plane, 256), 2048);
+    hipLaunchKernelGGL(frontend_epilogue_kernel, dim3(blocks, lanes), dim3(256), 0, (hipStream_t)stream, flow, logcov,
+                       cov_is_log, plane, bl_fx, bl_fx_sq, disparity, disparity_cov, depth, depth_cov, bad_mask,
+                       match_flow, match_cov);
+    return mv_launch_status();
+}
+
 extern "C" int mv_frontend_epilogue(const float* flow, const float* logcov, int cov_is_log, int H, int W,
                                     float bl_fx, float bl_fx_sq, float* disparity, float* disparity_cov, float* depth,
                                     float* depth_cov, uint8_t* bad_mask, float* match_flow, float* match_cov,
                                     mvStream_t stream) {
-    MV_CHECK_ARG(flow && logcov && H > 0 && W > 0);
-    const int plane = H * W;
-    const int blocks = min(mv_ceil_div(plane, 256), 2048);
-    hipLaunchKernelGGL(frontend_epilogue_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, flow, logcov,
-                       cov_is_log, plane, bl_fx, bl_fx_sq, disparity, disparity_cov, depth, depth_cov, bad_mask,
-                       match_flow, match_cov);
+    return mv_frontend_epilogue_lanes(flow, logcov, cov_is_log, H, W, bl_fx, bl_fx_sq, disparity, disparity_cov, depth,
+                                      depth_cov, bad_mask, match_flow, match_cov, 1, stream);
+}
+
+extern "C" int mv_kp_track_lanes(const int64_t* kp0_uv, int lanes, const int32_t* n_live, int cap, const float* match_flow,
+                                 const float* match_cov, const float* depth0, const float* disp0, const float* sdisp0,
+                                 const float* sdd0, const float* depth1, const float* disp1, const float* sdisp1,
+                                 const float* sdd1, int H, int W, int edge, float match_cov_default, float* out_kp0,
+                                 float* out_kp1, uint8_t* out_inbound, float* out_vals, float* out_sigma0,
+                                 float* out_sigma1, mvStream_t stream) {
+    MV_CHECK_ARG(H > 0 && W > 0 && edge >= 0);
+    mvLaneCounts c{};
+    int n_max = 0;
+    const int rc = check_lanes(lanes, n_live, cap, c, n_max);
+    if (rc != MV_OK) return rc;
+    if (n_max == 0) return MV_OK;
+    MV_CHECK_ARG(kp0_uv && match_flow && depth0 && depth1 && out_kp1 && out_inbound && out_vals);
+    hipLaunchKernelGGL(kp_track_kernel, dim3(mv_ceil_div(n_max, 256), lanes), dim3(256), 0, (hipStream_t)stream, kp0_uv, cap,
+                       c, match_flow, match_cov, depth0, disp0, sdisp0, sdd0, depth1, disp1, sdisp1, sdd1, H, W, edge,
+                       match_cov_default, out_kp0, out_kp1, out_inbound, out_vals, out_sigma0, out_sigma1);
     return mv_launch_status();
 }
 
@@ -241,39 +340,64 @@ extern "C" int mv_kp_track(const int64_t* kp0_uv, int N, const float* match_flow
                            int W, int edge, float match_cov_default, float* out_kp0, float* out_kp1,
                            uint8_t* out_inbound, float* out_vals, float* out_sigma0, float* out_sigma1,
                            mvStream_t stream) {
-    MV_CHECK_ARG(N >= 0 && H > 0 && W > 0 && edge >= 0);
-    if (N == 0) return MV_OK;
-    MV_CHECK_ARG(kp0_uv && match_flow && depth0 && depth1 && out_kp1 && out_inbound && out_vals);
-    hipLaunchKernelGGL(kp_track_kernel, dim3(mv_ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, kp0_uv, N,
-                       match_flow, match_cov, depth0, disp0, sdisp0, sdd0, depth1, disp1, sdisp1, sdd1, H, W, edge,
-                       match_cov_default, out_kp0, out_kp1, out_inbound, out_vals, out_sigma0, out_sigma1);
+    MV_CHECK_ARG(N >= 0);
+    const int32_t n = N;
+    return mv_kp_track_lanes(kp0_uv, 1, &n, N, match_flow, match_cov, depth0, disp0, sdisp0, sdd0, depth1, disp1, sdisp1,
+                             sdd1, H, W, edge, match_cov_default, out_kp0, out_kp1, out_inbound, out_vals, out_sigma0,
+                             out_sigma1, stream);
+}
+
+extern "C" int mv_backproject_lanes(const float* kp_uv, const float* depth_vals, int depth_stride, size_t depth_lane_stride,
+                                    float fx, float fy, float cx, float cy, const float* pose, int lanes,
+                                    const int32_t* n_live, int cap, float* pos_Tc, float* pos_Tw, double* rot,
+                                    mvStream_t stream) {
+    MV_CHECK_ARG(depth_stride >= 1);
+    MV_CHECK_ARG((!pos_Tw && !rot) || pose);
+    mvLaneCounts c{};
+    int n_max = 0;
+    const int rc = check_lanes(lanes, n_live, cap, c, n_max);
+    if (rc != MV_OK) return rc;
+    if (n_max == 0 && !rot) return MV_OK;
+    MV_CHECK_ARG(n_max == 0 || (kp_uv && depth_vals));
+    hipLaunchKernelGGL(backproject_kernel, dim3(n_max > 0 ? mv_ceil_div(n_max, 256) : 1, lanes), dim3(256), 0,
+                       (hipStream_t)stream, kp_uv, depth_vals, depth_stride, fx, fy, cx, cy, pose, cap, c,
+                       depth_lane_stride, pos_Tc, pos_Tw, rot);
     return mv_launch_status();
 }
 
 extern "C" int mv_backproject(const float* kp_uv, const float* depth_vals, int depth_stride, float fx, float fy,
                               float cx, float cy, const float* pose, int N, float* pos_Tc, float* pos_Tw, double* rot,
                               mvStream_t stream) {
-    MV_CHECK_ARG(N >= 0 && depth_stride >= 1);
-    MV_CHECK_ARG((!pos_Tw && !rot) || pose);
-    if (N == 0 && !rot) return MV_OK;
-    MV_CHECK_ARG(N == 0 || (kp_uv && depth_vals));
-    hipLaunchKernelGGL(backproject_kernel, dim3(N > 0 ? mv_ceil_div(N, 256) : 1), dim3(256), 0, (hipStream_t)stream,
-                       kp_uv, depth_vals, depth_stride, fx, fy, cx, cy, pose, N, pos_Tc, pos_Tw, rot);
+    MV_CHECK_ARG(N >= 0);
+    const int32_t n = N;
+    return mv_backproject_lanes(kp_uv, depth_vals, depth_stride, 0, fx, fy, cx, cy, pose, 1, &n, N, pos_Tc, pos_Tw, rot,
+                                stream);
+}
+
+extern "C" int mv_obs_filter_lanes(const uint8_t* inbound, const double* cov1, const double* cov2, const float* vals,
+                                   int flags, float min_depth, float max_depth, int lanes, const int32_t* n_live, int cap,
+                                   uint8_t* valid, int32_t* count, mvStream_t stream) {
+    MV_CHECK_ARG(count);
+    mvLaneCounts c{};
+    int n_max = 0;
+    const int rc = check_lanes(lanes, n_live, cap, c, n_max);
+    if (rc != MV_OK) return rc;
+    if (cap > 0) {
+        MV_CHECK_ARG(valid);
+        MV_CHECK_ARG(n_max == 0 || !(flags & 1) || (cov1 && cov2));
+        MV_CHECK_ARG(n_max == 0 || !(flags & 6) || vals);
+    }
+    hipLaunchKernelGGL(obs_filter_kernel, dim3(lanes), dim3(256), 0, (hipStream_t)stream, inbound, cov1, cov2, vals,
+                       flags, min_depth, max_depth, cap, c, valid, count);
     return mv_launch_status();
 }
 
 extern "C" int mv_obs_filter(const uint8_t* inbound, const double* cov1, const double* cov2, const float* vals,
                              int flags, float min_depth, float max_depth, int N, uint8_t* valid, int32_t* count,
                              mvStream_t stream) {
-    MV_CHECK_ARG(N >= 0 && count);
-    if (N > 0) {
-        MV_CHECK_ARG(valid);
-        MV_CHECK_ARG(!(flags & 1) || (cov1 && cov2));
-        MV_CHECK_ARG(!(flags & 6) || vals);
-    }
-    hipLaunchKernelGGL(obs_filter_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, inbound, cov1, cov2, vals,
-                       flags, min_depth, max_depth, N, valid, count);
-    return mv_launch_status();
+    MV_CHECK_ARG(N >= 0);
+    const int32_t n = N;
+    return mv_obs_filter_lanes(inbound, cov1, cov2, vals, flags, min_depth, max_depth, 1, &n, N, valid, count, stream);
 }
 
 extern "C" int mv_map_points(const int64_t* uv, int N, const float* depth, const float* depth_cov, const float* image, int H,

@@ -50,6 +50,13 @@ struct KpWs {
     float* rec_q;       // flow quality of the NMS pixel      (population of the flow-cov median)
     float* rec_d;       // depth0 variance of the NMS pixel   (population of the depth-cov median, FULL only)
     int* counters;      // [0] = number of records (= NMS pixels)
+    size_t lane_bytes;  // lane-batched launches: lane l works in the workspace copy at + l * lane_bytes
+
+    __device__ __forceinline__ KpWs lane(int l) const {
+        const size_t o = (size_t)l * lane_bytes;
+        return KpWs{(unsigned long long*)((char*)cand_bits + o), (unsigned*)((char*)rec_idx + o), (float*)((char*)rec_q + o),
+                    (float*)((char*)rec_d + o), (int*)((char*)counters + o), lane_bytes};
+    }
 };
 
 __device__ __forceinline__ float flow_quality(const float* __restrict__ fc, int plane, int idx) {
@@ -66,7 +73,19 @@ __global__ __launch_bounds__(256) void kp_nms_kernel(const float* __restrict__ f
                                                       const float* __restrict__ d1c,
                                                       const uint8_t* __restrict__ mask_a,
                                                       const uint8_t* __restrict__ mask_b, mvKpSelectParams p,
-                                                      KpWs ws, int words_per_row) {
+                                                      KpWs ws_all, int words_per_row) {
+    // lane-batched: blockIdx.z = lane (independent frame); maps are [lanes, ch, H, W], one workspace copy per lane
+    const KpWs ws = ws_all.lane(blockIdx.z);
+    {
+        const size_t lp = (size_t)blockIdx.z * p.H * p.W;
+        if (fc) fc += 3 * lp;
+        if (d0) d0 += lp;
+        if (d0c) d0c += lp;
+        if (d1) d1 += lp;
+        if (d1c) d1c += lp;
+        if (mask_a) mask_a += lp;
+        if (mask_b) mask_b += lp;
+    }
     __shared__ float tile[TILE_H + 2 * MAX_R][TILE_W + 2 * MAX_R + 1];
     __shared__ float hmin[TILE_H + 2 * MAX_R][TILE_W + 1];
     __shared__ int wg_count, wg_base;
@@ -528,11 +547,16 @@ __device__ __forceinline__ void kp_finish_body(const mvKpSelectParams& p, const 
 // <16, 5> covers 640x480-class images (2 chunks of 20 KB), <24, 15> up to 1280x768 (8 chunks of 15 KB; 24 slots keep
 // the kernel inside 128 VGPRs without scratch).
 template <int NT, int RPT, int WPT, bool USE_D>
-__global__ __launch_bounds__(NT) void kp_finish_kernel(mvKpSelectParams p, KpWs ws, int has_flow, int words_per_row,
+__global__ __launch_bounds__(NT) void kp_finish_kernel(mvKpSelectParams p, KpWs ws_all, int has_flow, int words_per_row,
                                                         int32_t* __restrict__ out_cand, int32_t* __restrict__ out_count,
                                                         float* __restrict__ out_stats) {
     __shared__ MedianLds L;
     extern __shared__ unsigned long long lds_words[];
+    // lane-batched: one finishing workgroup per lane (blockIdx.x); out_cand [lanes, H*W], out_count / out_stats [lanes, 4]
+    const KpWs ws = ws_all.lane(blockIdx.x);
+    out_cand += (size_t)blockIdx.x * p.H * p.W;
+    out_count += 4 * blockIdx.x;
+    out_stats += 4 * blockIdx.x;
     const int n_rec = p.mode == MV_KP_MAPPING ? 0 : ws.counters[0];
     if (n_rec <= RPT * NT && p.H * words_per_row <= WPT * NT)
         kp_finish_body<NT, true, RPT, WPT, USE_D>(p, ws, has_flow, words_per_row, out_cand, out_count, out_stats, n_rec, L,
@@ -544,9 +568,9 @@ __global__ __launch_bounds__(NT) void kp_finish_kernel(mvKpSelectParams p, KpWs 
 
 template <int NT, int RPT, int WPT, bool USE_D>
 static int launch_finish(const mvKpSelectParams& p, const KpWs& ws, int has_flow, int wpr, int32_t* out_cand,
-                         int32_t* out_count, float* out_stats, hipStream_t s) {
+                         int32_t* out_count, float* out_stats, int lanes, hipStream_t s) {
     const size_t dyn = (size_t)WPT * (NT / (WPT > 5 * 1024 / NT ? 8 : 2)) * sizeof(unsigned long long);   // one chunk of words
-    hipLaunchKernelGGL((kp_finish_kernel<NT, RPT, WPT, USE_D>), dim3(1), dim3(NT), dyn, s, p, ws, has_flow, wpr, out_cand,
+    hipLaunchKernelGGL((kp_finish_kernel<NT, RPT, WPT, USE_D>), dim3(lanes), dim3(NT), dyn, s, p, ws, has_flow, wpr, out_cand,
                        out_count, out_stats);
     return MV_OK;
 }
@@ -593,9 +617,14 @@ __global__ __launch_bounds__(256) void kp_map_emit_kernel(const unsigned long lo
     }
 }
 
-__global__ void kp_gather_kernel(const int32_t* __restrict__ cand, const int64_t* __restrict__ perm, int n_sel,
-                                 int W, int64_t* __restrict__ out_uv) {
+__global__ void kp_gather_kernel(const int32_t* __restrict__ cand, const int64_t* __restrict__ perm, mvLaneCounts cnt,
+                                 int cap, size_t cand_lane_stride, int W, int64_t* __restrict__ out_uv) {
+    // lane-batched (blockIdx.y): cand [lanes, cand_lane_stride], perm / out_uv [lanes, cap(, 2)]
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_sel = cnt.n[blockIdx.y];
+    cand += (size_t)blockIdx.y * cand_lane_stride;
+    perm += (size_t)blockIdx.y * cap;
+    out_uv += 2 * (size_t)blockIdx.y * cap;
     if (i < n_sel) {
         const int lin = cand[perm[i]];
         out_uv[2 * i + 0] = lin % W;  // u
@@ -613,11 +642,12 @@ extern "C" size_t mv_kp_select_workspace_bytes(int H, int W) {
     return align_up(words * 8, 256) + 3 * align_up((size_t)H * W * 4, 256) + 256;
 }
 
-extern "C" int mv_kp_select(const float* flow_cov, const float* depth0, const float* depth0_cov,
-                            const float* depth1, const float* depth1_cov, const uint8_t* mask_a,
-                            const uint8_t* mask_b, const mvKpSelectParams* params, void* workspace,
-                            size_t workspace_bytes, int32_t* out_cand, int32_t* out_count, float* out_stats,
-                            mvStream_t stream) {
+extern "C" int mv_kp_select_lanes(const float* flow_cov, const float* depth0, const float* depth0_cov,
+                                  const float* depth1, const float* depth1_cov, const uint8_t* mask_a,
+                                  const uint8_t* mask_b, const mvKpSelectParams* params, void* workspace,
+                                  size_t workspace_bytes, int32_t* out_cand, int32_t* out_count, float* out_stats,
+                                  int lanes, mvStream_t stream) {
+    MV_CHECK_ARG(lanes >= 1 && lanes <= MV_MAX_LANES);
     MV_CHECK_ARG(params && workspace && out_cand && out_count && out_stats);
     const mvKpSelectParams p = *params;
     MV_CHECK_ARG(p.H > 0 && p.W > 0 && p.mask_width >= 0);
@@ -634,8 +664,10 @@ extern "C" int mv_kp_select(const float* flow_cov, const float* depth0, const fl
         MV_CHECK_ARG(p.kernel_size >= 1 && (p.kernel_size & 1));
         if (p.kernel_size > 2 * MAX_R + 1) return MV_ERR_UNSUPPORTED;
     }
-    if (workspace_bytes < mv_kp_select_workspace_bytes(p.H, p.W)) return MV_ERR_WORKSPACE;
+    const size_t lane_bytes = mv_kp_select_workspace_bytes(p.H, p.W);
+    if (workspace_bytes < lane_bytes * (size_t)lanes) return MV_ERR_WORKSPACE;
     if (((uintptr_t)workspace & 7) != 0) return MV_ERR_INVALID_ARG;
+    if (p.mode == MV_KP_MAPPING && lanes != 1) return MV_ERR_UNSUPPORTED;
 
     const int wpr = mv_ceil_div(p.W, 64);
     const size_t words = (size_t)p.H * wpr;
@@ -651,11 +683,12 @@ extern "C" int mv_kp_select(const float* flow_cov, const float* depth0, const fl
     ws.rec_d = (float*)base;
     base += plane_bytes;
     ws.counters = (int*)base;
+    ws.lane_bytes = lane_bytes;
 
     hipStream_t s = (hipStream_t)stream;
     // ws.counters must be zero on entry: the caller zero-fills the workspace once after allocating it, and every
     // call leaves it zeroed again (kp_finish_kernel) — this saves a 5-us fill launch per frame.
-    dim3 grid(wpr, mv_ceil_div(p.H, TILE_H)), block(64, 4);
+    dim3 grid(wpr, mv_ceil_div(p.H, TILE_H), lanes), block(64, 4);
     hipLaunchKernelGGL(kp_nms_kernel, grid, block, 0, s, flow_cov, depth0, depth0_cov, depth1, depth1_cov, mask_a,
                        mask_b, p, ws, wpr);
     if (p.mode == MV_KP_MAPPING) {
@@ -671,23 +704,46 @@ extern "C" int mv_kp_select(const float* flow_cov, const float* depth0, const fl
     int rc;
     static int small_nt = -1;   // MV_KP_FINISH_SMALL_NT=512: 8-wave finishing workgroup (fits beside a 3-per-CU GEMM)
     if (small_nt < 0) { const char* e = getenv("MV_KP_FINISH_SMALL_NT"); small_nt = (e && atoi(e) == 512) ? 512 : 1024; }
-    if (big) rc = full ? launch_finish<1024, 24, 15, true>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, s)
-                       : launch_finish<1024, 24, 15, false>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, s);
+    if (big) rc = full ? launch_finish<1024, 24, 15, true>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, lanes, s)
+                       : launch_finish<1024, 24, 15, false>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, lanes, s);
     else if (small_nt == 512)
-        rc = full ? launch_finish<512, 16, 10, true>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, s)
-                  : launch_finish<512, 16, 10, false>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, s);
-    else rc = full ? launch_finish<1024, 16, 5, true>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, s)
-                   : launch_finish<1024, 16, 5, false>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, s);
+        rc = full ? launch_finish<512, 16, 10, true>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, lanes, s)
+                  : launch_finish<512, 16, 10, false>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, lanes, s);
+    else rc = full ? launch_finish<1024, 16, 5, true>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, lanes, s)
+                   : launch_finish<1024, 16, 5, false>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, lanes, s);
     if (rc != MV_OK) return rc;
+    return mv_launch_status();
+}
+
+extern "C" int mv_kp_select(const float* flow_cov, const float* depth0, const float* depth0_cov,
+                            const float* depth1, const float* depth1_cov, const uint8_t* mask_a,
+                            const uint8_t* mask_b, const mvKpSelectParams* params, void* workspace,
+                            size_t workspace_bytes, int32_t* out_cand, int32_t* out_count, float* out_stats,
+                            mvStream_t stream) {
+    return mv_kp_select_lanes(flow_cov, depth0, depth0_cov, depth1, depth1_cov, mask_a, mask_b, params, workspace,
+                              workspace_bytes, out_cand, out_count, out_stats, 1, stream);
+}
+
+extern "C" int mv_kp_gather_lanes(const int32_t* cand, size_t cand_lane_stride, const int64_t* perm, int lanes,
+                                  const int32_t* n_live, int cap, int W, int64_t* out_uv, mvStream_t stream) {
+    MV_CHECK_ARG(lanes >= 1 && lanes <= MV_MAX_LANES && n_live && cap >= 0 && W > 0);
+    mvLaneCounts c{};
+    int n_max = 0;
+    for (int l = 0; l < lanes; ++l) {
+        MV_CHECK_ARG(n_live[l] >= 0 && n_live[l] <= cap);
+        c.n[l] = n_live[l];
+        n_max = n_live[l] > n_max ? n_live[l] : n_max;
+    }
+    if (n_max == 0) return MV_OK;
+    MV_CHECK_ARG(cand && perm && out_uv);
+    hipLaunchKernelGGL(kp_gather_kernel, dim3(mv_ceil_div(n_max, 256), lanes), dim3(256), 0, (hipStream_t)stream, cand, perm,
+                       c, cap, cand_lane_stride, W, out_uv);
     return mv_launch_status();
 }
 
 extern "C" int mv_kp_gather(const int32_t* cand, const int64_t* perm, int n_sel, int W, int64_t* out_uv,
                             mvStream_t stream) {
-    MV_CHECK_ARG(n_sel >= 0 && W > 0);
-    if (n_sel == 0) return MV_OK;
-    MV_CHECK_ARG(cand && perm && out_uv);
-    hipLaunchKernelGGL(kp_gather_kernel, dim3(mv_ceil_div(n_sel, 256)), dim3(256), 0, (hipStream_t)stream, cand, perm,
-                       n_sel, W, out_uv);
-    return mv_launch_status();
+    MV_CHECK_ARG(n_sel >= 0);
+    const int32_t n = n_sel;
+    return mv_kp_gather_lanes(cand, 0, perm, 1, &n, n_sel, W, out_uv, stream);
 }

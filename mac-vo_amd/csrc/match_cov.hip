@@ -34,19 +34,23 @@ struct CovSet {
     float* out_stats;
 };
 
-__global__ __launch_bounds__(256) void match_cov_kernel(CovSet s0, CovSet s1, mvMatchCovParams p, int N) {
+// Lane-batched: blockIdx.z = pipeline lane (independent sequence); per-keypoint tables are [lanes, cap, .] with
+// cnt.n[lane] live rows, depth maps [lanes, H, W], rot [lanes, 9].  lanes = 1, cap = N is the plain call.
+__global__ __launch_bounds__(256) void match_cov_kernel(CovSet s0, CovSet s1, mvMatchCovParams p, int cap, mvLaneCounts cnt) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;  // whole wave exits together
+    const int pl = blockIdx.z;
+    if (n >= cnt.n[pl]) return;  // whole wave exits together
     const CovSet& S = blockIdx.y ? s1 : s0;   // the frame's two keypoint sets (kp0 on depth0, kp1 on depth1) share a launch
-    const float* __restrict__ depth_map = S.depth_map;
-    const float* __restrict__ kp_uv = S.kp_uv;
-    float* __restrict__ flow_cov = S.flow_cov;
-    const float* __restrict__ depth_cov = S.depth_cov;
-    const double* __restrict__ rot = S.rot;
-    double* __restrict__ out_cov = S.out_cov;
-    double* __restrict__ out_cov_rot = S.out_cov_rot;
-    float* __restrict__ out_stats = S.out_stats;
+    const size_t ln = (size_t)pl * cap;
+    const float* __restrict__ depth_map = S.depth_map + (size_t)pl * p.H * p.W;
+    const float* __restrict__ kp_uv = S.kp_uv + 2 * ln;
+    float* __restrict__ flow_cov = S.flow_cov + 3 * ln;
+    const float* __restrict__ depth_cov = S.depth_cov ? S.depth_cov + ln : nullptr;
+    const double* __restrict__ rot = S.rot ? S.rot + 9 * pl : nullptr;
+    double* __restrict__ out_cov = S.out_cov + 9 * ln;
+    double* __restrict__ out_cov_rot = S.out_cov_rot ? S.out_cov_rot + 9 * ln : nullptr;
+    float* __restrict__ out_stats = S.out_stats ? S.out_stats + 2 * ln : nullptr;
 
     const float u = kp_uv[2 * n], v = kp_uv[2 * n + 1];
     const int iu = (int)u, iv = (int)v;  // .long(): truncation toward zero
@@ -161,16 +165,26 @@ extern "C" int mv_match_cov(const float* depth_map, const float* kp_uv, float* f
     MV_CHECK_ARG(p.use_patch_var || depth_cov);
     MV_CHECK_ARG(!out_cov_rot || rot);
     const CovSet s0{depth_map, kp_uv, flow_cov, depth_cov, rot, out_cov, out_cov_rot, out_stats};
-    hipLaunchKernelGGL(match_cov_kernel, dim3(mv_ceil_div(N, 4), 1), dim3(256), 0, (hipStream_t)stream, s0, s0, p, N);
+    mvLaneCounts c{};
+    c.n[0] = N;
+    hipLaunchKernelGGL(match_cov_kernel, dim3(mv_ceil_div(N, 4), 1, 1), dim3(256), 0, (hipStream_t)stream, s0, s0, p, N, c);
     return mv_launch_status();
 }
 
-extern "C" int mv_match_cov_pair(const float* depth_map0, const float* kp_uv0, float* flow_cov0, const double* rot0,
-                                 double* out_cov0, double* out_cov_rot0, const float* depth_map1, const float* kp_uv1,
-                                 float* flow_cov1, double* out_cov1, const mvMatchCovParams* params, int N,
-                                 mvStream_t stream) {
-    MV_CHECK_ARG(params && N >= 0);
-    if (N == 0) return MV_OK;
+extern "C" int mv_match_cov_pair_lanes(const float* depth_map0, const float* kp_uv0, float* flow_cov0, const double* rot0,
+                                       double* out_cov0, double* out_cov_rot0, const float* depth_map1,
+                                       const float* kp_uv1, float* flow_cov1, double* out_cov1,
+                                       const mvMatchCovParams* params, int lanes, const int32_t* n_live, int cap,
+                                       mvStream_t stream) {
+    MV_CHECK_ARG(params && lanes >= 1 && lanes <= MV_MAX_LANES && n_live && cap >= 0);
+    mvLaneCounts c{};
+    int n_max = 0;
+    for (int l = 0; l < lanes; ++l) {
+        MV_CHECK_ARG(n_live[l] >= 0 && n_live[l] <= cap);
+        c.n[l] = n_live[l];
+        n_max = n_live[l] > n_max ? n_live[l] : n_max;
+    }
+    if (n_max == 0) return MV_OK;
     MV_CHECK_ARG(depth_map0 && kp_uv0 && flow_cov0 && out_cov0 && depth_map1 && kp_uv1 && flow_cov1 && out_cov1);
     const mvMatchCovParams p = *params;
     MV_CHECK_ARG(p.H > 0 && p.W > 0 && p.kernel_size >= 1 && (p.kernel_size & 1) && p.use_patch_var);
@@ -178,6 +192,17 @@ extern "C" int mv_match_cov_pair(const float* depth_map0, const float* kp_uv0, f
     MV_CHECK_ARG(!out_cov_rot0 || rot0);
     const CovSet s0{depth_map0, kp_uv0, flow_cov0, nullptr, rot0, out_cov0, out_cov_rot0, nullptr};
     const CovSet s1{depth_map1, kp_uv1, flow_cov1, nullptr, nullptr, out_cov1, nullptr, nullptr};
-    hipLaunchKernelGGL(match_cov_kernel, dim3(mv_ceil_div(N, 4), 2), dim3(256), 0, (hipStream_t)stream, s0, s1, p, N);
+    hipLaunchKernelGGL(match_cov_kernel, dim3(mv_ceil_div(n_max, 4), 2, lanes), dim3(256), 0, (hipStream_t)stream, s0, s1, p,
+                       cap, c);
     return mv_launch_status();
+}
+
+extern "C" int mv_match_cov_pair(const float* depth_map0, const float* kp_uv0, float* flow_cov0, const double* rot0,
+                                 double* out_cov0, double* out_cov_rot0, const float* depth_map1, const float* kp_uv1,
+                                 float* flow_cov1, double* out_cov1, const mvMatchCovParams* params, int N,
+                                 mvStream_t stream) {
+    MV_CHECK_ARG(N >= 0);
+    const int32_t n = N;
+    return mv_match_cov_pair_lanes(depth_map0, kp_uv0, flow_cov0, rot0, out_cov0, out_cov_rot0, depth_map1, kp_uv1, flow_cov1,
+                                   out_cov1, params, 1, &n, N, stream);
 }

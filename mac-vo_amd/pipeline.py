@@ -381,14 +381,23 @@ class _Pending:
 
 
 # ====================================================================================== native driver (default)
-class _NativeResult:
-    """Result of one natively driven frame.  Every tensor is a VIEW into the pipe's arena: valid until two more
-    frames have been finished (slots rotate); clone what must live longer."""
+def stack_lanes(inputs: "list[FrameInputs]") -> FrameInputs:
+    """Batch the per-sequence inputs of ``len(inputs)`` independent sequences ("lanes") along the pair axis — the
+    reference's batching point (``Frontend.py:219-224``): lane l contributes pairs 2l (stereo) and 2l + 1 (temporal)."""
+    cat = lambda name, dim=0: (None if getattr(inputs[0], name) is None  # noqa: E731
+                               else torch.cat([getattr(x, name) for x in inputs], dim=dim).contiguous())
+    return FrameInputs(fmap1=cat("fmap1"), fmap2=cat("fmap2"), coords=cat("coords", 1), flow=cat("flow"), logcov=cat("logcov"),
+                       flow8=cat("flow8"), cov8=cat("cov8"), up_mask=cat("up_mask"), cov_mask=cat("cov_mask"),
+                       static=all(x.static for x in inputs))
 
-    def __init__(self, hp: "NativeHotPath", n_sel: int, n_cand: int, age_fix: int):
-        self._hp, self.n_sel, self.n_cand = hp, n_sel, n_cand
+
+class _NativeResult:
+    """Result of one natively driven frame of one lane.  Every tensor is a VIEW into the pipe's arena: valid until two
+    more frames have been finished (slots rotate); clone what must live longer."""
+
+    def __init__(self, hp: "NativeHotPath", lane: int, n_sel: int, n_cand: int):
+        self._hp, self.lane, self.n_sel, self.n_cand = hp, lane, n_sel, n_cand
         self._fin = hp._n_fin          # finish counter at creation: views are resolved against it
-        self.pose = hp.pose
         self.extras: dict = {}
 
     def _age(self) -> int:
@@ -397,42 +406,66 @@ class _NativeResult:
             raise ops.L.MacvoHipError("this frame's buffers were recycled (results are views; clone them earlier)")
         return age
 
-    def _b(self, name, dtype, shape):
-        return self._hp._view(name, self._age(), dtype, shape)
+    def _rows(self, name, dtype, tail=()):
+        """[n_sel, *tail] live rows of this lane in a per-keypoint table [lanes, cap, *tail]."""
+        hp = self._hp
+        return hp._view(name, self._age(), dtype, (hp.lanes, hp._cap) + tuple(tail))[self.lane, : self.n_sel]
+
+    def _per_lane(self, name, dtype, tail):
+        hp = self._hp
+        return hp._view(name, self._age(), dtype, (hp.lanes,) + tuple(tail))[self.lane]
+
+    @property
+    def pose(self):
+        """fp32 [7]: this lane's optimised pose (valid on a stream after ``sync_pose``)."""
+        return self._per_lane("POSE", torch.float32, (7,))
 
     @property
     def kp0_uv(self):
-        return self._b("KP0", torch.int64, (self.n_sel, 2))
+        return self._rows("KP0", torch.int64, (2,))
 
     @property
     def n_valid(self):
-        return self._b("NVALID", torch.int32, (1,)) if self.n_sel else None
+        return self._per_lane("NVALID", torch.int32, ())[None] if self.n_sel else None
 
     @property
     def pose_f64(self):
-        return self._b("POSE64", torch.float64, (1, 7)) if self.n_sel else None
+        return self._per_lane("POSE64", torch.float64, (7,))[None] if self.n_sel else None
 
     @property
     def info(self):
-        return self._b("INFO", torch.float64, (1, 4)) if self.n_sel else None
+        return self._per_lane("INFO", torch.float64, (4,))[None] if self.n_sel else None
 
 
 class NativeHotPath:
     """Same contract as :class:`HotPath`, but the per-frame sequencing (streams, events, buffer rotation, ~30 launches)
     runs in C++ (``mv_frame_pipe_*``, csrc/frame_pipe.hip): two host calls per frame instead of ~30 Python-level ones.
     The Python loop was interpreter-bound (~370 us/frame, more than the GPU work); kernels, launch order and arguments
-    are identical, so results are bit-identical to :class:`HotPath` (tests/test_gpu_native.py)."""
+    are identical, so results are bit-identical to :class:`HotPath` (tests/test_gpu_native.py).
+
+    ``lanes`` > 1 (BASELINE configs[4], "batch-32 frames per GPU"): that many INDEPENDENT sequences advance in lock-step
+    through the same launches — one volume GEMM over ``2 * lanes`` pairs, lane-batched lookups / epilogue / selector /
+    backend kernels, one batched LM solve.  Inputs are the per-lane :class:`FrameInputs` concatenated along the pair axis
+    (:func:`stack_lanes`); ``finish`` then returns one result per lane.  Each lane draws its keypoint permutation from its
+    own CPU generator (``generators[l]``; ``None`` = torch's global generator, which is what the reference consumes), in
+    lane order — a lane seeded like a stand-alone run therefore selects exactly the keypoints of that stand-alone run."""
 
     def __init__(self, cam: Camera, cfg: HotPathConfig | None = None, device: str | torch.device = "cuda",
-                 keep_extras: bool = False):
+                 keep_extras: bool = False, lanes: int = 1, generators: "list | None" = None):
         self.cam, self.cfg = cam, cfg or HotPathConfig()
         if self.cfg.mapping:
             raise ops.L.MacvoHipError("the dense-mapping tail (mapping=True) is sequenced by pipeline.HotPath only: its cost is "
                                       "the host-side torch.randperm(n ~ 1e5), which the native driver cannot hide")
         if self.cfg.use_graphs:
             raise ops.L.MacvoHipError("use_graphs belongs to the Python-sequenced pipeline.HotPath")
+        if not 1 <= lanes <= ops.L.MV_MAX_LANES:
+            raise ops.L.MacvoHipError(f"lanes must be in [1, {ops.L.MV_MAX_LANES}]")
         self.dev = torch.device(device)
         self.keep_extras = keep_extras
+        self.lanes = int(lanes)
+        self.generators = list(generators) if generators is not None else [None] * self.lanes
+        assert len(self.generators) == self.lanes
+        self._cap = max(self.cfg.num_point, 1)
         self.lm = ops.lm_default_params()
         self._pipe = None
         self._arena = None
@@ -441,7 +474,9 @@ class NativeHotPath:
         self._n_enq = 0
         self._pending: list = []
         self._init_pose = None
-        self._ncand = ops.C.c_int32(0)
+        self._ncand = (ops.C.c_int32 * self.lanes)()
+        self._nsel = (ops.C.c_int32 * self.lanes)()
+        self._perm = torch.zeros((self.lanes, self._cap), dtype=torch.int64)
         self._ptr = ops.C.c_void_p()
         self._cnt = ops.C.c_size_t()
 
@@ -452,6 +487,8 @@ class NativeHotPath:
         lib = L.load()
         hwc = c.feature_layout == "hwc"
         pairs = x.fmap1.shape[0]
+        if pairs != 2 * self.lanes:
+            raise L.MacvoHipError(f"inputs carry {pairs} pairs but the pipe has {self.lanes} lane(s) (2 pairs per lane)")
         chans = x.fmap1.shape[-1] if hwc else x.fmap1.shape[1]
         dt = {torch.float32: L.MV_F32, torch.float16: L.MV_F16, torch.bfloat16: L.MV_BF16}[x.fmap1.dtype]
         bl_fx = float(cam.baseline) * float(cam.fx)
@@ -483,7 +520,11 @@ class NativeHotPath:
             self._pipe = None
 
     def _set_pose(self, pose: torch.Tensor) -> None:
-        host = pose.detach().to("cpu", torch.float32).reshape(7).contiguous()
+        host = pose.detach().to("cpu", torch.float32).reshape(-1, 7)
+        if host.shape[0] == 1 and self.lanes > 1:
+            host = host.expand(self.lanes, 7)
+        assert host.shape[0] == self.lanes, "pose must be [7] or [lanes, 7]"
+        host = host.contiguous()
         ops.L.check(self._lib.mv_frame_pipe_set_pose(self._pipe, host.data_ptr()), "mv_frame_pipe_set_pose")
 
     def _view(self, name: str, age: int, dtype: torch.dtype, shape: tuple) -> torch.Tensor:
@@ -505,8 +546,10 @@ class NativeHotPath:
 
     @property
     def pose(self) -> torch.Tensor:
-        """fp32 ``[7]`` view of the newest solve's output (valid on a stream after :meth:`sync_pose`)."""
-        return self._view("POSE", 0, torch.float32, (7,))
+        """fp32 ``[7]`` (``[lanes, 7]`` for lanes > 1) view of the newest solve's output (valid on a stream after
+        :meth:`sync_pose`)."""
+        v = self._view("POSE", 0, torch.float32, (self.lanes, 7))
+        return v[0] if self.lanes == 1 else v
 
     @pose.setter
     def pose(self, value: torch.Tensor) -> None:
@@ -522,9 +565,9 @@ class NativeHotPath:
         k = 2 * self.cfg.radius + 1
         return self._view("TOKENS", 0, torch.float32, (self._pc.pairs, k * k, self.cam.H // 8, self.cam.W // 8))
 
-    def maps(self, age: int = 0) -> "ops.FrontendMaps":
+    def maps(self, age: int = 0, lane: int = 0) -> "ops.FrontendMaps":
         H, W = self.cam.H, self.cam.W
-        v = lambda n, c: self._view(n, age, torch.float32, (1, c, H, W))  # noqa: E731
+        v = lambda n, c: self._view(n, age, torch.float32, (self.lanes, c, H, W))[lane: lane + 1]  # noqa: E731
         return ops.FrontendMaps(v("DEPTH", 1), v("DEPTH_COV", 1), v("DISPARITY", 1), v("DISPARITY_COV", 1), None,
                                 v("MATCH_FLOW", 2), v("MATCH_COV", 3))
 
@@ -533,7 +576,6 @@ class NativeHotPath:
         st = getattr(x, "_native_struct", None)
         if st is not None and x.static:
             return st
-        c = self.cfg
         q = lambda t, dt=torch.float32: None if t is None else ops._req(t, dt, "frame input").data_ptr()  # noqa: E731
         st = ops.L.mvFrameInputs(q(x.fmap1, x.fmap1.dtype), q(x.fmap2, x.fmap2.dtype), q(x.coords), q(x.flow), q(x.logcov),
                                  q(x.flow8), q(x.cov8), q(x.up_mask), q(x.cov_mask))
@@ -561,28 +603,49 @@ class NativeHotPath:
         self._enqueue(x, True)
         return x
 
-    def finish(self, pend=None, pose_sink: torch.Tensor | None = None) -> _NativeResult:
+    def finish(self, pend=None, pose_sink: torch.Tensor | None = None):
+        """Host half of a frame: wait for the candidate counts, draw the permutations (CPU generators, lane order), enqueue
+        the pose-dependent kernels.  Returns a :class:`_NativeResult` (a list of them, one per lane, for lanes > 1)."""
         L, lib = ops.L, self._lib
-        L.check(lib.mv_frame_pipe_wait_candidates(self._pipe, ops.C.byref(self._ncand)), "mv_frame_pipe_wait_candidates")
-        n = self._ncand.value
-        perm = torch.randperm(n)[: self.cfg.num_point]            # global CPU generator, exactly as the reference
-        n_sel = perm.numel()
-        L.check(lib.mv_frame_pipe_finish(self._pipe, perm.data_ptr() if n_sel else None, n_sel,
-                                         None if pose_sink is None else pose_sink.data_ptr()), "mv_frame_pipe_finish")
+        L.check(lib.mv_frame_pipe_wait_candidates(self._pipe, self._ncand), "mv_frame_pipe_wait_candidates")
+        num = self.cfg.num_point
+        if self.lanes == 1:
+            n = self._ncand[0]
+            g = self.generators[0]
+            # global CPU generator by default, exactly as the reference (KeypointSelector.py:331,404)
+            perm = (torch.randperm(n) if g is None else torch.randperm(n, generator=g))[:num]
+            self._nsel[0] = perm.numel()
+            perm_ptr = perm.data_ptr() if perm.numel() else None
+        else:
+            for l in range(self.lanes):
+                n = self._ncand[l]
+                g = self.generators[l]
+                perm = (torch.randperm(n) if g is None else torch.randperm(n, generator=g))[:num]
+                k = perm.numel()
+                self._nsel[l] = k
+                if k:
+                    self._perm[l, :k] = perm
+            perm_ptr = self._perm.data_ptr()
+        L.check(lib.mv_frame_pipe_finish(self._pipe, perm_ptr, self._nsel, None if pose_sink is None else pose_sink.data_ptr()),
+                "mv_frame_pipe_finish")
         self._n_fin += 1
-        res = _NativeResult(self, n_sel, n, 0)
-        if self.keep_extras and n_sel:
-            b = lambda nm, dt, sh: self._view(nm, 0, dt, sh)  # noqa: E731
-            f32, f64 = torch.float32, torch.float64
-            tr = ops.TrackedKeypoints(b("KP0F", f32, (n_sel, 2)), b("KP1", f32, (n_sel, 2)),
-                                      b("INBOUND", torch.bool, (n_sel,)), b("VALS", f32, (11, n_sel)),
-                                      b("SIGMA0", f32, (n_sel, 3)), b("SIGMA1", f32, (n_sel, 3)))
-            res.extras = dict(tracked=tr, cov0=b("COV0", f64, (n_sel, 3, 3)), cov0_w=b("COV0W", f64, (n_sel, 3, 3)),
-                              cov1=b("COV1", f64, (n_sel, 3, 3)), valid=b("VALID", torch.bool, (n_sel,)),
-                              pos_Tw=b("POS_TW", f32, (n_sel, 3)), n_cand=n)
-        return res
+        out = []
+        for l in range(self.lanes):
+            n_sel = self._nsel[l]
+            res = _NativeResult(self, l, n_sel, self._ncand[l])
+            if self.keep_extras and n_sel:
+                f32, f64 = torch.float32, torch.float64
+                vals = self._view("VALS", 0, f32, (11, self.lanes, self._cap))[:, l, :n_sel]
+                tr = ops.TrackedKeypoints(res._rows("KP0F", f32, (2,)), res._rows("KP1", f32, (2,)),
+                                          res._rows("INBOUND", torch.bool), vals,
+                                          res._rows("SIGMA0", f32, (3,)), res._rows("SIGMA1", f32, (3,)))
+                res.extras = dict(tracked=tr, cov0=res._rows("COV0", f64, (3, 3)), cov0_w=res._rows("COV0W", f64, (3, 3)),
+                                  cov1=res._rows("COV1", f64, (3, 3)), valid=res._rows("VALID", torch.bool),
+                                  pos_Tw=res._rows("POS_TW", f32, (3,)), n_cand=self._ncand[l])
+            out.append(res)
+        return out[0] if self.lanes == 1 else out
 
-    def step(self, x: FrameInputs) -> _NativeResult:
+    def step(self, x: FrameInputs):
         """One ``run_pair`` start to finish (no cross-frame overlap); results are valid on the current stream."""
         self.enqueue_frontend(x)
         res = self.finish()
@@ -618,7 +681,8 @@ class NativeHotPath:
             ops.L.check(self._lib.mv_frame_pipe_sync(self._pipe, None, 1), "mv_frame_pipe_sync")
 
     def run(self, frames, pose_sink: torch.Tensor | None = None):
-        """Software-pipelined stream (frame t+1's frontend is enqueued before frame t's host randperm)."""
+        """Software-pipelined stream (frame t+1's frontend is enqueued before frame t's host randperm).  ``pose_sink``:
+        ``[steps, 7]`` (``[steps, lanes, 7]`` for lanes > 1) device tensor receiving each step's poses."""
         it = iter(frames)
         try:
             self.enqueue_frontend(next(it))
