@@ -77,7 +77,8 @@ def test_pgo_vs_reference_golden(gpu, graph, variant):
         assert dt <= 1e-8 and dr <= 1e-8, (k, dt, dr)      # what is actually achieved
         steps, rej, loss, _ = [float(v) for v in stats[k]]
         assert int(info[k, 1]) == int(steps) and int(info[k, 2]) == int(rej), (k, info[k].tolist(), stats[k].tolist())
-        assert abs(float(info[k, 0]) - loss) <= 1e-8 * max(1.0, abs(loss))
+        # the robust loss has a slope of ~1e2 per metre of pose change: poses equal to 1e-8 leave it equal to ~1e-6
+        assert abs(float(info[k, 0]) - loss) <= 1e-6 * max(1.0, abs(loss)), (k, float(info[k, 0]), loss)
 
 
 def test_obs_filter_vs_reference_classes(gpu):
