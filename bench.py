@@ -1,15 +1,23 @@
 #!/usr/bin/env python
 """bench.py — stereo frames/sec of the MAC-VO hot path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
 
-One "step" = one ``run_pair`` of the hot path on one 640x480 stereo frame (BASELINE.json configs[1]):
-  2 all-pairs cost volumes (stereo + temporal pair, B = 2 in one launch) + 12 x 9x9 window lookups + frontend
-  epilogue + covariance-aware keypoint selection (200 pts, host randperm) + tracking gathers + 2 x covariance model +
-  observation filter + covariance-weighted two-frame PGO (LM, <= 10 steps), all in hand-written HIP kernels behind
-  the C ABI, inputs (feature maps, lookup coordinates, network flow / log-sigma) already resident in HBM.
+One "step" = one ``run_pair`` of the hot path over one batch of ``--lanes`` 640x480 stereo frames (default 1 =
+BASELINE.json configs[1], the 1-sequence stream; 32 = configs[4], batch-32 frames per GPU):
+  all-pairs cost volumes (stereo + temporal pair of every lane in ONE launch) + 12 x 9x9 window lookups + frontend
+  epilogue + covariance-aware keypoint selection (200 pts / frame, host randperm) + tracking gathers + 2 x covariance
+  model + observation filter + covariance-weighted two-frame PGO (LM, <= 10 steps), all in hand-written HIP kernels
+  behind the C ABI, inputs (feature maps, lookup coordinates, network flow / log-sigma) already resident in HBM.
 The learned FlowFormer layers are not part of the step (their source and weights are absent from the reference).
 
-N > 1: one process per GPU (torch.distributed / RCCL), each rank owns an independent sequence (weak scaling);
-the only collective is one all_gather of the per-frame poses at the end of the timed region.
+N > 1: one process per GPU (torch.distributed / RCCL), each rank owns independent sequence(s) (weak scaling);
+the only collective is one all_gather of the per-frame poses (+ timestamps + track lengths) at the end of the timed region.
+
+Besides the contract's fields the JSON line carries
+  roofline      dominant kernel (cost-volume GEMM): algorithmic FLOPs / HIP-event launch time, measured on its stream
+  cpu_baseline  oracle/pipeline.py (torch-CPU ops shaped like the reference) on a bounded sample, N = 1 only
+  parity        free-running HIP track vs the oracle's on the same frames: keypoints, per-frame pose diff, RTE
+                (Evaluation/MetricsSeq.py:9-16 formula); rte_vs_oracle is BASELINE.json's "pose RTE vs reference"
+  config4       a short second measurement at BASELINE configs[4] (32 lanes, B = 64 pairs per GEMM), N = 1 only
 """
 from __future__ import annotations
 
@@ -28,6 +36,8 @@ import torch  # noqa: E402
 # MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md §Chip-level parameters)
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+MIN_TIMED_LAUNCHES = 200       # the roofline average is taken over at least this many GEMM launches
+RAMP_SECONDS = 1.5             # untimed sustained load before the contract's warm-up: clocks ramp, queues are created
 
 
 def parse_args():
@@ -35,6 +45,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--lanes", "--batch-frames", dest="lanes", type=int, default=1,
+                    help="independent sequences advanced per step on each GPU (1 = configs[1]; 32 = configs[4], batch-32 frames)")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--channels", type=int, default=256)
@@ -46,12 +58,43 @@ def parse_args():
     ap.add_argument("--graph", choices=["disp", "reproj", "icp"], default="disp")
     ap.add_argument("--pool", type=int, default=24, help="distinct synthetic frames (closed trajectory) kept in HBM")
     ap.add_argument("--cpu-frames", type=int, default=120, help="frames timed for the CPU baseline (rank 0, N=1 only)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-frames", type=int, default=48, help="free-running frames compared with the oracle (N=1 only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the parity leg")
+    ap.add_argument("--config4-steps", type=int, default=12, help="steps of the extra configs[4] leg (32 lanes); 0 = skip")
     ap.add_argument("--graphs", action="store_true", help="replay the decoder-side segment (12 lookups + epilogue + selector) as a hipGraph (measured slower than eager launches on ROCm 7.2: 2.46 k vs 2.60 k fps)")
     ap.add_argument("--driver", choices=["native", "python"], default="native",
                     help="host-side frame sequencing: the C++ driver (mv_frame_pipe_*) or the Python loop over the per-op entry points")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events around the volume kernel")
+    ap.add_argument("--no-ramp", action="store_true", help="skip the untimed clock-ramp phase")
     return ap.parse_args()
+
+
+def volume_work(lanes, n_q, C, esz):
+    """Algorithmic work of one cost-volume launch: 2*N^2*C FLOP and 2*N*C*s + 4*N^2 bytes per pair."""
+    pairs = 2 * lanes
+    return pairs * 2.0 * n_q * n_q * C, pairs * (2.0 * n_q * C * esz + 4.0 * n_q * n_q)
+
+
+def roofline_of(ms, args, lanes, n_q, C, timed_region_launches, traffic=None):
+    flops, nbytes = volume_work(lanes, n_q, C, 4 if args.feat_dtype == "f32" else 2)
+    avg_s = sum(ms) / len(ms) / 1e3
+    common = {"avg_launch_us": round(avg_s * 1e6, 2), "launches": len(ms), "launches_in_timed_region": timed_region_launches,
+              "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes}
+    if args.feat_dtype == "f32" and args.volume_precision in ("split3", "split2"):
+        ach = flops / avg_s / 1e12
+        nprod = 6.0 if args.volume_precision == "split3" else 3.0
+        eff_peak = 2500.0 / nprod   # bf16 MFMA products executed per algorithmic product at the 2.5 PFLOP/s dense bf16 peak
+        return {"bound": "mfma", "achieved": round(ach, 2), "peak": round(eff_peak, 1), "unit": "TFLOP/s",
+                "frac": round(ach / eff_peak, 4), "traffic": None,
+                "kernel": f"{args.volume_precision} pre-pass + corr_volume_bf16x3_hwc<{int(nprod) // 3 + 1}>", **common,
+                "note": "achieved = algorithmic fp32 FLOPs / time; peak = 2500 TFLOP/s bf16 dense / executed products per algorithmic product"}
+    if args.feat_dtype == "f32":
+        ach = flops / avg_s / 1e12
+        return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "kernel": "corr_volume_f32_" + args.layout, **common}
+    ach = nbytes / avg_s / 1e9
+    return {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
+            "traffic": None, "kernel": "corr_volume_h_" + args.layout, **common}
 
 
 def main():
@@ -73,15 +116,23 @@ def main():
         dist = dist_mod
 
     from macvo_amd import ops
-    from macvo_amd.distributed import gather_poses
-    from macvo_amd.pipeline import Camera, FrameInputs, HotPath, HotPathConfig, NativeHotPath
+    from macvo_amd.distributed import gather_tracks
+    from macvo_amd.pipeline import Camera, FrameInputs, HotPath, HotPathConfig, NativeHotPath, stack_lanes
     from tests import synth
 
     H, W, C = args.height, args.width, args.channels
+    h8, w8 = H // 8, W // 8
+    n_q = h8 * w8
     fdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.feat_dtype]
+    native = args.driver == "native"
+    use_graphs = args.graphs
+    assert not (native and use_graphs), "--graphs belongs to the Python driver"
+    assert args.lanes == 1 or native, "--lanes > 1 needs the native driver"
+    assert args.pool % 6 == 0 or not use_graphs, "--pool must be a multiple of 6 with graphs (one graph per resident frame)"
+
     # ---- synthetic, seeded, per-rank sequence (closed trajectory so the pool can be cycled without a seam)
-    cam, frames_cpu, _ = synth.make_sequence(args.pool, H, W, C=C, iters=args.iters, seed=1000 + rank, feat_dtype=fdt,
-                                             pool=2, closed_loop=True)
+    cam, frames_cpu, truth = synth.make_sequence(args.pool, H, W, C=C, iters=args.iters, seed=1000 + rank, feat_dtype=fdt,
+                                                 pool=2, closed_loop=True)
     if args.layout == "hwc":
         for fr in frames_cpu:
             fr["fmap1"] = fr["fmap1"].permute(0, 2, 3, 1).contiguous()
@@ -94,125 +145,126 @@ def main():
             cache[k] = t.to(dev)
         return cache[k]
 
-    use_graphs = args.graphs
-    assert args.pool % 6 == 0 or not use_graphs, "--pool must be a multiple of 6 with graphs (one graph per resident frame)"
     frames = [FrameInputs(static=True, **{k: to_dev(v) for k, v in fr.items()}) for fr in frames_cpu]
-    native = args.driver == "native"
-    assert not (native and use_graphs), "--graphs belongs to the Python driver"
-    hot = (NativeHotPath if native else HotPath)(
-        Camera(**cam), HotPathConfig(graph_type=args.graph, feature_layout=args.layout,
-                                     volume_precision=args.volume_precision, use_graphs=use_graphs), dev)
-    torch.manual_seed(1234 + rank)  # the selector consumes the global CPU generator (reference behaviour)
 
-    # ---- per-launch HIP events around the dominant kernel (cost volume), on the launch stream
-    vol_events = []
-    orig_corr_volume = ops.corr_volume
-    record = {"on": False}
+    def lane_batches(lanes):
+        """Step t of an L-lane pipe = frames (t + l) % pool of the closed trajectory, l = 0..L-1: every lane is the same
+        kind of sequence at a different phase (consecutive frames per lane), stacked along the pair axis."""
+        if lanes == 1:
+            return frames
+        return [stack_lanes([frames[(t + l) % args.pool] for l in range(lanes)]) for t in range(args.pool)]
 
-    def timed_corr_volume(*a, **k):
-        if not record["on"]:
-            return orig_corr_volume(*a, **k)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = orig_corr_volume(*a, **k)
-        e1.record()
-        vol_events.append((e0, e1))
-        return out
-
-    if not args.no_kernel_events and not native:
-        ops.corr_volume = timed_corr_volume
-
-    hot.initialize(frames[0])
-    t_idx = 1
-    if use_graphs:
-        # setup (untimed, before the warm-up): one pass over the resident frames captures their decoder-side hipGraphs
-        for _ in hot.run(frames[(t_idx + k) % args.pool] for k in range(args.pool)):
-            pass
-        t_idx += args.pool
-    poses = torch.zeros((args.steps, 7), dtype=torch.float32, device=dev)
-    for _ in hot.run(frames[(t_idx + k) % args.pool] for k in range(args.warmup)):
-        pass
-    t_idx += args.warmup
+    def make_pipe(lanes, seed):
+        cfg = HotPathConfig(graph_type=args.graph, feature_layout=args.layout, volume_precision=args.volume_precision,
+                            use_graphs=use_graphs)
+        if native:
+            gens = None if lanes == 1 else [torch.Generator().manual_seed(seed + l) for l in range(lanes)]
+            return NativeHotPath(Camera(**cam), cfg, dev, lanes=lanes, generators=gens)
+        return HotPath(Camera(**cam), cfg, dev)
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    if dist is not None:  # warm the collectives used in / around the timed region (RCCL sets channels up lazily)
-        gather_poses(torch.zeros((args.steps, 7), dtype=torch.float32, device=dev), dist)
-        dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=dev), op=dist.ReduceOp.MAX)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    record["on"] = True
-    if native and not args.no_kernel_events:
-        hot.time_volume(args.steps)   # HIP-event pairs around the volume GEMM, recorded by the driver on its GEMM stream
-    t0 = time.perf_counter()
-    # software-pipelined stream (frame t+1's frontend is queued before frame t's host randperm); K full run_pairs
-    for _ in hot.run((frames[(t_idx + k) % args.pool] for k in range(args.steps)), pose_sink=poses):
-        pass
-    all_poses, _ = gather_poses(poses, dist)  # the one collective of the job (no-op for N = 1)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    record["on"] = False
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    assert torch.isfinite(all_poses).all(), "non-finite pose in the benchmark stream"
+    def measure(lanes, steps, warmup, seed, with_events):
+        """W untimed + K timed steps of an L-lane pipe.  Returns (elapsed s, poses, per-launch GEMM ms, launches in region)."""
+        batches = lane_batches(lanes)
+        hot = make_pipe(lanes, seed)
+        torch.manual_seed(seed)  # the selector consumes the global CPU generator (reference behaviour) when lanes == 1
+        hot.initialize(batches[0])
+        t_idx = 1
+        if use_graphs:   # setup: one pass over the resident frames captures their decoder-side hipGraphs
+            for _ in hot.run(batches[(t_idx + k) % args.pool] for k in range(args.pool)):
+                pass
+            t_idx += args.pool
+        if not args.no_ramp:   # untimed sustained load: the driver's short runs (--steps 20) would otherwise sample cold clocks
+            t_end = time.perf_counter() + RAMP_SECONDS
+            while time.perf_counter() < t_end:
+                for _ in hot.run(batches[(t_idx + k) % args.pool] for k in range(24)):
+                    pass
+                t_idx += 24
+                torch.cuda.synchronize()
+        for _ in hot.run(batches[(t_idx + k) % args.pool] for k in range(warmup)):
+            pass
+        t_idx += warmup
+        shape = (steps, 7) if lanes == 1 else (steps, lanes, 7)
+        poses = torch.zeros(shape, dtype=torch.float32, device=dev)
+        stamps = torch.arange(steps, dtype=torch.int64, device=dev) * 33_333_333   # synthetic 30 Hz frame timestamps (ns)
+        if dist is not None:  # warm the collectives used in / around the timed region (RCCL sets channels up lazily)
+            gather_tracks(torch.zeros((steps * lanes, 7), dtype=torch.float32, device=dev), stamps.repeat_interleave(lanes), dist)
+            dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=dev), op=dist.ReduceOp.MAX)
+        n_ev = max(steps, MIN_TIMED_LAUNCHES) if with_events else 0
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        if native and n_ev:
+            hot.time_volume(n_ev)   # HIP-event pairs around the volume GEMM, recorded by the driver on its GEMM stream
+        t0 = time.perf_counter()
+        # software-pipelined stream (frame t+1's frontend is queued before frame t's host randperm); K full run_pairs
+        for _ in hot.run((batches[(t_idx + k) % args.pool] for k in range(steps)), pose_sink=poses):
+            pass
+        # the one collective of the job (no-op for N = 1): poses [T,7] + time_ns [T] + T of every rank (SURVEY §8(e))
+        all_poses, _, _ = gather_tracks(poses.reshape(-1, 7), stamps.repeat_interleave(lanes), dist)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        assert torch.isfinite(all_poses).all(), "non-finite pose in the benchmark stream"
+        t_idx += steps
+        ms = []
+        if native and n_ev:
+            extra = n_ev - steps   # short runs: keep the same stream going (untimed for `value`) until enough GEMMs are timed
+            if extra > 0:
+                for _ in hot.run(batches[(t_idx + k) % args.pool] for k in range(extra)):
+                    pass
+            ms = hot.volume_times_ms()
+        del hot
+        return elapsed, all_poses, ms, min(steps, len(ms))
 
-    # ---- roofline of the dominant kernel (cost volume): algorithmic work per launch / measured launch duration
-    h8, w8 = H // 8, W // 8
-    n_q = h8 * w8
-    pairs = 2
-    flops_per_launch = pairs * 2.0 * n_q * n_q * C                       # 2*N^2*C per pair
-    esz = 4 if args.feat_dtype == "f32" else 2
-    bytes_per_launch = pairs * (2.0 * n_q * C * esz + 4.0 * n_q * n_q)   # read f1,f2 + write fp32 volume
+    # ---- per-launch HIP events around the dominant kernel for the Python driver (launch stream = torch's current stream)
+    vol_events = []
+    if not native and not args.no_kernel_events:
+        orig_corr_volume = ops.corr_volume
+
+        def timed_corr_volume(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig_corr_volume(*a, **k)
+            e1.record()
+            vol_events.append((e0, e1))
+            return out
+
+        ops.corr_volume = timed_corr_volume
+
+    elapsed, _, ms, in_region = measure(args.lanes, args.steps, args.warmup, 1234 + rank, not args.no_kernel_events)
+    if vol_events:
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in vol_events[-args.steps:]]
+        in_region = len(ms)
+        ops.corr_volume = orig_corr_volume
+
     # HBM traffic of the dominant kernel from a committed rocprofv3 --pmc pass over the same launch configuration
-    # (scripts/pmc_gpu.sh -> profiles/r01_pmc_corr_volume.json; PMC passes cannot be mixed into this run)
+    # (scripts/pmc_gpu.sh -> profiles/*_pmc_corr_volume.json; PMC passes cannot be mixed into this run)
     traffic = None
     try:
-        if H == 480 and W == 640 and C == 256 and args.feat_dtype == "f32" and args.volume_precision == "exact":
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_corr_volume.json")))
-            traffic = pm["corr_volume_f32_" + args.layout]["_derived"]["traffic_bytes_per_launch"]
+        if (H, W, C, args.lanes) == (480, 640, 256, 1) and args.feat_dtype == "f32" and args.volume_precision == "exact":
+            for name in ("r02_pmc_corr_volume.json", "r01_pmc_corr_volume.json"):
+                path = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(path):
+                    traffic = json.load(open(path))["corr_volume_f32_" + args.layout]["_derived"]["traffic_bytes_per_launch"]
+                    break
     except Exception:  # noqa: BLE001
         traffic = None
-    roofline = None
-    if native and not args.no_kernel_events:
-        vol_events = hot.volume_times_ms()
-    if vol_events:
-        ms = vol_events if native else [a.elapsed_time(b) for a, b in vol_events]
-        avg_s = sum(ms) / len(ms) / 1e3
-        if args.feat_dtype == "f32" and args.volume_precision in ("split3", "split2"):
-            ach = flops_per_launch / avg_s / 1e12
-            nprod = 6.0 if args.volume_precision == "split3" else 3.0
-            eff_peak = 2500.0 / nprod   # bf16 MFMA products executed per algorithmic product at the 2.5 PFLOP/s dense bf16 peak
-            roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(eff_peak, 1), "unit": "TFLOP/s",
-                        "frac": round(ach / eff_peak, 4), "traffic": None,
-                        "kernel": f"{args.volume_precision} pre-pass + corr_volume_bf16x3_hwc<{int(nprod) // 3 + 1}>",
-                        "avg_launch_us": round(avg_s * 1e6, 2), "launches": len(ms),
-                        "algorithmic_flops_per_launch": flops_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
-                        "note": "achieved = algorithmic fp32 FLOPs / time; peak = 2500 TFLOP/s bf16 dense / executed products per algorithmic product"}
-        elif args.feat_dtype == "f32":
-            ach = flops_per_launch / avg_s / 1e12
-            roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                        "kernel": "corr_volume_f32_" + args.layout, "avg_launch_us": round(avg_s * 1e6, 2),
-                        "launches": len(ms), "algorithmic_flops_per_launch": flops_per_launch,
-                        "algorithmic_bytes_per_launch": bytes_per_launch}
-        else:
-            ach = bytes_per_launch / avg_s / 1e9
-            roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
-                        "kernel": "corr_volume_h_" + args.layout, "avg_launch_us": round(avg_s * 1e6, 2),
-                        "launches": len(ms), "algorithmic_flops_per_launch": flops_per_launch,
-                        "algorithmic_bytes_per_launch": bytes_per_launch}
+    roofline = roofline_of(ms, args, args.lanes, n_q, C, in_region, traffic) if ms else None
 
-    # ---- CPU baseline: the oracle pipeline (torch-CPU ops shaped like the reference) on a bounded sample
-    cpu_baseline = None
+    # ---- CPU baseline (oracle pipeline, torch-CPU ops shaped like the reference) on a bounded sample + free-running parity
+    cpu_baseline = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import metrics, se3
         from oracle.pipeline import OracleHotPath
 
         # 8 threads = what the reference's optimizer child uses (Optimization/Interface.py:254); more threads on a
@@ -227,20 +279,56 @@ def main():
                 fr["fmap2"] = fr["fmap2"].permute(0, 3, 1, 2).contiguous()
         torch.manual_seed(1234)
         ora.initialize(cfr[0])
-        ora.step(cfr[1])  # warm-up (thread pools, first-call overheads)
+        ora_track = [ora.step(cfr[1])]  # warm-up (thread pools, first-call overheads); part of the free-running track
         c0 = time.perf_counter()
         ncpu = 0
         while ncpu < args.cpu_frames and (time.perf_counter() - c0) < 25.0:
-            ora.step(cfr[(2 + ncpu) % args.pool])
+            ora_track.append(ora.step(cfr[(2 + ncpu) % args.pool]))
             ncpu += 1
         csec = time.perf_counter() - c0
         cpu_baseline = {"value": round(ncpu / csec, 3), "unit": "stereo frames/s", "cores": cores, "kind": "port",
                         "sample": f"{ncpu} frames of the same {W}x{H} workload through oracle/pipeline.py "
                                   f"(torch-CPU einsum volume, grid_sample lookup, max_pool2d selector, float64 dense-weight LM), "
                                   f"{csec:.1f} s"}
+        # free-running parity: the HIP path on the same frames from the same start, chained on its OWN poses (no teacher
+        # forcing), same CPU generator seed -> keypoints must be identical, poses within 1e-4; RTE per MetricsSeq.py:9-16
+        if native and args.volume_precision == "exact" and args.feat_dtype == "f32":
+            n_par = min(len(ora_track), max(args.parity_frames, 2))
+            hot = make_pipe(1, 0)
+            torch.manual_seed(1234)
+            hot.initialize(frames[0])
+            sink = torch.zeros((n_par, 7), dtype=torch.float32, device=dev)
+            kp_same = 0
+            for t, r in enumerate(hot.run((frames[(1 + k) % args.pool] for k in range(n_par)), pose_sink=sink)):
+                hot.sync_pose()
+                kp_same += int(torch.equal(r.kp0_uv.cpu(), ora_track[t]["kp0_uv"]))
+            torch.cuda.synchronize()
+            ident = torch.tensor([[0, 0, 0, 0, 0, 0, 1.0]])
+            est = torch.cat([ident, sink.cpu()])
+            orc = torch.cat([ident, torch.stack([o["pose"] for o in ora_track[:n_par]])])
+            tru = torch.stack([truth[k % args.pool] for k in range(n_par + 1)])
+            diffs = [se3.pose_error(orc[t].double(), est[t].double()) for t in range(1, n_par + 1)]
+            m = metrics.rte(orc, est)
+            parity = {"frames": n_par, "free_running": True, "keypoints_bit_exact_frames": kp_same,
+                      "max_pose_dt_m": max(d[0] for d in diffs), "max_pose_dr_rad": max(d[1] for d in diffs),
+                      "rte_vs_oracle": {k: m[k] for k in ("mean", "rmse", "max", "roe_max_rad")},
+                      "rte_vs_truth": {"hip": metrics.rte(tru, est)["mean"], "oracle": metrics.rte(tru, orc)["mean"]},
+                      "formula": "evo RPE translation part, delta = 1 frame (Evaluation/MetricsSeq.py:9-16)",
+                      "within_north_star": bool(kp_same == n_par and max(d[0] for d in diffs) <= 1e-4 and max(d[1] for d in diffs) <= 1e-4)}
+            del hot
+
+    # ---- configs[4]: batch-32 frames per GPU (B = 64 pairs per GEMM) — a short second measurement, N = 1 only
+    config4 = None
+    if rank == 0 and world == 1 and native and args.config4_steps > 0 and args.lanes == 1 and (H, W) == (480, 640):
+        e4, _, ms4, in4 = measure(32, args.config4_steps, 3, 4321, not args.no_kernel_events)
+        config4 = {"workload": "configs[4]: batch-32 640x480 frames per GPU = 32 lanes, one cost-volume GEMM of B = 64 pairs per step",
+                   "value": round(32 * args.config4_steps / e4, 2), "unit": "stereo frames/s", "steps": args.config4_steps, "warmup": 3,
+                   "ms_per_step": round(e4 / args.config4_steps * 1e3, 4),
+                   "roofline": roofline_of(ms4, args, 32, n_q, C, in4) if ms4 else None}
 
     if rank == 0:
-        total_frames = world * args.steps
+        total_frames = world * args.steps * args.lanes
+        cfgname = {1: "configs[1]", 32: "configs[4]"}.get(args.lanes, f"{args.lanes}-lane variant of configs[1]")
         line = {
             "metric": "stereo frames/sec at 640x480 (hot path: cost volume + lookup, keypoint selection, covariance, PGO)",
             "value": round(total_frames / elapsed, 2),
@@ -255,14 +343,20 @@ def main():
             "dtype": {"f32": "f32 (volume/lookup/covariance) + f64 (PGO)", "f16": "f16 in / f32 acc (volume) + f32 + f64 (PGO)",
                       "bf16": "bf16 in / f32 acc (volume) + f32 + f64 (PGO)"}[args.feat_dtype],
             "data": "synthetic (seeded planar-scene stereo stream, random feature maps; no weights/datasets available)",
-            "config": {"workload": f"configs[1]: single MI355X, {W}x{H} synthetic stereo, HIP correlation volume + GN backend, 1-seq stream per GPU",
-                       "per_step": f"2 cost volumes [{n_q}x{C}x{n_q}] + {args.iters}x2 9x9 lookups + epilogue + CovAwareSelector_NoDepth(200) + 2x MatchCovariance(31x31) + TwoFrame_PGO({args.graph})",
-                       "feature_dtype": args.feat_dtype, "feature_layout": args.layout, "volume_precision": args.volume_precision,
-                       "hip_graphs": use_graphs, "host_driver": args.driver,
+            "rte_vs_oracle": None if parity is None else parity["rte_vs_oracle"]["mean"],
+            "config": {"workload": f"{cfgname}: single MI355X, {W}x{H} synthetic stereo, HIP correlation volume + GN backend, "
+                                   f"{args.lanes} sequence(s) per GPU in lock-step",
+                       "per_step": f"{args.lanes} frame(s): {2 * args.lanes} cost volumes [{n_q}x{C}x{n_q}] in one launch + {args.iters} 9x9 lookups "
+                                   f"+ epilogue + CovAwareSelector_NoDepth(200) + 2x MatchCovariance(31x31) + TwoFrame_PGO({args.graph})",
+                       "lanes": args.lanes, "feature_dtype": args.feat_dtype, "feature_layout": args.layout,
+                       "volume_precision": args.volume_precision, "hip_graphs": use_graphs, "host_driver": args.driver,
+                       "clock_ramp_s": 0.0 if args.no_ramp else RAMP_SECONDS,
                        "excluded": "learned FlowFormer layers (source + weights absent from the reference checkout)",
-                       "parallelism": f"{world} independent sequence(s), one per GPU; one all_gather of poses"},
+                       "parallelism": f"{world * args.lanes} independent sequence(s), {args.lanes} per GPU; one all_gather of poses + timestamps"},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "parity": parity,
+            "config4": config4,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -287,6 +287,251 @@ __global__ __launch_bounds__(256) void corr_volume_f32_chw(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp32, CHW operands, square volumes with N % 64 == 0: PERSISTENT kernel with a balanced mixed-tile schedule (round 2).
+//
+// What the one-tile-per-workgroup kernel above loses on the 640x480 shape (N = 4800, B = 2 pairs; measured):
+//   * 2888 tiles of 128x128 on 256 CUs = 11.28 tiles per CU -> the last CU finishes 12: 6 % tail, plus 2.6 % dead rows /
+//     columns in the 38th tile row / column (4800 = 37.5 x 128);
+//   * it allocates 148 registers (84 VGPR, 32 of them hoisted LDS row addresses: the 8-bit offsets of ds_read2_b32 cannot
+//     reach row k + 2 of a [BK][128] tile), i.e. 3 workgroups per CU, and runs FASTER with 2 (192 vs 201 us);
+//   * the LDS image of the next K step is written in one burst of 16 ds_write_b128 per workgroup at the end of a stage,
+//     which delays the other waves' fragment reads beyond their 256-cycle prefetch distance.
+// This kernel: 2 workgroups per CU (512 on MI355X), each walking a STATIC schedule computed arithmetically from a few
+// scalars (no table, no atomics): R_b rounds of 128x128 tiles covering the first n_big tiles of each pair in row-major
+// order, then R_m rounds of 128x64 tiles and R_s rounds of 64x64 tiles covering exactly what is left (the rest of the
+// last tile row, the remaining tile rows, the odd 64-wide column / row) — every workgroup does the same number of MFMA
+// blocks to within one 64x64 tile, no dead rows.  For N = 4800, B = 2: 5 + 0 + 2 rounds (5 x 16 + 2 x 4 = 88 of the
+// 45000 / 512 = 87.9 blocks per workgroup).  LDS tiles are stored column-permuted so that a wave's fragments of one k row
+// are 256 B apart: every fragment read is ONE base register + immediates (ds_read2st64_b32), 126 registers in total; the
+// register-staged next K step goes to LDS one float4 at a time between the MFMA groups.  The k loop order is unchanged
+// (k ascending per output element): results are bitwise identical to the kernel above.
+// Measured (tools/scratch/gemm3_probe.*): N = 4800, B = 2: 207.2 -> 190 us (72.4 -> 79 % of 157.3 TFLOP/s);
+// steady state (B = 16): 78.3 -> 80.4 %, + interleaved stores 81.8 %.  Measured and NOT adopted: 256x128 / 256x256
+// workgroup tiles (78.6 / 76.5 %), BK 8 / 32 / 64 (78.9 / 78.5 / 63 %), 1 / 3 / 4 workgroups per CU (74.6 / 80.5 / 77.8 %),
+// fragment prefetch two groups ahead (no gain), the K stream running across tile boundaries (no cold prologue: no gain),
+// de-phasing the two co-resident workgroups by a quarter tile (no gain).
+// ------------------------------------------------------------------------------------------------
+struct VolSched {   // host-computed, passed by value; everything per PAIR unless noted.  Cells are 64 x 64 outputs.
+    int Nc, Gb;                     // cells per dimension; 128x128 tile grid per dimension (Nc / 2)
+    int n_big_pp, full_rows, rem;   // big tiles of a pair: `full_rows` full tile rows + `rem` tiles of the next row
+    int e, A, Bc, U_pp;             // 128x64 "units" not covered by big tiles: e per full row (A in total), Bc in the partial row
+    int n_med_pp, n_small_pp;
+    int R_b, R_m, R_s;              // rounds of each kind: every workgroup takes one item per round
+    int B;
+};
+
+static bool make_vol_sched(int N, int B, int slots, VolSched& S) {
+    if (N % 64 || N < 128 || B < 1 || slots < 8 || (slots & 7)) return false;
+    S.B = B;
+    S.Nc = N / 64;
+    S.Gb = S.Nc / 2;
+    const long cells = (long)B * S.Nc * S.Nc;
+    long R_b = cells * 4 / 16 / slots;
+    while (R_b > 0 && (R_b * slots % B != 0 || R_b * slots / B > (long)S.Gb * S.Gb)) --R_b;
+    S.R_b = (int)R_b;
+    S.n_big_pp = (int)(R_b * slots / B);
+    S.full_rows = S.n_big_pp / S.Gb;
+    S.rem = S.n_big_pp % S.Gb;
+    S.e = S.Nc - 2 * S.Gb;
+    S.A = S.full_rows * S.e;
+    S.Bc = S.rem > 0 ? S.Nc - 2 * S.rem : 0;
+    const int rows_after = S.Gb - S.full_rows - (S.rem > 0 ? 1 : 0);
+    S.U_pp = S.A + S.Bc + rows_after * S.Nc;
+    const long rem_cells = cells - 4L * S.n_big_pp * B;
+    long R_m = rem_cells / 2 / slots;
+    while (R_m > 0 && (R_m * slots % B != 0 || R_m * slots / B > S.U_pp)) --R_m;
+    S.R_m = (int)R_m;
+    S.n_med_pp = (int)(R_m * slots / B);
+    S.n_small_pp = 2 * (S.U_pp - S.n_med_pp) + (S.e ? S.Nc : 0);
+    S.R_s = (int)(((long)S.n_small_pp * B + slots - 1) / slots);
+    // every cell covered exactly once, and the big tiles carry most of the work (otherwise the uniform kernel is better)
+    return 4L * S.n_big_pp + 2L * S.n_med_pp + S.n_small_pp == (long)S.Nc * S.Nc && 4L * S.n_big_pp * 4 >= 3L * S.Nc * S.Nc;
+}
+
+// unit u of a pair -> (128-row tile row, 64-column cell)
+__device__ __forceinline__ void vol_unit_coords(const VolSched& S, int u, int& tm, int& c) {
+    if (u < S.A) { tm = u / S.e; c = 2 * S.Gb + (u - tm * S.e); return; }
+    u -= S.A;
+    if (u < S.Bc) { tm = S.full_rows; c = 2 * S.rem + u; return; }
+    u -= S.Bc;
+    const int r = u / S.Nc;
+    tm = S.full_rows + (S.rem > 0 ? 1 : 0) + r;
+    c = u - r * S.Nc;
+}
+
+// big tile q of a pair -> (tm, tn): super-rows of 8 tile rows walked column by column, so that the 64 consecutive items an
+// XCD takes per round are an 8 x 8 block (8 + 8 operand tiles = 2 MB through its L2 instead of 2 + 37); the tiles of the
+// partial row come last, in row order.
+__device__ __forceinline__ void vol_big_coords(const VolSched& S, int q, int& tm, int& tn) {
+    const int in_full = S.full_rows * S.Gb;
+    if (q >= in_full) { tm = S.full_rows; tn = q - in_full; return; }
+    constexpr int RG = 8;
+    const int per_sr = RG * S.Gb;
+    const int sr = q / per_sr, within = q - sr * per_sr;
+    const int rows = min(RG, S.full_rows - sr * RG);
+    tn = within / rows;
+    tm = sr * RG + (within - tn * rows);
+}
+
+// One (64 MI) x (64 NJ) tile by the workgroup's 2 x 2 waves (wave tile 32 MI x 32 NJ), full K.  LDS: [stage][A: BK x 64 MI |
+// B: BK x 64 NJ] floats, columns permuted (tile column w * 32 M + i * 32 + l -> i * 64 + w * 32 + l).
+template <int MI, int NJ>
+__device__ __forceinline__ void vol_tile(const float* __restrict__ A, const float* __restrict__ Bp, float* __restrict__ O, int C,
+                                         int N, int m0, int n0, float* smem) {
+    constexpr int BK = 16;
+    constexpr int WA = 64 * MI, WB = 64 * NJ;             // operand tile widths (floats per k row)
+    constexpr int TA = WA / 4, TB = WB / 4;               // loader threads per k row
+    constexpr int NPA = BK * TA / 256, NPB = BK * TB / 256;   // float4 per thread per K step (2 or 1)
+    constexpr int STAGE = BK * (WA + WB);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1, kh = lane >> 5, li = lane & 31;
+    const int nk = C / BK, klast = C - BK;
+    const int arow = t / TA, acol = (t % TA) * 4, brow = t / TB, bcol = (t % TB) * 4;
+    // uniform (SGPR) tile bases + ONE 32-bit per-lane offset per operand (no 64-bit address VGPRs)
+    const float* Au = A + m0;
+    const float* Bu = Bp + n0;
+    const unsigned aoff = arow * N + acol, boff = brow * N + bcol;
+    auto perm = [](int col, int m) { return ((col >> 5) % m) * 64 + (col / (32 * m)) * 32 + (col & 31); };
+    float* wa = smem + arow * WA + perm(acol, MI);
+    float* wb = smem + BK * WA + brow * WB + perm(bcol, NJ);
+    const float* fa = smem + kh * WA + wm * 32 + li;
+    const float* fb = smem + BK * WA + kh * WB + wn * 32 + li;
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 ra[2][NPA], rb[2][NPB];
+    auto gload = [&](auto SET, int k0) {
+        constexpr int S = decltype(SET)::value;
+#pragma unroll
+        for (int p = 0; p < NPA; ++p) ra[S][p] = *reinterpret_cast<const f32x4*>(Au + (size_t)(k0 + (256 / TA) * p) * N + aoff);
+#pragma unroll
+        for (int p = 0; p < NPB; ++p) rb[S][p] = *reinterpret_cast<const f32x4*>(Bu + (size_t)(k0 + (256 / TB) * p) * N + boff);
+    };
+    auto sstore = [&](auto SET, int buf) {
+        constexpr int S = decltype(SET)::value;
+#pragma unroll
+        for (int p = 0; p < NPA; ++p) *reinterpret_cast<f32x4*>(wa + buf * STAGE + p * (256 / TA) * WA) = ra[S][p];
+#pragma unroll
+        for (int p = 0; p < NPB; ++p) *reinterpret_cast<f32x4*>(wb + buf * STAGE + p * (256 / TB) * WB) = rb[S][p];
+    };
+    // piece g (one float4) of the register-staged K step -> LDS; pieces 0..NPA-1 = A, then B
+    auto spiece = [&](auto SET, int buf, int g) {
+        constexpr int S = decltype(SET)::value;
+#pragma unroll
+        for (int p = 0; p < NPA; ++p)
+            if (g == p) *reinterpret_cast<f32x4*>(wa + buf * STAGE + p * (256 / TA) * WA) = ra[S][p];
+#pragma unroll
+        for (int p = 0; p < NPB; ++p)
+            if (g == NPA + p) *reinterpret_cast<f32x4*>(wb + buf * STAGE + p * (256 / TB) * WB) = rb[S][p];
+    };
+    // K step from LDS stage `buf`; fragments of k-pair kk + 2 are fetched before the MFMAs of k-pair kk are issued; after MFMA
+    // group g one piece of the NEXT K step is stored (no store burst in front of the barrier)
+    auto mma = [&](int buf, auto&& after) {
+        const float* qa = fa + buf * STAGE;
+        const float* qb = fb + buf * STAGE;
+        float a[2][MI], b[2][NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[0][i] = qa[i * 64];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[0][j] = qb[j * 64];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+            if (kk + 2 < BK) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[nxt][i] = qa[(kk + 2) * WA + i * 64];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[nxt][j] = qb[(kk + 2) * WB + j * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (hipcc otherwise sinks it back)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            after(kk >> 1);
+        }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    gload(S0{}, 0);
+    gload(S1{}, BK);
+    __syncthreads();   // the previous tile's last K step may still be reading the LDS stages
+    sstore(S0{}, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {   // 2-deep register-staged global prefetch (loads stay in flight across the barrier)
+        gload(S0{}, min((kt + 2) * BK, klast));
+        mma(0, [&](int g) { spiece(S1{}, 1, g); });
+        __syncthreads();
+        gload(S1{}, min((kt + 3) * BK, klast));
+        mma(1, [&](int g) { spiece(S0{}, 0, g); });
+        __syncthreads();
+    }
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5): one full 128-B line per
+    // half-wave and store instruction
+    float* Ou = O + (size_t)m0 * N + n0;
+    const unsigned so = (wm * 32 * MI + 4 * kh) * N + wn * 32 * NJ + li;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float* p = Ou + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * N;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) __builtin_nontemporal_store(acc[i][j][r], p + j * 32 + so);
+        }
+}
+
+__global__ __launch_bounds__(256) void corr_volume_f32_sched(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                              float* __restrict__ out, int C, int N, VolSched S) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 16 * 256];
+    const int slots = gridDim.x;
+    const int s = blockIdx.x;
+    const size_t fsz = (size_t)C * N, osz = (size_t)N * N;
+    // inside a round XCD x (= s & 7: consecutive workgroup ids land on different XCDs) owns a contiguous eighth of the items
+    const int lin = (s & 7) * (slots >> 3) + (s >> 3);
+#pragma unroll 1
+    for (int r = 0; r < S.R_b; ++r) {
+        const int idx = r * slots + lin;
+        const int b = idx / S.n_big_pp;
+        int tm, tn;
+        vol_big_coords(S, idx - b * S.n_big_pp, tm, tn);
+        vol_tile<2, 2>(f1 + b * fsz, f2 + b * fsz, out + b * osz, C, N, tm * 128, tn * 128, smem);
+    }
+#pragma unroll 1
+    for (int r = 0; r < S.R_m; ++r) {
+        const int idx = r * slots + lin;
+        if (idx < S.n_med_pp * S.B) {
+            const int b = idx / S.n_med_pp;
+            int tm, c;
+            vol_unit_coords(S, idx - b * S.n_med_pp, tm, c);
+            vol_tile<2, 1>(f1 + b * fsz, f2 + b * fsz, out + b * osz, C, N, tm * 128, c * 64, smem);
+        }
+    }
+#pragma unroll 1
+    for (int r = 0; r < S.R_s; ++r) {
+        const int idx = r * slots + lin;
+        if (idx < S.n_small_pp * S.B) {
+            const int b = idx / S.n_small_pp, sm = idx - b * S.n_small_pp;
+            const int from_units = 2 * (S.U_pp - S.n_med_pp);
+            int m0, n0;
+            if (sm < from_units) {   // the two 64x64 halves of a unit that did not become a 128x64 tile
+                int tm, c;
+                vol_unit_coords(S, S.n_med_pp + (sm >> 1), tm, c);
+                m0 = tm * 128 + (sm & 1) * 64;
+                n0 = c * 64;
+            } else {                 // the odd last cell row
+                m0 = (S.Nc - 1) * 64;
+                n0 = (sm - from_units) * 64;
+            }
+            vol_tile<1, 1>(f1 + b * fsz, f2 + b * fsz, out + b * osz, C, N, m0, n0, smem);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // fp32, HWC ([N][C]) operands: same MFMA core; the loader transposes through LDS
 // (global float4 along C -> 4 scalar LDS stores into the K-major tile; row padding +1 keeps them conflict-light).
 // ------------------------------------------------------------------------------------------------
@@ -716,6 +961,23 @@ static unsigned gemm_extra_lds() {
     return (unsigned)v;
 }
 
+// Grid of the scheduled fp32 kernel: 2 workgroups per CU (measured optimum), a multiple of 8 so that "id % 8 == XCD" holds.
+// MV_VOL_SCHED=0 switches back to the one-tile-per-workgroup kernel (A/B knob); MV_VOL_SCHED_WG_PER_CU=<k> changes the 2.
+static int sched_slots() {
+    static int v = -1;
+    if (v < 0) {
+        const char* off = getenv("MV_VOL_SCHED");
+        const char* e = getenv("MV_VOL_SCHED_WG_PER_CU");
+        const int per_cu = (off && atoi(off) == 0) ? 0 : (e ? atoi(e) : 2);
+        int dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        v = (per_cu * cus) / 8 * 8;
+    }
+    return v;
+}
+
 extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B, int C, int N1, int N2,
                               int in_dtype, int layout, mvStream_t stream) {
     MV_CHECK_ARG(f1 && f2 && out);
@@ -731,7 +993,11 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
         const float* a = (const float*)f1;
         const float* b = (const float*)f2;
         if (layout == MV_LAYOUT_CHW) {
-            if ((N1 % 4 == 0) && (N2 % 4 == 0)) {
+            VolSched vs;
+            const int slots = sched_slots();
+            if (slots > 0 && N1 == N2 && (C % 32) == 0 && make_vol_sched(N1, B, slots, vs)) {
+                hipLaunchKernelGGL(corr_volume_f32_sched, dim3(slots), block, 0, s, a, b, out, C, N1, vs);
+            } else if ((N1 % 4 == 0) && (N2 % 4 == 0)) {
                 const int pg = persistent_grid();
                 if (pg > 0 && tiles_m * tiles_n * B > pg)
                     hipLaunchKernelGGL((corr_volume_f32_chw<true, true>), dim3(pg), block, 0, s, a, b, out, C, N1, N2,

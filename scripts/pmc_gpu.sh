@@ -11,15 +11,4 @@ for SET in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONF
   i=$((i+1))
   ( cd /tmp && rocprofv3 --pmc $SET --output-format csv -d $R/gpurun_out/pmc_${TAG}_$i -o pmc -- python $R/tools/kernel_bench.py "$@" --iters 5 ) > gpurun_out/pmc_${TAG}_$i.log 2>&1
 done
-python - <<PY
-import csv, glob, collections
-agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob("gpurun_out/pmc_${TAG}_*/pmc_counter_collection.csv"):
-    for r in csv.DictReader(open(f)):
-        agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k, v in agg.items():
-    if "corr_" in k or "pgo" in k or "kp_" in k:
-        print(k)
-        for c, vals in sorted(v.items()):
-            print("    %-34s n=%3d mean=%.4e" % (c, len(vals), sum(vals) / len(vals)))
-PY
+python tools/pmc_summary.py "$TAG" "$*"
