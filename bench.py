@@ -91,7 +91,8 @@ def roofline_of(ms, args, lanes, n_q, C, timed_region_launches, traffic=None):
     if args.feat_dtype == "f32":
         ach = flops / avg_s / 1e12
         return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "kernel": "corr_volume_f32_" + args.layout, **common}
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "kernel": "corr_volume_f32_mixed" if args.layout == "chw" else "corr_volume_f32_hwc", **common}
     ach = nbytes / avg_s / 1e9
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
             "traffic": None, "kernel": "corr_volume_h_" + args.layout, **common}
@@ -255,8 +256,11 @@ def main():
             for name in ("r02_pmc_corr_volume.json", "r01_pmc_corr_volume.json"):
                 path = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(path):
-                    traffic = json.load(open(path))["corr_volume_f32_" + args.layout]["_derived"]["traffic_bytes_per_launch"]
-                    break
+                    pm = json.load(open(path))
+                    key = next((k for k in pm if k.startswith("corr_volume_f32_mixed" if args.layout == "chw" else "corr_volume_f32_hwc")), None)
+                    if key is not None:
+                        traffic = pm[key]["_derived"]["traffic_bytes_per_launch"]
+                        break
     except Exception:  # noqa: BLE001
         traffic = None
     roofline = roofline_of(ms, args, args.lanes, n_q, C, in_region, traffic) if ms else None

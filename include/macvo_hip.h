@@ -360,6 +360,7 @@ int mv_obs_filter_lanes(const uint8_t* inbound, const double* cov1, const double
  *     mv_frame_pipe_enqueue(p, &in0, s, 0);
  *     mv_frame_pipe_enqueue(p, &in1, s, 1);
  *     loop t = 1..: mv_frame_pipe_enqueue(p, &in[t+1], s, 1);          // next frame's frontend first (software pipeline)
+ *                   mv_frame_pipe_enqueue_volume(p, &in[t+2], s);        // (optional) and the GEMM of the one after
  *                   mv_frame_pipe_wait_candidates(p, &n);                // host blocks on frame t's selector only
  *                   perm = torch.randperm(n)[:num_point]                 // stays on the host CPU: bit-exact indices
  *                   mv_frame_pipe_finish(p, perm, n_sel, pose_sink);     // backend + solve of frame t
@@ -429,6 +430,10 @@ int mv_frame_pipe_set_pose(mvFramePipe* p, const float* pose7_host);      /* [la
 /* frontend half of a frame; inputs must be complete on `in_stream` (an event is recorded there) and stay untouched
  * until the frame's lookups ran.  with_selector = 0 for the very first frame. */
 int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_stream, int with_selector);
+/* optional: issue the volume GEMM of the NEXT frame (the one the next mv_frame_pipe_enqueue will complete) right away; it
+ * only needs fmap1 / fmap2 and a free volume buffer, so the host can queue it before it blocks on the previous frame's
+ * candidate count and the GEMM stream never waits for the host.  At most one GEMM ahead. */
+int mv_frame_pipe_enqueue_volume(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_stream);
 int mv_frame_pipe_wait_candidates(mvFramePipe* p, int32_t* n_cand /* [lanes] host */);   /* oldest unfinished frame; blocks the host */
 /* perm_host: int64 [lanes, num_point], row l = randperm(n_cand[l])[:num_point] (n_sel[l] entries used); n_sel: int32 [lanes]
  * host; pose_sink: device fp32 [lanes, 7] or NULL (copy of the new poses) */

@@ -114,6 +114,7 @@ SIGNATURES = {
     "mv_frame_pipe_destroy": (None, [_P]),
     "mv_frame_pipe_set_pose": (C.c_int, [_P, _P]),
     "mv_frame_pipe_enqueue": (C.c_int, [_P, C.POINTER(mvFrameInputs), _P, C.c_int]),
+    "mv_frame_pipe_enqueue_volume": (C.c_int, [_P, C.POINTER(mvFrameInputs), _P]),
     "mv_frame_pipe_wait_candidates": (C.c_int, [_P, _P]),
     "mv_frame_pipe_finish": (C.c_int, [_P, _P, _P, _P]),
     "mv_frame_pipe_sync": (C.c_int, [_P, _P, C.c_int]),

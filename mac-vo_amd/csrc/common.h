@@ -26,6 +26,14 @@ struct mvLaneCounts {
 #define MV_SMALL_KERNEL_PRIO() ((void)0)
 #endif
 
+// A/B knob (-DMV_PRIO_CHAIN): the selector / epilogue kernels — the rest of the volume -> lookups -> selector -> host chain whose
+// latency bounds a single-sequence stream — at raised wave priority as well
+#ifdef MV_PRIO_CHAIN
+#define MV_CHAIN_KERNEL_PRIO() __builtin_amdgcn_s_setprio(3)
+#else
+#define MV_CHAIN_KERNEL_PRIO() ((void)0)
+#endif
+
 static inline int mv_launch_status() {
     return hipGetLastError() == hipSuccess ? MV_OK : MV_ERR_LAUNCH;
 }

@@ -22,6 +22,7 @@
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -375,9 +376,9 @@ __device__ __forceinline__ void vol_big_coords(const VolSched& S, int q, int& tm
 
 // One (64 MI) x (64 NJ) tile by the workgroup's 2 x 2 waves (wave tile 32 MI x 32 NJ), full K.  LDS: [stage][A: BK x 64 MI |
 // B: BK x 64 NJ] floats, columns permuted (tile column w * 32 M + i * 32 + l -> i * 64 + w * 32 + l).
-template <int MI, int NJ>
+template <int MI, int NJ, class Pre>
 __device__ __forceinline__ void vol_tile(const float* __restrict__ A, const float* __restrict__ Bp, float* __restrict__ O, int C,
-                                         int N, int m0, int n0, float* smem) {
+                                         int N, int m0, int n0, float* smem, Pre&& pre_epilogue) {
     constexpr int BK = 16;
     constexpr int WA = 64 * MI, WB = 64 * NJ;             // operand tile widths (floats per k row)
     constexpr int TA = WA / 4, TB = WB / 4;               // loader threads per k row
@@ -470,6 +471,9 @@ __device__ __forceinline__ void vol_tile(const float* __restrict__ A, const floa
         mma(1, [&](int g) { spiece(S0{}, 0, g); });
         __syncthreads();
     }
+    // hook between the last K step and the epilogue stores: anything that must WAIT on a memory return belongs here (the
+    // vmcnt queue is in order: behind the 64 stores below such a wait would sit until they have drained to memory)
+    pre_epilogue();
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5): one full 128-B line per
     // half-wave and store instruction
     float* Ou = O + (size_t)m0 * N + n0;
@@ -484,51 +488,81 @@ __device__ __forceinline__ void vol_tile(const float* __restrict__ A, const floa
         }
 }
 
+// item (round r of the whole schedule, position lin inside the round) -> run the tile it denotes (or nothing)
+template <class Pre>
+__device__ __forceinline__ void vol_run_item(const VolSched& S, int r, int lin, int slots, const float* __restrict__ f1,
+                                             const float* __restrict__ f2, float* __restrict__ out, int C, int N, size_t fsz,
+                                             size_t osz, float* smem, Pre&& pre) {
+    if (r < S.R_b) {
+        const int idx = r * slots + lin;
+        const int b = idx / S.n_big_pp;
+        int tm, tn;
+        vol_big_coords(S, idx - b * S.n_big_pp, tm, tn);
+        vol_tile<2, 2>(f1 + b * fsz, f2 + b * fsz, out + b * osz, C, N, tm * 128, tn * 128, smem, pre);
+        return;
+    }
+    r -= S.R_b;
+    if (r < S.R_m) {
+        const int idx = r * slots + lin;
+        if (idx < S.n_med_pp * S.B) {
+            const int b = idx / S.n_med_pp;
+            int tm, c;
+            vol_unit_coords(S, idx - b * S.n_med_pp, tm, c);
+            vol_tile<2, 1>(f1 + b * fsz, f2 + b * fsz, out + b * osz, C, N, tm * 128, c * 64, smem, pre);
+        } else {
+            pre();
+        }
+        return;
+    }
+    r -= S.R_m;
+    const int idx = r * slots + lin;
+    if (idx < S.n_small_pp * S.B) {
+        const int b = idx / S.n_small_pp, sm = idx - b * S.n_small_pp;
+        const int from_units = 2 * (S.U_pp - S.n_med_pp);
+        int m0, n0;
+        if (sm < from_units) {   // the two 64x64 halves of a unit that did not become a 128x64 tile
+            int tm, c;
+            vol_unit_coords(S, S.n_med_pp + (sm >> 1), tm, c);
+            m0 = tm * 128 + (sm & 1) * 64;
+            n0 = c * 64;
+        } else {                 // the odd last cell row
+            m0 = (S.Nc - 1) * 64;
+            n0 = (sm - from_units) * 64;
+        }
+        vol_tile<1, 1>(f1 + b * fsz, f2 + b * fsz, out + b * osz, C, N, m0, n0, smem, pre);
+    } else {
+        pre();
+    }
+}
+
+// STATIC walk: workgroup s takes item s' of every round (s' = s with the XCD bits moved to the top, so that XCD x = s & 7 owns a
+// contiguous eighth of each round).  Perfectly balanced when the kernel has the GPU to itself; used when no queue is available.
 __global__ __launch_bounds__(256) void corr_volume_f32_sched(const float* __restrict__ f1, const float* __restrict__ f2,
                                                               float* __restrict__ out, int C, int N, VolSched S) {
     __shared__ __attribute__((aligned(16))) float smem[2 * 16 * 256];
     const int slots = gridDim.x;
     const int s = blockIdx.x;
     const size_t fsz = (size_t)C * N, osz = (size_t)N * N;
-    // inside a round XCD x (= s & 7: consecutive workgroup ids land on different XCDs) owns a contiguous eighth of the items
     const int lin = (s & 7) * (slots >> 3) + (s >> 3);
+    const int rounds = S.R_b + S.R_m + S.R_s;
 #pragma unroll 1
-    for (int r = 0; r < S.R_b; ++r) {
-        const int idx = r * slots + lin;
-        const int b = idx / S.n_big_pp;
-        int tm, tn;
-        vol_big_coords(S, idx - b * S.n_big_pp, tm, tn);
-        vol_tile<2, 2>(f1 + b * fsz, f2 + b * fsz, out + b * osz, C, N, tm * 128, tn * 128, smem);
-    }
-#pragma unroll 1
-    for (int r = 0; r < S.R_m; ++r) {
-        const int idx = r * slots + lin;
-        if (idx < S.n_med_pp * S.B) {
-            const int b = idx / S.n_med_pp;
-            int tm, c;
-            vol_unit_coords(S, idx - b * S.n_med_pp, tm, c);
-            vol_tile<2, 1>(f1 + b * fsz, f2 + b * fsz, out + b * osz, C, N, tm * 128, c * 64, smem);
-        }
-    }
-#pragma unroll 1
-    for (int r = 0; r < S.R_s; ++r) {
-        const int idx = r * slots + lin;
-        if (idx < S.n_small_pp * S.B) {
-            const int b = idx / S.n_small_pp, sm = idx - b * S.n_small_pp;
-            const int from_units = 2 * (S.U_pp - S.n_med_pp);
-            int m0, n0;
-            if (sm < from_units) {   // the two 64x64 halves of a unit that did not become a 128x64 tile
-                int tm, c;
-                vol_unit_coords(S, S.n_med_pp + (sm >> 1), tm, c);
-                m0 = tm * 128 + (sm & 1) * 64;
-                n0 = c * 64;
-            } else {                 // the odd last cell row
-                m0 = (S.Nc - 1) * 64;
-                n0 = (sm - from_units) * 64;
-            }
-            vol_tile<1, 1>(f1 + b * fsz, f2 + b * fsz, out + b * osz, C, N, m0, n0, smem);
-        }
-    }
+    for (int r = 0; r < rounds; ++r) vol_run_item(S, r, lin, slots, f1, f2, out, C, N, fsz, osz, smem, [] {});
+}
+
+// ONE ITEM PER WORKGROUP (default): grid = rounds x slots workgroups, workgroup i runs item (i / slots, i % slots) of the same
+// schedule.  The hardware dispatcher hands workgroups out in id order as CU slots free up — big tiles first, 64x64 tiles last
+// (longest processing time first) — so CUs that fall behind simply receive fewer items.  That matters inside the frame
+// pipeline, where this GEMM shares the chip with the latency-bound kernels of the other streams: with the persistent static
+// walk the slowest workgroup sets the kernel's end (measured: 190 us alone, 200 us beside one sequence's small kernels,
+// 564 -> 896 us with three lanes).  Residency is held at 2 workgroups per CU (the measured optimum) by padding the
+// workgroup's LDS request.  Also measured: a persistent grid pulling items from per-XCD atomic queues: 237 us — the returning
+// atomic makes hipcc drain the vmcnt queue (the previous tile's 64 epilogue stores per wave) at every item, 4.5 us per tile.
+__global__ __launch_bounds__(256) void corr_volume_f32_mixed(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                              float* __restrict__ out, int C, int N, VolSched S, int slots) {
+    extern __shared__ __attribute__((aligned(16))) float smem_mixed[];   // 32 KB used + occupancy padding
+    const int r = blockIdx.x / slots, s = blockIdx.x - r * slots;
+    const int lin = (s & 7) * (slots >> 3) + (s >> 3);     // XCD x = id & 7 owns a contiguous eighth of each round
+    vol_run_item(S, r, lin, slots, f1, f2, out, C, N, (size_t)C * N, (size_t)N * N, smem_mixed, [] {});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -978,6 +1012,25 @@ static int sched_slots() {
     return v;
 }
 
+// Scheduled fp32 kernel: schedule width (items per round) and residency.  MV_VOL_SCHED=0 -> one-tile-per-workgroup kernel;
+// MV_VOL_WALK=static -> persistent static walk; MV_VOL_WG_PER_CU=<k> residency of the default form (2).
+static int vol_walk_static() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MV_VOL_WALK"); v = (e && strcmp(e, "static") == 0) ? 1 : 0; }
+    return v;
+}
+static unsigned vol_lds_bytes() {   // dynamic LDS request that admits exactly k workgroups of this kernel per CU (160 KB LDS)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MV_VOL_WG_PER_CU");
+        const int k = e ? atoi(e) : 2;
+        const int used = 2 * 16 * 256 * 4;
+        v = used;
+        if (k >= 1 && k < 5) { const int need = 160 * 1024 / (k + 1) + 1024; v = need > used ? need : used; }
+    }
+    return (unsigned)v;
+}
+
 extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B, int C, int N1, int N2,
                               int in_dtype, int layout, mvStream_t stream) {
     MV_CHECK_ARG(f1 && f2 && out);
@@ -996,7 +1049,18 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
             VolSched vs;
             const int slots = sched_slots();
             if (slots > 0 && N1 == N2 && (C % 32) == 0 && make_vol_sched(N1, B, slots, vs)) {
-                hipLaunchKernelGGL(corr_volume_f32_sched, dim3(slots), block, 0, s, a, b, out, C, N1, vs);
+                if (vol_walk_static()) {
+                    hipLaunchKernelGGL(corr_volume_f32_sched, dim3(slots), block, 0, s, a, b, out, C, N1, vs);
+                } else {
+                    const unsigned lds = vol_lds_bytes();
+                    static bool attr_set = false;
+                    if (!attr_set && lds > 48 * 1024) {
+                        (void)hipFuncSetAttribute((const void*)corr_volume_f32_mixed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                        attr_set = true;
+                    }
+                    hipLaunchKernelGGL(corr_volume_f32_mixed, dim3((vs.R_b + vs.R_m + vs.R_s) * slots), block, lds, s, a, b, out, C,
+                                       N1, vs, slots);
+                }
             } else if ((N1 % 4 == 0) && (N2 % 4 == 0)) {
                 const int pg = persistent_grid();
                 if (pg > 0 && tiles_m * tiles_n * B > pg)

@@ -41,7 +41,7 @@
 
 namespace {
 
-constexpr int N_MAPS = 3, N_PERM = 4, N_INEV = 8;
+constexpr int N_MAPS = 3, N_PERM = 4, N_INEV = 8, MAX_VOL = 3;
 
 struct Maps {
     float *disparity, *disparity_cov, *depth, *depth_cov, *match_flow, *match_cov;
@@ -83,7 +83,8 @@ struct mvFramePipe {
     char* arena;
     size_t arena_bytes;
     // device buffers
-    float* vol[2];
+    float* vol[MAX_VOL];
+    int n_volbuf;   // 2, or 3 (MV_PIPE_VOL_BUFS=3: a GEMM issued ahead then waits for the lookups of frame t-1 instead of t)
     float* tok[2];
     void* planes[2];   // bf16x3 split planes of fmap1 / fmap2 (volume_split3)
     float *up_flow, *up_cov;
@@ -102,15 +103,19 @@ struct mvFramePipe {
     int64_t* h_perm[N_PERM];  // pinned
     // streams / events
     hipStream_t s_vol, s_main, s_back, s_side;
-    hipEvent_t e_in[N_INEV], e_vol_done[2], e_vol_free[2], e_cand[2], e_backend[2], e_pgo, e_perm[N_PERM];
-    bool vol_free_valid[2], backend_valid[2], pgo_valid, perm_valid[N_PERM];
+    hipEvent_t e_rest[N_INEV];   // inputs of the decoder side (coords, flow, ...) when the GEMM was issued ahead of them
+    hipEvent_t e_in[N_INEV], e_vol_done[MAX_VOL], e_vol_free[MAX_VOL], e_cand[2], e_backend[2], e_pgo, e_perm[N_PERM];
+    bool vol_free_valid[MAX_VOL], backend_valid[2], pgo_valid, perm_valid[N_PERM];
     // state
     long n_enq, n_fin;
+    long n_vol;            // volume GEMMs issued (n_enq <= n_vol <= n_enq + 1: at most one GEMM ahead of its frame's decoder side)
+    hipEvent_t e_in_of[MAX_VOL];   // per volume buffer: the input-ready event its GEMM waited for (the decoder side re-uses it)
     int lookups_on_main;   // default 1; MV_PIPE_LOOKUPS_ON=vol is the measured alternative
     int pose_cur;
     int newest_maps;
     std::deque<Pending> pending;
     // optional timing of the dominant kernel (bench.py roofline): event pairs around each volume GEMM on its stream
+    int vol_timed[MAX_VOL];      // timing slot of the GEMM that filled each volume buffer (-1: not timed)
     std::vector<hipEvent_t> tv0, tv1, tv2, tv3;   // GEMM start / end, last lookup done, selector done (timeline hook)
     int n_timed, timed_cap;
 };
@@ -124,12 +129,20 @@ static int wait_if_pending(hipStream_t s, hipEvent_t e) {
     return hipStreamWaitEvent(s, e, 0) == hipSuccess ? MV_OK : MV_ERR_LAUNCH;
 }
 
+static int volbufs_from_env() {
+    // 3 (default): with a GEMM issued one frame ahead (mv_frame_pipe_enqueue_volume) the buffer it rewrites was last read by
+    // the lookups of frame t - 1, long finished; with 2 it waits for frame t's lookups, which run beside the previous GEMM at a
+    // third of their isolated speed (measured 272 vs 245 us per frame).  MV_PIPE_VOL_BUFS=2 is the A/B knob.
+    const char* e = getenv("MV_PIPE_VOL_BUFS");
+    return (e && atoi(e) == 2) ? 2 : 3;
+}
+
 static size_t carve(mvFramePipe* p, char* base) {
     const mvFramePipeConfig& c = p->c;
     Carver a{base};
     const size_t L = p->lanes;
     const size_t plane = p->plane, n8 = p->n8, B = c.pairs, N = c.num_point > 0 ? c.num_point : 1;
-    for (int k = 0; k < 2; ++k) p->vol[k] = a.take<float>(B * n8 * n8);
+    for (int k = 0; k < p->n_volbuf; ++k) p->vol[k] = a.take<float>(B * n8 * n8);
     for (int k = 0; k < 2; ++k) p->tok[k] = a.take<float>(B * p->KK * n8);
     for (int k = 0; k < 2; ++k) p->planes[k] = c.volume_split ? (void*)a.take<uint16_t>(3 * B * n8 * c.C) : nullptr;
     p->up_flow = a.take<float>(B * 2 * plane);
@@ -201,6 +214,7 @@ extern "C" size_t mv_frame_pipe_arena_bytes(const mvFramePipeConfig* cfg) {
     tmp.n8 = tmp.h8 * tmp.w8;
     tmp.KK = (2 * cfg->radius + 1) * (2 * cfg->radius + 1);
     tmp.lanes = cfg->pairs / 2;
+    tmp.n_volbuf = volbufs_from_env();
     return carve(&tmp, nullptr);
 }
 
@@ -212,7 +226,9 @@ extern "C" void mv_frame_pipe_destroy(mvFramePipe* p) {
     (void)hipStreamSynchronize(p->s_side);
     auto ev = [](hipEvent_t e) { if (e) (void)hipEventDestroy(e); };
     for (auto e : p->e_in) ev(e);
-    for (int k = 0; k < 2; ++k) { ev(p->e_vol_done[k]); ev(p->e_vol_free[k]); ev(p->e_cand[k]); ev(p->e_backend[k]); }
+    for (auto e : p->e_rest) ev(e);
+    for (int k = 0; k < MAX_VOL; ++k) { ev(p->e_vol_done[k]); ev(p->e_vol_free[k]); }
+    for (int k = 0; k < 2; ++k) { ev(p->e_cand[k]); ev(p->e_backend[k]); }
     ev(p->e_pgo);
     for (auto e : p->e_perm) ev(e);
     for (auto e : p->tv0) ev(e);
@@ -280,15 +296,21 @@ static int create_impl(mvFramePipe* p) {
         } else {
             MV_HIP(hipStreamCreateWithPriority(&p->s_vol, hipStreamNonBlocking, 0));
         }
-        MV_HIP(hipStreamCreateWithPriority(&p->s_main, hipStreamNonBlocking, 0));
+        {
+            const char* e = getenv("MV_PIPE_MAIN_PRIO");   // A/B knob: queue priority of the lookups / epilogue / selector stream
+            MV_HIP(hipStreamCreateWithPriority(&p->s_main, hipStreamNonBlocking, (e && strcmp(e, "hi") == 0) ? hi : 0));
+        }
         MV_HIP(hipStreamCreateWithPriority(&p->s_back, hipStreamNonBlocking, hi));
         MV_HIP(hipStreamCreateWithPriority(&p->s_side, hipStreamNonBlocking, hi));
     }
     auto mk = [](hipEvent_t* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming); };
     for (auto& e : p->e_in) MV_HIP(mk(&e));
-    for (int k = 0; k < 2; ++k) {
+    for (auto& e : p->e_rest) MV_HIP(mk(&e));
+    for (int k = 0; k < MAX_VOL; ++k) {
         MV_HIP(mk(&p->e_vol_done[k]));
         MV_HIP(mk(&p->e_vol_free[k]));
+    }
+    for (int k = 0; k < 2; ++k) {
         MV_HIP(mk(&p->e_cand[k]));
         MV_HIP(mk(&p->e_backend[k]));
         MV_HIP(hipHostMalloc((void**)&p->h_count[k], (size_t)p->lanes * 4 * sizeof(int32_t), hipHostMallocDefault));
@@ -329,6 +351,7 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
     p->n8 = p->h8 * p->w8;
     p->KK = (2 * cfg->radius + 1) * (2 * cfg->radius + 1);
     p->lanes = cfg->pairs / 2;
+    p->n_volbuf = volbufs_from_env();
     p->arena = (char*)arena;
     p->arena_bytes = arena_bytes;
     if (((uintptr_t)arena & 255) != 0 || carve(p, p->arena) > arena_bytes) {
@@ -357,23 +380,16 @@ extern "C" int mv_frame_pipe_set_pose(mvFramePipe* p, const float* pose7_host) {
 }
 
 // ------------------------------------------------------------------------------------------------ frontend half
-extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_stream, int with_selector) {
-    MV_CHECK_ARG(p && in && in->fmap1 && in->fmap2);
+// volume GEMM of frame n_vol on its own stream; a buffer is rewritten only after the lookups that read it have finished
+static int issue_volume(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_stream) {
     const mvFramePipeConfig& c = p->c;
-    MV_CHECK_ARG(c.iters == 0 || in->coords);
-    const bool up = in->flow8 != nullptr;
-    MV_CHECK_ARG(up ? (in->cov8 && in->up_mask && in->cov_mask) : (in->flow && in->logcov));
-    const long f = p->n_enq;
-    const int k = (int)(f & 1), m = (int)(f % N_MAPS);
-    MV_CHECK_ARG(!with_selector || p->newest_maps >= 0);   // a tracked frame needs the previous frame's maps
-    MV_CHECK_ARG(!with_selector || p->pending.size() < 2);  // slot rotation covers two tracked frames in flight
+    const long f = p->n_vol;
+    const int k = (int)(f % p->n_volbuf);
     const int B = c.pairs;
-
     // inputs were produced on the caller's stream
     hipEvent_t e_in = p->e_in[f % N_INEV];
     MV_HIP(hipEventRecord(e_in, (hipStream_t)in_stream));
-
-    // ---- volume GEMM (own stream; a buffer is rewritten only after the lookups that read it have finished)
+    p->e_in_of[k] = e_in;
     MV_TRY(wait_if_pending(p->s_vol, e_in));
     if (p->vol_free_valid[k]) MV_TRY(wait_if_pending(p->s_vol, p->e_vol_free[k]));
     const bool timed = p->n_timed < p->timed_cap;
@@ -387,30 +403,68 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
     } else {
         MV_TRY(mv_corr_volume(in->fmap1, in->fmap2, p->vol[k], B, c.C, p->n8, p->n8, c.feat_dtype, c.layout, p->s_vol));
     }
-    const int ti = p->n_timed;
+    p->vol_timed[k] = timed ? p->n_timed : -1;
     if (timed) MV_HIP(hipEventRecord(p->tv1[p->n_timed++], p->s_vol));
+    MV_HIP(hipEventRecord(p->e_vol_done[k], p->s_vol));
+    p->n_vol = f + 1;
+    return MV_OK;
+}
+
+// Optional early issue of the NEXT frame's volume GEMM (frame n_enq, before its mv_frame_pipe_enqueue): the GEMM only
+// needs the feature maps and a free volume buffer, so the host can queue it one frame ahead — before it blocks on the
+// previous frame's candidate count — and the GEMM stream never waits for the host (measured: ~93 us of idle per frame).
+extern "C" int mv_frame_pipe_enqueue_volume(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_stream) {
+    MV_CHECK_ARG(p && in && in->fmap1 && in->fmap2);
+    MV_CHECK_ARG(p->n_vol == p->n_enq);                 // at most one GEMM ahead of its frame
+    MV_CHECK_ARG(p->lookups_on_main);                   // the alternative layout keeps the lookups behind the GEMM on its stream
+    // the volume buffer of frame n_vol was last read by the lookups of frame n_vol - 2: their event exists (frame enqueued)
+    return issue_volume(p, in, in_stream);
+}
+
+extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_stream, int with_selector) {
+    MV_CHECK_ARG(p && in && in->fmap1 && in->fmap2);
+    const mvFramePipeConfig& c = p->c;
+    MV_CHECK_ARG(c.iters == 0 || in->coords);
+    const bool up = in->flow8 != nullptr;
+    MV_CHECK_ARG(up ? (in->cov8 && in->up_mask && in->cov_mask) : (in->flow && in->logcov));
+    const long f = p->n_enq;
+    const int k = (int)(f & 1), m = (int)(f % N_MAPS);
+    MV_CHECK_ARG(!with_selector || p->newest_maps >= 0);   // a tracked frame needs the previous frame's maps
+    MV_CHECK_ARG(!with_selector || p->pending.size() < 2);  // slot rotation covers two tracked frames in flight
+    const int B = c.pairs;
+
+    // ---- volume GEMM (own stream) unless mv_frame_pipe_enqueue_volume already issued it
+    const bool ahead = p->n_vol != f;
+    if (!ahead) MV_TRY(issue_volume(p, in, in_stream));
+    const int kv = (int)(f % p->n_volbuf);   // volume buffer of this frame (k = its candidate / backend slot)
+    const int ti = p->vol_timed[kv];
+    const bool timed = ti >= 0;
 
     // ---- decoder side on `main`, overlapping the next frame's GEMM.  (MV_PIPE_LOOKUPS_ON=vol keeps the lookups on the
     // GEMM's stream instead — no cross-stream event in front of the first lookup, GEMM undisturbed at 215 us — measured
     // 0.3256 vs 0.3197 ms per frame: behind a 215-us kernel each of the 12 launch boundaries costs ~9 us.)
     const size_t coord_stride = (size_t)B * 2 * p->n8;
     hipStream_t s = p->s_main;
+    if (ahead) {   // the GEMM's input event predates this call: order the decoder side after the caller's stream as of NOW
+        hipEvent_t e = p->e_rest[f % N_INEV];
+        MV_HIP(hipEventRecord(e, (hipStream_t)in_stream));
+        MV_TRY(wait_if_pending(s, e));
+    }
     if (p->lookups_on_main) {
-        MV_HIP(hipEventRecord(p->e_vol_done[k], p->s_vol));
-        MV_HIP(hipStreamWaitEvent(s, p->e_vol_done[k], 0));   // also orders `s` after e_in (the GEMM stream waited for it)
+        MV_HIP(hipStreamWaitEvent(s, p->e_vol_done[kv], 0));   // also orders `s` after e_in (the GEMM stream waited for it)
         for (int it = 0; it < c.iters; ++it)
-            MV_TRY(mv_corr_lookup(p->vol[k], in->coords + it * coord_stride, p->tok[it & 1], B, p->h8, p->w8, p->h8, p->w8,
+            MV_TRY(mv_corr_lookup(p->vol[kv], in->coords + it * coord_stride, p->tok[it & 1], B, p->h8, p->w8, p->h8, p->w8,
                                   c.radius, s));
-        MV_HIP(hipEventRecord(p->e_vol_free[k], s));
-        p->vol_free_valid[k] = true;
+        MV_HIP(hipEventRecord(p->e_vol_free[kv], s));
+        p->vol_free_valid[kv] = true;
         if (timed) MV_HIP(hipEventRecord(p->tv2[ti], s));
     } else {
         for (int it = 0; it < c.iters; ++it)
-            MV_TRY(mv_corr_lookup(p->vol[k], in->coords + it * coord_stride, p->tok[it & 1], B, p->h8, p->w8, p->h8, p->w8,
+            MV_TRY(mv_corr_lookup(p->vol[kv], in->coords + it * coord_stride, p->tok[it & 1], B, p->h8, p->w8, p->h8, p->w8,
                                   c.radius, p->s_vol));
-        MV_HIP(hipEventRecord(p->e_vol_done[k], p->s_vol));   // volume AND its lookups done
-        MV_HIP(hipStreamWaitEvent(s, p->e_vol_done[k], 0));   // also orders `s` after e_in
-        p->vol_free_valid[k] = false;                         // vol[k] / tok are only touched on s_vol: stream order suffices
+        MV_HIP(hipEventRecord(p->e_vol_done[kv], p->s_vol));   // volume AND its lookups done
+        MV_HIP(hipStreamWaitEvent(s, p->e_vol_done[kv], 0));   // also orders `s` after e_in
+        p->vol_free_valid[kv] = false;                         // vol[k] / tok are only touched on s_vol: stream order suffices
     }
 
     // maps slot m and candidate slot k were last read by the backend of frame f - 2 (f - 3 for the maps) on `back`
@@ -613,7 +667,7 @@ extern "C" int mv_frame_pipe_buffer(mvFramePipe* p, int which, int age, void** p
     const Backend* b = back() ? &p->be[g & 1] : nullptr;
     const size_t N = L * (size_t)(c.num_point > 0 ? c.num_point : 1);   // capacity rows (a lane's live rows: its n_sel)
     switch (which) {
-        case MV_FB_VOLUME: if (!front(2)) break; *ptr = p->vol[f & 1]; *count = (size_t)c.pairs * p->n8 * p->n8; return MV_OK;
+        case MV_FB_VOLUME: if (!front(p->n_vol > p->n_enq ? 1 : 2)) break;   // a GEMM issued ahead is rewriting the older buffer *ptr = p->vol[f % p->n_volbuf]; *count = (size_t)c.pairs * p->n8 * p->n8; return MV_OK;
         case MV_FB_TOKENS: if (!front(1) || c.iters == 0) break; *ptr = p->tok[(c.iters - 1) & 1]; *count = (size_t)c.pairs * p->KK * p->n8; return MV_OK;
         case MV_FB_DISPARITY: if (!front(N_MAPS)) break; *ptr = p->maps[f % N_MAPS].disparity; *count = plane; return MV_OK;
         case MV_FB_DISPARITY_COV: if (!front(N_MAPS)) break; *ptr = p->maps[f % N_MAPS].disparity_cov; *count = plane; return MV_OK;

@@ -17,6 +17,7 @@ __global__ __launch_bounds__(256) void frontend_epilogue_kernel(
     float bl_fx_sq, float* __restrict__ disparity, float* __restrict__ disparity_cov, float* __restrict__ depth,
     float* __restrict__ depth_cov, uint8_t* __restrict__ bad_mask, float* __restrict__ match_flow,
     float* __restrict__ match_cov) {
+    MV_CHAIN_KERNEL_PRIO();
     // lane-batched (blockIdx.y = lane): inputs [lanes, 2, 2, H, W], every output [lanes, ch, H, W]
     const size_t lo = (size_t)blockIdx.y * plane;
     flow += 4 * lo; logcov += 4 * lo;

@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void kp_nms_kernel(const float* __restrict__ f
                                                       const uint8_t* __restrict__ mask_a,
                                                       const uint8_t* __restrict__ mask_b, mvKpSelectParams p,
                                                       KpWs ws_all, int words_per_row) {
+    MV_CHAIN_KERNEL_PRIO();
     // lane-batched: blockIdx.z = lane (independent frame); maps are [lanes, ch, H, W], one workspace copy per lane
     const KpWs ws = ws_all.lane(blockIdx.z);
     {
@@ -552,6 +553,7 @@ __global__ __launch_bounds__(NT) void kp_finish_kernel(mvKpSelectParams p, KpWs 
                                                         float* __restrict__ out_stats) {
     __shared__ MedianLds L;
     extern __shared__ unsigned long long lds_words[];
+    MV_CHAIN_KERNEL_PRIO();
     // lane-batched: one finishing workgroup per lane (blockIdx.x); out_cand [lanes, H*W], out_count / out_stats [lanes, 4]
     const KpWs ws = ws_all.lane(blockIdx.x);
     out_cand += (size_t)blockIdx.x * p.H * p.W;

@@ -21,6 +21,7 @@ The only host synchronisation per frame is the selector's candidate count (neede
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 
 import torch
@@ -466,6 +467,7 @@ class NativeHotPath:
         self.generators = list(generators) if generators is not None else [None] * self.lanes
         assert len(self.generators) == self.lanes
         self._cap = max(self.cfg.num_point, 1)
+        self._volume_ahead = os.environ.get("MV_PIPE_VOLUME_AHEAD", "1") != "0"   # A/B knob of run()
         self.lm = ops.lm_default_params()
         self._pipe = None
         self._arena = None
@@ -603,6 +605,15 @@ class NativeHotPath:
         self._enqueue(x, True)
         return x
 
+    def enqueue_volume(self, x: FrameInputs) -> None:
+        """Issue only the cost-volume GEMM of the frame the NEXT :meth:`enqueue_frontend` call will complete (same ``x``).
+        The GEMM needs nothing but the feature maps and a free volume buffer, so it can be queued a frame ahead — before the
+        host blocks on the previous frame's candidate count — and the GEMM stream never waits for the host."""
+        if x.ready is not None:
+            torch.cuda.current_stream().wait_event(x.ready)
+        ops.L.check(self._lib.mv_frame_pipe_enqueue_volume(self._pipe, ops.C.byref(self._inputs(x)), ops._stream()),
+                    "mv_frame_pipe_enqueue_volume")
+
     def finish(self, pend=None, pose_sink: torch.Tensor | None = None):
         """Host half of a frame: wait for the candidate counts, draw the permutations (CPU generators, lane order), enqueue
         the pose-dependent kernels.  Returns a :class:`_NativeResult` (a list of them, one per lane, for lanes > 1)."""
@@ -681,19 +692,33 @@ class NativeHotPath:
             ops.L.check(self._lib.mv_frame_pipe_sync(self._pipe, None, 1), "mv_frame_pipe_sync")
 
     def run(self, frames, pose_sink: torch.Tensor | None = None):
-        """Software-pipelined stream (frame t+1's frontend is enqueued before frame t's host randperm).  ``pose_sink``:
-        ``[steps, 7]`` (``[steps, lanes, 7]`` for lanes > 1) device tensor receiving each step's poses."""
+        """Software-pipelined stream: frame t+1's frontend AND frame t+2's volume GEMM are enqueued before the host blocks on
+        frame t's candidate count / draws its permutation.  ``pose_sink``: ``[steps, 7]`` (``[steps, lanes, 7]`` for
+        lanes > 1) device tensor receiving each step's poses."""
         it = iter(frames)
-        try:
-            self.enqueue_frontend(next(it))
-        except StopIteration:
+        nxt = next(it, None)
+        if nxt is None:
             return
-        i, more = 0, True
-        while more:
-            try:
-                self.enqueue_frontend(next(it))
-            except StopIteration:
+        self.enqueue_frontend(nxt)
+        nxt = next(it, None)
+        ahead = self._volume_ahead and nxt is not None
+        if ahead:
+            self.enqueue_volume(nxt)
+        i = 0
+        while True:
+            if nxt is not None:
+                self.enqueue_frontend(nxt)              # completes the frame whose GEMM is already queued
+                nxt = next(it, None)
+                if ahead and nxt is not None:
+                    self.enqueue_volume(nxt)
+                more = True
+            else:
                 more = False
             yield self.finish(None, None if pose_sink is None else pose_sink[i])
             i += 1
+            if not more and not self._has_pending():
+                break
         self.sync_pose()
+
+    def _has_pending(self) -> bool:
+        return self._n_fin < self._n_enq - 1          # frame 0 (initialize) is never finished

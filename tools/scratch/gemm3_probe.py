@@ -10,6 +10,9 @@ modes = [int(a) for a in sys.argv[2:]] or [0, 1, 3, 4, 5]
 torch.manual_seed(0)
 f1 = torch.randn(B, Cc, N, device="cuda"); f2 = torch.randn(B, Cc, N, device="cuda"); out = torch.empty(B, N, N, device="cuda")
 fl = B * 2.0 * N * N * Cc
+extq = torch.zeros(1 << 16, dtype=torch.int32, device="cuda")
+lib.gemm3_set_queue.argtypes = [C.c_void_p]
+lib.gemm3_set_queue(extq.data_ptr())
 def run(mode, n):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
