@@ -364,7 +364,7 @@ int mv_obs_filter_lanes(const uint8_t* inbound, const double* cov1, const double
  *                   mv_frame_pipe_wait_candidates(p, &n);                // host blocks on frame t's selector only
  *                   perm = torch.randperm(n)[:num_point]                 // stays on the host CPU: bit-exact indices
  *                   mv_frame_pipe_finish(p, perm, n_sel, pose_sink);     // backend + solve of frame t
- * At most two tracked frames may be in flight (enqueued, not finished).
+ * At most three tracked frames may be in flight (enqueued, not finished): candidates x3, maps x5, volumes x3 rotate.
  *
  * Lanes (BASELINE configs[4], "batch-32 frames per GPU"): with pairs = 2 * lanes the pipe advances `lanes` INDEPENDENT
  * sequences in lock-step through the same launches — one volume GEMM of 2 * lanes pairs (pair 2l = lane l's stereo pair,
@@ -438,7 +438,9 @@ int mv_frame_pipe_wait_candidates(mvFramePipe* p, int32_t* n_cand /* [lanes] hos
 /* perm_host: int64 [lanes, num_point], row l = randperm(n_cand[l])[:num_point] (n_sel[l] entries used); n_sel: int32 [lanes]
  * host; pose_sink: device fp32 [lanes, 7] or NULL (copy of the new poses) */
 int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, const int32_t* n_sel, float* pose_sink);
-/* block_host != 0: wait for all four streams; else make `stream` wait for everything enqueued so far */
+/* block_host = 1: wait for all four streams on the host; 0: make `stream` wait for everything enqueued so far (including the
+ * frontends of frames enqueued ahead); 2: make `stream` wait for the newest FINISHED frame's backend + solve only — what a
+ * consumer of that frame's results needs while later frames are already queued */
 int mv_frame_pipe_sync(mvFramePipe* p, mvStream_t stream, int block_host);
 /* measurement hook (bench.py roofline): record a HIP-event pair around each of the next max_launches volume GEMMs on the
  * stream they run on (0 = off; restarts the count), and read the elapsed milliseconds back (blocks on that stream) */

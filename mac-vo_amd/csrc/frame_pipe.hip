@@ -41,7 +41,9 @@
 
 namespace {
 
-constexpr int N_MAPS = 3, N_PERM = 4, N_INEV = 8, MAX_VOL = 3;
+// slot rotation for up to MAX_PENDING tracked frames in flight (enqueued, not finished): frame f's epilogue writes maps[f % N_MAPS]
+// while the backend of frame f - MAX_PENDING may still read maps of f - MAX_PENDING and f - MAX_PENDING - 1
+constexpr int MAX_PENDING = 3, N_MAPS = MAX_PENDING + 2, N_CAND = MAX_PENDING, N_PERM = 4, N_INEV = 8, MAX_VOL = 3;
 
 struct Maps {
     float *disparity, *disparity_cov, *depth, *depth_cov, *match_flow, *match_cov;
@@ -91,20 +93,20 @@ struct mvFramePipe {
     Maps maps[N_MAPS];
     void* kp_ws;
     size_t kp_ws_bytes;
-    int32_t* cand[2];
-    int32_t* count[2];
-    float* stats[2];
+    int32_t* cand[N_CAND];
+    int32_t* count[N_CAND];
+    float* stats[N_CAND];
     Backend be[2];
     float* pose[3];   // [lanes, 7]
     float *intr, *bl;   // [lanes, 4], [lanes]
     int32_t* offs;    // [lanes + 1]: lane l owns rows [l * cap, (l + 1) * cap) of the backend tables
     // host
-    int32_t* h_count[2];      // pinned
+    int32_t* h_count[N_CAND];      // pinned
     int64_t* h_perm[N_PERM];  // pinned
     // streams / events
     hipStream_t s_vol, s_main, s_back, s_side;
     hipEvent_t e_rest[N_INEV];   // inputs of the decoder side (coords, flow, ...) when the GEMM was issued ahead of them
-    hipEvent_t e_in[N_INEV], e_vol_done[MAX_VOL], e_vol_free[MAX_VOL], e_cand[2], e_backend[2], e_pgo, e_perm[N_PERM];
+    hipEvent_t e_in[N_INEV], e_vol_done[MAX_VOL], e_vol_free[MAX_VOL], e_cand[N_CAND], e_backend[2], e_pgo, e_perm[N_PERM];
     bool vol_free_valid[MAX_VOL], backend_valid[2], pgo_valid, perm_valid[N_PERM];
     // state
     long n_enq, n_fin;
@@ -159,10 +161,12 @@ static size_t carve(mvFramePipe* p, char* base) {
     }
     p->kp_ws_bytes = L * mv_kp_select_workspace_bytes(c.H, c.W);
     p->kp_ws = a.take<char>(p->kp_ws_bytes);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < N_CAND; ++k) {
         p->cand[k] = a.take<int32_t>(L * plane);
         p->count[k] = a.take<int32_t>(L * 4);
         p->stats[k] = a.take<float>(L * 4);
+    }
+    for (int k = 0; k < 2; ++k) {
         Backend& b = p->be[k];
         b.perm = a.take<int64_t>(L * N);
         b.kp0 = a.take<int64_t>(L * 2 * N);
@@ -228,14 +232,15 @@ extern "C" void mv_frame_pipe_destroy(mvFramePipe* p) {
     for (auto e : p->e_in) ev(e);
     for (auto e : p->e_rest) ev(e);
     for (int k = 0; k < MAX_VOL; ++k) { ev(p->e_vol_done[k]); ev(p->e_vol_free[k]); }
-    for (int k = 0; k < 2; ++k) { ev(p->e_cand[k]); ev(p->e_backend[k]); }
+    for (int k = 0; k < N_CAND; ++k) ev(p->e_cand[k]);
+    for (int k = 0; k < 2; ++k) ev(p->e_backend[k]);
     ev(p->e_pgo);
     for (auto e : p->e_perm) ev(e);
     for (auto e : p->tv0) ev(e);
     for (auto e : p->tv1) ev(e);
     for (auto e : p->tv2) ev(e);
     for (auto e : p->tv3) ev(e);
-    for (int k = 0; k < 2; ++k) if (p->h_count[k]) (void)hipHostFree(p->h_count[k]);
+    for (int k = 0; k < N_CAND; ++k) if (p->h_count[k]) (void)hipHostFree(p->h_count[k]);
     for (auto h : p->h_perm) if (h) (void)hipHostFree(h);
     if (p->s_vol) (void)hipStreamDestroy(p->s_vol);
     if (p->s_main) (void)hipStreamDestroy(p->s_main);
@@ -310,11 +315,11 @@ static int create_impl(mvFramePipe* p) {
         MV_HIP(mk(&p->e_vol_done[k]));
         MV_HIP(mk(&p->e_vol_free[k]));
     }
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < N_CAND; ++k) {
         MV_HIP(mk(&p->e_cand[k]));
-        MV_HIP(mk(&p->e_backend[k]));
         MV_HIP(hipHostMalloc((void**)&p->h_count[k], (size_t)p->lanes * 4 * sizeof(int32_t), hipHostMallocDefault));
     }
+    for (int k = 0; k < 2; ++k) MV_HIP(mk(&p->e_backend[k]));
     MV_HIP(mk(&p->e_pgo));
     const size_t N = c.num_point > 0 ? c.num_point : 1;
     for (int k = 0; k < N_PERM; ++k) {
@@ -428,9 +433,9 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
     const bool up = in->flow8 != nullptr;
     MV_CHECK_ARG(up ? (in->cov8 && in->up_mask && in->cov_mask) : (in->flow && in->logcov));
     const long f = p->n_enq;
-    const int k = (int)(f & 1), m = (int)(f % N_MAPS);
+    const int k = (int)(f % N_CAND), m = (int)(f % N_MAPS);
     MV_CHECK_ARG(!with_selector || p->newest_maps >= 0);   // a tracked frame needs the previous frame's maps
-    MV_CHECK_ARG(!with_selector || p->pending.size() < 2);  // slot rotation covers two tracked frames in flight
+    MV_CHECK_ARG(!with_selector || (int)p->pending.size() < MAX_PENDING);  // slot rotation covers MAX_PENDING tracked frames in flight
     const int B = c.pairs;
 
     // ---- volume GEMM (own stream) unless mv_frame_pipe_enqueue_volume already issued it
@@ -591,6 +596,10 @@ extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, co
 
 extern "C" int mv_frame_pipe_sync(mvFramePipe* p, mvStream_t stream, int block_host) {
     MV_CHECK_ARG(p);
+    if (block_host == 2) {   // results of the newest FINISHED frame only: its solve (which ran behind its backend kernels)
+        if (p->pgo_valid) MV_HIP(hipStreamWaitEvent((hipStream_t)stream, p->e_pgo, 0));
+        return MV_OK;
+    }
     if (block_host) {
         MV_HIP(hipStreamSynchronize(p->s_vol));
         MV_HIP(hipStreamSynchronize(p->s_main));
@@ -675,9 +684,9 @@ extern "C" int mv_frame_pipe_buffer(mvFramePipe* p, int which, int age, void** p
         case MV_FB_DEPTH_COV: if (!front(N_MAPS)) break; *ptr = p->maps[f % N_MAPS].depth_cov; *count = plane; return MV_OK;
         case MV_FB_MATCH_FLOW: if (!front(N_MAPS)) break; *ptr = p->maps[f % N_MAPS].match_flow; *count = 2 * plane; return MV_OK;
         case MV_FB_MATCH_COV: if (!front(N_MAPS)) break; *ptr = p->maps[f % N_MAPS].match_cov; *count = 3 * plane; return MV_OK;
-        case MV_FB_CAND: if (!front(2)) break; *ptr = p->cand[f & 1]; *count = plane; return MV_OK;
-        case MV_FB_COUNT: if (!front(2)) break; *ptr = p->count[f & 1]; *count = 4 * L; return MV_OK;
-        case MV_FB_STATS: if (!front(2)) break; *ptr = p->stats[f & 1]; *count = 4 * L; return MV_OK;
+        case MV_FB_CAND: if (!front(N_CAND)) break; *ptr = p->cand[f % N_CAND]; *count = plane; return MV_OK;
+        case MV_FB_COUNT: if (!front(N_CAND)) break; *ptr = p->count[f % N_CAND]; *count = 4 * L; return MV_OK;
+        case MV_FB_STATS: if (!front(N_CAND)) break; *ptr = p->stats[f % N_CAND]; *count = 4 * L; return MV_OK;
         case MV_FB_KP0: if (!b) break; *ptr = b->kp0; *count = 2 * N; return MV_OK;
         case MV_FB_KP0F: if (!b) break; *ptr = b->kp0f; *count = 2 * N; return MV_OK;
         case MV_FB_KP1: if (!b) break; *ptr = b->kp1; *count = 2 * N; return MV_OK;

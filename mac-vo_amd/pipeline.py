@@ -467,7 +467,8 @@ class NativeHotPath:
         self.generators = list(generators) if generators is not None else [None] * self.lanes
         assert len(self.generators) == self.lanes
         self._cap = max(self.cfg.num_point, 1)
-        self._volume_ahead = os.environ.get("MV_PIPE_VOLUME_AHEAD", "1") != "0"   # A/B knob of run()
+        self._volume_ahead = os.environ.get("MV_PIPE_VOLUME_AHEAD", "1") != "0"   # A/B knobs of run()
+        self._depth = max(1, min(3, int(os.environ.get("MV_PIPE_DEPTH", "3"))))
         self.lm = ops.lm_default_params()
         self._pipe = None
         self._arena = None
@@ -660,11 +661,18 @@ class NativeHotPath:
         """One ``run_pair`` start to finish (no cross-frame overlap); results are valid on the current stream."""
         self.enqueue_frontend(x)
         res = self.finish()
-        self.sync_pose()
+        self.sync_all()
         return res
 
     def sync_pose(self) -> None:
-        """Make the current stream wait for everything the pipe has enqueued (solve included)."""
+        """Make the current stream wait for the newest FINISHED frame's backend and solve (its results: keypoints, covariances,
+        pose) — not for the frontends of the frames :meth:`run` has already queued behind it.  Read a result right after this
+        call: its buffers are recycled two finishes later."""
+        if self._pipe is not None:
+            ops.L.check(self._lib.mv_frame_pipe_sync(self._pipe, ops._stream(), 2), "mv_frame_pipe_sync")
+
+    def sync_all(self) -> None:
+        """Make the current stream wait for everything the pipe has enqueued (frontends of queued frames included)."""
         if self._pipe is not None:
             ops.L.check(self._lib.mv_frame_pipe_sync(self._pipe, ops._stream(), 0), "mv_frame_pipe_sync")
 
@@ -691,34 +699,35 @@ class NativeHotPath:
         if self._pipe is not None:
             ops.L.check(self._lib.mv_frame_pipe_sync(self._pipe, None, 1), "mv_frame_pipe_sync")
 
-    def run(self, frames, pose_sink: torch.Tensor | None = None):
-        """Software-pipelined stream: frame t+1's frontend AND frame t+2's volume GEMM are enqueued before the host blocks on
-        frame t's candidate count / draws its permutation.  ``pose_sink``: ``[steps, 7]`` (``[steps, lanes, 7]`` for
-        lanes > 1) device tensor receiving each step's poses."""
+    def run(self, frames, pose_sink: torch.Tensor | None = None, depth: int | None = None):
+        """Software-pipelined stream: up to ``depth`` (default 3 = the pipe's slot rotation) tracked frames are enqueued ahead
+        of the frame whose candidate count the host waits for, plus the volume GEMM of the one after — the GPU-side chain
+        volume -> 12 lookups -> selector of a frame takes ~2.5 frame periods when it shares the chip with the next GEMMs, so
+        the host has to run that far ahead for the GEMM stream to stay busy.  ``pose_sink``: ``[steps, 7]``
+        (``[steps, lanes, 7]`` for lanes > 1) device tensor receiving each step's poses."""
+        depth = self._depth if depth is None else depth
         it = iter(frames)
         nxt = next(it, None)
-        if nxt is None:
-            return
-        self.enqueue_frontend(nxt)
-        nxt = next(it, None)
-        ahead = self._volume_ahead and nxt is not None
-        if ahead:
-            self.enqueue_volume(nxt)
+        state = {"nxt": nxt, "vol": False, "pending": 0}
+
+        def pump():
+            while state["nxt"] is not None and state["pending"] < depth:
+                self.enqueue_frontend(state["nxt"])       # completes the frame (its GEMM may already be queued)
+                state["pending"] += 1
+                state["nxt"], state["vol"] = next(it, None), False
+            if self._volume_ahead and state["nxt"] is not None and not state["vol"]:
+                self.enqueue_volume(state["nxt"])
+                state["vol"] = True
+
+        pump()
         i = 0
-        while True:
-            if nxt is not None:
-                self.enqueue_frontend(nxt)              # completes the frame whose GEMM is already queued
-                nxt = next(it, None)
-                if ahead and nxt is not None:
-                    self.enqueue_volume(nxt)
-                more = True
-            else:
-                more = False
-            yield self.finish(None, None if pose_sink is None else pose_sink[i])
+        while state["pending"]:
+            res = self.finish(None, None if pose_sink is None else pose_sink[i])
+            state["pending"] -= 1
             i += 1
-            if not more and not self._has_pending():
-                break
-        self.sync_pose()
+            pump()                                        # refill before handing the result out: the GPU stays fed
+            yield res
+        self.sync_all()
 
     def _has_pending(self) -> bool:
         return self._n_fin < self._n_enq - 1          # frame 0 (initialize) is never finished

@@ -125,7 +125,7 @@ def test_native_errors_are_loud(gpu):
     from macvo_amd import _lib as L
     from macvo_amd.pipeline import Camera, HotPathConfig, NativeHotPath
 
-    cam, frames, _ = synth.make_sequence(4, 240, 320, C=64, iters=1, seed=4)
+    cam, frames, _ = synth.make_sequence(5, 240, 320, C=64, iters=1, seed=4)
     ins = _inputs(frames, gpu)
     nat = NativeHotPath(Camera(**cam), HotPathConfig(), gpu)
     nat.initialize(ins[0])
@@ -133,11 +133,15 @@ def test_native_errors_are_loud(gpu):
         nat.finish()                              # nothing pending
     nat.enqueue_frontend(ins[1])
     nat.enqueue_frontend(ins[2])
+    nat.enqueue_frontend(ins[3])
     with pytest.raises(L.MacvoHipError):
-        nat.enqueue_frontend(ins[3])              # more than two tracked frames in flight
+        nat.enqueue_frontend(ins[4])              # more than three tracked frames in flight
+    with pytest.raises(L.MacvoHipError):
+        nat.enqueue_volume(ins[4])
+        nat.enqueue_volume(ins[4])                # at most one GEMM ahead of its frame
     r1 = nat.finish()
     nat.finish()
-    nat.enqueue_frontend(ins[3])
+    nat.enqueue_frontend(ins[4])                  # completes the frame whose GEMM was issued ahead
     nat.finish()
     with pytest.raises(L.MacvoHipError):
         r1.kp0_uv                                 # recycled two finishes ago

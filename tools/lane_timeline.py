@@ -21,8 +21,13 @@ hp = NativeHotPath(Camera(**cam), HotPathConfig(), dev, lanes=lanes, generators=
 hp.initialize(batches[0]); torch.manual_seed(0)
 warm = max(10, steps // 4)
 for _ in hp.run(batches[(1 + k) % pool] for k in range(warm)): pass
+import time
+sink = torch.zeros((steps, 7) if lanes == 1 else (steps, lanes, 7), device=dev) if os.environ.get("TL_SINK") else None
 hp.time_volume(steps)
-for _ in hp.run(batches[(1 + warm + k) % pool] for k in range(steps)): pass
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in hp.run((batches[(1 + warm + k) % pool] for k in range(steps)), pose_sink=sink): pass
+torch.cuda.synchronize(); wall = time.perf_counter() - t0
+print(f"wall: {wall / steps * 1e6:.1f} us/step = {lanes * steps / wall:.0f} frames/s over {steps} steps (incl. fill / drain)")
 tl = hp.timeline_ms()
 lo, hi = len(tl) // 4, len(tl) - 2
 per = [(tl[i + 1][0] - tl[i][0]) * 1e3 for i in range(lo, hi)]
