@@ -267,6 +267,23 @@ def main():
     except Exception:  # noqa: BLE001
         traffic = None
     roofline = roofline_of(ms, args, args.lanes, n_q, C, in_region, traffic) if ms else None
+    if roofline is not None and rank == 0 and args.volume_precision == "exact":
+        # the same kernel with the GPU to itself (50 back-to-back launches, HIP events): what the co-running lookups / selector /
+        # backend kernels of the neighbouring frames cost it inside the pipeline is the difference to avg_launch_us above
+        b0 = lane_batches(args.lanes)[0]
+        vol = ops.corr_volume(b0.fmap1, b0.fmap2, layout=args.layout)
+        for _ in range(10):
+            ops.corr_volume(b0.fmap1, b0.fmap2, layout=args.layout, out=vol)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            ops.corr_volume(b0.fmap1, b0.fmap2, layout=args.layout, out=vol)
+        e1.record()
+        torch.cuda.synchronize()
+        iso_us = e0.elapsed_time(e1) * 1e3 / 50
+        roofline["isolated_avg_launch_us"] = round(iso_us, 2)
+        roofline["isolated_frac"] = round(roofline["frac"] * roofline["avg_launch_us"] / iso_us, 4)
+        del vol
 
     # ---- CPU baseline (oracle pipeline, torch-CPU ops shaped like the reference) on a bounded sample + free-running parity
     cpu_baseline = parity = None

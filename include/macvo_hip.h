@@ -310,6 +310,75 @@ int mv_local_corr81(const float* first, const float* second, float* out, int B, 
                     mvStream_t stream);
 
 /* -------------------------------------------------------------------------------------------
+ * SURVEY §8(f) rank 4  device-resident VisualMap (tracking map of one sequence), output poses, MotionInterpolate.
+ * Replaces Module/Map/VisualMap.py:15-133 + Module/Map/Graph.py:19-298 as driven by Odometry/MACVO.py:158-171,244-311
+ * (MatchObs.init, `match_obs[mask]`, points.push(...[mask]), push_keyframe, the six edge updates, the lost-track flag), which
+ * the reference runs on the CPU behind ~25 `.cpu()` copies per frame; Odometry/Interface.py:47-49 (body poses of poses.npy);
+ * Module/MapProcessor.py:52-76 (MotionInterpolate) with Utility/Math.py:96-133.  The stores are caller-owned device arrays
+ * (SoA, the reference's field names / dtypes, VisualMap.py:23-69); `counts` is a DEVICE int64[4] = {frames, matches, points,
+ * lost frames} advanced by the kernel itself, so registering a frame needs no host synchronisation: the host only has to keep
+ * capacity >= an upper bound of the rows pushed (rows selected).
+ */
+typedef struct {
+    /* frames  [cap_f, .] */
+    float* K;                 /* [.,3,3] */
+    float* baseline;          /* [.]     */
+    float* pose;              /* [.,7]   sensor-to-world; prior at push time, overwritten by the optimised pose */
+    float* T_BS;              /* [.,7]   */
+    uint8_t* need_interp;     /* [.]     */
+    int64_t* time_ns;         /* [.]     */
+    /* points  [cap_p, .] */
+    float* pos_Tw;            /* [.,3]   */
+    double* cov_Tw;           /* [.,3,3] */
+    uint8_t* color;           /* [.,3]   */
+    /* match   [cap_m, .]  (VisualMap.py:51-69) */
+    float *pixel1_uv, *pixel2_uv;                    /* [.,2] */
+    float *pixel1_d, *pixel2_d, *pixel1_disp, *pixel2_disp, *pixel1_disp_cov, *pixel2_disp_cov;   /* [.,1] */
+    double *obs1_covTc, *obs2_covTc;                 /* [.,3,3] */
+    float *pixel1_uv_cov, *pixel2_uv_cov;            /* [.,3] */
+    float *pixel1_d_cov, *pixel2_d_cov;              /* [.,1] */
+    /* edges (Graph.py: DenseEdge_Multi ranges [n, max_deg, 2] + num [n]; SingleEdge mapping [n]; SparseEdge_Multi edges
+     * [n, max_deg] + deg [n]); all int64, -1 = empty */
+    int64_t *frame2match_ranges, *frame2match_num, *frame2map_ranges, *frame2map_num;
+    int64_t *match2frame1, *match2frame2, *match2point;
+    int64_t *point2match_edges, *point2match_deg;
+    int64_t* counts;          /* device int64[4] */
+    int32_t max_pt_obs;       /* 5  (VisualMap.py:18) */
+    int32_t max_frame_range;  /* 2  (VisualMap.py:19) */
+} mvMapStores;
+
+/* one frame's observations as the tracking kernels leave them (row order of the selected keypoints; `valid` = border test
+ * AND outlier filter, i.e. the rows the reference keeps, MACVO.py:200-206,269-270) */
+typedef struct {
+    int32_t n_rows;           /* selected keypoints of the frame (0 for the very first frame)           */
+    int32_t table_stride;     /* row stride of the SoA `vals` table (>= n_rows)                          */
+    int32_t prev_frame;       /* map index of the previous keyframe, -1 for the first frame (initialize) */
+    int32_t min_num_point;    /* fewer kept rows => need_interp (MACVO.py:303-307)                       */
+    const uint8_t* valid;     /* [n_rows] or NULL (keep all)                                             */
+    const float *kp0, *kp1;   /* [n_rows,2] pixel1_uv / pixel2_uv                                        */
+    const float* vals;        /* [11, table_stride] table of mv_kp_track                                 */
+    const float *sigma0, *sigma1;       /* [n_rows,3] pixel1_uv_cov / pixel2_uv_cov (after the in-place clamp)  */
+    const double *cov0, *cov1;          /* [n_rows,9] obs1_covTc / obs2_covTc                                   */
+    const float* pos_Tw;      /* [n_rows,3]  */
+    const double* cov0_world; /* [n_rows,9] R cov0 R^T (MACVO.py:273-281)                                */
+    const uint8_t* color;     /* [n_rows,3] or NULL                                                      */
+    const float* K;           /* [9] device */
+    const float* T_BS;        /* [7] device */
+    const float* prior_pose;  /* [7] device or NULL (identity): the pose the frame is pushed with         */
+    float baseline;
+    int64_t time_ns;
+    int32_t* out_frame_idx;   /* device int32[1] or NULL: the map index the frame received                */
+} mvMapFrame;
+
+int mv_map_append(const mvMapFrame* frame /* host */, const mvMapStores* stores /* host */, mvStream_t stream);
+/* out[i] = T_BS[i] @ pose[i] @ T_BS[i]^-1 in fp32 (Odometry/Interface.py:47-49) */
+int mv_body_poses(const float* pose, const float* T_BS, int T, float* out, mvStream_t stream);
+/* MotionInterpolate.elaborate_map on pose [T,7] in place (fp64 inside); scratch: double[7*(T-1)]; out_count int32[1] or NULL =
+ * number of interpolated motions */
+int mv_motion_interpolate(float* pose, const uint8_t* need_interp, int T, double* scratch, int32_t* out_count,
+                          mvStream_t stream);
+
+/* -------------------------------------------------------------------------------------------
  * Lane-batched variants: the same kernels over `lanes` INDEPENDENT frames (sequences) in ONE launch.  This is the
  * reference's batching point (Module/Frontend/Frontend.py:219-224 concatenates pairs along the batch axis) carried through
  * the rest of run_pair, for BASELINE configs[4] (batch-32 frames per GPU).  Layout rule: every argument gains a leading
@@ -438,6 +507,12 @@ int mv_frame_pipe_wait_candidates(mvFramePipe* p, int32_t* n_cand /* [lanes] hos
 /* perm_host: int64 [lanes, num_point], row l = randperm(n_cand[l])[:num_point] (n_sel[l] entries used); n_sel: int32 [lanes]
  * host; pose_sink: device fp32 [lanes, 7] or NULL (copy of the new poses) */
 int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, const int32_t* n_sel, float* pose_sink);
+/* register the newest FINISHED frame in a device-resident map (mv_map_append on the pipe's own streams, no copies; lanes = 1):
+ * frame_idx = the map index the frame receives (= frames pushed so far), prev_frame = the previous keyframe's index; the
+ * optimised pose is written over the frame's prior once its solve has finished */
+int mv_frame_pipe_map_append(mvFramePipe* p, const mvMapStores* stores /* host */, int frame_idx, int prev_frame,
+                             const float* K_dev, const float* T_BS_dev, float baseline, int64_t time_ns,
+                             const uint8_t* color_dev /* [n_sel,3] or NULL */);
 /* block_host = 1: wait for all four streams on the host; 0: make `stream` wait for everything enqueued so far (including the
  * frontends of frames enqueued ahead); 2: make `stream` wait for the newest FINISHED frame's backend + solve only — what a
  * consumer of that frame's results needs while later frames are already queued */

@@ -57,6 +57,22 @@ class mvFramePipeConfig(C.Structure):
         "max_depth", "min_flow_cov_sq", "min_depth_cov", "filter_min_depth", "reserved")] + [("lm", mvLMParams)]
 
 
+class mvMapStores(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "K", "baseline", "pose", "T_BS", "need_interp", "time_ns", "pos_Tw", "cov_Tw", "color",
+        "pixel1_uv", "pixel2_uv", "pixel1_d", "pixel2_d", "pixel1_disp", "pixel2_disp", "pixel1_disp_cov", "pixel2_disp_cov",
+        "obs1_covTc", "obs2_covTc", "pixel1_uv_cov", "pixel2_uv_cov", "pixel1_d_cov", "pixel2_d_cov",
+        "frame2match_ranges", "frame2match_num", "frame2map_ranges", "frame2map_num", "match2frame1", "match2frame2",
+        "match2point", "point2match_edges", "point2match_deg", "counts")] + [("max_pt_obs", C.c_int32), ("max_frame_range", C.c_int32)]
+
+
+class mvMapFrame(C.Structure):
+    _fields_ = [("n_rows", C.c_int32), ("table_stride", C.c_int32), ("prev_frame", C.c_int32), ("min_num_point", C.c_int32)] + \
+        [(n, C.c_void_p) for n in ("valid", "kp0", "kp1", "vals", "sigma0", "sigma1", "cov0", "cov1", "pos_Tw", "cov0_world",
+                                   "color", "K", "T_BS", "prior_pose")] + \
+        [("baseline", C.c_float), ("time_ns", C.c_int64), ("out_frame_idx", C.c_void_p)]
+
+
 class mvFrameInputs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("fmap1", "fmap2", "coords", "flow", "logcov", "flow8", "cov8", "up_mask",
                                           "cov_mask")]
@@ -96,6 +112,9 @@ SIGNATURES = {
     "mv_map_points": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _P,
                                 C.c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mv_local_corr81": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mv_map_append": (C.c_int, [C.POINTER(mvMapFrame), C.POINTER(mvMapStores), _P]),
+    "mv_body_poses": (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    "mv_motion_interpolate": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     # lane-batched variants (lanes independent frames per launch)
     "mv_frontend_epilogue_lanes": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                              _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
@@ -117,6 +136,7 @@ SIGNATURES = {
     "mv_frame_pipe_enqueue_volume": (C.c_int, [_P, C.POINTER(mvFrameInputs), _P]),
     "mv_frame_pipe_wait_candidates": (C.c_int, [_P, _P]),
     "mv_frame_pipe_finish": (C.c_int, [_P, _P, _P, _P]),
+    "mv_frame_pipe_map_append": (C.c_int, [_P, C.POINTER(mvMapStores), C.c_int, C.c_int, _P, _P, C.c_float, C.c_int64, _P]),
     "mv_frame_pipe_sync": (C.c_int, [_P, _P, C.c_int]),
     "mv_frame_pipe_time_volume": (C.c_int, [_P, C.c_int]),
     "mv_frame_pipe_volume_times": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),

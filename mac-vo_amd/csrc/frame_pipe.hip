@@ -114,6 +114,8 @@ struct mvFramePipe {
     hipEvent_t e_in_of[MAX_VOL];   // per volume buffer: the input-ready event its GEMM waited for (the decoder side re-uses it)
     int lookups_on_main;   // default 1; MV_PIPE_LOOKUPS_ON=vol is the measured alternative
     int pose_cur;
+    int prior_slot;        // pose slot the newest finished frame started from (its motion-model prior)
+    hipEvent_t e_map;
     int newest_maps;
     std::deque<Pending> pending;
     // optional timing of the dominant kernel (bench.py roofline): event pairs around each volume GEMM on its stream
@@ -235,6 +237,7 @@ extern "C" void mv_frame_pipe_destroy(mvFramePipe* p) {
     for (int k = 0; k < N_CAND; ++k) ev(p->e_cand[k]);
     for (int k = 0; k < 2; ++k) ev(p->e_backend[k]);
     ev(p->e_pgo);
+    ev(p->e_map);
     for (auto e : p->e_perm) ev(e);
     for (auto e : p->tv0) ev(e);
     for (auto e : p->tv1) ev(e);
@@ -321,6 +324,7 @@ static int create_impl(mvFramePipe* p) {
     }
     for (int k = 0; k < 2; ++k) MV_HIP(mk(&p->e_backend[k]));
     MV_HIP(mk(&p->e_pgo));
+    MV_HIP(mk(&p->e_map));
     const size_t N = c.num_point > 0 ? c.num_point : 1;
     for (int k = 0; k < N_PERM; ++k) {
         MV_HIP(mk(&p->e_perm[k]));
@@ -536,6 +540,7 @@ extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, co
     for (int l = 0; l < L; ++l) b.n_sel[l] = n_sel[l];
     p->n_fin = g + 1;
     hipStream_t s = p->s_back;
+    p->prior_slot = p->pose_cur;
     if (n_max == 0) {   // nothing to track in any lane: the poses stay at the motion-model prior (MACVO.py:303-307)
         if (pose_sink) {
             if (p->pgo_valid) MV_HIP(hipStreamWaitEvent(p->s_side, p->e_pgo, 0));
@@ -591,6 +596,43 @@ extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, co
     MV_HIP(hipEventRecord(p->e_pgo, ss));
     p->pgo_valid = true;
     p->pose_cur = nxt;
+    return MV_OK;
+}
+
+// Register the newest FINISHED frame in a device-resident map (call right after mv_frame_pipe_finish; lanes == 1): the
+// frame's tables are handed to mv_map_append where they lie (no copies), on the backend stream behind the observation filter;
+// the optimised pose is then written over the frame's prior on the solve stream (write_graph_data, Optimizer.py:104-108).
+extern "C" int mv_frame_pipe_map_append(mvFramePipe* p, const mvMapStores* stores, int frame_idx, int prev_frame,
+                                        const float* K_dev, const float* T_BS_dev, float baseline, int64_t time_ns,
+                                        const uint8_t* color_dev) {
+    MV_CHECK_ARG(p && stores && K_dev && T_BS_dev && p->lanes == 1 && p->n_fin > 0 && frame_idx >= 0);
+    const mvFramePipeConfig& c = p->c;
+    const long g = p->n_fin - 1;
+    const Backend& b = p->be[g & 1];
+    const int cap = c.num_point > 0 ? c.num_point : 1;
+    mvMapFrame f{};
+    f.n_rows = b.n_sel[0];
+    f.table_stride = cap;
+    f.prev_frame = prev_frame;
+    f.min_num_point = c.min_num_point;
+    f.valid = b.valid;
+    f.kp0 = b.kp0f; f.kp1 = b.kp1; f.vals = b.vals; f.sigma0 = b.sigma0; f.sigma1 = b.sigma1;
+    f.cov0 = b.cov0; f.cov1 = b.cov1; f.pos_Tw = b.pos_Tw; f.cov0_world = b.cov0w;
+    f.color = color_dev;
+    f.K = K_dev; f.T_BS = T_BS_dev;
+    f.prior_pose = p->pose[p->prior_slot];
+    f.baseline = baseline;
+    f.time_ns = time_ns;
+    f.out_frame_idx = nullptr;
+    MV_TRY(mv_map_append(&f, stores, p->s_back));
+    MV_HIP(hipEventRecord(p->e_map, p->s_back));
+    // the backend tables must outlive the append: later backends run on the same stream (ordered); the optimised pose goes
+    // in after the append wrote the prior
+    MV_HIP(hipStreamWaitEvent(p->s_side, p->e_map, 0));
+    MV_HIP(hipMemcpyAsync(stores->pose + 7 * (size_t)frame_idx, p->pose[p->pose_cur], 7 * sizeof(float), hipMemcpyDeviceToDevice,
+                          p->s_side));
+    MV_HIP(hipEventRecord(p->e_pgo, p->s_side));
+    p->pgo_valid = true;
     return MV_OK;
 }
 

@@ -100,6 +100,8 @@ class FrameInputs:
     ready: "torch.cuda.Event | None" = None
     # previous LEFT image [1|-,3,H,W] in [0,1] for the map-point colours (MACVO.py:326-328); optional, mapping mode only
     image: torch.Tensor | None = None
+    # frame timestamp (StereoData.frame_ns) — recorded in the device-resident map when one is attached
+    time_ns: int = 0
     # promise that every tensor above lives at a fixed address for the lifetime of the HotPath (e.g. the static output
     # buffers of a graph-captured network, as in the reference's CUDAGraph frontend): allows hipGraph replay
     static: bool = False
@@ -596,14 +598,31 @@ class NativeHotPath:
                                                     int(with_selector)), "mv_frame_pipe_enqueue")
         self._n_enq += 1
 
+    def attach_map(self, devmap, K: torch.Tensor, T_BS: torch.Tensor | None = None) -> None:
+        """Register every finished frame in a :class:`macvo_amd.devmap.DeviceVisualMap`: the frame's
+        tables go from the tracking kernels into the map's SoA stores on the pipe's own streams — no ``.cpu()`` round trip
+        (the reference: Odometry/MACVO.py:235-266, ~25 device-to-host copies per frame).  lanes == 1.  Call before
+        :meth:`initialize`."""
+        if self.lanes != 1:
+            raise ops.L.MacvoHipError("attach_map: one map per pipe, lanes must be 1")
+        self._map = devmap
+        self._map_K = K.to(self.dev, torch.float32).reshape(3, 3).contiguous()
+        self._map_TBS = (torch.tensor([0, 0, 0, 0, 0, 0, 1.0]) if T_BS is None else T_BS).to(self.dev, torch.float32).reshape(7).contiguous()
+        self._times: list = []
+
     def initialize(self, x: FrameInputs, init_pose: torch.Tensor | None = None) -> None:
         """Frame 0: ``MACVO.initialize`` (:158-171) — depth only, pose = prior."""
         self._init_pose = init_pose
         self._enqueue(x, False)
+        if getattr(self, "_map", None) is not None:   # MACVO.initialize pushes the first frame at the prior (:162-169)
+            self._map.push_frame(K=self._map_K, T_BS=self._map_TBS, baseline=self.cam.baseline, time_ns=x.time_ns, prior_pose=init_pose)
+            torch.cuda.current_stream().synchronize()   # later frames are appended on the pipe's streams: order them after this one
 
     def enqueue_frontend(self, x: FrameInputs):
         assert self._n_enq >= 1, "call initialize() with the first frame"
         self._enqueue(x, True)
+        if getattr(self, "_map", None) is not None:
+            self._times.append(int(x.time_ns))
         return x
 
     def enqueue_volume(self, x: FrameInputs) -> None:
@@ -641,6 +660,18 @@ class NativeHotPath:
         L.check(lib.mv_frame_pipe_finish(self._pipe, perm_ptr, self._nsel, None if pose_sink is None else pose_sink.data_ptr()),
                 "mv_frame_pipe_finish")
         self._n_fin += 1
+        mp = getattr(self, "_map", None)
+        if mp is not None:
+            n_rows = int(self._nsel[0])
+            if mp.n_frames + 1 >= mp.cap["frames"] or mp.rows_upper + n_rows >= mp.cap["match"]:
+                self.synchronize()                          # growth re-allocates the stores: rare (capacity doubles), so simply drain
+                mp.reserve(n_rows)
+                torch.cuda.synchronize()
+            L.check(lib.mv_frame_pipe_map_append(self._pipe, ops.C.byref(mp.stores()), mp.n_frames, mp.n_frames - 1,
+                                                 self._map_K.data_ptr(), self._map_TBS.data_ptr(), float(self.cam.baseline),
+                                                 self._times.pop(0), None), "mv_frame_pipe_map_append")
+            mp.n_frames += 1
+            mp.rows_upper += n_rows
         out = []
         for l in range(self.lanes):
             n_sel = self._nsel[l]

@@ -42,6 +42,8 @@ class OracleHotPath:
         if x.get("flow8") is not None:                                                 # covhead.py:119-135
             flow = frontend.upsample_flow(x["flow8"], 0.25 * x["up_mask"])
             cov = torch.exp(frontend.upsample_flow(x["cov8"], x["cov_mask"]) * 2)
+        elif x.get("cov_exp") is not None:                                             # tests: covariance already exponentiated
+            flow, cov = x["flow"], x["cov_exp"]
         else:
             flow = x["flow"]
             cov = torch.exp(x["logcov"] * 2)                                           # flownet.py:44

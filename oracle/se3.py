@@ -138,6 +138,25 @@ def so3_log(q: torch.Tensor) -> torch.Tensor:
     return v * scale
 
 
+def so3_Jl_inv(phi: torch.Tensor) -> torch.Tensor:
+    """PyPose ``so3_Jl_inv``: I - K/2 + c K@K, c = (1 - theta cos(theta/2) / (2 sin(theta/2))) / theta^2."""
+    eps = torch.finfo(phi.dtype).eps
+    K = vec2skew(phi)
+    theta = phi.norm(dim=-1, keepdim=True).unsqueeze(-1)
+    safe = torch.where(theta > eps, theta, torch.ones_like(theta))
+    half = 0.5 * safe
+    c = torch.where(theta > eps, (1.0 - safe * half.cos() / (2.0 * half.sin())) / (safe * safe), 1.0 / 12.0 + theta * theta / 720.0)
+    I = torch.eye(3, dtype=phi.dtype, device=phi.device).expand(K.shape)
+    return I - 0.5 * K + c * (K @ K)
+
+
+def se3_log(a: torch.Tensor) -> torch.Tensor:
+    """PyPose ``SE3_Log``: SE3 [..., 7] -> [rho, phi] [..., 6] with phi = SO3_Log(q), rho = Jl^-1(phi) t."""
+    phi = so3_log(a[..., 3:])
+    rho = (so3_Jl_inv(phi) @ a[..., :3].unsqueeze(-1)).squeeze(-1)
+    return torch.cat([rho, phi], dim=-1)
+
+
 def pose_error(T_a: torch.Tensor, T_b: torch.Tensor) -> tuple[float, float]:
     """(translation error [m], rotation error [rad]) between two SE3 [7] poses."""
     d = se3_mul(se3_inv(T_a.double()), T_b.double())

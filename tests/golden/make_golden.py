@@ -81,6 +81,7 @@ class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
             m.jaxtyped = lambda typechecker=None: (lambda c: c)
         if spec.name == "typeguard":
             m.typechecked = lambda f: f
+        m.__version__ = "999.0"   # version gates at import time (e.g. Utility/Visualize/Rerun_Visualize.py:21)
         return m
 
     def exec_module(self, m):
@@ -255,6 +256,72 @@ def gen_pgo(ref):
     save("pgo", **out)
 
 
+def gen_visual_map(ref):
+    """Drive the REAL map classes (Module/Map/VisualMap.py, Graph.py, Template.py) with the call sequence of MACVO.initialize
+    (Odometry/MACVO.py:162-169) and MACVO.run_pair (:244-311, 339-347) on the synthetic per-frame tables of
+    tests/synth.map_sequence, then VisualMap.serialize (:104-116), the poses.npy rows of Odometry/Interface.py:47-51 and the
+    REAL MotionInterpolate.elaborate_map (Module/MapProcessor.py:57-76; its PyPose calls run on the shim)."""
+    import Module.Map as MM
+    from Module.MapProcessor import MotionInterpolate
+    pp = sys.modules["pypose"]
+
+    meta, frames = synth.map_sequence()
+    vmap = MM.VisualMap()
+    min_num_point = 10
+
+    def push_keyframe(fr, est_pose):
+        return vmap.frames.push(MM.FrameNode.init({
+            "pose": est_pose, "T_BS": meta["T_BS"].reshape(1, 7), "need_interp": torch.tensor([False], dtype=torch.bool),
+            "time_ns": torch.tensor([fr["time_ns"]], dtype=torch.long), "K": meta["K"].reshape(1, 3, 3),
+            "baseline": torch.tensor([meta["baseline"]])}))
+
+    inputs = {}
+    prev_idx = int(push_keyframe(frames[0], torch.tensor([[0, 0, 0, 0, 0, 0, 1.0]])).item())     # MACVO.initialize
+    for t, fr in enumerate(frames[1:], start=1):
+        n, mask = fr["n"], fr["valid"]
+        v = fr["vals"]
+        match_obs = MM.MatchObs.init({                                                       # MACVO.py:244-266
+            "pixel1_uv": fr["kp0"], "pixel2_uv": fr["kp1"], "pixel1_d": v[0].unsqueeze(-1), "pixel2_d": v[4].unsqueeze(-1),
+            "pixel1_disp": v[1].unsqueeze(-1), "pixel2_disp": v[5].unsqueeze(-1), "pixel1_disp_cov": v[2].unsqueeze(-1),
+            "pixel2_disp_cov": v[6].unsqueeze(-1), "pixel1_d_cov": v[3].unsqueeze(-1), "pixel2_d_cov": v[7].unsqueeze(-1),
+            "pixel1_uv_cov": fr["sigma0"], "pixel2_uv_cov": fr["sigma1"], "obs1_covTc": fr["cov0"], "obs2_covTc": fr["cov1"]})
+        match_obs = match_obs[mask]                                                          # :270
+        num_match_orig = len(vmap.match)
+        point_idx = vmap.points.push(MM.PointNode.init({"pos_Tw": fr["pos_Tw"], "cov_Tw": fr["cov0w"], "color": fr["color"]})[mask])
+        frame_idx = push_keyframe(fr, fr["prior"].reshape(1, 7))                             # :282
+        prev_frame_idx = torch.tensor([prev_idx], dtype=torch.long)
+        match_idx = vmap.match.push(match_obs)
+        num_match_kp = len(match_obs)
+        vmap.point2match.add(point_idx, match_idx)                                           # :288-293
+        vmap.match2point.set(match_idx, point_idx)
+        vmap.frame2match.add(prev_frame_idx, torch.tensor([num_match_orig]), torch.tensor([num_match_kp]))
+        vmap.frame2match.add(frame_idx, torch.tensor([num_match_orig]), torch.tensor([num_match_kp]))
+        vmap.match2frame1.set(match_idx, torch.empty((num_match_kp,), dtype=torch.long).fill_(prev_frame_idx.item()))
+        vmap.match2frame2.set(match_idx, torch.empty((num_match_kp,), dtype=torch.long).fill_(frame_idx.item()))
+        prev_idx = int(frame_idx.item())
+        if match_idx.size(0) < min_num_point:                                               # :303-307 lost track
+            vmap.frames.data["need_interp"][frame_idx] = True
+        vmap.frames.data["pose"][frame_idx] = fr["opt"].reshape(1, 7)                        # write_graph_data (Optimizer.py:104-108)
+        for k in ("valid", "kp0", "kp1", "vals", "sigma0", "sigma1", "cov0", "cov1", "pos_Tw", "cov0w", "color", "prior", "opt"):
+            inputs[f"in/{t}/{k}"] = fr[k]
+        inputs[f"in/{t}/time_ns"] = np.array(fr["time_ns"], dtype=np.int64)
+    out = {f"ser/{k}": np.array(v, copy=True) for k, v in vmap.serialize().items()}   # serialize() returns views of the live stores
+    sensor_poses = pp.SE3(vmap.frames.data["pose"].tensor)                                    # Interface.py:47-51
+    T_BS = pp.SE3(vmap.frames.data["T_BS"].tensor)
+    body = (T_BS @ sensor_poses @ T_BS.Inv()).tensor().cpu().numpy()
+    time_ns = vmap.frames.data["time_ns"].tensor.cpu().numpy()[:, np.newaxis]
+    out["poses_npy"] = np.concatenate([time_ns, body], axis=-1)
+    assert np.array_equal(out["ser/frames//pose"], vmap.frames.data["pose"].tensor.numpy())
+    frames_store, interp_idx = MotionInterpolate(None).elaborate_map(vmap.frames)
+    out["interp/pose"] = frames_store.data["pose"].tensor.clone().numpy()
+    out["interp/idx"] = interp_idx.numpy()
+    out.update(inputs)
+    out["meta/K"], out["meta/T_BS"], out["meta/baseline"] = meta["K"], meta["T_BS"], np.array(meta["baseline"], dtype=np.float32)
+    out["meta/n_frames"] = np.array(len(frames))
+    out["meta/time0"] = np.array(frames[0]["time_ns"], dtype=np.int64)
+    save("visual_map", **out)
+
+
 def gen_filters():
     """The real observation filters (Module/OutlierFilter.py:91-145) on seeded rows with NaN / inf covariances, depths around
     the gates and variances around the 2-sigma front-of-camera test (one variant carries the -1 "no covariance" placeholder)."""
@@ -326,5 +393,6 @@ if __name__ == "__main__":
     gen_covariance(ref)
     gen_frontend_bits(ref)
     gen_pgo(ref)
+    gen_visual_map(ref)
     gen_upsample()
     gen_filters()

@@ -75,12 +75,52 @@ class _Rot:
         return _so3_act(self.q.unsqueeze(-2), I).transpose(-1, -2)
 
 
+def _so3_log(q):
+    """SO3_Log: factor = 2 atan(|v| / w) / |v|, small-|v| series 2/w - 2|v|^2/(3 w^3)."""
+    v, w = q[..., :3], q[..., 3:]
+    n = v.norm(dim=-1, keepdim=True)
+    eps = torch.finfo(q.dtype).eps
+    safe = torch.where(n > eps, n, torch.ones_like(n))
+    factor = torch.where(n > eps, 2.0 * torch.atan(safe / w) / safe, 2.0 / w - 2.0 * n * n / (3.0 * w * w * w))
+    return v * factor
+
+
+def _so3_Jl_inv(x):
+    eps = torch.finfo(x.dtype).eps
+    K = vec2skew(x)
+    th = x.norm(dim=-1, keepdim=True).unsqueeze(-1)
+    safe = torch.where(th > eps, th, torch.ones_like(th))
+    half = 0.5 * safe
+    c = torch.where(th > eps, (1.0 - safe * half.cos() / (2.0 * half.sin())) / (safe * safe), 1.0 / 12.0 + th * th / 720.0)
+    I = torch.eye(3, dtype=x.dtype, device=x.device).expand(K.shape)
+    return I - 0.5 * K + c * (K @ K)
+
+
+class _Se3Algebra(torch.Tensor):
+    """se3 tangent vectors [rho, phi] (what SE3.Log() returns; only .ltype / .Exp() / scaling are used by the reference)."""
+    ltype = "se3"
+
+    def Exp(self):
+        x = _raw(self)
+        t = (_so3_Jl(x[..., 3:]) @ x[..., :3].unsqueeze(-1)).squeeze(-1)
+        return LieTensor(torch.cat([t, _so3_exp(x[..., 3:])], -1))
+
+
 class LieTensor(torch.Tensor):
     """SE3 only ([tx ty tz qx qy qz qw])."""
+    ltype = "SE3"
 
     @staticmethod
     def __new__(cls, data, ltype=None):
+        if ltype == "se3":
+            return torch.Tensor._make_subclass(_Se3Algebra, _raw(data))
         return torch.Tensor._make_subclass(cls, _raw(data))
+
+    def Log(self):
+        d = _raw(self)
+        phi = _so3_log(d[..., 3:])
+        rho = (_so3_Jl_inv(phi) @ d[..., :3].unsqueeze(-1)).squeeze(-1)
+        return torch.Tensor._make_subclass(_Se3Algebra, torch.cat([rho, phi], -1))
 
     def __init__(self, data=None, ltype=None):
         pass
@@ -139,6 +179,21 @@ class Parameter(LieTensor, nn.Parameter):
 
 def SE3(data):
     return LieTensor(data)
+
+
+def cumops(input, dim, ops):
+    """pp.cumops: inclusive scan y_k = x_0 (ops) x_1 (ops) ... (ops) x_k by doubling (Hillis-Steele), earlier operand on the
+    LEFT — the order in which `pose[0] @ cumops(motions)` rebuilds a trajectory (Module/MapProcessor.py:73-74; the reference
+    notes that 0.6.7 and 0.6.8 differ here, :72).  Restated from memory: parity unpinned."""
+    assert dim == 0
+    v = LieTensor(_raw(input).clone())
+    L, i = v.shape[0], 1
+    while i < L:
+        idx = torch.arange(i, L)
+        new = ops(LieTensor(_raw(v)[idx - i]), LieTensor(_raw(v)[idx]))
+        _raw(v)[idx] = _raw(new)
+        i *= 2
+    return v
 
 
 def pixel2point(pixels, depth, intrinsics):
@@ -318,7 +373,7 @@ class _Permissive(types.ModuleType):
 def install():
     """Register the shim as ``pypose`` and its sub-modules in sys.modules."""
     pp = _Permissive("pypose")
-    for n in ("LieTensor", "Parameter", "SE3", "vec2skew", "pixel2point", "point2pixel"):
+    for n in ("LieTensor", "Parameter", "SE3", "vec2skew", "pixel2point", "point2pixel", "cumops"):
         setattr(pp, n, globals()[n])
     pp.SE3_type = types.SimpleNamespace(Act=lambda pose, p: LieTensor(_raw(pose)).Act(p))
     pp.from_matrix = lambda *a, **k: LieTensor(torch.tensor([[0.0, 0, 0, 0, 0, 0, 1]]))

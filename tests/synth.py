@@ -181,3 +181,36 @@ def tartanair_sequence(C=32, iters=1):
         fr.update(flow=fl, logcov=lc)
         frames.append(fr)
     return cam, frames, poses
+
+
+# ----------------------------------------------------------------------------------------------------------
+# S-map: per-frame observation tables for the device-resident VisualMap tests (values are only copied, never computed on)
+# ----------------------------------------------------------------------------------------------------------
+def map_sequence(seed=21, n_frames=9, max_rows=60, lost_frames=(4, 5)):
+    """Returns (meta, frames): meta = K [3,3], T_BS [7], baseline; frames[t] (t >= 1) holds one frame's tracking tables in the
+    layout the HIP kernels leave them (SoA ``vals`` [11, n]) plus the validity mask, the prior / optimised pose and a
+    timestamp.  Frames listed in ``lost_frames`` keep fewer than 10 rows (lost track -> need_interp)."""
+    g = torch.Generator().manual_seed(seed)
+    K = torch.tensor([[320.0, 0, 320.0], [0, 320.0, 240.0], [0, 0, 1.0]])
+    T_BS = torch.tensor([0.1, -0.2, 0.05, 0.0, 0.0, 0.38268343, 0.92387953])
+    frames = [dict(time_ns=1_700_000_000_000_000_000, n=0)]
+    pose = torch.tensor([0.0, 0, 0, 0, 0, 0, 1])
+    for t in range(1, n_frames):
+        n = int(torch.randint(max_rows // 2, max_rows + 1, (1,), generator=g))
+        valid = torch.rand(n, generator=g) > 0.15
+        if t in lost_frames:
+            valid[:] = False
+            valid[: int(torch.randint(0, 9, (1,), generator=g))] = True
+        A = torch.randn(n, 3, 3, generator=g, dtype=torch.float64)
+        B = torch.randn(n, 3, 3, generator=g, dtype=torch.float64)
+        q = torch.randn(4, generator=g) * 0.05 + torch.tensor([0, 0, 0, 1.0])
+        opt = torch.cat([pose[:3] + torch.tensor([0.1, 0.01, -0.02]) + 0.01 * torch.randn(3, generator=g), q / q.norm()])
+        frames.append(dict(
+            n=n, valid=valid, time_ns=1_700_000_000_000_000_000 + t * 33_333_333,
+            kp0=torch.randint(32, 600, (n, 2), generator=g).float(), kp1=torch.rand(n, 2, generator=g) * 500 + 40,
+            vals=torch.rand(11, n, generator=g) * 20 + 0.5, sigma0=torch.tensor([0.25, 0.25, 0.0]).repeat(n, 1),
+            sigma1=torch.rand(n, 3, generator=g) + 0.0625, cov0=A @ A.mT, cov1=B @ B.mT,
+            pos_Tw=torch.randn(n, 3, generator=g) * 5, cov0w=B @ A @ A.mT @ B.mT,
+            color=torch.randint(0, 256, (n, 3), generator=g, dtype=torch.uint8), prior=pose.clone(), opt=opt.float()))
+        pose = opt.float()
+    return dict(K=K, T_BS=T_BS, baseline=0.25), frames

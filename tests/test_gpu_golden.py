@@ -35,15 +35,17 @@ def test_covariance_vs_reference_golden(gpu):
     fc = z["flow_cov_in"].clone().to(gpu)
     out = ops.match_cov(depth, z["kp_int"].to(gpu), fc, None, *K)
     assert torch.equal(fc.cpu(), z["flow_cov_after"])                         # in-place clamp, bit-exact
-    torch.testing.assert_close(out.cpu(), z["cov_int_flowcov"], rtol=2e-3, atol=1e-7)
+    # tolerances = 5 x the measured bound (tools/scratch/cov_tolerance.py: max relative error 2.6e-6 / 1.0e-5 / 4.5e-7 / 2.4e-7):
+    # the kernel replays the reference's fp32 op order; what is left is the summation order of the 961-tap reductions
+    torch.testing.assert_close(out.cpu(), z["cov_int_flowcov"], rtol=5e-5, atol=1e-7)
     out = ops.match_cov(depth, z["kp_float"].to(gpu), z["flow_cov_in"].clone().to(gpu), None, *K)
-    torch.testing.assert_close(out.cpu(), z["cov_float_flowcov"], rtol=2e-3, atol=1e-7)
+    torch.testing.assert_close(out.cpu(), z["cov_float_flowcov"], rtol=5e-5, atol=1e-7)
     s0 = torch.ones(z["kp_int"].shape[0], 3) * 0.25
     s0[:, 2] = 0
     out = ops.match_cov(depth, z["kp_int"].to(gpu), s0.to(gpu), z["depth_cov_kp"].to(gpu), *K, use_patch_var=True)
-    torch.testing.assert_close(out.cpu(), z["cov_int_default_sigma"], rtol=2e-3, atol=1e-7)
+    torch.testing.assert_close(out.cpu(), z["cov_int_default_sigma"], rtol=5e-6, atol=1e-8)
     out = ops.match_cov(depth, z["kp_int"].to(gpu), s0.to(gpu), z["depth_cov_kp"].to(gpu), *K, use_patch_var=False)
-    torch.testing.assert_close(out.cpu(), z["cov_int_nodefault"], rtol=2e-4, atol=1e-8)
+    torch.testing.assert_close(out.cpu(), z["cov_int_nodefault"], rtol=2e-6, atol=1e-8)
 
 
 @pytest.mark.parametrize("graph", ["icp", "reproj", "disp"])

@@ -180,7 +180,7 @@ def test_config2_720p_through_frame_driver(gpu):
             assert torch.equal(rh.kp0_uv.cpu(), ro["kp0_uv"]), (dt, t)
             assert int(rh.n_valid.item()) == ro["n_valid"]
             inb = rh.extras["tracked"].inbound.cpu()
-            torch.testing.assert_close(rh.extras["cov1"].cpu()[inb], ro["cov1"], rtol=2e-3, atol=1e-7)
+            torch.testing.assert_close(rh.extras["cov1"].cpu()[inb], ro["cov1"], rtol=2e-4, atol=1e-7)
             d_t, d_r = se3.pose_error(ro["pose"].double(), rh.pose.cpu().double())
             assert d_t <= 1e-4 and d_r <= 1e-4, (dt, t, d_t, d_r)
             assert int(rh.info[0, 1].item()) == ro["steps"]

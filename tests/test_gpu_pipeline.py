@@ -41,8 +41,8 @@ def test_sequence_matches_oracle(gpu, H, W, graph, selector):
         assert int(rh.n_valid.item()) == ro["n_valid"]
         ex = rh.extras
         inb = ex["tracked"].inbound.cpu()
-        torch.testing.assert_close(ex["cov0"].cpu()[inb], ro["cov0"], rtol=2e-3, atol=1e-7)
-        torch.testing.assert_close(ex["cov1"].cpu()[inb], ro["cov1"], rtol=2e-3, atol=1e-7)
+        torch.testing.assert_close(ex["cov0"].cpu()[inb], ro["cov0"], rtol=2e-4, atol=1e-7)
+        torch.testing.assert_close(ex["cov1"].cpu()[inb], ro["cov1"], rtol=2e-4, atol=1e-7)
         torch.testing.assert_close(ex["pos_Tw"].cpu()[inb], ro["pos_Tw"], rtol=1e-6, atol=1e-6)
         # pose within the north_star tolerance after the same iteration count
         dt, dr = se3.pose_error(ro["pose"].double(), rh.pose.cpu().double())
@@ -102,21 +102,30 @@ def test_sequence_with_convex_upsample_path(gpu):
         x = FrameInputs(**{k: (None if v is None else v.to(gpu)) for k, v in fr.items()})
         torch.cuda.synchronize()
         return x
-    ora.initialize(frames[0])
+    from macvo_amd import ops as _ops
+
+    def exact_fields(fr):
+        """The oracle consumes the HIP path's own upsampled flow / exp(2*cov) maps (bit-identical inputs to everything behind
+        the upsampling): expf differs by an ulp between implementations, which can flip an exact-equality NMS tie — the
+        upsampling itself is checked against the oracle in test_gpu_corr::test_convex_upsample (3e-6)."""
+        flow = _ops.convex_upsample(fr["flow8"].to(gpu), fr["up_mask"].to(gpu), mask_scale=0.25)
+        cov = _ops.convex_upsample(fr["cov8"].to(gpu), fr["cov_mask"].to(gpu), mask_scale=1.0, exp2_out=True)
+        ref = OracleHotPath(cam, {}).frontend(fr)          # oracle upsampling, for the closeness check only
+        torch.testing.assert_close(cov.cpu()[1:2], ref["flow_cov"][:, :2], rtol=1e-5, atol=0)
+        out = dict(fr)
+        out.update(flow=flow.cpu(), cov_exp=cov.cpu(), flow8=None)
+        return out
+
+    ora.initialize(exact_fields(frames[0]))
     hot.initialize(dv(frames[0]))
     for t in range(1, n_frames):
         torch.manual_seed(40 + t)
-        ro = ora.step(frames[t])
+        ro = ora.step(exact_fields(frames[t]))
         torch.manual_seed(40 + t)
         rh = hot.step(dv(frames[t]))
-        # exp(2*cov) differs by an ulp between expf implementations, which can flip an exact-equality NMS tie; the
-        # selection must still agree on (nearly) every keypoint and the pose must match to the north_star tolerance
-        same = (rh.kp0_uv.cpu() == ro["kp0_uv"]).all(dim=1).float().mean().item() if rh.kp0_uv.shape == ro["kp0_uv"].shape else 0.0
-        assert same > 0.95, same
-        if same == 1.0:
-            dt, dr = se3.pose_error(ro["pose"].double(), rh.pose.cpu().double())
-            assert dt <= 1e-4 and dr <= 1e-4, (t, dt, dr)
-        hot.pose = ro["pose"].to(gpu)
+        assert torch.equal(rh.kp0_uv.cpu(), ro["kp0_uv"]), f"frame {t}: keypoints differ"
+        dt, dr = se3.pose_error(ro["pose"].double(), rh.pose.cpu().double())
+        assert dt <= 1e-4 and dr <= 1e-4, (t, dt, dr)       # free-running: each pipeline chains on its own pose
 
 
 def test_graph_replay_equals_eager(gpu):
@@ -176,6 +185,6 @@ def test_dense_mapping_tail_matches_oracle(gpu):
         torch.testing.assert_close(m.sigma_dd.cpu(), mo["sigma_dd"], rtol=1e-5, atol=0)   # exp(2*cov): expf ulp on the device
         torch.testing.assert_close(m.pos_Tc.cpu(), mo["pos_Tc"], rtol=1e-6, atol=1e-6)
         torch.testing.assert_close(m.pos_Tw.cpu(), mo["pos_Tw"], rtol=1e-6, atol=1e-6)
-        torch.testing.assert_close(m.cov_Tc.cpu(), mo["cov_Tc"], rtol=2e-3, atol=1e-7)
+        torch.testing.assert_close(m.cov_Tc.cpu(), mo["cov_Tc"], rtol=2e-4, atol=1e-7)
         assert torch.equal(m.color.cpu(), mo["color"])
         hot.pose = ro["pose"].to(gpu)

@@ -65,7 +65,8 @@ def test_hip_two_frame_pgo_plugin_protocol(gpu, parallel, graph):
     ref = pgo.solve(prob, graph)
     got = fmap.frames.data["pose"][1]
     assert got.dtype == torch.float32
-    assert torch.equal(got, ref.pose.float()) or se3.pose_error(ref.pose, got.double()) < (1e-6, 1e-6)
+    dt, dr = se3.pose_error(ref.pose, got.double())          # float32 write-back of a float64 solve that matches to ~1e-8
+    assert dt <= 2e-7 and dr <= 2e-7, (dt, dr)
     opt.terminate()
 
 
@@ -88,7 +89,7 @@ def test_hip_match_covariance_plugin_contract(gpu):
     assert out.device.type == "cpu" and out.dtype == torch.float64 and out.shape == (n, 3, 3)
     fc_ref = fc.clone()
     ref = covariance.match_covariance(kp.cpu(), depth, None, fc_ref, 160.0, 160.0, 160.0, 120.0)
-    torch.testing.assert_close(out, ref, rtol=2e-3, atol=1e-7)
+    torch.testing.assert_close(out, ref, rtol=2e-4, atol=1e-7)
     assert torch.equal(fc_dev.cpu(), fc_ref)             # caller's tensor was clamped in place
     # flow_cov None -> default sigma, given depth variance branch
     dc = dcov[0, 0, kp[:, 1].cpu(), kp[:, 0].cpu()].contiguous()

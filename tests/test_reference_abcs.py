@@ -1,0 +1,95 @@
+"""The `USING_REFERENCE` branch of mac-vo_amd/interfaces.py: inside a MAC-VO checkout the HIP plugins must subclass the
+reference's OWN ABCs (so `SubclassRegistry.instantiate` finds them by name with no change to Odometry/MACVO.py,
+Utility/Extensions/SubclassRegistry.py:24-48) and the reference's own `MACVO.is_valid_config` (Odometry/MACVO.py:137-156)
+must accept `Config/Experiment/MACVO/MACVO_Fast.yaml` with ONLY its `type:` strings swapped.
+
+Runs in a fresh interpreter (the mirror classes of this repository and the reference's must not mix in one process) with the
+import shims of tests/golden/make_golden.py standing in for third-party packages the hot path never calls (cv2, jaxtyping,
+rerun, ...; PyPose = tests/golden/pypose_shim.py).  Needs /root/reference: skipped on the GPU box."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+
+SCRIPT = r'''
+import sys
+from pathlib import Path
+from types import SimpleNamespace as NS
+sys.path.insert(0, %(root)r)
+from tests.golden import make_golden as MG
+MG.import_reference()                      # shims + sys.path for the reference checkout
+import Module                               # the reference's plugin package (Module/__init__.py:1-11)
+import macvo_amd.interfaces as I
+assert I.USING_REFERENCE, "the real-ABC branch must be taken when the reference is importable"
+import macvo_amd.plugins as P
+
+# 1. the plugins ARE subclasses of the reference's own interfaces and sit in their registries under cls.name()
+pairs = [(Module.IKeypointSelector, "HIP_CovAwareSelector_NoDepth"), (Module.IKeypointSelector, "HIP_CovAwareSelector"),
+         (Module.IKeypointSelector, "HIP_MappingPointSelector"), (Module.ICovariance2to3, "HIP_MatchCovariance"),
+         (Module.IOptimizer, "HIP_TwoFrame_PGO"), (Module.IFrontend, "HIP_FlowFormerCovFrontend"),
+         (Module.IFrontend, "HIP_CUDAGraph_FlowFormerCovFrontend"), (Module.IStereoDepth, "HIP_FlowFormerCovDepth"),
+         (Module.IMatcher, "HIP_FlowFormerCovMatcher")]
+for iface, name in pairs:
+    cls = iface.get_class(name)
+    assert cls is getattr(P, name) and issubclass(cls, iface), (iface, name)
+assert I.IStereoDepth is Module.IStereoDepth and I.IMatcher.Output is Module.IMatcher.Output
+from Module.Optimization.TwoFramePGO.Graphs import GraphInput
+assert I.GraphInput is GraphInput
+
+# 2. a name clash with a reference class is rejected by the reference's own registry (SubclassRegistry.py:42-46)
+try:
+    class CovAwareSelector_NoDepth(Module.IKeypointSelector):   # noqa: F811 - same name as the reference's class
+        def select_point(self, *a): ...
+        @classmethod
+        def is_valid_config(cls, config): ...
+    raise SystemExit("duplicate name was accepted")
+except NameError:
+    pass
+
+# 3. the reference's own loader + validator on MACVO_Fast.yaml with only the `type:` strings swapped
+from Utility.Config import load_config
+import Odometry.MACVO as OM
+cfg, _ = load_config(Path(%(ref)r) / "Config/Experiment/MACVO/MACVO_Fast.yaml")
+od = cfg.Odometry
+OM.MACVO.is_valid_config(od)                                     # the untouched config is valid to begin with
+swap = {"MatchCovariance": "HIP_MatchCovariance", "CovAwareSelector_NoDepth": "HIP_CovAwareSelector_NoDepth",
+        "MappingPointSelector": "HIP_MappingPointSelector",
+        "CUDAGraph_FlowFormerCovFrontend": "HIP_CUDAGraph_FlowFormerCovFrontend", "TwoFrame_PGO": "HIP_TwoFrame_PGO"}
+for sec in (od.cov.obs, od.keypoint, od.mappoint, od.frontend, od.optimizer):
+    sec.type = swap[sec.type]
+od.optimizer.args.device = "cuda"                                # the HIP solver runs on the GPU (the reference's is a CPU child)
+OM.MACVO.is_valid_config(od)
+# exact-key-set rule still applies to the plugins (Utility/Extensions/Testable.py:37-41)
+od.keypoint.args.bogus = 1
+try:
+    OM.MACVO.is_valid_config(od)
+    raise SystemExit("excess key was accepted")
+except (KeyError, AssertionError):
+    pass
+del od.keypoint.args.bogus
+
+# 4. instantiate through the reference's registry exactly as MACVO.from_config does (Odometry/MACVO.py:84-92) — the
+#    classes whose constructors need neither a GPU nor network weights
+kp = Module.IKeypointSelector.instantiate(od.keypoint.type, od.keypoint.args)
+mp = Module.IKeypointSelector.instantiate(od.mappoint.type, od.mappoint.args)
+cv = Module.ICovariance2to3.instantiate(od.cov.obs.type, od.cov.obs.args)
+assert isinstance(kp, P.HIP_CovAwareSelector_NoDepth) and isinstance(mp, P.HIP_MappingPointSelector)
+assert isinstance(cv, P.HIP_MatchCovariance) and cv.config.kernel_size == 31
+opt_cls = Module.IOptimizer.get_class(od.optimizer.type)
+seq_args = NS(**{**vars(od.optimizer.args), "parallel": False})  # parallel = True creates its HIP stream: needs the GPU
+ctx = opt_cls.init_context(seq_args)                             # static, picklable (Optimization/Interface.py:87-92)
+assert isinstance(ctx, dict) and ctx["stream"] is None
+print("REAL-ABC OK")
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "Module")), reason="needs the reference checkout (build container only)")
+def test_plugins_subclass_the_real_reference_abcs(tmp_path):
+    script = tmp_path / "real_abc.py"
+    script.write_text(SCRIPT % {"root": ROOT, "ref": REF})
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert out.returncode == 0 and "REAL-ABC OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
