@@ -18,6 +18,8 @@ Besides the contract's fields the JSON line carries
   parity        free-running HIP track vs the oracle's on the same frames: keypoints, per-frame pose diff, RTE
                 (Evaluation/MetricsSeq.py:9-16 formula); rte_vs_oracle is BASELINE.json's "pose RTE vs reference"
   config4       a short second measurement at BASELINE configs[4] (32 lanes, B = 64 pairs per GEMM), N = 1 only
+  decoder_loop  the HIP lookups / upsamplings interleaved with the PyTorch-ROCm kernels of a stand-in decoder network
+                (mac-vo_amd/decoder_harness.py, loop structure of covhead.py:85-135) next to the back-to-back figure, N = 1 only
 """
 from __future__ import annotations
 
@@ -66,6 +68,7 @@ def parse_args():
                     help="host-side frame sequencing: the C++ driver (mv_frame_pipe_*) or the Python loop over the per-op entry points")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events around the volume kernel")
     ap.add_argument("--no-ramp", action="store_true", help="skip the untimed clock-ramp phase")
+    ap.add_argument("--no-decoder-leg", action="store_true", help="skip the decoder-loop harness leg (HIP lookups / upsamplings interleaved with PyTorch-ROCm kernels)")
     return ap.parse_args()
 
 
@@ -350,6 +353,47 @@ def main():
                    "ms_per_step": round(e4 / args.config4_steps * 1e3, 4),
                    "roofline": roofline_of(ms4, args, 32, n_q, C, in4) if ms4 else None}
 
+    # ---- decoder-loop harness: the same lookups / upsamplings issued BETWEEN real PyTorch-ROCm kernels (GRU, convolutions,
+    # attention of a stand-in network with the reference's loop structure, covhead.py:85-135) instead of back to back
+    decoder_loop = None
+    if rank == 0 and world == 1 and not args.no_decoder_leg and args.lanes == 1 and args.feat_dtype == "f32" and args.layout == "chw":
+        try:
+            from macvo_amd.decoder_harness import DecoderLoopHarness
+
+            net = DecoderLoopHarness(dec_dtype=torch.bfloat16, depth=args.iters).to(dev).eval()
+            vol = ops.corr_volume(frames[0].fmap1, frames[0].fmap2)
+            memory = torch.randn(2 * n_q, 8, 128, device=dev)
+            context = torch.randn(2, 256, h8, w8, device=dev)
+            for _ in range(3):
+                net(vol, memory, context)
+            reps = 10
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                net(vol, memory, context)
+            e1.record()
+            torch.cuda.synchronize()
+            loop_ms = e0.elapsed_time(e1) / reps
+            net(vol, memory, context, time_hip=True)
+            torch.cuda.synchronize()
+            inter = net.hip_times_us()
+            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            tok = None
+            b0.record()
+            for it in range(args.iters * reps):
+                tok = ops.corr_lookup(vol, frames[0].coords[it % args.iters], 4, out=tok)
+            b1.record()
+            torch.cuda.synchronize()
+            decoder_loop = {"what": f"{args.iters}-iteration decoder loop of one estimate_pair (B = 2 pairs, {W}x{H}, bf16 stand-in network, fp32 HIP lookup + 2 convex upsamplings per iteration)",
+                            "ms_per_estimate_pair": round(loop_ms, 3),
+                            "hip_us_interleaved": {k: round(v, 2) for k, v in inter.items()},
+                            "lookup_us_back_to_back": round(b0.elapsed_time(b1) * 1e3 / (args.iters * reps), 2),
+                            "hip_share_of_loop": round(sum(v * (args.iters if k == "corr_lookup" else 2 * args.iters) for k, v in inter.items()) / (loop_ms * 1e3), 4)}
+            del net, vol, memory, context
+        except Exception as e:  # noqa: BLE001 - a measurement leg must not take the benchmark line down
+            decoder_loop = {"error": repr(e)[:300]}
+
     if rank == 0:
         total_frames = world * args.steps * args.lanes
         cfgname = {1: "configs[1]", 32: "configs[4]"}.get(args.lanes, f"{args.lanes}-lane variant of configs[1]")
@@ -381,6 +425,7 @@ def main():
             "cpu_baseline": cpu_baseline,
             "parity": parity,
             "config4": config4,
+            "decoder_loop": decoder_loop,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

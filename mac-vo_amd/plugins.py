@@ -11,6 +11,7 @@ replace, every hot arithmetic step in the HIP kernels (``include/macvo_hip.h``).
     FlowFormerCovFrontend                     HIP_FlowFormerCovFrontend  (network stays PyTorch; lookups + epilogue in HIP)
     CUDAGraph_FlowFormerCovFrontend           HIP_CUDAGraph_FlowFormerCovFrontend  (same, inference replayed as a hipGraph)
     FlowFormerCovDepth / FlowFormerCovMatcher HIP_FlowFormerCovDepth / HIP_FlowFormerCovMatcher  (for FrontendCompose configs)
+    TartanVOCovMatcher                        HIP_TartanVOCovMatcher  (in-tree RAFTFlowCovNet stays PyTorch; its local correlations in HIP)
     (FlowFormerCov's volume / lookup)         install_flowformer_hooks(model)
 
 Select them by changing only the ``type:`` strings of ``Config/Experiment/MACVO/MACVO_Fast.yaml`` (see
@@ -509,6 +510,90 @@ def install_flowformer_hooks(model) -> None:
     """
     dec = model.memory_decoder
     dec.encode_flow_token = lambda cost_maps, coords: ops.corr_lookup(cost_maps.float(), coords.float(), 4)
+
+
+def patch_reference_correlation(correlation=None) -> list[str]:
+    """Make the reference's in-tree PWC-Net family call the HIP local correlation: rebind ``FunctionCorrelation`` in every
+    reference module that imported it by name (``Module/Network/PWCNet/RAFTCov.py:7``, ``pwc/pwc_model.py:12``,
+    ``pwc/pwc_model_tartanvo.py:15``) and in ``pwc/correlation.py`` itself.  The reference's module imports ``cupy`` at the
+    top (correlation.py:5) only to JIT its CUDA kernels; on a ROCm box without cupy an inert placeholder is registered first
+    (the kernels are never launched once the function is rebound).  Returns the names of the patched modules."""
+    import importlib
+    import sys
+    import types
+
+    if "cupy" not in sys.modules:
+        try:
+            importlib.import_module("cupy")
+        except Exception:  # noqa: BLE001 - absent or CUDA-only build
+            stub = types.ModuleType("cupy")
+            stub.cuda = types.SimpleNamespace(compile_with_cache=lambda *a, **k: None)
+            stub.memoize = lambda **k: (lambda f: f)
+            sys.modules["cupy"] = stub
+    fn = correlation or FunctionCorrelation
+    patched = []
+    for name in ("Module.Network.PWCNet.pwc.correlation", "Module.Network.PWCNet.pwc.pwc_model",
+                 "Module.Network.PWCNet.pwc.pwc_model_tartanvo", "Module.Network.PWCNet.RAFTCov"):
+        try:
+            m = importlib.import_module(name)
+        except ImportError:
+            continue
+        m.FunctionCorrelation = fn
+        patched.append(name)
+    return patched
+
+
+class HIP_TartanVOCovMatcher(IMatcher):
+    """``TartanVOCovMatcher`` (Module/Frontend/Matching.py:233-274): the reference's in-tree ``RAFTFlowCovNet``
+    (Module/Network/PWCNet/RAFTCov.py:45-107 — PWC-Net feature pyramid + GaussianGRU covariance head) stays PyTorch-ROCm,
+    its five 81-channel local correlations per frame (pwc_model.py:178-233; the reference's only hand-written CUDA kernel,
+    JIT-compiled through cupy and unavailable on ROCm) run in ``mv_local_corr81``.  Same YAML ``args`` (weight, device);
+    ``weight: ""`` keeps the random initialisation (smoke tests / benchmarks without the release checkpoint).
+    The network source lives in the MAC-VO checkout: outside one the constructor raises."""
+
+    correlation = None      # injectable (tests run the wiring on the CPU with the oracle's definition)
+
+    def __init__(self, config: SimpleNamespace):
+        super().__init__(config)
+        patched = patch_reference_correlation(type(self).correlation)
+        if "Module.Network.PWCNet.RAFTCov" not in patched:
+            raise ops.L.MacvoHipError("HIP_TartanVOCovMatcher needs the MAC-VO checkout on sys.path (Module.Network.PWCNet)")
+        from Module.Network.PWCNet import RAFTFlowCovNet  # type: ignore
+
+        cfg = SimpleNamespace(decoder="raft", dim=64, dropout=0.1, num_heads=4, mixtures=4, gru_iters=12, kernel_size=3)
+        model = RAFTFlowCovNet(cfg, self.config.device)                          # Matching.py:242-248
+        if self.config.weight:
+            model.load_ddp_state_dict(torch.load(self.config.weight, map_location="cpu", weights_only=True))
+        self.model = model.to(self.config.device).eval()
+
+    @property
+    def provide_cov(self) -> bool:
+        return True
+
+    def forward(self, frame_t1, frame_t2) -> "IMatcher.Output":
+        flow, flow_cov = self.model.inference(frame_t1.imageL, frame_t2.imageL)
+        # Matching.py:260-268 as written: the validity mask marks the un-padded centre; with no padding (the network resizes
+        # back to the input size) the slice 0:-0 is empty and the mask stays all-False — reference behaviour, kept
+        mask = torch.zeros_like(flow[:, :1], dtype=torch.bool)
+        pad_h = (frame_t1.height - flow.size(-2)) // 2
+        pad_w = (frame_t1.width - flow.size(-1)) // 2
+        mask[..., pad_h:-pad_h, pad_w:-pad_w] = True
+        flow = _pad_to(flow, frame_t1.height, frame_t1.width)
+        flow_cov = _pad_to(flow_cov, frame_t1.height, frame_t1.width)
+        return IMatcher.Output.from_partial_cov(flow=flow, cov=flow_cov, mask=mask)
+
+    @classmethod
+    def is_valid_config(cls, config: SimpleNamespace | None) -> None:
+        cls._enforce_config_spec(config, {"weight": lambda s: isinstance(s, str), "device": _is_device})
+
+
+def _pad_to(x: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """``padTo(x, (H, W), dim=(-2, -1), value=nan)`` (Utility/Utils.py:95-125): symmetric NaN padding, even amounts only."""
+    ph, pw = H - x.size(-2), W - x.size(-1)
+    assert ph % 2 == 0 and pw % 2 == 0, "Can only handle even padding."
+    if ph == 0 and pw == 0:
+        return x
+    return torch.nn.functional.pad(x, (pw // 2, pw // 2, ph // 2, ph // 2), mode="constant", value=float("nan"))
 
 
 def FunctionCorrelation(tenFirst, tenSecond):

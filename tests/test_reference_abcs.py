@@ -83,6 +83,32 @@ opt_cls = Module.IOptimizer.get_class(od.optimizer.type)
 seq_args = NS(**{**vars(od.optimizer.args), "parallel": False})  # parallel = True creates its HIP stream: needs the GPU
 ctx = opt_cls.init_context(seq_args)                             # static, picklable (Optimization/Interface.py:87-92)
 assert isinstance(ctx, dict) and ctx["stream"] is None
+
+# 5. HIP_TartanVOCovMatcher: the reference's in-tree RAFTFlowCovNet (Module/Network/PWCNet/RAFTCov.py:45-107) built by the
+#    plugin with random weights, every FunctionCorrelation call site rebound — here to the oracle's CPU definition of the same
+#    81-channel local correlation (the HIP kernel is checked against that definition on the GPU: test_gpu_corr::test_local_corr81)
+import torch
+from oracle import corr as ocorr
+calls = []
+def cpu_corr(tenFirst, tenSecond):
+    calls.append(tuple(tenFirst.shape))
+    return ocorr.local_corr81(tenFirst.float(), tenSecond.float())
+assert Module.IMatcher.get_class("HIP_TartanVOCovMatcher") is P.HIP_TartanVOCovMatcher
+P.HIP_TartanVOCovMatcher.correlation = staticmethod(cpu_corr)
+Module.IMatcher.is_valid_config(NS(type="HIP_TartanVOCovMatcher", args=NS(weight="", device="cpu")))
+torch.manual_seed(0)
+torch.Tensor.cuda = lambda self, *a, **k: self      # the reference's warp() hard-codes .cuda() (pwc_model.py); no GPU in this container
+m = Module.IMatcher.instantiate("HIP_TartanVOCovMatcher", NS(weight="", device="cpu"))
+import Module.Network.PWCNet.RAFTCov as RC, Module.Network.PWCNet.pwc.pwc_model as PM
+assert RC.FunctionCorrelation is cpu_corr and PM.FunctionCorrelation is cpu_corr
+H, W = 128, 192
+fa = NS(imageL=torch.rand(1, 3, H, W), height=H, width=W)
+fb = NS(imageL=torch.rand(1, 3, H, W), height=H, width=W)
+out = m.estimate(fa, fb)
+assert len(calls) == 5 and calls[0][2:] == (H // 64, W // 64) and calls[-1][2:] == (H // 4, W // 4), calls   # five pyramid levels (pwc_model.py:178-233)
+assert out.flow.shape == (1, 2, H, W) and out.cov.shape == (1, 3, H, W) and out.mask.shape == (1, 1, H, W)
+assert torch.isfinite(out.flow).all() and (out.cov[:, :2] > 0).all() and (out.cov[:, 2] == 0).all()
+assert not out.mask.any()        # Matching.py:260-264 as written: without padding the 0:-0 slice is empty
 print("REAL-ABC OK")
 '''
 
