@@ -271,19 +271,21 @@ def main():
         traffic = None
     roofline = roofline_of(ms, args, args.lanes, n_q, C, in_region, traffic) if ms else None
     if roofline is not None and rank == 0 and args.volume_precision == "exact":
-        # the same kernel with the GPU to itself (50 back-to-back launches, HIP events): what the co-running lookups / selector /
-        # backend kernels of the neighbouring frames cost it inside the pipeline is the difference to avg_launch_us above
+        # the same kernel with the GPU to itself (back-to-back launches, HIP events): what the co-running lookups / selector /
+        # backend kernels of the neighbouring frames cost it inside the pipeline is the difference to avg_launch_us above.
+        # ~60 ms of launches first: after a few ms of idle the clocks need ~40 ms of load to come back (222 -> 190 us measured)
         b0 = lane_batches(args.lanes)[0]
         vol = ops.corr_volume(b0.fmap1, b0.fmap2, layout=args.layout)
-        for _ in range(10):
+        n_warm, n_iso = max(20, 300 // args.lanes), max(10, 100 // args.lanes)
+        for _ in range(n_warm):
             ops.corr_volume(b0.fmap1, b0.fmap2, layout=args.layout, out=vol)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(50):
+        for _ in range(n_iso):
             ops.corr_volume(b0.fmap1, b0.fmap2, layout=args.layout, out=vol)
         e1.record()
         torch.cuda.synchronize()
-        iso_us = e0.elapsed_time(e1) * 1e3 / 50
+        iso_us = e0.elapsed_time(e1) * 1e3 / n_iso
         roofline["isolated_avg_launch_us"] = round(iso_us, 2)
         roofline["isolated_frac"] = round(roofline["frac"] * roofline["avg_launch_us"] / iso_us, 4)
         del vol

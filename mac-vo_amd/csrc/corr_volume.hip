@@ -360,13 +360,13 @@ __device__ __forceinline__ void vol_unit_coords(const VolSched& S, int u, int& t
     c = u - r * S.Nc;
 }
 
-// big tile q of a pair -> (tm, tn): super-rows of 8 tile rows walked column by column, so that the 64 consecutive items an
-// XCD takes per round are an 8 x 8 block (8 + 8 operand tiles = 2 MB through its L2 instead of 2 + 37); the tiles of the
-// partial row come last, in row order.
+// big tile q of a pair -> (tm, tn): super-rows of 16 tile rows walked column by column, so that the 64 consecutive items an
+// XCD takes per round are a 16 x 4 block and its successive rounds continue to the right (16 row tiles = 2 MB stay in its
+// L2 while 128-KB column tiles stream through once); the tiles of the partial row come last, in row order.
 __device__ __forceinline__ void vol_big_coords(const VolSched& S, int q, int& tm, int& tn) {
     const int in_full = S.full_rows * S.Gb;
     if (q >= in_full) { tm = S.full_rows; tn = q - in_full; return; }
-    constexpr int RG = 8;
+    constexpr int RG = 16;
     const int per_sr = RG * S.Gb;
     const int sr = q / per_sr, within = q - sr * per_sr;
     const int rows = min(RG, S.full_rows - sr * RG);
@@ -488,13 +488,17 @@ __device__ __forceinline__ void vol_tile(const float* __restrict__ A, const floa
         }
 }
 
-// item (round r of the whole schedule, position lin inside the round) -> run the tile it denotes (or nothing)
+// item (round r of the whole schedule, slot s inside the round) -> run the tile it denotes (or nothing).  XCD-major item
+// numbering: XCD x (= s & 7: consecutive workgroup ids land on different XCDs) owns ONE contiguous run of each item list
+// (R rounds x slots / 8 items), walked round by round — with the super-row order of vol_big_coords its big tiles form a compact
+// 16-row x 20-column block of the output (N = 4800), so its 4 MB L2 sees 16 + 20 operand tiles instead of 8 x (8 + 8).
 template <class Pre>
-__device__ __forceinline__ void vol_run_item(const VolSched& S, int r, int lin, int slots, const float* __restrict__ f1,
+__device__ __forceinline__ void vol_run_item(const VolSched& S, int r, int s, int slots, const float* __restrict__ f1,
                                              const float* __restrict__ f2, float* __restrict__ out, int C, int N, size_t fsz,
                                              size_t osz, float* smem, Pre&& pre) {
+    const int per = slots >> 3, xcd = s & 7, j = s >> 3;
     if (r < S.R_b) {
-        const int idx = r * slots + lin;
+        const int idx = xcd * (S.R_b * per) + r * per + j;
         const int b = idx / S.n_big_pp;
         int tm, tn;
         vol_big_coords(S, idx - b * S.n_big_pp, tm, tn);
@@ -503,7 +507,7 @@ __device__ __forceinline__ void vol_run_item(const VolSched& S, int r, int lin, 
     }
     r -= S.R_b;
     if (r < S.R_m) {
-        const int idx = r * slots + lin;
+        const int idx = xcd * (S.R_m * per) + r * per + j;
         if (idx < S.n_med_pp * S.B) {
             const int b = idx / S.n_med_pp;
             int tm, c;
@@ -515,7 +519,7 @@ __device__ __forceinline__ void vol_run_item(const VolSched& S, int r, int lin, 
         return;
     }
     r -= S.R_m;
-    const int idx = r * slots + lin;
+    const int idx = xcd * (S.R_s * per) + r * per + j;
     if (idx < S.n_small_pp * S.B) {
         const int b = idx / S.n_small_pp, sm = idx - b * S.n_small_pp;
         const int from_units = 2 * (S.U_pp - S.n_med_pp);
@@ -543,10 +547,9 @@ __global__ __launch_bounds__(256) void corr_volume_f32_sched(const float* __rest
     const int slots = gridDim.x;
     const int s = blockIdx.x;
     const size_t fsz = (size_t)C * N, osz = (size_t)N * N;
-    const int lin = (s & 7) * (slots >> 3) + (s >> 3);
     const int rounds = S.R_b + S.R_m + S.R_s;
 #pragma unroll 1
-    for (int r = 0; r < rounds; ++r) vol_run_item(S, r, lin, slots, f1, f2, out, C, N, fsz, osz, smem, [] {});
+    for (int r = 0; r < rounds; ++r) vol_run_item(S, r, s, slots, f1, f2, out, C, N, fsz, osz, smem, [] {});
 }
 
 // ONE ITEM PER WORKGROUP (default): grid = rounds x slots workgroups, workgroup i runs item (i / slots, i % slots) of the same
@@ -561,8 +564,7 @@ __global__ __launch_bounds__(256) void corr_volume_f32_mixed(const float* __rest
                                                               float* __restrict__ out, int C, int N, VolSched S, int slots) {
     extern __shared__ __attribute__((aligned(16))) float smem_mixed[];   // 32 KB used + occupancy padding
     const int r = blockIdx.x / slots, s = blockIdx.x - r * slots;
-    const int lin = (s & 7) * (slots >> 3) + (s >> 3);     // XCD x = id & 7 owns a contiguous eighth of each round
-    vol_run_item(S, r, lin, slots, f1, f2, out, C, N, (size_t)C * N, (size_t)N * N, smem_mixed, [] {});
+    vol_run_item(S, r, s, slots, f1, f2, out, C, N, (size_t)C * N, (size_t)N * N, smem_mixed, [] {});
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -11,4 +11,4 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 tail -2 "$OUT/bench.log"
 find "$OUT" -name "*kernel_stats.csv" | head -3
 f=$(find "$OUT" -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && cp "$f" "gpurun_out/${TAG}_kernel_stats.csv" && column -s, -t < "$f" | cut -c1-200 | head -30
+[ -n "$f" ] && cp "$f" "gpurun_out/${TAG}_kernel_stats.csv" && cut -c1-160 "$f" | head -16

@@ -18,7 +18,7 @@ out = {}
 for k, v in agg.items():
     if not any(s in k for s in ("corr_", "pgo", "kp_", "match_cov", "lookup", "upsample")):
         continue
-    name = k.split("(")[0].split("::")[-1].replace("void ", "").strip()
+    name = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip() or k[:60]
     m = {c: sum(x) / len(x) for c, x in sorted(v.items())}
     d = {"launch_config": f"tools/kernel_bench.py {cfg} --iters 5", "launches_sampled": max(len(x) for x in v.values())}
     if "FETCH_SIZE" in m:

@@ -531,54 +531,6 @@ static bool make_sched(int N, int B, int slots, Sched& S) {
     return 4L * S.n_big_pp + 2L * S.n_med_pp + S.n_small_pp == (long)S.Nc * S.Nc;
 }
 
-// dynamic-queue experiments: V = 0 product kernel body with an external queue; 1 = synchronous pull (no prefetch);
-// 2 = prefetch issued in the MIDDLE of the tile is not expressible here -> pull by wave 3 only (a wave that also loads) ...
-template <int V>
-__global__ __launch_bounds__(256) void gemm_dynq(const float* __restrict__ f1, const float* __restrict__ f2, float* __restrict__ out,
-                                                  int C, int N, VolSched S, unsigned* __restrict__ q) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * 16 * 256];
-    __shared__ unsigned sh_pos;
-    const int slots = gridDim.x;
-    const int per = slots >> 3;
-    const unsigned qlen = (unsigned)((S.R_b + S.R_m + S.R_s) * per);
-    const size_t fsz = (size_t)C * N, osz = (size_t)N * N;
-    const int t = threadIdx.x;
-    int xq = blockIdx.x & 7;
-    int tried = 0;
-    if (V == 1) {
-        for (;;) {
-            if (t == 0) sh_pos = atomicAdd(&q[xq], 1u);
-            __syncthreads();
-            const unsigned pos = sh_pos;
-            __syncthreads();
-            if (pos >= qlen) {
-                if (++tried == 8) break;
-                xq = (xq + 1) & 7;
-                continue;
-            }
-            const int r = (int)(pos / (unsigned)per);
-            vol_run_item(S, r, xq * per + (int)(pos - (unsigned)r * per), slots, f1, f2, out, C, N, fsz, osz, smem, [] {});
-        }
-    } else if (V == 2) {
-        // static own items first (no atomics at all), then steal what is left of the OTHER workgroups' items via per-item claim words
-        const int lin = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-        const int rounds = S.R_b + S.R_m + S.R_s;
-        for (int r = 0; r < rounds; ++r) {
-            if (t == 0) sh_pos = atomicExch(&q[16 + r * slots + lin], 1u);
-            __syncthreads();
-            const unsigned taken = sh_pos;
-            __syncthreads();
-            if (!taken) vol_run_item(S, r, lin, slots, f1, f2, out, C, N, fsz, osz, smem, [] {});
-        }
-    }
-    if (t == 0) {
-        __threadfence();
-        if (atomicAdd(&q[8], 1u) == (unsigned)slots - 1u) {
-            for (int i = 0; i < 9; ++i) atomicExch(&q[i], 0u);
-            if (V == 2) for (int i = 0; i < (S.R_b + S.R_m + S.R_s) * slots; ++i) q[16 + i] = 0u;
-        }
-    }
-}
 }  // namespace
 
 static unsigned* g_extq = nullptr;
@@ -590,14 +542,6 @@ extern "C" int gemm3_launch(const float* f1, const float* f2, float* out, int B,
         case 0: return mv_corr_volume(f1, f2, out, B, C, N, N, MV_F32, MV_LAYOUT_CHW, s);
         case 1: hipLaunchKernelGGL(gemm_perm<1>, grid, block, 0, s, f1, f2, out, C, N, N, tiles, tiles); break;
         case 2: hipLaunchKernelGGL(gemm_perm<4>, grid, block, 0, s, f1, f2, out, C, N, N, tiles, tiles); break;
-        case 70: case 71: case 72: {
-            VolSched S;
-            if (!g_extq || !make_vol_sched(N, B, 512, S)) return -2;
-            if (mode == 70) hipLaunchKernelGGL(corr_volume_f32_dyn, dim3(512), block, 0, s, f1, f2, out, C, N, S, g_extq);
-            else if (mode == 71) hipLaunchKernelGGL(gemm_dynq<1>, dim3(512), block, 0, s, f1, f2, out, C, N, S, g_extq);
-            else hipLaunchKernelGGL(gemm_dynq<2>, dim3(512), block, 0, s, f1, f2, out, C, N, S, g_extq);
-            break;
-        }
         case 10: return launch_uni<2, 2, 1>(f1, f2, out, B, C, N, 1024, s);
         case 11: return launch_uni<2, 2, 1>(f1, f2, out, B, C, N, 768, s);
         case 12: return launch_uni<2, 2, 1>(f1, f2, out, B, C, N, 512, s);
