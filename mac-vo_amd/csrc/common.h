@@ -7,6 +7,17 @@
 #define MV_WAVE 64
 
 // live rows per lane of a lane-batched launch (kernel argument, passed by value: no H2D copy, no device table)
+// Volume epilogue stores.  Measured on MI355X (tools/scratch/store_probe.*, 184 MB in the MFMA C layout): plain stores 28.7 us
+// (6.4 TB/s, the rate of a linear fill), non-temporal stores 36.2 us (5.1 TB/s) — and plain stores leave the volume in the
+// 256 MB Infinity Cache for the lookups that follow.  -DMV_NT_STORES builds the round-1 behaviour for A/B.
+#ifdef MV_NT_STORES
+#define MV_VOL_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#define MV_VOL_STORE_ASM_MOD " nt"
+#else
+#define MV_VOL_STORE(v, p) (*(p) = (v))
+#define MV_VOL_STORE_ASM_MOD ""
+#endif
+
 struct mvLaneCounts {
     int32_t n[MV_MAX_LANES];
 };

@@ -101,7 +101,7 @@ def test_corr_volume_f32_split2(gpu, shape):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("layout", ["chw", "hwc"])
-@pytest.mark.parametrize("shape", [(2, 64, 8, 12), (1, 256, 60, 80), (1, 128, 9, 11)])
+@pytest.mark.parametrize("shape", [(2, 64, 8, 12), (1, 256, 60, 80), (1, 128, 9, 11), (2, 256, 59, 64), (2, 128, 48, 64)])
 def test_corr_volume_16bit(gpu, dtype, layout, shape):
     """Fast-mode path: 16-bit operands, fp32 accumulate.  Oracle = float64 einsum of the SAME rounded inputs;
     tolerance = fp32 accumulation error only (1e-5 * sqrt(C) scale)."""
@@ -117,6 +117,35 @@ def test_corr_volume_16bit(gpu, dtype, layout, shape):
         out = ops.corr_volume(f1.permute(0, 2, 3, 1).contiguous().to(gpu), f2.permute(0, 2, 3, 1).contiguous().to(gpu),
                               layout="hwc")
     assert (out.cpu().double() - ref64).abs().max().item() <= 2e-5 * float(C) ** 0.5
+
+
+_STREAM_VS_TILE = r"""
+import hashlib, sys, torch
+sys.path.insert(0, sys.argv[1])
+from macvo_amd import ops
+for dt, (B, C, H, W) in ((torch.float16, (2, 256, 60, 80)), (torch.bfloat16, (2, 256, 59, 64)), (torch.float16, (3, 128, 48, 64))):
+    g = torch.Generator().manual_seed(11)
+    f1 = torch.randn(B, H, W, C, generator=g).to(dt).cuda()
+    f2 = torch.randn(B, H, W, C, generator=g).to(dt).cuda()
+    out = ops.corr_volume(f1, f2, layout="hwc")
+    print(hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest())
+"""
+
+
+def test_corr_volume_16bit_streaming_form_is_bitwise_the_tile_form(gpu):
+    """The streaming kernel (whole-K A fragments in registers, LDS-DMA ring, hand-counted waits) must give the very bits of the
+    128x128 tile kernel it replaces: same MFMA, same k order.  Shapes: full bands, a half band at the bottom edge, three pairs
+    with C = 128.  MV_H_STREAM is read once per process, so each form runs in its own interpreter."""
+    import os, subprocess, sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shas = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, MV_H_STREAM=flag)
+        r = subprocess.run([sys.executable, "-c", _STREAM_VS_TILE, root], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        shas.append(r.stdout.split())
+    assert len(shas[0]) == 3 and shas[0] == shas[1], shas
 
 
 def _coords(B, H, W, seed, spread=8.0):
