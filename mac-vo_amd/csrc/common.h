@@ -7,10 +7,13 @@
 #define MV_WAVE 64
 
 // live rows per lane of a lane-batched launch (kernel argument, passed by value: no H2D copy, no device table)
-// Volume epilogue stores.  Measured on MI355X (tools/scratch/store_probe.*, 184 MB in the MFMA C layout): plain stores 28.7 us
-// (6.4 TB/s, the rate of a linear fill), non-temporal stores 36.2 us (5.1 TB/s) — and plain stores leave the volume in the
-// 256 MB Infinity Cache for the lookups that follow.  -DMV_NT_STORES builds the round-1 behaviour for A/B.
-#ifdef MV_NT_STORES
+// Volume epilogue stores: non-temporal.  Measured on MI355X: a store-only kernel in the MFMA C layout writes 184 MB in 28.7 us with
+// plain stores and 36.2 us with non-temporal ones (tools/scratch/store_probe.*), but the volume kernels themselves are not bound
+// there (fp32: 193 us either way; 16-bit streaming: 41 us either way) and IN THE PIPELINE, where the lookups / selectors of other
+// frames run beside the volume, non-temporal stores win because 184 MB per frame do not sweep the L2s: fp32 3.38-3.41 k vs
+// 3.31 k frames/s, 16-bit 5.13 k vs 4.83 k, 3 lanes 4.09 k vs 4.05 k (tools/scratch/ab_nt.sh).  -DMV_PLAIN_STORES builds the
+// other variant for A/B.
+#ifndef MV_PLAIN_STORES
 #define MV_VOL_STORE(v, p) __builtin_nontemporal_store((v), (p))
 #define MV_VOL_STORE_ASM_MOD " nt"
 #else
