@@ -148,6 +148,35 @@ def test_corr_volume_16bit_streaming_form_is_bitwise_the_tile_form(gpu):
     assert len(shas[0]) == 3 and shas[0] == shas[1], shas
 
 
+_F32_STREAM_VS_TILES = r"""
+import hashlib, sys, torch
+sys.path.insert(0, sys.argv[1])
+from macvo_amd import ops
+for B, C, H, W in ((2, 256, 60, 80), (1, 256, 64, 64), (3, 256, 59, 64)):
+    g = torch.Generator().manual_seed(12)
+    f1 = torch.randn(B, C, H, W, generator=g).cuda()
+    f2 = torch.randn(B, C, H, W, generator=g).cuda()
+    out = ops.corr_volume(f1, f2, layout="chw")
+    print(hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest())
+"""
+
+
+def test_corr_volume_f32_streaming_form_is_bitwise_the_mixed_tile_form(gpu):
+    """The opt-in fp32 streaming kernel (MV_VOL_STREAM=1: A fragments in registers, LDS-DMA ring in K halves, asm stores behind the
+    last MFMA with the hazard no-ops) against the default mixed-tile kernel: same instruction, same ascending k pairs -> same
+    bits.  Shapes: 37.5 bands (rows past N repeat row N - 1), whole bands, three pairs with a half band."""
+    import os, subprocess, sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shas = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, MV_VOL_STREAM=flag)
+        r = subprocess.run([sys.executable, "-c", _F32_STREAM_VS_TILES, root], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        shas.append(r.stdout.split())
+    assert len(shas[0]) == 3 and shas[0] == shas[1], shas
+
+
 def _coords(B, H, W, seed, spread=8.0):
     from oracle import corr
 
