@@ -312,6 +312,28 @@ __global__ __launch_bounds__(256) void corr_volume_f32_chw(const float* __restri
 // fragment prefetch two groups ahead (no gain), the K stream running across tile boundaries (no cold prologue: no gain),
 // de-phasing the two co-resident workgroups by a quarter tile (no gain).
 // ------------------------------------------------------------------------------------------------
+// ---- hand-counted memory waits and LDS-DMA (used by the DMA-staged tile below and by the streaming kernels) ----
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait for this wave's older memory operations (all but the newest N), then the workgroup barrier — one statement so that
+// nothing can be scheduled between the two
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+// LDS-DMA: 64 lanes x 16 B from (uniform base + per-lane 32-bit offset) to LDS bytes [lds_dst, lds_dst + 1024) in lane order.  M0
+// carries the destination and is compiler-reserved: saved, written and restored inside the one statement.  Invisible to
+// hipcc's s_waitcnt bookkeeping (counted by hand at the call sites).
+__device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
 struct VolSched {   // host-computed, passed by value; everything per PAIR unless noted.  Cells are 64 x 64 outputs.
     int Nc, Gb;                     // cells per dimension; 128x128 tile grid per dimension (Nc / 2)
     int n_big_pp, full_rows, rem;   // big tiles of a pair: `full_rows` full tile rows + `rem` tiles of the next row
@@ -488,11 +510,114 @@ __device__ __forceinline__ void vol_tile(const float* __restrict__ A, const floa
         }
 }
 
+// The same tile with LDS-DMA staging (the default of the one-item-per-workgroup kernel): operand K steps go global -> LDS by
+// global_load_lds_dwordx4 — no staging registers (96 instead of 116-126), no ds_write, and with nothing held in registers a K
+// step can be 32 deep: NST LDS stages of BK k rows, the pieces of K step kt + NST - 1 issued between the MFMA groups of step kt,
+// half as many barriers per tile with BK = 32.  The column permutation of the LDS image is applied to the SOURCE chunk each lane
+// fetches (the DMA destination is lane-linear).  Waits are counted by hand: the only memory operations of a workgroup before
+// its epilogue are its own DMA pieces, PPW per wave and K step, so "all but the newest PPW x (NST - 2)" = "K step kt has landed".
+// k still ascends per output element: bitwise the register-staged kernel.
+template <int MI, int NJ, int NST, int BK = 16>
+__device__ __forceinline__ void vol_tile_dma(const float* __restrict__ A, const float* __restrict__ Bp, float* __restrict__ O, int C,
+                                             int N, int m0, int n0, float* smem) {
+    constexpr int WA = 64 * MI, WB = 64 * NJ;
+    constexpr int STAGE = BK * (WA + WB);
+    constexpr int PA = BK * WA / 256, PB = BK * WB / 256;   // 1-KB pieces per K step
+    constexpr int PPW = (PA + PB) / 4;                      // per wave (4, 3 or 2)
+    constexpr int RA = 256 / WA, RB = 256 / WB;             // k rows per piece
+    constexpr int LA = NST - 1;                             // K steps a piece is issued ahead of its use
+    const int t = threadIdx.x, lane = t & 63, wm = (t >> 6) >> 1, wn = (t >> 6) & 1, kh = lane >> 5, li = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nk = C / BK;
+    const float* Au = A + m0;
+    const float* Bu = Bp + n0;
+    // lane -> (row inside the piece, position inside the LDS row) -> source column = inverse permutation of the position
+    auto unperm = [](int pos, int m) { return ((pos & 63) >> 5) * 32 * m + (pos >> 6) * 32 + (pos & 31); };
+    const unsigned voA = (unsigned)(((lane * 4) / WA) * N + unperm((lane * 4) % WA, MI)) * 4u;
+    const unsigned voB = (unsigned)(((lane * 4) / WB) * N + unperm((lane * 4) % WB, NJ)) * 4u;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
+    auto piece = [&](int kt, int p) __attribute__((always_inline)) {   // piece p of this wave for K step kt -> stage kt % NST
+        const int pi = wave + 4 * p;
+        const bool isA = pi < PA;
+        const int q = isA ? pi : pi - PA;
+        const float* base = isA ? Au + (size_t)(kt * BK + q * RA) * N : Bu + (size_t)(kt * BK + q * RB) * N;
+        const unsigned dst = lds0 + (unsigned)((kt % NST) * STAGE + (isA ? 0 : BK * WA) + q * 256) * 4u;
+        glds16_s(isA ? voA : voB, base, dst);
+    };
+    const float* fa = smem + kh * WA + wm * 32 + li;
+    const float* fb = smem + BK * WA + kh * WB + wn * 32 + li;
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto mma = [&](int buf, auto&& after) __attribute__((always_inline)) {
+        const float* qa = fa + buf * STAGE;
+        const float* qb = fb + buf * STAGE;
+        float a[2][MI], b[2][NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[0][i] = qa[i * 64];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[0][j] = qb[j * 64];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+            if (kk + 2 < BK) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[nxt][i] = qa[(kk + 2) * WA + i * 64];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[nxt][j] = qb[(kk + 2) * WB + j * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            after(kk >> 1);
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < LA; ++k)                 // (nk >= LA is the launcher's condition)
+#pragma unroll
+        for (int p = 0; p < PPW; ++p) piece(k, p);
+    int buf = 0;
+    for (int kt = 0; kt <= nk - LA; ++kt) {
+        wait_vmcnt_barrier<PPW * (LA - 1)>();     // K step kt has landed (LA - 1 later ones may be in flight); stage (kt + LA) % NST is free
+        const bool more = kt + LA < nk;
+        mma(buf, [&](int g) {
+            if (g < PPW && more) piece(kt + LA, g);
+        });
+        buf = buf == NST - 1 ? 0 : buf + 1;
+    }
+    if constexpr (LA >= 3) {                     // tail: one K step fewer in flight each time
+        wait_vmcnt_barrier<PPW * (LA - 2)>();
+        mma(buf, [](int) {});
+        buf = buf == NST - 1 ? 0 : buf + 1;
+    }
+    if constexpr (LA >= 2) {
+        wait_vmcnt_barrier<0>();
+        mma(buf, [](int) {});
+    }
+    float* Ou = O + (size_t)m0 * N + n0;
+    const unsigned so = (wm * 32 * MI + 4 * kh) * N + wn * 32 * NJ + li;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float* p = Ou + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * N;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) MV_VOL_STORE(acc[i][j][r], p + j * 32 + so);
+        }
+}
+
 // item (round r of the whole schedule, slot s inside the round) -> run the tile it denotes (or nothing).  XCD-major item
 // numbering: XCD x (= s & 7: consecutive workgroup ids land on different XCDs) owns ONE contiguous run of each item list
 // (R rounds x slots / 8 items), walked round by round — with the super-row order of vol_big_coords its big tiles form a compact
 // 16-row x 20-column block of the output (N = 4800), so its 4 MB L2 sees 16 + 20 operand tiles instead of 8 x (8 + 8).
-template <class Pre>
+template <int DMA = 0, class Pre>
 __device__ __forceinline__ void vol_run_item(const VolSched& S, int r, int s, int slots, const float* __restrict__ f1,
                                              const float* __restrict__ f2, float* __restrict__ out, int C, int N, size_t fsz,
                                              size_t osz, float* smem, Pre&& pre) {
@@ -502,7 +627,9 @@ __device__ __forceinline__ void vol_run_item(const VolSched& S, int r, int s, in
         const int b = idx / S.n_big_pp;
         int tm, tn;
         vol_big_coords(S, idx - b * S.n_big_pp, tm, tn);
-        vol_tile<2, 2>(f1 + b * fsz, f2 + b * fsz, out + b * osz, C, N, tm * 128, tn * 128, smem, pre);
+        if constexpr (DMA == 2) vol_tile_dma<2, 2, 2, 32>(f1 + b * fsz, f2 + b * fsz, out + b * osz, C, N, tm * 128, tn * 128, smem);
+        else if constexpr (DMA > 0) vol_tile_dma<2, 2, DMA>(f1 + b * fsz, f2 + b * fsz, out + b * osz, C, N, tm * 128, tn * 128, smem);
+        else vol_tile<2, 2>(f1 + b * fsz, f2 + b * fsz, out + b * osz, C, N, tm * 128, tn * 128, smem, pre);
         return;
     }
     r -= S.R_b;
@@ -512,7 +639,9 @@ __device__ __forceinline__ void vol_run_item(const VolSched& S, int r, int s, in
             const int b = idx / S.n_med_pp;
             int tm, c;
             vol_unit_coords(S, idx - b * S.n_med_pp, tm, c);
-            vol_tile<2, 1>(f1 + b * fsz, f2 + b * fsz, out + b * osz, C, N, tm * 128, c * 64, smem, pre);
+            if constexpr (DMA == 2) vol_tile_dma<2, 1, 2, 32>(f1 + b * fsz, f2 + b * fsz, out + b * osz, C, N, tm * 128, c * 64, smem);
+            else if constexpr (DMA > 0) vol_tile_dma<2, 1, DMA>(f1 + b * fsz, f2 + b * fsz, out + b * osz, C, N, tm * 128, c * 64, smem);
+            else vol_tile<2, 1>(f1 + b * fsz, f2 + b * fsz, out + b * osz, C, N, tm * 128, c * 64, smem, pre);
         } else {
             pre();
         }
@@ -533,7 +662,9 @@ __device__ __forceinline__ void vol_run_item(const VolSched& S, int r, int s, in
             m0 = (S.Nc - 1) * 64;
             n0 = (sm - from_units) * 64;
         }
-        vol_tile<1, 1>(f1 + b * fsz, f2 + b * fsz, out + b * osz, C, N, m0, n0, smem, pre);
+        if constexpr (DMA == 2) vol_tile_dma<1, 1, 2, 32>(f1 + b * fsz, f2 + b * fsz, out + b * osz, C, N, m0, n0, smem);
+        else if constexpr (DMA > 0) vol_tile_dma<1, 1, DMA>(f1 + b * fsz, f2 + b * fsz, out + b * osz, C, N, m0, n0, smem);
+        else vol_tile<1, 1>(f1 + b * fsz, f2 + b * fsz, out + b * osz, C, N, m0, n0, smem, pre);
     } else {
         pre();
     }
@@ -565,6 +696,14 @@ __global__ __launch_bounds__(256) void corr_volume_f32_mixed(const float* __rest
     extern __shared__ __attribute__((aligned(16))) float smem_mixed[];   // 32 KB used + occupancy padding
     const int r = blockIdx.x / slots, s = blockIdx.x - r * slots;
     vol_run_item(S, r, s, slots, f1, f2, out, C, N, (size_t)C * N, (size_t)N * N, smem_mixed, [] {});
+}
+
+template <int NST>
+__global__ __launch_bounds__(256) void corr_volume_f32_mixed_dma(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                                  float* __restrict__ out, int C, int N, VolSched S, int slots) {
+    extern __shared__ __attribute__((aligned(16))) float smem_mixed_dma[];   // NST stages x 16 KB + occupancy padding
+    const int r = blockIdx.x / slots, s = blockIdx.x - r * slots;
+    vol_run_item<NST>(S, r, s, slots, f1, f2, out, C, N, (size_t)C * N, (size_t)N * N, smem_mixed_dma, [] {});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -885,16 +1024,6 @@ __global__ __launch_bounds__(256) void corr_volume_h_hwc(const uint16_t* __restr
 // ------------------------------------------------------------------------------------------------
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-// wait for this wave's older memory operations (all but the newest N), then the workgroup barrier — one statement so that
-// nothing can be scheduled between the two
-template <int N>
-__device__ __forceinline__ void wait_vmcnt_barrier() {
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
-}
 // LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS bytes [lds_dst, lds_dst + 1024) in lane order.  M0 carries the
 // destination and is compiler-reserved: saved, written and restored inside the one statement.  Invisible to hipcc's s_waitcnt
 // bookkeeping (counted by hand, see the kernel).
@@ -1112,13 +1241,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // Edge (N = 4800 = 37.5 x 128): rows past N repeat row N - 1, in the operands and in the store addresses, so the duplicates
 // land on their original with identical values (1.3 % extra MFMAs).  N % 64 == 0 keeps the columns whole.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_dst)
-                 : "memory");
-}
 
 template <int C>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void corr_volume_f32_stream(
@@ -1507,6 +1629,38 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
                 if (vol_walk_static()) {
                     hipLaunchKernelGGL(corr_volume_f32_sched, dim3(slots), block, 0, s, a, b, out, C, N1, vs);
                 } else {
+                    // LDS-DMA staging (default): 2 = BK 32 x 2 stages, 3 / 4 = BK 16 x 3 / 4 stages; MV_VOL_DMA=16 -> 3, =0 -> the
+                    // register-staged tile.  Measured (tools/scratch/fvol_probe.py, 640x480, B = 2, alone): register-staged 185.8 us,
+                    // BK 16 x 3 stages 182.5 (x 4 stages: 182.5), BK 32 x 2 stages 175.7 us = 0.854 of the fp32 MFMA peak (1280x720: 0.878);
+                    // in the frame pipeline 3.43-3.45 k / 3.47-3.54 k / 3.39 k frames/s for BK 32 / BK 16 / register-staged at one lane
+                    // (the 128 KB of LDS two BK-32 workgroups hold leave the co-running small kernels 32 KB per CU) and
+                    // 4.52 k / 4.48 k / 4.32 k at three lanes.
+                    static int dma = -1;
+                    if (dma < 0) {
+                        const char* e = getenv("MV_VOL_DMA");
+                        const int v = e ? atoi(e) : 32;
+                        dma = v == 0 ? 0 : v == 16 ? 3 : v == 4 ? 4 : 2;
+                    }
+                    if (dma && (dma == 2 ? (C % 32 == 0 && C >= 64) : C >= 16 * (dma - 1))) {
+                        const unsigned ldsd = std::max(vol_lds_bytes(), (unsigned)(dma == 2 ? 4 : dma) * 16 * 256 * 4);
+                        static bool attr_dma = false;
+                        if (!attr_dma) {
+                            (void)hipFuncSetAttribute((const void*)corr_volume_f32_mixed_dma<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                            (void)hipFuncSetAttribute((const void*)corr_volume_f32_mixed_dma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                            (void)hipFuncSetAttribute((const void*)corr_volume_f32_mixed_dma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                            attr_dma = true;
+                        }
+                        if (dma == 2)
+                            hipLaunchKernelGGL(corr_volume_f32_mixed_dma<2>, dim3((vs.R_b + vs.R_m + vs.R_s) * slots), block, ldsd, s, a,
+                                               b, out, C, N1, vs, slots);
+                        else if (dma == 4)
+                            hipLaunchKernelGGL(corr_volume_f32_mixed_dma<4>, dim3((vs.R_b + vs.R_m + vs.R_s) * slots), block, ldsd, s, a,
+                                               b, out, C, N1, vs, slots);
+                        else
+                            hipLaunchKernelGGL(corr_volume_f32_mixed_dma<3>, dim3((vs.R_b + vs.R_m + vs.R_s) * slots), block, ldsd, s, a,
+                                               b, out, C, N1, vs, slots);
+                        return mv_launch_status();
+                    }
                     const unsigned lds = vol_lds_bytes();
                     static bool attr_set = false;
                     if (!attr_set && lds > 48 * 1024) {
