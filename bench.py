@@ -95,7 +95,7 @@ def roofline_of(ms, args, lanes, n_q, C, timed_region_launches, traffic=None):
         ach = flops / avg_s / 1e12
         return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                "kernel": "corr_volume_f32_mixed" if args.layout == "chw" else "corr_volume_f32_hwc", **common}
+                "kernel": "corr_volume_f32_mixed_dma" if args.layout == "chw" else "corr_volume_f32_hwc", **common}
     ach = nbytes / avg_s / 1e9
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
             "traffic": None, "kernel": "corr_volume_h_" + args.layout, **common}
