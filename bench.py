@@ -98,7 +98,8 @@ def roofline_of(ms, args, lanes, n_q, C, timed_region_launches, traffic=None):
                 "kernel": "corr_volume_f32_mixed_dma" if args.layout == "chw" else "corr_volume_f32_hwc", **common}
     ach = nbytes / avg_s / 1e9
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
-            "traffic": None, "kernel": "corr_volume_h_" + args.layout, **common}
+            "traffic": traffic, "kernel": "corr_volume_h_stream" if (args.layout == "hwc" and C in (128, 256)) else "corr_volume_h_" + args.layout,
+            **common}
 
 
 def main():
@@ -267,6 +268,13 @@ def main():
                     if key is not None:
                         traffic = pm[key]["_derived"]["traffic_bytes_per_launch"]
                         break
+        if (H, W, C, args.lanes) == (480, 640, 256, 1) and args.feat_dtype in ("f16", "bf16") and args.layout == "hwc":
+            path = os.path.join(ROOT, "profiles", "r02_pmc_corr_volume_16bit_stream.json")
+            if os.path.exists(path):
+                pm = json.load(open(path))
+                key = next((k for k in pm if k.startswith("corr_volume_h_stream")), None)
+                if key is not None:
+                    traffic = pm[key]["_derived"]["traffic_bytes_per_launch"]
     except Exception:  # noqa: BLE001
         traffic = None
     roofline = roofline_of(ms, args, args.lanes, n_q, C, in_region, traffic) if ms else None
