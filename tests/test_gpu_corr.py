@@ -161,6 +161,21 @@ for B, C, H, W in ((2, 256, 60, 80), (1, 256, 64, 64), (3, 256, 59, 64)):
 """
 
 
+def test_corr_volume_f32_staging_variants_are_bitwise_equal(gpu):
+    """The fp32 mixed-tile GEMM with LDS-DMA staging (BK 32 x 2 stages = default, BK 16 x 3 stages) against the register-staged
+    tile it replaced: k ascends per output element in all of them, so the volumes must agree bit for bit."""
+    import os, subprocess, sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shas = []
+    for flag in ("32", "16", "4", "0"):
+        env = dict(os.environ, MV_VOL_DMA=flag, MV_VOL_STREAM="0")
+        r = subprocess.run([sys.executable, "-c", _F32_STREAM_VS_TILES, root], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        shas.append(r.stdout.split())
+    assert len(shas[0]) == 3 and all(x == shas[0] for x in shas[1:]), shas
+
+
 def test_corr_volume_f32_streaming_form_is_bitwise_the_mixed_tile_form(gpu):
     """The opt-in fp32 streaming kernel (MV_VOL_STREAM=1: A fragments in registers, LDS-DMA ring in K halves, asm stores behind the
     last MFMA with the hazard no-ops) against the default mixed-tile kernel: same instruction, same ascending k pairs -> same
