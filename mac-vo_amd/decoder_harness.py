@@ -28,6 +28,17 @@ import torch.nn.functional as F
 from . import ops
 
 
+def _range(name: str):
+    """Profiler range with the reference's names (``covhead.py:90-135`` wraps the same statements in ``torch.cuda.nvtx.range``;
+    on ROCm these are roctx ranges, visible to ``rocprofv3 --marker-trace``).  A no-op context when the binding is unavailable."""
+    try:
+        return torch.cuda.nvtx.range(name)
+    except Exception:  # noqa: BLE001
+        import contextlib
+
+        return contextlib.nullcontext()
+
+
 class SepConvGRU(nn.Module):
     """RAFT's separable ConvGRU (1x5 then 5x1), the update cell of both branches (covhead.py:29-31)."""
 
@@ -135,32 +146,40 @@ class DecoderLoopHarness(nn.Module):
         flow_up = cov_up = None
         for it in range(self.depth):
             flow = (flow_c1 - coords0).to(dt)
-            tokens = hip(ops.corr_lookup, cost_maps, flow_c1, self.radius)                       # :92  MUST run in fp32
-            if self.trace is not None:
-                self.trace.append(dict(coords=flow_c1.clone(), tokens=tokens.clone()))
-            cost_forward = tokens.to(dt)
-            query = self.flow_token_encoder(cost_forward)                                        # :96
-            query = query.permute(0, 2, 3, 1).reshape(B * N, 1, self.dim)
-            att = torch.softmax(self.q_proj(query) @ k_mem.transpose(1, 2) / self.dim ** 0.5, dim=-1)   # :100-102
-            cost_global = self.attn_out(att @ v_mem).view(B, h8, w8, 128).permute(0, 3, 1, 2)
-            corr = torch.cat([cost_global, cost_forward], dim=1)                                  # :103
-            cor = F.relu(self.enc_c2(F.relu(self.enc_c1(corr))))                                  # :106 motion encoder
-            flo = F.relu(self.enc_f2(F.relu(self.enc_f1(flow))))
-            motion_feat = torch.cat([F.relu(self.enc_out(torch.cat([cor, flo], dim=1))), flow], dim=1)
-            motion_global = self.aggregate(motion_feat)                                           # :107
+            with _range("Encode Flow Token"):
+                tokens = hip(ops.corr_lookup, cost_maps, flow_c1, self.radius)                   # :92  MUST run in fp32
+                if self.trace is not None:
+                    self.trace.append(dict(coords=flow_c1.clone(), tokens=tokens.clone()))
+                cost_forward = tokens.to(dt)
+            with _range("CNN Encoder"):
+                query = self.flow_token_encoder(cost_forward)                                    # :96
+                query = query.permute(0, 2, 3, 1).reshape(B * N, 1, self.dim)
+            with _range("Cross Attention"):
+                att = torch.softmax(self.q_proj(query) @ k_mem.transpose(1, 2) / self.dim ** 0.5, dim=-1)   # :100-102
+                cost_global = self.attn_out(att @ v_mem).view(B, h8, w8, 128).permute(0, 3, 1, 2)
+                corr = torch.cat([cost_global, cost_forward], dim=1)                              # :103
+            with _range("GMA Update Block"):
+                cor = F.relu(self.enc_c2(F.relu(self.enc_c1(corr))))                              # :106 motion encoder
+                flo = F.relu(self.enc_f2(F.relu(self.enc_f1(flow))))
+                motion_feat = torch.cat([F.relu(self.enc_out(torch.cat([cor, flo], dim=1))), flow], dim=1)
+                motion_global = self.aggregate(motion_feat)                                       # :107
             inp_cat = torch.cat([flow_inp, motion_feat, motion_global], dim=1)                    # :109
-            flow_net = self.flow_gru(flow_net, inp_cat)                                           # :112-114
-            delta_flow, up_mask = self.flow_head(flow_net), self.flow_mask(flow_net)
-            fcov_net, delta_cov, cov_mask = self.cov_update(fcov_net, inp_cat)                    # :117
-            flow_c1 = flow_c1 + delta_flow.float()                                                # :121-126, fp32
-            um = up_mask.float().contiguous()
-            flow_up = hip(ops.convex_upsample, flow_c1 - coords0, um, mask_scale=0.25)
-            if self.trace is not None:
-                self.trace[-1].update(flow8=(flow_c1 - coords0).clone(), up_mask=um.clone(), flow_up=flow_up.clone())
-            cov_c1 = cov_c1 + delta_cov.float()                                                   # :130-135, fp32
-            last = it == self.depth - 1
-            cm = cov_mask.float().contiguous()
-            cov_up = hip(ops.convex_upsample, cov_c1 - cov_c0, cm, mask_scale=1.0, exp2_out=last)
+            with _range("Flow Update Block"):
+                flow_net = self.flow_gru(flow_net, inp_cat)                                       # :112-114
+                delta_flow, up_mask = self.flow_head(flow_net), self.flow_mask(flow_net)
+            with _range("Cov Update Block"):
+                fcov_net, delta_cov, cov_mask = self.cov_update(fcov_net, inp_cat)                # :117
+            with _range("Flow Upsample"):
+                flow_c1 = flow_c1 + delta_flow.float()                                            # :121-126, fp32
+                um = up_mask.float().contiguous()
+                flow_up = hip(ops.convex_upsample, flow_c1 - coords0, um, mask_scale=0.25)
+                if self.trace is not None:
+                    self.trace[-1].update(flow8=(flow_c1 - coords0).clone(), up_mask=um.clone(), flow_up=flow_up.clone())
+            with _range("Cov Upsample"):
+                cov_c1 = cov_c1 + delta_cov.float()                                               # :130-135, fp32
+                last = it == self.depth - 1
+                cm = cov_mask.float().contiguous()
+                cov_up = hip(ops.convex_upsample, cov_c1 - cov_c0, cm, mask_scale=1.0, exp2_out=last)
         # what the hot path takes over (pipeline.FrameInputs, the 1/8-resolution alternative): last iteration's fields + masks
         self.last = dict(flow8=(flow_c1 - coords0).contiguous(), cov8=(cov_c1 - cov_c0).contiguous(), up_mask=um, cov_mask=cm)
         return (flow_up, flow_c1 - coords0), (cov_up, cov_c1 - cov_c0)

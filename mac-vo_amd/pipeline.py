@@ -28,6 +28,28 @@ import torch
 
 from . import ops
 
+_RANGES = os.environ.get("MV_TRACE_RANGES", "0") not in ("", "0")
+
+
+def traced(name: str):
+    """Opt-in (``MV_TRACE_RANGES=1``) profiler range around a pipeline stage, named like the reference's ``Timer`` scopes
+    (``Frontend.estimate``: ``Module/Frontend/Frontend.py:215-216``; ``Odom_Runtime``: ``Odometry/MACVO.py:350-351``).  On ROCm
+    ``torch.cuda.nvtx`` emits roctx ranges (``rocprofv3 --marker-trace``).  Off by default: two host calls per stage per frame."""
+    def deco(fn):
+        if not _RANGES:
+            return fn
+        import functools
+
+        @functools.wraps(fn)
+        def wrapped(*a, **k):
+            torch.cuda.nvtx.range_push(name)
+            try:
+                return fn(*a, **k)
+            finally:
+                torch.cuda.nvtx.range_pop()
+        return wrapped
+    return deco
+
 
 @dataclass
 class Camera:
@@ -243,6 +265,7 @@ class HotPath:
             self.pose = init_pose.to(self.dev, torch.float32).reshape(7).clone()
 
     # ------------------------------------------------------------------ one run_pair, in two halves
+    @traced("Frontend.estimate")
     def enqueue_frontend(self, x: FrameInputs) -> "_Pending":
         """Everything of a frame that does not depend on the previous pose: volume, lookups, epilogue and the dense
         selector stage.  Only enqueues work; the candidate count travels to a pinned host word behind an event, so a
@@ -271,6 +294,7 @@ class HotPath:
         self._prev_image = x.image
         return pend
 
+    @traced("Odom_Runtime")
     def finish(self, pend: "_Pending", pose_sink: torch.Tensor | None = None) -> FrameResult:
         """Host randperm (bit-exact indices) + the pose-dependent half: tracking, back-projection, covariances, filter,
         PGO.  The solve runs on a side stream (the GPU analogue of the reference's optimizer child process,
@@ -618,6 +642,7 @@ class NativeHotPath:
             self._map.push_frame(K=self._map_K, T_BS=self._map_TBS, baseline=self.cam.baseline, time_ns=x.time_ns, prior_pose=init_pose)
             torch.cuda.current_stream().synchronize()   # later frames are appended on the pipe's streams: order them after this one
 
+    @traced("Frontend.estimate")
     def enqueue_frontend(self, x: FrameInputs):
         assert self._n_enq >= 1, "call initialize() with the first frame"
         self._enqueue(x, True)
@@ -634,6 +659,7 @@ class NativeHotPath:
         ops.L.check(self._lib.mv_frame_pipe_enqueue_volume(self._pipe, ops.C.byref(self._inputs(x)), ops._stream()),
                     "mv_frame_pipe_enqueue_volume")
 
+    @traced("Odom_Runtime")
     def finish(self, pend=None, pose_sink: torch.Tensor | None = None):
         """Host half of a frame: wait for the candidate counts, draw the permutations (CPU generators, lane order), enqueue
         the pose-dependent kernels.  Returns a :class:`_NativeResult` (a list of them, one per lane, for lanes > 1)."""
