@@ -1184,7 +1184,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     using Yes = std::true_type;
     using No = std::false_type;
     // whole-K A fragments of this wave's 32 rows of (pair b, band) -> registers.  asm like the DMA: the wait is placed by hand so
-    // that the previous band's last 32 stores can be issued BEHIND these loads and drain while the first sub-tile is multiplied.
+    // that the previous band's last 32 stores can be issued BEHIND these loads and drain while the first sub-tile is multiplied
+    // (a compiler-tracked load would be waited for with vmcnt(0), i.e. together with those stores: vmcnt retires in order).
+    // Caveat: to hipcc an asm load's destination is defined at the end of the statement; under register pressure it may copy or
+    // spill such a value before the hand-placed wait (this happened in the fp32 streaming kernel, which therefore uses tracked
+    // buffer loads).  Here the values stay put (no scratch, the "+v" re-definition below sits behind the wait), and
+    // test_corr_volume_16bit_streaming_form_is_bitwise_the_tile_form runs multi-band workgroups, so a build where they do not
+    // fails deterministically.
     i32x4 afr[KS];
     auto issue_a = [&](int b, int band) __attribute__((always_inline)) {
         const int gr = min(band * 128 + wave * 32 + li, N1 - 1);
