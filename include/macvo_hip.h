@@ -396,6 +396,22 @@ int mv_kp_select_lanes(const float* flow_cov, const float* depth0, const float* 
                        const mvKpSelectParams* params /* host */, void* workspace, size_t workspace_bytes,
                        int32_t* out_cand /* [lanes, H*W] */, int32_t* out_count /* [lanes, 4] */,
                        float* out_stats /* [lanes, 4] */, int lanes, mvStream_t stream);
+/* The pose-dependent remainder of a frame's backend (Odometry/MACVO.py:273-281), split off so that gather / track / back-projection /
+ * covariances / filters can run before the previous frame's solve has finished: pos_Tw = T * pos_Tc (fp32 SE3 Act),
+ * rot [lanes, 9] = R as fp64, cov_rot = R cov R^T (fp64).  Bit-identical to what mv_backproject(pose) and mv_match_cov(rot,
+ * out_cov_rot) produce.  pose [lanes, 7] device; tables [lanes, cap, .]; pos_* / cov* pairs may be null together. */
+int mv_pose_apply_lanes(const float* pose, const float* pos_Tc, const double* cov, int lanes, const int32_t* n_live /* host */,
+                        int cap, float* pos_Tw, double* rot, double* cov_rot, mvStream_t stream);
+/* mv_frontend_epilogue_lanes + mv_kp_select_lanes (MV_KP_NODEPTH) in one launch less: the selector's first kernel computes the
+ * quality sigma_uu + sigma_vv from the network's covariance planes itself and writes the epilogue's maps for its own pixels.
+ * Same results as the two calls in sequence, bit for bit (Frontend.py:183-200 + KeypointSelector.py:362-407).  Other
+ * selector modes read the previous frame's maps too: MV_ERR_UNSUPPORTED. */
+int mv_frontend_epilogue_select_lanes(const float* flow, const float* logcov, int cov_is_log, float bl_fx, float bl_fx_sq,
+                                      float* disparity, float* disparity_cov, float* depth, float* depth_cov,
+                                      uint8_t* bad_mask, float* match_flow, float* match_cov, const uint8_t* mask_a,
+                                      const uint8_t* mask_b, const mvKpSelectParams* params /* host */, void* workspace,
+                                      size_t workspace_bytes, int32_t* out_cand, int32_t* out_count, float* out_stats,
+                                      int lanes, mvStream_t stream);
 int mv_kp_gather_lanes(const int32_t* cand, size_t cand_lane_stride, const int64_t* perm /* [lanes, cap] */, int lanes,
                        const int32_t* n_live /* host */, int cap, int W, int64_t* out_uv /* [lanes, cap, 2] */,
                        mvStream_t stream);
@@ -513,6 +529,10 @@ int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, const int32_t
 int mv_frame_pipe_map_append(mvFramePipe* p, const mvMapStores* stores /* host */, int frame_idx, int prev_frame,
                              const float* K_dev, const float* T_BS_dev, float baseline, int64_t time_ns,
                              const uint8_t* color_dev /* [n_sel,3] or NULL */);
+/* Result views and slot reuse: a consumer that reads result views (mv_frame_pipe_buffer) asynchronously on its own stream
+ * calls this before it finishes the next frame; the pipe then orders the kernels that recycle those buffers behind
+ * everything enqueued on `stream` so far.  (Host-synchronous consumers do not need it.) */
+int mv_frame_pipe_release(mvFramePipe* p, mvStream_t stream);
 /* block_host = 1: wait for all four streams on the host; 0: make `stream` wait for everything enqueued so far (including the
  * frontends of frames enqueued ahead); 2: make `stream` wait for the newest FINISHED frame's backend + solve only — what a
  * consumer of that frame's results needs while later frames are already queued */

@@ -17,7 +17,7 @@ MV_F32, MV_F16, MV_BF16, MV_BF16X3, MV_BF16X2 = 0, 1, 2, 3, 4
 MV_LAYOUT_CHW, MV_LAYOUT_HWC = 0, 1
 MV_KP_NODEPTH, MV_KP_FULL, MV_KP_MAPPING = 0, 1, 2
 MV_GRAPH_ICP, MV_GRAPH_REPROJ, MV_GRAPH_DISP = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 MV_MAX_LANES = 64        # include/macvo_hip.h
 
 
@@ -118,6 +118,9 @@ SIGNATURES = {
     # lane-batched variants (lanes independent frames per launch)
     "mv_frontend_epilogue_lanes": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                              _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "mv_pose_apply_lanes": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P]),
+    "mv_frontend_epilogue_select_lanes": (C.c_int, [_P, _P, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                                    C.POINTER(mvKpSelectParams), _P, C.c_size_t, _P, _P, _P, C.c_int, _P]),
     "mv_kp_select_lanes": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(mvKpSelectParams), _P, C.c_size_t,
                                      _P, _P, _P, C.c_int, _P]),
     "mv_kp_gather_lanes": (C.c_int, [_P, C.c_size_t, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P]),
@@ -137,6 +140,7 @@ SIGNATURES = {
     "mv_frame_pipe_wait_candidates": (C.c_int, [_P, _P]),
     "mv_frame_pipe_finish": (C.c_int, [_P, _P, _P, _P]),
     "mv_frame_pipe_map_append": (C.c_int, [_P, C.POINTER(mvMapStores), C.c_int, C.c_int, _P, _P, C.c_float, C.c_int64, _P]),
+    "mv_frame_pipe_release": (C.c_int, [_P, _P]),
     "mv_frame_pipe_sync": (C.c_int, [_P, _P, C.c_int]),
     "mv_frame_pipe_time_volume": (C.c_int, [_P, C.c_int]),
     "mv_frame_pipe_volume_times": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),

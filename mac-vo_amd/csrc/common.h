@@ -21,6 +21,46 @@
 #define MV_VOL_STORE_ASM_MOD ""
 #endif
 
+// Per-pixel frontend epilogue (Frontend.py:183-200, StereoDepth.py:270-282, flownet.py:44), shared by frontend_epilogue_kernel and
+// the selector's fused form so that both produce the same bits.  Pointers are already offset to the lane; any output may be null.
+struct mvEpiArgs {
+    const float* flow;      // [2, 2, H, W]
+    const float* logcov;    // [2, 2, H, W]
+    int cov_is_log;
+    float bl_fx, bl_fx_sq;
+    float *disparity, *disparity_cov, *depth, *depth_cov, *match_flow, *match_cov;
+    uint8_t* bad_mask;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ void mv_epilogue_pixel(const mvEpiArgs& a, int plane, int i) {
+    // sample 0 (stereo pair): flow[0,0] -> disparity, cov[0,0] -> disparity variance
+    const float fx0 = a.flow[i];
+    const float lc0 = a.logcov[i];
+    const float dcov = a.cov_is_log ? expf(lc0 * 2.f) : lc0;
+    const float d = fabsf(fx0);
+    if (a.disparity) a.disparity[i] = d;
+    if (a.disparity_cov) a.disparity_cov[i] = dcov;
+    if (a.depth) a.depth[i] = a.bl_fx * (1.f / d);
+    if (a.depth_cov) {
+        const float d2 = d * d;
+        const float err2 = dcov * (1.f / d2);
+        a.depth_cov[i] = a.bl_fx_sq * (err2 / d2);
+    }
+    if (a.bad_mask) a.bad_mask[i] = fx0 <= 0.f;
+    // sample 1 (temporal pair): flow[1] and cov[1] padded with sigma_uv = 0
+    if (a.match_flow) {
+        a.match_flow[i] = a.flow[2 * plane + i];
+        a.match_flow[plane + i] = a.flow[3 * plane + i];
+    }
+    if (a.match_cov) {
+        const float l0 = a.logcov[2 * plane + i], l1 = a.logcov[3 * plane + i];
+        a.match_cov[i] = a.cov_is_log ? expf(l0 * 2.f) : l0;
+        a.match_cov[plane + i] = a.cov_is_log ? expf(l1 * 2.f) : l1;
+        a.match_cov[2 * plane + i] = 0.f;
+    }
+}
+#endif
+
 struct mvLaneCounts {
     int32_t n[MV_MAX_LANES];
 };

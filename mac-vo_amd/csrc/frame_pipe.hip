@@ -107,7 +107,11 @@ struct mvFramePipe {
     hipStream_t s_vol, s_main, s_back, s_side;
     hipEvent_t e_rest[N_INEV];   // inputs of the decoder side (coords, flow, ...) when the GEMM was issued ahead of them
     hipEvent_t e_in[N_INEV], e_vol_done[MAX_VOL], e_vol_free[MAX_VOL], e_cand[N_CAND], e_backend[2], e_pgo, e_perm[N_PERM];
-    bool vol_free_valid[MAX_VOL], backend_valid[2], pgo_valid, perm_valid[N_PERM];
+    hipEvent_t e_release;     // the consumer's reads of result views enqueued so far (mv_frame_pipe_release)
+    bool release_valid;
+    hipEvent_t e_posed[2];    // backend slot k: world-frame tables written (side stream, in front of the solve)
+    hipEvent_t e_solved[2];   // backend slot k: its solve has finished reading the tables
+    bool vol_free_valid[MAX_VOL], backend_valid[2], pgo_valid, perm_valid[N_PERM], solved_valid[2];
     // state
     long n_enq, n_fin;
     long n_vol;            // volume GEMMs issued (n_enq <= n_vol <= n_enq + 1: at most one GEMM ahead of its frame's decoder side)
@@ -235,9 +239,10 @@ extern "C" void mv_frame_pipe_destroy(mvFramePipe* p) {
     for (auto e : p->e_rest) ev(e);
     for (int k = 0; k < MAX_VOL; ++k) { ev(p->e_vol_done[k]); ev(p->e_vol_free[k]); }
     for (int k = 0; k < N_CAND; ++k) ev(p->e_cand[k]);
-    for (int k = 0; k < 2; ++k) ev(p->e_backend[k]);
+    for (int k = 0; k < 2; ++k) { ev(p->e_backend[k]); ev(p->e_posed[k]); ev(p->e_solved[k]); }
     ev(p->e_pgo);
     ev(p->e_map);
+    ev(p->e_release);
     for (auto e : p->e_perm) ev(e);
     for (auto e : p->tv0) ev(e);
     for (auto e : p->tv1) ev(e);
@@ -322,9 +327,14 @@ static int create_impl(mvFramePipe* p) {
         MV_HIP(mk(&p->e_cand[k]));
         MV_HIP(hipHostMalloc((void**)&p->h_count[k], (size_t)p->lanes * 4 * sizeof(int32_t), hipHostMallocDefault));
     }
-    for (int k = 0; k < 2; ++k) MV_HIP(mk(&p->e_backend[k]));
+    for (int k = 0; k < 2; ++k) {
+        MV_HIP(mk(&p->e_backend[k]));
+        MV_HIP(mk(&p->e_posed[k]));
+        MV_HIP(mk(&p->e_solved[k]));
+    }
     MV_HIP(mk(&p->e_pgo));
     MV_HIP(mk(&p->e_map));
+    MV_HIP(mk(&p->e_release));
     const size_t N = c.num_point > 0 ? c.num_point : 1;
     for (int k = 0; k < N_PERM; ++k) {
         MV_HIP(mk(&p->e_perm[k]));
@@ -479,14 +489,17 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
     // maps slot m and candidate slot k were last read by the backend of frame f - 2 (f - 3 for the maps) on `back`
     // (the newest backend event covers the older one: same stream)
     if (p->n_fin > 0 && p->backend_valid[(p->n_fin - 1) & 1]) MV_TRY(wait_if_pending(s, p->e_backend[(p->n_fin - 1) & 1]));
+    if (p->release_valid) MV_TRY(wait_if_pending(s, p->e_release));   // ... and by consumers of result views (mv_frame_pipe_release)
     Maps& mp = p->maps[m];
+    static int fuse_epi = -1;   // MV_PIPE_FUSE_EPI=0: epilogue and selector as separate launches (A/B knob)
+    if (fuse_epi < 0) { const char* e = getenv("MV_PIPE_FUSE_EPI"); fuse_epi = (e && atoi(e) == 0) ? 0 : 1; }
     if (up) {
         MV_TRY(mv_convex_upsample(in->flow8, in->up_mask, p->up_flow, B, p->h8, p->w8, 0.25f, 0, s));
         MV_TRY(mv_convex_upsample(in->cov8, in->cov_mask, p->up_cov, B, p->h8, p->w8, 1.0f, 1, s));
         MV_TRY(mv_frontend_epilogue_lanes(p->up_flow, p->up_cov, 0, c.H, c.W, c.bl_fx, c.bl_fx_sq, mp.disparity,
                                           mp.disparity_cov, mp.depth, mp.depth_cov, nullptr, mp.match_flow, mp.match_cov,
                                           p->lanes, s));
-    } else {
+    } else if (!(fuse_epi && with_selector && c.selector_mode == MV_KP_NODEPTH)) {
         MV_TRY(mv_frontend_epilogue_lanes(in->flow, in->logcov, 1, c.H, c.W, c.bl_fx, c.bl_fx_sq, mp.disparity,
                                           mp.disparity_cov, mp.depth, mp.depth_cov, nullptr, mp.match_flow, mp.match_cov,
                                           p->lanes, s));
@@ -495,7 +508,14 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
     if (with_selector) {
         mvKpSelectParams sp{c.H, c.W, c.selector_mode, c.kp_kernel_size, c.kp_mask_width, c.max_depth, c.max_depth_cov,
                             c.max_match_cov};
-        if (c.selector_mode == MV_KP_NODEPTH) {
+        if (c.selector_mode == MV_KP_NODEPTH && fuse_epi && !up) {
+            // epilogue + selector's first kernel in one launch (one launch and one pass over the maps less on the chain that
+            // bounds a single-sequence stream)
+            MV_TRY(mv_frontend_epilogue_select_lanes(in->flow, in->logcov, 1, c.bl_fx, c.bl_fx_sq, mp.disparity, mp.disparity_cov,
+                                                     mp.depth, mp.depth_cov, nullptr, mp.match_flow, mp.match_cov, nullptr,
+                                                     nullptr, &sp, p->kp_ws, p->kp_ws_bytes, p->cand[k], p->count[k],
+                                                     p->stats[k], p->lanes, s));
+        } else if (c.selector_mode == MV_KP_NODEPTH) {
             MV_TRY(mv_kp_select_lanes(mp.match_cov, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &sp, p->kp_ws,
                                       p->kp_ws_bytes, p->cand[k], p->count[k], p->stats[k], p->lanes, s));
         } else {
@@ -553,6 +573,11 @@ extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, co
     }
     const Maps &m0 = p->maps[pd.maps_prev], &m1 = p->maps[pd.maps];
 
+    // Slot reuse.  This backend slot's tables were last read by the solve of frame g - 2 (side stream) and by whoever looked at
+    // that frame's result views: the former has its event, the latter the event of mv_frame_pipe_release (a consumer that
+    // reads views asynchronously on its own stream calls it before it asks for the next frame).
+    if (p->solved_valid[k]) MV_TRY(wait_if_pending(s, p->e_solved[k]));
+    if (p->release_valid) MV_TRY(wait_if_pending(s, p->e_release));
     // permutations [lanes, cap] -> pinned slot -> device (ONE copy; rows beyond a lane's n_sel are never read)
     const int ps = (int)(g % N_PERM);
     if (p->perm_valid[ps]) MV_HIP(hipEventSynchronize(p->e_perm[ps]));   // long done; keeps the slot reuse provably safe
@@ -564,27 +589,36 @@ extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, co
     MV_HIP(hipEventRecord(p->e_perm[ps], s));
     p->perm_valid[ps] = true;
     MV_TRY(mv_kp_gather_lanes(p->cand[pd.cand], (size_t)p->plane, b.perm, L, b.n_sel, cap, c.W, b.kp0, s));
-    // the previous pose is produced by the previous solve; this also orders us after the solve of frame g - 2, the last
-    // reader of this backend slot
-    if (p->pgo_valid) MV_TRY(wait_if_pending(s, p->e_pgo));
-    const float* pose = p->pose[p->pose_cur];
+    // Pose-INDEPENDENT part first: it overlaps the previous frames' solves.  The chain solve(t-1) -> backend(t) -> solve(t) is the
+    // sequential dependency of visual odometry and, beside a GEMM that never pauses, it was the period of a single-sequence
+    // stream (track 19 + back-projection 9 + covariances 48 + filters 21 + solve 108 us + launch gaps and two stream hops =
+    // ~290 us).  Only the rotation into the world frame needs the previous pose (MACVO.py:273-281): it runs as one tiny kernel on
+    // the SOLVE's stream right behind the previous solve, so the critical chain is solve -> mv_pose_apply_lanes -> solve on one
+    // in-order stream.
+    static int pose_split = -1;   // MV_PIPE_POSE_SPLIT=0: the whole backend behind the previous solve, as before (A/B knob)
+    if (pose_split < 0) { const char* e = getenv("MV_PIPE_POSE_SPLIT"); pose_split = (e && atoi(e) == 0) ? 0 : 1; }
+    if (!pose_split && p->pgo_valid) MV_TRY(wait_if_pending(s, p->e_pgo));
     MV_TRY(mv_kp_track_lanes(b.kp0, L, b.n_sel, cap, m1.match_flow, m1.match_cov, m0.depth, m0.disparity, m0.disparity_cov,
                              m0.depth_cov, m1.depth, m1.disparity, m1.disparity_cov, m1.depth_cov, c.H, c.W, c.edgewidth,
                              c.match_cov_default, b.kp0f, b.kp1, b.inbound, b.vals, b.sigma0, b.sigma1, s));
-    MV_TRY(mv_backproject_lanes(b.kp0f, b.vals, 1, (size_t)cap, c.fx, c.fy, c.cx, c.cy, pose, L, b.n_sel, cap, b.pos_Tc,
-                                b.pos_Tw, b.rot, s));
+    MV_TRY(mv_backproject_lanes(b.kp0f, b.vals, 1, (size_t)cap, c.fx, c.fy, c.cx, c.cy, nullptr, L, b.n_sel, cap, b.pos_Tc,
+                                nullptr, nullptr, s));
     mvMatchCovParams cp{c.H, c.W, c.cov_kernel_size, 1, c.fx, c.fy, c.cx, c.cy, c.min_flow_cov_sq, c.min_depth_cov};
-    MV_TRY(mv_match_cov_pair_lanes(m0.depth, b.kp0f, b.sigma0, b.rot, b.cov0, b.cov0w, m1.depth, b.kp1, b.sigma1, b.cov1, &cp,
+    MV_TRY(mv_match_cov_pair_lanes(m0.depth, b.kp0f, b.sigma0, nullptr, b.cov0, nullptr, m1.depth, b.kp1, b.sigma1, b.cov1, &cp,
                                    L, b.n_sel, cap, s));
     MV_TRY(mv_obs_filter_lanes(b.inbound, b.cov0, b.cov1, b.vals, c.filters, c.filter_min_depth, c.max_depth, L, b.n_sel, cap,
                                b.valid, b.n_valid, s));
     MV_HIP(hipEventRecord(p->e_backend[k], s));
     p->backend_valid[k] = true;
 
-    // ---- LM solves of all lanes in ONE launch on the side stream (problem l = rows [l * cap, (l + 1) * cap), dead rows
-    // masked by `valid`); the optimised poses become the next frame's priors (StaticMotionModel)
+    // ---- side stream: world-frame tables from the previous solve's pose (same stream: no event), then the LM solves of all
+    // lanes in ONE launch (problem l = rows [l * cap, (l + 1) * cap), dead rows masked by `valid`); the optimised poses become
+    // the next frame's priors (StaticMotionModel)
     hipStream_t ss = p->s_side;
     MV_HIP(hipStreamWaitEvent(ss, p->e_backend[k], 0));
+    const float* pose = p->pose[p->pose_cur];
+    MV_TRY(mv_pose_apply_lanes(pose, b.pos_Tc, b.cov0, L, b.n_sel, cap, b.pos_Tw, b.rot, b.cov0w, ss));
+    MV_HIP(hipEventRecord(p->e_posed[k], ss));
     const int nxt = (p->pose_cur + 1) % 3;
     const size_t N = (size_t)cap;
     const size_t LN = (size_t)L * N;   // value table is [11, lanes, cap]: each of its rows is one concatenated per-point column
@@ -594,7 +628,9 @@ extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, co
     if (pose_sink)
         MV_HIP(hipMemcpyAsync(pose_sink, p->pose[nxt], (size_t)L * 7 * sizeof(float), hipMemcpyDeviceToDevice, ss));
     MV_HIP(hipEventRecord(p->e_pgo, ss));
+    MV_HIP(hipEventRecord(p->e_solved[k], ss));
     p->pgo_valid = true;
+    p->solved_valid[k] = true;
     p->pose_cur = nxt;
     return MV_OK;
 }
@@ -624,6 +660,7 @@ extern "C" int mv_frame_pipe_map_append(mvFramePipe* p, const mvMapStores* store
     f.baseline = baseline;
     f.time_ns = time_ns;
     f.out_frame_idx = nullptr;
+    MV_HIP(hipStreamWaitEvent(p->s_back, p->e_posed[g & 1], 0));   // pos_Tw / cov0_world come from the side stream
     MV_TRY(mv_map_append(&f, stores, p->s_back));
     MV_HIP(hipEventRecord(p->e_map, p->s_back));
     // the backend tables must outlive the append: later backends run on the same stream (ordered); the optimised pose goes
@@ -633,6 +670,13 @@ extern "C" int mv_frame_pipe_map_append(mvFramePipe* p, const mvMapStores* store
                           p->s_side));
     MV_HIP(hipEventRecord(p->e_pgo, p->s_side));
     p->pgo_valid = true;
+    return MV_OK;
+}
+
+extern "C" int mv_frame_pipe_release(mvFramePipe* p, mvStream_t stream) {
+    MV_CHECK_ARG(p);
+    MV_HIP(hipEventRecord(p->e_release, (hipStream_t)stream));
+    p->release_valid = true;
     return MV_OK;
 }
 

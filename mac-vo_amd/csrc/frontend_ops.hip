@@ -28,33 +28,9 @@ __global__ __launch_bounds__(256) void frontend_epilogue_kernel(
     if (bad_mask) bad_mask += lo;
     if (match_flow) match_flow += 2 * lo;
     if (match_cov) match_cov += 3 * lo;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
-        // sample 0 (stereo pair): flow[0,0] -> disparity, cov[0,0] -> disparity variance
-        const float fx0 = flow[i];
-        const float lc0 = logcov[i];
-        const float dcov = cov_is_log ? expf(lc0 * 2.f) : lc0;
-        const float d = fabsf(fx0);
-        if (disparity) disparity[i] = d;
-        if (disparity_cov) disparity_cov[i] = dcov;
-        if (depth) depth[i] = bl_fx * (1.f / d);
-        if (depth_cov) {
-            const float d2 = d * d;
-            const float err2 = dcov * (1.f / d2);
-            depth_cov[i] = bl_fx_sq * (err2 / d2);
-        }
-        if (bad_mask) bad_mask[i] = fx0 <= 0.f;
-        // sample 1 (temporal pair): flow[1] and cov[1] padded with sigma_uv = 0
-        if (match_flow) {
-            match_flow[i] = flow[2 * plane + i];
-            match_flow[plane + i] = flow[3 * plane + i];
-        }
-        if (match_cov) {
-            const float l0 = logcov[2 * plane + i], l1 = logcov[3 * plane + i];
-            match_cov[i] = cov_is_log ? expf(l0 * 2.f) : l0;
-            match_cov[plane + i] = cov_is_log ? expf(l1 * 2.f) : l1;
-            match_cov[2 * plane + i] = 0.f;
-        }
-    }
+    const mvEpiArgs ea{flow, logcov, cov_is_log, bl_fx, bl_fx_sq, disparity, disparity_cov, depth, depth_cov, match_flow, match_cov,
+                       bad_mask};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) mv_epilogue_pixel(ea, plane, i);
 }
 
 // Lane-batched: blockIdx.y = lane; every per-keypoint table is [lanes, ..., cap] with `cap` rows of capacity per lane of
@@ -185,6 +161,64 @@ __global__ __launch_bounds__(256) void backproject_kernel(const float* __restric
         float r[3];
         quat_act_f32(q, p, r);  // SE3 Act = SO3 Act + t
         pos_Tw[3 * n] = r[0] + t[0]; pos_Tw[3 * n + 1] = r[1] + t[1]; pos_Tw[3 * n + 2] = r[2] + t[2];
+    }
+}
+
+// The pose-dependent remainder of the backend, split off so that everything else of a frame's backend can run BEFORE the
+// previous frame's solve has finished (Odometry/MACVO.py:273-281): pos_Tw = T_prev * p_cam (fp32, PyPose SE3 Act),
+// rot = R_prev (fp32 -> fp64, as backproject_kernel writes it) and cov_Tw = R cov_Tc R^T (fp64, the grouping of match_cov_kernel).
+// Bit-identical to mv_backproject(..., pose, ...) + mv_match_cov(..., rot, ..., out_cov_rot) on the same inputs.
+__global__ __launch_bounds__(256) void pose_apply_kernel(const float* __restrict__ pose, const float* __restrict__ pos_Tc,
+                                                         const double* __restrict__ cov, int cap, mvLaneCounts cnt,
+                                                         float* __restrict__ pos_Tw, double* __restrict__ rot,
+                                                         double* __restrict__ cov_rot) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = blockIdx.y;
+    const int N = cnt.n[lane];
+    {
+        const size_t ln = (size_t)lane * cap;
+        pose += 7 * lane;
+        if (pos_Tc) pos_Tc += 3 * ln;
+        if (pos_Tw) pos_Tw += 3 * ln;
+        if (cov) cov += 9 * ln;
+        if (cov_rot) cov_rot += 9 * ln;
+        if (rot) rot += 9 * lane;
+    }
+    const float t[3] = {pose[0], pose[1], pose[2]}, q[4] = {pose[3], pose[4], pose[5], pose[6]};
+    double R[9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float e[3] = {c == 0 ? 1.f : 0.f, c == 1 ? 1.f : 0.f, c == 2 ? 1.f : 0.f};
+        float col[3];
+        quat_act_f32(q, e, col);
+        R[0 * 3 + c] = (double)col[0];
+        R[1 * 3 + c] = (double)col[1];
+        R[2 * 3 + c] = (double)col[2];
+    }
+    if (n == 0 && rot) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) rot[i] = R[i];
+    }
+    if (n >= N) return;
+    if (pos_Tw && pos_Tc) {
+        const float p[3] = {pos_Tc[3 * n], pos_Tc[3 * n + 1], pos_Tc[3 * n + 2]};
+        float r[3];
+        quat_act_f32(q, p, r);
+        pos_Tw[3 * n] = r[0] + t[0]; pos_Tw[3 * n + 1] = r[1] + t[1]; pos_Tw[3 * n + 2] = r[2] + t[2];
+    }
+    if (cov_rot && cov) {
+        double c[9], tm[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) c[i] = cov[(size_t)n * 9 + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) tm[3 * i + j] = (R[3 * i] * c[j] + R[3 * i + 1] * c[3 + j]) + R[3 * i + 2] * c[6 + j];
+        double* o = cov_rot + (size_t)n * 9;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) o[3 * i + j] = (tm[3 * i] * R[3 * j] + tm[3 * i + 1] * R[3 * j + 1]) + tm[3 * i + 2] * R[3 * j + 2];
     }
 }
 
@@ -363,6 +397,20 @@ extern "C" int mv_backproject_lanes(const float* kp_uv, const float* depth_vals,
     hipLaunchKernelGGL(backproject_kernel, dim3(n_max > 0 ? mv_ceil_div(n_max, 256) : 1, lanes), dim3(256), 0,
                        (hipStream_t)stream, kp_uv, depth_vals, depth_stride, fx, fy, cx, cy, pose, cap, c,
                        depth_lane_stride, pos_Tc, pos_Tw, rot);
+    return mv_launch_status();
+}
+
+extern "C" int mv_pose_apply_lanes(const float* pose, const float* pos_Tc, const double* cov, int lanes, const int32_t* n_live,
+                                   int cap, float* pos_Tw, double* rot, double* cov_rot, mvStream_t stream) {
+    MV_CHECK_ARG(pose);
+    MV_CHECK_ARG((pos_Tw == nullptr) == (pos_Tc == nullptr) && (cov_rot == nullptr) == (cov == nullptr));
+    mvLaneCounts c{};
+    int n_max = 0;
+    const int rc = check_lanes(lanes, n_live, cap, c, n_max);
+    if (rc != MV_OK) return rc;
+    if (n_max == 0 && !rot) return MV_OK;
+    hipLaunchKernelGGL(pose_apply_kernel, dim3(n_max > 0 ? mv_ceil_div(n_max, 256) : 1, lanes), dim3(256), 0, (hipStream_t)stream,
+                       pose, pos_Tc, cov, cap, c, pos_Tw, rot, cov_rot);
     return mv_launch_status();
 }
 

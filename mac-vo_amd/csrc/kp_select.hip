@@ -68,12 +68,16 @@ __device__ __forceinline__ float flow_quality(const float* __restrict__ fc, int 
 // min that propagates NaN from either side (max_pool2d keeps a NaN once seen)
 __device__ __forceinline__ float nanmin(float a, float b) { return (a < b || a != a) ? a : b; }
 
+// FUSE (MV_KP_NODEPTH only): the frontend epilogue rides along — the quality q = sigma_uu + sigma_vv of the tile and its halo is
+// computed from the network's log-sigma planes (the same expf as the epilogue's, so the same bits as reading match_cov back),
+// and every thread writes the epilogue outputs of its own four pixels: one launch and one pass over the maps less per frame.
+template <bool FUSE>
 __global__ __launch_bounds__(256) void kp_nms_kernel(const float* __restrict__ fc, const float* __restrict__ d0,
                                                       const float* __restrict__ d0c, const float* __restrict__ d1,
                                                       const float* __restrict__ d1c,
                                                       const uint8_t* __restrict__ mask_a,
                                                       const uint8_t* __restrict__ mask_b, mvKpSelectParams p,
-                                                      KpWs ws_all, int words_per_row) {
+                                                      KpWs ws_all, int words_per_row, mvEpiArgs ef) {
     MV_CHAIN_KERNEL_PRIO();
     // lane-batched: blockIdx.z = lane (independent frame); maps are [lanes, ch, H, W], one workspace copy per lane
     const KpWs ws = ws_all.lane(blockIdx.z);
@@ -86,6 +90,16 @@ __global__ __launch_bounds__(256) void kp_nms_kernel(const float* __restrict__ f
         if (d1c) d1c += lp;
         if (mask_a) mask_a += lp;
         if (mask_b) mask_b += lp;
+        if (FUSE) {   // inputs [lanes, 2, 2, H, W], outputs [lanes, ch, H, W]
+            ef.flow += 4 * lp; ef.logcov += 4 * lp;
+            if (ef.disparity) ef.disparity += lp;
+            if (ef.disparity_cov) ef.disparity_cov += lp;
+            if (ef.depth) ef.depth += lp;
+            if (ef.depth_cov) ef.depth_cov += lp;
+            if (ef.bad_mask) ef.bad_mask += lp;
+            if (ef.match_flow) ef.match_flow += 2 * lp;
+            if (ef.match_cov) ef.match_cov += 3 * lp;
+        }
     }
     __shared__ float tile[TILE_H + 2 * MAX_R][TILE_W + 2 * MAX_R + 1];
     __shared__ float hmin[TILE_H + 2 * MAX_R][TILE_W + 1];
@@ -111,7 +125,12 @@ __global__ __launch_bounds__(256) void kp_nms_kernel(const float* __restrict__ f
             float q = INFINITY;  // out-of-image == -inf padding of max_pool2d(-q): never the minimum
             if (e < tw * th && gx >= 0 && gx < W && gy >= 0 && gy < H) {
                 const int idx = gy * W + gx;
-                if (p.mode == MV_KP_NODEPTH) {
+                if (FUSE) {
+                    // flow_quality of (c0, c1, 0): (c0 + c1) - 2 * 0 = c0 + c1 exactly
+                    const float l0 = ef.logcov[2 * plane + idx], l1 = ef.logcov[3 * plane + idx];
+                    const float c0 = ef.cov_is_log ? expf(l0 * 2.f) : l0, c1 = ef.cov_is_log ? expf(l1 * 2.f) : l1;
+                    q = (c0 + c1) - 2.f * 0.f;
+                } else if (p.mode == MV_KP_NODEPTH) {
                     q = flow_quality(fc, plane, idx);
                 } else {
                     q = d0c[idx] + d1c[idx];
@@ -149,6 +168,7 @@ __global__ __launch_bounds__(256) void kp_nms_kernel(const float* __restrict__ f
         const int idx = gy * W + gx;
         bool nms = false, cand = false;
         float q = 0.f;
+        if (FUSE && inimg) mv_epilogue_pixel(ef, plane, idx);
         if (inimg) {
             const bool border = p.mask_width > 0 && gx >= p.mask_width && gx < W - p.mask_width &&
                                 gy >= p.mask_width && gy < H - p.mask_width;
@@ -644,11 +664,10 @@ extern "C" size_t mv_kp_select_workspace_bytes(int H, int W) {
     return align_up(words * 8, 256) + 3 * align_up((size_t)H * W * 4, 256) + 256;
 }
 
-extern "C" int mv_kp_select_lanes(const float* flow_cov, const float* depth0, const float* depth0_cov,
-                                  const float* depth1, const float* depth1_cov, const uint8_t* mask_a,
-                                  const uint8_t* mask_b, const mvKpSelectParams* params, void* workspace,
-                                  size_t workspace_bytes, int32_t* out_cand, int32_t* out_count, float* out_stats,
-                                  int lanes, mvStream_t stream) {
+static int kp_select_impl(const float* flow_cov, const float* depth0, const float* depth0_cov, const float* depth1,
+                          const float* depth1_cov, const uint8_t* mask_a, const uint8_t* mask_b, const mvKpSelectParams* params,
+                          void* workspace, size_t workspace_bytes, int32_t* out_cand, int32_t* out_count, float* out_stats,
+                          int lanes, mvStream_t stream, const mvEpiArgs* fuse) {
     MV_CHECK_ARG(lanes >= 1 && lanes <= MV_MAX_LANES);
     MV_CHECK_ARG(params && workspace && out_cand && out_count && out_stats);
     const mvKpSelectParams p = *params;
@@ -691,8 +710,12 @@ extern "C" int mv_kp_select_lanes(const float* flow_cov, const float* depth0, co
     // ws.counters must be zero on entry: the caller zero-fills the workspace once after allocating it, and every
     // call leaves it zeroed again (kp_finish_kernel) — this saves a 5-us fill launch per frame.
     dim3 grid(wpr, mv_ceil_div(p.H, TILE_H), lanes), block(64, 4);
-    hipLaunchKernelGGL(kp_nms_kernel, grid, block, 0, s, flow_cov, depth0, depth0_cov, depth1, depth1_cov, mask_a,
-                       mask_b, p, ws, wpr);
+    if (fuse)
+        hipLaunchKernelGGL(kp_nms_kernel<true>, grid, block, 0, s, flow_cov, depth0, depth0_cov, depth1, depth1_cov, mask_a,
+                           mask_b, p, ws, wpr, *fuse);
+    else
+        hipLaunchKernelGGL(kp_nms_kernel<false>, grid, block, 0, s, flow_cov, depth0, depth0_cov, depth1, depth1_cov, mask_a,
+                           mask_b, p, ws, wpr, mvEpiArgs{});
     if (p.mode == MV_KP_MAPPING) {
         const int n_words = p.H * wpr;
         int* word_off = (int*)ws.rec_idx;   // record arrays are unused in this mode
@@ -715,6 +738,30 @@ extern "C" int mv_kp_select_lanes(const float* flow_cov, const float* depth0, co
                    : launch_finish<1024, 16, 5, false>(p, ws, flow_cov ? 1 : 0, wpr, out_cand, out_count, out_stats, lanes, s);
     if (rc != MV_OK) return rc;
     return mv_launch_status();
+}
+
+extern "C" int mv_kp_select_lanes(const float* flow_cov, const float* depth0, const float* depth0_cov,
+                                  const float* depth1, const float* depth1_cov, const uint8_t* mask_a,
+                                  const uint8_t* mask_b, const mvKpSelectParams* params, void* workspace,
+                                  size_t workspace_bytes, int32_t* out_cand, int32_t* out_count, float* out_stats,
+                                  int lanes, mvStream_t stream) {
+    return kp_select_impl(flow_cov, depth0, depth0_cov, depth1, depth1_cov, mask_a, mask_b, params, workspace, workspace_bytes,
+                          out_cand, out_count, out_stats, lanes, stream, nullptr);
+}
+
+extern "C" int mv_frontend_epilogue_select_lanes(const float* flow, const float* logcov, int cov_is_log, float bl_fx,
+                                                 float bl_fx_sq, float* disparity, float* disparity_cov, float* depth,
+                                                 float* depth_cov, uint8_t* bad_mask, float* match_flow, float* match_cov,
+                                                 const uint8_t* mask_a, const uint8_t* mask_b, const mvKpSelectParams* params,
+                                                 void* workspace, size_t workspace_bytes, int32_t* out_cand,
+                                                 int32_t* out_count, float* out_stats, int lanes, mvStream_t stream) {
+    MV_CHECK_ARG(flow && logcov && params && match_cov);
+    if (params->mode != MV_KP_NODEPTH) return MV_ERR_UNSUPPORTED;   // the other selectors read the PREVIOUS frame's maps as well
+    const mvEpiArgs ef{flow, logcov, cov_is_log, bl_fx, bl_fx_sq, disparity, disparity_cov, depth, depth_cov, match_flow, match_cov,
+                       bad_mask};
+    // (flow_cov only has to be non-null for the argument check: the fused kernel never reads it)
+    return kp_select_impl(match_cov, nullptr, nullptr, nullptr, nullptr, mask_a, mask_b, params, workspace, workspace_bytes,
+                          out_cand, out_count, out_stats, lanes, stream, &ef);
 }
 
 extern "C" int mv_kp_select(const float* flow_cov, const float* depth0, const float* depth0_cov,

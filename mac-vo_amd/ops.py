@@ -273,6 +273,62 @@ def kp_select(mode: str, H: int, W: int, flow_cov: torch.Tensor | None = None, d
     return KeypointCandidates(cand, count, stats, W)
 
 
+def pose_apply(pose: torch.Tensor, pos_Tc: torch.Tensor, cov_Tc: torch.Tensor):
+    """World-frame tables from camera-frame ones and a pose (``mv_pose_apply_lanes``, MACVO.py:273-281): returns
+    ``(pos_Tw [N,3] f32, rot [9] f64, cov_Tw [N,3,3] f64)`` — what ``backproject(pose=...)`` / ``match_cov(rot=...)`` produce."""
+    lib = L.load()
+    pose = _req(pose.reshape(7), torch.float32, "pose")
+    pos_Tc = _req(pos_Tc, torch.float32, "pos_Tc")
+    cov_Tc = _req(cov_Tc, torch.float64, "cov_Tc")
+    n = pos_Tc.shape[0]
+    dev = pos_Tc.device
+    pos_Tw = torch.empty_like(pos_Tc)
+    rot = torch.empty(9, dtype=torch.float64, device=dev)
+    cov_Tw = torch.empty_like(cov_Tc)
+    cnt = (C.c_int32 * 1)(n)
+    L.check(lib.mv_pose_apply_lanes(pose.data_ptr(), pos_Tc.data_ptr(), cov_Tc.data_ptr(), 1, cnt, n, pos_Tw.data_ptr(),
+                                    rot.data_ptr(), cov_Tw.data_ptr(), _stream()), "mv_pose_apply_lanes")
+    return pos_Tw, rot, cov_Tw
+
+
+def frontend_epilogue_select(flow: torch.Tensor, cov: torch.Tensor, baseline: float, fx: float, cov_is_log: bool = True,
+                             enforce_positive_disparity: bool = False, kernel_size: int = 7, mask_width: int = 32,
+                             max_match_cov: float = 0.0, mask_a: torch.Tensor | None = None,
+                             mask_b: torch.Tensor | None = None) -> "tuple[FrontendMaps, KeypointCandidates]":
+    """``frontend_epilogue`` followed by ``kp_select("nodepth", ...)`` in one launch less (``mv_frontend_epilogue_select_lanes``):
+    the selector's first kernel derives the quality map from the network's covariance planes itself and writes the epilogue's
+    maps on the way.  Bit-identical to the two calls (``test_gpu_backend::test_fused_epilogue_selector_is_bitwise_the_two_calls``)."""
+    lib = L.load()
+    flow = _req(flow, torch.float32, "flow")
+    cov = _req(cov, torch.float32, "cov")
+    assert flow.shape == cov.shape and flow.shape[0] == 2 and flow.shape[1] == 2
+    _, _, H, W = flow.shape
+    dev = flow.device
+    mk = lambda c: torch.empty((1, c, H, W), dtype=torch.float32, device=dev)  # noqa: E731
+    disparity, disparity_cov, depth, depth_cov, mflow, mcov = mk(1), mk(1), mk(1), mk(1), mk(2), mk(3)
+    bad = torch.empty((1, 1, H, W), dtype=torch.bool, device=dev) if enforce_positive_disparity else None
+    ms = []
+    for name, t in (("mask_a", mask_a), ("mask_b", mask_b)):
+        if t is not None:
+            if t.dtype == torch.bool:
+                t = t.contiguous().view(torch.uint8)
+            t = _req(t, torch.uint8, name)
+        ms.append(t)
+    p = L.mvKpSelectParams(H, W, L.MV_KP_NODEPTH, kernel_size, mask_width, 0.0, 0.0, max_match_cov)
+    ws = _kp_workspace(H, W, dev)
+    cand = torch.empty((H * W,), dtype=torch.int32, device=dev)
+    count = torch.empty((4,), dtype=torch.int32, device=dev)
+    stats = torch.empty((4,), dtype=torch.float32, device=dev)
+    bl_fx = float(baseline) * float(fx)
+    L.check(lib.mv_frontend_epilogue_select_lanes(flow.data_ptr(), cov.data_ptr(), int(cov_is_log), bl_fx, bl_fx ** 2,
+                                                  disparity.data_ptr(), disparity_cov.data_ptr(), depth.data_ptr(),
+                                                  depth_cov.data_ptr(), _ptr(bad), mflow.data_ptr(), mcov.data_ptr(),
+                                                  _ptr(ms[0]), _ptr(ms[1]), C.byref(p), ws.data_ptr(), ws.numel() * 8,
+                                                  cand.data_ptr(), count.data_ptr(), stats.data_ptr(), 1, _stream()),
+            "mv_frontend_epilogue_select_lanes")
+    return FrontendMaps(depth, depth_cov, disparity, disparity_cov, bad, mflow, mcov), KeypointCandidates(cand, count, stats, W)
+
+
 # ------------------------------------------------------------------------------------------- A12
 @dataclass
 class TrackedKeypoints:

@@ -683,6 +683,8 @@ class NativeHotPath:
                 if k:
                     self._perm[l, :k] = perm
             perm_ptr = self._perm.data_ptr()
+        # views of earlier results may still be being read on the caller's stream: the pipe recycles their buffers behind that
+        L.check(lib.mv_frame_pipe_release(self._pipe, ops._stream()), "mv_frame_pipe_release")
         L.check(lib.mv_frame_pipe_finish(self._pipe, perm_ptr, self._nsel, None if pose_sink is None else pose_sink.data_ptr()),
                 "mv_frame_pipe_finish")
         self._n_fin += 1

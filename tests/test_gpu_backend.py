@@ -27,6 +27,38 @@ def test_selector_nodepth_bit_exact(gpu, H, W, seed, nan_frac):
     assert int(cands.count[1].item()) == aux["n_nms"]
 
 
+@pytest.mark.parametrize("H,W,cov_is_log,nan_frac,masked", [(480, 640, True, 0.0, False), (480, 640, True, 0.01, True),
+                                                             (96, 130, False, 0.02, False), (720, 1280, True, 0.0, False)])
+def test_fused_epilogue_selector_is_bitwise_the_two_calls(gpu, H, W, cov_is_log, nan_frac, masked):
+    """mv_frontend_epilogue_select_lanes (what the frame driver launches) against frontend_epilogue followed by kp_select: every
+    map, the candidate list, its count, the NMS count and the median must agree bit for bit — including NaNs in the covariance
+    planes, an image whose size is no multiple of the 64 x 16 tile, the already-exponentiated input form and selector masks."""
+    from macvo_amd import ops
+
+    g = torch.Generator().manual_seed(77)
+    flow = torch.randn(2, 2, H, W, generator=g) * 4
+    cov = torch.randn(2, 2, H, W, generator=g) * 0.5
+    if not cov_is_log:
+        cov = torch.exp(2 * cov)
+    if nan_frac:
+        cov[torch.rand(cov.shape, generator=g) < nan_frac] = float("nan")
+    ma = (torch.rand(1, 1, H, W, generator=g) > 0.3) if masked else None
+    flow, cov = flow.to(gpu), cov.to(gpu)
+    ma_d = ma.to(gpu) if masked else None
+    maps = ops.frontend_epilogue(flow, cov, 0.25, 320.0, cov_is_log=cov_is_log, enforce_positive_disparity=True)
+    cands = ops.kp_select("nodepth", H, W, flow_cov=maps.flow_cov, kernel_size=7, mask_width=32, max_match_cov=100.0, mask_a=ma_d)
+    fmaps, fcands = ops.frontend_epilogue_select(flow, cov, 0.25, 320.0, cov_is_log=cov_is_log, enforce_positive_disparity=True,
+                                                 kernel_size=7, mask_width=32, max_match_cov=100.0, mask_a=ma_d)
+    for name in ("depth", "depth_cov", "disparity", "disparity_cov", "flow", "flow_cov"):
+        a, b = getattr(maps, name), getattr(fmaps, name)
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), name
+    assert torch.equal(maps.bad_mask, fmaps.bad_mask)
+    assert cands.n == fcands.n and cands.n > 0
+    assert torch.equal(cands.cand[: cands.n], fcands.cand[: fcands.n])
+    assert torch.equal(cands.count, fcands.count)
+    assert torch.equal(cands.stats.view(torch.int32), fcands.stats.view(torch.int32))
+
+
 def test_selector_nodepth_plateau_and_mask(gpu):
     """Plateaus (equality NMS keeps every tied pixel), a validity mask, and a low max_match_cov cap."""
     from macvo_amd import ops
@@ -137,6 +169,28 @@ def test_match_cov_pair_equals_two_calls(gpu):
     p0, p0w, p1 = ops.match_cov_pair(d0.to(gpu), k0.to(gpu), b0, d1.to(gpu), k1.to(gpu), b1, *K, rot=R)
     assert torch.equal(p0, c0) and torch.equal(p0w, c0w) and torch.equal(p1, c1)
     assert torch.equal(a0, b0) and torch.equal(a1, b1)
+
+
+def test_pose_apply_is_bitwise_backproject_plus_rotated_covariance(gpu):
+    """mv_pose_apply_lanes (the pose-dependent remainder the frame driver runs behind the previous solve) against the kernels that
+    used to produce the same tables: mv_backproject with a pose (pos_Tw, rot) and mv_match_cov with rot (R cov R^T)."""
+    from macvo_amd import ops
+
+    g = torch.Generator().manual_seed(21)
+    n, H, W = 200, 480, 640
+    depth = (torch.rand(1, 1, H, W, generator=g) * 40 + 2).to(gpu)
+    kp = torch.stack([torch.randint(40, W - 40, (n,), generator=g), torch.randint(40, H - 40, (n,), generator=g)], 1).float().to(gpu)
+    dvals = (torch.rand(n, generator=g) * 30 + 1).to(gpu)
+    q = torch.randn(4, generator=g)
+    pose = torch.cat([torch.randn(3, generator=g), q / q.norm()]).float().to(gpu)
+    K4 = (320.0, 320.0, 320.0, 240.0)
+    pos_Tc, pos_Tw, rot = ops.backproject(kp, dvals, K4, pose, want_rot=True)
+    sigma = (torch.rand(n, 3, generator=g) * torch.tensor([2.0, 2.0, 0.2])).float().to(gpu)
+    cov, cov_w = ops.match_cov(depth, kp, sigma.clone(), None, *K4, rot=rot.view(3, 3))
+    pos_Tw2, rot2, cov_w2 = ops.pose_apply(pose, pos_Tc, cov)
+    assert torch.equal(pos_Tw.view(torch.int32), pos_Tw2.view(torch.int32))
+    assert torch.equal(rot.reshape(9).view(torch.int64), rot2.view(torch.int64))
+    assert torch.equal(cov_w.view(torch.int64), cov_w2.view(torch.int64))
 
 
 def test_match_cov_given_depth_cov_and_nan(gpu):
