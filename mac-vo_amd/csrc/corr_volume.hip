@@ -1612,7 +1612,7 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
         if (layout == MV_LAYOUT_CHW) {
             static int fstream = -1;   // MV_VOL_STREAM=1: streaming form (A/B knob while it is being measured)
             if (fstream < 0) { const char* e = getenv("MV_VOL_STREAM"); fstream = (e && atoi(e) > 0) ? 1 : 0; }
-            if (fstream && N1 == N2 && C == 256 && (N1 % 64) == 0 && N1 >= 256) {
+            if (fstream && N1 == N2 && C == 256 && (N1 % 64) == 0 && N1 >= 256 && ((size_t)N1 * N2) < ((size_t)1 << 30)) {
                 static int cus = 0;
                 if (!cus) {
                     int dev = 0;
@@ -1709,7 +1709,8 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
             if (C % 32) return MV_ERR_UNSUPPORTED;
             static int hstream = -1;   // MV_H_STREAM=0: the tile form below (A/B knob)
             if (hstream < 0) { const char* e = getenv("MV_H_STREAM"); hstream = (e && atoi(e) == 0) ? 0 : 1; }
-            if (hstream && (C == 256 || C == 128) && (N2 % 64) == 0 && ((size_t)N1 * N2 * B) >= ((size_t)1 << 22)) {
+            if (hstream && (C == 256 || C == 128) && (N2 % 64) == 0 && ((size_t)N1 * N2 * B) >= ((size_t)1 << 22) &&
+                ((size_t)N1 * N2) < ((size_t)1 << 30)) {   // (32-bit byte offsets inside a pair's block of the output)
                 static int cus = 0;
                 if (!cus) {
                     int dev = 0;
