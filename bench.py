@@ -69,7 +69,58 @@ def parse_args():
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events around the volume kernel")
     ap.add_argument("--no-ramp", action="store_true", help="skip the untimed clock-ramp phase")
     ap.add_argument("--no-decoder-leg", action="store_true", help="skip the decoder-loop harness leg (HIP lookups / upsamplings interleaved with PyTorch-ROCm kernels)")
+    ap.add_argument("--dry-collectives", action="store_true",
+                    help="CPU-only plumbing check of the N-rank launch path: gloo backend, no kernels, synthetic tracks through the "
+                         "same barrier / gather_tracks / max-over-ranks code; the line it prints is marked and is NOT a measurement")
     return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """``python bench.py --gpus N`` without a launcher (the form the round-end driver uses): re-exec this script under
+    ``torch.distributed.run`` with one rank per GPU on 127.0.0.1 and hand its output (rank 0's one JSON line) through."""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:           # a free rendezvous port
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this stack
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_collectives(args, rank, world) -> None:
+    """The N-rank control flow of ``main`` on CPU tensors over gloo: rendezvous, barrier, one gather_tracks of ragged tracks,
+    max-over-ranks clock.  Exists so that the launch path of ``--gpus N`` is testable without N GPUs (tests/test_abi_and_host.py)."""
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo")
+    from macvo_amd.distributed import gather_tracks
+
+    steps = args.steps
+    poses = torch.zeros((steps, 7))
+    poses[:, 6] = 1.0
+    poses[:, 0] = rank
+    stamps = torch.arange(steps, dtype=torch.int64) * 33_333_333
+    dist.barrier()
+    t0 = time.perf_counter()
+    all_poses, all_stamps, lengths = gather_tracks(poses, stamps, dist)
+    dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    ids = [None] * world
+    dist.all_gather_object(ids, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0"))})
+    ok = all_poses.shape[0] == world and all(float(all_poses[r, 0, 0]) == r for r in range(world))
+    if rank == 0:
+        print(json.dumps({"metric": "DRY RUN of the multi-rank launch path (gloo, CPU, no kernels) - not a measurement",
+                          "value": None, "unit": "stereo frames/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+                          "dry_collectives": True, "ranks_seen": dist.get_world_size(), "rank_ids": ids, "gather_ok": bool(ok),
+                          "track_lengths": [int(x) for x in lengths]}), flush=True)
+    dist.destroy_process_group()
 
 
 def volume_work(lanes, n_q, C, esz):
@@ -107,8 +158,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args))      # one rank per GPU under torch.distributed.run, output handed through
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
+    if args.dry_collectives:
+        return dry_collectives(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP hot path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -117,6 +172,8 @@ def main():
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
         dist_mod.init_process_group(backend="nccl", device_id=dev)
         dist = dist_mod
 
@@ -404,6 +461,14 @@ def main():
         except Exception as e:  # noqa: BLE001 - a measurement leg must not take the benchmark line down
             decoder_loop = {"error": repr(e)[:300]}
 
+    # what RCCL actually connected: world size as the process group reports it + every rank's device (one all_gather of 2 ints)
+    ranks_seen, rank_devices = 1, [torch.cuda.current_device()]
+    if dist is not None:
+        ranks_seen = dist.get_world_size()
+        mine = torch.tensor([rank, torch.cuda.current_device()], dtype=torch.int64, device=dev)
+        got = torch.empty((ranks_seen, 2), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(got, mine)
+        rank_devices = [int(d) for _, d in sorted((int(r), int(d)) for r, d in got.cpu().tolist())]
     if rank == 0:
         total_frames = world * args.steps * args.lanes
         cfgname = {1: "configs[1]", 32: "configs[4]"}.get(args.lanes, f"{args.lanes}-lane variant of configs[1]")
@@ -412,6 +477,8 @@ def main():
             "value": round(total_frames / elapsed, 2),
             "unit": "stereo frames/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
+            "rank_devices": rank_devices,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),

@@ -315,8 +315,8 @@ int mv_local_corr81(const float* first, const float* second, float* out, int B, 
  * (MatchObs.init, `match_obs[mask]`, points.push(...[mask]), push_keyframe, the six edge updates, the lost-track flag), which
  * the reference runs on the CPU behind ~25 `.cpu()` copies per frame; Odometry/Interface.py:47-49 (body poses of poses.npy);
  * Module/MapProcessor.py:52-76 (MotionInterpolate) with Utility/Math.py:96-133.  The stores are caller-owned device arrays
- * (SoA, the reference's field names / dtypes, VisualMap.py:23-69); `counts` is a DEVICE int64[4] = {frames, matches, points,
- * lost frames} advanced by the kernel itself, so registering a frame needs no host synchronisation: the host only has to keep
+ * (SoA, the reference's field names / dtypes, VisualMap.py:23-69); `counts` is a DEVICE int64[5] = {frames, matches, points,
+ * lost frames, refused appends} advanced by the kernel itself, so registering a frame needs no host synchronisation: the host only has to keep
  * capacity >= an upper bound of the rows pushed (rows selected).
  */
 typedef struct {
@@ -342,9 +342,15 @@ typedef struct {
     int64_t *frame2match_ranges, *frame2match_num, *frame2map_ranges, *frame2map_num;
     int64_t *match2frame1, *match2frame2, *match2point;
     int64_t *point2match_edges, *point2match_deg;
-    int64_t* counts;          /* device int64[4] */
+    int64_t* counts;          /* device int64[5]: {frames, matches, points, lost frames, REFUSED appends (error word)} */
     int32_t max_pt_obs;       /* 5  (VisualMap.py:18) */
     int32_t max_frame_range;  /* 2  (VisualMap.py:19) */
+    /* capacities (rows) of the frame / match / point stores and their edge tables.  The row offsets come from the DEVICE-side
+     * counts, so the kernel itself refuses an append that would not fit (counts unchanged, counts[4] += 1, out_frame_idx = -1)
+     * instead of writing past the stores; a frame2match range dropped because a frame already has max_frame_range ranges (the
+     * reference raises there, Graph.py:183-186) is counted in counts[4] as well.  The host reads counts[4] at its next
+     * synchronisation point (DeviceVisualMap.sizes -> MV_ERR_WORKSPACE). */
+    int64_t cap_frames, cap_match, cap_points;
 } mvMapStores;
 
 /* one frame's observations as the tracking kernels leave them (row order of the selected keypoints; `valid` = border test

@@ -17,7 +17,7 @@ MV_F32, MV_F16, MV_BF16, MV_BF16X3, MV_BF16X2 = 0, 1, 2, 3, 4
 MV_LAYOUT_CHW, MV_LAYOUT_HWC = 0, 1
 MV_KP_NODEPTH, MV_KP_FULL, MV_KP_MAPPING = 0, 1, 2
 MV_GRAPH_ICP, MV_GRAPH_REPROJ, MV_GRAPH_DISP = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 MV_MAX_LANES = 64        # include/macvo_hip.h
 
 
@@ -63,7 +63,8 @@ class mvMapStores(C.Structure):
         "pixel1_uv", "pixel2_uv", "pixel1_d", "pixel2_d", "pixel1_disp", "pixel2_disp", "pixel1_disp_cov", "pixel2_disp_cov",
         "obs1_covTc", "obs2_covTc", "pixel1_uv_cov", "pixel2_uv_cov", "pixel1_d_cov", "pixel2_d_cov",
         "frame2match_ranges", "frame2match_num", "frame2map_ranges", "frame2map_num", "match2frame1", "match2frame2",
-        "match2point", "point2match_edges", "point2match_deg", "counts")] + [("max_pt_obs", C.c_int32), ("max_frame_range", C.c_int32)]
+        "match2point", "point2match_edges", "point2match_deg", "counts")] + [("max_pt_obs", C.c_int32), ("max_frame_range", C.c_int32)] + \
+        [("cap_frames", C.c_int64), ("cap_match", C.c_int64), ("cap_points", C.c_int64)]
 
 
 class mvMapFrame(C.Structure):

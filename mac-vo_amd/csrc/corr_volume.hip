@@ -1595,6 +1595,11 @@ static unsigned vol_lds_bytes() {   // dynamic LDS request that admits exactly k
     return (unsigned)v;
 }
 
+// the streaming kernels number their (pair, 128-row band, 64-column sub-tile) items with an int
+static bool stream_items_fit(int B, int N1, int N2) {
+    return (size_t)B * (size_t)((N1 + 127) / 128) * (size_t)(N2 / 64) < ((size_t)1 << 31);
+}
+
 extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B, int C, int N1, int N2,
                               int in_dtype, int layout, mvStream_t stream) {
     MV_CHECK_ARG(f1 && f2 && out);
@@ -1612,7 +1617,8 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
         if (layout == MV_LAYOUT_CHW) {
             static int fstream = -1;   // MV_VOL_STREAM=1: streaming form (A/B knob while it is being measured)
             if (fstream < 0) { const char* e = getenv("MV_VOL_STREAM"); fstream = (e && atoi(e) > 0) ? 1 : 0; }
-            if (fstream && N1 == N2 && C == 256 && (N1 % 64) == 0 && N1 >= 256 && ((size_t)N1 * N2) < ((size_t)1 << 30)) {
+            if (fstream && N1 == N2 && C == 256 && (N1 % 64) == 0 && N1 >= 256 && ((size_t)N1 * N2) < ((size_t)1 << 30) &&
+                stream_items_fit(B, N1, N2)) {
                 static int cus = 0;
                 if (!cus) {
                     int dev = 0;
@@ -1710,7 +1716,8 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
             static int hstream = -1;   // MV_H_STREAM=0: the tile form below (A/B knob)
             if (hstream < 0) { const char* e = getenv("MV_H_STREAM"); hstream = (e && atoi(e) == 0) ? 0 : 1; }
             if (hstream && (C == 256 || C == 128) && (N2 % 64) == 0 && ((size_t)N1 * N2 * B) >= ((size_t)1 << 22) &&
-                ((size_t)N1 * N2) < ((size_t)1 << 30)) {   // (32-bit byte offsets inside a pair's block of the output)
+                ((size_t)N1 * N2) < ((size_t)1 << 30) &&   // (32-bit byte offsets inside a pair's block of the output)
+                stream_items_fit(B, N1, N2)) {             // (the item index T = B * bands * sub-tiles is an int)
                 static int cus = 0;
                 if (!cus) {
                     int dev = 0;

@@ -562,13 +562,22 @@ extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, co
     hipStream_t s = p->s_back;
     p->prior_slot = p->pose_cur;
     if (n_max == 0) {   // nothing to track in any lane: the poses stay at the motion-model prior (MACVO.py:303-307)
-        if (pose_sink) {
-            if (p->pgo_valid) MV_HIP(hipStreamWaitEvent(p->s_side, p->e_pgo, 0));
-            MV_HIP(hipMemcpyAsync(pose_sink, p->pose[p->pose_cur], (size_t)L * 7 * sizeof(float), hipMemcpyDeviceToDevice,
-                                  p->s_side));
-            MV_HIP(hipEventRecord(p->e_pgo, p->s_side));
-            p->pgo_valid = true;
-        }
+        // The pose slots still rotate (MV_FB_POSE age a = the pose after the a-th newest finish) and the slot's events are
+        // refreshed, so that everything keyed on "slot of finish g" (mv_frame_pipe_map_append, result views) sees this frame and
+        // not the one two finishes back.  In-order on the side stream: behind the previous solve, no extra wait needed.
+        const int nxt0 = (p->pose_cur + 1) % 3;
+        MV_HIP(hipMemcpyAsync(p->pose[nxt0], p->pose[p->pose_cur], (size_t)L * 7 * sizeof(float), hipMemcpyDeviceToDevice,
+                              p->s_side));
+        if (pose_sink)
+            MV_HIP(hipMemcpyAsync(pose_sink, p->pose[nxt0], (size_t)L * 7 * sizeof(float), hipMemcpyDeviceToDevice, p->s_side));
+        MV_HIP(hipEventRecord(p->e_posed[k], p->s_side));
+        MV_HIP(hipEventRecord(p->e_pgo, p->s_side));
+        MV_HIP(hipEventRecord(p->e_solved[k], p->s_side));
+        MV_HIP(hipEventRecord(p->e_backend[k], s));
+        p->pgo_valid = true;
+        p->solved_valid[k] = true;
+        p->backend_valid[k] = true;
+        p->pose_cur = nxt0;
         return MV_OK;
     }
     const Maps &m0 = p->maps[pd.maps_prev], &m1 = p->maps[pd.maps];
@@ -762,7 +771,10 @@ extern "C" int mv_frame_pipe_buffer(mvFramePipe* p, int which, int age, void** p
     const Backend* b = back() ? &p->be[g & 1] : nullptr;
     const size_t N = L * (size_t)(c.num_point > 0 ? c.num_point : 1);   // capacity rows (a lane's live rows: its n_sel)
     switch (which) {
-        case MV_FB_VOLUME: if (!front(p->n_vol > p->n_enq ? 1 : 2)) break;   // a GEMM issued ahead is rewriting the older buffer *ptr = p->vol[f % p->n_volbuf]; *count = (size_t)c.pairs * p->n8 * p->n8; return MV_OK;
+        case MV_FB_VOLUME:
+            // age limit: with a GEMM issued ahead (n_vol > n_enq) the buffer of frame f - 1 is being rewritten
+            if (!front(p->n_vol > p->n_enq ? 1 : 2)) break;
+            *ptr = p->vol[f % p->n_volbuf]; *count = (size_t)c.pairs * p->n8 * p->n8; return MV_OK;
         case MV_FB_TOKENS: if (!front(1) || c.iters == 0) break; *ptr = p->tok[(c.iters - 1) & 1]; *count = (size_t)c.pairs * p->KK * p->n8; return MV_OK;
         case MV_FB_DISPARITY: if (!front(N_MAPS)) break; *ptr = p->maps[f % N_MAPS].disparity; *count = plane; return MV_OK;
         case MV_FB_DISPARITY_COV: if (!front(N_MAPS)) break; *ptr = p->maps[f % N_MAPS].disparity_cov; *count = plane; return MV_OK;

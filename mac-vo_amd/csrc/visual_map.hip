@@ -132,6 +132,14 @@ __global__ __launch_bounds__(256) void map_append_kernel(mvMapFrame fr, mvMapSto
     }
     __syncthreads();
     const int F = frame_idx, M0 = base_match, P0 = base_point;
+    // row offsets are device-side state: a caller whose capacity bookkeeping slipped must get an error, not a scribble
+    if ((int64_t)F >= st.cap_frames || (int64_t)M0 + fr.n_rows > st.cap_match || (int64_t)P0 + fr.n_rows > st.cap_points) {
+        if (t == 0) {
+            cnt[4] += 1;
+            if (fr.out_frame_idx) fr.out_frame_idx[0] = -1;
+        }
+        return;
+    }
     int kept_total = 0;
     // rows are processed in chunks of 256 so that any n_rows works; order is preserved (== `bundle[mask]`)
     for (int r0 = 0; r0 < fr.n_rows; r0 += 256) {
@@ -213,6 +221,8 @@ __global__ __launch_bounds__(256) void map_append_kernel(mvMapFrame fr, mvMapSto
                 st.frame2match_ranges[2 * (st.max_frame_range * pf + np)] = M0;
                 st.frame2match_ranges[2 * (st.max_frame_range * pf + np) + 1] = kept_total;
                 st.frame2match_num[pf] = np + 1;
+            } else {
+                cnt[4] += 1;   // DenseEdge_Multi.add raises when a frame runs out of range slots (Graph.py:183-186)
             }
             st.frame2match_ranges[2 * st.max_frame_range * f] = M0;
             st.frame2match_ranges[2 * st.max_frame_range * f + 1] = kept_total;
@@ -336,6 +346,7 @@ extern "C" int mv_map_append(const mvMapFrame* frame, const mvMapStores* stores,
     MV_CHECK_ARG(f.n_rows >= 0 && f.table_stride >= f.n_rows && f.K && f.T_BS && s.counts);
     MV_CHECK_ARG(f.n_rows == 0 || (f.kp0 && f.kp1 && f.vals && f.sigma0 && f.sigma1 && f.cov0 && f.cov1 && f.pos_Tw && f.cov0_world));
     MV_CHECK_ARG(s.max_pt_obs >= 1 && s.max_frame_range >= 1);
+    MV_CHECK_ARG(s.cap_frames > 0 && s.cap_match > 0 && s.cap_points > 0);
     MV_CHECK_ARG(s.K && s.baseline && s.pose && s.T_BS && s.need_interp && s.time_ns && s.pos_Tw && s.cov_Tw && s.color);
     MV_CHECK_ARG(s.pixel1_uv && s.pixel2_uv && s.pixel1_d && s.pixel2_d && s.pixel1_disp && s.pixel2_disp && s.pixel1_disp_cov &&
                  s.pixel2_disp_cov && s.obs1_covTc && s.obs2_covTc && s.pixel1_uv_cov && s.pixel2_uv_cov && s.pixel1_d_cov &&

@@ -67,7 +67,7 @@ class DeviceVisualMap:
             "point2match_edges": self._alloc(init_size, (max_pt_obs,), i64, -1),
             "point2match_deg": self._alloc(init_size, (), i64, 0),
         }
-        self.counts = torch.zeros(4, dtype=i64, device=self.dev)      # {frames, matches, points, lost frames}: advanced on device
+        self.counts = torch.zeros(5, dtype=i64, device=self.dev)      # {frames, matches, points, lost frames, refused appends}: advanced on device
         self.n_frames = 0                                             # exact (one per push)
         self.rows_upper = 0                                           # upper bound of matches == points pushed
         self._stores = None
@@ -113,7 +113,8 @@ class DeviceVisualMap:
         if self._stores is None:
             p = {k: v.data_ptr() for tbl in (self.frames, self.points, self.match, self.edges) for k, v in tbl.items()}
             self._stores = L.mvMapStores(**p, counts=self.counts.data_ptr(), max_pt_obs=self.max_pt_obs,
-                                         max_frame_range=self.max_frame_range)
+                                         max_frame_range=self.max_frame_range, cap_frames=self.cap["frames"],
+                                         cap_match=self.cap["match"], cap_points=self.cap["points"])
         return self._stores
 
     def push_frame(self, *, K, T_BS, baseline: float, time_ns: int, prior_pose=None, tracked=None, valid=None, cov0=None,
@@ -152,6 +153,11 @@ class DeviceVisualMap:
     # ------------------------------------------------------------------ outputs
     def sizes(self) -> tuple[int, int, int, int]:
         c = self.counts.cpu().tolist()          # the one host synchronisation, at write-out time
+        if c[4]:
+            # the append kernel refused a frame (stores too small for the device-side row offsets) or dropped an edge range the
+            # reference would have raised on (Graph.py:183-186): the map is incomplete
+            raise L.MacvoHipError(f"device map: {int(c[4])} append(s) refused or edge range(s) dropped (MV_ERR_WORKSPACE): "
+                                  "reserve() must cover every frame before it is appended")
         return int(c[0]), int(c[1]), int(c[2]), int(c[3])
 
     def serialize(self) -> dict[str, np.ndarray]:

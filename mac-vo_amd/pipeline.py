@@ -411,10 +411,18 @@ class _Pending:
 def stack_lanes(inputs: "list[FrameInputs]") -> FrameInputs:
     """Batch the per-sequence inputs of ``len(inputs)`` independent sequences ("lanes") along the pair axis — the
     reference's batching point (``Frontend.py:219-224``): lane l contributes pairs 2l (stereo) and 2l + 1 (temporal)."""
+    # the per-lane inputs may have been produced on other streams: the concatenation below runs on the current one
+    for x in inputs:
+        if x.ready is not None:
+            torch.cuda.current_stream().wait_event(x.ready)
+    # one device map per pipe (lanes == 1), so per-lane images have no consumer in a batched step: refuse them rather than
+    # drop them silently; the lanes advance in lock-step, so the step carries lane 0's timestamp
+    assert len(inputs) == 1 or all(x.image is None for x in inputs), "stack_lanes: per-lane images are not carried"
     cat = lambda name, dim=0: (None if getattr(inputs[0], name) is None  # noqa: E731
                                else torch.cat([getattr(x, name) for x in inputs], dim=dim).contiguous())
     return FrameInputs(fmap1=cat("fmap1"), fmap2=cat("fmap2"), coords=cat("coords", 1), flow=cat("flow"), logcov=cat("logcov"),
                        flow8=cat("flow8"), cov8=cat("cov8"), up_mask=cat("up_mask"), cov_mask=cat("cov_mask"),
+                       image=inputs[0].image if len(inputs) == 1 else None, time_ns=inputs[0].time_ns,
                        static=all(x.static for x in inputs))
 
 

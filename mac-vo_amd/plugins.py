@@ -315,7 +315,7 @@ class HIP_FlowFormerCovFrontend(IFrontend):
             model.eval()
             model.to(self.config.device)
             model.load_ddp_state_dict(ckpt)
-        if hasattr(model, "memory_decoder"):
+        if hasattr(model, "memory_decoder") or hasattr(model, "memory_encoder"):
             install_flowformer_hooks(model)
         self.model = model
 
@@ -387,7 +387,7 @@ def _build_flowformer_cov(config: SimpleNamespace, who: str):
         model.load_ddp_state_dict(torch.load(config.weight, weights_only=True))
         model.to(config.device)
         model.eval()
-    if hasattr(model, "memory_decoder"):
+    if hasattr(model, "memory_decoder") or hasattr(model, "memory_encoder"):
         install_flowformer_hooks(model)
     return model
 
@@ -499,17 +499,48 @@ class HIP_CUDAGraph_FlowFormerCovFrontend(HIP_FlowFormerCovFrontend):
 
 
 # ----------------------------------------------------------------------------------------------- FlowFormer hooks
-def install_flowformer_hooks(model) -> None:
-    """Route FlowFormerCov's window lookup through the HIP kernel.
+def install_flowformer_hooks(model, volume_precision: str = "exact") -> list[str]:
+    """Route the three frontend kernels of ``FlowFormerCov`` through the HIP library by rebinding bound methods on the model
+    instance — signatures and result layouts are those of the methods they replace, the network's own code is untouched:
 
-    ``MemoryCovDecoder.forward`` calls ``self.encode_flow_token(cost_maps, flow_coords1)`` every decoder iteration
-    (Module/Network/FlowFormerCov/covhead.py:92); replacing that bound method is all it takes — signature and result
-    layout ([B, 81, H1, W1] fp32) are those of the upstream method.  The cost-volume build lives inside the (absent)
-    FlowFormer ``MemoryEncoder``; a maintainer replaces its ``einsum`` with ``ops.corr_volume(feat_s, feat_t)`` as
-    shown in INTEGRATION.md.
-    """
-    dec = model.memory_decoder
-    dec.encode_flow_token = lambda cost_maps, coords: ops.corr_lookup(cost_maps.float(), coords.float(), 4)
+    * ``memory_decoder.encode_flow_token(cost_maps, coords)`` — the 9x9 window lookup, once per decoder iteration
+      (Module/Network/FlowFormerCov/covhead.py:92) -> ``ops.corr_lookup`` (``[B, 81, H1, W1]`` fp32);
+    * ``memory_decoder.upsample_flow(flow, mask)`` — the convex 8x upsampling of flow and log-sigma, twice per iteration
+      (covhead.py:124-126, 133-135; both callers hand over fp32 and an already scaled mask) -> ``ops.convex_upsample``;
+    * ``memory_encoder.corr(fmap1, fmap2)`` — the all-pairs volume (``einsum('bhid,bhjd->bhij')`` of FlowFormer's
+      ``MemoryEncoder``, reached from flownet.py:26) -> ``ops.corr_volume``; result ``[B, heads = 1, H1, W1, H2, W2]`` in the
+      dtype of the feature maps, as the einsum would return it (fp32 features: the kernel's fp32 output as is; 16-bit
+      encoder dtypes: one cast, exactly the rounding the einsum's 16-bit output has — flownet.py:27 widens it again).
+
+    Every attribute that exists is rebound (the FlowFormer submodule is absent from some checkouts, and a stand-in model may
+    carry only part of them); the names of the rebound methods are returned so that a caller can insist on all three."""
+    done = []
+    dec = getattr(model, "memory_decoder", None)
+    if dec is not None and hasattr(dec, "encode_flow_token"):
+        dec.encode_flow_token = lambda cost_maps, coords: ops.corr_lookup(cost_maps.float(), coords.float(), 4)
+        done.append("memory_decoder.encode_flow_token")
+    if dec is not None and hasattr(dec, "upsample_flow"):
+        dec.upsample_flow = lambda flow, mask: ops.convex_upsample(flow.float(), mask.float(), 1.0, False)
+        done.append("memory_decoder.upsample_flow")
+    enc = getattr(model, "memory_encoder", None)
+    if enc is not None and hasattr(enc, "corr"):
+        heads = int(getattr(getattr(enc, "cfg", None), "cost_heads_num", 1) or 1)
+        if heads != 1:
+            raise ops.L.MacvoHipError("install_flowformer_hooks: cost_heads_num != 1 (every MAC-VO config uses 1, Config/Train/Demo.yaml)")
+
+        def corr(fmap1, fmap2):
+            B, _, H, W = fmap1.shape
+            vol = ops.corr_volume(fmap1.contiguous(), fmap2.contiguous(), layout="chw",
+                                  precision=volume_precision if fmap1.dtype == torch.float32 else "exact")
+            vol = vol if vol.dtype == fmap1.dtype else vol.to(fmap1.dtype)
+            return vol.view(B, 1, H, W, fmap2.shape[2], fmap2.shape[3])
+
+        enc.corr = corr
+        done.append("memory_encoder.corr")
+    if not done:
+        raise ops.L.MacvoHipError("install_flowformer_hooks: the model has none of memory_decoder.encode_flow_token / "
+                                  "upsample_flow / memory_encoder.corr")
+    return done
 
 
 def patch_reference_correlation(correlation=None) -> list[str]:

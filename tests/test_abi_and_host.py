@@ -179,3 +179,23 @@ def test_header_is_plain_c_and_layouts_match_ctypes(tmp_path):
     assert int(kv["offsetof lm"]) == L.mvFramePipeConfig.lm.offset and int(kv["fx"]) == L.mvFramePipeConfig.fx.offset
     assert int(kv["arena"]) > 2 * 4800 * 4800 * 4 * 2 and int(kv["MV_FB_POSE"]) == L.FB["POSE"] and int(kv["MV_BF16X2"]) == L.MV_BF16X2
     assert "steps=10" in out.stdout and "reject=16" in out.stdout and "err=unsupported" in out.stdout
+
+
+def test_bench_gpus_n_launches_itself_and_gathers(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher in front of it (the form the round-end driver uses) must start one rank
+    per GPU by itself and print rank 0's one JSON line.  `--dry-collectives` runs exactly that launch path on gloo / CPU tensors
+    (rendezvous on 127.0.0.1, barrier, ragged gather_tracks, max-over-ranks clock) without touching a GPU."""
+    env = dict(os.environ)
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--dry-collectives"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]           # ONE line, from rank 0
+    import json
+
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["gather_ok"] is True and line["dry_collectives"] is True
+    assert [d["rank"] for d in line["rank_ids"]] == [0, 1] and line["track_lengths"] == [5, 5]
+    assert line["value"] is None                       # a dry run can never be mistaken for a measurement

@@ -196,3 +196,54 @@ def test_native_measurement_hooks(gpu):
     for _ in nat.run(ins[(13 + k) % n_pool] for k in range(2)):
         pass
     assert nat.volume_times_ms() == []
+
+
+def test_volume_view_and_empty_finish_pose_rotation(gpu):
+    """(1) MV_FB_VOLUME must hand out the volume buffer of the asked frame (the `case` once fell through into the
+    token view); with a GEMM issued ahead only age 0 is valid.  (2) a finish with no keypoints in any lane keeps the pose at the
+    prior but still ROTATES the pose slots, so MV_FB_POSE age 1 is the previous finish's pose, not the one before it."""
+    from macvo_amd import ops
+    from macvo_amd.pipeline import Camera, HotPathConfig, NativeHotPath
+
+    H, W, C = 192, 256, 32
+    cam, frames, _ = synth.make_sequence(5, H, W, C=C, iters=2, seed=5)
+    ins = _inputs(frames, gpu)
+    n8 = (H // 8) * (W // 8)
+    hot = NativeHotPath(Camera(**cam), HotPathConfig(num_point=40), gpu)
+    hot.initialize(ins[0])
+    torch.manual_seed(1)
+    hot.step(ins[1])
+    torch.cuda.synchronize()
+    vol = hot._view("VOLUME", 0, torch.float32, (2 * n8, 1, H // 8, W // 8))
+    want = ops.corr_volume(ins[1].fmap1, ins[1].fmap2)
+    assert torch.equal(vol, want)                                   # frame 1's volume, not its tokens
+    assert vol.data_ptr() != hot.last_tokens.data_ptr()
+    prev = hot._view("VOLUME", 1, torch.float32, (2 * n8, 1, H // 8, W // 8))
+    assert torch.equal(prev, ops.corr_volume(ins[0].fmap1, ins[0].fmap2)) and prev.data_ptr() != vol.data_ptr()
+    hot.enqueue_volume(ins[2])                                      # a GEMM issued ahead rewrites the older buffer: age 1 is gone
+    with pytest.raises(ops.L.MacvoHipError):
+        hot._view("VOLUME", 1, torch.float32, (2 * n8, 1, H // 8, W // 8))
+    hot.enqueue_frontend(ins[2])
+    torch.manual_seed(2)
+    r2 = hot.finish()
+    hot.sync_all()
+    torch.cuda.synchronize()
+    pose2 = r2.pose.clone()
+    # an empty finish: drive the C entry point with n_sel = 0 (what finish() does when the selector found no candidate)
+    hot.enqueue_frontend(ins[3])
+    L, lib = ops.L, hot._lib
+    L.check(lib.mv_frame_pipe_wait_candidates(hot._pipe, hot._ncand), "wait")
+    hot._nsel[0] = 0
+    L.check(lib.mv_frame_pipe_release(hot._pipe, ops._stream()), "release")
+    L.check(lib.mv_frame_pipe_finish(hot._pipe, None, hot._nsel, None), "finish")
+    hot._n_fin += 1
+    hot.sync_all()
+    torch.cuda.synchronize()
+    assert torch.equal(hot._view("POSE", 0, torch.float32, (1, 7))[0], pose2)      # stays at the prior (MACVO.py:303-307)
+    assert torch.equal(hot._view("POSE", 1, torch.float32, (1, 7))[0], pose2)      # = frame 2's pose: the slots rotated
+    hot.enqueue_frontend(ins[4])
+    torch.manual_seed(3)
+    r4 = hot.finish()
+    hot.sync_all()
+    torch.cuda.synchronize()
+    assert torch.equal(hot._view("POSE", 1, torch.float32, (1, 7))[0], pose2) and not torch.equal(r4.pose, pose2)

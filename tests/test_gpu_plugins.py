@@ -273,3 +273,82 @@ def test_depth_and_matcher_plugins(gpu):
     flow, cov = [t.cpu() for t in Net().inference(f1.imageL.to(gpu), f2.imageL.to(gpu))]
     assert torch.equal(m.flow.cpu(), flow) and torch.equal(m.cov.cpu(), ofr.from_partial_cov(cov)) and m.mask is None
     assert dep.provide_cov and mat.provide_cov
+
+
+@pytest.mark.parametrize("enc_dtype", [torch.float32, torch.float16])
+def test_flowformer_hooks_rebind_volume_lookup_and_upsampling(gpu, enc_dtype):
+    """install_flowformer_hooks on a model SHAPED like FlowFormerCov (flownet.py:18-44): `memory_encoder.corr` builds the
+    volume, the decoder loop calls `encode_flow_token` and twice `upsample_flow` per iteration (covhead.py:92,124-126,133-135).
+    The stand-in's own methods are plain-torch restatements (einsum / grid_sample / unfold-softmax) that RAISE if they are still
+    reached after the hooks went in, so every one of the three kernels provably runs through the HIP library; results are
+    compared with the oracle's definitions."""
+    from types import SimpleNamespace
+
+    from macvo_amd import plugins
+    from oracle import corr, frontend
+
+    B, C, h8, w8, depth = 2, 64, 12, 16, 3
+    g = torch.Generator().manual_seed(3)
+
+    class Encoder:
+        cfg = SimpleNamespace(cost_heads_num=1)
+
+        def corr(self, fmap1, fmap2):
+            raise AssertionError("MemoryEncoder.corr was not rebound")
+
+        def __call__(self, fmap1, fmap2):
+            c = self.corr(fmap1, fmap2)                                    # [B, heads, H1, W1, H2, W2], feature dtype
+            assert c.shape == (B, 1, h8, w8, h8, w8) and c.dtype == fmap1.dtype
+            return c.permute(0, 2, 3, 1, 4, 5).reshape(B * h8 * w8, 1, h8, w8)   # cost_maps as MemoryEncoder hands them on
+
+    class Decoder:
+        def encode_flow_token(self, cost_maps, coords):
+            raise AssertionError("encode_flow_token was not rebound")
+
+        def upsample_flow(self, flow, mask):
+            raise AssertionError("upsample_flow was not rebound")
+
+    class Net:
+        def __init__(self):
+            self.memory_encoder, self.memory_decoder = Encoder(), Decoder()
+            self.trace = []
+
+        def forward(self, fmap1, fmap2, deltas, masks, cmasks):
+            cost_maps = self.memory_encoder(fmap1.to(enc_dtype), fmap2.to(enc_dtype)).float()      # flownet.py:26-27
+            coords0 = corr.coords_grid(B, h8, w8).to(fmap1.device)
+            coords1, cov1 = coords0.clone(), coords0.clone()
+            for it in range(depth):
+                tok = self.memory_decoder.encode_flow_token(cost_maps, coords1)                     # covhead.py:92
+                coords1 = coords1 + deltas[it]
+                flow_up = self.memory_decoder.upsample_flow(coords1 - coords0, 0.25 * masks[it])    # :124-126
+                cov1 = cov1 + 0.1 * deltas[it]
+                cov_up = self.memory_decoder.upsample_flow(cov1 - coords0, cmasks[it])              # :133-135
+                self.trace.append(dict(coords=coords1 - deltas[it], tok=tok, flow8=coords1 - coords0, flow_up=flow_up,
+                                       cov8=cov1 - coords0, cov_up=cov_up))
+            return cost_maps
+
+    net = Net()
+    done = plugins.install_flowformer_hooks(net)
+    assert done == ["memory_decoder.encode_flow_token", "memory_decoder.upsample_flow", "memory_encoder.corr"]
+    f1, f2 = torch.randn(B, C, h8, w8, generator=g), torch.randn(B, C, h8, w8, generator=g)
+    deltas = [torch.rand(B, 2, h8, w8, generator=g) * 4 - 2 for _ in range(depth)]
+    masks = [torch.randn(B, 576, h8, w8, generator=g) for _ in range(depth)]
+    cmasks = [torch.randn(B, 576, h8, w8, generator=g) for _ in range(depth)]
+    dev = lambda xs: [x.to(gpu) for x in xs]  # noqa: E731
+    cost_maps = net.forward(f1.to(gpu), f2.to(gpu), dev(deltas), dev(masks), dev(cmasks))
+    torch.cuda.synchronize()
+    # volume: fp64 einsum of the features as the encoder saw them (16-bit features: rounded first, result rounded once more)
+    a, b = f1.to(enc_dtype).double(), f2.to(enc_dtype).double()
+    want = corr.corr_volume(a, b, torch.float64)
+    if enc_dtype == torch.float32:
+        assert (cost_maps.cpu().double() - want).abs().max() <= 2e-5 * C ** 0.5
+    else:
+        torch.testing.assert_close(cost_maps.cpu(), want.to(enc_dtype).float(), rtol=2e-3, atol=2e-3)   # one fp16 rounding of ~|8|
+    vol_cpu = cost_maps.cpu()
+    for it, tr in enumerate(net.trace):
+        torch.testing.assert_close(tr["tok"].cpu(), corr.corr_lookup(vol_cpu, tr["coords"].cpu(), 4), rtol=1e-5, atol=2e-4)
+        torch.testing.assert_close(tr["flow_up"].cpu(), frontend.upsample_flow(tr["flow8"].cpu(), 0.25 * masks[it]), rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(tr["cov_up"].cpu(), frontend.upsample_flow(tr["cov8"].cpu(), cmasks[it]), rtol=2e-5, atol=2e-5)
+    # a model that carries none of the three attributes is an error, not a silent no-op
+    with pytest.raises(Exception):
+        plugins.install_flowformer_hooks(SimpleNamespace())
