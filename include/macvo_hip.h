@@ -75,6 +75,9 @@ int mv_corr_volume(const void* f1, const void* f2, float* out, int B, int C, int
 
 /* fp32 -> three bf16 planes (hi, mid, lo; residuals exact): planes[3][n] (uint16 bf16 bits), n % 4 == 0. */
 int mv_split_bf16x3(const float* x, void* planes, size_t n, mvStream_t stream);
+/* Diagnostics: name of the kernel the calling thread's last mv_corr_volume dispatched ("" before the first call); the
+ * string is static.  Used by the dispatch tests and by bench.py to name the kernel its roofline line is about. */
+const char* mv_corr_volume_last_kernel(void);
 
 /* -------------------------------------------------------------------------------------------
  * A6  (2r+1)^2 bilinear window lookup in each query's own cost slice.

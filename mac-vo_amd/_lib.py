@@ -92,6 +92,7 @@ SIGNATURES = {
     "mv_error_string": (C.c_char_p, [C.c_int]),
     "mv_corr_volume": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv_split_bf16x3": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "mv_corr_volume_last_kernel": (C.c_char_p, []),
     "mv_corr_lookup": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv_frontend_epilogue": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                        _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -20,6 +20,7 @@
 //     plain stores are also within noise.  An LDS-free fp32 variant (fragments straight from global memory with an
 //     8- or 16-deep register ring, no barriers) measured 395 / 628 us vs 250 us: the LDS tile is worth keeping.)
 #include "common.h"
+#include "vol_asm.h"
 #include <type_traits>
 #include <stdlib.h>
 #include <string.h>
@@ -312,28 +313,6 @@ __global__ __launch_bounds__(256) void corr_volume_f32_chw(const float* __restri
 // fragment prefetch two groups ahead (no gain), the K stream running across tile boundaries (no cold prologue: no gain),
 // de-phasing the two co-resident workgroups by a quarter tile (no gain).
 // ------------------------------------------------------------------------------------------------
-// ---- hand-counted memory waits and LDS-DMA (used by the DMA-staged tile below and by the streaming kernels) ----
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-// wait for this wave's older memory operations (all but the newest N), then the workgroup barrier — one statement so that
-// nothing can be scheduled between the two
-template <int N>
-__device__ __forceinline__ void wait_vmcnt_barrier() {
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
-}
-// LDS-DMA: 64 lanes x 16 B from (uniform base + per-lane 32-bit offset) to LDS bytes [lds_dst, lds_dst + 1024) in lane order.  M0
-// carries the destination and is compiler-reserved: saved, written and restored inside the one statement.  Invisible to
-// hipcc's s_waitcnt bookkeeping (counted by hand at the call sites).
-__device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_dst)
-                 : "memory");
-}
-
 struct VolSched {   // host-computed, passed by value; everything per PAIR unless noted.  Cells are 64 x 64 outputs.
     int Nc, Gb;                     // cells per dimension; 128x128 tile grid per dimension (Nc / 2)
     int n_big_pp, full_rows, rem;   // big tiles of a pair: `full_rows` full tile rows + `rem` tiles of the next row
@@ -1024,17 +1003,6 @@ __global__ __launch_bounds__(256) void corr_volume_h_hwc(const uint16_t* __restr
 // ------------------------------------------------------------------------------------------------
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-// LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS bytes [lds_dst, lds_dst + 1024) in lane order.  M0 carries the
-// destination and is compiler-reserved: saved, written and restored inside the one statement.  Invisible to hipcc's s_waitcnt
-// bookkeeping (counted by hand, see the kernel).
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-}
-
 template <bool IS_BF16, int KS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void corr_volume_h_stream(
     const uint16_t* __restrict__ f1, const uint16_t* __restrict__ f2, float* __restrict__ out, int N1, int N2, int B, int R) {
@@ -1595,6 +1563,12 @@ static unsigned vol_lds_bytes() {   // dynamic LDS request that admits exactly k
     return (unsigned)v;
 }
 
+// name of the kernel the last mv_corr_volume call of this thread dispatched (tests assert the dispatch; bench.py names the kernel
+// its roofline line is about)
+static thread_local const char* g_last_vol_kernel = "";
+extern "C" const char* mv_corr_volume_last_kernel(void) { return g_last_vol_kernel; }
+#define MV_VOL_KERNEL(name) (g_last_vol_kernel = (name))
+
 // the streaming kernels number their (pair, 128-row band, 64-column sub-tile) items with an int
 static bool stream_items_fit(int B, int N1, int N2) {
     return (size_t)B * (size_t)((N1 + 127) / 128) * (size_t)(N2 / 64) < ((size_t)1 << 31);
@@ -1632,6 +1606,7 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
                 const int nc = N1 / 64;
                 int R = regs_env > 0 ? regs_env : (int)(((size_t)nc * 64 * C * 4 + (2u << 20) - 1) / (2u << 20));
                 R = std::max(1, std::min(R, nc));
+                MV_VOL_KERNEL("corr_volume_f32_stream");
                 hipLaunchKernelGGL((corr_volume_f32_stream<256>), dim3((cus & ~7) * 2), block, 64 * 1024, s, a, b, out, N1, B, R);
                 return mv_launch_status();
             }
@@ -1639,6 +1614,7 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
             const int slots = sched_slots();
             if (slots > 0 && N1 == N2 && (C % 32) == 0 && make_vol_sched(N1, B, slots, vs)) {
                 if (vol_walk_static()) {
+                    MV_VOL_KERNEL("corr_volume_f32_sched");
                     hipLaunchKernelGGL(corr_volume_f32_sched, dim3(slots), block, 0, s, a, b, out, C, N1, vs);
                 } else {
                     // LDS-DMA staging (default): 2 = BK 32 x 2 stages, 3 / 4 = BK 16 x 3 / 4 stages; MV_VOL_DMA=16 -> 3, =0 -> the
@@ -1662,6 +1638,7 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
                             (void)hipFuncSetAttribute((const void*)corr_volume_f32_mixed_dma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                             attr_dma = true;
                         }
+                        MV_VOL_KERNEL("corr_volume_f32_mixed_dma");
                         if (dma == 2)
                             hipLaunchKernelGGL(corr_volume_f32_mixed_dma<2>, dim3((vs.R_b + vs.R_m + vs.R_s) * slots), block, ldsd, s, a,
                                                b, out, C, N1, vs, slots);
@@ -1679,10 +1656,12 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
                         (void)hipFuncSetAttribute((const void*)corr_volume_f32_mixed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                         attr_set = true;
                     }
+                    MV_VOL_KERNEL("corr_volume_f32_mixed");
                     hipLaunchKernelGGL(corr_volume_f32_mixed, dim3((vs.R_b + vs.R_m + vs.R_s) * slots), block, lds, s, a, b, out, C,
                                        N1, vs, slots);
                 }
             } else if ((N1 % 4 == 0) && (N2 % 4 == 0)) {
+                MV_VOL_KERNEL("corr_volume_f32_chw");
                 const int pg = persistent_grid();
                 if (pg > 0 && tiles_m * tiles_n * B > pg)
                     hipLaunchKernelGGL((corr_volume_f32_chw<true, true>), dim3(pg), block, 0, s, a, b, out, C, N1, N2,
@@ -1691,20 +1670,24 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
                     hipLaunchKernelGGL((corr_volume_f32_chw<true, false>), grid, block, gemm_extra_lds(), s, a, b, out, C, N1, N2,
                                        tiles_m, tiles_n, B);
             } else {
+                MV_VOL_KERNEL("corr_volume_f32_chw");
                 hipLaunchKernelGGL((corr_volume_f32_chw<false, false>), grid, block, 0, s, a, b, out, C, N1, N2, tiles_m,
                                    tiles_n, B);
             }
         } else {
+            MV_VOL_KERNEL("corr_volume_f32_hwc");
             hipLaunchKernelGGL(corr_volume_f32_hwc, grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
         }
     } else if (in_dtype == MV_BF16X3) {
         // f1 / f2 = planes produced by mv_split_bf16x3: [3][B][N][C] bf16
         if (layout != MV_LAYOUT_HWC || (C % 32)) return MV_ERR_UNSUPPORTED;
+        MV_VOL_KERNEL("corr_volume_bf16x3_hwc<3>");
         hipLaunchKernelGGL(corr_volume_bf16x3_hwc<3>, grid, block, 0, s, (const uint16_t*)f1, (const uint16_t*)f2, out, C,
                            N1, N2, B, tiles_m, tiles_n);
     } else if (in_dtype == MV_BF16X2) {
         // same planes, only the two leading pieces are read
         if (layout != MV_LAYOUT_HWC || (C % 32)) return MV_ERR_UNSUPPORTED;
+        MV_VOL_KERNEL("corr_volume_bf16x3_hwc<2>");
         hipLaunchKernelGGL(corr_volume_bf16x3_hwc<2>, grid, block, 0, s, (const uint16_t*)f1, (const uint16_t*)f2, out, C,
                            N1, N2, B, tiles_m, tiles_n);
     } else if (in_dtype == MV_F16 || in_dtype == MV_BF16) {
@@ -1745,6 +1728,7 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
                 const int nc = N2 / 64;
                 int R = regs_env > 0 ? regs_env : (int)(((size_t)nc * 64 * C * 2 + (2u << 20) - 1) / (2u << 20));
                 R = std::max(1, std::min(R, nc));
+                MV_VOL_KERNEL("corr_volume_h_stream");
                 if (C == 256) {
                     if (bf) hipLaunchKernelGGL((corr_volume_h_stream<true, 16>), g, blk, lds, s, a, b, out, N1, N2, B, R);
                     else hipLaunchKernelGGL((corr_volume_h_stream<false, 16>), g, blk, lds, s, a, b, out, N1, N2, B, R);
@@ -1754,6 +1738,7 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
                 }
                 return mv_launch_status();
             }
+            MV_VOL_KERNEL("corr_volume_h_hwc");
             static int hbk = -1;
             if (hbk < 0) { const char* e = getenv("MV_H_BK"); hbk = e ? atoi(e) : 32; }
             if (hbk == 64 && (C % 64) == 0) {
@@ -1765,6 +1750,7 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
             }
         } else {
             if (C % 32) return MV_ERR_UNSUPPORTED;
+            MV_VOL_KERNEL("corr_volume_h_chw");
             if (bf)
                 hipLaunchKernelGGL(corr_volume_h_chw<true>, grid, block, 0, s, a, b, out, C, N1, N2, tiles_m, tiles_n);
             else

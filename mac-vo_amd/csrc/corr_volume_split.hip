@@ -1,0 +1,415 @@
+// A5 — all-pairs cost volume of fp32 feature maps on the 16-bit matrix pipe:  SPLIT + STREAMING form  (round 3)
+//
+//   out[b,i,j] = sum_c f1[b,c,i] * f2[b,c,j]      (FlowFormer MemoryEncoder.corr, reached from
+//                                                   Module/Network/FlowFormerCov/flownet.py:26; `.float()` at :27)
+//
+// Why.  The exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the 16-bit MFMA rate: 23.6 GFLOP per 640x480 frame = 150 us
+// at its 157 TFLOP/s peak, and corr_volume_f32_mixed_dma sits at 0.85 of that.  gfx950 has no TF32 path, but the reference itself
+// runs this GEMM in TF32 (torch.backends.cuda.matmul.allow_tf32 / set_float32_matmul_precision("medium"),
+// Module/Frontend/Frontend.py:275-277) or fp16 (MACVO_Fast.yaml:69-76), i.e. with 11-bit operands.  Here every fp32 operand is
+// split into 16-bit pieces whose sum is the operand to ~2^-24 (three bf16 pieces, 8 + 8 + 8 bits: x = p0 + p1 + p2, residuals
+// exact) and the fp32 product is rebuilt from the six piece products with i + j <= 2, accumulated in fp32, smallest first:
+// the dropped terms are O(2^-24 |a||b|), the class of fp32's own rounding; the parity bar is the exact path's
+// (|out - einsum_f64| <= 2e-5 sqrt(C), tests/test_gpu_corr.py).  Six products at the 2.5 PFLOP/s 16-bit rate = 57 us of matrix work
+// per frame next to 29-40 us of output stores (184 MB): the kernel is shaped like corr_volume_h_stream — a fill kernel with a GEMM
+// attached — with three operand planes.
+//
+// Operand PACK (mv_volume_pack, one launch for both feature maps).  fp32 [B,C,N] (CHW, as the reference hands it over) or [B,N,C]
+// is split and written in exactly the order the GEMM consumes it:
+//     packed[b][rb][ks][piece][lane][8 x 16-bit]      rb = row / 32, ks = k / 16, lane = (k / 8 % 2) * 32 + row % 32
+// i.e. one 1-KB unit per (32 rows, 16 k, piece) = one v_mfma_f32_32x32x16 operand fragment for all 64 lanes.  A fragments are
+// then ONE coalesced 1-KB global_load_dwordx4 each, B sub-tiles are contiguous runs that the LDS-DMA copies verbatim (no swizzle:
+// lane-linear 16-B reads are conflict-free), and the GEMM needs neither a layout requirement nor any VALU work.  Rows past N
+// repeat row N - 1 and every pair carries one extra row block holding 32 copies of row N - 1: waves beyond the bottom edge compute
+// duplicates of the last row and store them ON TOP of it (identical values) instead of branching around their stores, which keeps
+// the hand-counted vmcnt arithmetic identical for all waves.  The pack moves 20 MB in and 30 MB out (L2 / Infinity-Cache traffic)
+// and is issued by the frame driver on another stream one frame ahead, off the GEMM stream's critical path.
+//
+// GEMM (corr_volume_split_stream).  Persistent 256-thread workgroups, ONE per CU and one wave per SIMD (the whole-K fragments of
+// three planes are 192 registers: AGPRs), item = 128-row band x 64-column sub-tile:
+//   * a wave owns 32 rows: its A fragments (KS k-steps x NP pieces x 4 registers) stay in registers for a whole band segment;
+//   * B sub-tiles stream through a 3-slot LDS ring in K HALVES (64 columns x C/2 k x NP pieces = 48 KB) by LDS-DMA, two halves
+//     ahead of the MFMAs; one barrier per half;
+//   * per k-step 2 x NQ MFMAs (NQ = 6 piece products, 2 column blocks) against 2 x NP ds_read_b128 and 2 output stores: ~1 filler
+//     per MFMA, so a single wave per SIMD keeps the matrix pipe issuing back to back;
+//   * the 32 stores of item j are interleaved with the MFMAs of item j + 1 (two accumulator sets), DMA / stores / A loads are
+//     inline asm with hand-counted s_waitcnt vmcnt (in-order counter) exactly as in corr_volume_h_stream;
+//   * XCD-aware item order (pair, column region, band, sub-tile): one region's B planes (<= 2 MB) stay in the XCD's L2.
+#include "common.h"
+#include "vol_asm.h"
+#include <type_traits>
+#include <algorithm>
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ operand pack
+// One thread = one 16-byte chunk per piece: (operand, pair b, row block rb, k-step ks, lane).  A wave writes NP contiguous 1-KB
+// units; for CHW input its loads are 8 x (2 x 128 B) coalesced rows, for HWC 2 x float4 per lane.
+template <int NP, bool F16>
+__global__ __launch_bounds__(256) void volume_pack_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                          uint16_t* __restrict__ p1, uint16_t* __restrict__ p2, int B, int C,
+                                                          int N1, int N2, int hwc) {
+    const int op = blockIdx.y;
+    const float* __restrict__ f = op ? f2 : f1;
+    uint16_t* __restrict__ out = op ? p2 : p1;
+    const int N = op ? N2 : N1;
+    const int KS = C >> 4, nrb = ((N + 31) >> 5) + 1;           // + the replica block of row N - 1
+    const long units = (long)B * nrb * KS;                      // (b, rb, ks)
+    const int lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;
+    for (long u = (long)blockIdx.x * 4 + (threadIdx.x >> 6); u < units; u += (long)gridDim.x * 4) {
+        const int ks = (int)(u % KS);
+        const long t = u / KS;
+        const int rb = (int)(t % nrb), b = (int)(t / nrb);
+        const int row = rb == nrb - 1 ? N - 1 : min(rb * 32 + li, N - 1);
+        const int k0 = ks * 16 + kh * 8;
+        float x[8];
+        if (hwc) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(f + ((size_t)b * N + row) * C + k0);
+            const f32x4 lo = src[0], hi = src[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[e] = lo[e]; x[4 + e] = hi[e]; }
+        } else {
+            const float* src = f + ((size_t)b * C + k0) * N + row;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = src[(size_t)e * N];
+        }
+        s16x8 pc[NP];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float r = x[e];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {                      // piece p = round-to-nearest of what is left; residual exact in fp32
+                if (F16) {
+                    const _Float16 h = (_Float16)r;
+                    pc[p][e] = __builtin_bit_cast(short, h);
+                    r -= (float)h;
+                } else {
+                    const __bf16 h = (__bf16)r;
+                    pc[p][e] = __builtin_bit_cast(short, h);
+                    r -= (float)h;
+                }
+            }
+        }
+        s16x8* dst = reinterpret_cast<s16x8*>(out) + (size_t)u * NP * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) dst[p * 64] = pc[p];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GEMM
+// asm loads / stores on accumulator-file registers (gfx90a+: VMEM destinations and MFMA A/B sources may be AGPRs)
+#define MV_STR2(x) #x
+#define MV_STR(x) MV_STR2(x)
+
+template <int NP, bool F16, int KS>
+struct SplitCfg {
+    static constexpr int KH = KS / 2;                  // k-steps per K half
+    static constexpr int NA = KS * NP;                 // A fragment units per wave and band
+    static constexpr int HALF_UNITS = KH * NP;         // 1-KB units of one row block in one K half
+    static constexpr int SLOT_BYTES = 2 * HALF_UNITS * 1024;   // 64 columns = 2 row blocks
+    static constexpr int NSLOT = 3;
+    static constexpr int D = HALF_UNITS / 2;           // DMA pieces per wave and half (4 waves x D = 2 x HALF_UNITS)
+    static constexpr int NQ = NP == 3 ? 6 : 3;         // piece products
+    static constexpr int SPH = 16;                     // output stores per wave and half (32 per item)
+    static constexpr int W_STEADY = SPH + D + SPH;     // ops issued behind the pieces a half waits for, steady state
+    static_assert(W_STEADY <= 63, "vmcnt is a 6-bit counter");
+    static_assert(KS % 2 == 0 && HALF_UNITS % 2 == 0, "");
+};
+
+template <int NP, bool F16, int KS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void corr_volume_split_stream(
+    const uint16_t* __restrict__ pk1, const uint16_t* __restrict__ pk2, float* __restrict__ out, int N1, int N2, int B, int R) {
+    using Cf = SplitCfg<NP, F16, KS>;
+    constexpr int KH = Cf::KH, NA = Cf::NA, HU = Cf::HALF_UNITS, D = Cf::D, NQ = Cf::NQ, NSLOT = Cf::NSLOT;
+    constexpr unsigned SLOT_BYTES = Cf::SLOT_BYTES;
+    extern __shared__ __attribute__((aligned(16))) i32x4 smem_sp[];   // B ring: NSLOT slots of [2 row blocks][KH][NP][64 lanes] x 16 B
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int kh = lane >> 5, li = lane & 31;
+    const int nb = (N1 + 127) >> 7, nc = N2 >> 6;
+    const int nrb1 = ((N1 + 31) >> 5) + 1, nrb2 = ((N2 + 31) >> 5) + 1;   // row blocks per pair incl. the replica block
+    const int per = nb * nc, T = B * per;                                  // T < 2^31 (host-checked)
+    int it, it_end;
+    {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, nj = gridDim.x >> 3;
+        const long lo = (long)x * T / 8, hi = ((long)x + 1) * T / 8;
+        it = (int)(lo + (hi - lo) * j / nj);
+        it_end = (int)(lo + (hi - lo) * (j + 1) / nj);
+    }
+    if (it >= it_end) return;
+    auto reg_c0 = [&](int g) { return (int)((long)g * nc / R); };        // first sub-tile of column region g
+    auto decode = [&](int i, int& b, int& g, int& band, int& c) {        // rare: once per run and per segment
+        b = i / per;
+        int rem = i - b * per;
+        g = 0;
+        while (g + 1 < R && rem >= nb * reg_c0(g + 1)) ++g;
+        rem -= nb * reg_c0(g);
+        const int w = reg_c0(g + 1) - reg_c0(g);
+        band = rem / w;
+        c = reg_c0(g) + (rem - band * w);
+        b = __builtin_amdgcn_readfirstlane(b);
+        g = __builtin_amdgcn_readfirstlane(g);
+        band = __builtin_amdgcn_readfirstlane(band);
+        c = __builtin_amdgcn_readfirstlane(c);
+    };
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem_sp);   // low 32 bits of a flat LDS pointer = LDS byte offset
+    const unsigned lane16 = (unsigned)lane * 16u;
+
+    // ---- B loader (LDS-DMA), two K halves ahead of the MFMAs; all walking state wave-uniform.  A half of a sub-tile is two
+    // contiguous runs of HU units (row blocks 2c, 2c + 1); wave w copies D units of row block 2c + (w >> 1) from offset (w & 1) * D
+    // to the same position of the slot image.
+    int ld_it = it, ld_hh = 0, ld_slot = 0, ld_b, ld_g, ld_band, ld_c, ld_c0, ld_cend;
+    decode(it, ld_b, ld_g, ld_band, ld_c);
+    ld_c0 = reg_c0(ld_g);
+    ld_cend = reg_c0(ld_g + 1);
+    auto src_of = [&](int b, int c) {
+        return reinterpret_cast<const char*>(pk2) + (((size_t)b * nrb2 + 2 * c + (wave >> 1)) * (2 * HU) + (wave & 1) * D) * 1024;
+    };
+    const char* ld_ptr = src_of(ld_b, ld_c);
+    auto issue_half = [&]() __attribute__((always_inline)) {
+        const char* src = ld_ptr + (size_t)ld_hh * (HU * 1024);
+        const unsigned dst = lds0 + (unsigned)ld_slot * SLOT_BYTES + (unsigned)(wave * D) * 1024u;
+#pragma unroll
+        for (int i = 0; i < D; ++i) glds16_s(lane16, src + i * 1024, dst + (unsigned)i * 1024u);
+        ld_slot = ld_slot == NSLOT - 1 ? 0 : ld_slot + 1;
+        if (ld_hh == 0) {
+            ld_hh = 1;
+        } else if (ld_it + 1 < it_end) {         // past the end of the run the last half is simply fetched again
+            ld_hh = 0;
+            ++ld_it;
+            if (++ld_c == ld_cend) {             // next band of the region / next region / next pair
+                if (++ld_band == nb) {
+                    ld_band = 0;
+                    if (++ld_g == R) {
+                        ld_g = 0;
+                        ++ld_b;
+                    }
+                    ld_c0 = reg_c0(ld_g);
+                    ld_cend = reg_c0(ld_g + 1);
+                }
+                ld_c = ld_c0;
+            }
+            ld_ptr = src_of(ld_b, ld_c);
+        }
+    };
+
+    // ---- A fragments: NA coalesced 1-KB units of this wave's row block, whole K, all pieces -> accumulator-file registers.
+    // asm like the DMA: the wait is placed by hand so that the previous segment's last 32 stores can be issued BEHIND these loads
+    // and drain while the next sub-tile is multiplied (vmcnt retires in order; a compiler-tracked load would be waited for with
+    // vmcnt(0)).  The destination counts as defined at the end of the asm statement; the "+a" re-definition behind the hand-placed
+    // wait is where the values become usable (same scheme as corr_volume_h_stream, whose bitwise test guards it; here
+    // test_corr_volume_split_* run multi-segment workgroups).
+    i32x4 afr[NA];
+    auto issue_a = [&](int b, int band) __attribute__((always_inline)) {
+        const int rb = min(band * 4 + wave, nrb1 - 1);           // waves past the bottom edge take the replica block (row N1 - 1 x 32)
+        const char* A = reinterpret_cast<const char*>(pk1) + ((size_t)b * nrb1 + rb) * (size_t)(NA * 1024);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            // 12-bit immediates reach 4 units; the rest of the offset rides on the (uniform) base
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&a"(afr[i]) : "v"(lane16), "s"(A + (i >> 2) * 4096), "n"((i & 3) * 1024) : "memory");
+        }
+    };
+
+    float* O = nullptr;                          // wave-uniform: column 0 of the CURRENT item's output block (row 0 of the pair)
+    unsigned roff[16];                           // per-lane byte offsets of the 16 accumulator rows (C/D layout), fixed for a band segment
+    auto store_r = [&](const f32x16& p0, const f32x16& p1, int r, float* Ob) __attribute__((always_inline)) {
+        asm volatile("global_store_dword %0, %1, %2" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(p0[r]), "s"(Ob) : "memory");
+        asm volatile("global_store_dword %0, %1, %2 offset:128" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(p1[r]), "s"(Ob) : "memory");
+    };
+    int slot = 0;                                // ring slot of the half about to be multiplied
+
+    // piece products, smallest first: (a0,b2) (a1,b1) (a2,b0) (a0,b1) (a1,b0) (a0,b0)   [NP = 2: (a0,b1) (a1,b0) (a0,b0)]
+    constexpr int PA[6] = {0, 1, NP == 3 ? 2 : 0, 0, 1, 0};
+    constexpr int PB[6] = {NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0, 0};
+
+    // one K half of one item: ring upkeep, KH x 2 x NQ MFMAs into (c0, c1); with PREV, SPH stores of (p0, p1) ride between them.
+    // W = how many of this wave's memory operations were issued behind the DMA pieces this half consumes (see SplitCfg).
+    auto half = [&](auto HH, auto WW, auto PREV, f32x16& c0, f32x16& c1, const f32x16& p0, const f32x16& p1) __attribute__((always_inline)) {
+        constexpr int H = decltype(HH)::value;
+        constexpr int W = decltype(WW)::value;
+        constexpr bool HAVE_PREV = decltype(PREV)::value;
+        wait_vmcnt_barrier<W>();                 // behind the barrier all four waves' pieces are in, and everyone has left slot - 1
+        issue_half();                            // half + 2 -> the slot everyone has just left
+        const i32x4* q = smem_sp + (unsigned)slot * (SLOT_BYTES / 16) + lane;
+        if (H == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.f;
+        }
+        i32x4 fb[2][2][NP];                      // [stage][column block][piece]
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) fb[0][j][p] = q[((j * KH + 0) * NP + p) * 64];
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < KH) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) fb[nxt][j][p] = q[((j * KH + ks + 1) * NP + p) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (hipcc otherwise sinks it back)
+#pragma unroll
+            for (int qd = 0; qd < NQ; ++qd) {
+                constexpr int base = NP == 3 ? 0 : 3;
+                const int pa = PA[base + qd], pb = PB[base + qd];
+                const i32x4 a = afr[(H * KH + ks) * NP + pa];
+                if (F16) {
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, fb[cur][0][pb]), c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, fb[cur][1][pb]), c1, 0, 0, 0);
+                } else {
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, fb[cur][0][pb]), c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, fb[cur][1][pb]), c1, 0, 0, 0);
+                }
+                if (HAVE_PREV && qd == NQ / 2) {
+                    constexpr int RPK = 16 / KS;                 // accumulator rows of the previous item stored per k-step
+#pragma unroll
+                    for (int rr = 0; rr < (RPK > 0 ? RPK : 1); ++rr) store_r(p0, p1, (H * KH + ks) * RPK + rr, O - 64);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        slot = slot == NSLOT - 1 ? 0 : slot + 1;
+    };
+    using Yes = std::true_type;
+    using No = std::false_type;
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    auto item = [&](auto W0, auto W1, auto PREV, f32x16& c0, f32x16& c1, const f32x16& p0, const f32x16& p1) __attribute__((always_inline)) {
+        half(H0{}, W0, PREV, c0, c1, p0, p1);
+        half(H1{}, W1, PREV, c0, c1, p0, p1);
+        ++it;
+        O += 64;
+    };
+    auto flush = [&](const f32x16& p0, const f32x16& p1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) store_r(p0, p1, r, O - 64);
+    };
+    static_assert(KS == 16, "store interleave: one accumulator row per k-step");
+    template_unused:;
+    // waits: see the derivation in SplitCfg / DESIGN.md.  first item of a segment: everything older than the 32 flush stores has
+    // landed (hand wait below), no stores ride along; second item: D pieces (+ SPH stores) behind the pieces it consumes; then steady.
+    using WF0 = std::integral_constant<int, 32>;
+    using WF1 = std::integral_constant<int, 32 + D>;
+    using WS0 = std::integral_constant<int, D>;
+    using WS1 = std::integral_constant<int, D + Cf::SPH>;
+    using WW = std::integral_constant<int, Cf::W_STEADY>;
+
+    f32x16 x0, x1, y0, y1;
+    int b, g, band, c0i;
+    decode(it, b, g, band, c0i);
+    issue_a(b, band);
+    issue_half();                                // halves 0 and 1 of the first item -> slots 0, 1
+    issue_half();
+    wait_vmcnt<0>();
+    while (true) {                               // one pass per (pair, region, band) segment of the run
+        const int seg_end = min(it_end, it + (reg_c0(g + 1) - c0i));
+#pragma unroll
+        for (int i = 0; i < NA; ++i) asm volatile("" : "+a"(afr[i]));   // the fragments count as defined only here, behind the hand-placed wait
+        O = out + (size_t)b * N1 * N2 + (size_t)c0i * 64;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            roff[r] = ((unsigned)min(band * 128 + wave * 32 + 4 * kh + (r & 3) + 8 * (r >> 2), N1 - 1) * (unsigned)N2 + li) * 4u;
+        item(WF0{}, WF1{}, No{}, x0, x1, x0, x1);
+        bool in_y = false;
+        if (it < seg_end) {
+            item(WS0{}, WS1{}, Yes{}, y0, y1, x0, x1);
+            in_y = true;
+            while (it + 2 <= seg_end) {
+                item(WW{}, WW{}, Yes{}, x0, x1, y0, y1);
+                item(WW{}, WW{}, Yes{}, y0, y1, x0, x1);
+            }
+            if (it < seg_end) {
+                item(WW{}, WW{}, Yes{}, x0, x1, y0, y1);
+                in_y = false;
+            }
+        }
+        const bool more = it < it_end;           // (uniform) next segment: its A loads go out first, the flush rides behind them
+        // asm accesses straight behind the last MFMAs: "XDL write VGPR -> VMEM read" (11 wait states for an 8-pass MFMA) and the
+        // overwrite of MFMA source registers are software hazards that hipcc's recognizer does not see through inline asm
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+        if (more) {
+            decode(it, b, g, band, c0i);
+            issue_a(b, band);
+        }
+        if (in_y) flush(y0, y1);
+        else flush(x0, x1);
+        if (!more) break;
+        wait_vmcnt<32>();                        // the A loads precede the 32 flush stores
+    }
+    wait_vmcnt<0>();                             // nothing of this workgroup may still be in flight towards its LDS when it retires
+}
+
+static int cu_count() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+
+}  // namespace
+
+static int pieces_of(int mode) { return mode == MV_PACK_BF16X3 ? 3 : 0; }
+
+extern "C" size_t mv_volume_pack_bytes(int B, int C, int N, int mode) {
+    const int np = pieces_of(mode);
+    if (np == 0 || B <= 0 || C <= 0 || (C % 16) || N <= 0) return 0;
+    return (size_t)B * (size_t)((N + 31) / 32 + 1) * (size_t)(C / 16) * (size_t)np * 1024;
+}
+
+extern "C" int mv_volume_pack(const float* f1, const float* f2, void* packed1, void* packed2, int B, int C, int N1, int N2,
+                              int layout, int mode, mvStream_t stream) {
+    MV_CHECK_ARG(f1 && f2 && packed1 && packed2 && B > 0 && N1 > 0 && N2 > 0);
+    MV_CHECK_ARG(layout == MV_LAYOUT_CHW || layout == MV_LAYOUT_HWC);
+    MV_CHECK_ARG(((uintptr_t)f1 & 15) == 0 && ((uintptr_t)f2 & 15) == 0 && ((uintptr_t)packed1 & 15) == 0 && ((uintptr_t)packed2 & 15) == 0);
+    if (pieces_of(mode) == 0 || C <= 0 || (C % 16)) return MV_ERR_UNSUPPORTED;
+    const long units = (long)B * ((std::max(N1, N2) + 31) / 32 + 1) * (C / 16);
+    const int blocks = (int)std::min<long>((units + 3) / 4, 8192);
+    hipLaunchKernelGGL((volume_pack_kernel<3, false>), dim3(blocks, 2), dim3(256), 0, (hipStream_t)stream, f1, f2, (uint16_t*)packed1,
+                       (uint16_t*)packed2, B, C, N1, N2, layout == MV_LAYOUT_HWC ? 1 : 0);
+    return mv_launch_status();
+}
+
+// shapes the streaming GEMM covers (the caller falls back to the exact fp32 kernel otherwise — never less accurate)
+extern "C" int mv_corr_volume_packed_supported(int B, int C, int N1, int N2, int mode) {
+    return pieces_of(mode) == 3 && C == 256 && B > 0 && B <= 65535 && N1 >= 32 && N2 >= 64 && (N2 % 64) == 0 &&
+           ((size_t)N1 * N2) < ((size_t)1 << 30) &&                                               // 32-bit byte offsets inside a pair's block
+           (size_t)B * (size_t)((N1 + 127) / 128) * (size_t)(N2 / 64) < ((size_t)1 << 31);        // int item index
+}
+
+extern "C" int mv_corr_volume_packed(const void* packed1, const void* packed2, float* out, int B, int C, int N1, int N2, int mode,
+                                     mvStream_t stream) {
+    MV_CHECK_ARG(packed1 && packed2 && out);
+    MV_CHECK_ARG(((uintptr_t)packed1 & 15) == 0 && ((uintptr_t)packed2 & 15) == 0);
+    if (!mv_corr_volume_packed_supported(B, C, N1, N2, mode)) return MV_ERR_UNSUPPORTED;
+    using K = SplitCfg<3, false, 16>;
+    const unsigned lds = K::NSLOT * K::SLOT_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)corr_volume_split_stream<3, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    // column regions: one region's B planes (nc / R sub-tiles x 64 rows x C x 2 B x pieces) <= 2 MB of an XCD's 4 MB L2
+    static int regs_env = -1;   // MV_SPLIT_REGIONS: A/B knob
+    if (regs_env < 0) { const char* e = getenv("MV_SPLIT_REGIONS"); regs_env = e ? atoi(e) : 0; }
+    const int nc = N2 / 64;
+    int R = regs_env > 0 ? regs_env : (int)(((size_t)nc * 64 * C * 2 * 3 + (2u << 20) - 1) / (2u << 20));
+    R = std::max(1, std::min(R, nc));
+    const dim3 g((cu_count() & ~7)), blk(256);   // one workgroup per CU, a multiple of 8: one run per XCD
+    hipLaunchKernelGGL((corr_volume_split_stream<3, false, 16>), g, blk, lds, (hipStream_t)stream, (const uint16_t*)packed1,
+                       (const uint16_t*)packed2, out, N1, N2, B, R);
+    return mv_launch_status();
+}

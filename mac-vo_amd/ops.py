@@ -97,6 +97,11 @@ def corr_volume(f1: torch.Tensor, f2: torch.Tensor, layout: str = "chw", out: to
     return out
 
 
+def last_volume_kernel() -> str:
+    """Name of the kernel the last ``corr_volume`` call of this thread dispatched (diagnostics: dispatch tests, bench.py)."""
+    return (L.load().mv_corr_volume_last_kernel() or b"").decode()
+
+
 # ------------------------------------------------------------------------------------------- A23
 def local_corr81(first: torch.Tensor, second: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
     """PWC-Net ``FunctionCorrelation(tenFirst, tenSecond)`` forward (pwc/correlation.py:277-325): ``[B,C,H,W]`` x2 ->

@@ -159,13 +159,22 @@ def test_config2_720p_through_frame_driver(gpu):
     from oracle import se3
     from oracle.pipeline import OracleHotPath
 
+    from macvo_amd import ops
+
     H, W, n_frames = 720, 1280, 3
     cam, frames, _ = synth.make_sequence(n_frames, H, W, C=64, iters=2, seed=12)
-    for dt in (torch.float32, torch.bfloat16):
-        fr_dev = [dict(fr, fmap1=fr["fmap1"].to(dt), fmap2=fr["fmap2"].to(dt)) for fr in frames]
-        fr_cpu = [dict(fr, fmap1=fr["fmap1"].to(dt).float(), fmap2=fr["fmap2"].to(dt).float()) for fr in frames]
+    cam256, frames256, _ = synth.make_sequence(n_frames, H, W, C=256, iters=2, seed=12)
+    # (dtype, layout, frames): fp32 / bf16 CHW at C = 64 (tile kernels), and the configuration of the 720p Fast-mode bench line:
+    # f16 features, HWC, C = 256 -> the streaming kernel `corr_volume_h_stream`
+    for dt, layout, frs, kernel in ((torch.float32, "chw", frames, None), (torch.bfloat16, "chw", frames, "corr_volume_h_chw"),
+                                    (torch.float16, "hwc", frames256, "corr_volume_h_stream")):
+        fr_dev = [dict(fr, fmap1=fr["fmap1"].to(dt), fmap2=fr["fmap2"].to(dt)) for fr in frs]
+        if layout == "hwc":
+            fr_dev = [dict(fr, fmap1=fr["fmap1"].permute(0, 2, 3, 1).contiguous(), fmap2=fr["fmap2"].permute(0, 2, 3, 1).contiguous())
+                      for fr in fr_dev]
+        fr_cpu = [dict(fr, fmap1=fr["fmap1"].to(dt).float(), fmap2=fr["fmap2"].to(dt).float()) for fr in frs]
         ora = OracleHotPath(cam, {})
-        hot = NativeHotPath(Camera(**cam), HotPathConfig(), gpu, keep_extras=True)
+        hot = NativeHotPath(Camera(**cam), HotPathConfig(feature_layout=layout), gpu, keep_extras=True)
         ins = [_inputs(fr, gpu) for fr in fr_dev]
         torch.cuda.synchronize()
         ora.initialize(fr_cpu[0])
@@ -184,6 +193,7 @@ def test_config2_720p_through_frame_driver(gpu):
             d_t, d_r = se3.pose_error(ro["pose"].double(), rh.pose.cpu().double())
             assert d_t <= 1e-4 and d_r <= 1e-4, (dt, t, d_t, d_r)
             assert int(rh.info[0, 1].item()) == ro["steps"]
+        assert kernel is None or ops.last_volume_kernel() == kernel, (dt, layout, ops.last_volume_kernel())
         del hot
         torch.cuda.empty_cache()
 
