@@ -37,6 +37,7 @@ import torch  # noqa: E402
 
 # MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md §Chip-level parameters)
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 MIN_TIMED_LAUNCHES = 200       # the roofline average is taken over at least this many GEMM launches
 RAMP_SECONDS = 1.5             # untimed sustained load before the contract's warm-up: clocks ramp, queues are created
@@ -55,14 +56,18 @@ def parse_args():
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--feat-dtype", choices=["f32", "f16", "bf16"], default="f32")
     ap.add_argument("--layout", choices=["chw", "hwc"], default="chw")
-    ap.add_argument("--volume-precision", choices=["exact", "split3", "split2"], default="exact",
-                    help="fp32 features: exact fp32 MFMA (default) or bf16x3 split (fp32-class accuracy; needs --layout hwc)")
+    ap.add_argument("--volume-precision", choices=["bf16x3", "exact", "split3", "split2"], default="bf16x3",
+                    help="fp32 features: 'bf16x3' (default) = packed three-piece bf16 split, six products on the 16-bit matrix pipe, fp32 "
+                         "accumulate — same parity bar as 'exact', not bitwise (the reference runs this GEMM in TF32, Frontend.py:275-277); "
+                         "'exact' = fp32 MFMA (bitwise fmaf chain; reported as `exact_fp32` beside the default line); split3 / split2 = "
+                         "round-1 tile kernels (need --layout hwc)")
+    ap.add_argument("--exact-steps", type=int, default=60, help="steps of the extra exact-fp32 leg beside the default line; 0 = skip")
     ap.add_argument("--graph", choices=["disp", "reproj", "icp"], default="disp")
     ap.add_argument("--pool", type=int, default=24, help="distinct synthetic frames (closed trajectory) kept in HBM")
     ap.add_argument("--cpu-frames", type=int, default=120, help="frames timed for the CPU baseline (rank 0, N=1 only)")
     ap.add_argument("--parity-frames", type=int, default=48, help="free-running frames compared with the oracle (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the parity leg")
-    ap.add_argument("--config4-steps", type=int, default=12, help="steps of the extra configs[4] leg (32 lanes); 0 = skip")
+    ap.add_argument("--config4-steps", type=int, default=100, help="steps of the extra configs[4] leg (32 lanes); 0 = skip")
     ap.add_argument("--graphs", action="store_true", help="replay the decoder-side segment (12 lookups + epilogue + selector) as a hipGraph (measured slower than eager launches on ROCm 7.2: 2.46 k vs 2.60 k fps)")
     ap.add_argument("--driver", choices=["native", "python"], default="native",
                     help="host-side frame sequencing: the C++ driver (mv_frame_pipe_*) or the Python loop over the per-op entry points")
@@ -134,14 +139,17 @@ def roofline_of(ms, args, lanes, n_q, C, timed_region_launches, traffic=None):
     avg_s = sum(ms) / len(ms) / 1e3
     common = {"avg_launch_us": round(avg_s * 1e6, 2), "launches": len(ms), "launches_in_timed_region": timed_region_launches,
               "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes}
-    if args.feat_dtype == "f32" and args.volume_precision in ("split3", "split2"):
-        ach = flops / avg_s / 1e12
-        nprod = 6.0 if args.volume_precision == "split3" else 3.0
-        eff_peak = 2500.0 / nprod   # bf16 MFMA products executed per algorithmic product at the 2.5 PFLOP/s dense bf16 peak
-        return {"bound": "mfma", "achieved": round(ach, 2), "peak": round(eff_peak, 1), "unit": "TFLOP/s",
-                "frac": round(ach / eff_peak, 4), "traffic": None,
-                "kernel": f"{args.volume_precision} pre-pass + corr_volume_bf16x3_hwc<{int(nprod) // 3 + 1}>", **common,
-                "note": "achieved = algorithmic fp32 FLOPs / time; peak = 2500 TFLOP/s bf16 dense / executed products per algorithmic product"}
+    prec = getattr(args, "_precision", args.volume_precision)
+    if args.feat_dtype == "f32" and prec in ("bf16x3", "split3", "split2"):
+        nprod = 3.0 if prec == "split2" else 6.0
+        ach = nprod * flops / avg_s / 1e12          # bf16 MFMA FLOPs the kernel executes: `nprod` piece products per algorithmic product
+        return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": traffic,
+                "kernel": "corr_volume_split_stream<bf16x3>" if prec == "bf16x3" else f"{prec} pre-pass + corr_volume_bf16x3_hwc<{int(nprod) // 3 + 1}>",
+                **common, "executed_flops_per_launch": nprod * flops, "algorithmic_tflops": round(flops / avg_s / 1e12, 2),
+                "note": f"achieved = {int(nprod)} bf16 piece products per algorithmic fp32 product x algorithmic FLOPs / time, against the dense bf16 "
+                        "MFMA peak (2.5 PFLOP/s; with N(0,1) operands the chip's power limit holds a bare v_mfma_f32_32x32x16_bf16 stream at "
+                        "~1.89 PFLOP/s = 0.76, tools/scratch/mfma16_probe.*); the operand pack runs on another stream and is not in this time"}
     if args.feat_dtype == "f32":
         ach = flops / avg_s / 1e12
         return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -216,8 +224,9 @@ def main():
             return frames
         return [stack_lanes([frames[(t + l) % args.pool] for l in range(lanes)]) for t in range(args.pool)]
 
-    def make_pipe(lanes, seed):
-        cfg = HotPathConfig(graph_type=args.graph, feature_layout=args.layout, volume_precision=args.volume_precision,
+    def make_pipe(lanes, seed, precision=None):
+        cfg = HotPathConfig(graph_type=args.graph, feature_layout=args.layout,
+                            volume_precision=(precision or args.volume_precision) if args.feat_dtype == "f32" else "exact",
                             use_graphs=use_graphs)
         if native:
             gens = None if lanes == 1 else [torch.Generator().manual_seed(seed + l) for l in range(lanes)]
@@ -228,10 +237,10 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def measure(lanes, steps, warmup, seed, with_events):
+    def measure(lanes, steps, warmup, seed, with_events, precision=None):
         """W untimed + K timed steps of an L-lane pipe.  Returns (elapsed s, poses, per-launch GEMM ms, launches in region)."""
         batches = lane_batches(lanes)
-        hot = make_pipe(lanes, seed)
+        hot = make_pipe(lanes, seed, precision)
         torch.manual_seed(seed)  # the selector consumes the global CPU generator (reference behaviour) when lanes == 1
         hot.initialize(batches[0])
         t_idx = 1
@@ -316,6 +325,13 @@ def main():
     # (scripts/pmc_gpu.sh -> profiles/*_pmc_corr_volume.json; PMC passes cannot be mixed into this run)
     traffic = None
     try:
+        if (H, W, C, args.lanes) == (480, 640, 256, 1) and args.feat_dtype == "f32" and args.volume_precision == "bf16x3":
+            path = os.path.join(ROOT, "profiles", "r03_pmc_corr_volume_split.json")
+            if os.path.exists(path):
+                pm = json.load(open(path))
+                key = next((k for k in pm if k.startswith("corr_volume_split_stream")), None)
+                if key is not None:
+                    traffic = pm[key]["_derived"]["traffic_bytes_per_launch"]
         if (H, W, C, args.lanes) == (480, 640, 256, 1) and args.feat_dtype == "f32" and args.volume_precision == "exact":
             for name in ("r02_pmc_corr_volume.json", "r01_pmc_corr_volume.json"):
                 path = os.path.join(ROOT, "profiles", name)
@@ -335,25 +351,48 @@ def main():
     except Exception:  # noqa: BLE001
         traffic = None
     roofline = roofline_of(ms, args, args.lanes, n_q, C, in_region, traffic) if ms else None
-    if roofline is not None and rank == 0 and args.volume_precision == "exact":
-        # the same kernel with the GPU to itself (back-to-back launches, HIP events): what the co-running lookups / selector /
-        # backend kernels of the neighbouring frames cost it inside the pipeline is the difference to avg_launch_us above.
-        # ~60 ms of launches first: after a few ms of idle the clocks need ~40 ms of load to come back (222 -> 190 us measured)
-        b0 = lane_batches(args.lanes)[0]
-        vol = ops.corr_volume(b0.fmap1, b0.fmap2, layout=args.layout)
-        n_warm, n_iso = max(20, 300 // args.lanes), max(10, 100 // args.lanes)
+    def isolated_us(lanes, precision):
+        """The dominant kernel with the GPU to itself (back-to-back launches, HIP events): what the co-running lookups / selector /
+        backend kernels of the neighbouring frames cost it inside the pipeline is the difference to avg_launch_us.  ~60 ms of
+        launches first: after a few ms of idle the clocks need ~40 ms of load to come back (222 -> 190 us measured)."""
+        b0 = lane_batches(lanes)[0]
+        vol = ops.corr_volume(b0.fmap1, b0.fmap2, layout=args.layout, precision=precision)
+        if precision == "bf16x3" and ops.last_volume_kernel().startswith("corr_volume_split"):
+            pk = ops.volume_pack(b0.fmap1, b0.fmap2, args.layout)       # the GEMM alone: the pack is a separate launch on another stream
+            Bp = b0.fmap1.shape[0]
+            launch = lambda: ops.corr_volume_packed(pk[0], pk[1], Bp, C, n_q, n_q, out=vol)  # noqa: E731
+        else:
+            launch = lambda: ops.corr_volume(b0.fmap1, b0.fmap2, layout=args.layout, out=vol, precision=precision)  # noqa: E731
+        n_warm, n_iso = max(20, 300 // lanes), max(10, 100 // lanes)
         for _ in range(n_warm):
-            ops.corr_volume(b0.fmap1, b0.fmap2, layout=args.layout, out=vol)
+            launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(n_iso):
-            ops.corr_volume(b0.fmap1, b0.fmap2, layout=args.layout, out=vol)
+            launch()
         e1.record()
         torch.cuda.synchronize()
-        iso_us = e0.elapsed_time(e1) * 1e3 / n_iso
+        return e0.elapsed_time(e1) * 1e3 / n_iso
+
+    if roofline is not None and rank == 0 and args.feat_dtype == "f32" and args.volume_precision in ("exact", "bf16x3"):
+        iso_us = isolated_us(args.lanes, args.volume_precision)
         roofline["isolated_avg_launch_us"] = round(iso_us, 2)
         roofline["isolated_frac"] = round(roofline["frac"] * roofline["avg_launch_us"] / iso_us, 4)
-        del vol
+
+    # ---- the exact-fp32 volume beside the default line (VERDICT r2 #3): same stream, same steps definition, fp32 MFMA kernel
+    exact_leg = None
+    if rank == 0 and world == 1 and native and args.feat_dtype == "f32" and args.volume_precision == "bf16x3" and args.exact_steps > 0:
+        args._precision = "exact"
+        ee, _, mse, ine = measure(args.lanes, args.exact_steps, 5, 1234, not args.no_kernel_events, precision="exact")
+        exact_leg = {"what": "the same stream with volume_precision='exact': v_mfma_f32_32x32x2_f32, bitwise an fmaf chain (round-2 default)",
+                     "value": round(args.lanes * args.exact_steps / ee, 2), "unit": "stereo frames/s", "steps": args.exact_steps, "warmup": 5,
+                     "ms_per_step": round(ee / args.exact_steps * 1e3, 4),
+                     "roofline": roofline_of(mse, args, args.lanes, n_q, C, ine) if mse else None}
+        if exact_leg["roofline"] is not None:
+            iso = isolated_us(args.lanes, "exact")
+            exact_leg["roofline"]["isolated_avg_launch_us"] = round(iso, 2)
+            exact_leg["roofline"]["isolated_frac"] = round(exact_leg["roofline"]["frac"] * exact_leg["roofline"]["avg_launch_us"] / iso, 4)
+        del args._precision
 
     # ---- CPU baseline (oracle pipeline, torch-CPU ops shaped like the reference) on a bounded sample + free-running parity
     cpu_baseline = parity = None
@@ -386,7 +425,7 @@ def main():
                                   f"{csec:.1f} s"}
         # free-running parity: the HIP path on the same frames from the same start, chained on its OWN poses (no teacher
         # forcing), same CPU generator seed -> keypoints must be identical, poses within 1e-4; RTE per MetricsSeq.py:9-16
-        if native and args.volume_precision == "exact" and args.feat_dtype == "f32":
+        if native and args.volume_precision in ("exact", "bf16x3") and args.feat_dtype == "f32":
             n_par = min(len(ora_track), max(args.parity_frames, 2))
             hot = make_pipe(1, 0)
             torch.manual_seed(1234)
@@ -414,9 +453,9 @@ def main():
     # ---- configs[4]: batch-32 frames per GPU (B = 64 pairs per GEMM) — a short second measurement, N = 1 only
     config4 = None
     if rank == 0 and world == 1 and native and args.config4_steps > 0 and args.lanes == 1 and (H, W) == (480, 640):
-        e4, _, ms4, in4 = measure(32, args.config4_steps, 3, 4321, not args.no_kernel_events)
+        e4, _, ms4, in4 = measure(32, args.config4_steps, 10, 4321, not args.no_kernel_events)
         config4 = {"workload": "configs[4]: batch-32 640x480 frames per GPU = 32 lanes, one cost-volume GEMM of B = 64 pairs per step",
-                   "value": round(32 * args.config4_steps / e4, 2), "unit": "stereo frames/s", "steps": args.config4_steps, "warmup": 3,
+                   "value": round(32 * args.config4_steps / e4, 2), "unit": "stereo frames/s", "steps": args.config4_steps, "warmup": 10,
                    "ms_per_step": round(e4 / args.config4_steps * 1e3, 4),
                    "roofline": roofline_of(ms4, args, 32, n_q, C, in4) if ms4 else None}
 
@@ -485,7 +524,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"f32": "f32 (volume/lookup/covariance) + f64 (PGO)", "f16": "f16 in / f32 acc (volume) + f32 + f64 (PGO)",
+            "dtype": {"f32": ("f32 via bf16x3 (volume: fp32 operands split into three bf16 pieces, six products, fp32 accumulate) + f32 "
+                              "(lookup/covariance) + f64 (PGO)" if args.volume_precision == "bf16x3" else
+                              "f32 (volume/lookup/covariance) + f64 (PGO)"),
+                      "f16": "f16 in / f32 acc (volume) + f32 + f64 (PGO)",
                       "bf16": "bf16 in / f32 acc (volume) + f32 + f64 (PGO)"}[args.feat_dtype],
             "data": "synthetic (seeded planar-scene stereo stream, random feature maps; no weights/datasets available)",
             "rte_vs_oracle": None if parity is None else parity["rte_vs_oracle"]["mean"],
@@ -499,6 +541,7 @@ def main():
                        "excluded": "learned FlowFormer layers (source + weights absent from the reference checkout)",
                        "parallelism": f"{world * args.lanes} independent sequence(s), {args.lanes} per GPU; one all_gather of poses + timestamps"},
             "roofline": roofline,
+            "exact_fp32": exact_leg,
             "cpu_baseline": cpu_baseline,
             "parity": parity,
             "config4": config4,

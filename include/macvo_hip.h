@@ -40,9 +40,11 @@ enum {
     MV_BF16 = 2,
     MV_BF16X3 = 3,     /* fp32 operands pre-split by mv_split_bf16x3 into 3 bf16 planes; 6 bf16 MFMA products, fp32
                           accumulate: fp32-class accuracy (dropped terms O(2^-24)), not bitwise; layout HWC only     */
-    MV_BF16X2 = 4      /* the same planes, but only the two leading pieces (16 significant bits) and the 3 products
+    MV_BF16X2 = 4,     /* the same planes, but only the two leading pieces (16 significant bits) and the 3 products
                           a0b1 + a1b0 + a0b0: relative error ~2^-16, finer than TF32 — the class the reference's fast
                           frontend runs this GEMM in (allow_tf32, Module/Frontend/Frontend.py:275-277); layout HWC only */
+    MV_PACK_BF16X3 = 5 /* `mode` of mv_volume_pack / mv_corr_volume_packed: fp32 operands split into three bf16 pieces and
+                          written in MFMA-fragment order; six piece products, fp32 accumulate (fp32-class, as MV_BF16X3) */
 };
 
 /* feature-map memory layouts accepted by mv_corr_volume */
@@ -75,6 +77,26 @@ int mv_corr_volume(const void* f1, const void* f2, float* out, int B, int C, int
 
 /* fp32 -> three bf16 planes (hi, mid, lo; residuals exact): planes[3][n] (uint16 bf16 bits), n % 4 == 0. */
 int mv_split_bf16x3(const float* x, void* planes, size_t n, mvStream_t stream);
+/* -------------------------------------------------------------------------------------------
+ * A5, split + streaming form (csrc/corr_volume_split.hip): the same volume from fp32 feature maps on the 16-bit matrix pipe.
+ * gfx950 has no TF32 MFMA; the reference runs this GEMM in TF32 / fp16 (Module/Frontend/Frontend.py:275-277,
+ * Config/Experiment/MACVO/MACVO_Fast.yaml:69-76).  mode MV_PACK_BF16X3: x = p0 + p1 + p2 (bf16 pieces, residuals exact), product
+ * rebuilt from the six piece products with i + j <= 2 — same parity bar as the exact fp32 path, not bitwise.
+ *
+ * mv_volume_pack       both feature maps ([B,C,N] for MV_LAYOUT_CHW, [B,N,C] for MV_LAYOUT_HWC, fp32) -> packed operands
+ *                      [B][ceil(N/32)+1 row blocks][C/16 k-steps][pieces][64 lanes][8 x 16 bit], one launch;
+ *                      mv_volume_pack_bytes(B, C, N, mode) bytes each (0 = unsupported mode / shape).
+ * mv_corr_volume_packed  out[b,i,j] fp32 [B,N1,N2] from two packed operands (C == 256, N2 % 64 == 0, N1*N2 < 2^30:
+ *                      mv_corr_volume_packed_supported; MV_ERR_UNSUPPORTED otherwise — callers then use mv_corr_volume(MV_F32)).
+ * Two entry points because the pack needs nothing but the feature maps: the frame driver issues it on another stream one
+ * frame ahead of the GEMM. */
+size_t mv_volume_pack_bytes(int B, int C, int N, int mode);
+int mv_volume_pack(const float* f1, const float* f2, void* packed1, void* packed2, int B, int C, int N1, int N2, int layout,
+                   int mode, mvStream_t stream);
+int mv_corr_volume_packed_supported(int B, int C, int N1, int N2, int mode);
+int mv_corr_volume_packed(const void* packed1, const void* packed2, float* out, int B, int C, int N1, int N2, int mode,
+                          mvStream_t stream);
+
 /* Diagnostics: name of the kernel the calling thread's last mv_corr_volume dispatched ("" before the first call); the
  * string is static.  Used by the dispatch tests and by bench.py to name the kernel its roofline line is about. */
 const char* mv_corr_volume_last_kernel(void);
@@ -476,7 +498,10 @@ typedef struct {
     int32_t radius;            /* lookup radius (4) */
     int32_t feat_dtype;        /* MV_F32 | MV_F16 | MV_BF16 */
     int32_t layout;            /* MV_LAYOUT_* of the feature maps */
-    int32_t volume_split;      /* 0 | 3 | 2: fp32 HWC features split on the device, multiplied as MV_BF16X3 / MV_BF16X2 */
+    int32_t volume_split;      /* 0 exact fp32 | MV_PACK_BF16X3 (5): fp32 features of either layout packed on the device
+                                  (mv_volume_pack, beside the previous frame's GEMM) + mv_corr_volume_packed, shapes it does not
+                                  cover run the exact kernel | 3 | 2: fp32 HWC features through the round-1 plane split, multiplied
+                                  as MV_BF16X3 / MV_BF16X2 */
     int32_t selector_mode;     /* MV_KP_NODEPTH | MV_KP_FULL */
     int32_t kp_kernel_size, kp_mask_width;
     int32_t num_point;         /* keypoints per frame (200) */

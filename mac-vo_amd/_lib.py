@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmacvo_hip.so")
 
 MV_OK = 0
-MV_F32, MV_F16, MV_BF16, MV_BF16X3, MV_BF16X2 = 0, 1, 2, 3, 4
+MV_F32, MV_F16, MV_BF16, MV_BF16X3, MV_BF16X2, MV_PACK_BF16X3 = 0, 1, 2, 3, 4, 5
 MV_LAYOUT_CHW, MV_LAYOUT_HWC = 0, 1
 MV_KP_NODEPTH, MV_KP_FULL, MV_KP_MAPPING = 0, 1, 2
 MV_GRAPH_ICP, MV_GRAPH_REPROJ, MV_GRAPH_DISP = 0, 1, 2
@@ -93,6 +93,10 @@ SIGNATURES = {
     "mv_corr_volume": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv_split_bf16x3": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "mv_corr_volume_last_kernel": (C.c_char_p, []),
+    "mv_volume_pack_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mv_volume_pack": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mv_corr_volume_packed_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mv_corr_volume_packed": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv_corr_lookup": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv_frontend_epilogue": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                        _P, _P, _P, _P, _P, _P, _P, _P]),

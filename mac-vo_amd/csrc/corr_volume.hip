@@ -1567,6 +1567,7 @@ static unsigned vol_lds_bytes() {   // dynamic LDS request that admits exactly k
 // its roofline line is about)
 static thread_local const char* g_last_vol_kernel = "";
 extern "C" const char* mv_corr_volume_last_kernel(void) { return g_last_vol_kernel; }
+void mv_note_volume_kernel(const char* name) { g_last_vol_kernel = name; }   // (library-internal: corr_volume_split.hip)
 #define MV_VOL_KERNEL(name) (g_last_vol_kernel = (name))
 
 // the streaming kernels number their (pair, 128-row band, 64-column sub-tile) items with an int

@@ -105,10 +105,7 @@ __global__ __launch_bounds__(256) void volume_pack_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ GEMM
-// asm loads / stores on accumulator-file registers (gfx90a+: VMEM destinations and MFMA A/B sources may be AGPRs)
-#define MV_STR2(x) #x
-#define MV_STR(x) MV_STR2(x)
-
+// (asm loads / stores below work on accumulator-file registers: on gfx90a+ VMEM data operands and MFMA A/B sources may be AGPRs)
 template <int NP, bool F16, int KS>
 struct SplitCfg {
     static constexpr int KH = KS / 2;                  // k-steps per K half
@@ -118,11 +115,42 @@ struct SplitCfg {
     static constexpr int NSLOT = 3;
     static constexpr int D = HALF_UNITS / 2;           // DMA pieces per wave and half (4 waves x D = 2 x HALF_UNITS)
     static constexpr int NQ = NP == 3 ? 6 : 3;         // piece products
-    static constexpr int SPH = 16;                     // output stores per wave and half (32 per item)
-    static constexpr int W_STEADY = SPH + D + SPH;     // ops issued behind the pieces a half waits for, steady state
+    static constexpr int SPH = 16;                     // output stores per wave and half (32 per item): 2 behind each k-step
+    // LDS-DMA pieces of a half: PH straight behind the barrier, the rest spread over the k-steps (at most 2 per k-step)
+    static constexpr int PH = D >= 12 ? 3 : 2;
+    static constexpr int pieces_in(int ks) { return (D - PH) / KH + (ks < (D - PH) % KH ? 1 : 0); }
+    static constexpr int first_piece(int ks) { return PH + ks * ((D - PH) / KH) + (ks < (D - PH) % KH ? ks : (D - PH) % KH); }
+    static constexpr int last_piece_ks() { int k = 0; for (int i = 0; i < KH; ++i) if (pieces_in(i) > 0) k = i; return k; }
+    // vmcnt arithmetic (in-order counter).  The pieces of half h are issued inside half h - 2; its last piece goes out in k-step
+    // last_piece_ks(), BEHIND that k-step's two stores.  Behind that last piece the wave issues: the stores of the remaining
+    // k-steps of half h - 2, then the D pieces and SPH stores of half h - 1.  "vmcnt <= that number" at the barrier of half h
+    // therefore means the pieces have landed.  Without stores in flight (first / second item of a segment) the counts shrink.
+    static constexpr int STORES_BEHIND_LAST_PIECE = 2 * (KH - 1 - last_piece_ks());
+    static constexpr int W_STEADY = STORES_BEHIND_LAST_PIECE + D + SPH;
     static_assert(W_STEADY <= 63, "vmcnt is a 6-bit counter");
     static_assert(KS % 2 == 0 && HALF_UNITS % 2 == 0, "");
 };
+
+#ifdef MV_SPLIT_PROBE
+#define MV_SPLIT_PROBE_SLACK 2      // the stamp store of the probe build is one more memory operation per item
+#else
+#define MV_SPLIT_PROBE_SLACK 0
+#endif
+// Timing probes (tools/scratch/split_variants.sh builds the library with -DMV_SPLIT_PROBE): MV_SPLIT_DBG=<bits> knocks pieces of the
+// kernel out at run time — 1 stores, 2 LDS-DMA, 4 barriers + waits, 8 B-fragment reads — results are then wrong by design.
+#ifdef MV_SPLIT_PROBE
+__constant__ int g_split_dbg = 0;
+__constant__ long long* g_split_stamps = nullptr;   // [workgroup][wave][64 items][8] s_memtime stamps (MV_SPLIT_DBG bit 16)
+#ifdef MV_SPLIT_KNOCK        // compile-time knock-outs (no run-time branches in the stream): -DMV_SPLIT_KNOCK=<bits>
+#define DBG(bit) ((bit) == 16 ? (g_split_dbg & 16) : ((MV_SPLIT_KNOCK) & (bit)))
+#else
+#define DBG(bit) (g_split_dbg & (bit))
+#endif
+#define STAMP(i) do { if (DBG(16)) stamps[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DBG(bit) false
+#define STAMP(i) ((void)0)
+#endif
 
 template <int NP, bool F16, int KS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void corr_volume_split_stream(
@@ -174,11 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         return reinterpret_cast<const char*>(pk2) + (((size_t)b * nrb2 + 2 * c + (wave >> 1)) * (2 * HU) + (wave & 1) * D) * 1024;
     };
     const char* ld_ptr = src_of(ld_b, ld_c);
-    auto issue_half = [&]() __attribute__((always_inline)) {
-        const char* src = ld_ptr + (size_t)ld_hh * (HU * 1024);
-        const unsigned dst = lds0 + (unsigned)ld_slot * SLOT_BYTES + (unsigned)(wave * D) * 1024u;
-#pragma unroll
-        for (int i = 0; i < D; ++i) glds16_s(lane16, src + i * 1024, dst + (unsigned)i * 1024u);
+    auto advance_loader = [&]() __attribute__((always_inline)) {   // behind the last piece of a half
         ld_slot = ld_slot == NSLOT - 1 ? 0 : ld_slot + 1;
         if (ld_hh == 0) {
             ld_hh = 1;
@@ -200,6 +224,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             ld_ptr = src_of(ld_b, ld_c);
         }
     };
+    auto issue_half = [&]() __attribute__((always_inline)) {       // prologue form: the D pieces as one block
+        const char* src = ld_ptr + (size_t)ld_hh * (HU * 1024);
+        const unsigned dst = lds0 + (unsigned)ld_slot * SLOT_BYTES + (unsigned)(wave * D) * 1024u;
+#pragma unroll
+        for (int i = 0; i < D; ++i) glds16_s(lane16, src + i * 1024, dst + (unsigned)i * 1024u);
+        advance_loader();
+    };
 
     // ---- A fragments: NA coalesced 1-KB units of this wave's row block, whole K, all pieces -> accumulator-file registers.
     // asm like the DMA: the wait is placed by hand so that the previous segment's last 32 stores can be issued BEHIND these loads
@@ -220,11 +251,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     float* O = nullptr;                          // wave-uniform: column 0 of the CURRENT item's output block (row 0 of the pair)
     unsigned roff[16];                           // per-lane byte offsets of the 16 accumulator rows (C/D layout), fixed for a band segment
+    // one output store: accumulator row r of column block j; data straight from the accumulator file ("a": the MFMA results never
+    // visit a VGPR)
+    auto store_j = [&](const f32x16& pj, int r, int j, float* Ob) __attribute__((always_inline)) {
+        if (DBG(1)) {                            // (probe builds only) keep the accumulators alive without storing them
+            asm volatile("" ::"a"(pj[r]));
+            return;
+        }
+        if (j == 0) asm volatile("global_store_dword %0, %1, %2" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "a"(pj[r]), "s"(Ob) : "memory");
+        else asm volatile("global_store_dword %0, %1, %2 offset:128" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "a"(pj[r]), "s"(Ob) : "memory");
+    };
     auto store_r = [&](const f32x16& p0, const f32x16& p1, int r, float* Ob) __attribute__((always_inline)) {
-        asm volatile("global_store_dword %0, %1, %2" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(p0[r]), "s"(Ob) : "memory");
-        asm volatile("global_store_dword %0, %1, %2 offset:128" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(p1[r]), "s"(Ob) : "memory");
+        store_j(p0, r, 0, Ob);
+        store_j(p1, r, 1, Ob);
     };
     int slot = 0;                                // ring slot of the half about to be multiplied
+#ifdef MV_SPLIT_PROBE
+    long long stamps[6] = {0, 0, 0, 0, 0, 0};
+    int n_stamped = 0;
+#endif
 
     // piece products, smallest first: (a0,b2) (a1,b1) (a2,b0) (a0,b1) (a1,b0) (a0,b0)   [NP = 2: (a0,b1) (a1,b0) (a0,b0)]
     constexpr int PA[6] = {0, 1, NP == 3 ? 2 : 0, 0, 1, 0};
@@ -232,53 +277,79 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // one K half of one item: ring upkeep, KH x 2 x NQ MFMAs into (c0, c1); with PREV, SPH stores of (p0, p1) ride between them.
     // W = how many of this wave's memory operations were issued behind the DMA pieces this half consumes (see SplitCfg).
+    //
+    // With ONE wave per SIMD every instruction that is not an MFMA has to fit into the 32-cycle shadow of one: measured on this
+    // kernel (tools/scratch/split_variants.sh), each class of filler issued in bursts cost the matrix pipe ~5 % (B-fragment reads,
+    // stores, DMA pieces: 122.6 -> 117 / 116 / 115 us when knocked out, 102 us with all of them gone; in-kernel stamps: 49 cycles
+    // per MFMA instead of 32).  So the fillers are placed ONE BY ONE behind individual MFMAs ("slots", 2 NQ per k-step):
+    //   slots 0 .. 2 NP - 1   one B-fragment read each for the NEXT k-step,
+    //   slots 2 NP, 2 NP + 1  the two output stores of the previous item this k-step carries,
+    //   slots 2 NP + 2, + 4   an LDS-DMA piece of half + 2 (the D pieces are spread over the whole half; the first ones go out
+    //                         straight behind the barrier, in the shadow of the first fragment reads' LDS latency).
     auto half = [&](auto HH, auto WW, auto PREV, f32x16& c0, f32x16& c1, const f32x16& p0, const f32x16& p1) __attribute__((always_inline)) {
         constexpr int H = decltype(HH)::value;
         constexpr int W = decltype(WW)::value;
         constexpr bool HAVE_PREV = decltype(PREV)::value;
-        wait_vmcnt_barrier<W>();                 // behind the barrier all four waves' pieces are in, and everyone has left slot - 1
-        issue_half();                            // half + 2 -> the slot everyone has just left
+        STAMP(H * 3 + 0);
+        if (!DBG(4)) wait_vmcnt_barrier<(W > 2 ? W - (MV_SPLIT_PROBE_SLACK) : W)>();    // behind the barrier all four waves' pieces are in, and everyone has left slot - 1
+        STAMP(H * 3 + 1);
+        const char* src = ld_ptr + (size_t)ld_hh * (HU * 1024);   // half + 2 -> the slot everyone has just left
+        const unsigned dst = lds0 + (unsigned)ld_slot * SLOT_BYTES + (unsigned)(wave * D) * 1024u;
+        auto piece = [&](int pi) __attribute__((always_inline)) {
+            if (!DBG(2)) glds16_s(lane16, src + pi * 1024, dst + (unsigned)pi * 1024u);
+            if (pi == D - 1) advance_loader();
+        };
         const i32x4* q = smem_sp + (unsigned)slot * (SLOT_BYTES / 16) + lane;
-        if (H == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.f;
-        }
         i32x4 fb[2][2][NP];                      // [stage][column block][piece]
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int p = 0; p < NP; ++p) fb[0][j][p] = q[((j * KH + 0) * NP + p) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pi = 0; pi < Cf::PH; ++pi) piece(pi);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KH; ++ks) {
             const int cur = ks & 1, nxt = cur ^ 1;
-            if (ks + 1 < KH) {
+            const int npk = Cf::pieces_in(ks), pk0 = Cf::first_piece(ks);     // (compile-time after unrolling)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) fb[nxt][j][p] = q[((j * KH + ks + 1) * NP + p) * 64];
-            }
-            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (hipcc otherwise sinks it back)
-#pragma unroll
-            for (int qd = 0; qd < NQ; ++qd) {
+            for (int sl = 0; sl < 2 * NQ; ++sl) {
+                const int qd = sl >> 1, jb = sl & 1;
                 constexpr int base = NP == 3 ? 0 : 3;
                 const int pa = PA[base + qd], pb = PB[base + qd];
                 const i32x4 a = afr[(H * KH + ks) * NP + pa];
-                if (F16) {
-                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, fb[cur][0][pb]), c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, fb[cur][1][pb]), c1, 0, 0, 0);
-                } else {
-                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, fb[cur][0][pb]), c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, fb[cur][1][pb]), c1, 0, 0, 0);
-                }
-                if (HAVE_PREV && qd == NQ / 2) {
-                    constexpr int RPK = 16 / KS;                 // accumulator rows of the previous item stored per k-step
+                f32x16& c = jb ? c1 : c0;
+                if (H == 0 && ks == 0 && qd == 0) {      // the first product of an item starts its accumulators (C = 0 operand)
+                    f32x16 z;
 #pragma unroll
-                    for (int rr = 0; rr < (RPK > 0 ? RPK : 1); ++rr) store_r(p0, p1, (H * KH + ks) * RPK + rr, O - 64);
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    if (F16) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, fb[cur][jb][pb]), z, 0, 0, 0);
+                    else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, fb[cur][jb][pb]), z, 0, 0, 0);
+                } else {
+                    if (F16) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, fb[cur][jb][pb]), c, 0, 0, 0);
+                    else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, fb[cur][jb][pb]), c, 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- the filler of this slot
+                if (sl < 2 * NP) {
+                    if (ks + 1 < KH) {
+                        const int j2 = sl / NP, p2 = sl % NP;
+                        fb[nxt][j2][p2] = DBG(8) ? fb[cur][j2][p2] : q[((j2 * KH + ks + 1) * NP + p2) * 64];
+                    }
+                } else if (sl == 2 * NP || sl == 2 * NP + 1) {
+                    if (HAVE_PREV) store_j(sl == 2 * NP ? p0 : p1, H * KH + ks, sl - 2 * NP, O - 64);   // one accumulator row per k-step
+                    if (sl == 2 * NQ - 1 && npk > 0) piece(pk0);                 // (NQ = 3: the last slot also carries the k-step's piece)
+                } else if (sl == 2 * NP + 2) {
+                    if (npk > 0) piece(pk0);
+                } else if (sl == 2 * NP + 4) {
+                    if (npk > 1) piece(pk0 + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         slot = slot == NSLOT - 1 ? 0 : slot + 1;
+        STAMP(H * 3 + 2);
     };
     using Yes = std::true_type;
     using No = std::false_type;
@@ -287,6 +358,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto item = [&](auto W0, auto W1, auto PREV, f32x16& c0, f32x16& c1, const f32x16& p0, const f32x16& p1) __attribute__((always_inline)) {
         half(H0{}, W0, PREV, c0, c1, p0, p1);
         half(H1{}, W1, PREV, c0, c1, p0, p1);
+#ifdef MV_SPLIT_PROBE
+        if (DBG(16) && lane == 0 && n_stamped < 64) {
+            long long* o = g_split_stamps + (((size_t)blockIdx.x * 4 + wave) * 64 + n_stamped) * 8;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) o[i] = stamps[i];
+            o[6] = it;
+        }
+        ++n_stamped;
+#endif
         ++it;
         O += 64;
     };
@@ -295,7 +375,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int r = 0; r < 16; ++r) store_r(p0, p1, r, O - 64);
     };
     static_assert(KS == 16, "store interleave: one accumulator row per k-step");
-    template_unused:;
     // waits: see the derivation in SplitCfg / DESIGN.md.  first item of a segment: everything older than the 32 flush stores has
     // landed (hand wait below), no stores ride along; second item: D pieces (+ SPH stores) behind the pieces it consumes; then steady.
     using WF0 = std::integral_constant<int, 32>;
@@ -362,6 +441,14 @@ static int cu_count() {
 
 }  // namespace
 
+#ifdef MV_SPLIT_PROBE
+static long long* g_stamp_host = nullptr;
+extern "C" int mv_split_probe_stamps(long long* host_out, size_t n) {   // (probe builds only)
+    if (!g_stamp_host) return -1;
+    return hipMemcpy(host_out, g_stamp_host, n * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
+
 static int pieces_of(int mode) { return mode == MV_PACK_BF16X3 ? 3 : 0; }
 
 extern "C" size_t mv_volume_pack_bytes(int B, int C, int N, int mode) {
@@ -402,13 +489,33 @@ extern "C" int mv_corr_volume_packed(const void* packed1, const void* packed2, f
         (void)hipFuncSetAttribute((const void*)corr_volume_split_stream<3, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    // column regions: one region's B planes (nc / R sub-tiles x 64 rows x C x 2 B x pieces) <= 2 MB of an XCD's 4 MB L2
+    // column regions: one region's B planes (nc / R sub-tiles x 64 rows x C x 2 B x pieces) <= 4 MB.  Measured at 640x480 (7.4 MB
+    // of B planes per pair, all of it Infinity-Cache resident): R = 1 / 2 / 3 / 4 / 6 -> 117 / 110 / 113 / 114 / 116 us: fewer, longer
+    // band segments (each segment change reloads 192 KB of A fragments per workgroup, ~3 us) against L2 hits on the B sub-tiles
     static int regs_env = -1;   // MV_SPLIT_REGIONS: A/B knob
     if (regs_env < 0) { const char* e = getenv("MV_SPLIT_REGIONS"); regs_env = e ? atoi(e) : 0; }
     const int nc = N2 / 64;
-    int R = regs_env > 0 ? regs_env : (int)(((size_t)nc * 64 * C * 2 * 3 + (2u << 20) - 1) / (2u << 20));
+    int R = regs_env > 0 ? regs_env : (int)(((size_t)nc * 64 * C * 2 * 3 + (4u << 20) - 1) / (4u << 20));
     R = std::max(1, std::min(R, nc));
+#ifdef MV_SPLIT_PROBE
+    {
+        static int dbg = -1;
+        if (dbg < 0) {
+            const char* e = getenv("MV_SPLIT_DBG");
+            dbg = e ? atoi(e) : 0;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_split_dbg), &dbg, sizeof(int));
+            if (dbg & 16) {
+                long long* buf = nullptr;
+                (void)hipMalloc((void**)&buf, (size_t)2048 * 4 * 64 * 8 * sizeof(long long));
+                (void)hipMemset(buf, 0, (size_t)2048 * 4 * 64 * 8 * sizeof(long long));
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_split_stamps), &buf, sizeof(buf));
+                g_stamp_host = buf;
+            }
+        }
+    }
+#endif
     const dim3 g((cu_count() & ~7)), blk(256);   // one workgroup per CU, a multiple of 8: one run per XCD
+    mv_note_volume_kernel("corr_volume_split_stream<bf16x3>");
     hipLaunchKernelGGL((corr_volume_split_stream<3, false, 16>), g, blk, lds, (hipStream_t)stream, (const uint16_t*)packed1,
                        (const uint16_t*)packed2, out, N1, N2, B, R);
     return mv_launch_status();

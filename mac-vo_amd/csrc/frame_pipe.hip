@@ -89,6 +89,13 @@ struct mvFramePipe {
     int n_volbuf;   // 2, or 3 (MV_PIPE_VOL_BUFS=3: a GEMM issued ahead then waits for the lookups of frame t-1 instead of t)
     float* tok[2];
     void* planes[2];   // bf16x3 split planes of fmap1 / fmap2 (volume_split3)
+    // volume_split = MV_PACK_BF16X3: packed three-piece operands of the streaming split GEMM, two sets (the pack of frame f + 1 may
+    // run beside the GEMM of frame f); `packed` = the shape is covered by the streaming kernel (exact fp32 kernel otherwise)
+    void* pk[2][2];
+    size_t pk_bytes;
+    bool packed;
+    int pack_on;       // 0 = on the GEMM's stream (in front of it), 1 = backend stream, 2 = decoder-side stream
+    hipEvent_t e_packed[2];
     float *up_flow, *up_cov;
     Maps maps[N_MAPS];
     void* kp_ws;
@@ -152,7 +159,11 @@ static size_t carve(mvFramePipe* p, char* base) {
     const size_t plane = p->plane, n8 = p->n8, B = c.pairs, N = c.num_point > 0 ? c.num_point : 1;
     for (int k = 0; k < p->n_volbuf; ++k) p->vol[k] = a.take<float>(B * n8 * n8);
     for (int k = 0; k < 2; ++k) p->tok[k] = a.take<float>(B * p->KK * n8);
-    for (int k = 0; k < 2; ++k) p->planes[k] = c.volume_split ? (void*)a.take<uint16_t>(3 * B * n8 * c.C) : nullptr;
+    for (int k = 0; k < 2; ++k)
+        p->planes[k] = (c.volume_split == 2 || c.volume_split == 3) ? (void*)a.take<uint16_t>(3 * B * n8 * c.C) : nullptr;
+    p->pk_bytes = p->packed ? mv_volume_pack_bytes((int)B, c.C, (int)n8, MV_PACK_BF16X3) : 0;
+    for (int k = 0; k < 2; ++k)
+        for (int o = 0; o < 2; ++o) p->pk[k][o] = p->packed ? (void*)a.take<char>(p->pk_bytes) : nullptr;
     p->up_flow = a.take<float>(B * 2 * plane);
     p->up_cov = a.take<float>(B * 2 * plane);
     for (int k = 0; k < N_MAPS; ++k) {   // every map is [lanes, ch, H, W]
@@ -209,8 +220,9 @@ static int check_config(const mvFramePipeConfig* c) {
     MV_CHECK_ARG(c->selector_mode == MV_KP_NODEPTH || c->selector_mode == MV_KP_FULL);
     MV_CHECK_ARG(c->num_point >= 0 && c->edgewidth >= 0 && c->min_num_point >= 0);
     MV_CHECK_ARG(c->graph_type >= MV_GRAPH_ICP && c->graph_type <= MV_GRAPH_DISP);
-    MV_CHECK_ARG(c->volume_split == 0 || c->volume_split == 2 || c->volume_split == 3);
-    MV_CHECK_ARG(!c->volume_split || (c->feat_dtype == MV_F32 && c->layout == MV_LAYOUT_HWC));
+    MV_CHECK_ARG(c->volume_split == 0 || c->volume_split == 2 || c->volume_split == 3 || c->volume_split == MV_PACK_BF16X3);
+    MV_CHECK_ARG(!c->volume_split || c->feat_dtype == MV_F32);
+    MV_CHECK_ARG(!(c->volume_split == 2 || c->volume_split == 3) || c->layout == MV_LAYOUT_HWC);   // (the packed form takes either layout)
     return MV_OK;
 }
 
@@ -225,6 +237,7 @@ extern "C" size_t mv_frame_pipe_arena_bytes(const mvFramePipeConfig* cfg) {
     tmp.KK = (2 * cfg->radius + 1) * (2 * cfg->radius + 1);
     tmp.lanes = cfg->pairs / 2;
     tmp.n_volbuf = volbufs_from_env();
+    tmp.packed = cfg->volume_split == MV_PACK_BF16X3 && mv_corr_volume_packed_supported(cfg->pairs, cfg->C, tmp.n8, tmp.n8, MV_PACK_BF16X3);
     return carve(&tmp, nullptr);
 }
 
@@ -241,6 +254,8 @@ extern "C" void mv_frame_pipe_destroy(mvFramePipe* p) {
     for (int k = 0; k < N_CAND; ++k) ev(p->e_cand[k]);
     for (int k = 0; k < 2; ++k) { ev(p->e_backend[k]); ev(p->e_posed[k]); ev(p->e_solved[k]); }
     ev(p->e_pgo);
+    ev(p->e_packed[0]);
+    ev(p->e_packed[1]);
     ev(p->e_map);
     ev(p->e_release);
     for (auto e : p->e_perm) ev(e);
@@ -333,6 +348,8 @@ static int create_impl(mvFramePipe* p) {
         MV_HIP(mk(&p->e_solved[k]));
     }
     MV_HIP(mk(&p->e_pgo));
+    MV_HIP(mk(&p->e_packed[0]));
+    MV_HIP(mk(&p->e_packed[1]));
     MV_HIP(mk(&p->e_map));
     MV_HIP(mk(&p->e_release));
     const size_t N = c.num_point > 0 ? c.num_point : 1;
@@ -371,6 +388,15 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
     p->KK = (2 * cfg->radius + 1) * (2 * cfg->radius + 1);
     p->lanes = cfg->pairs / 2;
     p->n_volbuf = volbufs_from_env();
+    p->packed = cfg->volume_split == MV_PACK_BF16X3 && mv_corr_volume_packed_supported(cfg->pairs, cfg->C, p->n8, p->n8, MV_PACK_BF16X3);
+    {
+        // Where the operand pack of frame f + 1 runs.  It needs only the feature maps, so it can run beside GEMM(f) on another of
+        // the pipe's streams (a fifth stream measured 2.50 k vs 3.41 k frames/s in round 2: four is the ceiling on this stack).
+        const char* e = getenv("MV_PIPE_PACK_ON");
+        // Measured (640x480, one lane, frames/s): in front of the GEMM on its own stream 4.28 k, backend stream 4.09 k, decoder-side
+        // stream 3.11 k: beside a one-wave-per-SIMD GEMM every co-running kernel costs the GEMM more than the 8 us the pack takes.
+        p->pack_on = (e && strcmp(e, "back") == 0) ? 1 : (e && strcmp(e, "main") == 0) ? 2 : 0;
+    }
     p->arena = (char*)arena;
     p->arena_bytes = arena_bytes;
     if (((uintptr_t)arena & 255) != 0 || carve(p, p->arena) > arena_bytes) {
@@ -412,8 +438,24 @@ static int issue_volume(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_s
     MV_TRY(wait_if_pending(p->s_vol, e_in));
     if (p->vol_free_valid[k]) MV_TRY(wait_if_pending(p->s_vol, p->e_vol_free[k]));
     const bool timed = p->n_timed < p->timed_cap;
-    if (timed) MV_HIP(hipEventRecord(p->tv0[p->n_timed], p->s_vol));
-    if (c.volume_split) {
+    if (timed && !(p->packed && p->pack_on != 0)) MV_HIP(hipEventRecord(p->tv0[p->n_timed], p->s_vol));
+    if (p->packed) {
+        void** pk = p->pk[f & 1];
+        hipStream_t sp = p->pack_on == 0 ? p->s_vol : p->pack_on == 1 ? p->s_back : p->s_main;
+        if (sp != p->s_vol) {
+            MV_TRY(wait_if_pending(sp, e_in));
+            // this operand set was last read by the GEMM of frame f - 2 (same stream order as the volume buffers' events)
+            if (f >= 2) MV_TRY(wait_if_pending(sp, p->e_vol_done[(f - 2) % p->n_volbuf]));
+        }
+        MV_TRY(mv_volume_pack((const float*)in->fmap1, (const float*)in->fmap2, pk[0], pk[1], B, c.C, p->n8, p->n8, c.layout,
+                              MV_PACK_BF16X3, sp));
+        if (sp != p->s_vol) {
+            MV_HIP(hipEventRecord(p->e_packed[f & 1], sp));
+            MV_HIP(hipStreamWaitEvent(p->s_vol, p->e_packed[f & 1], 0));
+            if (timed) MV_HIP(hipEventRecord(p->tv0[p->n_timed], p->s_vol));   // the GEMM alone: its operands were packed elsewhere
+        }
+        MV_TRY(mv_corr_volume_packed(pk[0], pk[1], p->vol[k], B, c.C, p->n8, p->n8, MV_PACK_BF16X3, p->s_vol));
+    } else if (c.volume_split == 2 || c.volume_split == 3) {
         const size_t nel = (size_t)B * p->n8 * c.C;
         MV_TRY(mv_split_bf16x3((const float*)in->fmap1, p->planes[0], nel, p->s_vol));
         MV_TRY(mv_split_bf16x3((const float*)in->fmap2, p->planes[1], nel, p->s_vol));

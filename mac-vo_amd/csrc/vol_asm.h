@@ -3,6 +3,8 @@
 #pragma once
 #include "common.h"
 
+void mv_note_volume_kernel(const char* name);   // corr_volume.hip: what mv_corr_volume_last_kernel reports
+
 // ---- hand-counted memory waits and LDS-DMA (used by the DMA-staged tile below and by the streaming kernels) ----
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {

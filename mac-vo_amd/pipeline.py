@@ -93,8 +93,9 @@ class HotPathConfig:
     map_max_depth: float = 5.0           # MappingPointSelector args (Config/Experiment/MACVO/MACVO_Fast.yaml)
     map_max_depth_cov: float = 0.005
     map_mask_width: int = 32
-    volume_precision: str = "exact"      # "exact" fp32 MFMA | "split3" bf16x3, fp32-class | "split2" 3 products, finer
-                                         # than TF32 (the reference's own fast-frontend class); splits need layout "hwc"
+    volume_precision: str = "exact"      # fp32 features: "exact" fp32 MFMA | "bf16x3" packed three-piece split on the 16-bit
+                                         # matrix pipe, six products, fp32-class (same parity bar, not bitwise), either layout |
+                                         # "split3" / "split2" the round-1 tile kernels over pre-split planes (layout "hwc")
 
 
 @dataclass
@@ -532,7 +533,7 @@ class NativeHotPath:
         max_depth = cam.fx * cam.baseline if c.max_depth == "auto" else float(c.max_depth)
         pc = L.mvFramePipeConfig(
             H=cam.H, W=cam.W, C=chans, pairs=pairs, iters=x.coords.shape[0], radius=c.radius, feat_dtype=dt,
-            layout=L.MV_LAYOUT_HWC if hwc else L.MV_LAYOUT_CHW, volume_split={"exact": 0, "split3": 3, "split2": 2}[c.volume_precision],
+            layout=L.MV_LAYOUT_HWC if hwc else L.MV_LAYOUT_CHW, volume_split={"exact": 0, "split3": 3, "split2": 2, "bf16x3": L.MV_PACK_BF16X3}[c.volume_precision],
             selector_mode=L.MV_KP_NODEPTH if c.selector == "nodepth" else L.MV_KP_FULL,
             kp_kernel_size=c.kp_kernel_size, kp_mask_width=c.kp_mask_width, num_point=c.num_point, edgewidth=c.edgewidth,
             min_num_point=c.min_num_point, graph_type=ops._GRAPH[c.graph_type], filters=c.filters,

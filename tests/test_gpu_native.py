@@ -247,3 +247,74 @@ def test_volume_view_and_empty_finish_pose_rotation(gpu):
     hot.sync_all()
     torch.cuda.synchronize()
     assert torch.equal(hot._view("POSE", 1, torch.float32, (1, 7))[0], pose2) and not torch.equal(r4.pose, pose2)
+
+
+_BF16X3_PIPE = r"""
+import hashlib, sys, torch
+sys.path.insert(0, sys.argv[1])
+from tests import synth
+from tests.test_gpu_native import _inputs
+from macvo_amd import ops
+from macvo_amd.pipeline import Camera, HotPathConfig, NativeHotPath
+gpu = torch.device("cuda:0")
+cam, frames, _ = synth.make_sequence(7, 256, 384, C=256, iters=3, seed=31)
+ins = _inputs(frames, gpu)
+nat = NativeHotPath(Camera(**cam), HotPathConfig(volume_precision="bf16x3"), gpu)
+nat.initialize(ins[0])
+torch.manual_seed(5)
+sink = torch.zeros(6, 7, device=gpu)
+h = hashlib.sha1()
+for r in nat.run(ins[1:], pose_sink=sink):            # pipelined: packs and GEMMs of up to three frames in flight
+    nat.sync_pose()
+    h.update(r.kp0_uv.cpu().numpy().tobytes())
+torch.cuda.synchronize()
+h.update(sink.cpu().numpy().tobytes())
+h.update(nat.last_tokens.cpu().numpy().tobytes())
+print(ops.last_volume_kernel(), h.hexdigest())
+"""
+
+
+def test_native_bf16x3_volume_equals_python_driver_and_oracle(gpu):
+    """volume_precision="bf16x3" through both drivers (C = 256: the packed streaming GEMM): the native pipe — pack on another
+    stream beside the previous GEMM, two operand sets — must reproduce the Python-sequenced run bit for bit, frame by frame and
+    pipelined, whatever stream the pack runs on (MV_PIPE_PACK_ON); keypoints equal the ORACLE's (fp32 einsum volume) and the pose
+    stays within the north-star tolerance — the volume's 1e-5-level differences do not reach the backend through the tokens."""
+    import os, subprocess, sys
+
+    from macvo_amd import ops
+    from oracle import se3
+    from oracle.pipeline import OracleHotPath
+
+    H, W, n_frames = 256, 384, 5                      # 32 x 48 = 1536 queries = 24 sub-tiles of 64 columns
+    cam, frames, _ = synth.make_sequence(n_frames, H, W, C=256, iters=3, seed=30)
+    ins = _inputs(frames, gpu)
+    py, nat = _pair(cam, dict(volume_precision="bf16x3"), gpu)
+    ora = OracleHotPath(cam, {})
+    py.initialize(ins[0])
+    nat.initialize(ins[0])
+    ora.initialize(frames[0])
+    for t in range(1, n_frames):
+        torch.manual_seed(70 + t)
+        a = py.step(ins[t])
+        torch.manual_seed(70 + t)
+        b = nat.step(ins[t])
+        torch.cuda.synchronize()
+        assert ops.last_volume_kernel() == "corr_volume_split_stream<bf16x3>"
+        torch.manual_seed(70 + t)
+        ro = ora.step(frames[t])
+        assert torch.equal(py.last_tokens, nat.last_tokens)
+        assert torch.equal(a.kp0_uv, b.kp0_uv) and torch.equal(a.pose, b.pose) and torch.equal(a.pose_f64, b.pose_f64)
+        torch.testing.assert_close(nat.last_tokens.cpu(), ora.last_tokens, rtol=1e-5, atol=3e-4)
+        assert torch.equal(b.kp0_uv.cpu(), ro["kp0_uv"])
+        d_t, d_r = se3.pose_error(ro["pose"].double(), b.pose.cpu().double())
+        assert d_t <= 1e-4 and d_r <= 1e-4, (t, d_t, d_r)
+        py.pose = b.pose.clone()
+        ora.pose = ro["pose"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for where in ("back", "vol", "main"):
+        r = subprocess.run([sys.executable, "-c", _BF16X3_PIPE, root], env=dict(os.environ, MV_PIPE_PACK_ON=where), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.split())
+    assert all(o[0] == "corr_volume_split_stream<bf16x3>" for o in outs) and len({o[1] for o in outs}) == 1, outs

@@ -1,0 +1,142 @@
+"""GPU parity of the split + streaming cost volume (csrc/corr_volume_split.hip): fp32 feature maps packed into three bf16
+pieces, six piece products on the 16-bit matrix pipe, fp32 accumulate.  The bar is the EXACT fp32 path's
+(|out - einsum_f64| <= 2e-5 sqrt(C), tests/test_gpu_corr.py::test_corr_volume_f32_chw) on every shape of that test the kernel
+covers, plus 1280x720, B = 64, ragged row counts, wide dynamic range, and size-independent properties."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _feats(B, C, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+
+
+def test_pack_layout_and_piece_sums(gpu):
+    """mv_volume_pack: unit (b, rb, ks, piece) holds, for lane = kh * 32 + li, the 8 values k = 16 ks + 8 kh + e of row 32 rb + li;
+    pieces are round-to-nearest bf16 of the running residual (so p0 + p1 + p2 reproduces x to 2^-24 |x| and p0 = bf16(x)); rows
+    past N and the extra row block repeat row N - 1.  CHW and HWC inputs give the same bytes."""
+    from macvo_amd import ops
+
+    B, C, N1, N2 = 2, 256, 100, 128
+    g = torch.Generator().manual_seed(0)
+    f1, f2 = torch.randn(B, N1, C, generator=g), torch.randn(B, N2, C, generator=g)
+    f1[0, 3] *= 1e4
+    f1[1, 7] *= 1e-4
+    p1, p2 = ops.volume_pack(f1.to(gpu), f2.to(gpu), layout="hwc")
+    q1, q2 = ops.volume_pack(f1.permute(0, 2, 1).contiguous().to(gpu).view(B, C, 10, 10), f2.permute(0, 2, 1).contiguous().to(gpu).view(B, C, 8, 16), layout="chw")
+    assert torch.equal(p1, q1) and torch.equal(p2, q2)
+    for f, p, N in ((f1, p1, N1), (f2, p2, N2)):
+        nrb = (N + 31) // 32 + 1
+        u = p.cpu().view(torch.bfloat16).view(B, nrb, C // 16, 3, 2, 32, 8).float()        # [b, rb, ks, piece, kh, li, e]
+        rows = torch.arange(nrb * 32).clamp_max(N - 1)
+        rows[(nrb - 1) * 32:] = N - 1
+        want = f[:, rows].view(B, nrb, 32, C // 16, 2, 8).permute(0, 1, 3, 4, 2, 5)          # [b, rb, ks, kh, li, e]
+        assert torch.equal(u[:, :, :, 0], want.to(torch.bfloat16).float())                    # leading piece = bf16(x)
+        s = (u[:, :, :, 0].double() + u[:, :, :, 1].double() + u[:, :, :, 2].double())
+        assert ((s - want.double()).abs() <= want.double().abs() * 2.0 ** -23).all()
+        r1 = want - u[:, :, :, 0]
+        assert torch.equal(u[:, :, :, 1], r1.to(torch.bfloat16).float())                      # second piece = bf16(residual)
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 16, 24), (1, 256, 60, 80), (2, 256, 60, 80), (3, 256, 59, 64), (1, 256, 8, 8)])
+@pytest.mark.parametrize("layout", ["chw", "hwc"])
+def test_corr_volume_bf16x3_parity(gpu, shape, layout):
+    from macvo_amd import ops
+    from oracle import corr
+
+    B, C, H, W = shape
+    f1, f2 = _feats(B, C, H, W, seed=0)
+    ref64 = corr.corr_volume(f1, f2, torch.float64)
+    a1, a2 = (f1, f2) if layout == "chw" else (f1.permute(0, 2, 3, 1).contiguous(), f2.permute(0, 2, 3, 1).contiguous())
+    out = ops.corr_volume(a1.to(gpu), a2.to(gpu), layout=layout, precision="bf16x3")
+    assert ops.last_volume_kernel() == "corr_volume_split_stream<bf16x3>"
+    out = out.cpu()
+    assert out.shape == (B * H * W, 1, H, W) and out.dtype == torch.float32
+    err = (out.double() - ref64).abs().max().item()
+    assert err <= 2e-5 * float(C) ** 0.5, err
+    ref32 = corr.corr_volume(f1, f2, torch.float32)
+    assert err <= 4 * (ref32.double() - ref64).abs().max().item() + 1e-6      # and not worse than a float32 einsum on the CPU
+    exact = ops.corr_volume(a1.to(gpu), a2.to(gpu), layout=layout).cpu()
+    assert err <= 1.5 * (exact.double() - ref64).abs().max().item() + 1e-6     # ... nor than the exact fp32 MFMA path
+
+
+def test_corr_volume_bf16x3_ragged_rows_and_dynamic_range(gpu):
+    """N1 not a multiple of 32 / 128 (row replication, replica block, waves past the bottom edge), N1 != N2, and rows scaled by
+    1e3 / 1e-3: the error relative to sum |a||b| stays at the fp32 level."""
+    from macvo_amd import ops
+
+    C = 256
+    g = torch.Generator().manual_seed(7)
+    for B, N1, N2 in ((2, 100, 128), (1, 4800 - 17, 4800), (2, 33, 64), (1, 129, 192)):
+        f1, f2 = torch.randn(B, N1, C, generator=g), torch.randn(B, N2, C, generator=g)
+        f1[0, 0] *= 1e3
+        f2[0, 1] *= 1e-3
+        f1[0, N1 - 1] *= 17.0
+        out = ops.corr_volume(f1.to(gpu), f2.to(gpu), layout="hwc", precision="bf16x3")
+        assert ops.last_volume_kernel() == "corr_volume_split_stream<bf16x3>"
+        out = out.cpu().view(B, N1, N2).double()
+        ref = torch.einsum("bid,bjd->bij", f1.double(), f2.double())
+        scale = torch.einsum("bid,bjd->bij", f1.double().abs(), f2.double().abs())
+        assert ((out - ref).abs() / scale.clamp_min(1e-30)).max().item() <= 1e-6, (B, N1, N2)
+
+
+def test_corr_volume_bf16x3_falls_back_to_exact_outside_its_shapes(gpu):
+    from macvo_amd import ops
+    from oracle import corr
+
+    f1, f2 = _feats(1, 64, 8, 12, seed=1)                    # C = 64: not covered by the streaming kernel
+    out = ops.corr_volume(f1.to(gpu), f2.to(gpu), precision="bf16x3")
+    assert not ops.last_volume_kernel().startswith("corr_volume_split")
+    assert torch.equal(out, ops.corr_volume(f1.to(gpu), f2.to(gpu)))
+    assert (out.cpu().double() - corr.corr_volume(f1, f2, torch.float64)).abs().max() <= 2e-5 * 8
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 90, 160), (64, 60, 80)])
+def test_corr_volume_bf16x3_fullsize_sampled_rows_and_properties(gpu, B, H, W):
+    """BASELINE configs[2] (1280x720, N = 14400) and configs[4] (B = 64 pairs): sampled query rows + edge rows vs fp64, exact
+    homogeneity under a power-of-two scale (pieces scale exactly), batch independence (bitwise)."""
+    from macvo_amd import ops
+
+    C = 256
+    f1, f2 = _feats(B, C, H, W, seed=0)
+    N = H * W
+    d1, d2 = f1.to(gpu), f2.to(gpu)
+    vol = ops.corr_volume(d1, d2, precision="bf16x3")
+    assert ops.last_volume_kernel() == "corr_volume_split_stream<bf16x3>" and vol.shape == (B * N, 1, H, W)
+    a, b_ = f1.reshape(B, C, N).double(), f2.reshape(B, C, N).double()
+    idx = torch.cat([torch.arange(0, B * N, 1009 if B == 2 else 30011), torch.tensor([0, N - 1, B * N - 1, (B - 1) * N, B * N - 64, B * N - 65])])
+    ref = torch.stack([a[int(i) // N, :, int(i) % N] @ b_[int(i) // N] for i in idx])
+    got = vol[idx.to(gpu)].reshape(len(idx), -1).cpu().double()
+    assert (got - ref).abs().max().item() <= 2e-5 * C ** 0.5
+    chk = vol[:: 997].clone()
+    vol2 = ops.corr_volume(d1 * 4.0, d2, precision="bf16x3")
+    assert torch.equal(vol2[:: 997], chk * 4.0)
+    del vol2
+    b = B - 1
+    solo = ops.corr_volume(d1[b:b + 1].contiguous(), d2[b:b + 1].contiguous(), precision="bf16x3")
+    assert torch.equal(solo, vol[b * N:(b + 1) * N])
+
+
+def test_corr_volume_bf16x3_is_deterministic_and_item_order_free(gpu):
+    """Two launches give the same bits, and so do different XCD region counts (MV_SPLIT_REGIONS only reorders whole items)."""
+    import hashlib, os, subprocess, sys
+
+    code = r'''
+import hashlib, sys, torch
+sys.path.insert(0, sys.argv[1])
+from macvo_amd import ops
+g = torch.Generator().manual_seed(3)
+f1 = torch.randn(2, 256, 60, 80, generator=g).cuda(); f2 = torch.randn(2, 256, 60, 80, generator=g).cuda()
+a = ops.corr_volume(f1, f2, precision="bf16x3"); b = ops.corr_volume(f1, f2, precision="bf16x3")
+assert torch.equal(a, b)
+print(hashlib.sha1(a.cpu().numpy().tobytes()).hexdigest())
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shas = []
+    for regions in ("1", "4", "7"):
+        r = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, MV_SPLIT_REGIONS=regions), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        shas.append(r.stdout.split()[-1])
+    assert len(set(shas)) == 1, shas
