@@ -43,8 +43,12 @@ enum {
     MV_BF16X2 = 4,     /* the same planes, but only the two leading pieces (16 significant bits) and the 3 products
                           a0b1 + a1b0 + a0b0: relative error ~2^-16, finer than TF32 — the class the reference's fast
                           frontend runs this GEMM in (allow_tf32, Module/Frontend/Frontend.py:275-277); layout HWC only */
-    MV_PACK_BF16X3 = 5 /* `mode` of mv_volume_pack / mv_corr_volume_packed: fp32 operands split into three bf16 pieces and
+    MV_PACK_BF16X3 = 5,/* `mode` of mv_volume_pack / mv_corr_volume_packed: fp32 operands split into three bf16 pieces and
                           written in MFMA-fragment order; six piece products, fp32 accumulate (fp32-class, as MV_BF16X3) */
+    MV_PACK_F16X2 = 6  /* the same with two fp16 pieces (11 + 11 bits) of every value after an exact power-of-two scaling of its
+                          ROW (one pixel's feature vector) into fp16's range, three piece products, the scales undone exactly in
+                          the epilogue: |error| <= ~2^-21 sum_k |a_k||b_k| — inside the exact path's parity bar, half the matrix
+                          work of MV_PACK_BF16X3; rows whose largest magnitude is outside [2^-46, 2^74] are not rescued */
 };
 
 /* feature-map memory layouts accepted by mv_corr_volume */

@@ -51,56 +51,86 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 // ------------------------------------------------------------------------------------------------ operand pack
-// One thread = one 16-byte chunk per piece: (operand, pair b, row block rb, k-step ks, lane).  A wave writes NP contiguous 1-KB
-// units; for CHW input its loads are 8 x (2 x 128 B) coalesced rows, for HWC 2 x float4 per lane.
+// One 256-thread workgroup = one (operand, pair b, row block rb): wave w handles k-steps w, w + 4, ..; one thread = one 16-byte chunk
+// per piece: lane = kh * 32 + li holds k = 16 ks + 8 kh + e of row 32 rb + li.  A wave writes NP contiguous 1-KB units per k-step;
+// for CHW input its loads are 8 x (2 x 128 B) coalesced rows, for HWC 2 x float4 per lane.
+// F16 (two fp16 pieces, 11 + 11 bits): fp16 has 5 exponent bits, so every ROW (one pixel's feature vector) is first scaled by a
+// power of two 2^sh that puts its largest magnitude into [2^14, 2^15) — exact, and undone exactly by the GEMM's epilogue
+// (v_ldexp_f32 by -(sh_i + sh_j)); the row's `sh` goes into the int32 table behind the units.  With the scale the pieces carry
+// x to 2^-22 |x| + 2^-40 max_k|x_k| whatever the magnitude of the row (|sh| <= 60: rows below 2^-46 or above 2^74 are not rescued).
 template <int NP, bool F16>
 __global__ __launch_bounds__(256) void volume_pack_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                           uint16_t* __restrict__ p1, uint16_t* __restrict__ p2, int B, int C,
                                                           int N1, int N2, int hwc) {
+    __shared__ float wmax[4][32];
     const int op = blockIdx.y;
     const float* __restrict__ f = op ? f2 : f1;
     uint16_t* __restrict__ out = op ? p2 : p1;
     const int N = op ? N2 : N1;
     const int KS = C >> 4, nrb = ((N + 31) >> 5) + 1;           // + the replica block of row N - 1
-    const long units = (long)B * nrb * KS;                      // (b, rb, ks)
-    const int lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;
-    for (long u = (long)blockIdx.x * 4 + (threadIdx.x >> 6); u < units; u += (long)gridDim.x * 4) {
-        const int ks = (int)(u % KS);
-        const long t = u / KS;
-        const int rb = (int)(t % nrb), b = (int)(t / nrb);
-        const int row = rb == nrb - 1 ? N - 1 : min(rb * 32 + li, N - 1);
-        const int k0 = ks * 16 + kh * 8;
-        float x[8];
-        if (hwc) {
-            const f32x4* src = reinterpret_cast<const f32x4*>(f + ((size_t)b * N + row) * C + k0);
-            const f32x4 lo = src[0], hi = src[1];
+    if ((int)blockIdx.x >= B * nrb) return;
+    const int b = blockIdx.x / nrb, rb = blockIdx.x - b * nrb;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, kh = lane >> 5;
+    const int row = rb == nrb - 1 ? N - 1 : min(rb * 32 + li, N - 1);
+    constexpr int MAXKS = 8;                                     // k-steps per wave held in registers (C <= 512)
+    float x[MAXKS][8];
+    float m = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { x[e] = lo[e]; x[4 + e] = hi[e]; }
-        } else {
-            const float* src = f + ((size_t)b * C + k0) * N + row;
+    for (int q = 0; q < MAXKS; ++q) {
+        const int ks = wave + 4 * q;
+        if (ks < KS) {
+            const int k0 = ks * 16 + kh * 8;
+            if (hwc) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(f + ((size_t)b * N + row) * C + k0);
+                const f32x4 lo = src[0], hi = src[1];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = src[(size_t)e * N];
-        }
-        s16x8 pc[NP];
+                for (int e = 0; e < 4; ++e) { x[q][e] = lo[e]; x[q][4 + e] = hi[e]; }
+            } else {
+                const float* src = f + ((size_t)b * C + k0) * N + row;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float r = x[e];
+                for (int e = 0; e < 8; ++e) x[q][e] = src[(size_t)e * N];
+            }
+            if (F16) {
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {                      // piece p = round-to-nearest of what is left; residual exact in fp32
-                if (F16) {
-                    const _Float16 h = (_Float16)r;
-                    pc[p][e] = __builtin_bit_cast(short, h);
-                    r -= (float)h;
-                } else {
-                    const __bf16 h = (__bf16)r;
-                    pc[p][e] = __builtin_bit_cast(short, h);
-                    r -= (float)h;
-                }
+                for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(x[q][e]));
             }
         }
-        s16x8* dst = reinterpret_cast<s16x8*>(out) + (size_t)u * NP * 64 + lane;
+    }
+    int sh = 0;
+    if (F16) {
+        m = fmaxf(m, __shfl_xor(m, 32, 64));                     // the two k halves of the row
+        if (kh == 0) wmax[wave][li] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(wmax[0][li], wmax[1][li]), fmaxf(wmax[2][li], wmax[3][li]));
+        if (m > 0.f && m < INFINITY) sh = min(60, max(-60, 14 - ilogbf(m)));     // NaN / inf / all-zero rows: unscaled
+        int* exps = reinterpret_cast<int*>(reinterpret_cast<char*>(out) + (size_t)B * nrb * KS * NP * 1024);
+        if (wave == 0 && kh == 0) exps[((size_t)b * nrb + rb) * 32 + li] = sh;
+    }
 #pragma unroll
-        for (int p = 0; p < NP; ++p) dst[p * 64] = pc[p];
+    for (int q = 0; q < MAXKS; ++q) {
+        const int ks = wave + 4 * q;
+        if (ks < KS) {
+            s16x8 pc[NP];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float r = F16 ? ldexpf(x[q][e], sh) : x[q][e];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {                  // piece p = round-to-nearest of what is left; residual exact in fp32
+                    if (F16) {
+                        const _Float16 h = (_Float16)r;
+                        pc[p][e] = __builtin_bit_cast(short, h);
+                        r -= (float)h;
+                    } else {
+                        const __bf16 h = (__bf16)r;
+                        pc[p][e] = __builtin_bit_cast(short, h);
+                        r -= (float)h;
+                    }
+                }
+            }
+            s16x8* dst = reinterpret_cast<s16x8*>(out) + (((size_t)b * nrb + rb) * KS + ks) * NP * 64 + lane;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) dst[p * 64] = pc[p];
+        }
     }
 }
 
@@ -126,8 +156,11 @@ struct SplitCfg {
     // k-steps of half h - 2, then the D pieces and SPH stores of half h - 1.  "vmcnt <= that number" at the barrier of half h
     // therefore means the pieces have landed.  Without stores in flight (first / second item of a segment) the counts shrink.
     static constexpr int STORES_BEHIND_LAST_PIECE = 2 * (KH - 1 - last_piece_ks());
-    static constexpr int W_STEADY = STORES_BEHIND_LAST_PIECE + D + SPH;
-    static_assert(W_STEADY <= 63, "vmcnt is a 6-bit counter");
+    static constexpr int EB = F16 ? 2 : 0;             // F16: two column-exponent loads at the head of every item's first half
+    static constexpr int W_STEADY0 = STORES_BEHIND_LAST_PIECE + D + SPH;        // first half of an item: the half before was a second half
+    static constexpr int W_STEADY = STORES_BEHIND_LAST_PIECE + D + SPH + EB;    // second half: the half before carried the EB loads
+    static constexpr int NEA = F16 ? 4 : 0;            // F16: row-exponent loads riding with the A fragments
+    static_assert(W_STEADY <= 63 && 2 * (D + SPH) + EB <= 63, "vmcnt is a 6-bit counter");
     static_assert(KS % 2 == 0 && HALF_UNITS % 2 == 0, "");
 };
 
@@ -190,6 +223,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem_sp);   // low 32 bits of a flat LDS pointer = LDS byte offset
     const unsigned lane16 = (unsigned)lane * 16u;
+    // F16: per-row scale exponents behind the units of each packed operand (volume_pack_kernel)
+    const int* ex1 = reinterpret_cast<const int*>(reinterpret_cast<const char*>(pk1) + (size_t)B * nrb1 * (NA * 1024));
+    const int* ex2 = reinterpret_cast<const int*>(reinterpret_cast<const char*>(pk2) + (size_t)B * nrb2 * (NA * 1024));
 
     // ---- B loader (LDS-DMA), two K halves ahead of the MFMAs; all walking state wave-uniform.  A half of a sub-tile is two
     // contiguous runs of HU units (row blocks 2c, 2c + 1); wave w copies D units of row block 2c + (w >> 1) from offset (w & 1) * D
@@ -239,6 +275,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // wait is where the values become usable (same scheme as corr_volume_h_stream, whose bitwise test guards it; here
     // test_corr_volume_split_* run multi-segment workgroups).
     i32x4 afr[NA];
+    i32x4 ear[4];                                // F16: scale exponents of this lane's 16 accumulator rows (rows 8 g + 4 kh + 0..3)
     auto issue_a = [&](int b, int band) __attribute__((always_inline)) {
         const int rb = min(band * 4 + wave, nrb1 - 1);           // waves past the bottom edge take the replica block (row N1 - 1 x 32)
         const char* A = reinterpret_cast<const char*>(pk1) + ((size_t)b * nrb1 + rb) * (size_t)(NA * 1024);
@@ -247,23 +284,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // 12-bit immediates reach 4 units; the rest of the offset rides on the (uniform) base
             asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&a"(afr[i]) : "v"(lane16), "s"(A + (i >> 2) * 4096), "n"((i & 3) * 1024) : "memory");
         }
+        if (F16) {
+            const int* E = ex1 + ((size_t)b * nrb1 + rb) * 32;
+            const unsigned vo = (unsigned)kh * 16u;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(ear[gq]) : "v"(vo), "s"(E), "n"(gq * 32) : "memory");
+        }
+    };
+    int nea[16];                                 // F16: minus the row exponents, per accumulator register
+    // F16: scale exponents of this lane's two output columns of an item, loaded at the head of the item's first half
+    int cur_b = 0, cur_c = 0;                    // (pair, sub-tile) of the item being multiplied
+    auto issue_eb = [&](int& e0, int& e1) __attribute__((always_inline)) {
+        const int* E = ex2 + ((size_t)cur_b * nrb2 + 2 * cur_c) * 32;
+        const unsigned vo = (unsigned)li * 4u;
+        asm volatile("global_load_dword %0, %1, %2" : "=&v"(e0) : "v"(vo), "s"(E) : "memory");
+        asm volatile("global_load_dword %0, %1, %2 offset:128" : "=&v"(e1) : "v"(vo), "s"(E) : "memory");
     };
 
     float* O = nullptr;                          // wave-uniform: column 0 of the CURRENT item's output block (row 0 of the pair)
     unsigned roff[16];                           // per-lane byte offsets of the 16 accumulator rows (C/D layout), fixed for a band segment
     // one output store: accumulator row r of column block j; data straight from the accumulator file ("a": the MFMA results never
     // visit a VGPR)
-    auto store_j = [&](const f32x16& pj, int r, int j, float* Ob) __attribute__((always_inline)) {
+    // F16: the value is first rescaled by 2^-(row exponent + column exponent) (exact: v_ldexp_f32), `ebj` = the column's exponent
+    auto store_j = [&](const f32x16& pj, int r, int j, float* Ob, int ebj) __attribute__((always_inline)) {
         if (DBG(1)) {                            // (probe builds only) keep the accumulators alive without storing them
             asm volatile("" ::"a"(pj[r]));
             return;
         }
-        if (j == 0) asm volatile("global_store_dword %0, %1, %2" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "a"(pj[r]), "s"(Ob) : "memory");
-        else asm volatile("global_store_dword %0, %1, %2 offset:128" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "a"(pj[r]), "s"(Ob) : "memory");
-    };
-    auto store_r = [&](const f32x16& p0, const f32x16& p1, int r, float* Ob) __attribute__((always_inline)) {
-        store_j(p0, r, 0, Ob);
-        store_j(p1, r, 1, Ob);
+        if (F16) {
+            const float v = __builtin_ldexpf(pj[r], nea[r] - ebj);
+            if (j == 0) asm volatile("global_store_dword %0, %1, %2" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(v), "s"(Ob) : "memory");
+            else asm volatile("global_store_dword %0, %1, %2 offset:128" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(v), "s"(Ob) : "memory");
+        } else {
+            if (j == 0) asm volatile("global_store_dword %0, %1, %2" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "a"(pj[r]), "s"(Ob) : "memory");
+            else asm volatile("global_store_dword %0, %1, %2 offset:128" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "a"(pj[r]), "s"(Ob) : "memory");
+        }
     };
     int slot = 0;                                // ring slot of the half about to be multiplied
 #ifdef MV_SPLIT_PROBE
@@ -286,7 +342,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     //   slots 2 NP, 2 NP + 1  the two output stores of the previous item this k-step carries,
     //   slots 2 NP + 2, + 4   an LDS-DMA piece of half + 2 (the D pieces are spread over the whole half; the first ones go out
     //                         straight behind the barrier, in the shadow of the first fragment reads' LDS latency).
-    auto half = [&](auto HH, auto WW, auto PREV, f32x16& c0, f32x16& c1, const f32x16& p0, const f32x16& p1) __attribute__((always_inline)) {
+    auto half = [&](auto HH, auto WW, auto PREV, f32x16& c0, f32x16& c1, const f32x16& p0, const f32x16& p1, int (&ec)[2], int (&ep)[2]) __attribute__((always_inline)) {
         constexpr int H = decltype(HH)::value;
         constexpr int W = decltype(WW)::value;
         constexpr bool HAVE_PREV = decltype(PREV)::value;
@@ -306,6 +362,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int p = 0; p < NP; ++p) fb[0][j][p] = q[((j * KH + 0) * NP + p) * 64];
         __builtin_amdgcn_sched_barrier(0);
+        if (F16 && H == 0) {
+            // the previous item's column exponents were loaded in front of the pieces this barrier has just waited for: usable now
+            if (HAVE_PREV) asm volatile("" : "+v"(ep[0]), "+v"(ep[1]));
+            issue_eb(ec[0], ec[1]);
+        }
 #pragma unroll
         for (int pi = 0; pi < Cf::PH; ++pi) piece(pi);
         __builtin_amdgcn_sched_barrier(0);
@@ -338,7 +399,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         fb[nxt][j2][p2] = DBG(8) ? fb[cur][j2][p2] : q[((j2 * KH + ks + 1) * NP + p2) * 64];
                     }
                 } else if (sl == 2 * NP || sl == 2 * NP + 1) {
-                    if (HAVE_PREV) store_j(sl == 2 * NP ? p0 : p1, H * KH + ks, sl - 2 * NP, O - 64);   // one accumulator row per k-step
+                    if (HAVE_PREV) store_j(sl == 2 * NP ? p0 : p1, H * KH + ks, sl - 2 * NP, O - 64, ep[sl - 2 * NP]);   // one accumulator row per k-step
                     if (sl == 2 * NQ - 1 && npk > 0) piece(pk0);                 // (NQ = 3: the last slot also carries the k-step's piece)
                 } else if (sl == 2 * NP + 2) {
                     if (npk > 0) piece(pk0);
@@ -355,9 +416,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     using No = std::false_type;
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
-    auto item = [&](auto W0, auto W1, auto PREV, f32x16& c0, f32x16& c1, const f32x16& p0, const f32x16& p1) __attribute__((always_inline)) {
-        half(H0{}, W0, PREV, c0, c1, p0, p1);
-        half(H1{}, W1, PREV, c0, c1, p0, p1);
+    auto item = [&](auto W0, auto W1, auto PREV, f32x16& c0, f32x16& c1, const f32x16& p0, const f32x16& p1, int (&ec)[2], int (&ep)[2]) __attribute__((always_inline)) {
+        half(H0{}, W0, PREV, c0, c1, p0, p1, ec, ep);
+        half(H1{}, W1, PREV, c0, c1, p0, p1, ec, ep);
+        ++cur_c;
 #ifdef MV_SPLIT_PROBE
         if (DBG(16) && lane == 0 && n_stamped < 64) {
             long long* o = g_split_stamps + (((size_t)blockIdx.x * 4 + wave) * 64 + n_stamped) * 8;
@@ -370,20 +432,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         ++it;
         O += 64;
     };
-    auto flush = [&](const f32x16& p0, const f32x16& p1) __attribute__((always_inline)) {
+    auto flush = [&](const f32x16& p0, const f32x16& p1, int (&ep)[2]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) store_r(p0, p1, r, O - 64);
+        for (int r = 0; r < 16; ++r) {
+            store_j(p0, r, 0, O - 64, ep[0]);
+            store_j(p1, r, 1, O - 64, ep[1]);
+        }
     };
     static_assert(KS == 16, "store interleave: one accumulator row per k-step");
     // waits: see the derivation in SplitCfg / DESIGN.md.  first item of a segment: everything older than the 32 flush stores has
     // landed (hand wait below), no stores ride along; second item: D pieces (+ SPH stores) behind the pieces it consumes; then steady.
     using WF0 = std::integral_constant<int, 32>;
-    using WF1 = std::integral_constant<int, 32 + D>;
+    using WF1 = std::integral_constant<int, 32 + D + Cf::EB>;
     using WS0 = std::integral_constant<int, D>;
-    using WS1 = std::integral_constant<int, D + Cf::SPH>;
+    using WS1 = std::integral_constant<int, D + Cf::SPH + Cf::EB>;
+    using WW0 = std::integral_constant<int, Cf::W_STEADY0>;
     using WW = std::integral_constant<int, Cf::W_STEADY>;
 
     f32x16 x0, x1, y0, y1;
+    int ex[2] = {0, 0}, ey[2] = {0, 0};           // F16: column exponents of the items accumulating in (x0, x1) / (y0, y1)
     int b, g, band, c0i;
     decode(it, b, g, band, c0i);
     issue_a(b, band);
@@ -394,21 +461,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int seg_end = min(it_end, it + (reg_c0(g + 1) - c0i));
 #pragma unroll
         for (int i = 0; i < NA; ++i) asm volatile("" : "+a"(afr[i]));   // the fragments count as defined only here, behind the hand-placed wait
+        if (F16) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) asm volatile("" : "+v"(ear[gq]));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nea[r] = -ear[r >> 2][r & 3];
+        }
         O = out + (size_t)b * N1 * N2 + (size_t)c0i * 64;
+        cur_b = b;
+        cur_c = c0i;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             roff[r] = ((unsigned)min(band * 128 + wave * 32 + 4 * kh + (r & 3) + 8 * (r >> 2), N1 - 1) * (unsigned)N2 + li) * 4u;
-        item(WF0{}, WF1{}, No{}, x0, x1, x0, x1);
+        item(WF0{}, WF1{}, No{}, x0, x1, x0, x1, ex, ex);
         bool in_y = false;
         if (it < seg_end) {
-            item(WS0{}, WS1{}, Yes{}, y0, y1, x0, x1);
+            item(WS0{}, WS1{}, Yes{}, y0, y1, x0, x1, ey, ex);
             in_y = true;
             while (it + 2 <= seg_end) {
-                item(WW{}, WW{}, Yes{}, x0, x1, y0, y1);
-                item(WW{}, WW{}, Yes{}, y0, y1, x0, x1);
+                item(WW0{}, WW{}, Yes{}, x0, x1, y0, y1, ex, ey);
+                item(WW0{}, WW{}, Yes{}, y0, y1, x0, x1, ey, ex);
             }
             if (it < seg_end) {
-                item(WW{}, WW{}, Yes{}, x0, x1, y0, y1);
+                item(WW0{}, WW{}, Yes{}, x0, x1, y0, y1, ex, ey);
                 in_y = false;
             }
         }
@@ -416,14 +491,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // asm accesses straight behind the last MFMAs: "XDL write VGPR -> VMEM read" (11 wait states for an 8-pass MFMA) and the
         // overwrite of MFMA source registers are software hazards that hipcc's recognizer does not see through inline asm
         asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+        if (F16) {
+            // the last item's column exponents: behind their loads went at most 2 (D + SPH) operations (its own pieces and the
+            // stores of the item before it); 2 D is a bound that holds for a one-item segment as well
+            wait_vmcnt<2 * D>();
+            if (in_y) asm volatile("" : "+v"(ey[0]), "+v"(ey[1]));
+            else asm volatile("" : "+v"(ex[0]), "+v"(ex[1]));
+        }
         if (more) {
             decode(it, b, g, band, c0i);
             issue_a(b, band);
         }
-        if (in_y) flush(y0, y1);
-        else flush(x0, x1);
+        if (in_y) flush(y0, y1, ey);
+        else flush(x0, x1, ex);
         if (!more) break;
-        wait_vmcnt<32>();                        // the A loads precede the 32 flush stores
+        wait_vmcnt<32>();                        // the A (+ row exponent) loads precede the 32 flush stores
     }
     wait_vmcnt<0>();                             // nothing of this workgroup may still be in flight towards its LDS when it retires
 }
@@ -449,12 +531,15 @@ extern "C" int mv_split_probe_stamps(long long* host_out, size_t n) {   // (prob
 }
 #endif
 
-static int pieces_of(int mode) { return mode == MV_PACK_BF16X3 ? 3 : 0; }
+static int pieces_of(int mode) { return mode == MV_PACK_BF16X3 ? 3 : mode == MV_PACK_F16X2 ? 2 : 0; }
 
 extern "C" size_t mv_volume_pack_bytes(int B, int C, int N, int mode) {
     const int np = pieces_of(mode);
-    if (np == 0 || B <= 0 || C <= 0 || (C % 16) || N <= 0) return 0;
-    return (size_t)B * (size_t)((N + 31) / 32 + 1) * (size_t)(C / 16) * (size_t)np * 1024;
+    if (np == 0 || B <= 0 || C <= 0 || (C % 16) || C > 512 || N <= 0) return 0;
+    const size_t nrb = (size_t)((N + 31) / 32 + 1);
+    const size_t units = (size_t)B * nrb * (size_t)(C / 16) * (size_t)np * 1024;
+    const size_t exps = mode == MV_PACK_F16X2 ? (((size_t)B * nrb * 32 * sizeof(int32_t) + 1023) & ~(size_t)1023) : 0;   // per-row scale exponents
+    return units + exps;
 }
 
 extern "C" int mv_volume_pack(const float* f1, const float* f2, void* packed1, void* packed2, int B, int C, int N1, int N2,
@@ -462,17 +547,23 @@ extern "C" int mv_volume_pack(const float* f1, const float* f2, void* packed1, v
     MV_CHECK_ARG(f1 && f2 && packed1 && packed2 && B > 0 && N1 > 0 && N2 > 0);
     MV_CHECK_ARG(layout == MV_LAYOUT_CHW || layout == MV_LAYOUT_HWC);
     MV_CHECK_ARG(((uintptr_t)f1 & 15) == 0 && ((uintptr_t)f2 & 15) == 0 && ((uintptr_t)packed1 & 15) == 0 && ((uintptr_t)packed2 & 15) == 0);
-    if (pieces_of(mode) == 0 || C <= 0 || (C % 16)) return MV_ERR_UNSUPPORTED;
-    const long units = (long)B * ((std::max(N1, N2) + 31) / 32 + 1) * (C / 16);
-    const int blocks = (int)std::min<long>((units + 3) / 4, 8192);
-    hipLaunchKernelGGL((volume_pack_kernel<3, false>), dim3(blocks, 2), dim3(256), 0, (hipStream_t)stream, f1, f2, (uint16_t*)packed1,
-                       (uint16_t*)packed2, B, C, N1, N2, layout == MV_LAYOUT_HWC ? 1 : 0);
+    if (pieces_of(mode) == 0 || C <= 0 || (C % 16) || C > 512) return MV_ERR_UNSUPPORTED;
+    const long blocks = (long)B * ((std::max(N1, N2) + 31) / 32 + 1);
+    if (blocks > 0x7fffffffL) return MV_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)blocks, 2), blk(256);
+    const int hwc = layout == MV_LAYOUT_HWC ? 1 : 0;
+    if (mode == MV_PACK_BF16X3)
+        hipLaunchKernelGGL((volume_pack_kernel<3, false>), grid, blk, 0, (hipStream_t)stream, f1, f2, (uint16_t*)packed1, (uint16_t*)packed2, B, C,
+                           N1, N2, hwc);
+    else
+        hipLaunchKernelGGL((volume_pack_kernel<2, true>), grid, blk, 0, (hipStream_t)stream, f1, f2, (uint16_t*)packed1, (uint16_t*)packed2, B, C,
+                           N1, N2, hwc);
     return mv_launch_status();
 }
 
 // shapes the streaming GEMM covers (the caller falls back to the exact fp32 kernel otherwise — never less accurate)
 extern "C" int mv_corr_volume_packed_supported(int B, int C, int N1, int N2, int mode) {
-    return pieces_of(mode) == 3 && C == 256 && B > 0 && B <= 65535 && N1 >= 32 && N2 >= 64 && (N2 % 64) == 0 &&
+    return pieces_of(mode) != 0 && C == 256 && B > 0 && B <= 65535 && N1 >= 32 && N2 >= 64 && (N2 % 64) == 0 &&
            ((size_t)N1 * N2) < ((size_t)1 << 30) &&                                               // 32-bit byte offsets inside a pair's block
            (size_t)B * (size_t)((N1 + 127) / 128) * (size_t)(N2 / 64) < ((size_t)1 << 31);        // int item index
 }
@@ -482,11 +573,11 @@ extern "C" int mv_corr_volume_packed(const void* packed1, const void* packed2, f
     MV_CHECK_ARG(packed1 && packed2 && out);
     MV_CHECK_ARG(((uintptr_t)packed1 & 15) == 0 && ((uintptr_t)packed2 & 15) == 0);
     if (!mv_corr_volume_packed_supported(B, C, N1, N2, mode)) return MV_ERR_UNSUPPORTED;
-    using K = SplitCfg<3, false, 16>;
-    const unsigned lds = K::NSLOT * K::SLOT_BYTES;
+    const int np = pieces_of(mode);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)corr_volume_split_stream<3, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)corr_volume_split_stream<2, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     // column regions: one region's B planes (nc / R sub-tiles x 64 rows x C x 2 B x pieces) <= 4 MB.  Measured at 640x480 (7.4 MB
@@ -495,7 +586,7 @@ extern "C" int mv_corr_volume_packed(const void* packed1, const void* packed2, f
     static int regs_env = -1;   // MV_SPLIT_REGIONS: A/B knob
     if (regs_env < 0) { const char* e = getenv("MV_SPLIT_REGIONS"); regs_env = e ? atoi(e) : 0; }
     const int nc = N2 / 64;
-    int R = regs_env > 0 ? regs_env : (int)(((size_t)nc * 64 * C * 2 * 3 + (4u << 20) - 1) / (4u << 20));
+    int R = regs_env > 0 ? regs_env : (int)(((size_t)nc * 64 * C * 2 * np + (4u << 20) - 1) / (4u << 20));
     R = std::max(1, std::min(R, nc));
 #ifdef MV_SPLIT_PROBE
     {
@@ -515,8 +606,16 @@ extern "C" int mv_corr_volume_packed(const void* packed1, const void* packed2, f
     }
 #endif
     const dim3 g((cu_count() & ~7)), blk(256);   // one workgroup per CU, a multiple of 8: one run per XCD
-    mv_note_volume_kernel("corr_volume_split_stream<bf16x3>");
-    hipLaunchKernelGGL((corr_volume_split_stream<3, false, 16>), g, blk, lds, (hipStream_t)stream, (const uint16_t*)packed1,
-                       (const uint16_t*)packed2, out, N1, N2, B, R);
+    if (mode == MV_PACK_BF16X3) {
+        using K = SplitCfg<3, false, 16>;
+        mv_note_volume_kernel("corr_volume_split_stream<bf16x3>");
+        hipLaunchKernelGGL((corr_volume_split_stream<3, false, 16>), g, blk, K::NSLOT * K::SLOT_BYTES, (hipStream_t)stream,
+                           (const uint16_t*)packed1, (const uint16_t*)packed2, out, N1, N2, B, R);
+    } else {
+        using K = SplitCfg<2, true, 16>;
+        mv_note_volume_kernel("corr_volume_split_stream<f16x2>");
+        hipLaunchKernelGGL((corr_volume_split_stream<2, true, 16>), g, blk, K::NSLOT * K::SLOT_BYTES, (hipStream_t)stream,
+                           (const uint16_t*)packed1, (const uint16_t*)packed2, out, N1, N2, B, R);
+    }
     return mv_launch_status();
 }

@@ -161,7 +161,7 @@ static size_t carve(mvFramePipe* p, char* base) {
     for (int k = 0; k < 2; ++k) p->tok[k] = a.take<float>(B * p->KK * n8);
     for (int k = 0; k < 2; ++k)
         p->planes[k] = (c.volume_split == 2 || c.volume_split == 3) ? (void*)a.take<uint16_t>(3 * B * n8 * c.C) : nullptr;
-    p->pk_bytes = p->packed ? mv_volume_pack_bytes((int)B, c.C, (int)n8, MV_PACK_BF16X3) : 0;
+    p->pk_bytes = p->packed ? mv_volume_pack_bytes((int)B, c.C, (int)n8, c.volume_split) : 0;
     for (int k = 0; k < 2; ++k)
         for (int o = 0; o < 2; ++o) p->pk[k][o] = p->packed ? (void*)a.take<char>(p->pk_bytes) : nullptr;
     p->up_flow = a.take<float>(B * 2 * plane);
@@ -220,7 +220,8 @@ static int check_config(const mvFramePipeConfig* c) {
     MV_CHECK_ARG(c->selector_mode == MV_KP_NODEPTH || c->selector_mode == MV_KP_FULL);
     MV_CHECK_ARG(c->num_point >= 0 && c->edgewidth >= 0 && c->min_num_point >= 0);
     MV_CHECK_ARG(c->graph_type >= MV_GRAPH_ICP && c->graph_type <= MV_GRAPH_DISP);
-    MV_CHECK_ARG(c->volume_split == 0 || c->volume_split == 2 || c->volume_split == 3 || c->volume_split == MV_PACK_BF16X3);
+    MV_CHECK_ARG(c->volume_split == 0 || c->volume_split == 2 || c->volume_split == 3 || c->volume_split == MV_PACK_BF16X3 ||
+                 c->volume_split == MV_PACK_F16X2);
     MV_CHECK_ARG(!c->volume_split || c->feat_dtype == MV_F32);
     MV_CHECK_ARG(!(c->volume_split == 2 || c->volume_split == 3) || c->layout == MV_LAYOUT_HWC);   // (the packed form takes either layout)
     return MV_OK;
@@ -237,7 +238,8 @@ extern "C" size_t mv_frame_pipe_arena_bytes(const mvFramePipeConfig* cfg) {
     tmp.KK = (2 * cfg->radius + 1) * (2 * cfg->radius + 1);
     tmp.lanes = cfg->pairs / 2;
     tmp.n_volbuf = volbufs_from_env();
-    tmp.packed = cfg->volume_split == MV_PACK_BF16X3 && mv_corr_volume_packed_supported(cfg->pairs, cfg->C, tmp.n8, tmp.n8, MV_PACK_BF16X3);
+    tmp.packed = (cfg->volume_split == MV_PACK_BF16X3 || cfg->volume_split == MV_PACK_F16X2) &&
+                 mv_corr_volume_packed_supported(cfg->pairs, cfg->C, tmp.n8, tmp.n8, cfg->volume_split);
     return carve(&tmp, nullptr);
 }
 
@@ -388,7 +390,8 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
     p->KK = (2 * cfg->radius + 1) * (2 * cfg->radius + 1);
     p->lanes = cfg->pairs / 2;
     p->n_volbuf = volbufs_from_env();
-    p->packed = cfg->volume_split == MV_PACK_BF16X3 && mv_corr_volume_packed_supported(cfg->pairs, cfg->C, p->n8, p->n8, MV_PACK_BF16X3);
+    p->packed = (cfg->volume_split == MV_PACK_BF16X3 || cfg->volume_split == MV_PACK_F16X2) &&
+                mv_corr_volume_packed_supported(cfg->pairs, cfg->C, p->n8, p->n8, cfg->volume_split);
     {
         // Where the operand pack of frame f + 1 runs.  It needs only the feature maps, so it can run beside GEMM(f) on another of
         // the pipe's streams (a fifth stream measured 2.50 k vs 3.41 k frames/s in round 2: four is the ceiling on this stack).
@@ -448,13 +451,13 @@ static int issue_volume(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_s
             if (f >= 2) MV_TRY(wait_if_pending(sp, p->e_vol_done[(f - 2) % p->n_volbuf]));
         }
         MV_TRY(mv_volume_pack((const float*)in->fmap1, (const float*)in->fmap2, pk[0], pk[1], B, c.C, p->n8, p->n8, c.layout,
-                              MV_PACK_BF16X3, sp));
+                              c.volume_split, sp));
         if (sp != p->s_vol) {
             MV_HIP(hipEventRecord(p->e_packed[f & 1], sp));
             MV_HIP(hipStreamWaitEvent(p->s_vol, p->e_packed[f & 1], 0));
             if (timed) MV_HIP(hipEventRecord(p->tv0[p->n_timed], p->s_vol));   // the GEMM alone: its operands were packed elsewhere
         }
-        MV_TRY(mv_corr_volume_packed(pk[0], pk[1], p->vol[k], B, c.C, p->n8, p->n8, MV_PACK_BF16X3, p->s_vol));
+        MV_TRY(mv_corr_volume_packed(pk[0], pk[1], p->vol[k], B, c.C, p->n8, p->n8, c.volume_split, p->s_vol));
     } else if (c.volume_split == 2 || c.volume_split == 3) {
         const size_t nel = (size_t)B * p->n8 * c.C;
         MV_TRY(mv_split_bf16x3((const float*)in->fmap1, p->planes[0], nel, p->s_vol));

@@ -53,7 +53,8 @@ def corr_volume(f1: torch.Tensor, f2: torch.Tensor, layout: str = "chw", out: to
     """All-pairs cost volume (FlowFormer ``MemoryEncoder.corr``; call site flownet.py:26-27).
 
     layout "chw": f1, f2 ``[B, C, H, W]`` (NCHW);  layout "hwc": ``[B, H, W, C]`` / ``[B, N, C]``.
-    precision (fp32 inputs only): "exact" = fp32 MFMA (bitwise fmaf chain); "bf16x3" = operands packed into three bf16 pieces
+    precision (fp32 inputs only): "exact" = fp32 MFMA (bitwise fmaf chain); "f16x2" = rows scaled by a power of two into fp16's
+    range, two fp16 pieces, three products (error <= ~2^-21 sum |a||b|: inside the parity bar, the fastest form); "bf16x3" = operands packed into three bf16 pieces
     (``volume_pack``) + the streaming six-product kernel on the 16-bit matrix pipe, fp32-class accuracy (same parity bar as
     "exact", not bitwise), either layout, shapes the kernel does not cover fall back to "exact"; "split3" / "split2" = the
     round-1/2 tile kernels over pre-split planes (6 / 3 products; "split2": relative error ~2^-16, finer than TF32, the class
@@ -84,12 +85,12 @@ def corr_volume(f1: torch.Tensor, f2: torch.Tensor, layout: str = "chw", out: to
         out = torch.empty((B * N1, 1, H2, W2), dtype=torch.float32, device=f1.device)
     dt = _DT[f1.dtype]
     p1, p2 = f1, f2
-    if precision == "bf16x3":
+    if precision in _PACK_MODE:
         if f1.dtype != torch.float32:
-            raise L.MacvoHipError("corr_volume: precision='bf16x3' splits float32 inputs")
-        if lib.mv_corr_volume_packed_supported(B, Cc, N1, N2, L.MV_PACK_BF16X3):
-            pk1, pk2 = volume_pack(f1, f2, layout)
-            return corr_volume_packed(pk1, pk2, B, Cc, N1, N2, out=out)
+            raise L.MacvoHipError(f"corr_volume: precision='{precision}' splits float32 inputs")
+        if lib.mv_corr_volume_packed_supported(B, Cc, N1, N2, _PACK_MODE[precision]):
+            pk1, pk2 = volume_pack(f1, f2, layout, mode=precision)
+            return corr_volume_packed(pk1, pk2, B, Cc, N1, N2, out=out, mode=precision)
         precision = "exact"
     if precision in ("split3", "split2"):
         if f1.dtype != torch.float32 or lay != L.MV_LAYOUT_HWC:
@@ -106,9 +107,14 @@ def corr_volume(f1: torch.Tensor, f2: torch.Tensor, layout: str = "chw", out: to
     return out
 
 
-def volume_pack(f1: torch.Tensor, f2: torch.Tensor, layout: str = "chw", out: "tuple | None" = None):
-    """fp32 feature maps -> the packed three-piece bf16 operands of ``corr_volume_packed`` (``mv_volume_pack``: both maps in one
-    launch, MFMA-fragment order, row N - 1 replicated past the edge).  Returns two uint8 tensors (opaque)."""
+_PACK_MODE = {"bf16x3": L.MV_PACK_BF16X3, "f16x2": L.MV_PACK_F16X2}
+
+
+def volume_pack(f1: torch.Tensor, f2: torch.Tensor, layout: str = "chw", out: "tuple | None" = None, mode: str = "bf16x3"):
+    """fp32 feature maps -> the packed operands of ``corr_volume_packed`` (``mv_volume_pack``: both maps in one launch,
+    MFMA-fragment order, row N - 1 replicated past the edge).  mode "bf16x3": three bf16 pieces; "f16x2": two fp16 pieces of
+    every value after a per-row power-of-two scaling (+ the table of row exponents).  Returns two uint8 tensors (opaque)."""
+    md = _PACK_MODE[mode]
     lib = L.load()
     f1 = _req(f1, torch.float32, "f1")
     f2 = _req(f2, torch.float32, "f2")
@@ -118,22 +124,24 @@ def volume_pack(f1: torch.Tensor, f2: torch.Tensor, layout: str = "chw", out: "t
     else:
         B, Cc = f1.shape[0], f1.shape[-1]
         N1, N2 = f1[0, ..., 0].numel(), f2[0, ..., 0].numel()
-    n1, n2 = lib.mv_volume_pack_bytes(B, Cc, N1, L.MV_PACK_BF16X3), lib.mv_volume_pack_bytes(B, Cc, N2, L.MV_PACK_BF16X3)
+    n1, n2 = lib.mv_volume_pack_bytes(B, Cc, N1, md), lib.mv_volume_pack_bytes(B, Cc, N2, md)
     if n1 == 0 or n2 == 0:
         raise L.MacvoHipError("volume_pack: unsupported shape (C % 16 != 0?)")
     p1, p2 = out if out is not None else (torch.empty(n1, dtype=torch.uint8, device=f1.device), torch.empty(n2, dtype=torch.uint8, device=f1.device))
     assert p1.numel() >= n1 and p2.numel() >= n2
     L.check(lib.mv_volume_pack(f1.data_ptr(), f2.data_ptr(), p1.data_ptr(), p2.data_ptr(), B, Cc, N1, N2,
-                               L.MV_LAYOUT_CHW if layout == "chw" else L.MV_LAYOUT_HWC, L.MV_PACK_BF16X3, _stream()), "mv_volume_pack")
+                               L.MV_LAYOUT_CHW if layout == "chw" else L.MV_LAYOUT_HWC, md, _stream()), "mv_volume_pack")
     return p1, p2
 
 
-def corr_volume_packed(pk1: torch.Tensor, pk2: torch.Tensor, B: int, C_: int, N1: int, N2: int, out: torch.Tensor | None = None) -> torch.Tensor:
-    """The cost volume ``[B*N1, 1, 1, N2]`` fp32 from two packed operands (``mv_corr_volume_packed``, six bf16 piece products)."""
+def corr_volume_packed(pk1: torch.Tensor, pk2: torch.Tensor, B: int, C_: int, N1: int, N2: int, out: torch.Tensor | None = None,
+                       mode: str = "bf16x3") -> torch.Tensor:
+    """The cost volume ``[B*N1, 1, 1, N2]`` fp32 from two packed operands (``mv_corr_volume_packed``: six bf16 / three fp16 piece
+    products, fp32 accumulate)."""
     lib = L.load()
     if out is None:
         out = torch.empty((B * N1, 1, 1, N2), dtype=torch.float32, device=pk1.device)
-    L.check(lib.mv_corr_volume_packed(pk1.data_ptr(), pk2.data_ptr(), out.data_ptr(), B, C_, N1, N2, L.MV_PACK_BF16X3, _stream()),
+    L.check(lib.mv_corr_volume_packed(pk1.data_ptr(), pk2.data_ptr(), out.data_ptr(), B, C_, N1, N2, _PACK_MODE[mode], _stream()),
             "mv_corr_volume_packed")
     return out
 

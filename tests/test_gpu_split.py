@@ -40,9 +40,40 @@ def test_pack_layout_and_piece_sums(gpu):
         assert torch.equal(u[:, :, :, 1], r1.to(torch.bfloat16).float())                      # second piece = bf16(residual)
 
 
+def test_pack_f16x2_row_scales_and_pieces(gpu):
+    """mode "f16x2": every row is scaled by 2^sh with its largest magnitude landing in [2^14, 2^15) (sh in the int32 table behind
+    the units, 0 for all-zero rows), pieces are fp16(x 2^sh) and fp16 of the exact residual: (p0 + p1) 2^-sh reproduces x to
+    2^-21 |x| + 2^-40 max|row| — whatever the magnitude of the row."""
+    from macvo_amd import ops
+
+    B, C, N = 2, 256, 96
+    g = torch.Generator().manual_seed(1)
+    f = torch.randn(B, N, C, generator=g)
+    f[0, 3] *= 1e6
+    f[0, 4] *= 1e-6
+    f[1, 5] = 0.0
+    f[1, 6, :200] *= 1e-5                       # wide range INSIDE a row: small entries keep absolute, not relative, accuracy
+    p, _ = ops.volume_pack(f.to(gpu), f.to(gpu), layout="hwc", mode="f16x2")
+    nrb = N // 32 + 1
+    units = B * nrb * (C // 16) * 2 * 1024
+    u = p[:units].cpu().view(torch.float16).view(B, nrb, C // 16, 2, 2, 32, 8).double()      # [b, rb, ks, piece, kh, li, e]
+    sh = p[units: units + B * nrb * 32 * 4].cpu().view(torch.int32).view(B, nrb, 32)
+    rows = torch.arange(nrb * 32).clamp_max(N - 1)
+    rows[(nrb - 1) * 32:] = N - 1
+    want = f[:, rows].view(B, nrb, 32, C // 16, 2, 8).permute(0, 1, 3, 4, 2, 5).double()       # [b, rb, ks, kh, li, e]
+    rmax = f[:, rows].abs().amax(-1).view(B, nrb, 32)
+    scaled_max = rmax.double() * torch.pow(2.0, sh.double())
+    nz = rmax > 0
+    assert ((scaled_max[nz] >= 2.0 ** 14) & (scaled_max[nz] < 2.0 ** 15)).all() and (sh[~nz] == 0).all()
+    back = (u[:, :, :, 0] + u[:, :, :, 1]) * torch.pow(2.0, -sh.double())[:, :, None, None, :, None]
+    tol = want.abs() * 2.0 ** -21 + rmax.double()[:, :, None, None, :, None] * 2.0 ** -39
+    assert ((back - want).abs() <= tol).all()
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("shape", [(2, 256, 16, 24), (1, 256, 60, 80), (2, 256, 60, 80), (3, 256, 59, 64), (1, 256, 8, 8)])
 @pytest.mark.parametrize("layout", ["chw", "hwc"])
-def test_corr_volume_bf16x3_parity(gpu, shape, layout):
+def test_corr_volume_split_parity(gpu, shape, layout, mode):
     from macvo_amd import ops
     from oracle import corr
 
@@ -50,8 +81,8 @@ def test_corr_volume_bf16x3_parity(gpu, shape, layout):
     f1, f2 = _feats(B, C, H, W, seed=0)
     ref64 = corr.corr_volume(f1, f2, torch.float64)
     a1, a2 = (f1, f2) if layout == "chw" else (f1.permute(0, 2, 3, 1).contiguous(), f2.permute(0, 2, 3, 1).contiguous())
-    out = ops.corr_volume(a1.to(gpu), a2.to(gpu), layout=layout, precision="bf16x3")
-    assert ops.last_volume_kernel() == "corr_volume_split_stream<bf16x3>"
+    out = ops.corr_volume(a1.to(gpu), a2.to(gpu), layout=layout, precision=mode)
+    assert ops.last_volume_kernel() == f"corr_volume_split_stream<{mode}>"
     out = out.cpu()
     assert out.shape == (B * H * W, 1, H, W) and out.dtype == torch.float32
     err = (out.double() - ref64).abs().max().item()
@@ -62,9 +93,11 @@ def test_corr_volume_bf16x3_parity(gpu, shape, layout):
     assert err <= 1.5 * (exact.double() - ref64).abs().max().item() + 1e-6     # ... nor than the exact fp32 MFMA path
 
 
-def test_corr_volume_bf16x3_ragged_rows_and_dynamic_range(gpu):
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+def test_corr_volume_split_ragged_rows_and_dynamic_range(gpu, mode):
     """N1 not a multiple of 32 / 128 (row replication, replica block, waves past the bottom edge), N1 != N2, and rows scaled by
-    1e3 / 1e-3: the error relative to sum |a||b| stays at the fp32 level."""
+    1e3 / 1e-3 (f16x2: up to 1e+-12 — the per-row power-of-two scales carry them): the error relative to sum |a||b| stays at the
+    fp32 level."""
     from macvo_amd import ops
 
     C = 256
@@ -74,12 +107,17 @@ def test_corr_volume_bf16x3_ragged_rows_and_dynamic_range(gpu):
         f1[0, 0] *= 1e3
         f2[0, 1] *= 1e-3
         f1[0, N1 - 1] *= 17.0
-        out = ops.corr_volume(f1.to(gpu), f2.to(gpu), layout="hwc", precision="bf16x3")
-        assert ops.last_volume_kernel() == "corr_volume_split_stream<bf16x3>"
+        if mode == "f16x2":
+            f1[0, 2] *= 1e12
+            f2[0, 3] *= 1e-12
+            f1[0, 5] = 0.0
+        out = ops.corr_volume(f1.to(gpu), f2.to(gpu), layout="hwc", precision=mode)
+        assert ops.last_volume_kernel() == f"corr_volume_split_stream<{mode}>"
         out = out.cpu().view(B, N1, N2).double()
         ref = torch.einsum("bid,bjd->bij", f1.double(), f2.double())
         scale = torch.einsum("bid,bjd->bij", f1.double().abs(), f2.double().abs())
         assert ((out - ref).abs() / scale.clamp_min(1e-30)).max().item() <= 1e-6, (B, N1, N2)
+        assert (out[0, 5] == 0).all() if mode == "f16x2" else True
 
 
 def test_corr_volume_bf16x3_falls_back_to_exact_outside_its_shapes(gpu):
@@ -93,8 +131,9 @@ def test_corr_volume_bf16x3_falls_back_to_exact_outside_its_shapes(gpu):
     assert (out.cpu().double() - corr.corr_volume(f1, f2, torch.float64)).abs().max() <= 2e-5 * 8
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("B,H,W", [(2, 90, 160), (64, 60, 80)])
-def test_corr_volume_bf16x3_fullsize_sampled_rows_and_properties(gpu, B, H, W):
+def test_corr_volume_split_fullsize_sampled_rows_and_properties(gpu, B, H, W, mode):
     """BASELINE configs[2] (1280x720, N = 14400) and configs[4] (B = 64 pairs): sampled query rows + edge rows vs fp64, exact
     homogeneity under a power-of-two scale (pieces scale exactly), batch independence (bitwise)."""
     from macvo_amd import ops
@@ -103,23 +142,24 @@ def test_corr_volume_bf16x3_fullsize_sampled_rows_and_properties(gpu, B, H, W):
     f1, f2 = _feats(B, C, H, W, seed=0)
     N = H * W
     d1, d2 = f1.to(gpu), f2.to(gpu)
-    vol = ops.corr_volume(d1, d2, precision="bf16x3")
-    assert ops.last_volume_kernel() == "corr_volume_split_stream<bf16x3>" and vol.shape == (B * N, 1, H, W)
+    vol = ops.corr_volume(d1, d2, precision=mode)
+    assert ops.last_volume_kernel() == f"corr_volume_split_stream<{mode}>" and vol.shape == (B * N, 1, H, W)
     a, b_ = f1.reshape(B, C, N).double(), f2.reshape(B, C, N).double()
     idx = torch.cat([torch.arange(0, B * N, 1009 if B == 2 else 30011), torch.tensor([0, N - 1, B * N - 1, (B - 1) * N, B * N - 64, B * N - 65])])
     ref = torch.stack([a[int(i) // N, :, int(i) % N] @ b_[int(i) // N] for i in idx])
     got = vol[idx.to(gpu)].reshape(len(idx), -1).cpu().double()
     assert (got - ref).abs().max().item() <= 2e-5 * C ** 0.5
     chk = vol[:: 997].clone()
-    vol2 = ops.corr_volume(d1 * 4.0, d2, precision="bf16x3")
+    vol2 = ops.corr_volume(d1 * 4.0, d2, precision=mode)
     assert torch.equal(vol2[:: 997], chk * 4.0)
     del vol2
     b = B - 1
-    solo = ops.corr_volume(d1[b:b + 1].contiguous(), d2[b:b + 1].contiguous(), precision="bf16x3")
+    solo = ops.corr_volume(d1[b:b + 1].contiguous(), d2[b:b + 1].contiguous(), precision=mode)
     assert torch.equal(solo, vol[b * N:(b + 1) * N])
 
 
-def test_corr_volume_bf16x3_is_deterministic_and_item_order_free(gpu):
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+def test_corr_volume_split_is_deterministic_and_item_order_free(gpu, mode):
     """Two launches give the same bits, and so do different XCD region counts (MV_SPLIT_REGIONS only reorders whole items)."""
     import hashlib, os, subprocess, sys
 
@@ -129,14 +169,14 @@ sys.path.insert(0, sys.argv[1])
 from macvo_amd import ops
 g = torch.Generator().manual_seed(3)
 f1 = torch.randn(2, 256, 60, 80, generator=g).cuda(); f2 = torch.randn(2, 256, 60, 80, generator=g).cuda()
-a = ops.corr_volume(f1, f2, precision="bf16x3"); b = ops.corr_volume(f1, f2, precision="bf16x3")
+a = ops.corr_volume(f1, f2, precision=sys.argv[2]); b = ops.corr_volume(f1, f2, precision=sys.argv[2])
 assert torch.equal(a, b)
 print(hashlib.sha1(a.cpu().numpy().tobytes()).hexdigest())
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     shas = []
     for regions in ("1", "4", "7"):
-        r = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, MV_SPLIT_REGIONS=regions), capture_output=True, text=True, timeout=300)
+        r = subprocess.run([sys.executable, "-c", code, root, mode], env=dict(os.environ, MV_SPLIT_REGIONS=regions), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         shas.append(r.stdout.split()[-1])
     assert len(set(shas)) == 1, shas

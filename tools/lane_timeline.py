@@ -17,7 +17,7 @@ def to_dev(t):
 frames = [FrameInputs(static=True, **{k: to_dev(v) for k, v in fr.items()}) for fr in frames_cpu]
 batches = frames if lanes == 1 else [stack_lanes([frames[(t + l) % pool] for l in range(lanes)]) for t in range(pool)]
 gens = None if lanes == 1 else [torch.Generator().manual_seed(l) for l in range(lanes)]
-hp = NativeHotPath(Camera(**cam), HotPathConfig(), dev, lanes=lanes, generators=gens)
+hp = NativeHotPath(Camera(**cam), HotPathConfig(volume_precision=os.environ.get("TL_PRECISION", "bf16x3")), dev, lanes=lanes, generators=gens)
 hp.initialize(batches[0]); torch.manual_seed(0)
 warm = max(10, steps // 4)
 for _ in hp.run(batches[(1 + k) % pool] for k in range(warm)): pass

@@ -20,12 +20,12 @@ for B, H, W in shapes:
     out = torch.empty((B * N, 1, H, W), device="cuda")
     n = 100 if B * N * N < 1e9 else 12
     for _ in range(3 * n): ops.corr_volume(f1, f2, out=out)            # clocks
-    pk = ops.volume_pack(f1, f2)
-    t_pack = t(lambda: ops.volume_pack(f1, f2, out=pk), n, n // 3)
-    t_gemm = t(lambda: ops.corr_volume_packed(pk[0], pk[1], B, C, N, N, out=out), n, n // 3)
-    t_both = t(lambda: ops.corr_volume(f1, f2, out=out, precision="bf16x3"), n, n // 3)
-    t_exact = t(lambda: ops.corr_volume(f1, f2, out=out), n, n // 3)
     fl = 2.0 * B * N * N * C
-    print(f"B={B} {H}x{W}: pack {t_pack:.1f} us | split GEMM {t_gemm:.1f} us = {fl / t_gemm / 1e6:.1f} TF algorithmic "
-          f"({6 * fl / t_gemm / 1e6 / 2500:.3f} of 2.5 PF executed; write {B * N * N * 4 / t_gemm / 1e3:.0f} GB/s) | pack+GEMM {t_both:.1f} us | "
-          f"exact fp32 {t_exact:.1f} us = {fl / t_exact / 1e6 / 157.3:.3f} of 157.3 TF", flush=True)
+    for mode, nprod in (("bf16x3", 6), ("f16x2", 3)):
+        pk = ops.volume_pack(f1, f2, mode=mode)
+        t_pack = t(lambda: ops.volume_pack(f1, f2, out=pk, mode=mode), n, n // 3)
+        t_gemm = t(lambda: ops.corr_volume_packed(pk[0], pk[1], B, C, N, N, out=out, mode=mode), n, n // 3)
+        print(f"B={B} {H}x{W} {mode}: pack {t_pack:.1f} us | split GEMM {t_gemm:.1f} us = {fl / t_gemm / 1e6:.1f} TF algorithmic "
+              f"({nprod * fl / t_gemm / 1e6 / 2500:.3f} of 2.5 PF executed; write {B * N * N * 4 / t_gemm / 1e3:.0f} GB/s)", flush=True)
+    t_exact = t(lambda: ops.corr_volume(f1, f2, out=out), n, n // 3)
+    print(f"B={B} {H}x{W} exact fp32 {t_exact:.1f} us = {fl / t_exact / 1e6 / 157.3:.3f} of 157.3 TF", flush=True)
