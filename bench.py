@@ -56,12 +56,13 @@ def parse_args():
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--feat-dtype", choices=["f32", "f16", "bf16"], default="f32")
     ap.add_argument("--layout", choices=["chw", "hwc"], default="chw")
-    ap.add_argument("--volume-precision", choices=["bf16x3", "exact", "split3", "split2"], default="bf16x3",
-                    help="fp32 features: 'bf16x3' (default) = packed three-piece bf16 split, six products on the 16-bit matrix pipe, fp32 "
-                         "accumulate — same parity bar as 'exact', not bitwise (the reference runs this GEMM in TF32, Frontend.py:275-277); "
-                         "'exact' = fp32 MFMA (bitwise fmaf chain; reported as `exact_fp32` beside the default line); split3 / split2 = "
-                         "round-1 tile kernels (need --layout hwc)")
-    ap.add_argument("--exact-steps", type=int, default=60, help="steps of the extra exact-fp32 leg beside the default line; 0 = skip")
+    ap.add_argument("--volume-precision", choices=["f16x2", "bf16x3", "exact", "split3", "split2"], default="f16x2",
+                    help="fp32 features: 'f16x2' (default) = rows scaled by a power of two into fp16's range, two fp16 pieces, three "
+                         "products on the 16-bit matrix pipe, fp32 accumulate, scales undone exactly; 'bf16x3' = three bf16 pieces, six "
+                         "products — both meet the parity bar of 'exact', not bitwise (the reference runs this GEMM in TF32, "
+                         "Frontend.py:275-277); 'exact' = fp32 MFMA (bitwise fmaf chain).  The other two are reported as `other_precisions` "
+                         "beside the default line; split3 / split2 = round-1 tile kernels (need --layout hwc)")
+    ap.add_argument("--exact-steps", type=int, default=60, help="steps of the extra legs with the other volume precisions beside the default line; 0 = skip")
     ap.add_argument("--graph", choices=["disp", "reproj", "icp"], default="disp")
     ap.add_argument("--pool", type=int, default=24, help="distinct synthetic frames (closed trajectory) kept in HBM")
     ap.add_argument("--cpu-frames", type=int, default=120, help="frames timed for the CPU baseline (rank 0, N=1 only)")
@@ -140,14 +141,15 @@ def roofline_of(ms, args, lanes, n_q, C, timed_region_launches, traffic=None):
     common = {"avg_launch_us": round(avg_s * 1e6, 2), "launches": len(ms), "launches_in_timed_region": timed_region_launches,
               "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes}
     prec = getattr(args, "_precision", args.volume_precision)
-    if args.feat_dtype == "f32" and prec in ("bf16x3", "split3", "split2"):
-        nprod = 3.0 if prec == "split2" else 6.0
-        ach = nprod * flops / avg_s / 1e12          # bf16 MFMA FLOPs the kernel executes: `nprod` piece products per algorithmic product
+    if args.feat_dtype == "f32" and prec in ("f16x2", "bf16x3", "split3", "split2"):
+        nprod = 3.0 if prec in ("split2", "f16x2") else 6.0
+        ach = nprod * flops / avg_s / 1e12          # 16-bit MFMA FLOPs the kernel executes: `nprod` piece products per algorithmic product
         return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": traffic,
-                "kernel": "corr_volume_split_stream<bf16x3>" if prec == "bf16x3" else f"{prec} pre-pass + corr_volume_bf16x3_hwc<{int(nprod) // 3 + 1}>",
+                "kernel": f"corr_volume_split_stream<{prec}>" if prec in ("bf16x3", "f16x2") else f"{prec} pre-pass + corr_volume_bf16x3_hwc<{int(nprod) // 3 + 1}>",
+                "hbm_write_GBps": round(nbytes / avg_s / 1e9, 1),
                 **common, "executed_flops_per_launch": nprod * flops, "algorithmic_tflops": round(flops / avg_s / 1e12, 2),
-                "note": f"achieved = {int(nprod)} bf16 piece products per algorithmic fp32 product x algorithmic FLOPs / time, against the dense bf16 "
+                "note": f"achieved = {int(nprod)} 16-bit piece products per algorithmic fp32 product x algorithmic FLOPs / time, against the dense 16-bit "
                         "MFMA peak (2.5 PFLOP/s; with N(0,1) operands the chip's power limit holds a bare v_mfma_f32_32x32x16_bf16 stream at "
                         "~1.89 PFLOP/s = 0.76, tools/scratch/mfma16_probe.*); the operand pack runs on another stream and is not in this time"}
     if args.feat_dtype == "f32":
@@ -229,7 +231,9 @@ def main():
                             volume_precision=(precision or args.volume_precision) if args.feat_dtype == "f32" else "exact",
                             use_graphs=use_graphs)
         if native:
-            gens = None if lanes == 1 else [torch.Generator().manual_seed(seed + l) for l in range(lanes)]
+            # lanes > 1: integer seeds = the driver's native per-lane MT19937 generators (bit-identical to torch.Generator(seed) +
+            # torch.randperm; 32 host-side torch.randperm calls per step were the bound of the 32-lane configuration)
+            gens = None if lanes == 1 else [seed + l for l in range(lanes)]
             return NativeHotPath(Camera(**cam), cfg, dev, lanes=lanes, generators=gens)
         return HotPath(Camera(**cam), cfg, dev)
 
@@ -325,8 +329,8 @@ def main():
     # (scripts/pmc_gpu.sh -> profiles/*_pmc_corr_volume.json; PMC passes cannot be mixed into this run)
     traffic = None
     try:
-        if (H, W, C, args.lanes) == (480, 640, 256, 1) and args.feat_dtype == "f32" and args.volume_precision == "bf16x3":
-            path = os.path.join(ROOT, "profiles", "r03_pmc_corr_volume_split.json")
+        if (H, W, C, args.lanes) == (480, 640, 256, 1) and args.feat_dtype == "f32" and args.volume_precision in ("bf16x3", "f16x2"):
+            path = os.path.join(ROOT, "profiles", f"r03_pmc_corr_volume_split_{args.volume_precision}.json")
             if os.path.exists(path):
                 pm = json.load(open(path))
                 key = next((k for k in pm if k.startswith("corr_volume_split_stream")), None)
@@ -357,10 +361,10 @@ def main():
         launches first: after a few ms of idle the clocks need ~40 ms of load to come back (222 -> 190 us measured)."""
         b0 = lane_batches(lanes)[0]
         vol = ops.corr_volume(b0.fmap1, b0.fmap2, layout=args.layout, precision=precision)
-        if precision == "bf16x3" and ops.last_volume_kernel().startswith("corr_volume_split"):
-            pk = ops.volume_pack(b0.fmap1, b0.fmap2, args.layout)       # the GEMM alone: the pack is a separate launch on another stream
+        if precision in ("bf16x3", "f16x2") and ops.last_volume_kernel().startswith("corr_volume_split"):
+            pk = ops.volume_pack(b0.fmap1, b0.fmap2, args.layout, mode=precision)       # the GEMM alone: the pack is a separate launch
             Bp = b0.fmap1.shape[0]
-            launch = lambda: ops.corr_volume_packed(pk[0], pk[1], Bp, C, n_q, n_q, out=vol)  # noqa: E731
+            launch = lambda: ops.corr_volume_packed(pk[0], pk[1], Bp, C, n_q, n_q, out=vol, mode=precision)  # noqa: E731
         else:
             launch = lambda: ops.corr_volume(b0.fmap1, b0.fmap2, layout=args.layout, out=vol, precision=precision)  # noqa: E731
         n_warm, n_iso = max(20, 300 // lanes), max(10, 100 // lanes)
@@ -374,25 +378,33 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / n_iso
 
-    if roofline is not None and rank == 0 and args.feat_dtype == "f32" and args.volume_precision in ("exact", "bf16x3"):
+    if roofline is not None and rank == 0 and args.feat_dtype == "f32" and args.volume_precision in ("exact", "bf16x3", "f16x2"):
         iso_us = isolated_us(args.lanes, args.volume_precision)
         roofline["isolated_avg_launch_us"] = round(iso_us, 2)
         roofline["isolated_frac"] = round(roofline["frac"] * roofline["avg_launch_us"] / iso_us, 4)
 
-    # ---- the exact-fp32 volume beside the default line: same stream, same steps definition, fp32 MFMA kernel
-    exact_leg = None
-    if rank == 0 and world == 1 and native and args.feat_dtype == "f32" and args.volume_precision == "bf16x3" and args.exact_steps > 0:
-        args._precision = "exact"
-        ee, _, mse, ine = measure(args.lanes, args.exact_steps, 5, 1234, not args.no_kernel_events, precision="exact")
-        exact_leg = {"what": "the same stream with volume_precision='exact': v_mfma_f32_32x32x2_f32, bitwise an fmaf chain (round-2 default)",
-                     "value": round(args.lanes * args.exact_steps / ee, 2), "unit": "stereo frames/s", "steps": args.exact_steps, "warmup": 5,
-                     "ms_per_step": round(ee / args.exact_steps * 1e3, 4),
-                     "roofline": roofline_of(mse, args, args.lanes, n_q, C, ine) if mse else None}
-        if exact_leg["roofline"] is not None:
-            iso = isolated_us(args.lanes, "exact")
-            exact_leg["roofline"]["isolated_avg_launch_us"] = round(iso, 2)
-            exact_leg["roofline"]["isolated_frac"] = round(exact_leg["roofline"]["frac"] * exact_leg["roofline"]["avg_launch_us"] / iso, 4)
-        del args._precision
+    # ---- the other volume precisions beside the default line: same stream, same step definition
+    other_legs = None
+    if rank == 0 and world == 1 and native and args.feat_dtype == "f32" and args.volume_precision in ("f16x2", "bf16x3", "exact") and args.exact_steps > 0:
+        other_legs = {}
+        what = {"exact": "v_mfma_f32_32x32x2_f32, bitwise an fmaf chain (the round-2 default)",
+                "bf16x3": "three bf16 pieces per operand, six products (corr_volume_split_stream<bf16x3>)",
+                "f16x2": "row-scaled, two fp16 pieces per operand, three products (corr_volume_split_stream<f16x2>)"}
+        for prec in ("exact", "bf16x3", "f16x2"):
+            if prec == args.volume_precision:
+                continue
+            args._precision = prec
+            ee, _, mse, ine = measure(args.lanes, args.exact_steps, 5, 1234, not args.no_kernel_events, precision=prec)
+            leg = {"what": "the same stream with volume_precision='%s': %s" % (prec, what[prec]),
+                   "value": round(args.lanes * args.exact_steps / ee, 2), "unit": "stereo frames/s", "steps": args.exact_steps, "warmup": 5,
+                   "ms_per_step": round(ee / args.exact_steps * 1e3, 4),
+                   "roofline": roofline_of(mse, args, args.lanes, n_q, C, ine) if mse else None}
+            if leg["roofline"] is not None:
+                iso = isolated_us(args.lanes, prec)
+                leg["roofline"]["isolated_avg_launch_us"] = round(iso, 2)
+                leg["roofline"]["isolated_frac"] = round(leg["roofline"]["frac"] * leg["roofline"]["avg_launch_us"] / iso, 4)
+            other_legs[prec] = leg
+            del args._precision
 
     # ---- CPU baseline (oracle pipeline, torch-CPU ops shaped like the reference) on a bounded sample + free-running parity
     cpu_baseline = parity = None
@@ -425,7 +437,7 @@ def main():
                                   f"{csec:.1f} s"}
         # free-running parity: the HIP path on the same frames from the same start, chained on its OWN poses (no teacher
         # forcing), same CPU generator seed -> keypoints must be identical, poses within 1e-4; RTE per MetricsSeq.py:9-16
-        if native and args.volume_precision in ("exact", "bf16x3") and args.feat_dtype == "f32":
+        if native and args.volume_precision in ("exact", "bf16x3", "f16x2") and args.feat_dtype == "f32":
             n_par = min(len(ora_track), max(args.parity_frames, 2))
             hot = make_pipe(1, 0)
             torch.manual_seed(1234)
@@ -524,9 +536,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"f32": ("f32 via bf16x3 (volume: fp32 operands split into three bf16 pieces, six products, fp32 accumulate) + f32 "
-                              "(lookup/covariance) + f64 (PGO)" if args.volume_precision == "bf16x3" else
-                              "f32 (volume/lookup/covariance) + f64 (PGO)"),
+            "dtype": {"f32": {"bf16x3": "f32 via bf16x3 (volume: fp32 operands split into three bf16 pieces, six products, fp32 accumulate) + f32 "
+                                        "(lookup/covariance) + f64 (PGO)",
+                              "f16x2": "f32 via f16x2 (volume: fp32 operands row-scaled by powers of two and split into two fp16 pieces, three "
+                                       "products, fp32 accumulate, scales undone exactly) + f32 (lookup/covariance) + f64 (PGO)"}.get(
+                                  args.volume_precision, "f32 (volume/lookup/covariance) + f64 (PGO)"),
                       "f16": "f16 in / f32 acc (volume) + f32 + f64 (PGO)",
                       "bf16": "bf16 in / f32 acc (volume) + f32 + f64 (PGO)"}[args.feat_dtype],
             "data": "synthetic (seeded planar-scene stereo stream, random feature maps; no weights/datasets available)",
@@ -541,7 +555,7 @@ def main():
                        "excluded": "learned FlowFormer layers (source + weights absent from the reference checkout)",
                        "parallelism": f"{world * args.lanes} independent sequence(s), {args.lanes} per GPU; one all_gather of poses + timestamps"},
             "roofline": roofline,
-            "exact_fp32": exact_leg,
+            "other_precisions": other_legs,
             "cpu_baseline": cpu_baseline,
             "parity": parity,
             "config4": config4,

@@ -561,6 +561,13 @@ int mv_frame_pipe_wait_candidates(mvFramePipe* p, int32_t* n_cand /* [lanes] hos
 /* perm_host: int64 [lanes, num_point], row l = randperm(n_cand[l])[:num_point] (n_sel[l] entries used); n_sel: int32 [lanes]
  * host; pose_sink: device fp32 [lanes, 7] or NULL (copy of the new poses) */
 int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, const int32_t* n_sel, float* pose_sink);
+/* Native keypoint permutations.  The reference draws `torch.randperm(n)[:numPoint]` from torch's CPU generator
+ * (Module/KeypointSelector.py:331,404) = MT19937 + Fisher-Yates (ATen randperm_cpu).  mv_frame_pipe_seed_lanes gives every lane
+ * its own MT19937 seeded like `torch.Generator().manual_seed(seed)`; mv_frame_pipe_finish_seeded then replaces
+ * wait_candidates + host randperm + finish by one call (first numPoint swaps, the remaining draws discarded: same bits, ~20x
+ * less host time — what a 32-lane step needs).  n_cand_out / n_sel_out: [lanes] host or NULL. */
+int mv_frame_pipe_seed_lanes(mvFramePipe* p, const uint64_t* seeds /* [lanes] host */);
+int mv_frame_pipe_finish_seeded(mvFramePipe* p, float* pose_sink, int32_t* n_cand_out, int32_t* n_sel_out);
 /* register the newest FINISHED frame in a device-resident map (mv_map_append on the pipe's own streams, no copies; lanes = 1):
  * frame_idx = the map index the frame receives (= frames pushed so far), prev_frame = the previous keyframe's index; the
  * optimised pose is written over the frame's prior once its solve has finished */

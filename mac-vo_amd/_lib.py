@@ -145,6 +145,8 @@ SIGNATURES = {
     "mv_frame_pipe_enqueue_volume": (C.c_int, [_P, C.POINTER(mvFrameInputs), _P]),
     "mv_frame_pipe_wait_candidates": (C.c_int, [_P, _P]),
     "mv_frame_pipe_finish": (C.c_int, [_P, _P, _P, _P]),
+    "mv_frame_pipe_seed_lanes": (C.c_int, [_P, _P]),
+    "mv_frame_pipe_finish_seeded": (C.c_int, [_P, _P, _P, _P]),
     "mv_frame_pipe_map_append": (C.c_int, [_P, C.POINTER(mvMapStores), C.c_int, C.c_int, _P, _P, C.c_float, C.c_int64, _P]),
     "mv_frame_pipe_release": (C.c_int, [_P, _P]),
     "mv_frame_pipe_sync": (C.c_int, [_P, _P, C.c_int]),

@@ -24,6 +24,7 @@
 // cross-stream hazards are closed with events (see `enqueue` / `finish`).
 #include "common.h"
 #include <deque>
+#include <random>
 #include <vector>
 #include <new>
 #include <stdlib.h>
@@ -129,6 +130,11 @@ struct mvFramePipe {
     hipEvent_t e_map;
     int newest_maps;
     std::deque<Pending> pending;
+    // native keypoint permutations (mv_frame_pipe_seed_lanes): one MT19937 per lane, the engine behind torch's CPU generator
+    std::vector<std::mt19937> rng;
+    std::vector<int32_t> perm_scratch;   // identity array of the partial Fisher-Yates, reused
+    std::vector<int64_t> perm_host;      // [lanes, cap]
+    std::vector<int32_t> nsel_host;
     // optional timing of the dominant kernel (bench.py roofline): event pairs around each volume GEMM on its stream
     int vol_timed[MAX_VOL];      // timing slot of the GEMM that filled each volume buffer (-1: not timed)
     std::vector<hipEvent_t> tv0, tv1, tv2, tv3;   // GEMM start / end, last lookup done, selector done (timeline hook)
@@ -584,6 +590,60 @@ extern "C" int mv_frame_pipe_wait_candidates(mvFramePipe* p, int32_t* n_cand) {
     MV_HIP(hipEventSynchronize(p->e_cand[pd.cand]));
     for (int l = 0; l < p->lanes; ++l) n_cand[l] = p->h_count[pd.cand][4 * l];
     return MV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ native permutations
+// `selected[torch.randperm(n)[:numPoint]]` (Module/KeypointSelector.py:331,404) draws from torch's CPU generator, which is a
+// standard MT19937 (at::mt19937, init_genrand(seed & 0xffffffff)), and torch.randperm on the CPU is the plain Fisher-Yates
+//     r = arange(n); for i in 0 .. n - 2: z = random32() % (n - i); swap(r[i], r[i + z])          (ATen randperm_cpu, n < 2^32 / 20)
+// Position i is final after iteration i, so the first numPoint outputs need numPoint swaps; the other n - 1 - numPoint draws only
+// advance the generator.  One lane of the reference's own call costs ~45 us at n = 8000; 32 lanes are 1.4-3 ms per step on the
+// host — more than the 2.6 ms volume GEMM of the whole batch leaves idle (measured: 1.9 ms of GEMM-stream idle per 32-lane step).
+// Here: ~2 ns per draw, no allocation.  Identical bits to `torch.Generator().manual_seed(seed)` + torch.randperm
+// (tests/test_gpu_lanes.py::test_native_seeded_lanes_equal_torch_generators).
+extern "C" int mv_frame_pipe_seed_lanes(mvFramePipe* p, const uint64_t* seeds) {
+    MV_CHECK_ARG(p && seeds);
+    p->rng.clear();
+    for (int l = 0; l < p->lanes; ++l) p->rng.emplace_back((uint32_t)(seeds[l] & 0xffffffffull));
+    const int cap = p->c.num_point > 0 ? p->c.num_point : 1;
+    p->perm_host.assign((size_t)p->lanes * cap, 0);
+    p->nsel_host.assign((size_t)p->lanes, 0);
+    return MV_OK;
+}
+
+static void randperm_head(std::mt19937& eng, int64_t n, int k, std::vector<int32_t>& r, int64_t* out) {
+    if (n <= 0) return;
+    if ((int64_t)r.size() < n) r.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) r[(size_t)i] = (int32_t)i;
+    const int64_t swaps = k < n - 1 ? k : n - 1;
+    for (int64_t i = 0; i < swaps; ++i) {
+        const int64_t z = (int64_t)((uint32_t)eng()) % (n - i);
+        const int32_t sav = r[(size_t)i];
+        r[(size_t)i] = r[(size_t)(i + z)];
+        r[(size_t)(i + z)] = sav;
+    }
+    if (n - 1 > swaps) eng.discard((unsigned long long)(n - 1 - swaps));   // the draws of the remaining iterations
+    const int64_t m = k < n ? k : n;
+    for (int64_t i = 0; i < m; ++i) out[i] = r[(size_t)i];
+}
+
+extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, const int32_t* n_sel, float* pose_sink);
+
+// wait_candidates + permutations (per-lane generators of mv_frame_pipe_seed_lanes) + finish in one host call
+extern "C" int mv_frame_pipe_finish_seeded(mvFramePipe* p, float* pose_sink, int32_t* n_cand_out, int32_t* n_sel_out) {
+    MV_CHECK_ARG(p && !p->pending.empty() && (int)p->rng.size() == p->lanes);
+    const Pending& pd = p->pending.front();
+    MV_HIP(hipEventSynchronize(p->e_cand[pd.cand]));
+    const int cap = p->c.num_point > 0 ? p->c.num_point : 1;
+    for (int l = 0; l < p->lanes; ++l) {
+        const int64_t n = p->h_count[pd.cand][4 * l];
+        const int k = (int)(n < p->c.num_point ? n : p->c.num_point);
+        randperm_head(p->rng[(size_t)l], n, p->c.num_point, p->perm_scratch, p->perm_host.data() + (size_t)l * cap);
+        p->nsel_host[(size_t)l] = k;
+        if (n_cand_out) n_cand_out[l] = (int32_t)n;
+        if (n_sel_out) n_sel_out[l] = k;
+    }
+    return mv_frame_pipe_finish(p, p->perm_host.data(), p->nsel_host.data(), pose_sink);
 }
 
 // ------------------------------------------------------------------------------------------------ pose-dependent half

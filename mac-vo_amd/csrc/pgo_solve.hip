@@ -107,6 +107,41 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double (*__restrict__ 
     __syncthreads();
 }
 
+// The 55-value reduction of a build pass, round 3.  In-kernel cycle stamps (tools/scratch/pgo_stamps.py) put the form above — per
+// value four dependent DPP stages (two v_mov_dpp + one v_add_f64 each, with their wait states), eight v_readlane and three more
+// adds — at 13.7 k of the 30 k cycles of an LM step: fp64 has no DPP-fused add, and the readlane -> SGPR -> VALU round trip of 55
+// values is a long dependent instruction stream for the single wave of a SIMD.  Here only the three cheapest stages stay in
+// registers (quad_perm x2 + row_half_mirror: every 8-lane group then holds its sum); the 8 partials per wave and value go to LDS
+// (one ds_write_b64 per value with 8 lanes active), 55 threads add the 32 partials of one value each (ds_read_b128, four
+// independent accumulators), and every thread reads the 55 sums back as broadcast ds_read_b128.  14 KB of LDS, three barriers.
+// The summation tree changes (8-lane groups first, then 32 partials in order), i.e. results move by ~1e-16 relative.
+template <int NW>
+__device__ __forceinline__ void block_sum_build(double (&v)[NRED], double* __restrict__ part /* [NRED][NW * 8] */,
+                                                double* __restrict__ fin /* [NRED + 1] */) {
+    static_assert(NW == 4, "the wide variant");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, t = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < NRED; ++k) {
+        double s = v[k];
+        s = dpp_add<0xB1>(s);    // quad_perm [1,0,3,2]
+        s = dpp_add<0x4E>(s);    // quad_perm [2,3,0,1]
+        s = dpp_add<0x141>(s);   // row_half_mirror: the other quad of the 8-lane half
+        if ((lane & 7) == 0) part[k * (NW * 8) + wave * 8 + (lane >> 3)] = s;
+    }
+    __syncthreads();
+    if (t < NRED) {
+        const double* p = part + t * (NW * 8);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NW * 8; i += 4) { a0 += p[i]; a1 += p[i + 1]; a2 += p[i + 2]; a3 += p[i + 3]; }
+        fin[t] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NRED; ++k) v[k] = fin[k];
+    __syncthreads();   // `part` / `fin` are rewritten by the next pass
+}
+
 __device__ __forceinline__ void quat_to_R(Pose& P) {
     const double x = P.q[0], y = P.q[1], z = P.q[2], w = P.q[3];
     P.R[0] = 1 - 2 * (y * y + z * z); P.R[1] = 2 * (x * y - z * w);     P.R[2] = 2 * (x * z + y * w);
@@ -398,6 +433,8 @@ template <int GT, int NW>
 __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParams lm) {
     constexpr int PGO_THREADS = 64 * NW;
     __shared__ double red_tab[NW][NRED];
+    __shared__ __attribute__((aligned(16))) double red_part[NW == 4 ? NRED * NW * 8 : 1];
+    __shared__ __attribute__((aligned(16))) double red_fin[NW == 4 ? NRED + 1 : 1];
     const int prob = blockIdx.x;
     const int tid = threadIdx.x;
     const int beg = a.offsets[prob], end = a.offsets[prob + 1];
@@ -452,7 +489,8 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
                 if (d.valid) accumulate_point<GT>(g, lm, P, d, acc);
             }
         }
-        block_sum<NRED, NW>(acc, red_tab);
+        if constexpr (NW == 4) block_sum_build<NW>(acc, red_part, red_fin);
+        else block_sum<NRED, NW>(acc, red_tab);
         double* Aw = acc;
         const double* gw = acc + 21;
         const double* Au = acc + 27;
@@ -471,7 +509,9 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
 #pragma unroll
             for (int j = 0; j < 6; ++j) Aw[tri(j, j)] += Aw[tri(j, j)] * damping;
             // solve A D = b, b = -gw, by Cholesky (A = L L^T); every thread solves redundantly (uniform control flow)
-            double L[6][6], D[6];
+            // (the two substitutions multiply by the reciprocal pivots the factorisation already has: an fp64 division is a ~12
+            // instruction dependent chain, and with up to 17 solves in a rejected step this serial piece was 3.5 k cycles each)
+            double L[6][6], D[6], linv[6];
             bool ok = true;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
@@ -482,6 +522,7 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
                 const double ljj = sqrt(dd);
                 const double inv = 1.0 / ljj;
                 L[j][j] = ljj;
+                linv[j] = inv;
 #pragma unroll
                 for (int i2 = j + 1; i2 < 6; ++i2) {
                     double sacc = Aw[tri(j, i2)];
@@ -497,14 +538,14 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
                 double sacc = -gw[j];
 #pragma unroll
                 for (int k = 0; k < j; ++k) sacc -= L[j][k] * yv[k];
-                yv[j] = sacc / L[j][j];
+                yv[j] = sacc * linv[j];
             }
 #pragma unroll
             for (int j = 5; j >= 0; --j) {
                 double sacc = yv[j];
 #pragma unroll
                 for (int k = j + 1; k < 6; ++k) sacc -= L[k][j] * D[k];
-                D[j] = sacc / L[j][j];
+                D[j] = sacc * linv[j];
             }
 
             const Pose P_prev = P;

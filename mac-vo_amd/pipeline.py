@@ -501,6 +501,11 @@ class NativeHotPath:
         self.lanes = int(lanes)
         self.generators = list(generators) if generators is not None else [None] * self.lanes
         assert len(self.generators) == self.lanes
+        # integer entries = seeds of NATIVE per-lane generators (mv_frame_pipe_seed_lanes: MT19937 + Fisher-Yates in C++, the bits of
+        # torch.Generator().manual_seed(seed) + torch.randperm at ~1/20 of the host time — what many-lane steps need)
+        self._native_seeds = all(isinstance(g, int) and not isinstance(g, bool) for g in self.generators)
+        if not self._native_seeds and any(isinstance(g, int) for g in self.generators):
+            raise ops.L.MacvoHipError("generators: either all torch.Generator / None or all integer seeds")
         self._cap = max(self.cfg.num_point, 1)
         self._volume_ahead = os.environ.get("MV_PIPE_VOLUME_AHEAD", "1") != "0"   # A/B knobs of run()
         self._depth = max(1, min(3, int(os.environ.get("MV_PIPE_DEPTH", "3"))))
@@ -549,6 +554,9 @@ class NativeHotPath:
         pipe = C.c_void_p()
         L.check(lib.mv_frame_pipe_create(C.byref(pc), self._base, nbytes, C.byref(pipe)), "mv_frame_pipe_create")
         self._pipe, self._lib, self._pc = pipe, lib, pc
+        if self._native_seeds:
+            seeds = (C.c_uint64 * self.lanes)(*[int(g) & 0xFFFFFFFFFFFFFFFF for g in self.generators])
+            L.check(lib.mv_frame_pipe_seed_lanes(pipe, seeds), "mv_frame_pipe_seed_lanes")
         if self._init_pose is not None:
             self._set_pose(self._init_pose)
 
@@ -673,6 +681,11 @@ class NativeHotPath:
         """Host half of a frame: wait for the candidate counts, draw the permutations (CPU generators, lane order), enqueue
         the pose-dependent kernels.  Returns a :class:`_NativeResult` (a list of them, one per lane, for lanes > 1)."""
         L, lib = ops.L, self._lib
+        if self._native_seeds:
+            L.check(lib.mv_frame_pipe_release(self._pipe, ops._stream()), "mv_frame_pipe_release")
+            L.check(lib.mv_frame_pipe_finish_seeded(self._pipe, None if pose_sink is None else pose_sink.data_ptr(), self._ncand, self._nsel),
+                    "mv_frame_pipe_finish_seeded")
+            return self._finished()
         L.check(lib.mv_frame_pipe_wait_candidates(self._pipe, self._ncand), "mv_frame_pipe_wait_candidates")
         num = self.cfg.num_point
         if self.lanes == 1:
@@ -696,6 +709,11 @@ class NativeHotPath:
         L.check(lib.mv_frame_pipe_release(self._pipe, ops._stream()), "mv_frame_pipe_release")
         L.check(lib.mv_frame_pipe_finish(self._pipe, perm_ptr, self._nsel, None if pose_sink is None else pose_sink.data_ptr()),
                 "mv_frame_pipe_finish")
+        return self._finished()
+
+    def _finished(self):
+        """Bookkeeping behind a finish call: map registration, result views."""
+        L, lib = ops.L, self._lib
         self._n_fin += 1
         mp = getattr(self, "_map", None)
         if mp is not None:

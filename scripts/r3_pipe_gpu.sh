@@ -1,12 +1,15 @@
 cd $GRAFT_REPO_ROOT
-L=gpurun_out/r3_pipe1.log; : > $L
-timeout 600 python -m pytest tests/test_gpu_native.py tests/test_gpu_split.py -x -q 2>&1 | tail -5 >> $L
-for w in back vol main; do echo "== pack on $w" >> $L; MV_PIPE_PACK_ON=$w timeout 300 python bench.py --steps 300 --no-cpu-baseline --config4-steps 0 --no-decoder-leg --exact-steps 0 2>&1 | tail -1 | python -c "
-import sys, json
-d = json.loads(sys.stdin.read()); r = d['roofline']
-print(d['value'], 'fps', d['ms_per_step'], 'ms/step | GEMM', r['avg_launch_us'], 'us in pipe, alone', r.get('isolated_avg_launch_us'), '| frac', r['frac'], r['kernel'])" >> $L 2>&1; done
-timeout 600 python bench.py --steps 300 2>&1 | tail -1 > gpurun_out/r3_bench_default.json
+L=gpurun_out/r3_pipe2.log; : > $L
+timeout 600 python -m pytest tests/test_gpu_native.py -x -q 2>&1 | tail -5 >> $L
+timeout 900 python bench.py --steps 300 2>&1 | tail -1 > gpurun_out/r3_bench_default.json
 python -c "
 import json; d = json.load(open('gpurun_out/r3_bench_default.json'))
-print(json.dumps({k: d[k] for k in ('value','ms_per_step','roofline','exact_fp32','config4','parity')}, indent=1)[:3500])" >> $L 2>&1
+def rl(r): return None if r is None else {k: r[k] for k in ('kernel','avg_launch_us','frac','isolated_avg_launch_us','isolated_frac') if k in r}
+print('default', d['value'], 'fps', d['ms_per_step'], rl(d['roofline']))
+for k, v in (d.get('other_precisions') or {}).items(): print(k, v['value'], v['ms_per_step'], rl(v['roofline']))
+c = d['config4']; print('config4', c['value'], c['ms_per_step'], rl(c['roofline']))
+print('parity', d['parity']['keypoints_bit_exact_frames'], d['parity']['max_pose_dt_m'], d['rte_vs_oracle'], 'cpu', d['cpu_baseline']['value'])
+print('decoder', d['decoder_loop'])" >> $L 2>&1
+python tools/lane_timeline.py 1 300 2>&1 | tail -5 >> $L
+TL_PRECISION=f16x2 python tools/lane_timeline.py 1 300 2>&1 | tail -5 >> $L
 cat $L

@@ -245,3 +245,31 @@ def test_config4_batch32_through_frame_driver(gpu):
             d_t, d_r = se3.pose_error(ro["pose"].double(), pose.cpu().double())
             assert d_t <= 1e-4 and d_r <= 1e-4, (l, t, d_t, d_r)
             assert int(info[0, 1].item()) == ro["steps"]
+
+
+def test_native_seeded_lanes_equal_torch_generators(gpu):
+    """`generators=[int, ...]`: the driver's own per-lane MT19937 + partial Fisher-Yates (mv_frame_pipe_seed_lanes /
+    mv_frame_pipe_finish_seeded) must select exactly what `torch.Generator().manual_seed(seed)` + `torch.randperm(n)[:num]` selects —
+    frame after frame (the generator state advances by n - 1 draws per call), with ragged candidate counts."""
+    from macvo_amd.pipeline import Camera, HotPathConfig, NativeHotPath, stack_lanes
+
+    H, W, n_frames, lanes = 240, 320, 6, 3
+    seqs = [synth.make_sequence(n_frames, H, W, C=64, iters=2, seed=400 + l, pool=1) for l in range(lanes)]
+    cam = seqs[0][0]
+    seeds = [77, 2 ** 40 + 5, 123456789]                      # (torch seeds its MT19937 with the low 32 bits)
+    a = NativeHotPath(Camera(**cam), HotPathConfig(num_point=150), gpu, lanes=lanes, generators=seeds)
+    b = NativeHotPath(Camera(**cam), HotPathConfig(num_point=150), gpu, lanes=lanes, generators=_gens(seeds))
+    batched = [stack_lanes([_inputs(seqs[l][1][t], gpu) for l in range(lanes)]) for t in range(n_frames)]
+    torch.cuda.synchronize()
+    a.initialize(batched[0])
+    b.initialize(batched[0])
+    sa, sb = torch.zeros(n_frames - 1, lanes, 7, device=gpu), torch.zeros(n_frames - 1, lanes, 7, device=gpu)
+    ra = [[(r.kp0_uv.clone(), r.n_cand) for r in res] for res in a.run(batched[1:], pose_sink=sa) if a.sync_pose() is None]
+    rb = [[(r.kp0_uv.clone(), r.n_cand) for r in res] for res in b.run(batched[1:], pose_sink=sb) if b.sync_pose() is None]
+    torch.cuda.synchronize()
+    assert len(ra) == n_frames - 1
+    for t in range(n_frames - 1):
+        for l in range(lanes):
+            assert ra[t][l][1] == rb[t][l][1] and ra[t][l][1] > 150          # more candidates than selected points
+            assert torch.equal(ra[t][l][0], rb[t][l][0]), (t, l)
+    assert torch.equal(sa, sb)

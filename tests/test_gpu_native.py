@@ -259,7 +259,7 @@ from macvo_amd.pipeline import Camera, HotPathConfig, NativeHotPath
 gpu = torch.device("cuda:0")
 cam, frames, _ = synth.make_sequence(7, 256, 384, C=256, iters=3, seed=31)
 ins = _inputs(frames, gpu)
-nat = NativeHotPath(Camera(**cam), HotPathConfig(volume_precision="bf16x3"), gpu)
+nat = NativeHotPath(Camera(**cam), HotPathConfig(volume_precision=sys.argv[2]), gpu)
 nat.initialize(ins[0])
 torch.manual_seed(5)
 sink = torch.zeros(6, 7, device=gpu)
@@ -274,7 +274,8 @@ print(ops.last_volume_kernel(), h.hexdigest())
 """
 
 
-def test_native_bf16x3_volume_equals_python_driver_and_oracle(gpu):
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+def test_native_split_volume_equals_python_driver_and_oracle(gpu, mode):
     """volume_precision="bf16x3" through both drivers (C = 256: the packed streaming GEMM): the native pipe — pack on another
     stream beside the previous GEMM, two operand sets — must reproduce the Python-sequenced run bit for bit, frame by frame and
     pipelined, whatever stream the pack runs on (MV_PIPE_PACK_ON); keypoints equal the ORACLE's (fp32 einsum volume) and the pose
@@ -288,7 +289,7 @@ def test_native_bf16x3_volume_equals_python_driver_and_oracle(gpu):
     H, W, n_frames = 256, 384, 5                      # 32 x 48 = 1536 queries = 24 sub-tiles of 64 columns
     cam, frames, _ = synth.make_sequence(n_frames, H, W, C=256, iters=3, seed=30)
     ins = _inputs(frames, gpu)
-    py, nat = _pair(cam, dict(volume_precision="bf16x3"), gpu)
+    py, nat = _pair(cam, dict(volume_precision=mode), gpu)
     ora = OracleHotPath(cam, {})
     py.initialize(ins[0])
     nat.initialize(ins[0])
@@ -299,7 +300,7 @@ def test_native_bf16x3_volume_equals_python_driver_and_oracle(gpu):
         torch.manual_seed(70 + t)
         b = nat.step(ins[t])
         torch.cuda.synchronize()
-        assert ops.last_volume_kernel() == "corr_volume_split_stream<bf16x3>"
+        assert ops.last_volume_kernel() == f"corr_volume_split_stream<{mode}>"
         torch.manual_seed(70 + t)
         ro = ora.step(frames[t])
         assert torch.equal(py.last_tokens, nat.last_tokens)
@@ -313,8 +314,8 @@ def test_native_bf16x3_volume_equals_python_driver_and_oracle(gpu):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for where in ("back", "vol", "main"):
-        r = subprocess.run([sys.executable, "-c", _BF16X3_PIPE, root], env=dict(os.environ, MV_PIPE_PACK_ON=where), capture_output=True,
+        r = subprocess.run([sys.executable, "-c", _BF16X3_PIPE, root, mode], env=dict(os.environ, MV_PIPE_PACK_ON=where), capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.split())
-    assert all(o[0] == "corr_volume_split_stream<bf16x3>" for o in outs) and len({o[1] for o in outs}) == 1, outs
+    assert all(o[0] == f"corr_volume_split_stream<{mode}>" for o in outs) and len({o[1] for o in outs}) == 1, outs
