@@ -136,32 +136,43 @@ __global__ __launch_bounds__(256) void volume_pack_kernel(const float* __restric
 
 // ------------------------------------------------------------------------------------------------ GEMM
 // (asm loads / stores below work on accumulator-file registers: on gfx90a+ VMEM data operands and MFMA A/B sources may be AGPRs)
-template <int NP, bool F16, int KS>
+template <int NP, bool F16, int KS, int NWV>
 struct SplitCfg {
+    static_assert(NWV == 4 || NWV == 8, "waves per workgroup");
+    static constexpr int JB = 8 / NWV;                 // 32-column blocks of the sub-tile a wave owns (NWV = 8: one, 2 waves per SIMD)
     static constexpr int KH = KS / 2;                  // k-steps per K half
     static constexpr int NA = KS * NP;                 // A fragment units per wave and band
+    static constexpr int NA_ACC = NWV == 8 ? NA - 8 : NA;   // ... of which this many live in the accumulator register file
     static constexpr int HALF_UNITS = KH * NP;         // 1-KB units of one row block in one K half
     static constexpr int SLOT_BYTES = 2 * HALF_UNITS * 1024;   // 64 columns = 2 row blocks
     static constexpr int NSLOT = 3;
-    static constexpr int D = HALF_UNITS / 2;           // DMA pieces per wave and half (4 waves x D = 2 x HALF_UNITS)
+    static constexpr int D = 2 * HALF_UNITS / NWV;     // DMA pieces per wave and half
     static constexpr int NQ = NP == 3 ? 6 : 3;         // piece products
-    static constexpr int SPH = 16;                     // output stores per wave and half (32 per item): 2 behind each k-step
+    static constexpr int NM = NQ * JB;                 // MFMAs (= filler slots) per k-step
+    static constexpr int SPH = KH * JB;                // output stores per wave and half: JB behind each k-step
+    static constexpr int FLUSH = 2 * SPH;              // stores of one item
     // LDS-DMA pieces of a half: PH straight behind the barrier, the rest spread over the k-steps (at most 2 per k-step)
     static constexpr int PH = D >= 12 ? 3 : 2;
     static constexpr int pieces_in(int ks) { return (D - PH) / KH + (ks < (D - PH) % KH ? 1 : 0); }
     static constexpr int first_piece(int ks) { return PH + ks * ((D - PH) / KH) + (ks < (D - PH) % KH ? ks : (D - PH) % KH); }
     static constexpr int last_piece_ks() { int k = 0; for (int i = 0; i < KH; ++i) if (pieces_in(i) > 0) k = i; return k; }
+    // filler slots of a k-step: reads [0, JB NP), stores [JB NP, JB NP + JB), then up to two pieces (sharing the last slot with a
+    // store when the k-step has no slot left: NP = 2)
+    static constexpr int SL_STORE = JB * NP;
+    static constexpr int SL_PIECE0 = SL_STORE + JB < NM ? SL_STORE + JB : NM - 1;
+    static constexpr int SL_PIECE1 = SL_PIECE0 + 2 < NM ? SL_PIECE0 + 2 : -1;
+    static_assert(SL_STORE + JB <= NM, "a k-step must have a slot for each read and store");
+    static_assert(SL_PIECE1 >= 0 || pieces_in(0) <= 1, "two pieces per k-step need two slots");
     // vmcnt arithmetic (in-order counter).  The pieces of half h are issued inside half h - 2; its last piece goes out in k-step
-    // last_piece_ks(), BEHIND that k-step's two stores.  Behind that last piece the wave issues: the stores of the remaining
+    // last_piece_ks(), BEHIND that k-step's stores.  Behind that last piece the wave issues: the stores of the remaining
     // k-steps of half h - 2, then the D pieces and SPH stores of half h - 1.  "vmcnt <= that number" at the barrier of half h
     // therefore means the pieces have landed.  Without stores in flight (first / second item of a segment) the counts shrink.
-    static constexpr int STORES_BEHIND_LAST_PIECE = 2 * (KH - 1 - last_piece_ks());
-    static constexpr int EB = F16 ? 2 : 0;             // F16: two column-exponent loads at the head of every item's first half
+    static constexpr int STORES_BEHIND_LAST_PIECE = JB * (KH - 1 - last_piece_ks());
+    static constexpr int EB = F16 ? JB : 0;            // F16: column-exponent loads at the head of every item's first half
     static constexpr int W_STEADY0 = STORES_BEHIND_LAST_PIECE + D + SPH;        // first half of an item: the half before was a second half
     static constexpr int W_STEADY = STORES_BEHIND_LAST_PIECE + D + SPH + EB;    // second half: the half before carried the EB loads
-    static constexpr int NEA = F16 ? 4 : 0;            // F16: row-exponent loads riding with the A fragments
-    static_assert(W_STEADY <= 63 && 2 * (D + SPH) + EB <= 63, "vmcnt is a 6-bit counter");
-    static_assert(KS % 2 == 0 && HALF_UNITS % 2 == 0, "");
+    static_assert(W_STEADY <= 63 && 2 * (D + SPH) + EB <= 63 && FLUSH + D + EB <= 63, "vmcnt is a 6-bit counter");
+    static_assert(KS % 2 == 0 && (2 * HALF_UNITS) % NWV == 0 && HALF_UNITS % D == 0, "a wave's pieces lie inside one row block");
 };
 
 #ifdef MV_SPLIT_PROBE
@@ -185,15 +196,19 @@ __constant__ long long* g_split_stamps = nullptr;   // [workgroup][wave][64 item
 #define STAMP(i) ((void)0)
 #endif
 
-template <int NP, bool F16, int KS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void corr_volume_split_stream(
+template <int NP, bool F16, int KS, int NWV>
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 4, NWV / 4))) void corr_volume_split_stream(
     const uint16_t* __restrict__ pk1, const uint16_t* __restrict__ pk2, float* __restrict__ out, int N1, int N2, int B, int R) {
-    using Cf = SplitCfg<NP, F16, KS>;
-    constexpr int KH = Cf::KH, NA = Cf::NA, HU = Cf::HALF_UNITS, D = Cf::D, NQ = Cf::NQ, NSLOT = Cf::NSLOT;
+    using Cf = SplitCfg<NP, F16, KS, NWV>;
+    constexpr int KH = Cf::KH, NA = Cf::NA, HU = Cf::HALF_UNITS, D = Cf::D, NSLOT = Cf::NSLOT, JB = Cf::JB;
     constexpr unsigned SLOT_BYTES = Cf::SLOT_BYTES;
     extern __shared__ __attribute__((aligned(16))) i32x4 smem_sp[];   // B ring: NSLOT slots of [2 row blocks][KH][NP][64 lanes] x 16 B
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // NWV = 4: wave w owns rows 32 w .. and both 32-column blocks of the sub-tile; NWV = 8 (two waves per SIMD: the fillers of one
+    // hide behind the MFMAs of the other): waves 2 w, 2 w + 1 share rows 32 w .. and take one column block each
+    const int wr = NWV == 8 ? wave >> 1 : wave;
+    const int jb0 = NWV == 8 ? wave & 1 : 0;
     const int kh = lane >> 5, li = lane & 31;
     const int nb = (N1 + 127) >> 7, nc = N2 >> 6;
     const int nrb1 = ((N1 + 31) >> 5) + 1, nrb2 = ((N2 + 31) >> 5) + 1;   // row blocks per pair incl. the replica block
@@ -228,14 +243,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int* ex2 = reinterpret_cast<const int*>(reinterpret_cast<const char*>(pk2) + (size_t)B * nrb2 * (NA * 1024));
 
     // ---- B loader (LDS-DMA), two K halves ahead of the MFMAs; all walking state wave-uniform.  A half of a sub-tile is two
-    // contiguous runs of HU units (row blocks 2c, 2c + 1); wave w copies D units of row block 2c + (w >> 1) from offset (w & 1) * D
-    // to the same position of the slot image.
+    // contiguous runs of HU units (row blocks 2c, 2c + 1); wave w copies units [w D, (w + 1) D) of that 2 HU-unit image to the same
+    // position of the slot.
     int ld_it = it, ld_hh = 0, ld_slot = 0, ld_b, ld_g, ld_band, ld_c, ld_c0, ld_cend;
     decode(it, ld_b, ld_g, ld_band, ld_c);
     ld_c0 = reg_c0(ld_g);
     ld_cend = reg_c0(ld_g + 1);
-    auto src_of = [&](int b, int c) {
-        return reinterpret_cast<const char*>(pk2) + (((size_t)b * nrb2 + 2 * c + (wave >> 1)) * (2 * HU) + (wave & 1) * D) * 1024;
+    auto src_of = [&](int b, int c) {   // the wave's D units of a half: units [wave D, (wave + 1) D) of the 2 HU-unit slot image
+        return reinterpret_cast<const char*>(pk2) + (((size_t)b * nrb2 + 2 * c + (wave * D) / HU) * (2 * HU) + (wave * D) % HU) * 1024;
     };
     const char* ld_ptr = src_of(ld_b, ld_c);
     auto advance_loader = [&]() __attribute__((always_inline)) {   // behind the last piece of a half
@@ -277,12 +292,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     i32x4 afr[NA];
     i32x4 ear[4];                                // F16: scale exponents of this lane's 16 accumulator rows (rows 8 g + 4 kh + 0..3)
     auto issue_a = [&](int b, int band) __attribute__((always_inline)) {
-        const int rb = min(band * 4 + wave, nrb1 - 1);           // waves past the bottom edge take the replica block (row N1 - 1 x 32)
+        const int rb = min(band * 4 + wr, nrb1 - 1);             // waves past the bottom edge take the replica block (row N1 - 1 x 32)
         const char* A = reinterpret_cast<const char*>(pk1) + ((size_t)b * nrb1 + rb) * (size_t)(NA * 1024);
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            // 12-bit immediates reach 4 units; the rest of the offset rides on the (uniform) base
-            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&a"(afr[i]) : "v"(lane16), "s"(A + (i >> 2) * 4096), "n"((i & 3) * 1024) : "memory");
+            // 12-bit immediates reach 4 units; the rest of the offset rides on the (uniform) base.  Register file of the destination:
+            // an asm output counts as defined at the end of the statement, so hipcc may MOVE it right away — before the data has
+            // landed — if the file the constraint names has no room for it until its first use.  With two waves per SIMD (256
+            // registers: 128 + 128) the accumulator file holds 32 accumulator registers + 24 of the 32 A units; the last 8 units
+            // are therefore loaded into VGPRs in the first place (seen otherwise: v_accvgpr_read copies of half the fragments in
+            // front of the wait, garbage products).  The ISA dump must show no move of `afr` between these loads and the "+" marks.
+            if (i < Cf::NA_ACC) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&a"(afr[i]) : "v"(lane16), "s"(A + (i >> 2) * 4096), "n"((i & 3) * 1024) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(afr[i]) : "v"(lane16), "s"(A + (i >> 2) * 4096), "n"((i & 3) * 1024) : "memory");
         }
         if (F16) {
             const int* E = ex1 + ((size_t)b * nrb1 + rb) * 32;
@@ -296,10 +317,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // F16: scale exponents of this lane's two output columns of an item, loaded at the head of the item's first half
     int cur_b = 0, cur_c = 0;                    // (pair, sub-tile) of the item being multiplied
     auto issue_eb = [&](int& e0, int& e1) __attribute__((always_inline)) {
-        const int* E = ex2 + ((size_t)cur_b * nrb2 + 2 * cur_c) * 32;
+        const int* E = ex2 + ((size_t)cur_b * nrb2 + 2 * cur_c + jb0) * 32;
         const unsigned vo = (unsigned)li * 4u;
         asm volatile("global_load_dword %0, %1, %2" : "=&v"(e0) : "v"(vo), "s"(E) : "memory");
-        asm volatile("global_load_dword %0, %1, %2 offset:128" : "=&v"(e1) : "v"(vo), "s"(E) : "memory");
+        if (JB == 2) asm volatile("global_load_dword %0, %1, %2 offset:128" : "=&v"(e1) : "v"(vo), "s"(E) : "memory");
     };
 
     float* O = nullptr;                          // wave-uniform: column 0 of the CURRENT item's output block (row 0 of the pair)
@@ -356,11 +377,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (pi == D - 1) advance_loader();
         };
         const i32x4* q = smem_sp + (unsigned)slot * (SLOT_BYTES / 16) + lane;
-        i32x4 fb[2][2][NP];                      // [stage][column block][piece]
+        i32x4 fb[2][JB][NP];                     // [stage][column block][piece]
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < JB; ++j)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) fb[0][j][p] = q[((j * KH + 0) * NP + p) * 64];
+            for (int p = 0; p < NP; ++p) fb[0][j][p] = q[(((jb0 + j) * KH + 0) * NP + p) * 64];
         __builtin_amdgcn_sched_barrier(0);
         if (F16 && H == 0) {
             // the previous item's column exponents were loaded in front of the pieces this barrier has just waited for: usable now
@@ -375,8 +396,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int cur = ks & 1, nxt = cur ^ 1;
             const int npk = Cf::pieces_in(ks), pk0 = Cf::first_piece(ks);     // (compile-time after unrolling)
 #pragma unroll
-            for (int sl = 0; sl < 2 * NQ; ++sl) {
-                const int qd = sl >> 1, jb = sl & 1;
+            for (int sl = 0; sl < Cf::NM; ++sl) {
+                const int qd = sl / JB, jb = sl % JB;
                 constexpr int base = NP == 3 ? 0 : 3;
                 const int pa = PA[base + qd], pb = PB[base + qd];
                 const i32x4 a = afr[(H * KH + ks) * NP + pa];
@@ -392,20 +413,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, fb[cur][jb][pb]), c, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                // ---- the filler of this slot
-                if (sl < 2 * NP) {
+                // ---- the filler(s) of this slot
+                if (sl < Cf::SL_STORE) {
                     if (ks + 1 < KH) {
                         const int j2 = sl / NP, p2 = sl % NP;
-                        fb[nxt][j2][p2] = DBG(8) ? fb[cur][j2][p2] : q[((j2 * KH + ks + 1) * NP + p2) * 64];
+                        fb[nxt][j2][p2] = DBG(8) ? fb[cur][j2][p2] : q[(((jb0 + j2) * KH + ks + 1) * NP + p2) * 64];
                     }
-                } else if (sl == 2 * NP || sl == 2 * NP + 1) {
-                    if (HAVE_PREV) store_j(sl == 2 * NP ? p0 : p1, H * KH + ks, sl - 2 * NP, O - 64, ep[sl - 2 * NP]);   // one accumulator row per k-step
-                    if (sl == 2 * NQ - 1 && npk > 0) piece(pk0);                 // (NQ = 3: the last slot also carries the k-step's piece)
-                } else if (sl == 2 * NP + 2) {
-                    if (npk > 0) piece(pk0);
-                } else if (sl == 2 * NP + 4) {
-                    if (npk > 1) piece(pk0 + 1);
+                } else if (sl < Cf::SL_STORE + JB) {
+                    const int js = sl - Cf::SL_STORE;
+                    if (HAVE_PREV) store_j(js ? p1 : p0, H * KH + ks, js, O - 64, ep[js]);   // one accumulator row per k-step and column block
                 }
+                if (sl == Cf::SL_PIECE0 && npk > 0) piece(pk0);
+                if (sl == Cf::SL_PIECE1 && npk > 1) piece(pk0 + 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -436,14 +455,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             store_j(p0, r, 0, O - 64, ep[0]);
-            store_j(p1, r, 1, O - 64, ep[1]);
+            if (JB == 2) store_j(p1, r, 1, O - 64, ep[1]);
         }
     };
-    static_assert(KS == 16, "store interleave: one accumulator row per k-step");
+    static_assert(KS == 16, "store interleave: one accumulator row per k-step and column block");
     // waits: see the derivation in SplitCfg / DESIGN.md.  first item of a segment: everything older than the 32 flush stores has
     // landed (hand wait below), no stores ride along; second item: D pieces (+ SPH stores) behind the pieces it consumes; then steady.
-    using WF0 = std::integral_constant<int, 32>;
-    using WF1 = std::integral_constant<int, 32 + D + Cf::EB>;
+    using WF0 = std::integral_constant<int, Cf::FLUSH>;
+    using WF1 = std::integral_constant<int, Cf::FLUSH + D + Cf::EB>;
     using WS0 = std::integral_constant<int, D>;
     using WS1 = std::integral_constant<int, D + Cf::SPH + Cf::EB>;
     using WW0 = std::integral_constant<int, Cf::W_STEADY0>;
@@ -460,19 +479,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     while (true) {                               // one pass per (pair, region, band) segment of the run
         const int seg_end = min(it_end, it + (reg_c0(g + 1) - c0i));
 #pragma unroll
-        for (int i = 0; i < NA; ++i) asm volatile("" : "+a"(afr[i]));   // the fragments count as defined only here, behind the hand-placed wait
+        for (int i = 0; i < NA; ++i) {          // the fragments count as defined only here, behind the hand-placed wait
+            if (i < Cf::NA_ACC) asm volatile("" : "+a"(afr[i]));
+            else asm volatile("" : "+v"(afr[i]));
+        }
         if (F16) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) asm volatile("" : "+v"(ear[gq]));
 #pragma unroll
             for (int r = 0; r < 16; ++r) nea[r] = -ear[r >> 2][r & 3];
         }
-        O = out + (size_t)b * N1 * N2 + (size_t)c0i * 64;
+        O = out + (size_t)b * N1 * N2 + (size_t)c0i * 64 + jb0 * 32;
         cur_b = b;
         cur_c = c0i;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            roff[r] = ((unsigned)min(band * 128 + wave * 32 + 4 * kh + (r & 3) + 8 * (r >> 2), N1 - 1) * (unsigned)N2 + li) * 4u;
+            roff[r] = ((unsigned)min(band * 128 + wr * 32 + 4 * kh + (r & 3) + 8 * (r >> 2), N1 - 1) * (unsigned)N2 + li) * 4u;
         item(WF0{}, WF1{}, No{}, x0, x1, x0, x1, ex, ex);
         bool in_y = false;
         if (it < seg_end) {
@@ -505,7 +527,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (in_y) flush(y0, y1, ey);
         else flush(x0, x1, ex);
         if (!more) break;
-        wait_vmcnt<32>();                        // the A (+ row exponent) loads precede the 32 flush stores
+        wait_vmcnt<Cf::FLUSH>();                 // the A (+ row exponent) loads precede the flush stores
     }
     wait_vmcnt<0>();                             // nothing of this workgroup may still be in flight towards its LDS when it retires
 }
@@ -576,10 +598,17 @@ extern "C" int mv_corr_volume_packed(const void* packed1, const void* packed2, f
     const int np = pieces_of(mode);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)corr_volume_split_stream<3, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)corr_volume_split_stream<2, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)corr_volume_split_stream<3, false, 16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)corr_volume_split_stream<2, true, 16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)corr_volume_split_stream<2, true, 16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
+    // MV_SPLIT_WAVES=8: the f16x2 kernel as ONE 8-wave workgroup per CU (two waves per SIMD, each wave one 32-column block).  Built to
+    // hide the fillers of one wave behind the MFMAs of the other; measured it is no faster (74.7 vs 74.4 us alone) — with N(0,1)
+    // operands both forms sit at the chip's POWER limit (all-zero operands, same instruction stream: 55-57 us; every filler class
+    // knocked out: 55 us) — and it costs the co-running small kernels their registers (one-lane pipeline 4.40 k vs 4.84 k frames/s).
+    static int waves = -1;
+    if (waves < 0) { const char* e = getenv("MV_SPLIT_WAVES"); waves = (e && atoi(e) == 8) ? 8 : 4; }
     // column regions: one region's B planes (nc / R sub-tiles x 64 rows x C x 2 B x pieces) <= 4 MB.  Measured at 640x480 (7.4 MB
     // of B planes per pair, all of it Infinity-Cache resident): R = 1 / 2 / 3 / 4 / 6 -> 117 / 110 / 113 / 114 / 116 us: fewer, longer
     // band segments (each segment change reloads 192 KB of A fragments per workgroup, ~3 us) against L2 hits on the B sub-tiles
@@ -605,16 +634,21 @@ extern "C" int mv_corr_volume_packed(const void* packed1, const void* packed2, f
         }
     }
 #endif
-    const dim3 g((cu_count() & ~7)), blk(256);   // one workgroup per CU, a multiple of 8: one run per XCD
+    const dim3 g((cu_count() & ~7));             // one workgroup per CU, a multiple of 8: one run per XCD
     if (mode == MV_PACK_BF16X3) {
-        using K = SplitCfg<3, false, 16>;
+        using K = SplitCfg<3, false, 16, 4>;
         mv_note_volume_kernel("corr_volume_split_stream<bf16x3>");
-        hipLaunchKernelGGL((corr_volume_split_stream<3, false, 16>), g, blk, K::NSLOT * K::SLOT_BYTES, (hipStream_t)stream,
+        hipLaunchKernelGGL((corr_volume_split_stream<3, false, 16, 4>), g, dim3(256), K::NSLOT * K::SLOT_BYTES, (hipStream_t)stream,
+                           (const uint16_t*)packed1, (const uint16_t*)packed2, out, N1, N2, B, R);
+    } else if (waves == 4) {
+        using K = SplitCfg<2, true, 16, 4>;
+        mv_note_volume_kernel("corr_volume_split_stream<f16x2>");
+        hipLaunchKernelGGL((corr_volume_split_stream<2, true, 16, 4>), g, dim3(256), K::NSLOT * K::SLOT_BYTES, (hipStream_t)stream,
                            (const uint16_t*)packed1, (const uint16_t*)packed2, out, N1, N2, B, R);
     } else {
-        using K = SplitCfg<2, true, 16>;
+        using K = SplitCfg<2, true, 16, 8>;
         mv_note_volume_kernel("corr_volume_split_stream<f16x2>");
-        hipLaunchKernelGGL((corr_volume_split_stream<2, true, 16>), g, blk, K::NSLOT * K::SLOT_BYTES, (hipStream_t)stream,
+        hipLaunchKernelGGL((corr_volume_split_stream<2, true, 16, 8>), g, dim3(512), K::NSLOT * K::SLOT_BYTES, (hipStream_t)stream,
                            (const uint16_t*)packed1, (const uint16_t*)packed2, out, N1, N2, B, R);
     }
     return mv_launch_status();

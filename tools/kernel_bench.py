@@ -60,14 +60,17 @@ def main():
             print(f"volume_split3_hwc B={B} {med:6.1f} us (min {mn:.1f})  {flops / med / 1e6:7.1f} TFLOP/s algorithmic")
         elif w == "volume_split":
             z1, z2 = (torch.zeros_like(f1), torch.zeros_like(f2)) if a.zeros else (f1, f2)
-            pk = ops.volume_pack(z1, z2)
-            med, mn = timeit(lambda: ops.volume_pack(z1, z2, out=pk), a.iters)
-            print(f"volume_pack     B={B} {med:8.1f} us (min {mn:.1f})")
-            for _ in range(100):
-                ops.corr_volume_packed(pk[0], pk[1], B, C, n, n, out=vol)
-            med, mn = timeit(lambda: ops.corr_volume_packed(pk[0], pk[1], B, C, n, n, out=vol), a.iters, warm=20)
-            print(f"volume_split    B={B} {med:8.1f} us (min {mn:.1f})  {flops / med / 1e6:7.1f} TFLOP/s algorithmic = {6 * flops / med / 1e6 / 2500 * 100:.1f}% of the "
-                  f"bf16 MFMA peak executed ({'zero' if a.zeros else 'random'} operands)")
+            for mode, nprod in (("bf16x3", 6), ("f16x2", 3)):
+                if os.environ.get("MV_SPLIT_MODE", mode) != mode:
+                    continue
+                pk = ops.volume_pack(z1, z2, mode=mode)
+                med, mn = timeit(lambda: ops.volume_pack(z1, z2, out=pk, mode=mode), a.iters)
+                print(f"volume_pack  {mode} B={B} {med:8.1f} us (min {mn:.1f})")
+                for _ in range(100):
+                    ops.corr_volume_packed(pk[0], pk[1], B, C, n, n, out=vol, mode=mode)
+                med, mn = timeit(lambda: ops.corr_volume_packed(pk[0], pk[1], B, C, n, n, out=vol, mode=mode), a.iters, warm=20)
+                print(f"volume_split {mode} B={B} {med:8.1f} us (min {mn:.1f})  {flops / med / 1e6:7.1f} TFLOP/s algorithmic = {nprod * flops / med / 1e6 / 2500 * 100:.1f}% of the "
+                      f"16-bit MFMA peak executed ({'zero' if a.zeros else 'random'} operands)")
         elif w == "volume_f16":
             for dt in (torch.float16, torch.bfloat16):
                 a1, a2 = f1.permute(0, 2, 3, 1).contiguous().to(dt), f2.permute(0, 2, 3, 1).contiguous().to(dt)
