@@ -32,7 +32,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-REF = "/root/reference"
+REF = os.environ.get("MACVO_REFERENCE_ROOT", "/root/reference")   # (tools/raft_gpu_probe.py unpacks the .py tree elsewhere on the GPU box)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, REF)
 
