@@ -344,8 +344,8 @@ int mv_local_corr81(const float* first, const float* second, float* out, int B, 
  * (MatchObs.init, `match_obs[mask]`, points.push(...[mask]), push_keyframe, the six edge updates, the lost-track flag), which
  * the reference runs on the CPU behind ~25 `.cpu()` copies per frame; Odometry/Interface.py:47-49 (body poses of poses.npy);
  * Module/MapProcessor.py:52-76 (MotionInterpolate) with Utility/Math.py:96-133.  The stores are caller-owned device arrays
- * (SoA, the reference's field names / dtypes, VisualMap.py:23-69); `counts` is a DEVICE int64[5] = {frames, matches, points,
- * lost frames, refused appends} advanced by the kernel itself, so registering a frame needs no host synchronisation: the host only has to keep
+ * (SoA, the reference's field names / dtypes, VisualMap.py:23-69); `counts` is a DEVICE int64[6] = {frames, matches, points,
+ * lost frames, refused appends, map points} advanced by the kernel itself, so registering a frame needs no host synchronisation: the host only has to keep
  * capacity >= an upper bound of the rows pushed (rows selected).
  */
 typedef struct {
@@ -371,7 +371,7 @@ typedef struct {
     int64_t *frame2match_ranges, *frame2match_num, *frame2map_ranges, *frame2map_num;
     int64_t *match2frame1, *match2frame2, *match2point;
     int64_t *point2match_edges, *point2match_deg;
-    int64_t* counts;          /* device int64[5]: {frames, matches, points, lost frames, REFUSED appends (error word)} */
+    int64_t* counts;          /* device int64[6]: {frames, matches, points, lost frames, REFUSED appends (error word), map points} */
     int32_t max_pt_obs;       /* 5  (VisualMap.py:18) */
     int32_t max_frame_range;  /* 2  (VisualMap.py:19) */
     /* capacities (rows) of the frame / match / point stores and their edge tables.  The row offsets come from the DEVICE-side
@@ -380,6 +380,11 @@ typedef struct {
      * reference raises there, Graph.py:183-186) is counted in counts[4] as well.  The host reads counts[4] at its next
      * synchronisation point (DeviceVisualMap.sizes -> MV_ERR_WORKSPACE). */
     int64_t cap_frames, cap_match, cap_points;
+    /* dense map points of `mapping: true` (VisualMap.map_points, VisualMap.py:47-54; indexed by the frame2map edges) */
+    float* mp_pos_Tw;         /* [cap_mp,3]   */
+    double* mp_cov_Tw;        /* [cap_mp,3,3] camera-frame covariance, stored unrotated as the reference does (MACVO.py:324,334) */
+    uint8_t* mp_color;        /* [cap_mp,3]   */
+    int64_t cap_map_points;   /* 0 = no map-point store attached */
 } mvMapStores;
 
 /* one frame's observations as the tracking kernels leave them (row order of the selected keypoints; `valid` = border test
@@ -406,6 +411,12 @@ typedef struct {
 } mvMapFrame;
 
 int mv_map_append(const mvMapFrame* frame /* host */, const mvMapStores* stores /* host */, mvStream_t stream);
+/* Dense-mapping tail (Odometry/MACVO.py:329-337): `map_points.push(PointNode.init({pos_Tw, cov_Tw, color}))` +
+ * `frame2map.add(frame_idx, num_map_orig, n)` for the NEWEST registered frame (counts[0] - 1).  n rows of pos_Tw [n,3] fp32,
+ * cov [n,9] fp64, color [n,3] uint8 (NULL = zeros), all device.  Refused (counts[4] += 1) when the store or the frame's range
+ * slots are full. */
+int mv_map_append_points(const mvMapStores* stores /* host */, int n, const float* pos_Tw, const double* cov, const uint8_t* color,
+                         mvStream_t stream);
 /* out[i] = T_BS[i] @ pose[i] @ T_BS[i]^-1 in fp32 (Odometry/Interface.py:47-49) */
 int mv_body_poses(const float* pose, const float* T_BS, int T, float* out, mvStream_t stream);
 /* MotionInterpolate.elaborate_map on pose [T,7] in place (fp64 inside); scratch: double[7*(T-1)]; out_count int32[1] or NULL =
@@ -514,11 +525,15 @@ typedef struct {
     int32_t graph_type;        /* MV_GRAPH_* */
     int32_t filters;           /* mv_obs_filter flags */
     int32_t cov_kernel_size;   /* 31 */
+    int32_t mapping;           /* 1: dense-mapping tail of run_pair (Odometry/MACVO.py:313-337; `mapping: true`), lanes == 1 */
+    int32_t map_num_point;     /* 2000 (:315) */
+    int32_t map_mask_width;    /* MappingPointSelector args (Config/Experiment/MACVO/MACVO_Fast.yaml) */
+    int32_t reserved_i;
     float fx, fy, cx, cy, baseline;
     float bl_fx, bl_fx_sq;     /* baseline*fx and its square, rounded once from double (StereoDepth.py:270-282) */
     float match_cov_default, max_match_cov, max_depth_cov, max_depth;
     float min_flow_cov_sq, min_depth_cov, filter_min_depth;
-    float reserved;
+    float map_max_depth, map_max_depth_cov;   /* MappingPointSelector: z < map_max_depth, sigma_z^2 < map_max_depth_cov (KeypointSelector.py:87-100) */
     mvLMParams lm;
 } mvFramePipeConfig;
 
@@ -542,7 +557,9 @@ enum {
     MV_FB_MATCH_COV, MV_FB_CAND, MV_FB_COUNT, MV_FB_STATS,                       /* frontend side: age counts enqueued frames */
     MV_FB_KP0, MV_FB_KP0F, MV_FB_KP1, MV_FB_INBOUND, MV_FB_VALS, MV_FB_SIGMA0, MV_FB_SIGMA1, MV_FB_POS_TC, MV_FB_POS_TW,
     MV_FB_ROT, MV_FB_COV0, MV_FB_COV0W, MV_FB_COV1, MV_FB_VALID, MV_FB_NVALID, MV_FB_POSE64, MV_FB_INFO,   /* backend side */
-    MV_FB_POSE                                                                   /* fp32 [lanes, 7]; age 0 = newest solve's output */
+    MV_FB_POSE,                                                                  /* fp32 [lanes, 7]; age 0 = newest solve's output */
+    /* dense-mapping tail of the newest finished frame (mapping = 1; rows = what mv_frame_pipe_map_points was called with) */
+    MV_FB_MAP_UV, MV_FB_MAP_D, MV_FB_MAP_SDD, MV_FB_MAP_TC, MV_FB_MAP_TW, MV_FB_MAP_COV /* fp64 [.,9] */, MV_FB_MAP_COLOR /* u8 [.,3] */
 };
 
 size_t mv_frame_pipe_arena_bytes(const mvFramePipeConfig* cfg);           /* 0 = invalid configuration */
@@ -566,6 +583,19 @@ int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, const int32_t
  * its own MT19937 seeded like `torch.Generator().manual_seed(seed)`; mv_frame_pipe_finish_seeded then replaces
  * wait_candidates + host randperm + finish by one call (first numPoint swaps, the remaining draws discarded: same bits, ~20x
  * less host time — what a 32-lane step needs).  n_cand_out / n_sel_out: [lanes] host or NULL. */
+/* Dense-mapping tail (config.mapping = 1, lanes == 1; Odometry/MACVO.py:303-337).  The reference maps only when tracking
+ * succeeded and then draws its SECOND randperm of the frame, so the host has to see the frame's observation count first:
+ *   mv_frame_pipe_wait_tracked   blocks until the newest finished frame's filter count is on the host; returns it and the number
+ *                                of MappingPointSelector candidates (found on the PREVIOUS frame's depth maps, on the decoder-side
+ *                                stream next to the tracking selector);
+ *   mv_frame_pipe_map_points     perm_host = randperm(n_cand_map)[:map_num_point]: gather, depth / variance gathers,
+ *                                pixel2point_NED, prev_pose.Act, constant match sigma, colours (image_dev [3,H,W] fp32 in [0,1] or
+ *                                NULL), the 31x31 covariance model (stored unrotated, :324) — into the MV_FB_MAP_* buffers — and,
+ *                                with `stores`, map_points.push + frame2map.add (mv_map_append_points) behind this frame's
+ *                                mv_frame_pipe_map_append.  Call order per frame: finish, [map_append], wait_tracked, [map_points]. */
+int mv_frame_pipe_wait_tracked(mvFramePipe* p, int32_t* n_valid, int32_t* n_cand_map);
+int mv_frame_pipe_map_points(mvFramePipe* p, const int64_t* perm_host, int n_sel, const float* image_dev,
+                             const mvMapStores* stores /* host, or NULL */);
 int mv_frame_pipe_seed_lanes(mvFramePipe* p, const uint64_t* seeds /* [lanes] host */);
 int mv_frame_pipe_finish_seeded(mvFramePipe* p, float* pose_sink, int32_t* n_cand_out, int32_t* n_sel_out);
 /* register the newest FINISHED frame in a device-resident map (mv_map_append on the pipe's own streams, no copies; lanes = 1):

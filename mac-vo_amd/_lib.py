@@ -52,9 +52,9 @@ class mvFramePipeConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "H", "W", "C", "pairs", "iters", "radius", "feat_dtype", "layout", "volume_split", "selector_mode",
         "kp_kernel_size", "kp_mask_width", "num_point", "edgewidth", "min_num_point", "graph_type", "filters",
-        "cov_kernel_size")] + [(n, C.c_float) for n in (
+        "cov_kernel_size", "mapping", "map_num_point", "map_mask_width", "reserved_i")] + [(n, C.c_float) for n in (
         "fx", "fy", "cx", "cy", "baseline", "bl_fx", "bl_fx_sq", "match_cov_default", "max_match_cov", "max_depth_cov",
-        "max_depth", "min_flow_cov_sq", "min_depth_cov", "filter_min_depth", "reserved")] + [("lm", mvLMParams)]
+        "max_depth", "min_flow_cov_sq", "min_depth_cov", "filter_min_depth", "map_max_depth", "map_max_depth_cov")] + [("lm", mvLMParams)]
 
 
 class mvMapStores(C.Structure):
@@ -64,7 +64,8 @@ class mvMapStores(C.Structure):
         "obs1_covTc", "obs2_covTc", "pixel1_uv_cov", "pixel2_uv_cov", "pixel1_d_cov", "pixel2_d_cov",
         "frame2match_ranges", "frame2match_num", "frame2map_ranges", "frame2map_num", "match2frame1", "match2frame2",
         "match2point", "point2match_edges", "point2match_deg", "counts")] + [("max_pt_obs", C.c_int32), ("max_frame_range", C.c_int32)] + \
-        [("cap_frames", C.c_int64), ("cap_match", C.c_int64), ("cap_points", C.c_int64)]
+        [("cap_frames", C.c_int64), ("cap_match", C.c_int64), ("cap_points", C.c_int64)] + \
+        [("mp_pos_Tw", C.c_void_p), ("mp_cov_Tw", C.c_void_p), ("mp_color", C.c_void_p), ("cap_map_points", C.c_int64)]
 
 
 class mvMapFrame(C.Structure):
@@ -82,7 +83,8 @@ class mvFrameInputs(C.Structure):
 # mv_frame_pipe_buffer ids (enum order of the header)
 FB_NAMES = ("VOLUME", "TOKENS", "DISPARITY", "DISPARITY_COV", "DEPTH", "DEPTH_COV", "MATCH_FLOW", "MATCH_COV", "CAND",
             "COUNT", "STATS", "KP0", "KP0F", "KP1", "INBOUND", "VALS", "SIGMA0", "SIGMA1", "POS_TC", "POS_TW", "ROT", "COV0",
-            "COV0W", "COV1", "VALID", "NVALID", "POSE64", "INFO", "POSE")
+            "COV0W", "COV1", "VALID", "NVALID", "POSE64", "INFO", "POSE", "MAP_UV", "MAP_D", "MAP_SDD", "MAP_TC", "MAP_TW", "MAP_COV",
+            "MAP_COLOR")
 FB = {n: i for i, n in enumerate(FB_NAMES)}
 
 _P = C.c_void_p
@@ -145,6 +147,9 @@ SIGNATURES = {
     "mv_frame_pipe_enqueue_volume": (C.c_int, [_P, C.POINTER(mvFrameInputs), _P]),
     "mv_frame_pipe_wait_candidates": (C.c_int, [_P, _P]),
     "mv_frame_pipe_finish": (C.c_int, [_P, _P, _P, _P]),
+    "mv_map_append_points": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
+    "mv_frame_pipe_wait_tracked": (C.c_int, [_P, _P, _P]),
+    "mv_frame_pipe_map_points": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "mv_frame_pipe_seed_lanes": (C.c_int, [_P, _P]),
     "mv_frame_pipe_finish_seeded": (C.c_int, [_P, _P, _P, _P]),
     "mv_frame_pipe_map_append": (C.c_int, [_P, C.POINTER(mvMapStores), C.c_int, C.c_int, _P, _P, C.c_float, C.c_int64, _P]),

@@ -130,6 +130,23 @@ struct mvFramePipe {
     hipEvent_t e_map;
     int newest_maps;
     std::deque<Pending> pending;
+    // dense-mapping tail (config.mapping; lanes == 1)
+    int32_t* cand_m[N_CAND];
+    int32_t* count_m[N_CAND];
+    float* stats_m[N_CAND];
+    int32_t* h_count_m[N_CAND];    // pinned
+    int32_t* h_nvalid[2];          // pinned: observation count of backend slot k
+    hipEvent_t e_nvalid[2];
+    bool nvalid_valid[2];
+    int64_t *mp_perm, *mp_uv;      // [map_num_point], [map_num_point, 2]
+    float *mp_uvf, *mp_d, *mp_sdd, *mp_sigma, *mp_Tc, *mp_Tw;
+    double* mp_cov;
+    uint8_t* mp_color;
+    int64_t* h_perm_m;             // pinned
+    hipEvent_t e_maptail;          // the map tail's last kernel (buffers + pinned permutation reusable)
+    bool maptail_valid;
+    int mp_rows;                   // rows of the newest map tail (0: none for the newest finished frame)
+    int last_maps_prev, last_cand;   // of the newest finished frame
     // native keypoint permutations (mv_frame_pipe_seed_lanes): one MT19937 per lane, the engine behind torch's CPU generator
     std::vector<std::mt19937> rng;
     std::vector<int32_t> perm_scratch;   // identity array of the partial Fisher-Yates, reused
@@ -210,6 +227,24 @@ static size_t carve(mvFramePipe* p, char* base) {
         b.info = a.take<double>(L * 4);
         b.n_valid = a.take<int32_t>(L);
     }
+    if (c.mapping) {
+        const size_t MP = c.map_num_point > 0 ? c.map_num_point : 1;
+        for (int k = 0; k < N_CAND; ++k) {
+            p->cand_m[k] = a.take<int32_t>(plane);
+            p->count_m[k] = a.take<int32_t>(4);
+            p->stats_m[k] = a.take<float>(4);
+        }
+        p->mp_perm = a.take<int64_t>(MP);
+        p->mp_uv = a.take<int64_t>(2 * MP);
+        p->mp_uvf = a.take<float>(2 * MP);
+        p->mp_d = a.take<float>(MP);
+        p->mp_sdd = a.take<float>(MP);
+        p->mp_sigma = a.take<float>(3 * MP);
+        p->mp_Tc = a.take<float>(3 * MP);
+        p->mp_Tw = a.take<float>(3 * MP);
+        p->mp_cov = a.take<double>(9 * MP);
+        p->mp_color = a.take<uint8_t>(3 * MP);
+    }
     for (int k = 0; k < 3; ++k) p->pose[k] = a.take<float>(L * 7);
     p->intr = a.take<float>(L * 4);
     p->bl = a.take<float>(L);
@@ -226,6 +261,7 @@ static int check_config(const mvFramePipeConfig* c) {
     MV_CHECK_ARG(c->selector_mode == MV_KP_NODEPTH || c->selector_mode == MV_KP_FULL);
     MV_CHECK_ARG(c->num_point >= 0 && c->edgewidth >= 0 && c->min_num_point >= 0);
     MV_CHECK_ARG(c->graph_type >= MV_GRAPH_ICP && c->graph_type <= MV_GRAPH_DISP);
+    MV_CHECK_ARG(c->mapping == 0 || (c->mapping == 1 && c->pairs == 2 && c->map_num_point > 0 && c->map_mask_width >= 0));
     MV_CHECK_ARG(c->volume_split == 0 || c->volume_split == 2 || c->volume_split == 3 || c->volume_split == MV_PACK_BF16X3 ||
                  c->volume_split == MV_PACK_F16X2);
     MV_CHECK_ARG(!c->volume_split || c->feat_dtype == MV_F32);
@@ -262,6 +298,10 @@ extern "C" void mv_frame_pipe_destroy(mvFramePipe* p) {
     for (int k = 0; k < N_CAND; ++k) ev(p->e_cand[k]);
     for (int k = 0; k < 2; ++k) { ev(p->e_backend[k]); ev(p->e_posed[k]); ev(p->e_solved[k]); }
     ev(p->e_pgo);
+    ev(p->e_maptail);
+    for (int k = 0; k < 2; ++k) { ev(p->e_nvalid[k]); if (p->h_nvalid[k]) (void)hipHostFree(p->h_nvalid[k]); }
+    for (int k = 0; k < N_CAND; ++k) if (p->h_count_m[k]) (void)hipHostFree(p->h_count_m[k]);
+    if (p->h_perm_m) (void)hipHostFree(p->h_perm_m);
     ev(p->e_packed[0]);
     ev(p->e_packed[1]);
     ev(p->e_map);
@@ -356,6 +396,15 @@ static int create_impl(mvFramePipe* p) {
         MV_HIP(mk(&p->e_solved[k]));
     }
     MV_HIP(mk(&p->e_pgo));
+    MV_HIP(mk(&p->e_maptail));
+    for (int k = 0; k < 2; ++k) {
+        MV_HIP(mk(&p->e_nvalid[k]));
+        MV_HIP(hipHostMalloc((void**)&p->h_nvalid[k], (size_t)p->lanes * sizeof(int32_t), hipHostMallocDefault));
+    }
+    if (c.mapping) {
+        for (int k = 0; k < N_CAND; ++k) MV_HIP(hipHostMalloc((void**)&p->h_count_m[k], 4 * sizeof(int32_t), hipHostMallocDefault));
+        MV_HIP(hipHostMalloc((void**)&p->h_perm_m, (size_t)c.map_num_point * sizeof(int64_t), hipHostMallocDefault));
+    }
     MV_HIP(mk(&p->e_packed[0]));
     MV_HIP(mk(&p->e_packed[1]));
     MV_HIP(mk(&p->e_map));
@@ -575,6 +624,16 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
                                       p->kp_ws, p->kp_ws_bytes, p->cand[k], p->count[k], p->stats[k], p->lanes, s));
         }
         MV_HIP(hipMemcpyAsync(p->h_count[k], p->count[k], (size_t)p->lanes * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        if (c.mapping) {
+            // MappingPointSelector works on the PREVIOUS frame's depth maps (KeypointSelector.py:87-100; MACVO.py:315): its count
+            // travels to the host with the tracking selector's
+            const Maps& m0 = p->maps[pd.maps_prev];
+            mvKpSelectParams spm{c.H, c.W, MV_KP_MAPPING, c.kp_kernel_size, c.map_mask_width, c.map_max_depth, c.map_max_depth_cov,
+                                 c.max_match_cov};
+            MV_TRY(mv_kp_select_lanes(nullptr, m0.depth, m0.depth_cov, nullptr, nullptr, nullptr, nullptr, &spm, p->kp_ws,
+                                      p->kp_ws_bytes, p->cand_m[k], p->count_m[k], p->stats_m[k], 1, s));
+            MV_HIP(hipMemcpyAsync(p->h_count_m[k], p->count_m[k], 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        }
         MV_HIP(hipEventRecord(p->e_cand[k], s));
         if (timed) MV_HIP(hipEventRecord(p->tv3[ti], s));
         p->pending.push_back(pd);
@@ -683,6 +742,8 @@ extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, co
         p->solved_valid[k] = true;
         p->backend_valid[k] = true;
         p->pose_cur = nxt0;
+        p->nvalid_valid[k] = false;   // (mv_frame_pipe_wait_tracked then reports 0 observations: no mapping either)
+        p->mp_rows = 0;
         return MV_OK;
     }
     const Maps &m0 = p->maps[pd.maps_prev], &m1 = p->maps[pd.maps];
@@ -722,6 +783,14 @@ extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, co
                                    L, b.n_sel, cap, s));
     MV_TRY(mv_obs_filter_lanes(b.inbound, b.cov0, b.cov1, b.vals, c.filters, c.filter_min_depth, c.max_depth, L, b.n_sel, cap,
                                b.valid, b.n_valid, s));
+    if (c.mapping) {   // the mapping decision of this frame (MACVO.py:303-307) needs the observation count on the host
+        MV_HIP(hipMemcpyAsync(p->h_nvalid[k], b.n_valid, (size_t)L * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        MV_HIP(hipEventRecord(p->e_nvalid[k], s));
+        p->nvalid_valid[k] = true;
+    }
+    p->last_maps_prev = pd.maps_prev;
+    p->last_cand = pd.cand;
+    p->mp_rows = 0;
     MV_HIP(hipEventRecord(p->e_backend[k], s));
     p->backend_valid[k] = true;
 
@@ -784,6 +853,52 @@ extern "C" int mv_frame_pipe_map_append(mvFramePipe* p, const mvMapStores* store
                           p->s_side));
     MV_HIP(hipEventRecord(p->e_pgo, p->s_side));
     p->pgo_valid = true;
+    return MV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ dense-mapping tail
+extern "C" int mv_frame_pipe_wait_tracked(mvFramePipe* p, int32_t* n_valid, int32_t* n_cand_map) {
+    MV_CHECK_ARG(p && n_valid && p->c.mapping && p->n_fin > 0);
+    const int k = (int)((p->n_fin - 1) & 1);
+    if (!p->nvalid_valid[k]) {          // a frame without keypoints: nothing was tracked
+        *n_valid = 0;
+        if (n_cand_map) *n_cand_map = 0;
+        return MV_OK;
+    }
+    MV_HIP(hipEventSynchronize(p->e_nvalid[k]));
+    *n_valid = p->h_nvalid[k][0];
+    if (n_cand_map) *n_cand_map = p->h_count_m[p->last_cand][0];   // (its copy preceded e_cand, which the host waited for before finish)
+    return MV_OK;
+}
+
+extern "C" int mv_frame_pipe_map_points(mvFramePipe* p, const int64_t* perm_host, int n_sel, const float* image_dev,
+                                        const mvMapStores* stores) {
+    MV_CHECK_ARG(p && p->c.mapping && p->n_fin > 0 && n_sel >= 0 && n_sel <= p->c.map_num_point && (n_sel == 0 || perm_host));
+    const mvFramePipeConfig& c = p->c;
+    const int k = (int)((p->n_fin - 1) & 1);
+    hipStream_t s = p->s_back;
+    const Maps& m0 = p->maps[p->last_maps_prev];
+    if (p->maptail_valid) MV_HIP(hipEventSynchronize(p->e_maptail));   // pinned permutation + map buffers of the previous tail (long done)
+    if (p->release_valid) MV_TRY(wait_if_pending(s, p->e_release));    // ... and consumers of its result views
+    if (n_sel > 0) {
+        memcpy(p->h_perm_m, perm_host, (size_t)n_sel * sizeof(int64_t));
+        MV_HIP(hipMemcpyAsync(p->mp_perm, p->h_perm_m, (size_t)n_sel * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        MV_TRY(mv_kp_gather(p->cand_m[p->last_cand], p->mp_perm, n_sel, c.W, p->mp_uv, s));
+        // prev_pose.Act (MACVO.py:334): the pose the frame started from = the previous frame's optimised pose
+        MV_TRY(wait_if_pending(s, p->e_pgo));   // (the solve that produced it; the newest solve is recorded later on `side`: also fine)
+        MV_TRY(mv_map_points(p->mp_uv, n_sel, m0.depth, m0.depth_cov, image_dev, c.H, c.W, c.fx, c.fy, c.cx, c.cy,
+                             p->pose[p->prior_slot], c.match_cov_default, p->mp_uvf, p->mp_d, p->mp_sdd, p->mp_sigma, p->mp_Tc, p->mp_Tw,
+                             image_dev ? p->mp_color : nullptr, s));
+        mvMatchCovParams cp{c.H, c.W, c.cov_kernel_size, 1, c.fx, c.fy, c.cx, c.cy, c.min_flow_cov_sq, c.min_depth_cov};
+        MV_TRY(mv_match_cov(m0.depth, p->mp_uvf, p->mp_sigma, p->mp_sdd, nullptr, &cp, n_sel, p->mp_cov, nullptr, nullptr, s));
+    }
+    if (stores) {   // map_points.push + frame2map.add (also for n_sel == 0: the reference adds the empty range), behind the frame's registration
+        MV_TRY(mv_map_append_points(stores, n_sel, p->mp_Tw, p->mp_cov, image_dev ? p->mp_color : nullptr, s));
+    }
+    p->mp_rows = n_sel;
+    MV_HIP(hipEventRecord(p->e_maptail, s));
+    p->maptail_valid = true;
+    MV_HIP(hipEventRecord(p->e_backend[k], s));   // the previous frame's maps stay in use until here (the next enqueue waits for this event)
     return MV_OK;
 }
 
@@ -908,6 +1023,13 @@ extern "C" int mv_frame_pipe_buffer(mvFramePipe* p, int which, int age, void** p
         case MV_FB_POSE64: if (!b) break; *ptr = b->pose64; *count = 7 * L; return MV_OK;
         case MV_FB_INFO: if (!b) break; *ptr = b->info; *count = 4 * L; return MV_OK;
         case MV_FB_POSE: if (age > 1) break; *ptr = p->pose[(p->pose_cur + 3 - age) % 3]; *count = 7 * L; return MV_OK;
+        case MV_FB_MAP_UV: if (!c.mapping || age) break; *ptr = p->mp_uvf; *count = 2 * (size_t)p->mp_rows; return MV_OK;
+        case MV_FB_MAP_D: if (!c.mapping || age) break; *ptr = p->mp_d; *count = (size_t)p->mp_rows; return MV_OK;
+        case MV_FB_MAP_SDD: if (!c.mapping || age) break; *ptr = p->mp_sdd; *count = (size_t)p->mp_rows; return MV_OK;
+        case MV_FB_MAP_TC: if (!c.mapping || age) break; *ptr = p->mp_Tc; *count = 3 * (size_t)p->mp_rows; return MV_OK;
+        case MV_FB_MAP_TW: if (!c.mapping || age) break; *ptr = p->mp_Tw; *count = 3 * (size_t)p->mp_rows; return MV_OK;
+        case MV_FB_MAP_COV: if (!c.mapping || age) break; *ptr = p->mp_cov; *count = 9 * (size_t)p->mp_rows; return MV_OK;
+        case MV_FB_MAP_COLOR: if (!c.mapping || age) break; *ptr = p->mp_color; *count = 3 * (size_t)p->mp_rows; return MV_OK;
         default: break;
     }
     return MV_ERR_INVALID_ARG;

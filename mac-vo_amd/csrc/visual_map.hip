@@ -236,6 +236,40 @@ __global__ __launch_bounds__(256) void map_append_kernel(mvMapFrame fr, mvMapSto
     }
 }
 
+// dense-mapping tail: map_points.push + frame2map.add for the newest frame (Odometry/MACVO.py:329-337)
+__global__ __launch_bounds__(256) void map_append_points_kernel(mvMapStores st, int n, const float* __restrict__ pos, const double* __restrict__ cov,
+                                                                 const uint8_t* __restrict__ color) {
+    __shared__ int base, frame, ok;
+    int64_t* cnt = st.counts;
+    if (threadIdx.x == 0) {
+        base = (int)cnt[5];
+        frame = (int)cnt[0] - 1;
+        const bool fits = frame >= 0 && (int64_t)base + n <= st.cap_map_points && st.frame2map_num[frame] < st.max_frame_range;
+        ok = fits ? 1 : 0;
+        if (!fits) cnt[4] += 1;
+    }
+    __syncthreads();
+    if (!ok) return;
+    const size_t P0 = (size_t)base;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            st.mp_pos_Tw[3 * (P0 + i) + c] = pos[3 * (size_t)i + c];
+            st.mp_color[3 * (P0 + i) + c] = color ? color[3 * (size_t)i + c] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) st.mp_cov_Tw[9 * (P0 + i) + c] = cov[9 * (size_t)i + c];
+    }
+    if (threadIdx.x == 0) {
+        const size_t f = (size_t)frame;
+        const int64_t k = st.frame2map_num[f];
+        st.frame2map_ranges[2 * (st.max_frame_range * f + k)] = (int64_t)P0;
+        st.frame2map_ranges[2 * (st.max_frame_range * f + k) + 1] = (int64_t)n;
+        st.frame2map_num[f] = k + 1;
+        cnt[5] = (int64_t)P0 + n;
+    }
+}
+
 // body poses of Odometry/Interface.py:47-49: T_BS @ pose @ T_BS^-1, float32 arithmetic like pp.SE3(float32 tensors)
 __global__ void body_poses_kernel(const float* __restrict__ pose, const float* __restrict__ T_BS, int T, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -354,6 +388,17 @@ extern "C" int mv_map_append(const mvMapFrame* frame, const mvMapStores* stores,
     MV_CHECK_ARG(s.frame2match_ranges && s.frame2match_num && s.frame2map_ranges && s.frame2map_num && s.match2frame1 &&
                  s.match2frame2 && s.match2point && s.point2match_edges && s.point2match_deg);
     hipLaunchKernelGGL(map_append_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, f, s);
+    return mv_launch_status();
+}
+
+extern "C" int mv_map_append_points(const mvMapStores* stores, int n, const float* pos_Tw, const double* cov, const uint8_t* color,
+                                    mvStream_t stream) {
+    MV_CHECK_ARG(stores && n >= 0);
+    const mvMapStores& s = *stores;
+    MV_CHECK_ARG(s.counts && s.frame2map_ranges && s.frame2map_num && s.max_frame_range >= 1);
+    MV_CHECK_ARG(s.cap_map_points > 0 && s.mp_pos_Tw && s.mp_cov_Tw && s.mp_color);
+    MV_CHECK_ARG(n == 0 || (pos_Tw && cov));
+    hipLaunchKernelGGL(map_append_points_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, s, n, pos_Tw, cov, color);
     return mv_launch_status();
 }
 

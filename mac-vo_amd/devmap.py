@@ -51,10 +51,11 @@ class DeviceVisualMap:
             raise L.MacvoHipError("DeviceVisualMap lives on the GPU (no CPU fallback)")
         self.lib = L.load()
         self.max_pt_obs, self.max_frame_range = max_pt_obs, max_frame_range
-        self.cap = {"frames": init_size, "match": init_size, "points": init_size}
+        self.cap = {"frames": init_size, "match": init_size, "points": init_size, "map_points": init_size}
         self.frames = {k: self._alloc(init_size, s, d) for k, (s, d) in _FRAME.items()}
         self.points = {k: self._alloc(init_size, s, d) for k, (s, d) in _POINT.items()}
         self.match = {k: self._alloc(init_size, s, d) for k, (s, d) in _MATCH.items()}
+        self.map_points = {k: self._alloc(init_size, s, d) for k, (s, d) in _POINT.items()}     # VisualMap.map_points (VisualMap.py:47-54)
         i64 = torch.int64
         self.edges = {
             "frame2match_ranges": self._alloc(init_size, (max_frame_range, 2), i64, -1),
@@ -67,9 +68,10 @@ class DeviceVisualMap:
             "point2match_edges": self._alloc(init_size, (max_pt_obs,), i64, -1),
             "point2match_deg": self._alloc(init_size, (), i64, 0),
         }
-        self.counts = torch.zeros(5, dtype=i64, device=self.dev)      # {frames, matches, points, lost frames, refused appends}: advanced on device
+        self.counts = torch.zeros(6, dtype=i64, device=self.dev)      # {frames, matches, points, lost frames, refused appends, map points}: advanced on device
         self.n_frames = 0                                             # exact (one per push)
         self.rows_upper = 0                                           # upper bound of matches == points pushed
+        self.map_rows_upper = 0                                       # upper bound of map points pushed
         self._stores = None
 
     def _alloc(self, n, shape, dtype, fill=None):
@@ -92,9 +94,14 @@ class DeviceVisualMap:
             table[k] = nt
         self._stores = None
 
-    def reserve(self, new_rows: int) -> None:
-        """Make room for one more frame with at most ``new_rows`` kept observations (``AutoScalingTensor.push`` :106-114 grows
-        when size + n >= capacity; copies are enqueued on the current stream)."""
+    def reserve(self, new_rows: int, new_map_points: int = 0) -> None:
+        """Make room for one more frame with at most ``new_rows`` kept observations and ``new_map_points`` dense map points
+        (``AutoScalingTensor.push`` :106-114 grows when size + n >= capacity; copies are enqueued on the current stream)."""
+        need_mp = self.map_rows_upper + new_map_points
+        if new_map_points and need_mp >= self.cap["map_points"]:
+            cap = _grow_to(need_mp)
+            self._regrow(self.map_points, list(self.map_points), cap)
+            self.cap["map_points"] = cap
         need_f, need_r = self.n_frames + 1, self.rows_upper + new_rows
         if need_f >= self.cap["frames"]:
             cap = _grow_to(need_f)
@@ -112,9 +119,11 @@ class DeviceVisualMap:
     def stores(self) -> "L.mvMapStores":
         if self._stores is None:
             p = {k: v.data_ptr() for tbl in (self.frames, self.points, self.match, self.edges) for k, v in tbl.items()}
-            self._stores = L.mvMapStores(**p, counts=self.counts.data_ptr(), max_pt_obs=self.max_pt_obs,
+            mp = {f"mp_{k}": v.data_ptr() for k, v in self.map_points.items()}
+            self._stores = L.mvMapStores(**p, **mp, counts=self.counts.data_ptr(), max_pt_obs=self.max_pt_obs,
                                          max_frame_range=self.max_frame_range, cap_frames=self.cap["frames"],
-                                         cap_match=self.cap["match"], cap_points=self.cap["points"])
+                                         cap_match=self.cap["match"], cap_points=self.cap["points"],
+                                         cap_map_points=self.cap["map_points"])
         return self._stores
 
     def push_frame(self, *, K, T_BS, baseline: float, time_ns: int, prior_pose=None, tracked=None, valid=None, cov0=None,
@@ -145,6 +154,31 @@ class DeviceVisualMap:
         self.n_frames += 1
         self.rows_upper += n
         return idx
+
+    def push_map_points(self, pos_Tw: torch.Tensor, cov: torch.Tensor, color: torch.Tensor | None = None) -> None:
+        """Dense-mapping tail (Odometry/MACVO.py:329-337): append the map points of the NEWEST frame and its frame2map range."""
+        from . import ops
+
+        n = pos_Tw.shape[0]
+        self.reserve_map_points(n)
+        pos = ops._req(pos_Tw, torch.float32, "pos_Tw")
+        cv = ops._req(cov.reshape(n, 9), torch.float64, "cov")
+        col = None if color is None else ops._req(color, torch.uint8, "color")
+        L.check(self.lib.mv_map_append_points(C.byref(self.stores()), n, pos.data_ptr(), cv.data_ptr(), None if col is None else col.data_ptr(),
+                                              ops._stream()), "mv_map_append_points")
+        self.map_rows_upper += n
+
+    def reserve_map_points(self, n: int) -> None:
+        need = self.map_rows_upper + n
+        if need >= self.cap["map_points"]:
+            cap = _grow_to(need)
+            self._regrow(self.map_points, list(self.map_points), cap)
+            self.cap["map_points"] = cap
+
+    def map_point_arrays(self) -> dict[str, np.ndarray]:
+        """The map-point store (``VisualMap.map_points``; not part of ``VisualMap.serialize``) as numpy arrays."""
+        n = int(self.counts.cpu()[5])
+        return {k: v[:n].cpu().numpy() for k, v in self.map_points.items()}
 
     def set_pose(self, frame_idx: int, pose: torch.Tensor) -> None:
         """``write_graph_data`` (Optimizer.py:104-108): the optimised pose replaces the prior the frame was pushed with."""

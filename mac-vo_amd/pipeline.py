@@ -435,6 +435,7 @@ class _NativeResult:
         self._hp, self.lane, self.n_sel, self.n_cand = hp, lane, n_sel, n_cand
         self._fin = hp._n_fin          # finish counter at creation: views are resolved against it
         self.extras: dict = {}
+        self.map_points = None          # mapping mode: ops.MapPoints views of the frame's dense map points
 
     def _age(self) -> int:
         age = self._hp._n_fin - self._fin
@@ -489,9 +490,8 @@ class NativeHotPath:
     def __init__(self, cam: Camera, cfg: HotPathConfig | None = None, device: str | torch.device = "cuda",
                  keep_extras: bool = False, lanes: int = 1, generators: "list | None" = None):
         self.cam, self.cfg = cam, cfg or HotPathConfig()
-        if self.cfg.mapping:
-            raise ops.L.MacvoHipError("the dense-mapping tail (mapping=True) is sequenced by pipeline.HotPath only: its cost is "
-                                      "the host-side torch.randperm(n ~ 1e5), which the native driver cannot hide")
+        if self.cfg.mapping and lanes != 1:
+            raise ops.L.MacvoHipError("the dense-mapping tail (mapping=True) runs one sequence per pipe (lanes == 1), as the reference does")
         if self.cfg.use_graphs:
             raise ops.L.MacvoHipError("use_graphs belongs to the Python-sequenced pipeline.HotPath")
         if not 1 <= lanes <= ops.L.MV_MAX_LANES:
@@ -506,6 +506,10 @@ class NativeHotPath:
         self._native_seeds = all(isinstance(g, int) and not isinstance(g, bool) for g in self.generators)
         if not self._native_seeds and any(isinstance(g, int) for g in self.generators):
             raise ops.L.MacvoHipError("generators: either all torch.Generator / None or all integer seeds")
+        if self._native_seeds and self.cfg.mapping:
+            raise ops.L.MacvoHipError("mapping=True draws its second permutation on the Python side: use torch generators")
+        self._prev_image = None          # mapping: LEFT image of the previously enqueued frame (map-point colours, MACVO.py:326-328)
+        self._images: list = []
         self._cap = max(self.cfg.num_point, 1)
         self._volume_ahead = os.environ.get("MV_PIPE_VOLUME_AHEAD", "1") != "0"   # A/B knobs of run()
         self._depth = max(1, min(3, int(os.environ.get("MV_PIPE_DEPTH", "3"))))
@@ -545,7 +549,8 @@ class NativeHotPath:
             cov_kernel_size=c.cov_kernel_size, fx=cam.fx, fy=cam.fy, cx=cam.cx, cy=cam.cy, baseline=cam.baseline,
             bl_fx=bl_fx, bl_fx_sq=bl_fx ** 2, match_cov_default=c.match_cov_default, max_match_cov=c.max_match_cov,
             max_depth_cov=c.max_depth_cov, max_depth=max_depth, min_flow_cov_sq=c.min_flow_cov ** 2,
-            min_depth_cov=c.min_depth_cov, filter_min_depth=c.filter_min_depth, reserved=0.0, lm=self.lm)
+            min_depth_cov=c.min_depth_cov, filter_min_depth=c.filter_min_depth, mapping=int(c.mapping), map_num_point=c.map_num_point,
+            map_mask_width=c.map_mask_width, reserved_i=0, map_max_depth=c.map_max_depth, map_max_depth_cov=c.map_max_depth_cov, lm=self.lm)
         nbytes = lib.mv_frame_pipe_arena_bytes(C.byref(pc))
         if nbytes == 0:
             raise L.MacvoHipError("mv_frame_pipe_arena_bytes: invalid configuration")
@@ -655,6 +660,7 @@ class NativeHotPath:
         """Frame 0: ``MACVO.initialize`` (:158-171) — depth only, pose = prior."""
         self._init_pose = init_pose
         self._enqueue(x, False)
+        self._prev_image = x.image
         if getattr(self, "_map", None) is not None:   # MACVO.initialize pushes the first frame at the prior (:162-169)
             self._map.push_frame(K=self._map_K, T_BS=self._map_TBS, baseline=self.cam.baseline, time_ns=x.time_ns, prior_pose=init_pose)
             torch.cuda.current_stream().synchronize()   # later frames are appended on the pipe's streams: order them after this one
@@ -663,6 +669,9 @@ class NativeHotPath:
     def enqueue_frontend(self, x: FrameInputs):
         assert self._n_enq >= 1, "call initialize() with the first frame"
         self._enqueue(x, True)
+        if self.cfg.mapping:
+            self._images.append(self._prev_image)
+            self._prev_image = x.image
         if getattr(self, "_map", None) is not None:
             self._times.append(int(x.time_ns))
         return x
@@ -711,6 +720,35 @@ class NativeHotPath:
                 "mv_frame_pipe_finish")
         return self._finished()
 
+    def _map_tail(self, mp):
+        """Dense-mapping tail of the frame just finished (Odometry/MACVO.py:303-337): the reference maps only when tracking
+        succeeded — so the frame's observation count has to reach the host first (one blocking wait per frame: mapping mode gives
+        up the driver's run-ahead, as the reference's own `.cpu()` calls do) — and then draws its SECOND randperm of the frame from
+        the same CPU generator."""
+        L, lib, c = ops.L, self._lib, self.cfg
+        image0 = self._images.pop(0)
+        nv, nm = ops.C.c_int32(0), ops.C.c_int32(0)
+        L.check(lib.mv_frame_pipe_wait_tracked(self._pipe, ops.C.byref(nv), ops.C.byref(nm)), "mv_frame_pipe_wait_tracked")
+        if nv.value < c.min_num_point:
+            return None
+        g = self.generators[0]
+        perm = (torch.randperm(nm.value) if g is None else torch.randperm(nm.value, generator=g))[: c.map_num_point]
+        n = perm.numel()
+        img = None if image0 is None else ops._req(image0.reshape(3, self.cam.H, self.cam.W), torch.float32, "image")
+        if mp is not None:
+            if mp.map_rows_upper + n >= mp.cap["map_points"]:
+                self.synchronize()
+                mp.reserve_map_points(n)
+                torch.cuda.synchronize()
+            mp.map_rows_upper += n
+        L.check(lib.mv_frame_pipe_map_points(self._pipe, perm.data_ptr() if n else None, n, None if img is None else img.data_ptr(),
+                                             None if mp is None else ops.C.byref(mp.stores())), "mv_frame_pipe_map_points")
+        self._map_keep = img
+        f32 = torch.float32
+        v = lambda name, dt, tail: self._view(name, 0, dt, (n,) + tail)  # noqa: E731
+        return ops.MapPoints(v("MAP_UV", f32, (2,)), v("MAP_D", f32, ()), v("MAP_SDD", f32, ()), v("MAP_TC", f32, (3,)), v("MAP_TW", f32, (3,)),
+                             v("MAP_COV", torch.float64, (3, 3)), None if img is None else v("MAP_COLOR", torch.uint8, (3,)))
+
     def _finished(self):
         """Bookkeeping behind a finish call: map registration, result views."""
         L, lib = ops.L, self._lib
@@ -727,10 +765,12 @@ class NativeHotPath:
                                                  self._times.pop(0), None), "mv_frame_pipe_map_append")
             mp.n_frames += 1
             mp.rows_upper += n_rows
+        map_pts = self._map_tail(mp) if self.cfg.mapping else None
         out = []
         for l in range(self.lanes):
             n_sel = self._nsel[l]
             res = _NativeResult(self, l, n_sel, self._ncand[l])
+            res.map_points = map_pts
             if self.keep_extras and n_sel:
                 f32, f64 = torch.float32, torch.float64
                 vals = self._view("VALS", 0, f32, (11, self.lanes, self._cap))[:, l, :n_sel]

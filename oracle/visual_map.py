@@ -33,6 +33,8 @@ class OracleVisualMap:
         self.f2m_ranges, self.f2m_num, self.f2map_ranges, self.f2map_num = [], [], [], []
         self.m2f1, self.m2f2, self.m2p, self.p2m_edges, self.p2m_deg = [], [], [], [], []
         self.n_match = self.n_points = 0
+        self.map_points = {k: [] for k in ("pos_Tw", "cov_Tw", "color")}
+        self.n_map_points = 0
 
     def push_frame(self, meta, fr, min_num_point: int = 10) -> int:
         F = len(self.frames["pose"])
@@ -76,6 +78,23 @@ class OracleVisualMap:
         self.n_match += kept
         self.n_points += kept
         return F
+
+    def push_map_points(self, frame_idx: int, pos_Tw: torch.Tensor, cov_Tw: torch.Tensor, color: torch.Tensor | None = None) -> None:
+        """Dense-mapping tail of run_pair (Odometry/MACVO.py:329-337): ``map_points.push(...)`` + ``frame2map.add(frame_idx, start, n)``
+        (only for frames that kept >= min_num_point observations, :303-307; the covariance is stored unrotated, :324,334)."""
+        n = pos_Tw.shape[0]
+        self.map_points["pos_Tw"].append(pos_Tw.float())
+        self.map_points["cov_Tw"].append(cov_Tw.double())
+        self.map_points["color"].append(color if color is not None else torch.zeros(n, 3, dtype=torch.uint8))
+        k = self.f2map_num[frame_idx]
+        assert k < self.max_frame_range, "DenseEdge_Multi.add: no free range slot"         # the reference raises here (Graph.py:183-186)
+        self.f2map_ranges[frame_idx][k] = torch.tensor([self.n_map_points, n])
+        self.f2map_num[frame_idx] = k + 1
+        self.n_map_points += n
+
+    def map_point_arrays(self) -> dict:
+        shapes = {"pos_Tw": ((0, 3), torch.float32), "cov_Tw": ((0, 3, 3), torch.float64), "color": ((0, 3), torch.uint8)}
+        return {k: (torch.cat(v) if v else torch.zeros(shapes[k][0], dtype=shapes[k][1])).numpy() for k, v in self.map_points.items()}
 
     def set_pose(self, idx: int, pose: torch.Tensor) -> None:                         # write_graph_data (Optimizer.py:104-108)
         self.frames["pose"][idx] = pose.reshape(1, 7).float()

@@ -299,13 +299,24 @@ def gen_visual_map(ref):
         vmap.match2frame1.set(match_idx, torch.empty((num_match_kp,), dtype=torch.long).fill_(prev_frame_idx.item()))
         vmap.match2frame2.set(match_idx, torch.empty((num_match_kp,), dtype=torch.long).fill_(frame_idx.item()))
         prev_idx = int(frame_idx.item())
-        if match_idx.size(0) < min_num_point:                                               # :303-307 lost track
+        if match_idx.size(0) < min_num_point:                                               # :303-307 lost track: no mapping either
             vmap.frames.data["need_interp"][frame_idx] = True
+        else:                                                                               # dense-mapping tail, :313-337
+            num_map_orig = len(vmap.map_points)
+            vmap.map_points.push(MM.PointNode.init({"pos_Tw": fr["map_pos_Tw"], "cov_Tw": fr["map_cov"], "color": fr["map_color"]}))
+            vmap.frame2map.add(frame_idx, torch.tensor([num_map_orig], dtype=torch.long),
+                               torch.tensor([fr["map_pos_Tw"].size(0)], dtype=torch.long))
         vmap.frames.data["pose"][frame_idx] = fr["opt"].reshape(1, 7)                        # write_graph_data (Optimizer.py:104-108)
-        for k in ("valid", "kp0", "kp1", "vals", "sigma0", "sigma1", "cov0", "cov1", "pos_Tw", "cov0w", "color", "prior", "opt"):
+        for k in ("valid", "kp0", "kp1", "vals", "sigma0", "sigma1", "cov0", "cov1", "pos_Tw", "cov0w", "color", "prior", "opt",
+                  "map_pos_Tw", "map_cov", "map_color"):
             inputs[f"in/{t}/{k}"] = fr[k]
         inputs[f"in/{t}/time_ns"] = np.array(fr["time_ns"], dtype=np.int64)
     out = {f"ser/{k}": np.array(v, copy=True) for k, v in vmap.serialize().items()}   # serialize() returns views of the live stores
+    # VisualMap.serialize leaves the map-point store itself out (VisualMap.py:104-116): record it next to the edges that index it
+    nmp = len(vmap.map_points)
+    for k in ("pos_Tw", "cov_Tw", "color"):
+        out[f"mp/{k}"] = vmap.map_points.data[k].tensor[:nmp].clone().numpy()
+    out["mp/project_last"] = vmap.frame2map.project(torch.tensor([prev_idx], dtype=torch.long)).numpy()   # get_frame2map of the newest frame
     sensor_poses = pp.SE3(vmap.frames.data["pose"].tensor)                                    # Interface.py:47-51
     T_BS = pp.SE3(vmap.frames.data["T_BS"].tensor)
     body = (T_BS @ sensor_poses @ T_BS.Inv()).tensor().cpu().numpy()
@@ -389,10 +400,9 @@ def gen_upsample():
 if __name__ == "__main__":
     assert os.path.isdir(REF), "make_golden.py must run where /root/reference exists"
     ref = import_reference()
-    gen_selectors(ref)
-    gen_covariance(ref)
-    gen_frontend_bits(ref)
-    gen_pgo(ref)
-    gen_visual_map(ref)
-    gen_upsample()
-    gen_filters()
+    only = set(sys.argv[1:])          # e.g. `make_golden.py visual_map`: regenerate one file
+    gens = {"selector": lambda: gen_selectors(ref), "covariance": lambda: gen_covariance(ref), "frontend_bits": lambda: gen_frontend_bits(ref),
+            "pgo": lambda: gen_pgo(ref), "visual_map": lambda: gen_visual_map(ref), "upsample": gen_upsample, "filters": gen_filters}
+    for name, fn in gens.items():
+        if not only or name in only:
+            fn()

@@ -213,4 +213,14 @@ def map_sequence(seed=21, n_frames=9, max_rows=60, lost_frames=(4, 5)):
             pos_Tw=torch.randn(n, 3, generator=g) * 5, cov0w=B @ A @ A.mT @ B.mT,
             color=torch.randint(0, 256, (n, 3), generator=g, dtype=torch.uint8), prior=pose.clone(), opt=opt.float()))
         pose = opt.float()
+    # dense-mapping tail (Odometry/MACVO.py:313-337): tracked frames also push map points (own generator: the tables above
+    # stay what they were before this field existed)
+    gm = torch.Generator().manual_seed(seed + 1000)
+    for t in range(1, n_frames):
+        fr = frames[t]
+        nm = int(torch.randint(20, 51, (1,), generator=gm))
+        C = torch.randn(nm, 3, 3, generator=gm, dtype=torch.float64)
+        fr["map_pos_Tw"] = torch.randn(nm, 3, generator=gm) * 4
+        fr["map_cov"] = C @ C.mT
+        fr["map_color"] = torch.randint(0, 256, (nm, 3), generator=gm, dtype=torch.uint8)
     return dict(K=K, T_BS=T_BS, baseline=0.25), frames

@@ -131,7 +131,7 @@ def test_frame_pipe_config_validation_without_gpu():
                  min_num_point=10, graph_type=L.MV_GRAPH_DISP, filters=1, cov_kernel_size=31, fx=320.0, fy=320.0, cx=320.0,
                  cy=240.0, baseline=0.25, bl_fx=80.0, bl_fx_sq=6400.0, match_cov_default=0.25, max_match_cov=100.0,
                  max_depth_cov=250.0, max_depth=80.0, min_flow_cov_sq=0.0625, min_depth_cov=0.05, filter_min_depth=0.05,
-                 reserved=0.0, lm=lm)
+                 map_max_depth=5.0, map_max_depth_cov=0.005, lm=lm)
         d.update(kw)
         return L.mvFramePipeConfig(**d)
 

@@ -16,7 +16,8 @@ def load_golden():
     frames = [dict(n=0, time_ns=int(z["meta/time0"]))]
     for t in range(1, int(z["meta/n_frames"])):
         fr = {k: torch.from_numpy(z[f"in/{t}/{k}"]) for k in ("valid", "kp0", "kp1", "vals", "sigma0", "sigma1", "cov0", "cov1",
-                                                               "pos_Tw", "cov0w", "color", "prior", "opt")}
+                                                               "pos_Tw", "cov0w", "color", "prior", "opt", "map_pos_Tw", "map_cov",
+                                                               "map_color")}
         fr["n"] = fr["kp0"].shape[0]
         fr["time_ns"] = int(z[f"in/{t}/time_ns"])
         frames.append(fr)
@@ -38,9 +39,18 @@ def test_oracle_map_equals_real_visualmap():
     for t, fr in enumerate(frames):
         idx = m.push_frame(meta, fr)
         if t:
+            if int(fr["valid"].sum()) >= 10:            # mapping only when tracking succeeded (MACVO.py:303-307, 313-337)
+                m.push_map_points(idx, fr["map_pos_Tw"], fr["map_cov"], fr["map_color"])
             m.set_pose(idx, fr["opt"])
     ser = m.serialize()
     assert_serialized_equal(ser, z)
+    # the map-point store (not part of VisualMap.serialize) and the frame2map edges that index it
+    mp = m.map_point_arrays()
+    for k in ("pos_Tw", "cov_Tw", "color"):
+        assert mp[k].dtype == z[f"mp/{k}"].dtype and np.array_equal(mp[k], z[f"mp/{k}"]), k
+    assert (ser["edge/frame2map/deg"] == np.array([0, 1, 1, 1, 0, 0, 1, 1, 1])).all()          # frames 4, 5 lost track: no map points
+    last = ser["edge/frame2map/ranges"][-1, 0]
+    assert np.array_equal(np.arange(last[0], last[0] + last[1]), z["mp/project_last"])
     assert ser["frames//need_interp"].sum() == 2 and "frames//K" in ser                     # the lost-track frames are in the golden
     # poses.npy rows (Odometry/Interface.py:47-51): int64 time column + float32 body poses, concatenated -> float64
     P = m.poses_array()
