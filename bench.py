@@ -241,6 +241,8 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    last_timeline: dict = {}
+
     def measure(lanes, steps, warmup, seed, with_events, precision=None):
         """W untimed + K timed steps of an L-lane pipe.  Returns (elapsed s, poses, per-launch GEMM ms, launches in region)."""
         batches = lane_batches(lanes)
@@ -300,6 +302,21 @@ def main():
                 for _ in hot.run(batches[(t_idx + k) % args.pool] for k in range(extra)):
                     pass
             ms = hot.volume_times_ms()
+            # where a step's time goes, from the HIP events the driver records on its own streams (tools/lane_timeline.py):
+            # GEMM start -> next GEMM start = period; the part of it the GEMM stream idles; how far the decoder-side chain lags
+            tl = hot.timeline_ms()
+            if len(tl) > 12:
+                import statistics as st
+
+                lo, hi = len(tl) // 4, len(tl) - 2
+                med = lambda xs: round(st.median(xs) * 1e3, 1)  # noqa: E731
+                last_timeline.clear()
+                last_timeline.update({
+                    "period_us": med([tl[i + 1][0] - tl[i][0] for i in range(lo, hi)]),
+                    "gemm_us": med([tl[i][1] - tl[i][0] for i in range(lo, hi)]),
+                    "gemm_stream_idle_us": med([tl[i + 1][0] - tl[i][1] for i in range(lo, hi)]),
+                    "gemm_end_to_last_lookup_us": med([tl[i][2] - tl[i][1] for i in range(lo, hi)]),
+                    "last_lookup_to_selector_done_us": med([tl[i][3] - tl[i][2] for i in range(lo, hi)])})
         del hot
         return elapsed, all_poses, ms, min(steps, len(ms))
 
@@ -319,6 +336,7 @@ def main():
         ops.corr_volume = timed_corr_volume
 
     elapsed, _, ms, in_region = measure(args.lanes, args.steps, args.warmup, 1234 + rank, not args.no_kernel_events)
+    main_timeline = dict(last_timeline)
     if vol_events:
         torch.cuda.synchronize()
         ms = [a.elapsed_time(b) for a, b in vol_events[-args.steps:]]
@@ -469,7 +487,10 @@ def main():
         config4 = {"workload": "configs[4]: batch-32 640x480 frames per GPU = 32 lanes, one cost-volume GEMM of B = 64 pairs per step",
                    "value": round(32 * args.config4_steps / e4, 2), "unit": "stereo frames/s", "steps": args.config4_steps, "warmup": 10,
                    "ms_per_step": round(e4 / args.config4_steps * 1e3, 4),
-                   "roofline": roofline_of(ms4, args, 32, n_q, C, in4) if ms4 else None}
+                   "roofline": roofline_of(ms4, args, 32, n_q, C, in4) if ms4 else None,
+                   "timeline": dict(last_timeline) or None,
+                   "permutations": "native per-lane MT19937 + partial Fisher-Yates in the frame driver (bit-identical to torch.Generator(seed) + "
+                                   "torch.randperm; 32 torch.randperm calls per step cost the host 1.4-3 ms)"}
 
     # ---- decoder-loop harness: the same lookups / upsamplings issued BETWEEN real PyTorch-ROCm kernels (GRU, convolutions,
     # attention of a stand-in network with the reference's loop structure, covhead.py:85-135) instead of back to back
@@ -555,6 +576,7 @@ def main():
                        "excluded": "learned FlowFormer layers (source + weights absent from the reference checkout)",
                        "parallelism": f"{world * args.lanes} independent sequence(s), {args.lanes} per GPU; one all_gather of poses + timestamps"},
             "roofline": roofline,
+            "timeline": main_timeline or None,
             "other_precisions": other_legs,
             "cpu_baseline": cpu_baseline,
             "parity": parity,
