@@ -96,6 +96,8 @@ struct mvFramePipe {
     size_t pk_bytes;
     bool packed;
     int pack_on;       // 0 = on the GEMM's stream (in front of it), 1 = backend stream, 2 = decoder-side stream
+    int sel_on_back;   // 1: upsampling / epilogue / selector / count copy of a frame run on the backend stream behind its lookups
+    hipEvent_t e_lk[N_CAND];   // a frame's last lookup (decoder-side stream)
     hipEvent_t e_packed[2];
     float *up_flow, *up_cov;
     Maps maps[N_MAPS];
@@ -298,6 +300,7 @@ extern "C" void mv_frame_pipe_destroy(mvFramePipe* p) {
     for (int k = 0; k < N_CAND; ++k) ev(p->e_cand[k]);
     for (int k = 0; k < 2; ++k) { ev(p->e_backend[k]); ev(p->e_posed[k]); ev(p->e_solved[k]); }
     ev(p->e_pgo);
+    for (int k = 0; k < N_CAND; ++k) ev(p->e_lk[k]);
     ev(p->e_maptail);
     for (int k = 0; k < 2; ++k) { ev(p->e_nvalid[k]); if (p->h_nvalid[k]) (void)hipHostFree(p->h_nvalid[k]); }
     for (int k = 0; k < N_CAND; ++k) if (p->h_count_m[k]) (void)hipHostFree(p->h_count_m[k]);
@@ -396,6 +399,7 @@ static int create_impl(mvFramePipe* p) {
         MV_HIP(mk(&p->e_solved[k]));
     }
     MV_HIP(mk(&p->e_pgo));
+    for (int k = 0; k < N_CAND; ++k) MV_HIP(mk(&p->e_lk[k]));
     MV_HIP(mk(&p->e_maptail));
     for (int k = 0; k < 2; ++k) {
         MV_HIP(mk(&p->e_nvalid[k]));
@@ -447,6 +451,15 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
     p->n_volbuf = volbufs_from_env();
     p->packed = (cfg->volume_split == MV_PACK_BF16X3 || cfg->volume_split == MV_PACK_F16X2) &&
                 mv_corr_volume_packed_supported(cfg->pairs, cfg->C, p->n8, p->n8, cfg->volume_split);
+    {
+        // MV_PIPE_SELECTOR_ON=back: the selector segment of a frame (epilogue, NMS, finishing workgroup, count copy: ~60 us beside the
+        // GEMM) moves from the decoder-side stream — which a one-lane stream saturates: 12 dependent lookups + that segment = one
+        // period — to the backend stream, behind an event on the frame's last lookup; the next frame's lookups start meanwhile.
+        // Measured (640x480, f16x2 volume): one lane 5.38 k vs 4.94 k frames/s (period 183 vs 198 us), 32 lanes 7.43 k vs 7.64 k: the
+        // default follows the lane count; MV_PIPE_SELECTOR_ON=main|back forces it.
+        const char* e = getenv("MV_PIPE_SELECTOR_ON");
+        p->sel_on_back = e ? (strcmp(e, "back") == 0 ? 1 : 0) : (p->lanes <= 2 ? 1 : 0);
+    }
     {
         // Where the operand pack of frame f + 1 runs.  It needs only the feature maps, so it can run beside GEMM(f) on another of
         // the pipe's streams (a fifth stream measured 2.50 k vs 3.41 k frames/s in round 2: four is the ceiling on this stack).
@@ -586,6 +599,11 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
         p->vol_free_valid[kv] = false;                         // vol[k] / tok are only touched on s_vol: stream order suffices
     }
 
+    if (p->sel_on_back) {   // everything behind the lookups continues on the backend stream (in order with the backends it must follow)
+        MV_HIP(hipEventRecord(p->e_lk[k], s));
+        s = p->s_back;
+        MV_HIP(hipStreamWaitEvent(s, p->e_lk[k], 0));
+    }
     // maps slot m and candidate slot k were last read by the backend of frame f - 2 (f - 3 for the maps) on `back`
     // (the newest backend event covers the older one: same stream)
     if (p->n_fin > 0 && p->backend_valid[(p->n_fin - 1) & 1]) MV_TRY(wait_if_pending(s, p->e_backend[(p->n_fin - 1) & 1]));
