@@ -149,9 +149,13 @@ def roofline_of(ms, args, lanes, n_q, C, timed_region_launches, traffic=None):
                 "kernel": f"corr_volume_split_stream<{prec}>" if prec in ("bf16x3", "f16x2") else f"{prec} pre-pass + corr_volume_bf16x3_hwc<{int(nprod) // 3 + 1}>",
                 "hbm_write_GBps": round(nbytes / avg_s / 1e9, 1),
                 **common, "executed_flops_per_launch": nprod * flops, "algorithmic_tflops": round(flops / avg_s / 1e12, 2),
+                "algorithmic_vs_fp32_mfma_peak": round(flops / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                 "note": f"achieved = {int(nprod)} 16-bit piece products per algorithmic fp32 product x algorithmic FLOPs / time, against the dense 16-bit "
                         "MFMA peak (2.5 PFLOP/s; with N(0,1) operands the chip's power limit holds a bare v_mfma_f32_32x32x16_bf16 stream at "
-                        "~1.89 PFLOP/s = 0.76, tools/scratch/mfma16_probe.*); the operand pack runs on another stream and is not in this time"}
+                        "~1.89 PFLOP/s = 0.76, tools/scratch/mfma16_probe.*, and this kernel runs 1.3x faster on all-zero operands: it is "
+                        "power-, not issue-limited); algorithmic_vs_fp32_mfma_peak = algorithmic fp32 FLOPs / time against the 157.3 TFLOP/s "
+                        "fp32-MFMA peak that bounds ANY exact-fp32 form of this GEMM (> 1 = beyond that roofline); the operand pack is a "
+                        "separate launch in front of the GEMM and is not in this time"}
     if args.feat_dtype == "f32":
         ach = flops / avg_s / 1e12
         return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

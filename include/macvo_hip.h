@@ -461,6 +461,16 @@ int mv_frontend_epilogue_select_lanes(const float* flow, const float* logcov, in
 int mv_kp_gather_lanes(const int32_t* cand, size_t cand_lane_stride, const int64_t* perm /* [lanes, cap] */, int lanes,
                        const int32_t* n_live /* host */, int cap, int W, int64_t* out_uv /* [lanes, cap, 2] */,
                        mvStream_t stream);
+/* mv_kp_gather_lanes + mv_kp_track_lanes + mv_backproject_lanes (camera frame, depth = the depth0 value the tracking gather
+ * read) of a frame in ONE launch: same expressions, same bits (tests/test_gpu_backend.py::test_kp_front_equals_the_three_calls).
+ * perm: device [lanes, cap] or — one lane, <= 256 rows — host: the indices then travel inside the kernel arguments (no copy). */
+int mv_kp_front_lanes(const int32_t* cand, size_t cand_lane_stride, const int64_t* perm_dev, const int64_t* perm_host /* or NULL */,
+                      int lanes, const int32_t* n_live /* host */, int cap, const float* match_flow, const float* match_cov,
+                      const float* depth0, const float* disp0, const float* sdisp0, const float* sdd0, const float* depth1,
+                      const float* disp1, const float* sdisp1, const float* sdd1, int H, int W, int edge, float match_cov_default,
+                      float fx, float fy, float cx, float cy, int64_t* out_kp0_uv /* [lanes, cap, 2] */, float* out_kp0,
+                      float* out_kp1, uint8_t* out_inbound, float* out_vals /* [11, lanes, cap] */, float* out_sigma0,
+                      float* out_sigma1, float* out_pos_Tc /* [lanes, cap, 3] */, mvStream_t stream);
 int mv_kp_track_lanes(const int64_t* kp0_uv, int lanes, const int32_t* n_live /* host */, int cap, const float* match_flow,
                       const float* match_cov, const float* depth0, const float* disp0, const float* sdisp0,
                       const float* sdd0, const float* depth1, const float* disp1, const float* sdisp1, const float* sdd1,

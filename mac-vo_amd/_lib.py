@@ -148,6 +148,8 @@ SIGNATURES = {
     "mv_frame_pipe_wait_candidates": (C.c_int, [_P, _P]),
     "mv_frame_pipe_finish": (C.c_int, [_P, _P, _P, _P]),
     "mv_map_append_points": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
+    "mv_kp_front_lanes": (C.c_int, [_P, C.c_size_t, _P, _P, C.c_int, _P, C.c_int] + [_P] * 10 + [C.c_int, C.c_int, C.c_int] +
+                          [C.c_float] * 5 + [_P] * 8 + [_P]),
     "mv_frame_pipe_wait_tracked": (C.c_int, [_P, _P, _P]),
     "mv_frame_pipe_map_points": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "mv_frame_pipe_seed_lanes": (C.c_int, [_P, _P]),

@@ -777,11 +777,16 @@ extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, co
     for (int l = 0; l < L; ++l)
         memcpy(p->h_perm[ps] + (size_t)l * cap, perm_host + (size_t)l * cap, (size_t)n_sel[l] * sizeof(int64_t));
     MV_TRY(wait_if_pending(s, p->e_cand[pd.cand]));   // fired: the host has just read this frame's count
-    const size_t perm_bytes = ((size_t)(L - 1) * cap + n_sel[L - 1]) * sizeof(int64_t);
-    MV_HIP(hipMemcpyAsync(b.perm, p->h_perm[ps], perm_bytes, hipMemcpyHostToDevice, s));
-    MV_HIP(hipEventRecord(p->e_perm[ps], s));
-    p->perm_valid[ps] = true;
-    MV_TRY(mv_kp_gather_lanes(p->cand[pd.cand], (size_t)p->plane, b.perm, L, b.n_sel, cap, c.W, b.kp0, s));
+    static int fuse_front = -1;   // MV_PIPE_FUSE_FRONT=0: gather / track / back-projection as three launches + a permutation copy (A/B knob)
+    if (fuse_front < 0) { const char* e = getenv("MV_PIPE_FUSE_FRONT"); fuse_front = (e && atoi(e) == 0) ? 0 : 1; }
+    const bool perm_in_args = fuse_front && L == 1 && n_max <= 256;
+    if (!perm_in_args) {
+        const size_t perm_bytes = ((size_t)(L - 1) * cap + n_sel[L - 1]) * sizeof(int64_t);
+        MV_HIP(hipMemcpyAsync(b.perm, p->h_perm[ps], perm_bytes, hipMemcpyHostToDevice, s));
+        MV_HIP(hipEventRecord(p->e_perm[ps], s));
+        p->perm_valid[ps] = true;
+    }
+    if (!fuse_front) MV_TRY(mv_kp_gather_lanes(p->cand[pd.cand], (size_t)p->plane, b.perm, L, b.n_sel, cap, c.W, b.kp0, s));
     // Pose-INDEPENDENT part first: it overlaps the previous frames' solves.  The chain solve(t-1) -> backend(t) -> solve(t) is the
     // sequential dependency of visual odometry and, beside a GEMM that never pauses, it was the period of a single-sequence
     // stream (track 19 + back-projection 9 + covariances 48 + filters 21 + solve 108 us + launch gaps and two stream hops =
@@ -791,11 +796,18 @@ extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, co
     static int pose_split = -1;   // MV_PIPE_POSE_SPLIT=0: the whole backend behind the previous solve, as before (A/B knob)
     if (pose_split < 0) { const char* e = getenv("MV_PIPE_POSE_SPLIT"); pose_split = (e && atoi(e) == 0) ? 0 : 1; }
     if (!pose_split && p->pgo_valid) MV_TRY(wait_if_pending(s, p->e_pgo));
-    MV_TRY(mv_kp_track_lanes(b.kp0, L, b.n_sel, cap, m1.match_flow, m1.match_cov, m0.depth, m0.disparity, m0.disparity_cov,
-                             m0.depth_cov, m1.depth, m1.disparity, m1.disparity_cov, m1.depth_cov, c.H, c.W, c.edgewidth,
-                             c.match_cov_default, b.kp0f, b.kp1, b.inbound, b.vals, b.sigma0, b.sigma1, s));
-    MV_TRY(mv_backproject_lanes(b.kp0f, b.vals, 1, (size_t)cap, c.fx, c.fy, c.cx, c.cy, nullptr, L, b.n_sel, cap, b.pos_Tc,
-                                nullptr, nullptr, s));
+    if (fuse_front) {
+        MV_TRY(mv_kp_front_lanes(p->cand[pd.cand], (size_t)p->plane, b.perm, perm_in_args ? p->h_perm[ps] : nullptr, L, b.n_sel, cap,
+                                 m1.match_flow, m1.match_cov, m0.depth, m0.disparity, m0.disparity_cov, m0.depth_cov, m1.depth,
+                                 m1.disparity, m1.disparity_cov, m1.depth_cov, c.H, c.W, c.edgewidth, c.match_cov_default, c.fx, c.fy,
+                                 c.cx, c.cy, b.kp0, b.kp0f, b.kp1, b.inbound, b.vals, b.sigma0, b.sigma1, b.pos_Tc, s));
+    } else {
+        MV_TRY(mv_kp_track_lanes(b.kp0, L, b.n_sel, cap, m1.match_flow, m1.match_cov, m0.depth, m0.disparity, m0.disparity_cov,
+                                 m0.depth_cov, m1.depth, m1.disparity, m1.disparity_cov, m1.depth_cov, c.H, c.W, c.edgewidth,
+                                 c.match_cov_default, b.kp0f, b.kp1, b.inbound, b.vals, b.sigma0, b.sigma1, s));
+        MV_TRY(mv_backproject_lanes(b.kp0f, b.vals, 1, (size_t)cap, c.fx, c.fy, c.cx, c.cy, nullptr, L, b.n_sel, cap, b.pos_Tc,
+                                    nullptr, nullptr, s));
+    }
     mvMatchCovParams cp{c.H, c.W, c.cov_kernel_size, 1, c.fx, c.fy, c.cx, c.cy, c.min_flow_cov_sq, c.min_depth_cov};
     MV_TRY(mv_match_cov_pair_lanes(m0.depth, b.kp0f, b.sigma0, nullptr, b.cov0, nullptr, m1.depth, b.kp1, b.sigma1, b.cov1, &cp,
                                    L, b.n_sel, cap, s));

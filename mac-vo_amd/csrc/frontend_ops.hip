@@ -36,41 +36,16 @@ __global__ __launch_bounds__(256) void frontend_epilogue_kernel(
 // Lane-batched: blockIdx.y = lane; every per-keypoint table is [lanes, ..., cap] with `cap` rows of capacity per lane of
 // which cnt.n[lane] are live (rows beyond are left untouched); every map is [lanes, ch, H, W].  lanes = 1, cap = N is the
 // plain single-frame call.
-__global__ __launch_bounds__(256) void kp_track_kernel(const int64_t* __restrict__ kp0_uv, int N, mvLaneCounts cnt,
-                                                       const float* __restrict__ match_flow,
-                                                       const float* __restrict__ match_cov,
-                                                       const float* __restrict__ depth0, const float* __restrict__ disp0,
-                                                       const float* __restrict__ sdisp0, const float* __restrict__ sdd0,
-                                                       const float* __restrict__ depth1, const float* __restrict__ disp1,
-                                                       const float* __restrict__ sdisp1, const float* __restrict__ sdd1,
-                                                       int H, int W, int edge, float match_cov_default,
-                                                       float* __restrict__ out_kp0, float* __restrict__ out_kp1,
-                                                       uint8_t* __restrict__ out_inbound, float* __restrict__ out_vals,
-                                                       float* __restrict__ out_sigma0, float* __restrict__ out_sigma1) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = blockIdx.y;
-    if (n >= cnt.n[lane]) return;
+// one keypoint of kp_track (pointers already offset to the lane; `vs` = row stride of the SoA value table)
+__device__ __forceinline__ void kp_track_one(int n, int u0, int v0, const float* __restrict__ match_flow, const float* __restrict__ match_cov,
+                                             const float* __restrict__ depth0, const float* __restrict__ disp0,
+                                             const float* __restrict__ sdisp0, const float* __restrict__ sdd0,
+                                             const float* __restrict__ depth1, const float* __restrict__ disp1,
+                                             const float* __restrict__ sdisp1, const float* __restrict__ sdd1, int H, int W, int edge,
+                                             float match_cov_default, float* __restrict__ out_kp0, float* __restrict__ out_kp1,
+                                             uint8_t* __restrict__ out_inbound, float* __restrict__ out_vals, size_t vs,
+                                             float* __restrict__ out_sigma0, float* __restrict__ out_sigma1) {
     const int plane = H * W;
-    {
-        const size_t lp = (size_t)lane * plane, ln = (size_t)lane * N;
-        kp0_uv += 2 * ln;
-        match_flow += 2 * lp;
-        if (match_cov) match_cov += 3 * lp;
-        depth0 += lp; depth1 += lp;
-        if (disp0) disp0 += lp;
-        if (sdisp0) sdisp0 += lp;
-        if (sdd0) sdd0 += lp;
-        if (disp1) disp1 += lp;
-        if (sdisp1) sdisp1 += lp;
-        if (sdd1) sdd1 += lp;
-        if (out_kp0) out_kp0 += 2 * ln;
-        out_kp1 += 2 * ln;
-        out_inbound += ln;
-        out_vals += ln;   // SoA table [11, lanes, cap]: row stride = lanes * cap
-        if (out_sigma0) out_sigma0 += 3 * ln;
-        if (out_sigma1) out_sigma1 += 3 * ln;
-    }
-    const int u0 = (int)kp0_uv[2 * n], v0 = (int)kp0_uv[2 * n + 1];
     const bool ok0 = u0 >= 0 && u0 < W && v0 >= 0 && v0 < H;
     const int i0 = ok0 ? v0 * W + u0 : 0;
     // int64 + float32 -> float32 (torch type promotion)
@@ -82,7 +57,6 @@ __global__ __launch_bounds__(256) void kp_track_kernel(const int64_t* __restrict
     out_kp1[2 * n + 1] = v1;
     out_inbound[n] = inb;
     float* o = out_vals + n;   // SoA: column k of lane l lives at out_vals[(k * lanes + l) * N + n]
-    const size_t vs = (size_t)gridDim.y * N;
     o[0 * vs] = depth0[i0];
     o[1 * vs] = disp0 ? disp0[i0] : -1.f;
     o[2 * vs] = sdisp0 ? sdisp0[i0] : -1.f;
@@ -106,6 +80,82 @@ __global__ __launch_bounds__(256) void kp_track_kernel(const int64_t* __restrict
     if (out_sigma0) { out_sigma0[3 * n] = match_cov_default; out_sigma0[3 * n + 1] = match_cov_default; out_sigma0[3 * n + 2] = 0.f; }
 }
 
+struct TrackArgs {   // per-lane base pointers of kp_track (offset by the kernels)
+    const float *match_flow, *match_cov, *depth0, *disp0, *sdisp0, *sdd0, *depth1, *disp1, *sdisp1, *sdd1;
+    int H, W, edge;
+    float match_cov_default;
+    float *out_kp0, *out_kp1;
+    uint8_t* out_inbound;
+    float *out_vals, *out_sigma0, *out_sigma1;
+};
+__device__ __forceinline__ void track_lane_offsets(TrackArgs& a, int lane, int N) {
+    const size_t lp = (size_t)lane * a.H * a.W, ln = (size_t)lane * N;
+    a.match_flow += 2 * lp;
+    if (a.match_cov) a.match_cov += 3 * lp;
+    a.depth0 += lp; a.depth1 += lp;
+    if (a.disp0) a.disp0 += lp;
+    if (a.sdisp0) a.sdisp0 += lp;
+    if (a.sdd0) a.sdd0 += lp;
+    if (a.disp1) a.disp1 += lp;
+    if (a.sdisp1) a.sdisp1 += lp;
+    if (a.sdd1) a.sdd1 += lp;
+    if (a.out_kp0) a.out_kp0 += 2 * ln;
+    a.out_kp1 += 2 * ln;
+    a.out_inbound += ln;
+    a.out_vals += ln;   // SoA table [11, lanes, cap]: row stride = lanes * cap
+    if (a.out_sigma0) a.out_sigma0 += 3 * ln;
+    if (a.out_sigma1) a.out_sigma1 += 3 * ln;
+}
+
+// Lane-batched: blockIdx.y = lane; every per-keypoint table is [lanes, ..., cap] with `cap` rows of capacity per lane of
+// which cnt.n[lane] are live (rows beyond are left untouched); every map is [lanes, ch, H, W].  lanes = 1, cap = N is the
+// plain single-frame call.
+__global__ __launch_bounds__(256) void kp_track_kernel(const int64_t* __restrict__ kp0_uv, int N, mvLaneCounts cnt, TrackArgs a) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = blockIdx.y;
+    if (n >= cnt.n[lane]) return;
+    kp0_uv += 2 * (size_t)lane * N;
+    track_lane_offsets(a, lane, N);
+    kp_track_one(n, (int)kp0_uv[2 * n], (int)kp0_uv[2 * n + 1], a.match_flow, a.match_cov, a.depth0, a.disp0, a.sdisp0, a.sdd0, a.depth1,
+                 a.disp1, a.sdisp1, a.sdd1, a.H, a.W, a.edge, a.match_cov_default, a.out_kp0, a.out_kp1, a.out_inbound, a.out_vals,
+                 (size_t)gridDim.y * N, a.out_sigma0, a.out_sigma1);
+}
+
+// Round 3: gather + track + camera-frame back-projection of a frame's keypoints in ONE launch (mv_kp_front_lanes).  On the
+// backend stream of a one-lane pipeline every launch boundary costs ~5 us beside the volume GEMM, and the three kernels are
+// per-keypoint maps over the same 200 rows: `selected[perm][..., 2:].roll(1, 1)` (KeypointSelector.py:331-332,404-405), the
+// tracking gathers of MACVO.py:198-232 and pixel2point_NED (Utility/Point.py:15-17) — same expressions, same bits.  With one
+// lane the permutation travels INSIDE the kernel arguments (<= 256 indices = 1 KB of the 4 KB kernarg segment): no pinned
+// staging copy, no host-to-device memcpy node on the stream.
+struct PermArg {
+    int32_t idx[256];
+};
+template <bool PERM_IN_ARGS>
+__global__ __launch_bounds__(256) void kp_front_kernel(const int32_t* __restrict__ cand, size_t cand_lane_stride,
+                                                       const int64_t* __restrict__ perm, PermArg pa, int cap, mvLaneCounts cnt,
+                                                       int64_t* __restrict__ out_uv, TrackArgs a, float fx, float fy, float cx, float cy,
+                                                       float* __restrict__ pos_Tc) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = blockIdx.y;
+    if (n >= cnt.n[lane]) return;
+    cand += (size_t)lane * cand_lane_stride;
+    out_uv += 2 * (size_t)lane * cap;
+    pos_Tc += 3 * (size_t)lane * cap;
+    track_lane_offsets(a, lane, cap);
+    const long pi = PERM_IN_ARGS ? (long)pa.idx[n] : (long)perm[(size_t)lane * cap + n];
+    const int lin = cand[pi];
+    const int u0 = lin % a.W, v0 = lin / a.W;
+    out_uv[2 * n + 0] = u0;
+    out_uv[2 * n + 1] = v0;
+    const size_t vs = (size_t)gridDim.y * cap;
+    kp_track_one(n, u0, v0, a.match_flow, a.match_cov, a.depth0, a.disp0, a.sdisp0, a.sdd0, a.depth1, a.disp1, a.sdisp1, a.sdd1, a.H,
+                 a.W, a.edge, a.match_cov_default, a.out_kp0, a.out_kp1, a.out_inbound, a.out_vals, vs, a.out_sigma0, a.out_sigma1);
+    // pixel2point_NED on (kp0, depth0 at kp0): pp.pixel2point -> (((u-cx)*d)/fx, ((v-cy)*d)/fy, d) rolled to (d, x, y)
+    const float u = (float)u0, v = (float)v0, d = a.out_vals[n];
+    pos_Tc[3 * n] = d;
+    pos_Tc[3 * n + 1] = ((u - cx) * d) / fx;
+    pos_Tc[3 * n + 2] = ((v - cy) * d) / fy;
+}
 
 // pp.SO3.matrix() in the pose dtype (fp32): columns are SO3_Act(q, e_i)  (PyPose: self.Act(I).T)
 __device__ __forceinline__ void quat_act_f32(const float* q, const float* p, float* o) {
@@ -363,9 +413,45 @@ extern "C" int mv_kp_track_lanes(const int64_t* kp0_uv, int lanes, const int32_t
     if (rc != MV_OK) return rc;
     if (n_max == 0) return MV_OK;
     MV_CHECK_ARG(kp0_uv && match_flow && depth0 && depth1 && out_kp1 && out_inbound && out_vals);
-    hipLaunchKernelGGL(kp_track_kernel, dim3(mv_ceil_div(n_max, 256), lanes), dim3(256), 0, (hipStream_t)stream, kp0_uv, cap,
-                       c, match_flow, match_cov, depth0, disp0, sdisp0, sdd0, depth1, disp1, sdisp1, sdd1, H, W, edge,
-                       match_cov_default, out_kp0, out_kp1, out_inbound, out_vals, out_sigma0, out_sigma1);
+    const TrackArgs ta{match_flow, match_cov, depth0, disp0, sdisp0, sdd0, depth1, disp1, sdisp1, sdd1, H, W, edge, match_cov_default,
+                       out_kp0, out_kp1, out_inbound, out_vals, out_sigma0, out_sigma1};
+    hipLaunchKernelGGL(kp_track_kernel, dim3(mv_ceil_div(n_max, 256), lanes), dim3(256), 0, (hipStream_t)stream, kp0_uv, cap, c, ta);
+    return mv_launch_status();
+}
+
+extern "C" int mv_kp_front_lanes(const int32_t* cand, size_t cand_lane_stride, const int64_t* perm_dev, const int64_t* perm_host,
+                                 int lanes, const int32_t* n_live, int cap, const float* match_flow, const float* match_cov,
+                                 const float* depth0, const float* disp0, const float* sdisp0, const float* sdd0,
+                                 const float* depth1, const float* disp1, const float* sdisp1, const float* sdd1, int H, int W,
+                                 int edge, float match_cov_default, float fx, float fy, float cx, float cy, int64_t* out_kp0_uv,
+                                 float* out_kp0, float* out_kp1, uint8_t* out_inbound, float* out_vals, float* out_sigma0,
+                                 float* out_sigma1, float* out_pos_Tc, mvStream_t stream) {
+    MV_CHECK_ARG(H > 0 && W > 0 && edge >= 0);
+    mvLaneCounts c{};
+    int n_max = 0;
+    const int rc = check_lanes(lanes, n_live, cap, c, n_max);
+    if (rc != MV_OK) return rc;
+    if (n_max == 0) return MV_OK;
+    MV_CHECK_ARG(cand && (perm_dev || perm_host) && match_flow && depth0 && depth1 && out_kp0_uv && out_kp1 && out_inbound && out_vals &&
+                 out_pos_Tc);
+    const TrackArgs ta{match_flow, match_cov, depth0, disp0, sdisp0, sdd0, depth1, disp1, sdisp1, sdd1, H, W, edge, match_cov_default,
+                       out_kp0, out_kp1, out_inbound, out_vals, out_sigma0, out_sigma1};
+    const dim3 grid(mv_ceil_div(n_max, 256), lanes), block(256);
+    if (perm_host && lanes == 1 && n_max <= 256) {     // the permutation rides in the kernel arguments
+        PermArg pa;
+        for (int i = 0; i < n_max; ++i) {
+            MV_CHECK_ARG(perm_host[i] >= 0 && perm_host[i] <= 0x7fffffffLL);
+            pa.idx[i] = (int32_t)perm_host[i];
+        }
+        hipLaunchKernelGGL(kp_front_kernel<true>, grid, block, 0, (hipStream_t)stream, cand, cand_lane_stride, nullptr, pa, cap, c,
+                           out_kp0_uv, ta, fx, fy, cx, cy, out_pos_Tc);
+    } else {
+        MV_CHECK_ARG(perm_dev);
+        PermArg pa;
+        pa.idx[0] = 0;
+        hipLaunchKernelGGL(kp_front_kernel<false>, grid, block, 0, (hipStream_t)stream, cand, cand_lane_stride, perm_dev, pa, cap, c,
+                           out_kp0_uv, ta, fx, fy, cx, cy, out_pos_Tc);
+    }
     return mv_launch_status();
 }
 
