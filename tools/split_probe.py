@@ -1,4 +1,5 @@
-"""Timing of the split + streaming volume (pack, GEMM, both) next to the exact fp32 kernel, HIP events, GPU to itself."""
+"""Timing of the split + streaming volume (pack, GEMM, both) next to the exact fp32 kernel, HIP events, GPU to itself; and the
+largest deviation of each precision from the fp64 product (sampled rows) in units of the parity bar 2e-5 sqrt(C)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -29,3 +30,12 @@ for B, H, W in shapes:
               f"({nprod * fl / t_gemm / 1e6 / 2500:.3f} of 2.5 PF executed; write {B * N * N * 4 / t_gemm / 1e3:.0f} GB/s)", flush=True)
     t_exact = t(lambda: ops.corr_volume(f1, f2, out=out), n, n // 3)
     print(f"B={B} {H}x{W} exact fp32 {t_exact:.1f} us = {fl / t_exact / 1e6 / 157.3:.3f} of 157.3 TF", flush=True)
+    if B * N * N < 1e9:
+        rows = torch.arange(0, N, 37)
+        for b in range(B):
+            a64, b64 = f1[b].reshape(C, N).double(), f2[b].reshape(C, N).double()
+            ref = a64[:, rows.cuda()].T @ b64
+            for prec in ("exact", "bf16x3", "f16x2"):
+                v = ops.corr_volume(f1, f2, precision=prec)[b * N:(b + 1) * N].reshape(N, N)[rows.cuda()].double()
+                e = (v - ref).abs().max().item()
+                print(f"    pair {b} {prec:7s} max |out - fp64| = {e:.3e} = {e / (2e-5 * C ** 0.5):.3f} of the bar (N(0,1) features)", flush=True)
