@@ -575,7 +575,7 @@ def main():
                        "per_step": f"{args.lanes} frame(s): {2 * args.lanes} cost volumes [{n_q}x{C}x{n_q}] in one launch + {args.iters} 9x9 lookups "
                                    f"+ epilogue + CovAwareSelector_NoDepth(200) + 2x MatchCovariance(31x31) + TwoFrame_PGO({args.graph})",
                        "lanes": args.lanes, "feature_dtype": args.feat_dtype, "feature_layout": args.layout,
-                       "volume_precision": args.volume_precision, "hip_graphs": use_graphs, "host_driver": args.driver,
+                       "volume_precision": args.volume_precision, "hip_graphs": use_graphs, "host_driver": args.driver, "backend_launch_thread": (os.environ.get("MV_PIPE_ASYNC_BACKEND", "1") != "0") if args.driver == "native" else False,
                        "clock_ramp_s": 0.0 if args.no_ramp else RAMP_SECONDS,
                        "excluded": "learned FlowFormer layers (source + weights absent from the reference checkout)",
                        "parallelism": f"{world * args.lanes} independent sequence(s), {args.lanes} per GPU; one all_gather of poses + timestamps"},

@@ -538,7 +538,9 @@ typedef struct {
     int32_t mapping;           /* 1: dense-mapping tail of run_pair (Odometry/MACVO.py:313-337; `mapping: true`), lanes == 1 */
     int32_t map_num_point;     /* 2000 (:315) */
     int32_t map_mask_width;    /* MappingPointSelector args (Config/Experiment/MACVO/MACVO_Fast.yaml) */
-    int32_t reserved_i;
+    int32_t async_backend;     /* backend launch thread: the ~10 launches of `finish` (+ the permutation draw of finish_seeded) are issued by
+                                  a second host thread while the caller's thread enqueues the next frame.  1 on, -1 off, 0 = environment
+                                  MV_PIPE_ASYNC_BACKEND if set, else the library default.  Results are identical either way. */
     float fx, fy, cx, cy, baseline;
     float bl_fx, bl_fx_sq;     /* baseline*fx and its square, rounded once from double (StereoDepth.py:270-282) */
     float match_cov_default, max_match_cov, max_depth_cov, max_depth;

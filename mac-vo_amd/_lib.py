@@ -17,7 +17,7 @@ MV_F32, MV_F16, MV_BF16, MV_BF16X3, MV_BF16X2, MV_PACK_BF16X3, MV_PACK_F16X2 = 0
 MV_LAYOUT_CHW, MV_LAYOUT_HWC = 0, 1
 MV_KP_NODEPTH, MV_KP_FULL, MV_KP_MAPPING = 0, 1, 2
 MV_GRAPH_ICP, MV_GRAPH_REPROJ, MV_GRAPH_DISP = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 MV_MAX_LANES = 64        # include/macvo_hip.h
 
 
@@ -52,7 +52,7 @@ class mvFramePipeConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "H", "W", "C", "pairs", "iters", "radius", "feat_dtype", "layout", "volume_split", "selector_mode",
         "kp_kernel_size", "kp_mask_width", "num_point", "edgewidth", "min_num_point", "graph_type", "filters",
-        "cov_kernel_size", "mapping", "map_num_point", "map_mask_width", "reserved_i")] + [(n, C.c_float) for n in (
+        "cov_kernel_size", "mapping", "map_num_point", "map_mask_width", "async_backend")] + [(n, C.c_float) for n in (
         "fx", "fy", "cx", "cy", "baseline", "bl_fx", "bl_fx_sq", "match_cov_default", "max_match_cov", "max_depth_cov",
         "max_depth", "min_flow_cov_sq", "min_depth_cov", "filter_min_depth", "map_max_depth", "map_max_depth_cov")] + [("lm", mvLMParams)]
 

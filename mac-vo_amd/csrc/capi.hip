@@ -1,7 +1,7 @@
 // Library-level entry points of libmacvo_hip.so (see include/macvo_hip.h).
 #include "common.h"
 
-extern "C" int mv_abi_version(void) { return 4; }
+extern "C" int mv_abi_version(void) { return 5; }
 
 extern "C" const char* mv_error_string(int code) {
     switch (code) {

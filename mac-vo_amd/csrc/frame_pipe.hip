@@ -23,8 +23,12 @@
 // stage never overwrites data a still-running stage of another stream reads (maps x3, everything else x2) and the
 // cross-stream hazards are closed with events (see `enqueue` / `finish`).
 #include "common.h"
+#include <atomic>
+#include <condition_variable>
 #include <deque>
+#include <mutex>
 #include <random>
+#include <thread>
 #include <vector>
 #include <new>
 #include <stdlib.h>
@@ -44,7 +48,10 @@ namespace {
 
 // slot rotation for up to MAX_PENDING tracked frames in flight (enqueued, not finished): frame f's epilogue writes maps[f % N_MAPS]
 // while the backend of frame f - MAX_PENDING may still read maps of f - MAX_PENDING and f - MAX_PENDING - 1
-constexpr int MAX_PENDING = 3, N_MAPS = MAX_PENDING + 2, N_CAND = MAX_PENDING, N_PERM = 4, N_INEV = 8, MAX_VOL = 3;
+// N_CAND = MAX_PENDING + 1 (round 3): the candidate slot frame f's selector writes was last read by the backend of frame f - 4, not of the
+// frame finished a moment ago — so that the enqueue of frame f never has to wait for the backend launch thread (below) to have ISSUED
+// the newest finish.
+constexpr int MAX_PENDING = 3, N_MAPS = MAX_PENDING + 2, N_CAND = MAX_PENDING + 1, N_PERM = 4, N_INEV = 8, MAX_VOL = 3;
 
 struct Maps {
     float *disparity, *disparity_cov, *depth, *depth_cov, *match_flow, *match_cov;
@@ -63,6 +70,20 @@ struct Backend {   // every table is [lanes, cap = num_point, ...]; rows beyond 
 struct Pending {
     int maps, maps_prev, cand;
     bool has_cand;
+};
+
+// One `finish` split in two: the host-visible bookkeeping (slot rotation, counts, views) happens on the calling thread, the
+// launches are described by this job and issued either inline or by the backend launch thread.
+struct FinishJob {
+    Pending pd;
+    long g;                 // finish index; backend slot k = g & 1
+    int pose_from, pose_to; // pose slots: prior of the frame / its optimised pose
+    int n_max;
+    int32_t n_sel[MV_MAX_LANES];
+    int64_t n_cand[MV_MAX_LANES];   // seeded: candidate count per lane (the permutation is drawn by whoever issues the job)
+    bool seeded;
+    std::vector<int64_t> perm;      // explicit permutations [lanes, cap] (asynchronous issue: a copy of the caller's array)
+    float* pose_sink;
 };
 
 struct Carver {   // bump allocator over the arena (or a size counter when base == nullptr)
@@ -158,6 +179,24 @@ struct mvFramePipe {
     int vol_timed[MAX_VOL];      // timing slot of the GEMM that filled each volume buffer (-1: not timed)
     std::vector<hipEvent_t> tv0, tv1, tv2, tv3;   // GEMM start / end, last lookup done, selector done (timeline hook)
     int n_timed, timed_cap;
+    // Backend launch thread (round 3).  A one-lane stream is bound by the HOST: ~38 launches per frame at ~4 us each on one thread
+    // (tools/host_breakdown.py: 172 us of host time per frame, 6 us of it waiting for the GPU).  With `async_backend` the ~10
+    // launches of `finish` + the permutation draw are issued by this thread while the caller's thread already enqueues the next
+    // frame's decoder side.  Everything that is not enqueue / enqueue_volume / wait_candidates / finish / release / buffer first
+    // drains the job queue (`flush_jobs`), so the two threads never touch the same piece of driver state:
+    //   caller's thread: pending, n_enq / n_fin / pose_cur / views, s_vol + s_main launches, the selector segment on s_back
+    //   launch thread:   Backend tables, e_solved / e_posed / e_pgo / e_perm / e_backend, pinned permutation slots, rng
+    // Cross-thread event edges: e_cand and e_release are recorded by the caller BEFORE the job is queued; e_backend is consumed by
+    // the caller's enqueue only after `issued` says the launch thread has recorded it.
+    int async_backend;
+    int device;
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::deque<FinishJob> jobs;
+    long issued;            // finishes whose launches have all been issued (guarded by mu)
+    bool stop;
+    int async_rc;           // first error of an asynchronously issued job, reported by the next call
 };
 
 // cross-stream dependency; when the event has already fired no barrier packet is queued at all (every
@@ -168,6 +207,11 @@ static int wait_if_pending(hipStream_t s, hipEvent_t e) {
     if (q != hipErrorNotReady) return MV_ERR_LAUNCH;
     return hipStreamWaitEvent(s, e, 0) == hipSuccess ? MV_OK : MV_ERR_LAUNCH;
 }
+
+#define MV_ASYNC_DEFAULT(p) (1)   // measured (640x480, f16x2 volume): one lane 6.01 k vs 5.26 k frames/s, 32 lanes 7.56 k vs 7.54 k
+static int wait_issued(mvFramePipe* p, long n);
+static int flush_jobs(mvFramePipe* p);
+static void launch_thread_main(mvFramePipe* p);
 
 static int volbufs_from_env() {
     // 3 (default): with a GEMM issued one frame ahead (mv_frame_pipe_enqueue_volume) the buffer it rewrites was last read by
@@ -289,6 +333,14 @@ extern "C" size_t mv_frame_pipe_arena_bytes(const mvFramePipeConfig* cfg) {
 
 extern "C" void mv_frame_pipe_destroy(mvFramePipe* p) {
     if (!p) return;
+    if (p->worker.joinable()) {
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            p->stop = true;
+        }
+        p->cv_job.notify_all();
+        p->worker.join();   // (drains the queue first)
+    }
     (void)hipStreamSynchronize(p->s_vol);
     (void)hipStreamSynchronize(p->s_main);
     (void)hipStreamSynchronize(p->s_back);
@@ -484,12 +536,21 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
         mv_frame_pipe_destroy(p);
         return rc;
     }
+    {
+        // config.async_backend: 1 on, -1 off, 0 = MV_PIPE_ASYNC_BACKEND if set, else the measured default (see mvFramePipe)
+        const char* e = getenv("MV_PIPE_ASYNC_BACKEND");
+        const int want = cfg->async_backend ? cfg->async_backend : (e ? (atoi(e) ? 1 : -1) : MV_ASYNC_DEFAULT(p));
+        p->async_backend = want > 0 ? 1 : 0;
+        if (hipGetDevice(&p->device) != hipSuccess) p->async_backend = 0;
+        if (p->async_backend) p->worker = std::thread(launch_thread_main, p);
+    }
     *out = p;
     return MV_OK;
 }
 
 extern "C" int mv_frame_pipe_set_pose(mvFramePipe* p, const float* pose7_host) {
     MV_CHECK_ARG(p && pose7_host);
+    MV_TRY(flush_jobs(p));
     if (p->pgo_valid) MV_HIP(hipEventSynchronize(p->e_pgo));
     MV_HIP(hipMemcpy(p->pose[p->pose_cur], pose7_host, (size_t)p->lanes * 7 * sizeof(float), hipMemcpyHostToDevice));
     return MV_OK;
@@ -606,7 +667,23 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
     }
     // maps slot m and candidate slot k were last read by the backend of frame f - 2 (f - 3 for the maps) on `back`
     // (the newest backend event covers the older one: same stream)
-    if (p->n_fin > 0 && p->backend_valid[(p->n_fin - 1) & 1]) MV_TRY(wait_if_pending(s, p->e_backend[(p->n_fin - 1) & 1]));
+    if (p->async_backend) {
+        // Maps slot m and candidate slot k were last read by the backend of frame f - 4.  Of the three tracked frames behind it,
+        // pending.size() are not finished yet and the others are the newest finishes: frame f - 4 is finish number
+        // n_fin - 3 + pending.size() - 1, which the launch thread issued long ago (this wait does not block in steady state); any
+        // backend event recorded at or after it orders this stream behind it (same stream).
+        if (!with_selector) MV_TRY(flush_jobs(p));   // (re-)initialisation: no assumption about what is in flight
+        long issued;
+        {
+            const long need = p->n_fin - MAX_PENDING + (long)p->pending.size();
+            MV_TRY(wait_issued(p, need < 0 ? 0 : need));
+            std::lock_guard<std::mutex> lk(p->mu);
+            issued = p->issued;
+        }
+        if (issued > 0) MV_TRY(wait_if_pending(s, p->e_backend[(issued - 1) & 1]));
+    } else if (p->n_fin > 0 && p->backend_valid[(p->n_fin - 1) & 1]) {
+        MV_TRY(wait_if_pending(s, p->e_backend[(p->n_fin - 1) & 1]));
+    }
     if (p->release_valid) MV_TRY(wait_if_pending(s, p->e_release));   // ... and by consumers of result views (mv_frame_pipe_release)
     Maps& mp = p->maps[m];
     static int fuse_epi = -1;   // MV_PIPE_FUSE_EPI=0: epilogue and selector as separate launches (A/B knob)
@@ -704,54 +781,57 @@ static void randperm_head(std::mt19937& eng, int64_t n, int k, std::vector<int32
     for (int64_t i = 0; i < m; ++i) out[i] = r[(size_t)i];
 }
 
-extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, const int32_t* n_sel, float* pose_sink);
-
-// wait_candidates + permutations (per-lane generators of mv_frame_pipe_seed_lanes) + finish in one host call
-extern "C" int mv_frame_pipe_finish_seeded(mvFramePipe* p, float* pose_sink, int32_t* n_cand_out, int32_t* n_sel_out) {
-    MV_CHECK_ARG(p && !p->pending.empty() && (int)p->rng.size() == p->lanes);
-    const Pending& pd = p->pending.front();
-    MV_HIP(hipEventSynchronize(p->e_cand[pd.cand]));
-    const int cap = p->c.num_point > 0 ? p->c.num_point : 1;
-    for (int l = 0; l < p->lanes; ++l) {
-        const int64_t n = p->h_count[pd.cand][4 * l];
-        const int k = (int)(n < p->c.num_point ? n : p->c.num_point);
-        randperm_head(p->rng[(size_t)l], n, p->c.num_point, p->perm_scratch, p->perm_host.data() + (size_t)l * cap);
-        p->nsel_host[(size_t)l] = k;
-        if (n_cand_out) n_cand_out[l] = (int32_t)n;
-        if (n_sel_out) n_sel_out[l] = k;
-    }
-    return mv_frame_pipe_finish(p, p->perm_host.data(), p->nsel_host.data(), pose_sink);
-}
-
 // ------------------------------------------------------------------------------------------------ pose-dependent half
-extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, const int32_t* n_sel, float* pose_sink) {
-    MV_CHECK_ARG(p && n_sel && !p->pending.empty());
+// Host part of a finish: validate, take the frame off the pending list, rotate the slots and update everything the caller's
+// thread reads afterwards (views, counts).  No HIP call.
+static int finish_host(mvFramePipe* p, const int32_t* n_sel, float* pose_sink, FinishJob& j) {
     const mvFramePipeConfig& c = p->c;
-    const int L = p->lanes, cap = c.num_point > 0 ? c.num_point : 1;
+    const int L = p->lanes;
     int n_max = 0;
     for (int l = 0; l < L; ++l) {
         MV_CHECK_ARG(n_sel[l] >= 0 && n_sel[l] <= c.num_point);
         n_max = n_sel[l] > n_max ? n_sel[l] : n_max;
     }
-    MV_CHECK_ARG(n_max == 0 || perm_host);
-    const Pending pd = p->pending.front();
+    j.pd = p->pending.front();
     p->pending.pop_front();
-    const long g = p->n_fin;
+    j.g = p->n_fin;
+    j.n_max = n_max;
+    j.pose_sink = pose_sink;
+    Backend& b = p->be[j.g & 1];
+    for (int l = 0; l < L; ++l) b.n_sel[l] = j.n_sel[l] = n_sel[l];
+    p->n_fin = j.g + 1;
+    p->prior_slot = p->pose_cur;
+    j.pose_from = p->pose_cur;
+    j.pose_to = (p->pose_cur + 1) % 3;
+    p->pose_cur = j.pose_to;
+    p->mp_rows = 0;
+    if (n_max > 0) {
+        p->last_maps_prev = j.pd.maps_prev;
+        p->last_cand = j.pd.cand;
+    }
+    return MV_OK;
+}
+
+// Device part: every launch of the frame's backend + solve.  Runs on the caller's thread, or on the launch thread (then it must
+// not touch anything but the job, the Backend slot and the launch thread's own events / flags).
+static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_host) {
+    const mvFramePipeConfig& c = p->c;
+    const int L = p->lanes, cap = c.num_point > 0 ? c.num_point : 1;
+    const int n_max = j.n_max;
+    const Pending& pd = j.pd;
+    const long g = j.g;
     const int k = (int)(g & 1);
     Backend& b = p->be[k];
-    for (int l = 0; l < L; ++l) b.n_sel[l] = n_sel[l];
-    p->n_fin = g + 1;
+    const int32_t* n_sel = j.n_sel;
     hipStream_t s = p->s_back;
-    p->prior_slot = p->pose_cur;
     if (n_max == 0) {   // nothing to track in any lane: the poses stay at the motion-model prior (MACVO.py:303-307)
         // The pose slots still rotate (MV_FB_POSE age a = the pose after the a-th newest finish) and the slot's events are
         // refreshed, so that everything keyed on "slot of finish g" (mv_frame_pipe_map_append, result views) sees this frame and
         // not the one two finishes back.  In-order on the side stream: behind the previous solve, no extra wait needed.
-        const int nxt0 = (p->pose_cur + 1) % 3;
-        MV_HIP(hipMemcpyAsync(p->pose[nxt0], p->pose[p->pose_cur], (size_t)L * 7 * sizeof(float), hipMemcpyDeviceToDevice,
+        MV_HIP(hipMemcpyAsync(p->pose[j.pose_to], p->pose[j.pose_from], (size_t)L * 7 * sizeof(float), hipMemcpyDeviceToDevice,
                               p->s_side));
-        if (pose_sink)
-            MV_HIP(hipMemcpyAsync(pose_sink, p->pose[nxt0], (size_t)L * 7 * sizeof(float), hipMemcpyDeviceToDevice, p->s_side));
+        if (j.pose_sink)
+            MV_HIP(hipMemcpyAsync(j.pose_sink, p->pose[j.pose_to], (size_t)L * 7 * sizeof(float), hipMemcpyDeviceToDevice, p->s_side));
         MV_HIP(hipEventRecord(p->e_posed[k], p->s_side));
         MV_HIP(hipEventRecord(p->e_pgo, p->s_side));
         MV_HIP(hipEventRecord(p->e_solved[k], p->s_side));
@@ -759,9 +839,7 @@ extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, co
         p->pgo_valid = true;
         p->solved_valid[k] = true;
         p->backend_valid[k] = true;
-        p->pose_cur = nxt0;
         p->nvalid_valid[k] = false;   // (mv_frame_pipe_wait_tracked then reports 0 observations: no mapping either)
-        p->mp_rows = 0;
         return MV_OK;
     }
     const Maps &m0 = p->maps[pd.maps_prev], &m1 = p->maps[pd.maps];
@@ -786,7 +864,7 @@ extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, co
         MV_HIP(hipEventRecord(p->e_perm[ps], s));
         p->perm_valid[ps] = true;
     }
-    if (!fuse_front) MV_TRY(mv_kp_gather_lanes(p->cand[pd.cand], (size_t)p->plane, b.perm, L, b.n_sel, cap, c.W, b.kp0, s));
+    if (!fuse_front) MV_TRY(mv_kp_gather_lanes(p->cand[pd.cand], (size_t)p->plane, b.perm, L, n_sel, cap, c.W, b.kp0, s));
     // Pose-INDEPENDENT part first: it overlaps the previous frames' solves.  The chain solve(t-1) -> backend(t) -> solve(t) is the
     // sequential dependency of visual odometry and, beside a GEMM that never pauses, it was the period of a single-sequence
     // stream (track 19 + back-projection 9 + covariances 48 + filters 21 + solve 108 us + launch gaps and two stream hops =
@@ -797,30 +875,27 @@ extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, co
     if (pose_split < 0) { const char* e = getenv("MV_PIPE_POSE_SPLIT"); pose_split = (e && atoi(e) == 0) ? 0 : 1; }
     if (!pose_split && p->pgo_valid) MV_TRY(wait_if_pending(s, p->e_pgo));
     if (fuse_front) {
-        MV_TRY(mv_kp_front_lanes(p->cand[pd.cand], (size_t)p->plane, b.perm, perm_in_args ? p->h_perm[ps] : nullptr, L, b.n_sel, cap,
+        MV_TRY(mv_kp_front_lanes(p->cand[pd.cand], (size_t)p->plane, b.perm, perm_in_args ? p->h_perm[ps] : nullptr, L, n_sel, cap,
                                  m1.match_flow, m1.match_cov, m0.depth, m0.disparity, m0.disparity_cov, m0.depth_cov, m1.depth,
                                  m1.disparity, m1.disparity_cov, m1.depth_cov, c.H, c.W, c.edgewidth, c.match_cov_default, c.fx, c.fy,
                                  c.cx, c.cy, b.kp0, b.kp0f, b.kp1, b.inbound, b.vals, b.sigma0, b.sigma1, b.pos_Tc, s));
     } else {
-        MV_TRY(mv_kp_track_lanes(b.kp0, L, b.n_sel, cap, m1.match_flow, m1.match_cov, m0.depth, m0.disparity, m0.disparity_cov,
+        MV_TRY(mv_kp_track_lanes(b.kp0, L, n_sel, cap, m1.match_flow, m1.match_cov, m0.depth, m0.disparity, m0.disparity_cov,
                                  m0.depth_cov, m1.depth, m1.disparity, m1.disparity_cov, m1.depth_cov, c.H, c.W, c.edgewidth,
                                  c.match_cov_default, b.kp0f, b.kp1, b.inbound, b.vals, b.sigma0, b.sigma1, s));
-        MV_TRY(mv_backproject_lanes(b.kp0f, b.vals, 1, (size_t)cap, c.fx, c.fy, c.cx, c.cy, nullptr, L, b.n_sel, cap, b.pos_Tc,
+        MV_TRY(mv_backproject_lanes(b.kp0f, b.vals, 1, (size_t)cap, c.fx, c.fy, c.cx, c.cy, nullptr, L, n_sel, cap, b.pos_Tc,
                                     nullptr, nullptr, s));
     }
     mvMatchCovParams cp{c.H, c.W, c.cov_kernel_size, 1, c.fx, c.fy, c.cx, c.cy, c.min_flow_cov_sq, c.min_depth_cov};
     MV_TRY(mv_match_cov_pair_lanes(m0.depth, b.kp0f, b.sigma0, nullptr, b.cov0, nullptr, m1.depth, b.kp1, b.sigma1, b.cov1, &cp,
-                                   L, b.n_sel, cap, s));
-    MV_TRY(mv_obs_filter_lanes(b.inbound, b.cov0, b.cov1, b.vals, c.filters, c.filter_min_depth, c.max_depth, L, b.n_sel, cap,
+                                   L, n_sel, cap, s));
+    MV_TRY(mv_obs_filter_lanes(b.inbound, b.cov0, b.cov1, b.vals, c.filters, c.filter_min_depth, c.max_depth, L, n_sel, cap,
                                b.valid, b.n_valid, s));
     if (c.mapping) {   // the mapping decision of this frame (MACVO.py:303-307) needs the observation count on the host
         MV_HIP(hipMemcpyAsync(p->h_nvalid[k], b.n_valid, (size_t)L * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         MV_HIP(hipEventRecord(p->e_nvalid[k], s));
         p->nvalid_valid[k] = true;
     }
-    p->last_maps_prev = pd.maps_prev;
-    p->last_cand = pd.cand;
-    p->mp_rows = 0;
     MV_HIP(hipEventRecord(p->e_backend[k], s));
     p->backend_valid[k] = true;
 
@@ -829,23 +904,106 @@ extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, co
     // the next frame's priors (StaticMotionModel)
     hipStream_t ss = p->s_side;
     MV_HIP(hipStreamWaitEvent(ss, p->e_backend[k], 0));
-    const float* pose = p->pose[p->pose_cur];
-    MV_TRY(mv_pose_apply_lanes(pose, b.pos_Tc, b.cov0, L, b.n_sel, cap, b.pos_Tw, b.rot, b.cov0w, ss));
+    const float* pose = p->pose[j.pose_from];
+    MV_TRY(mv_pose_apply_lanes(pose, b.pos_Tc, b.cov0, L, n_sel, cap, b.pos_Tw, b.rot, b.cov0w, ss));
     MV_HIP(hipEventRecord(p->e_posed[k], ss));
-    const int nxt = (p->pose_cur + 1) % 3;
     const size_t N = (size_t)cap;
     const size_t LN = (size_t)L * N;   // value table is [11, lanes, cap]: each of its rows is one concatenated per-point column
     MV_TRY(mv_pgo_solve(L, p->offs, c.graph_type, pose, p->intr, p->bl, b.pos_Tw, b.cov0w, b.kp1, b.vals + 4 * LN,
                         b.vals + 5 * LN, b.vals + 6 * LN, b.sigma1, b.cov1, b.valid, c.min_num_point, &c.lm, b.pose64, b.info,
-                        p->pose[nxt], ss));
-    if (pose_sink)
-        MV_HIP(hipMemcpyAsync(pose_sink, p->pose[nxt], (size_t)L * 7 * sizeof(float), hipMemcpyDeviceToDevice, ss));
+                        p->pose[j.pose_to], ss));
+    if (j.pose_sink)
+        MV_HIP(hipMemcpyAsync(j.pose_sink, p->pose[j.pose_to], (size_t)L * 7 * sizeof(float), hipMemcpyDeviceToDevice, ss));
     MV_HIP(hipEventRecord(p->e_pgo, ss));
     MV_HIP(hipEventRecord(p->e_solved[k], ss));
     p->pgo_valid = true;
     p->solved_valid[k] = true;
-    p->pose_cur = nxt;
     return MV_OK;
+}
+
+// permutations of a seeded job: torch.randperm of each lane's generator (see above)
+static const int64_t* draw_perms(mvFramePipe* p, const FinishJob& j) {
+    const int cap = p->c.num_point > 0 ? p->c.num_point : 1;
+    for (int l = 0; l < p->lanes; ++l)
+        randperm_head(p->rng[(size_t)l], j.n_cand[l], p->c.num_point, p->perm_scratch, p->perm_host.data() + (size_t)l * cap);
+    return p->perm_host.data();
+}
+
+// ------------------------------------------------------------------------------------------------ backend launch thread
+static void launch_thread_main(mvFramePipe* p) {
+    (void)hipSetDevice(p->device);
+    for (;;) {
+        FinishJob j;
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->cv_job.wait(lk, [&] { return p->stop || !p->jobs.empty(); });
+            if (p->jobs.empty()) return;
+            j = std::move(p->jobs.front());
+            p->jobs.pop_front();
+        }
+        const int rc = finish_issue(p, j, j.seeded ? draw_perms(p, j) : j.perm.data());
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            p->issued = j.g + 1;
+            if (rc != MV_OK && p->async_rc == MV_OK) p->async_rc = rc;
+        }
+        p->cv_done.notify_all();
+    }
+}
+
+// block until the launch thread has issued the first `n` finishes (n <= n_fin); returns the first asynchronous error
+static int wait_issued(mvFramePipe* p, long n) {
+    if (!p->async_backend) return MV_OK;
+    std::unique_lock<std::mutex> lk(p->mu);
+    p->cv_done.wait(lk, [&] { return p->issued >= n; });
+    return p->async_rc;
+}
+static int flush_jobs(mvFramePipe* p) { return wait_issued(p, p->n_fin); }
+
+static int submit_or_issue(mvFramePipe* p, FinishJob& j, const int64_t* perm_host) {
+    if (!p->async_backend) return finish_issue(p, j, j.seeded ? draw_perms(p, j) : perm_host);
+    if (!j.seeded && j.n_max > 0) {
+        const size_t cap = p->c.num_point > 0 ? p->c.num_point : 1;
+        j.perm.assign(perm_host, perm_host + (size_t)p->lanes * cap);
+    }
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        rc = p->async_rc;
+        p->jobs.push_back(std::move(j));
+    }
+    p->cv_job.notify_one();
+    return rc;
+}
+
+// wait_candidates + permutations (per-lane generators of mv_frame_pipe_seed_lanes) + finish in one host call
+extern "C" int mv_frame_pipe_finish_seeded(mvFramePipe* p, float* pose_sink, int32_t* n_cand_out, int32_t* n_sel_out) {
+    MV_CHECK_ARG(p && !p->pending.empty() && (int)p->rng.size() == p->lanes);
+    const Pending& pd = p->pending.front();
+    MV_HIP(hipEventSynchronize(p->e_cand[pd.cand]));
+    FinishJob j{};
+    j.seeded = true;
+    int32_t nsel[MV_MAX_LANES];
+    for (int l = 0; l < p->lanes; ++l) {
+        const int64_t n = p->h_count[pd.cand][4 * l];
+        const int k = (int)(n < p->c.num_point ? n : p->c.num_point);
+        j.n_cand[l] = n;
+        nsel[l] = k;
+        if (n_cand_out) n_cand_out[l] = (int32_t)n;
+        if (n_sel_out) n_sel_out[l] = k;
+    }
+    MV_TRY(finish_host(p, nsel, pose_sink, j));
+    return submit_or_issue(p, j, nullptr);
+}
+
+extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, const int32_t* n_sel, float* pose_sink) {
+    MV_CHECK_ARG(p && n_sel && !p->pending.empty());
+    for (int l = 0; l < p->lanes; ++l)
+        MV_CHECK_ARG(n_sel[l] >= 0 && n_sel[l] <= p->c.num_point && (n_sel[l] == 0 || perm_host));
+    FinishJob j{};
+    j.seeded = false;
+    MV_TRY(finish_host(p, n_sel, pose_sink, j));
+    return submit_or_issue(p, j, perm_host);
 }
 
 // Register the newest FINISHED frame in a device-resident map (call right after mv_frame_pipe_finish; lanes == 1): the
@@ -855,6 +1013,7 @@ extern "C" int mv_frame_pipe_map_append(mvFramePipe* p, const mvMapStores* store
                                         const float* K_dev, const float* T_BS_dev, float baseline, int64_t time_ns,
                                         const uint8_t* color_dev) {
     MV_CHECK_ARG(p && stores && K_dev && T_BS_dev && p->lanes == 1 && p->n_fin > 0 && frame_idx >= 0);
+    MV_TRY(flush_jobs(p));
     const mvFramePipeConfig& c = p->c;
     const long g = p->n_fin - 1;
     const Backend& b = p->be[g & 1];
@@ -889,6 +1048,7 @@ extern "C" int mv_frame_pipe_map_append(mvFramePipe* p, const mvMapStores* store
 // ------------------------------------------------------------------------------------------------ dense-mapping tail
 extern "C" int mv_frame_pipe_wait_tracked(mvFramePipe* p, int32_t* n_valid, int32_t* n_cand_map) {
     MV_CHECK_ARG(p && n_valid && p->c.mapping && p->n_fin > 0);
+    MV_TRY(flush_jobs(p));
     const int k = (int)((p->n_fin - 1) & 1);
     if (!p->nvalid_valid[k]) {          // a frame without keypoints: nothing was tracked
         *n_valid = 0;
@@ -904,6 +1064,7 @@ extern "C" int mv_frame_pipe_wait_tracked(mvFramePipe* p, int32_t* n_valid, int3
 extern "C" int mv_frame_pipe_map_points(mvFramePipe* p, const int64_t* perm_host, int n_sel, const float* image_dev,
                                         const mvMapStores* stores) {
     MV_CHECK_ARG(p && p->c.mapping && p->n_fin > 0 && n_sel >= 0 && n_sel <= p->c.map_num_point && (n_sel == 0 || perm_host));
+    MV_TRY(flush_jobs(p));
     const mvFramePipeConfig& c = p->c;
     const int k = (int)((p->n_fin - 1) & 1);
     hipStream_t s = p->s_back;
@@ -941,6 +1102,7 @@ extern "C" int mv_frame_pipe_release(mvFramePipe* p, mvStream_t stream) {
 
 extern "C" int mv_frame_pipe_sync(mvFramePipe* p, mvStream_t stream, int block_host) {
     MV_CHECK_ARG(p);
+    MV_TRY(flush_jobs(p));   // everything finished so far has been issued
     if (block_host == 2) {   // results of the newest FINISHED frame only: its solve (which ran behind its backend kernels)
         if (p->pgo_valid) MV_HIP(hipStreamWaitEvent((hipStream_t)stream, p->e_pgo, 0));
         return MV_OK;

@@ -96,6 +96,8 @@ class HotPathConfig:
     volume_precision: str = "exact"      # fp32 features: "exact" fp32 MFMA | "bf16x3" packed three-piece split on the 16-bit
                                          # matrix pipe, six products, fp32-class (same parity bar, not bitwise), either layout |
                                          # "split3" / "split2" the round-1 tile kernels over pre-split planes (layout "hwc")
+    async_backend: bool | None = None    # native driver: issue a frame's backend launches from a second host thread (None: the
+                                         # library's default / MV_PIPE_ASYNC_BACKEND); identical results either way
 
 
 @dataclass
@@ -550,7 +552,7 @@ class NativeHotPath:
             bl_fx=bl_fx, bl_fx_sq=bl_fx ** 2, match_cov_default=c.match_cov_default, max_match_cov=c.max_match_cov,
             max_depth_cov=c.max_depth_cov, max_depth=max_depth, min_flow_cov_sq=c.min_flow_cov ** 2,
             min_depth_cov=c.min_depth_cov, filter_min_depth=c.filter_min_depth, mapping=int(c.mapping), map_num_point=c.map_num_point,
-            map_mask_width=c.map_mask_width, reserved_i=0, map_max_depth=c.map_max_depth, map_max_depth_cov=c.map_max_depth_cov, lm=self.lm)
+            map_mask_width=c.map_mask_width, async_backend=0 if c.async_backend is None else (1 if c.async_backend else -1), map_max_depth=c.map_max_depth, map_max_depth_cov=c.map_max_depth_cov, lm=self.lm)
         nbytes = lib.mv_frame_pipe_arena_bytes(C.byref(pc))
         if nbytes == 0:
             raise L.MacvoHipError("mv_frame_pipe_arena_bytes: invalid configuration")

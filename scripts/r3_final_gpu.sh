@@ -11,6 +11,7 @@ tail -1 gpurun_out/prof_r03_bench/bench.log > gpurun_out/r03_bench_profiled_line
 MV_SPLIT_MODE=f16x2 bash scripts/pmc_gpu.sh r03_split_f16x2 volume_split >> $L 2>&1
 MV_SPLIT_MODE=bf16x3 bash scripts/pmc_gpu.sh r03_split_bf16x3 volume_split >> $L 2>&1
 bash scripts/profile_kernels_gpu.sh r03_kernels volume_split volume_f32 lookup pgo >> $L 2>&1
+timeout 300 python tools/split_probe.py 2x60x80 >> $L 2>&1
 python - >> $L 2>&1 <<'PY'
 import json
 for f in ("r03_bench_default_line.json", "r03_bench_steps20_line.json"):

@@ -273,3 +273,49 @@ def test_native_seeded_lanes_equal_torch_generators(gpu):
             assert ra[t][l][1] == rb[t][l][1] and ra[t][l][1] > 150          # more candidates than selected points
             assert torch.equal(ra[t][l][0], rb[t][l][0]), (t, l)
     assert torch.equal(sa, sb)
+
+
+@pytest.mark.parametrize("lanes,seeded,sync_each", [(1, True, False), (1, False, False), (2, True, True), (3, False, False)])
+def test_backend_launch_thread_equals_inline_issue(gpu, lanes, seeded, sync_each):
+    """`async_backend`: the launches of `finish` (+ the permutation draw of the seeded form) issued by the driver's second host thread
+    while the caller's thread already enqueues the next frames.  Same bits as the inline form — every pose of a 3-deep pipelined run
+    (device-side pose sink, no host sync in between when `sync_each` is off, so that the two threads really overlap), the newest
+    frame's tables and LM info — and the same keypoints frame by frame when the consumer syncs after each frame (which drains the
+    job queue: the other code path)."""
+    from macvo_amd.pipeline import Camera, HotPathConfig, NativeHotPath, stack_lanes
+
+    H, W, n_frames = 240, 320, 14
+    seqs = [synth.make_sequence(n_frames, H, W, C=64, iters=2, seed=700 + l, pool=1) for l in range(lanes)]
+    cam = seqs[0][0]
+    seeds = [11 + 5 * l for l in range(lanes)]
+    batched = [stack_lanes([_inputs(seqs[l][1][t], gpu) for l in range(lanes)]) for t in range(n_frames)]
+    torch.cuda.synchronize()
+    outs = []
+    for mode in (True, False):
+        hot = NativeHotPath(Camera(**cam), HotPathConfig(num_point=120, async_backend=mode), gpu, lanes=lanes,
+                            generators=seeds if seeded else _gens(seeds), keep_extras=True)
+        hot.initialize(batched[0])
+        sink = torch.zeros(n_frames - 1, lanes, 7, device=gpu)
+        per_frame = []
+        for res in hot.run(batched[1:], pose_sink=sink):
+            res = res if isinstance(res, list) else [res]
+            if sync_each:
+                hot.sync_pose()
+                per_frame.append([(r.kp0_uv.clone(), r.pose.clone(), r.n_cand) for r in res])
+            last = res
+        hot.sync_pose()
+        tail = [(r.kp0_uv.clone(), r.extras["tracked"].kp1_uv.clone(), r.extras["pos_Tw"].clone(), r.extras["cov0_w"].clone(),
+                 r.extras["cov1"].clone(), r.info.clone(), r.pose_f64.clone(), r.pose.clone()) for r in last]
+        torch.cuda.synchronize()
+        outs.append((sink.clone(), per_frame, tail))
+        del hot
+    (sa, fa, ta), (sb, fb, tb) = outs
+    assert sa.abs().sum().item() > 0
+    assert torch.equal(sa, sb)
+    for x, y in zip(ta, tb):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v)
+    assert len(fa) == len(fb)
+    for x, y in zip(fa, fb):
+        for (k0, p0, n0), (k1, p1, n1) in zip(x, y):
+            assert n0 == n1 and torch.equal(k0, k1) and torch.equal(p0, p1)
