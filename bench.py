@@ -152,8 +152,9 @@ def roofline_of(ms, args, lanes, n_q, C, timed_region_launches, traffic=None):
                 "algorithmic_vs_fp32_mfma_peak": round(flops / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                 "note": f"achieved = {int(nprod)} 16-bit piece products per algorithmic fp32 product x algorithmic FLOPs / time, against the dense 16-bit "
                         "MFMA peak (2.5 PFLOP/s; with N(0,1) operands the chip's power limit holds a bare v_mfma_f32_32x32x16_bf16 stream at "
-                        "~1.89 PFLOP/s = 0.76, tools/scratch/mfma16_probe.*, and this kernel runs 1.3x faster on all-zero operands: it is "
-                        "power-, not issue-limited); algorithmic_vs_fp32_mfma_peak = algorithmic fp32 FLOPs / time against the 157.3 TFLOP/s "
+                        "~1.89 PFLOP/s = 0.76, tools/scratch/mfma16_probe.*; this kernel runs 1.3x faster on all-zero operands with identical cycle "
+                        "counters = the clock, and inside its cycles the matrix pipe is busy 46 % (f16x2) / 63 % (bf16x3), "
+                        "profiles/r03_split_wait_counters.log); algorithmic_vs_fp32_mfma_peak = algorithmic fp32 FLOPs / time against the 157.3 TFLOP/s "
                         "fp32-MFMA peak that bounds ANY exact-fp32 form of this GEMM (> 1 = beyond that roofline); the operand pack is a "
                         "separate launch in front of the GEMM and is not in this time"}
     if args.feat_dtype == "f32":

@@ -634,7 +634,11 @@ extern "C" int mv_corr_volume_packed(const void* packed1, const void* packed2, f
         }
     }
 #endif
-    const dim3 g((cu_count() & ~7));             // one workgroup per CU, a multiple of 8: one run per XCD
+    // one workgroup per CU, a multiple of 8: one run per XCD.  MV_SPLIT_WGS=<n>: fewer persistent workgroups (A/B knob for streams
+    // confined to a CU subset, MV_PIPE_SMALL_CUS)
+    static int wgs_env = -1;
+    if (wgs_env < 0) { const char* e = getenv("MV_SPLIT_WGS"); wgs_env = e ? atoi(e) : 0; }
+    const dim3 g((wgs_env >= 8 && wgs_env <= cu_count() ? wgs_env : cu_count()) & ~7);
     if (mode == MV_PACK_BF16X3) {
         using K = SplitCfg<3, false, 16, 4>;
         mv_note_volume_kernel("corr_volume_split_stream<bf16x3>");

@@ -51,7 +51,10 @@ namespace {
 // N_CAND = MAX_PENDING + 1 (round 3): the candidate slot frame f's selector writes was last read by the backend of frame f - 4, not of the
 // frame finished a moment ago — so that the enqueue of frame f never has to wait for the backend launch thread (below) to have ISSUED
 // the newest finish.
-constexpr int MAX_PENDING = 3, N_MAPS = MAX_PENDING + 2, N_CAND = MAX_PENDING + 1, N_PERM = 4, N_INEV = 8, MAX_VOL = 3;
+#ifndef MV_MAX_PENDING
+#define MV_MAX_PENDING 3
+#endif
+constexpr int MAX_PENDING = MV_MAX_PENDING, N_MAPS = MAX_PENDING + 2, N_CAND = MAX_PENDING + 1, N_PERM = 4, N_INEV = 8, MAX_VOL = 3;
 
 struct Maps {
     float *disparity, *disparity_cov, *depth, *depth_cov, *match_flow, *match_cov;
@@ -570,7 +573,7 @@ static int issue_volume(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_s
     MV_TRY(wait_if_pending(p->s_vol, e_in));
     if (p->vol_free_valid[k]) MV_TRY(wait_if_pending(p->s_vol, p->e_vol_free[k]));
     const bool timed = p->n_timed < p->timed_cap;
-    if (timed && !(p->packed && p->pack_on != 0)) MV_HIP(hipEventRecord(p->tv0[p->n_timed], p->s_vol));
+    if (timed && !p->packed) MV_HIP(hipEventRecord(p->tv0[p->n_timed], p->s_vol));
     if (p->packed) {
         void** pk = p->pk[f & 1];
         hipStream_t sp = p->pack_on == 0 ? p->s_vol : p->pack_on == 1 ? p->s_back : p->s_main;
@@ -584,8 +587,8 @@ static int issue_volume(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_s
         if (sp != p->s_vol) {
             MV_HIP(hipEventRecord(p->e_packed[f & 1], sp));
             MV_HIP(hipStreamWaitEvent(p->s_vol, p->e_packed[f & 1], 0));
-            if (timed) MV_HIP(hipEventRecord(p->tv0[p->n_timed], p->s_vol));   // the GEMM alone: its operands were packed elsewhere
         }
+        if (timed) MV_HIP(hipEventRecord(p->tv0[p->n_timed], p->s_vol));   // the GEMM alone: behind the pack, wherever that ran
         MV_TRY(mv_corr_volume_packed(pk[0], pk[1], p->vol[k], B, c.C, p->n8, p->n8, c.volume_split, p->s_vol));
     } else if (c.volume_split == 2 || c.volume_split == 3) {
         const size_t nel = (size_t)B * p->n8 * c.C;

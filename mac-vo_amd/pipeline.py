@@ -514,7 +514,7 @@ class NativeHotPath:
         self._images: list = []
         self._cap = max(self.cfg.num_point, 1)
         self._volume_ahead = os.environ.get("MV_PIPE_VOLUME_AHEAD", "1") != "0"   # A/B knobs of run()
-        self._depth = max(1, min(3, int(os.environ.get("MV_PIPE_DEPTH", "3"))))
+        self._depth = max(1, min(int(os.environ.get("MV_PIPE_MAX_DEPTH", "3")), int(os.environ.get("MV_PIPE_DEPTH", "3"))))
         self.lm = ops.lm_default_params()
         self._pipe = None
         self._arena = None

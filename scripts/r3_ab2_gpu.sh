@@ -1,0 +1,20 @@
+#!/bin/bash
+# placement A/Bs in the GPU-bound regime (backend launch thread on)
+cd $GRAFT_REPO_ROOT
+L=gpurun_out/r3_ab2.log; : > $L
+run() {
+  echo "== $*" >> $L
+  env "$@" timeout 200 python bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-decoder-leg --exact-steps 0 --config4-steps 0 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print(d['value'],'fps',d['ms_per_step'],'ms | GEMM',r['avg_launch_us'],'alone',r.get('isolated_avg_launch_us'),'| timeline',d.get('timeline'))
+" >> $L 2>&1
+}
+run MV_X=0
+run MV_PIPE_PACK_ON=back
+run MV_PIPE_SELECTOR_ON=main
+run MV_PIPE_SELECTOR_ON=main MV_PIPE_PACK_ON=back
+run MV_PIPE_VOL_BUFS=2
+run MV_PIPE_MAIN_PRIO=hi
+run MV_LOOKUP_QPB=8
+cat $L
