@@ -142,7 +142,11 @@ struct SplitCfg {
     static constexpr int JB = 8 / NWV;                 // 32-column blocks of the sub-tile a wave owns (NWV = 8: one, 2 waves per SIMD)
     static constexpr int KH = KS / 2;                  // k-steps per K half
     static constexpr int NA = KS * NP;                 // A fragment units per wave and band
-    static constexpr int NA_ACC = NWV == 8 ? NA - 8 : NA;   // ... of which this many live in the accumulator register file
+    // ... of which this many live in the accumulator register file.  Three planes (192 registers) + 2 x 32 accumulators would fill
+    // all 256 AGPRs: hipcc then has no register for the copy it makes of an accumulator element on its way into an asm store and
+    // evicts part of an A unit for it — also during the flush, while that unit's load is still in flight (seen in the ISA: v_accvgpr_read
+    // of a72..a75 behind the loads, v_accvgpr_write a72 in front of every store).  The last two units therefore live in VGPRs.
+    static constexpr int NA_ACC = NWV == 8 ? NA - 8 : (NP == 3 ? NA - 2 : NA);
     static constexpr int HALF_UNITS = KH * NP;         // 1-KB units of one row block in one K half
     static constexpr int SLOT_BYTES = 2 * HALF_UNITS * 1024;   // 64 columns = 2 row blocks
     static constexpr int NSLOT = 3;
@@ -173,6 +177,20 @@ struct SplitCfg {
     static constexpr int W_STEADY = STORES_BEHIND_LAST_PIECE + D + SPH + EB;    // second half: the half before carried the EB loads
     static_assert(W_STEADY <= 63 && 2 * (D + SPH) + EB <= 63 && FLUSH + D + EB <= 63, "vmcnt is a 6-bit counter");
     static_assert(KS % 2 == 0 && (2 * HALF_UNITS) % NWV == 0 && HALF_UNITS % D == 0, "a wave's pieces lie inside one row block");
+    // EARLY START of a band segment (FIRSTK = 1: band change, the previous segment's FLUSH stores ride behind the A loads;
+    // FIRSTK = 2: kernel start, the A loads ride behind the first two halves of B pieces).  The first item does not wait for all NA
+    // fragment units: in front of k-step ks of its first half it waits for the units of k-steps 0 .. ks only — "at most as many
+    // operations outstanding as were issued BEHIND that unit" (in-order counter; never more than VM_MAX can be in flight, so a
+    // larger count needs no wait at all and is clamped) — and the rest lands while the first k-steps are multiplied.
+    static constexpr int VM_MAX = 60;                  // (the counter has 6 bits; a margin of 3)
+    static constexpr int EARN = F16 ? 4 : 0;           // row-exponent loads behind the A units
+    static constexpr int clampw(int x) { return x < VM_MAX ? x : VM_MAX; }
+    static constexpr int behind_unit(int firstk, int ks) { return NA - NP * (ks + 1) + EARN + (firstk == 1 ? FLUSH : 0); }
+    static constexpr int first_wait(int firstk, int ks) { return clampw(behind_unit(firstk, ks)); }
+    // barrier waits of the first item: half 0 needs its B pieces (issued before the A units: NA + EARN (+ FLUSH | + D: the other
+    // half's pieces) operations behind them), half 1 additionally every A unit and row exponent
+    static constexpr int WB0_CHANGE = clampw(NA + EARN + FLUSH), WB1_CHANGE = FLUSH + D + EB;
+    static constexpr int WB0_START = clampw(D + NA + EARN), WB1_START = D + EB;
 };
 
 #ifdef MV_SPLIT_PROBE
@@ -363,10 +381,34 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 
     //   slots 2 NP, 2 NP + 1  the two output stores of the previous item this k-step carries,
     //   slots 2 NP + 2, + 4   an LDS-DMA piece of half + 2 (the D pieces are spread over the whole half; the first ones go out
     //                         straight behind the barrier, in the shadow of the first fragment reads' LDS latency).
-    auto half = [&](auto HH, auto WW, auto PREV, f32x16& c0, f32x16& c1, const f32x16& p0, const f32x16& p1, int (&ec)[2], int (&ep)[2]) __attribute__((always_inline)) {
+    // the A units of k-step `ks` count as defined behind the wait that covers them (see issue_a)
+    auto mark_a = [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int i = ks * NP + p;
+            if (i < Cf::NA_ACC) asm volatile("" : "+a"(afr[i]));
+            else asm volatile("" : "+v"(afr[i]));
+        }
+    };
+    auto first_wait = [&](auto FK, int ks) __attribute__((always_inline)) {     // (ks is a constant after unrolling)
+        constexpr int F = decltype(FK)::value;
+        switch (ks) {
+            case 0: wait_vmcnt<Cf::first_wait(F, 0)>(); break;
+            case 1: wait_vmcnt<Cf::first_wait(F, 1)>(); break;
+            case 2: wait_vmcnt<Cf::first_wait(F, 2)>(); break;
+            case 3: wait_vmcnt<Cf::first_wait(F, 3)>(); break;
+            case 4: wait_vmcnt<Cf::first_wait(F, 4)>(); break;
+            case 5: wait_vmcnt<Cf::first_wait(F, 5)>(); break;
+            case 6: wait_vmcnt<Cf::first_wait(F, 6)>(); break;
+            default: wait_vmcnt<Cf::first_wait(F, 7)>(); break;
+        }
+    };
+    static_assert(KH == 8, "first_wait covers eight k-steps per half");
+    auto half = [&](auto HH, auto WW, auto PREV, auto FK, f32x16& c0, f32x16& c1, const f32x16& p0, const f32x16& p1, int (&ec)[2], int (&ep)[2]) __attribute__((always_inline)) {
         constexpr int H = decltype(HH)::value;
         constexpr int W = decltype(WW)::value;
         constexpr bool HAVE_PREV = decltype(PREV)::value;
+        constexpr int FIRSTK = decltype(FK)::value;
         STAMP(H * 3 + 0);
         if (!DBG(4)) wait_vmcnt_barrier<(W > 2 ? W - (MV_SPLIT_PROBE_SLACK) : W)>();    // behind the barrier all four waves' pieces are in, and everyone has left slot - 1
         STAMP(H * 3 + 1);
@@ -395,6 +437,11 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 
         for (int ks = 0; ks < KH; ++ks) {
             const int cur = ks & 1, nxt = cur ^ 1;
             const int npk = Cf::pieces_in(ks), pk0 = Cf::first_piece(ks);     // (compile-time after unrolling)
+            if (FIRSTK != 0) {                   // first item of a band segment: the A units arrive while it runs
+                if (H == 0) first_wait(FK, ks);  // ... half 0: unit by unit; half 1: all of them are in behind its barrier
+                mark_a(H * KH + ks);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int sl = 0; sl < Cf::NM; ++sl) {
                 const int qd = sl / JB, jb = sl % JB;
@@ -435,9 +482,9 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 
     using No = std::false_type;
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
-    auto item = [&](auto W0, auto W1, auto PREV, f32x16& c0, f32x16& c1, const f32x16& p0, const f32x16& p1, int (&ec)[2], int (&ep)[2]) __attribute__((always_inline)) {
-        half(H0{}, W0, PREV, c0, c1, p0, p1, ec, ep);
-        half(H1{}, W1, PREV, c0, c1, p0, p1, ec, ep);
+    auto item = [&](auto W0, auto W1, auto PREV, auto FK, f32x16& c0, f32x16& c1, const f32x16& p0, const f32x16& p1, int (&ec)[2], int (&ep)[2]) __attribute__((always_inline)) {
+        half(H0{}, W0, PREV, FK, c0, c1, p0, p1, ec, ep);
+        half(H1{}, W1, PREV, FK, c0, c1, p0, p1, ec, ep);
         ++cur_c;
 #ifdef MV_SPLIT_PROBE
         if (DBG(16) && lane == 0 && n_stamped < 64) {
@@ -461,8 +508,13 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 
     static_assert(KS == 16, "store interleave: one accumulator row per k-step and column block");
     // waits: see the derivation in SplitCfg / DESIGN.md.  first item of a segment: everything older than the 32 flush stores has
     // landed (hand wait below), no stores ride along; second item: D pieces (+ SPH stores) behind the pieces it consumes; then steady.
-    using WF0 = std::integral_constant<int, Cf::FLUSH>;
-    using WF1 = std::integral_constant<int, Cf::FLUSH + D + Cf::EB>;
+    using WF0 = std::integral_constant<int, Cf::WB0_CHANGE>;      // first item behind a band change
+    using WF1 = std::integral_constant<int, Cf::WB1_CHANGE>;
+    using WP0 = std::integral_constant<int, Cf::WB0_START>;       // first item of the kernel
+    using WP1 = std::integral_constant<int, Cf::WB1_START>;
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
     using WS0 = std::integral_constant<int, D>;
     using WS1 = std::integral_constant<int, D + Cf::SPH + Cf::EB>;
     using WW0 = std::integral_constant<int, Cf::W_STEADY0>;
@@ -472,40 +524,43 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 
     int ex[2] = {0, 0}, ey[2] = {0, 0};           // F16: column exponents of the items accumulating in (x0, x1) / (y0, y1)
     int b, g, band, c0i;
     decode(it, b, g, band, c0i);
-    issue_a(b, band);
     issue_half();                                // halves 0 and 1 of the first item -> slots 0, 1
     issue_half();
-    wait_vmcnt<0>();
-    while (true) {                               // one pass per (pair, region, band) segment of the run
-        const int seg_end = min(it_end, it + (reg_c0(g + 1) - c0i));
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {          // the fragments count as defined only here, behind the hand-placed wait
-            if (i < Cf::NA_ACC) asm volatile("" : "+a"(afr[i]));
-            else asm volatile("" : "+v"(afr[i]));
-        }
-        if (F16) {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) asm volatile("" : "+v"(ear[gq]));
-#pragma unroll
-            for (int r = 0; r < 16; ++r) nea[r] = -ear[r >> 2][r & 3];
-        }
+    issue_a(b, band);                            // behind them: the first item starts on the units of its first k-steps (EARLY START)
+    // Rotated loop: a segment's FIRST item sits at the bottom of the previous pass (two instantiations — kernel start / band
+    // change — without a branch that would merge the loader's scalar state through phis hipcc then keeps in VGPRs).
+    int seg_end;
+    auto seg_setup = [&]() __attribute__((always_inline)) {
+        seg_end = min(it_end, it + (reg_c0(g + 1) - c0i));
         O = out + (size_t)b * N1 * N2 + (size_t)c0i * 64 + jb0 * 32;
         cur_b = b;
         cur_c = c0i;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             roff[r] = ((unsigned)min(band * 128 + wr * 32 + 4 * kh + (r & 3) + 8 * (r >> 2), N1 - 1) * (unsigned)N2 + li) * 4u;
-        item(WF0{}, WF1{}, No{}, x0, x1, x0, x1, ex, ex);
+    };
+    auto row_exponents = [&]() __attribute__((always_inline)) {   // landed with the last A units (second barrier wait of the first item)
+        if (F16) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) asm volatile("" : "+v"(ear[gq]));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nea[r] = -ear[r >> 2][r & 3];
+        }
+    };
+    seg_setup();
+    item(WP0{}, WP1{}, No{}, K2{}, x0, x1, x0, x1, ex, ex);
+    row_exponents();
+    while (true) {                               // one pass per (pair, region, band) segment of the run, entered behind its first item
         bool in_y = false;
         if (it < seg_end) {
-            item(WS0{}, WS1{}, Yes{}, y0, y1, x0, x1, ey, ex);
+            item(WS0{}, WS1{}, Yes{}, K0{}, y0, y1, x0, x1, ey, ex);
             in_y = true;
             while (it + 2 <= seg_end) {
-                item(WW0{}, WW{}, Yes{}, x0, x1, y0, y1, ex, ey);
-                item(WW0{}, WW{}, Yes{}, y0, y1, x0, x1, ey, ex);
+                item(WW0{}, WW{}, Yes{}, K0{}, x0, x1, y0, y1, ex, ey);
+                item(WW0{}, WW{}, Yes{}, K0{}, y0, y1, x0, x1, ey, ex);
             }
             if (it < seg_end) {
-                item(WW0{}, WW{}, Yes{}, x0, x1, y0, y1, ex, ey);
+                item(WW0{}, WW{}, Yes{}, K0{}, x0, x1, y0, y1, ex, ey);
                 in_y = false;
             }
         }
@@ -527,7 +582,9 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 
         if (in_y) flush(y0, y1, ey);
         else flush(x0, x1, ex);
         if (!more) break;
-        wait_vmcnt<Cf::FLUSH>();                 // the A (+ row exponent) loads precede the flush stores
+        seg_setup();                             // the next segment's first item waits for its A units k-step by k-step
+        item(WF0{}, WF1{}, No{}, K1{}, x0, x1, x0, x1, ex, ex);
+        row_exponents();
     }
     wait_vmcnt<0>();                             // nothing of this workgroup may still be in flight towards its LDS when it retires
 }
