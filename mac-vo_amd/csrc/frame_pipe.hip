@@ -521,7 +521,7 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
         const char* e = getenv("MV_PIPE_PACK_ON");
         // Measured (640x480, one lane, frames/s): in front of the GEMM on its own stream 4.28 k, backend stream 4.09 k, decoder-side
         // stream 3.11 k: beside a one-wave-per-SIMD GEMM every co-running kernel costs the GEMM more than the 8 us the pack takes.
-        p->pack_on = (e && strcmp(e, "back") == 0) ? 1 : (e && strcmp(e, "main") == 0) ? 2 : 0;
+        p->pack_on = (e && strcmp(e, "back") == 0) ? 1 : (e && strcmp(e, "main") == 0) ? 2 : (e && strcmp(e, "side") == 0) ? 3 : 0;
     }
     p->arena = (char*)arena;
     p->arena_bytes = arena_bytes;
@@ -576,7 +576,7 @@ static int issue_volume(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_s
     if (timed && !p->packed) MV_HIP(hipEventRecord(p->tv0[p->n_timed], p->s_vol));
     if (p->packed) {
         void** pk = p->pk[f & 1];
-        hipStream_t sp = p->pack_on == 0 ? p->s_vol : p->pack_on == 1 ? p->s_back : p->s_main;
+        hipStream_t sp = p->pack_on == 0 ? p->s_vol : p->pack_on == 1 ? p->s_back : p->pack_on == 2 ? p->s_main : p->s_side;
         if (sp != p->s_vol) {
             MV_TRY(wait_if_pending(sp, e_in));
             // this operand set was last read by the GEMM of frame f - 2 (same stream order as the volume buffers' events)

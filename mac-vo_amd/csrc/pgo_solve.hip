@@ -47,6 +47,7 @@ struct PgoArgs {
     double* out_pose;
     double* out_info;
     float* out_pose_f32;
+    int spec;   // speculative reject rounds: 1 on, 0 off (MV_PGO_SPEC), 2 = on + round / trial counts into out_info[3] (debugging)
 };
 
 struct Pose {
@@ -429,12 +430,98 @@ __device__ __forceinline__ void accumulate_point(const Geometry& g, const mvLMPa
     }
 }
 
+// solve A D = b, b = -gw, by Cholesky (A = L L^T) with the diagonal of A taken from `dg6` (the damped one); every thread solves
+// redundantly (uniform control flow).  The two substitutions multiply by the reciprocal pivots the factorisation already has: an
+// fp64 division is a ~12 instruction dependent chain, and with up to 17 solves in a rejected step this serial piece was 3.5 k
+// cycles each.  Returns false where PyPose reports "Linear solver failed".
+__device__ __forceinline__ bool chol_solve6(const double* __restrict__ Aw, const double (&dg6)[6], const double* __restrict__ gw,
+                                            double (&D)[6]) {
+    double L[6][6], linv[6];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double dd = dg6[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) dd -= L[j][k] * L[j][k];
+        ok = ok && (dd > 0.0) && (dd < INFINITY);
+        const double ljj = sqrt(dd);
+        const double inv = 1.0 / ljj;
+        L[j][j] = ljj;
+        linv[j] = inv;
+#pragma unroll
+        for (int i2 = j + 1; i2 < 6; ++i2) {
+            double sacc = Aw[tri(j, i2)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) sacc -= L[i2][k] * L[j][k];
+            L[i2][j] = sacc * inv;
+        }
+    }
+    if (!ok) return false;
+    double yv[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double sacc = -gw[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) sacc -= L[j][k] * yv[k];
+        yv[j] = sacc * linv[j];
+    }
+#pragma unroll
+    for (int j = 5; j >= 0; --j) {
+        double sacc = yv[j];
+#pragma unroll
+        for (int k = j + 1; k < 6; ++k) sacc -= L[k][j] * D[k];
+        D[j] = sacc * linv[j];
+    }
+    return true;
+}
+
+// TrustRegion.update: quality = (last - loss) / -((J D)^T (2 R + J D)) on the corrected, unweighted J, R
+__device__ __forceinline__ double tr_quality(const double (&D)[6], const double* __restrict__ gu, const double* __restrict__ Au,
+                                             double last, double loss) {
+    double dAd = 0.0, dg = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        dg += D[j] * gu[j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dAd += D[j] * D[k] * Au[(j <= k) ? tri(j, k) : tri(k, j)];
+    }
+    return (last - loss) / -(2.0 * dg + dAd);
+}
+
+// ... and the radius / damping update it drives; returns the branch taken (1: quality > high, 2: > low, 3: shrink)
+__device__ __forceinline__ void tr_apply(const mvLMParams& lm, int branch, double& damping, double& tr_down) {
+    double radius = 1.0 / damping;
+    if (branch == 1) {
+        radius = lm.tr_up * radius;
+        tr_down = lm.tr_down;
+    } else if (branch == 2) {
+        tr_down = lm.tr_down;
+    } else {
+        radius = radius * tr_down;
+        tr_down = tr_down * lm.tr_factor;
+    }
+    tr_down = fmax(lm.tr_min, fmin(tr_down, lm.tr_max));
+    radius = fmax(lm.tr_min, fmin(radius, lm.tr_max));
+    damping = 1.0 / radius;
+}
+__device__ __forceinline__ int tr_update(const mvLMParams& lm, double quality, double& damping, double& tr_down) {
+    const int branch = (quality > lm.tr_high) ? 1 : (quality > lm.tr_low) ? 2 : 3;
+    tr_apply(lm, branch, damping, tr_down);
+    return branch;
+}
+
 template <int GT, int NW>
 __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParams lm) {
     constexpr int PGO_THREADS = 64 * NW;
     __shared__ double red_tab[NW][NRED];
     __shared__ __attribute__((aligned(16))) double red_part[NW == 4 ? NRED * NW * 8 : 1];
     __shared__ __attribute__((aligned(16))) double red_fin[NW == 4 ? NRED + 1 : 1];
+    // speculative reject rounds (NW == 4, one point per thread): every point's position / observation for the trial-loss passes, and
+    // what each wave found for its trial
+    constexpr int SPEC = (NW == 4) ? 1 : 0;
+    __shared__ double pt_tab[SPEC ? 6 : 1][SPEC ? 64 * NW : 1];
+    __shared__ int pt_valid[SPEC ? 64 * NW : 1];
+    __shared__ double spec_res[SPEC ? NW : 1][10];   // per wave: ok, loss, quality, pose t[3] q[4]
     const int prob = blockIdx.x;
     const int tid = threadIdx.x;
     const int beg = a.offsets[prob], end = a.offsets[prob + 1];
@@ -456,12 +543,19 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
     PointData<GT> mine;
     mine.valid = false;
     if (cached) load_point<GT>(a, g, lm, beg + tid, tid < npts, mine);
+    if (SPEC && cached) {   // (read behind the barriers of the observation count below)
+        pt_valid[tid] = mine.valid ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { pt_tab[k][tid] = mine.valid ? mine.pw[k] : 0.0; pt_tab[3 + k][tid] = mine.valid ? mine.obs[k] : 0.0; }
+    }
 
     double damping = 1.0 / lm.radius, tr_down = lm.tr_down;
     double loss = 0.0, last = 0.0, loss0 = 0.0;
     bool have_loss = false;
     int steps = 0, patience_count = 0, reject_count = 0;
     bool continual = true;
+    int dbg_rounds = 0, dbg_trials = 0;
+    int pred_branch = 3;   // trust-region branch the last rejected trial took: the prediction for the following ones
 
     // Odometry/MACVO.py:303-307: fewer than min_num_point observations => no optimisation, pose stays at the prior
     {
@@ -505,101 +599,130 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
         for (int j = 0; j < 6; ++j) Aw[tri(j, j)] = fmin(fmax(Aw[tri(j, j)], lm.diag_min), lm.diag_max);
 
         // ------------------------------------------------------------------ inner damping / reject loop
+        // Round 3: once a step's first trial has been rejected, the following trials are evaluated FOUR AT A TIME, one per wave.
+        // A rejected trial leaves the pose where it was, multiplies the damping into A's diagonal once more and updates the trust
+        // region through one of the three branches of TrustRegion.update — in practice the SAME branch trial after trial (at the
+        // end of a solve the unweighted model the quality is measured against predicts an increase: quality > tr_high although
+        // the loss went up) — so the inputs of the next trials are known before the previous ones have been evaluated, PROVIDED
+        // those are rejected through the predicted branch (= the branch of the last rejected trial).  Wave w replays that scalar
+        // recurrence w times, solves its own system, moves its own copy of the pose and sums the trial loss over ALL points (four
+        // 64-point passes over the LDS point table, each reduced with the same DPP tree and added in the same order as the block
+        // reduction of the sequential form: identical bits).  Then every thread walks the four results in order with the sequential
+        // form's own update code and stops at the first trial that is accepted, fails to factorise, or was rejected through another
+        // branch (the later results of the round are then discarded, the prediction becomes that branch and the next round starts
+        // from the true state).  A step that exhausts its 16 rejections costs 1 + 4 rounds instead of 17 sequential trials.
         while (last <= loss) {
+            dbg_trials += 1;
+            const bool spec_round = SPEC && cached && reject_count >= 1 && a.spec != 0;
+            if (spec_round) dbg_rounds += 1;
+            if (!spec_round) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) Aw[tri(j, j)] += Aw[tri(j, j)] * damping;
-            // solve A D = b, b = -gw, by Cholesky (A = L L^T); every thread solves redundantly (uniform control flow)
-            // (the two substitutions multiply by the reciprocal pivots the factorisation already has: an fp64 division is a ~12
-            // instruction dependent chain, and with up to 17 solves in a rejected step this serial piece was 3.5 k cycles each)
-            double L[6][6], D[6], linv[6];
-            bool ok = true;
+                for (int j = 0; j < 6; ++j) Aw[tri(j, j)] += Aw[tri(j, j)] * damping;
+                double dg6[6], D[6];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                double dd = Aw[tri(j, j)];
-#pragma unroll
-                for (int k = 0; k < j; ++k) dd -= L[j][k] * L[j][k];
-                ok = ok && (dd > 0.0) && (dd < INFINITY);
-                const double ljj = sqrt(dd);
-                const double inv = 1.0 / ljj;
-                L[j][j] = ljj;
-                linv[j] = inv;
-#pragma unroll
-                for (int i2 = j + 1; i2 < 6; ++i2) {
-                    double sacc = Aw[tri(j, i2)];
-#pragma unroll
-                    for (int k = 0; k < j; ++k) sacc -= L[i2][k] * L[j][k];
-                    L[i2][j] = sacc * inv;
-                }
-            }
-            if (!ok) break;  // "Linear solver failed. Breaking optimization step..."
-            double yv[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                double sacc = -gw[j];
-#pragma unroll
-                for (int k = 0; k < j; ++k) sacc -= L[j][k] * yv[k];
-                yv[j] = sacc * linv[j];
-            }
-#pragma unroll
-            for (int j = 5; j >= 0; --j) {
-                double sacc = yv[j];
-#pragma unroll
-                for (int k = j + 1; k < 6; ++k) sacc -= L[k][j] * D[k];
-                D[j] = sacc * linv[j];
-            }
+                for (int j = 0; j < 6; ++j) dg6[j] = Aw[tri(j, j)];
+                if (!chol_solve6(Aw, dg6, gw, D)) break;  // "Linear solver failed. Breaking optimization step..."
 
-            const Pose P_prev = P;
-            se3_left_update(P, D);
+                const Pose P_prev = P;
+                se3_left_update(P, D);
 
-            // loss at the trial pose (RobustModel.loss: unweighted, uncorrected)
-            double la[1] = {0.0};
-            if (cached) {
-                if (mine.valid) {
-                    double r[3] = {0, 0, 0}, pc[3];
-                    la[0] = huber(residual<GT>(g, P, mine, r, pc), lm.huber_delta);
-                }
-            } else {
-                for (int i = beg + tid; i < end; i += PGO_THREADS) {
-                    PointData<GT> d;
-                    load_point<GT>(a, g, lm, i, true, d);
-                    if (d.valid) {
+                // loss at the trial pose (RobustModel.loss: unweighted, uncorrected)
+                double la[1] = {0.0};
+                if (cached) {
+                    if (mine.valid) {
                         double r[3] = {0, 0, 0}, pc[3];
-                        la[0] += huber(residual<GT>(g, P, d, r, pc), lm.huber_delta);
+                        la[0] = huber(residual<GT>(g, P, mine, r, pc), lm.huber_delta);
+                    }
+                } else {
+                    for (int i = beg + tid; i < end; i += PGO_THREADS) {
+                        PointData<GT> d;
+                        load_point<GT>(a, g, lm, i, true, d);
+                        if (d.valid) {
+                            double r[3] = {0, 0, 0}, pc[3];
+                            la[0] += huber(residual<GT>(g, P, d, r, pc), lm.huber_delta);
+                        }
                     }
                 }
-            }
-            block_sum<1, NW>(la, red_tab);
-            loss = la[0];
+                block_sum<1, NW>(la, red_tab);
+                loss = la[0];
 
-            // TrustRegion.update: quality = (last - loss) / -((J D)^T (2 R + J D)) on the corrected, unweighted J, R
-            double dAd = 0.0, dg = 0.0;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                dg += D[j] * gu[j];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) dAd += D[j] * D[k] * Au[(j <= k) ? tri(j, k) : tri(k, j)];
-            }
-            const double quality = (last - loss) / -(2.0 * dg + dAd);
-            double radius = 1.0 / damping;
-            if (quality > lm.tr_high) {
-                radius = lm.tr_up * radius;
-                tr_down = lm.tr_down;
-            } else if (quality > lm.tr_low) {
-                tr_down = lm.tr_down;
-            } else {
-                radius = radius * tr_down;
-                tr_down = tr_down * lm.tr_factor;
-            }
-            tr_down = fmax(lm.tr_min, fmin(tr_down, lm.tr_max));
-            radius = fmax(lm.tr_min, fmin(radius, lm.tr_max));
-            damping = 1.0 / radius;
+                const double quality = tr_quality(D, gu, Au, last, loss);
+                pred_branch = tr_update(lm, quality, damping, tr_down);
 
-            if (last < loss && reject_count < lm.reject) {  // reject step
-                P = P_prev;
-                loss = last;
-                reject_count += 1;
+                if (last < loss && reject_count < lm.reject) {  // reject step
+                    P = P_prev;
+                    loss = last;
+                    reject_count += 1;
+                } else {
+                    break;
+                }
             } else {
-                break;
+                const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+                // ---- this wave's trial: the (wv + 1)-th from here, assuming the wv before it are rejected through the predicted branch
+                double dg6[6], damp_s = damping, trd_s = tr_down;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) dg6[j] = Aw[tri(j, j)];
+                for (int i = 0; i <= wv; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) dg6[j] += dg6[j] * damp_s;
+                    if (i < wv) tr_apply(lm, pred_branch, damp_s, trd_s);
+                }
+                double D[6];
+                const bool ok = chol_solve6(Aw, dg6, gw, D);
+                Pose Pw = P;
+                double loss_w = 0.0, quality_w = 0.0;
+                if (ok) {
+                    se3_left_update(Pw, D);
+                    double part[NW];
+#pragma unroll
+                    for (int c = 0; c < NW; ++c) {
+                        const int i = c * 64 + lane;
+                        double v = 0.0;
+                        if (pt_valid[i]) {
+                            PointData<GT> d;
+                            d.valid = true;
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) { d.pw[k] = pt_tab[k][i]; d.obs[k] = pt_tab[3 + k][i]; }
+                            double r[3] = {0, 0, 0}, pc[3];
+                            v = huber(residual<GT>(g, Pw, d, r, pc), lm.huber_delta);
+                        }
+                        part[c] = wave_sum_dpp(v);
+                    }
+                    loss_w = part[0];
+#pragma unroll
+                    for (int c = 1; c < NW; ++c) loss_w += part[c];
+                    quality_w = tr_quality(D, gu, Au, last, loss_w);
+                }
+                if (lane == 0) {
+                    double* o = spec_res[wv];
+                    o[0] = ok ? 1.0 : 0.0; o[1] = loss_w; o[2] = quality_w;
+                    o[3] = Pw.t[0]; o[4] = Pw.t[1]; o[5] = Pw.t[2];
+                    o[6] = Pw.q[0]; o[7] = Pw.q[1]; o[8] = Pw.q[2]; o[9] = Pw.q[3];
+                }
+                __syncthreads();
+                // ---- the sequential form's bookkeeping over the four results
+                bool leave = false;
+                for (int i = 0; i < NW; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) Aw[tri(j, j)] += Aw[tri(j, j)] * damping;
+                    const double* o = spec_res[i];
+                    if (o[0] == 0.0) { leave = true; break; }       // "Linear solver failed"
+                    loss = o[1];
+                    const int branch = tr_update(lm, o[2], damping, tr_down);
+                    if (last < loss && reject_count < lm.reject) {   // reject step
+                        loss = last;
+                        reject_count += 1;
+                        if (branch != pred_branch) { pred_branch = branch; break; }   // the later trials of this round started from other inputs
+                    } else {
+                        P.t[0] = o[3]; P.t[1] = o[4]; P.t[2] = o[5];
+                        P.q[0] = o[6]; P.q[1] = o[7]; P.q[2] = o[8]; P.q[3] = o[9];
+                        quat_to_R(P);
+                        leave = true;
+                        break;
+                    }
+                }
+                __syncthreads();   // spec_res is rewritten by the next round
+                if (leave) break;
             }
         }
 
@@ -617,6 +740,7 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
         o[3] = P.q[0]; o[4] = P.q[1]; o[5] = P.q[2]; o[6] = P.q[3];
         double* inf = a.out_info + 4 * (size_t)prob;
         inf[0] = loss; inf[1] = (double)steps; inf[2] = (double)reject_count; inf[3] = loss0;
+        if (a.spec == 2) inf[3] = (double)(dbg_rounds * 1000 + dbg_trials);
         if (a.out_pose_f32) {
             float* of = a.out_pose_f32 + 7 * (size_t)prob;  // write_graph_data: pose = motion.float()
             of[0] = (float)P.t[0]; of[1] = (float)P.t[1]; of[2] = (float)P.t[2];
@@ -650,7 +774,12 @@ extern "C" int mv_pgo_solve(int nprob, const int32_t* offsets, int graph_type, c
     MV_CHECK_ARG(offsets && init_pose && intrinsics && baseline && pos_Tw && pixel2_uv && out_pose && out_info);
     MV_CHECK_ARG(params->max_steps >= 1 && params->reject >= 0 && params->stop_on_reject >= 0 && params->radius > 0 && params->huber_delta > 0);
     PgoArgs a{offsets, init_pose, intrinsics, baseline, pos_Tw, cov_Tw, pixel2_uv, pixel2_d, pixel2_disp,
-              pixel2_disp_cov, pixel2_uv_cov, obs2_covTc, valid, min_points, out_pose, out_info, out_pose_f32};
+              pixel2_disp_cov, pixel2_uv_cov, obs2_covTc, valid, min_points, out_pose, out_info, out_pose_f32, 1};
+    {
+        static int spec = -1;   // MV_PGO_SPEC=0: every trial of the reject loop sequentially (A/B knob)
+        if (spec < 0) { const char* e = getenv("MV_PGO_SPEC"); spec = e ? atoi(e) : 1; }
+        a.spec = spec;
+    }
     hipStream_t s = (hipStream_t)stream;
     // latency variant (4 waves per problem, one point per thread in registers) for small batches; throughput variant
     // (1 wave per problem, 4x more problems resident per CU) once the batch alone fills the chip
