@@ -444,8 +444,15 @@ __device__ __forceinline__ bool chol_solve6(const double* __restrict__ Aw, const
 #pragma unroll
         for (int k = 0; k < j; ++k) dd -= L[j][k] * L[j][k];
         ok = ok && (dd > 0.0) && (dd < INFINITY);
+#ifdef MV_PGO_SQRT_DIV
         const double ljj = sqrt(dd);
         const double inv = 1.0 / ljj;
+#else
+        // one reciprocal square root per pivot instead of a square root AND a division (each a ~15-instruction dependent fp64
+        // sequence on the critical path of every trial); l_jj = dd / sqrt(dd) to ~1 ulp
+        const double inv = rsqrt(dd);
+        const double ljj = dd * inv;
+#endif
         L[j][j] = ljj;
         linv[j] = inv;
 #pragma unroll
