@@ -97,6 +97,10 @@ int mv_split_bf16x3(const float* x, void* planes, size_t n, mvStream_t stream);
 size_t mv_volume_pack_bytes(int B, int C, int N, int mode);
 int mv_volume_pack(const float* f1, const float* f2, void* packed1, void* packed2, int B, int C, int N1, int N2, int layout,
                    int mode, mvStream_t stream);
+/* mv_volume_pack with operand 2 (an H2 x W2 map, both multiples of 4) in 4 x 4-tile order: the GEMM's output columns then are that
+ * order (see mv_corr_lookup_tiled); operand 1 and everything else as mv_volume_pack with N2 = H2 * W2 */
+int mv_volume_pack_tiled(const float* f1, const float* f2, void* packed1, void* packed2, int B, int C, int N1, int H2, int W2,
+                         int layout, int mode, mvStream_t stream);
 int mv_corr_volume_packed_supported(int B, int C, int N1, int N2, int mode);
 int mv_corr_volume_packed(const void* packed1, const void* packed2, float* out, int B, int C, int N1, int N2, int mode,
                           mvStream_t stream);
@@ -116,6 +120,14 @@ const char* mv_corr_volume_last_kernel(void);
  */
 int mv_corr_lookup(const float* vol, const float* coords, float* out, int B, int H1, int W1,
                    int H2, int W2, int radius, mvStream_t stream);
+
+/* The same lookup (same reference code, Module/Network/FlowFormerCov/covhead.py:92) on a volume whose per-query slices are stored in
+ * 4 x 4-cell tiles: vol[(b N1 + q) H2 W2 + ((y / 4) * (W2 / 4) + x / 4) * 16 + (y % 4) * 4 + x % 4] — what mv_corr_volume_packed writes
+ * when operand 2 was packed by mv_volume_pack_tiled.  Used inside the frame driver for >= 3 lanes, where it owns both the producer and
+ * the consumer of the volume (the drop-in hook keeps the reference's [B*N1, 1, H2, W2]).  radius == 4, H2 % 4 == W2 % 4 == 0
+ * (MV_ERR_UNSUPPORTED otherwise).  Results are bit-identical to mv_corr_lookup on the row-major volume. */
+int mv_corr_lookup_tiled(const float* vol, const float* coords, float* out, int B, int H1, int W1,
+                         int H2, int W2, int radius, mvStream_t stream);
 
 /* -------------------------------------------------------------------------------------------
  * A8/A2  frontend epilogue: network output -> the typed records of IStereoDepth.Output / IMatcher.Output.

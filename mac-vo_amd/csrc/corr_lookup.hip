@@ -196,6 +196,140 @@ __global__ __launch_bounds__(64 * (QPB / QPW)) void corr_lookup_kernel(const flo
     }
 }
 
+
+// ---- the same lookup in a TILED volume (round 3): query q's slice is stored as 4 x 4-cell tiles,
+//      vol[(b N1 + q) H2 W2 + (ty * W2/4 + tx) * 16 + (y % 4) * 4 + x % 4]   — what mv_corr_volume_packed writes when operand 2 was packed by
+// mv_volume_pack_tiled (the GEMM itself is unchanged: only the order of its columns is).  A tile is one aligned 64-byte line, so the
+// 10 x 10 (12 x 12 with margins) cell block of a query costs (10 + 3) / 4 = 3.25 tiles per axis = ~10.6 lines = 676 B instead of
+// 10 row segments x 2.1 sectors of 32 B = 680 B in 21 separately addressed pieces: the same bytes in half as many, aligned, fully
+// used DRAM bursts.  Staging: a wave-wide load = one tile row of the 4 x 4 tile grid that covers the block (lane = tile column x 16
+// cells); tiles outside the needed cell range or the image are skipped / zero.  The staged block is 16 x 16 cells anchored at the
+// first tile; axis math, tap phase and the transposed store are those of corr_lookup_kernel (r = 4 only), results bit-identical.
+template <int QPW, int QPB>
+__global__ __launch_bounds__(64 * (QPB / QPW)) void corr_lookup_tiled_kernel(const float* __restrict__ vol,
+                                                                              const float* __restrict__ coords,
+                                                                              float* __restrict__ out, int N1, int H2, int W2) {
+    constexpr int R = 4, K = 9, KK = 81;
+    constexpr int BS = 16, CELLS = 256;        // staged block: 4 x 4 tiles of 4 x 4 cells
+    constexpr int NWAVE = QPB / QPW, NTHR = 64 * NWAVE;
+    constexpr int TAP_ROUNDS = (KK + 63) / 64;
+    constexpr int QPA = 64 / (2 * K);
+    constexpr int APASS = (QPW + QPA - 1) / QPA;
+    constexpr int BLK_STRIDE = QPW * CELLS;
+    constexpr int BLK_FLOATS = NWAVE * BLK_STRIDE;
+    constexpr int OUT_FLOATS = KK * (QPB + 1);
+    __shared__ float smem[BLK_FLOATS > OUT_FLOATS ? BLK_FLOATS : OUT_FLOATS];
+    float* blk = smem + (threadIdx.x >> 6) * BLK_STRIDE;
+    float (*outs)[QPB + 1] = reinterpret_cast<float (*)[QPB + 1]>(smem);
+
+    MV_SMALL_KERNEL_PRIO();
+    const int b = blockIdx.y;
+    const int q0 = blockIdx.x * QPB;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int slice = H2 * W2, tpr = W2 >> 2, tpc = H2 >> 2;
+
+    const int qmine = q0 + wave * QPW + (lane & (QPW - 1));
+    float x = 0.f, y = 0.f;
+    if (qmine < N1) {
+        x = coords[((size_t)b * 2 + 0) * N1 + qmine];
+        y = coords[((size_t)b * 2 + 1) * N1 + qmine];
+    }
+    const float xc = fminf(fmaxf(x, -1.0e6f), 1.0e6f), yc = fminf(fmaxf(y, -1.0e6f), 1.0e6f);
+    const int bx = ((xc == xc) ? (int)floorf(xc) : 0) - R - 1;      // origin of the 12 x 12 cell block of corr_lookup_kernel
+    const int by = ((yc == yc) ? (int)floorf(yc) : 0) - R - 1;
+    const float frx = xc - floorf(xc), fry = yc - floorf(yc);
+    const int x_lo = bx + ((frx < 0.01f) ? 0 : 1), x_hi = bx + ((frx > 0.99f) ? K + 2 : K + 1);   // cells a tap can touch (see TRIM above)
+    const int y_lo = by + ((fry < 0.01f) ? 0 : 1), y_hi = by + ((fry > 0.99f) ? K + 2 : K + 1);
+    const int tox = bx >> 2, toy = by >> 2;                          // first tile (floor division: arithmetic shift)
+
+    // ---- stage: per query four wave-wide loads (tile rows), lane = (tile column, cell)
+    const int ti = lane >> 4, cell = lane & 15;
+    float v[QPW][4];
+#pragma unroll
+    for (int s = 0; s < QPW; ++s) {
+        const int stx = __builtin_amdgcn_readlane(tox, s), sty = __builtin_amdgcn_readlane(toy, s);
+        const int sxl = __builtin_amdgcn_readlane(x_lo, s), sxh = __builtin_amdgcn_readlane(x_hi, s);
+        const int syl = __builtin_amdgcn_readlane(y_lo, s), syh = __builtin_amdgcn_readlane(y_hi, s);
+        const int q = q0 + wave * QPW + s;
+        const float* __restrict__ base = vol + ((size_t)b * N1 + q) * slice;
+        const int tx = stx + ti;
+        const bool okx = q < N1 && tx >= 0 && tx < tpr && 4 * tx + 3 >= sxl && 4 * tx <= sxh;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ty = sty + k;
+            const bool ok = okx && ty >= 0 && ty < tpc && 4 * ty + 3 >= syl && 4 * ty <= syh;
+            v[s][k] = ok ? base[((ty * tpr + tx) << 4) + cell] : 0.f;
+        }
+    }
+
+    // ---- per-axis coordinate math (as corr_lookup_kernel; cell offsets relative to the first tile)
+    const float wm1 = (float)(W2 - 1), hm1 = (float)(H2 - 1);
+    const int asq = lane / (2 * K), aa = lane - asq * (2 * K);
+    const bool a_is_y = aa >= K;
+    const int aoff = (a_is_y ? aa - K : aa) - R;
+    const float adim = a_is_y ? hm1 : wm1;
+    float ax_w[APASS];
+    int ax_c[APASS];
+#pragma unroll
+    for (int ps = 0; ps < APASS; ++ps) {
+        const int s = ps * QPA + asq;
+        const float qx = __shfl(x, s, 64), qy = __shfl(y, s, 64);
+        const int obx = __shfl(tox, s, 64) * 4, oby = __shfl(toy, s, 64) * 4;
+        const float cs = (a_is_y ? qy : qx) + (float)aoff;
+        const float g = (2.f * cs) / adim - 1.f;
+        const float ic = (g + 1.f) * (adim / 2.f);
+        const float f0 = floorf(ic);
+        ax_w[ps] = ic - f0;
+        const int c = (int)fminf(fmaxf(f0, -2.0e6f), 2.0e6f) - (a_is_y ? oby : obx);
+        const bool inb = c >= 0 && c <= BS - 2;
+        ax_c[ps] = min(max(c, 0), BS - 2) | (inb ? 256 : 0);
+    }
+
+#pragma unroll
+    for (int s = 0; s < QPW; ++s)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) blk[s * CELLS + (4 * k + (cell >> 2)) * BS + 4 * ti + (cell & 3)] = v[s][k];
+    __syncthreads();
+
+    float res[TAP_ROUNDS][QPW];
+#pragma unroll
+    for (int tr = 0; tr < TAP_ROUNDS; ++tr) {
+        const int tap = tr * 64 + lane;
+        const int tpi = tap / K, tpj = tap - tpi * K;
+#pragma unroll
+        for (int s = 0; s < QPW; ++s) {
+            const int ps = s / QPA, sq = s - ps * QPA;
+            const int srcx = sq * 2 * K + tpi, srcy = sq * 2 * K + K + tpj;
+            const float w = __shfl(ax_w[ps], srcx, 64), n = __shfl(ax_w[ps], srcy, 64);
+            const int pcx = __shfl(ax_c[ps], srcx, 64), pcy = __shfl(ax_c[ps], srcy, 64);
+            const bool inblk = ((pcx & pcy) & 256) != 0;
+            const float* p = &blk[s * CELLS + (pcy & 255) * BS + (pcx & 255)];
+            const float e = 1.f - w, so = 1.f - n;
+            const float vnw = inblk ? p[0] : 0.f, vne = inblk ? p[1] : 0.f;
+            const float vsw = inblk ? p[BS] : 0.f, vse = inblk ? p[BS + 1] : 0.f;
+            float r0 = vnw * (so * e);
+            r0 = r0 + vne * (so * w);
+            r0 = r0 + vsw * (n * e);
+            r0 = r0 + vse * (n * w);
+            res[tr][s] = r0;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tr = 0; tr < TAP_ROUNDS; ++tr) {
+        const int tap = tr * 64 + lane;
+        if (tap < KK) {
+#pragma unroll
+            for (int s = 0; s < QPW; ++s) outs[tap][wave * QPW + s] = res[tr][s];
+        }
+    }
+    __syncthreads();
+    for (int idx = t; idx < KK * QPB; idx += NTHR) {
+        const int k = idx / QPB, c = idx - k * QPB;
+        if (q0 + c < N1) out[((size_t)b * KK + k) * N1 + q0 + c] = outs[k][c];
+    }
+}
+
 }  // namespace
 
 // queries-per-launch at or below which the 16-wave variant is used; MV_LOOKUP_SMALL=<n> overrides it for A/B runs
@@ -241,5 +375,21 @@ extern "C" int mv_corr_lookup(const float* vol, const float* coords, float* out,
         default: MV_LOOKUP(4); break;
     }
 #undef MV_LOOKUP
+    return mv_launch_status();
+}
+
+// the same on a volume whose slices are stored in 4 x 4-cell tiles (mv_volume_pack_tiled + mv_corr_volume_packed); radius 4, H2 and W2
+// multiples of 4
+extern "C" int mv_corr_lookup_tiled(const float* vol, const float* coords, float* out, int B, int H1, int W1, int H2, int W2,
+                                    int radius, mvStream_t stream) {
+    MV_CHECK_ARG(vol && coords && out);
+    MV_CHECK_ARG(B > 0 && H1 > 0 && W1 > 0 && H2 > 1 && W2 > 1);
+    if (radius != 4 || (H2 % 4) || (W2 % 4) || B > 65535) return MV_ERR_UNSUPPORTED;
+    const int N1 = H1 * W1;
+    hipStream_t s = (hipStream_t)stream;
+    if ((size_t)B * N1 <= (size_t)lookup_small_threshold())
+        hipLaunchKernelGGL((corr_lookup_tiled_kernel<2, 16>), dim3(mv_ceil_div(N1, 16), B), dim3(512), 0, s, vol, coords, out, N1, H2, W2);
+    else
+        hipLaunchKernelGGL((corr_lookup_tiled_kernel<4, 32>), dim3(mv_ceil_div(N1, 32), B), dim3(512), 0, s, vol, coords, out, N1, H2, W2);
     return mv_launch_status();
 }

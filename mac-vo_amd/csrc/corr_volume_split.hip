@@ -61,7 +61,7 @@ namespace {
 template <int NP, bool F16>
 __global__ __launch_bounds__(256) void volume_pack_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                           uint16_t* __restrict__ p1, uint16_t* __restrict__ p2, int B, int C,
-                                                          int N1, int N2, int hwc) {
+                                                          int N1, int N2, int hwc, int tile_w) {
     __shared__ float wmax[4][32];
     const int op = blockIdx.y;
     const float* __restrict__ f = op ? f2 : f1;
@@ -72,6 +72,19 @@ __global__ __launch_bounds__(256) void volume_pack_kernel(const float* __restric
     const int b = blockIdx.x / nrb, rb = blockIdx.x - b * nrb;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, kh = lane >> 5;
     const int row = rb == nrb - 1 ? N - 1 : min(rb * 32 + li, N - 1);
+    // tile_w > 0 (mv_volume_pack_tiled): operand 2's pixels are packed in 4 x 4-cell tile order of its tile_w-pixel-wide map — packed
+    // row r' = (tile, cell): the GEMM's output columns then ARE that order, i.e. every query's slice of the volume comes out tiled
+    // (16 consecutive floats = one 4 x 4 block of target pixels = one 64-byte line) with the GEMM and its coalesced stores untouched.
+    // The workgroup still READS 32 consecutive pixels (coalesced for CHW input) and scatters on the write side: pixel (y, x) goes to
+    // packed row r' = ((y / 4) * (W / 4) + x / 4) * 16 + (y % 4) * 4 + x % 4 — four consecutive pixels stay four consecutive rows
+    // (64-byte runs).  (Permuting on the read side instead cost the B = 64 pack 2x and the 32-lane step 4 %.)
+    int rb_d = rb, li_d = li;
+    if (tile_w > 0 && op == 1 && rb != nrb - 1 && rb * 32 + li < N) {
+        const int r = rb * 32 + li, y = r / tile_w, xx = r - y * tile_w;
+        const int rd = (((y >> 2) * (tile_w >> 2) + (xx >> 2)) << 4) + ((y & 3) << 2) + (xx & 3);
+        rb_d = rd >> 5;
+        li_d = rd & 31;
+    }
     constexpr int MAXKS = 8;                                     // k-steps per wave held in registers (C <= 512)
     float x[MAXKS][8];
     float m = 0.f;
@@ -104,7 +117,7 @@ __global__ __launch_bounds__(256) void volume_pack_kernel(const float* __restric
         m = fmaxf(fmaxf(wmax[0][li], wmax[1][li]), fmaxf(wmax[2][li], wmax[3][li]));
         if (m > 0.f && m < INFINITY) sh = min(60, max(-60, 14 - ilogbf(m)));     // NaN / inf / all-zero rows: unscaled
         int* exps = reinterpret_cast<int*>(reinterpret_cast<char*>(out) + (size_t)B * nrb * KS * NP * 1024);
-        if (wave == 0 && kh == 0) exps[((size_t)b * nrb + rb) * 32 + li] = sh;
+        if (wave == 0 && kh == 0) exps[((size_t)b * nrb + rb_d) * 32 + li_d] = sh;
     }
 #pragma unroll
     for (int q = 0; q < MAXKS; ++q) {
@@ -127,7 +140,7 @@ __global__ __launch_bounds__(256) void volume_pack_kernel(const float* __restric
                     }
                 }
             }
-            s16x8* dst = reinterpret_cast<s16x8*>(out) + (((size_t)b * nrb + rb) * KS + ks) * NP * 64 + lane;
+            s16x8* dst = reinterpret_cast<s16x8*>(out) + (((size_t)b * nrb + rb_d) * KS + ks) * NP * 64 + kh * 32 + li_d;
 #pragma unroll
             for (int p = 0; p < NP; ++p) dst[p * 64] = pc[p];
         }
@@ -621,8 +634,8 @@ extern "C" size_t mv_volume_pack_bytes(int B, int C, int N, int mode) {
     return units + exps;
 }
 
-extern "C" int mv_volume_pack(const float* f1, const float* f2, void* packed1, void* packed2, int B, int C, int N1, int N2,
-                              int layout, int mode, mvStream_t stream) {
+static int volume_pack_impl(const float* f1, const float* f2, void* packed1, void* packed2, int B, int C, int N1, int N2,
+                            int layout, int mode, int tile_w, mvStream_t stream) {
     MV_CHECK_ARG(f1 && f2 && packed1 && packed2 && B > 0 && N1 > 0 && N2 > 0);
     MV_CHECK_ARG(layout == MV_LAYOUT_CHW || layout == MV_LAYOUT_HWC);
     MV_CHECK_ARG(((uintptr_t)f1 & 15) == 0 && ((uintptr_t)f2 & 15) == 0 && ((uintptr_t)packed1 & 15) == 0 && ((uintptr_t)packed2 & 15) == 0);
@@ -633,11 +646,24 @@ extern "C" int mv_volume_pack(const float* f1, const float* f2, void* packed1, v
     const int hwc = layout == MV_LAYOUT_HWC ? 1 : 0;
     if (mode == MV_PACK_BF16X3)
         hipLaunchKernelGGL((volume_pack_kernel<3, false>), grid, blk, 0, (hipStream_t)stream, f1, f2, (uint16_t*)packed1, (uint16_t*)packed2, B, C,
-                           N1, N2, hwc);
+                           N1, N2, hwc, tile_w);
     else
         hipLaunchKernelGGL((volume_pack_kernel<2, true>), grid, blk, 0, (hipStream_t)stream, f1, f2, (uint16_t*)packed1, (uint16_t*)packed2, B, C,
-                           N1, N2, hwc);
+                           N1, N2, hwc, tile_w);
     return mv_launch_status();
+}
+
+extern "C" int mv_volume_pack(const float* f1, const float* f2, void* packed1, void* packed2, int B, int C, int N1, int N2,
+                              int layout, int mode, mvStream_t stream) {
+    return volume_pack_impl(f1, f2, packed1, packed2, B, C, N1, N2, layout, mode, 0, stream);
+}
+
+// ... with operand 2 (an H2 x W2 map, both multiples of 4) in 4 x 4-tile order: mv_corr_volume_packed then writes the TILED volume
+// out[b][i][(ty * W2/4 + tx) * 16 + (y % 4) * 4 + x % 4] that mv_corr_lookup_tiled reads (frame driver, lanes >= 3)
+extern "C" int mv_volume_pack_tiled(const float* f1, const float* f2, void* packed1, void* packed2, int B, int C, int N1, int H2,
+                                    int W2, int layout, int mode, mvStream_t stream) {
+    MV_CHECK_ARG(H2 > 0 && W2 > 0 && (H2 % 4) == 0 && (W2 % 4) == 0);
+    return volume_pack_impl(f1, f2, packed1, packed2, B, C, N1, H2 * W2, layout, mode, W2, stream);
 }
 
 // shapes the streaming GEMM covers (the caller falls back to the exact fp32 kernel otherwise — never less accurate)

@@ -119,6 +119,8 @@ struct mvFramePipe {
     void* pk[2][2];
     size_t pk_bytes;
     bool packed;
+    bool tiled;        // MV_PIPE_TILED=1 && packed: operand 2 packed in 4 x 4-tile order -> the volume is tiled for mv_corr_lookup_tiled
+                       // (the driver owns both the producer and the consumer of the volume; MV_FB_VOLUME then shows that layout)
     int pack_on;       // 0 = on the GEMM's stream (in front of it), 1 = backend stream, 2 = decoder-side stream
     int sel_on_back;   // 1: upsampling / epilogue / selector / count copy of a frame run on the backend stream behind its lookups
     hipEvent_t e_lk[N_CAND];   // a frame's last lookup (decoder-side stream)
@@ -507,6 +509,15 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
     p->packed = (cfg->volume_split == MV_PACK_BF16X3 || cfg->volume_split == MV_PACK_F16X2) &&
                 mv_corr_volume_packed_supported(cfg->pairs, cfg->C, p->n8, p->n8, cfg->volume_split);
     {
+        // Tiled volume for the batched lookups, MV_PIPE_TILED=1.  Measured (640x480, 32 lanes, f16x2): the tiled lookup
+        // alone is 15 % faster (B = 64: 114 -> 97 us: the same bytes in half as many, aligned 64-byte requests), the 32-lane step
+        // 6 % SLOWER (7.44 k vs 7.95 k frames/s; beside the GEMM's write stream the row-major form's 32-byte sector gathers do better)
+        // -> off by default.
+        const char* e = getenv("MV_PIPE_TILED");
+        const bool want = e ? atoi(e) != 0 : false;
+        p->tiled = want && p->packed && cfg->radius == 4 && (p->h8 % 4) == 0 && (p->w8 % 4) == 0;
+    }
+    {
         // MV_PIPE_SELECTOR_ON=back: the selector segment of a frame (epilogue, NMS, finishing workgroup, count copy: ~60 us beside the
         // GEMM) moves from the decoder-side stream — which a one-lane stream saturates: 12 dependent lookups + that segment = one
         // period — to the backend stream, behind an event on the frame's last lookup; the next frame's lookups start meanwhile.
@@ -582,8 +593,12 @@ static int issue_volume(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_s
             // this operand set was last read by the GEMM of frame f - 2 (same stream order as the volume buffers' events)
             if (f >= 2) MV_TRY(wait_if_pending(sp, p->e_vol_done[(f - 2) % p->n_volbuf]));
         }
-        MV_TRY(mv_volume_pack((const float*)in->fmap1, (const float*)in->fmap2, pk[0], pk[1], B, c.C, p->n8, p->n8, c.layout,
-                              c.volume_split, sp));
+        if (p->tiled)
+            MV_TRY(mv_volume_pack_tiled((const float*)in->fmap1, (const float*)in->fmap2, pk[0], pk[1], B, c.C, p->n8, p->h8, p->w8,
+                                        c.layout, c.volume_split, sp));
+        else
+            MV_TRY(mv_volume_pack((const float*)in->fmap1, (const float*)in->fmap2, pk[0], pk[1], B, c.C, p->n8, p->n8, c.layout,
+                                  c.volume_split, sp));
         if (sp != p->s_vol) {
             MV_HIP(hipEventRecord(p->e_packed[f & 1], sp));
             MV_HIP(hipStreamWaitEvent(p->s_vol, p->e_packed[f & 1], 0));
@@ -649,15 +664,15 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
     if (p->lookups_on_main) {
         MV_HIP(hipStreamWaitEvent(s, p->e_vol_done[kv], 0));   // also orders `s` after e_in (the GEMM stream waited for it)
         for (int it = 0; it < c.iters; ++it)
-            MV_TRY(mv_corr_lookup(p->vol[kv], in->coords + it * coord_stride, p->tok[it & 1], B, p->h8, p->w8, p->h8, p->w8,
-                                  c.radius, s));
+            MV_TRY((p->tiled ? mv_corr_lookup_tiled : mv_corr_lookup)(p->vol[kv], in->coords + it * coord_stride, p->tok[it & 1], B, p->h8,
+                                                                      p->w8, p->h8, p->w8, c.radius, s));
         MV_HIP(hipEventRecord(p->e_vol_free[kv], s));
         p->vol_free_valid[kv] = true;
         if (timed) MV_HIP(hipEventRecord(p->tv2[ti], s));
     } else {
         for (int it = 0; it < c.iters; ++it)
-            MV_TRY(mv_corr_lookup(p->vol[kv], in->coords + it * coord_stride, p->tok[it & 1], B, p->h8, p->w8, p->h8, p->w8,
-                                  c.radius, p->s_vol));
+            MV_TRY((p->tiled ? mv_corr_lookup_tiled : mv_corr_lookup)(p->vol[kv], in->coords + it * coord_stride, p->tok[it & 1], B, p->h8,
+                                                                      p->w8, p->h8, p->w8, c.radius, p->s_vol));
         MV_HIP(hipEventRecord(p->e_vol_done[kv], p->s_vol));   // volume AND its lookups done
         MV_HIP(hipStreamWaitEvent(s, p->e_vol_done[kv], 0));   // also orders `s` after e_in
         p->vol_free_valid[kv] = false;                         // vol[k] / tok are only touched on s_vol: stream order suffices

@@ -110,10 +110,13 @@ def corr_volume(f1: torch.Tensor, f2: torch.Tensor, layout: str = "chw", out: to
 _PACK_MODE = {"bf16x3": L.MV_PACK_BF16X3, "f16x2": L.MV_PACK_F16X2}
 
 
-def volume_pack(f1: torch.Tensor, f2: torch.Tensor, layout: str = "chw", out: "tuple | None" = None, mode: str = "bf16x3"):
+def volume_pack(f1: torch.Tensor, f2: torch.Tensor, layout: str = "chw", out: "tuple | None" = None, mode: str = "bf16x3",
+                tiled_hw: "tuple | None" = None):
     """fp32 feature maps -> the packed operands of ``corr_volume_packed`` (``mv_volume_pack``: both maps in one launch,
     MFMA-fragment order, row N - 1 replicated past the edge).  mode "bf16x3": three bf16 pieces; "f16x2": two fp16 pieces of
-    every value after a per-row power-of-two scaling (+ the table of row exponents).  Returns two uint8 tensors (opaque)."""
+    every value after a per-row power-of-two scaling (+ the table of row exponents).  Returns two uint8 tensors (opaque).
+    ``tiled_hw=(H2, W2)``: operand 2 in 4 x 4-tile order (``mv_volume_pack_tiled``) -> the volume comes out tiled for
+    ``corr_lookup(..., tiled=True)``."""
     md = _PACK_MODE[mode]
     lib = L.load()
     f1 = _req(f1, torch.float32, "f1")
@@ -129,8 +132,15 @@ def volume_pack(f1: torch.Tensor, f2: torch.Tensor, layout: str = "chw", out: "t
         raise L.MacvoHipError("volume_pack: unsupported shape (C % 16 != 0?)")
     p1, p2 = out if out is not None else (torch.empty(n1, dtype=torch.uint8, device=f1.device), torch.empty(n2, dtype=torch.uint8, device=f1.device))
     assert p1.numel() >= n1 and p2.numel() >= n2
-    L.check(lib.mv_volume_pack(f1.data_ptr(), f2.data_ptr(), p1.data_ptr(), p2.data_ptr(), B, Cc, N1, N2,
-                               L.MV_LAYOUT_CHW if layout == "chw" else L.MV_LAYOUT_HWC, md, _stream()), "mv_volume_pack")
+    lay = L.MV_LAYOUT_CHW if layout == "chw" else L.MV_LAYOUT_HWC
+    if tiled_hw is not None:
+        H2, W2 = tiled_hw
+        assert H2 * W2 == N2
+        L.check(lib.mv_volume_pack_tiled(f1.data_ptr(), f2.data_ptr(), p1.data_ptr(), p2.data_ptr(), B, Cc, N1, H2, W2, lay, md, _stream()),
+                "mv_volume_pack_tiled")
+    else:
+        L.check(lib.mv_volume_pack(f1.data_ptr(), f2.data_ptr(), p1.data_ptr(), p2.data_ptr(), B, Cc, N1, N2, lay, md, _stream()),
+                "mv_volume_pack")
     return p1, p2
 
 
@@ -169,8 +179,10 @@ def local_corr81(first: torch.Tensor, second: torch.Tensor, out: torch.Tensor | 
 
 
 # ------------------------------------------------------------------------------------------- A6
-def corr_lookup(cost_maps: torch.Tensor, coords: torch.Tensor, radius: int = 4, out: torch.Tensor | None = None) -> torch.Tensor:
-    """``encode_flow_token(cost_maps, coords)`` (covhead.py:92): ``[B*N1,1,H2,W2]``, ``[B,2,H1,W1]`` -> ``[B,(2r+1)^2,H1,W1]``."""
+def corr_lookup(cost_maps: torch.Tensor, coords: torch.Tensor, radius: int = 4, out: torch.Tensor | None = None,
+                tiled: bool = False) -> torch.Tensor:
+    """``encode_flow_token(cost_maps, coords)`` (covhead.py:92): ``[B*N1,1,H2,W2]``, ``[B,2,H1,W1]`` -> ``[B,(2r+1)^2,H1,W1]``.
+    ``tiled``: the slices of ``cost_maps`` are stored in 4 x 4-cell tiles (``volume_pack(tiled_hw=...)`` + ``corr_volume_packed``)."""
     lib = L.load()
     cost_maps = _req(cost_maps, torch.float32, "cost_maps")
     coords = _req(coords, torch.float32, "coords")
@@ -182,8 +194,9 @@ def corr_lookup(cost_maps: torch.Tensor, coords: torch.Tensor, radius: int = 4, 
     K = 2 * radius + 1
     if out is None:
         out = torch.empty((B, K * K, H1, W1), dtype=torch.float32, device=coords.device)
-    L.check(lib.mv_corr_lookup(cost_maps.data_ptr(), coords.data_ptr(), out.data_ptr(), B, H1, W1, H2, W2, radius,
-                               _stream()), "mv_corr_lookup")
+    fn = lib.mv_corr_lookup_tiled if tiled else lib.mv_corr_lookup
+    L.check(fn(cost_maps.data_ptr(), coords.data_ptr(), out.data_ptr(), B, H1, W1, H2, W2, radius, _stream()),
+            "mv_corr_lookup_tiled" if tiled else "mv_corr_lookup")
     return out
 
 

@@ -319,3 +319,38 @@ def test_backend_launch_thread_equals_inline_issue(gpu, lanes, seeded, sync_each
     for x, y in zip(fa, fb):
         for (k0, p0, n0), (k1, p1, n1) in zip(x, y):
             assert n0 == n1 and torch.equal(k0, k1) and torch.equal(p0, p1)
+
+
+def test_driver_tiled_volume_for_three_lanes_equals_row_major(gpu, monkeypatch):
+    """`MV_PIPE_TILED=1` with a split volume precision: the frame driver packs operand 2 in tile order and runs
+    `mv_corr_lookup_tiled` (measured slower in the pipeline, hence opt-in).  Same tokens, keypoints and poses as the
+    same pipe with the row-major volume, bit for bit."""
+    from macvo_amd.pipeline import Camera, HotPathConfig, NativeHotPath, stack_lanes
+
+    H, W, n_frames, lanes = 480, 640, 4, 3
+    seqs = [synth.make_sequence(n_frames, H, W, C=256, iters=3, seed=900 + l, pool=1) for l in range(lanes)]
+    cam = seqs[0][0]
+    batched = [stack_lanes([_inputs(seqs[l][1][t], gpu) for l in range(lanes)]) for t in range(n_frames)]
+    torch.cuda.synchronize()
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MV_PIPE_TILED", flag)
+        hot = NativeHotPath(Camera(**cam), HotPathConfig(num_point=100, volume_precision="f16x2"), gpu, lanes=lanes,
+                            generators=[5, 6, 7])
+        hot.initialize(batched[0])
+        sink = torch.zeros(n_frames - 1, lanes, 7, device=gpu)
+        toks, kps = [], []
+        for t in range(1, n_frames):
+            res = hot.step(batched[t])
+            toks.append(hot.last_tokens.clone())
+            kps.append([r.kp0_uv.clone() for r in res])
+            sink[t - 1] = torch.stack([r.pose for r in res])
+        torch.cuda.synchronize()
+        outs.append((toks, kps, sink.clone()))
+        del hot
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a, b)
+    for fa, fb in zip(outs[0][1], outs[1][1]):
+        for a, b in zip(fa, fb):
+            assert torch.equal(a, b)
+    assert torch.equal(outs[0][2], outs[1][2]) and outs[0][2].abs().sum().item() > 0

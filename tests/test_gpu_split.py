@@ -206,3 +206,63 @@ for B, H, W in ((2, 60, 80), (3, 59, 64), (1, 16, 24)):
         assert r.returncode == 0, r.stderr[-2000:]
         shas.append(r.stdout.split())
     assert len(shas[0]) == 3 and shas[0] == shas[1], shas
+
+
+@pytest.mark.parametrize("mode", ["f16x2", "bf16x3"])
+@pytest.mark.parametrize("B,H,W", [(2, 60, 80), (6, 24, 32), (1, 8, 8)])
+def test_tiled_volume_and_tiled_lookup_equal_the_row_major_forms(gpu, mode, B, H, W):
+    """`mv_volume_pack_tiled` permutes operand 2's pixels into 4 x 4-tile order, so the unchanged GEMM writes every query's slice
+    tiled; `mv_corr_lookup_tiled` reads that layout.  (i) the tiled volume is the row-major one permuted, bit for bit (each output
+    element is the same k-ordered sum wherever its column sits); (ii) the tiled lookup returns the row-major lookup's tokens bit for
+    bit — for coordinates inside, across the border, far outside, on / next to integers (the margin-tile predicate) and in both
+    kernel variants (B * N <= / > the small-launch threshold)."""
+    from macvo_amd import ops
+    from oracle import corr
+
+    C = 256
+    N = H * W
+    f1, f2 = _feats(B, C, H, W, seed=5)
+    d1, d2 = f1.to(gpu), f2.to(gpu)
+    pk = ops.volume_pack(d1, d2, mode=mode)
+    vol = ops.corr_volume_packed(pk[0], pk[1], B, C, N, N, mode=mode).view(B * N, 1, H, W)
+    pkt = ops.volume_pack(d1, d2, mode=mode, tiled_hw=(H, W))
+    volt = ops.corr_volume_packed(pkt[0], pkt[1], B, C, N, N, mode=mode).view(B * N, 1, H, W)
+    assert ops.last_volume_kernel() == f"corr_volume_split_stream<{mode}>"
+    # (i) un-tile on the host: [q][ty][tx][4][4] -> [q][y][x]
+    unt = volt.view(B * N, H // 4, W // 4, 4, 4).permute(0, 1, 3, 2, 4).reshape(B * N, 1, H, W)
+    assert torch.equal(unt, vol)
+    # (ii) lookups
+    g = torch.Generator().manual_seed(9)
+    eps = torch.tensor([0.0, 1.2e-7, -1.2e-7, 1e-4, -1e-4, 9.9e-3, -9.9e-3, 1.01e-2, -1.01e-2, 0.3, 0.5, -0.4])
+    for it in range(3):
+        pick = torch.randint(0, len(eps), (B, 2, H, W), generator=g)
+        shift = torch.randint(-7, 8, (B, 2, H, W), generator=g).float()
+        coords = corr.coords_grid(B, H, W) + shift + eps[pick] + (torch.rand(B, 2, H, W, generator=g) * 4 - 2) * (it == 2)
+        if it == 1:
+            coords[:, :, 0, 0] = 1000.0                                   # far outside: zeros
+            coords[:, 0, 1, 1] = -3.0                                     # window across the left border
+        cd = coords.to(gpu)
+        a = ops.corr_lookup(vol, cd, 4)
+        b_ = ops.corr_lookup(volt, cd, 4, tiled=True)
+        assert torch.equal(a, b_), it
+    for thr in ("0", "1000000000"):                                       # force the other kernel variant through its A/B knob
+        import os, subprocess, sys
+        code = (
+            "import sys, torch; sys.path.insert(0, sys.argv[1])\n"
+            "from macvo_amd import ops\n"
+            "from oracle import corr\n"
+            f"B, C, H, W = {B}, 256, {H}, {W}; N = H * W\n"
+            "g = torch.Generator().manual_seed(5)\n"
+            "f1 = torch.randn(B, C, H, W, generator=g).cuda(); f2 = torch.randn(B, C, H, W, generator=g).cuda()\n"
+            f"pk = ops.volume_pack(f1, f2, mode='{mode}'); pkt = ops.volume_pack(f1, f2, mode='{mode}', tiled_hw=(H, W))\n"
+            f"vol = ops.corr_volume_packed(pk[0], pk[1], B, C, N, N, mode='{mode}').view(B * N, 1, H, W)\n"
+            f"volt = ops.corr_volume_packed(pkt[0], pkt[1], B, C, N, N, mode='{mode}').view(B * N, 1, H, W)\n"
+            "coords = (corr.coords_grid(B, H, W) + torch.rand(B, 2, H, W, generator=g) * 12 - 6).cuda()\n"
+            "assert torch.equal(ops.corr_lookup(vol, coords, 4), ops.corr_lookup(volt, coords, 4, tiled=True))\n"
+        )
+        if (B, H, W) != (6, 24, 32):
+            continue
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, MV_LOOKUP_SMALL=thr), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
