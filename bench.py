@@ -286,14 +286,21 @@ def main():
             hot.time_volume(n_ev)   # HIP-event pairs around the volume GEMM, recorded by the driver on its GEMM stream
         t0 = time.perf_counter()
         # software-pipelined stream (frame t+1's frontend is queued before frame t's host randperm); K full run_pairs
+        trace = [] if os.environ.get("MV_BENCH_TRACE") else None   # host time of every finished step (diagnostics, stderr)
         for _ in hot.run((batches[(t_idx + k) % args.pool] for k in range(steps)), pose_sink=poses):
-            pass
+            if trace is not None:
+                trace.append(time.perf_counter() - t0)
+        t_run = time.perf_counter() - t0
         # the one collective of the job (no-op for N = 1): poses [T,7] + time_ns [T] + T of every rank
         all_poses, _, _ = gather_tracks(poses.reshape(-1, 7), stamps.repeat_interleave(lanes), dist)
+        t_gather = time.perf_counter() - t0
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        if trace is not None and rank == 0:
+            print("[bench trace] step-finished times (us): " + " ".join(f"{x * 1e6:.0f}" for x in trace[:40]) +
+                  f" | run() returned {t_run * 1e6:.0f} | gather issued {t_gather * 1e6:.0f} | synchronized {elapsed * 1e6:.0f}", file=sys.stderr)
         if dist is not None:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
