@@ -329,6 +329,15 @@ def main():
                     "gemm_stream_idle_us": med([tl[i + 1][0] - tl[i][1] for i in range(lo, hi)]),
                     "gemm_end_to_last_lookup_us": med([tl[i][2] - tl[i][1] for i in range(lo, hi)]),
                     "last_lookup_to_selector_done_us": med([tl[i][3] - tl[i][2] for i in range(lo, hi)])})
+                tb = hot.timeline_backend_ms()
+                ok = [i for i in range(lo, min(hi, len(tb))) if min(tb[i]) >= 0]
+                if len(ok) > 8:
+                    last_timeline.update({
+                        "selector_done_to_backend_start_us": med([tb[i][0] - tl[i][3] for i in ok]),
+                        "backend_us": med([tb[i][1] - tb[i][0] for i in ok]),
+                        "backend_end_to_pose_apply_us": med([tb[i][2] - tb[i][1] for i in ok]),
+                        "pose_apply_plus_solve_us": med([tb[i][3] - tb[i][2] for i in ok]),
+                        "gemm_start_to_pose_us": med([tb[i][3] - tl[i][0] for i in ok])})
         del hot
         return elapsed, all_poses, ms, min(steps, len(ms))
 

@@ -642,6 +642,8 @@ int mv_frame_pipe_time_volume(mvFramePipe* p, int max_launches);
 int mv_frame_pipe_volume_times(mvFramePipe* p, float* ms, int cap, int* n);
 /* per timed frame: {GEMM start, GEMM end, last lookup done, selector done} in ms since the first timed GEMM start */
 int mv_frame_pipe_timeline(mvFramePipe* p, float* ms, int cap_frames, int* n);
+/* ... and {backend start, backend end, pose_apply start, solve end} of the same frames (-1: not finished / no keypoints) */
+int mv_frame_pipe_timeline_backend(mvFramePipe* p, float* ms, int cap_frames, int* n);
 /* where a result lives inside the arena; age 0 = newest frame that passed that stage, 1 = the one before */
 int mv_frame_pipe_buffer(mvFramePipe* p, int which, int age, void** ptr, size_t* count);
 

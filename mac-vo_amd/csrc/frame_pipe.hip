@@ -73,6 +73,18 @@ struct Backend {   // every table is [lanes, cap = num_point, ...]; rows beyond 
 struct Pending {
     int maps, maps_prev, cand;
     bool has_cand;
+    int ti;   // timing slot of the frame (mv_frame_pipe_time_volume), -1: not timed
+};
+
+// The selector segment of a frame (upsampling / epilogue / selector(s) / count copies): everything behind the frame's last lookup.
+// Issued by mv_frame_pipe_enqueue itself, or — MV_PIPE_SELECTOR_ON=vol — deferred until the NEXT frame's GEMM has been queued, so that
+// it lands behind that GEMM on the GEMM's stream.
+struct SelSeg {
+    mvFrameInputs in;
+    long f;
+    int k, m, ti, maps_prev;
+    bool timed, with_selector, up;
+    long need_issued;   // backend launch thread: finishes that must have been issued before the segment's slot-reuse wait
 };
 
 // One `finish` split in two: the host-visible bookkeeping (slot rotation, counts, views) happens on the calling thread, the
@@ -141,6 +153,9 @@ struct mvFramePipe {
     int64_t* h_perm[N_PERM];  // pinned
     // streams / events
     hipStream_t s_vol, s_main, s_back, s_side;
+    hipStream_t s_sel;   // MV_PIPE_SELECTOR_ON=own: a fifth stream for the selector segment (nullptr otherwise)
+    SelSeg deferred;     // MV_PIPE_SELECTOR_ON=vol: the newest frame's selector segment, not issued yet
+    bool deferred_valid;
     hipEvent_t e_rest[N_INEV];   // inputs of the decoder side (coords, flow, ...) when the GEMM was issued ahead of them
     hipEvent_t e_in[N_INEV], e_vol_done[MAX_VOL], e_vol_free[MAX_VOL], e_cand[N_CAND], e_backend[2], e_pgo, e_perm[N_PERM];
     hipEvent_t e_release;     // the consumer's reads of result views enqueued so far (mv_frame_pipe_release)
@@ -183,6 +198,7 @@ struct mvFramePipe {
     // optional timing of the dominant kernel (bench.py roofline): event pairs around each volume GEMM on its stream
     int vol_timed[MAX_VOL];      // timing slot of the GEMM that filled each volume buffer (-1: not timed)
     std::vector<hipEvent_t> tv0, tv1, tv2, tv3;   // GEMM start / end, last lookup done, selector done (timeline hook)
+    std::vector<hipEvent_t> tv4, tv5, tv6, tv7;   // backend start / end (backend stream), pose_apply start / solve end (solve stream)
     int n_timed, timed_cap;
     // Backend launch thread (round 3).  A one-lane stream is bound by the HOST: ~38 launches per frame at ~4 us each on one thread
     // (tools/host_breakdown.py: 172 us of host time per frame, 6 us of it waiting for the GPU).  With `async_backend` the ~10
@@ -215,6 +231,7 @@ static int wait_if_pending(hipStream_t s, hipEvent_t e) {
 
 #define MV_ASYNC_DEFAULT(p) (1)   // measured (640x480, f16x2 volume): one lane 6.01 k vs 5.26 k frames/s, 32 lanes 7.56 k vs 7.54 k
 static int wait_issued(mvFramePipe* p, long n);
+static int flush_deferred(mvFramePipe* p);
 static int flush_jobs(mvFramePipe* p);
 static void launch_thread_main(mvFramePipe* p);
 
@@ -350,6 +367,7 @@ extern "C" void mv_frame_pipe_destroy(mvFramePipe* p) {
     (void)hipStreamSynchronize(p->s_main);
     (void)hipStreamSynchronize(p->s_back);
     (void)hipStreamSynchronize(p->s_side);
+    if (p->s_sel) (void)hipStreamSynchronize(p->s_sel);
     auto ev = [](hipEvent_t e) { if (e) (void)hipEventDestroy(e); };
     for (auto e : p->e_in) ev(e);
     for (auto e : p->e_rest) ev(e);
@@ -371,12 +389,17 @@ extern "C" void mv_frame_pipe_destroy(mvFramePipe* p) {
     for (auto e : p->tv1) ev(e);
     for (auto e : p->tv2) ev(e);
     for (auto e : p->tv3) ev(e);
+    for (auto e : p->tv4) ev(e);
+    for (auto e : p->tv5) ev(e);
+    for (auto e : p->tv6) ev(e);
+    for (auto e : p->tv7) ev(e);
     for (int k = 0; k < N_CAND; ++k) if (p->h_count[k]) (void)hipHostFree(p->h_count[k]);
     for (auto h : p->h_perm) if (h) (void)hipHostFree(h);
     if (p->s_vol) (void)hipStreamDestroy(p->s_vol);
     if (p->s_main) (void)hipStreamDestroy(p->s_main);
     if (p->s_back) (void)hipStreamDestroy(p->s_back);
     if (p->s_side) (void)hipStreamDestroy(p->s_side);
+    if (p->s_sel) (void)hipStreamDestroy(p->s_sel);
     delete p;
 }
 
@@ -439,6 +462,7 @@ static int create_impl(mvFramePipe* p) {
         MV_HIP(hipStreamCreateWithPriority(&p->s_back, hipStreamNonBlocking, hi));
         MV_HIP(hipStreamCreateWithPriority(&p->s_side, hipStreamNonBlocking, hi));
     }
+    if (p->sel_on_back == 2) MV_HIP(hipStreamCreateWithPriority(&p->s_sel, hipStreamNonBlocking, hi));
     auto mk = [](hipEvent_t* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming); };
     for (auto& e : p->e_in) MV_HIP(mk(&e));
     for (auto& e : p->e_rest) MV_HIP(mk(&e));
@@ -524,7 +548,7 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
         // Measured (640x480, f16x2 volume): one lane 5.38 k vs 4.94 k frames/s (period 183 vs 198 us), 32 lanes 7.43 k vs 7.64 k: the
         // default follows the lane count; MV_PIPE_SELECTOR_ON=main|back forces it.
         const char* e = getenv("MV_PIPE_SELECTOR_ON");
-        p->sel_on_back = e ? (strcmp(e, "back") == 0 ? 1 : 0) : (p->lanes <= 2 ? 1 : 0);
+        p->sel_on_back = e ? (strcmp(e, "back") == 0 ? 1 : strcmp(e, "own") == 0 ? 2 : strcmp(e, "vol") == 0 ? 3 : 0) : (p->lanes <= 2 ? 1 : 0);
     }
     {
         // Where the operand pack of frame f + 1 runs.  It needs only the feature maps, so it can run beside GEMM(f) on another of
@@ -629,7 +653,96 @@ extern "C" int mv_frame_pipe_enqueue_volume(mvFramePipe* p, const mvFrameInputs*
     MV_CHECK_ARG(p->n_vol == p->n_enq);                 // at most one GEMM ahead of its frame
     MV_CHECK_ARG(p->lookups_on_main);                   // the alternative layout keeps the lookups behind the GEMM on its stream
     // the volume buffer of frame n_vol was last read by the lookups of frame n_vol - 2: their event exists (frame enqueued)
-    return issue_volume(p, in, in_stream);
+    MV_TRY(issue_volume(p, in, in_stream));
+    // MV_PIPE_SELECTOR_ON=vol: the newest enqueued frame's selector segment goes behind this GEMM on the GEMM's stream — it needs that
+    // frame's lookups, which finish about when this GEMM does, and then runs in the gap the GEMM stream idles in anyway, alone on the chip
+    return flush_deferred(p);
+}
+
+static int issue_selector_segment(mvFramePipe* p, const SelSeg& d) {
+    const mvFramePipeConfig& c = p->c;
+    const mvFrameInputs* in = &d.in;
+    const int k = d.k, m = d.m, ti = d.ti, B = c.pairs;
+    const bool timed = d.timed, with_selector = d.with_selector, up = d.up;
+    hipStream_t s = p->s_main;   // (same stream as the lookups: in order behind them)
+    if (p->sel_on_back) {   // everything behind the lookups continues on another stream (in order with the backends it must follow)
+        s = p->sel_on_back == 2 ? p->s_sel : p->sel_on_back == 3 ? p->s_vol : p->s_back;
+        MV_HIP(hipStreamWaitEvent(s, p->e_lk[k], 0));
+    }
+    // maps slot m and candidate slot k were last read by the backend of frame f - 2 (f - 3 for the maps) on `back`
+    // (the newest backend event covers the older one: same stream)
+    if (p->async_backend) {
+        // Maps slot m and candidate slot k were last read by the backend of frame f - 4.  Of the three tracked frames behind it,
+        // pending.size() are not finished yet and the others are the newest finishes: frame f - 4 is finish number
+        // n_fin - 3 + pending.size() - 1, which the launch thread issued long ago (this wait does not block in steady state); any
+        // backend event recorded at or after it orders this stream behind it (same stream).
+        if (!with_selector) MV_TRY(flush_jobs(p));   // (re-)initialisation: no assumption about what is in flight
+        long issued;
+        {
+            const long need = d.need_issued;
+            MV_TRY(wait_issued(p, need < 0 ? 0 : need));
+            std::lock_guard<std::mutex> lk(p->mu);
+            issued = p->issued;
+        }
+        if (issued > 0) MV_TRY(wait_if_pending(s, p->e_backend[(issued - 1) & 1]));
+    } else if (p->n_fin > 0 && p->backend_valid[(p->n_fin - 1) & 1]) {
+        MV_TRY(wait_if_pending(s, p->e_backend[(p->n_fin - 1) & 1]));
+    }
+    if (p->release_valid) MV_TRY(wait_if_pending(s, p->e_release));   // ... and by consumers of result views (mv_frame_pipe_release)
+    Maps& mp = p->maps[m];
+    static int fuse_epi = -1;   // MV_PIPE_FUSE_EPI=0: epilogue and selector as separate launches (A/B knob)
+    if (fuse_epi < 0) { const char* e = getenv("MV_PIPE_FUSE_EPI"); fuse_epi = (e && atoi(e) == 0) ? 0 : 1; }
+    if (up) {
+        MV_TRY(mv_convex_upsample(in->flow8, in->up_mask, p->up_flow, B, p->h8, p->w8, 0.25f, 0, s));
+        MV_TRY(mv_convex_upsample(in->cov8, in->cov_mask, p->up_cov, B, p->h8, p->w8, 1.0f, 1, s));
+        MV_TRY(mv_frontend_epilogue_lanes(p->up_flow, p->up_cov, 0, c.H, c.W, c.bl_fx, c.bl_fx_sq, mp.disparity,
+                                          mp.disparity_cov, mp.depth, mp.depth_cov, nullptr, mp.match_flow, mp.match_cov,
+                                          p->lanes, s));
+    } else if (!(fuse_epi && with_selector && c.selector_mode == MV_KP_NODEPTH)) {
+        MV_TRY(mv_frontend_epilogue_lanes(in->flow, in->logcov, 1, c.H, c.W, c.bl_fx, c.bl_fx_sq, mp.disparity,
+                                          mp.disparity_cov, mp.depth, mp.depth_cov, nullptr, mp.match_flow, mp.match_cov,
+                                          p->lanes, s));
+    }
+    const Pending pd{m, d.maps_prev, k, with_selector, ti};
+    if (with_selector) {
+        mvKpSelectParams sp{c.H, c.W, c.selector_mode, c.kp_kernel_size, c.kp_mask_width, c.max_depth, c.max_depth_cov,
+                            c.max_match_cov};
+        if (c.selector_mode == MV_KP_NODEPTH && fuse_epi && !up) {
+            // epilogue + selector's first kernel in one launch (one launch and one pass over the maps less on the chain that
+            // bounds a single-sequence stream)
+            MV_TRY(mv_frontend_epilogue_select_lanes(in->flow, in->logcov, 1, c.bl_fx, c.bl_fx_sq, mp.disparity, mp.disparity_cov,
+                                                     mp.depth, mp.depth_cov, nullptr, mp.match_flow, mp.match_cov, nullptr,
+                                                     nullptr, &sp, p->kp_ws, p->kp_ws_bytes, p->cand[k], p->count[k],
+                                                     p->stats[k], p->lanes, s));
+        } else if (c.selector_mode == MV_KP_NODEPTH) {
+            MV_TRY(mv_kp_select_lanes(mp.match_cov, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &sp, p->kp_ws,
+                                      p->kp_ws_bytes, p->cand[k], p->count[k], p->stats[k], p->lanes, s));
+        } else {
+            const Maps& m0 = p->maps[pd.maps_prev];
+            MV_TRY(mv_kp_select_lanes(mp.match_cov, m0.depth, m0.depth_cov, mp.depth, mp.depth_cov, nullptr, nullptr, &sp,
+                                      p->kp_ws, p->kp_ws_bytes, p->cand[k], p->count[k], p->stats[k], p->lanes, s));
+        }
+        MV_HIP(hipMemcpyAsync(p->h_count[k], p->count[k], (size_t)p->lanes * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        if (c.mapping) {
+            // MappingPointSelector works on the PREVIOUS frame's depth maps (KeypointSelector.py:87-100; MACVO.py:315): its count
+            // travels to the host with the tracking selector's
+            const Maps& m0 = p->maps[pd.maps_prev];
+            mvKpSelectParams spm{c.H, c.W, MV_KP_MAPPING, c.kp_kernel_size, c.map_mask_width, c.map_max_depth, c.map_max_depth_cov,
+                                 c.max_match_cov};
+            MV_TRY(mv_kp_select_lanes(nullptr, m0.depth, m0.depth_cov, nullptr, nullptr, nullptr, nullptr, &spm, p->kp_ws,
+                                      p->kp_ws_bytes, p->cand_m[k], p->count_m[k], p->stats_m[k], 1, s));
+            MV_HIP(hipMemcpyAsync(p->h_count_m[k], p->count_m[k], 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        }
+        MV_HIP(hipEventRecord(p->e_cand[k], s));
+        if (timed) MV_HIP(hipEventRecord(p->tv3[ti], s));
+    }
+    return MV_OK;
+}
+
+static int flush_deferred(mvFramePipe* p) {
+    if (!p->deferred_valid) return MV_OK;
+    p->deferred_valid = false;
+    return issue_selector_segment(p, p->deferred);
 }
 
 extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_stream, int with_selector) {
@@ -643,6 +756,7 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
     MV_CHECK_ARG(!with_selector || p->newest_maps >= 0);   // a tracked frame needs the previous frame's maps
     MV_CHECK_ARG(!with_selector || (int)p->pending.size() < MAX_PENDING);  // slot rotation covers MAX_PENDING tracked frames in flight
     const int B = c.pairs;
+    MV_TRY(flush_deferred(p));   // (the previous frame's selector segment, had nobody asked for it yet: frames stay in order)
 
     // ---- volume GEMM (own stream) unless mv_frame_pipe_enqueue_volume already issued it
     const bool ahead = p->n_vol != f;
@@ -678,79 +792,16 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
         p->vol_free_valid[kv] = false;                         // vol[k] / tok are only touched on s_vol: stream order suffices
     }
 
-    if (p->sel_on_back) {   // everything behind the lookups continues on the backend stream (in order with the backends it must follow)
-        MV_HIP(hipEventRecord(p->e_lk[k], s));
-        s = p->s_back;
-        MV_HIP(hipStreamWaitEvent(s, p->e_lk[k], 0));
+    SelSeg d{*in, f, k, m, ti, p->newest_maps, timed, with_selector != 0, up,
+             p->n_fin - MAX_PENDING + (long)p->pending.size()};
+    if (p->sel_on_back) MV_HIP(hipEventRecord(p->e_lk[k], s));   // the segment continues on another stream behind the last lookup
+    if (p->sel_on_back == 3 && with_selector) {
+        p->deferred = d;            // issued behind the next frame's GEMM (mv_frame_pipe_enqueue_volume) or by whoever needs it first
+        p->deferred_valid = true;
+    } else {
+        MV_TRY(issue_selector_segment(p, d));
     }
-    // maps slot m and candidate slot k were last read by the backend of frame f - 2 (f - 3 for the maps) on `back`
-    // (the newest backend event covers the older one: same stream)
-    if (p->async_backend) {
-        // Maps slot m and candidate slot k were last read by the backend of frame f - 4.  Of the three tracked frames behind it,
-        // pending.size() are not finished yet and the others are the newest finishes: frame f - 4 is finish number
-        // n_fin - 3 + pending.size() - 1, which the launch thread issued long ago (this wait does not block in steady state); any
-        // backend event recorded at or after it orders this stream behind it (same stream).
-        if (!with_selector) MV_TRY(flush_jobs(p));   // (re-)initialisation: no assumption about what is in flight
-        long issued;
-        {
-            const long need = p->n_fin - MAX_PENDING + (long)p->pending.size();
-            MV_TRY(wait_issued(p, need < 0 ? 0 : need));
-            std::lock_guard<std::mutex> lk(p->mu);
-            issued = p->issued;
-        }
-        if (issued > 0) MV_TRY(wait_if_pending(s, p->e_backend[(issued - 1) & 1]));
-    } else if (p->n_fin > 0 && p->backend_valid[(p->n_fin - 1) & 1]) {
-        MV_TRY(wait_if_pending(s, p->e_backend[(p->n_fin - 1) & 1]));
-    }
-    if (p->release_valid) MV_TRY(wait_if_pending(s, p->e_release));   // ... and by consumers of result views (mv_frame_pipe_release)
-    Maps& mp = p->maps[m];
-    static int fuse_epi = -1;   // MV_PIPE_FUSE_EPI=0: epilogue and selector as separate launches (A/B knob)
-    if (fuse_epi < 0) { const char* e = getenv("MV_PIPE_FUSE_EPI"); fuse_epi = (e && atoi(e) == 0) ? 0 : 1; }
-    if (up) {
-        MV_TRY(mv_convex_upsample(in->flow8, in->up_mask, p->up_flow, B, p->h8, p->w8, 0.25f, 0, s));
-        MV_TRY(mv_convex_upsample(in->cov8, in->cov_mask, p->up_cov, B, p->h8, p->w8, 1.0f, 1, s));
-        MV_TRY(mv_frontend_epilogue_lanes(p->up_flow, p->up_cov, 0, c.H, c.W, c.bl_fx, c.bl_fx_sq, mp.disparity,
-                                          mp.disparity_cov, mp.depth, mp.depth_cov, nullptr, mp.match_flow, mp.match_cov,
-                                          p->lanes, s));
-    } else if (!(fuse_epi && with_selector && c.selector_mode == MV_KP_NODEPTH)) {
-        MV_TRY(mv_frontend_epilogue_lanes(in->flow, in->logcov, 1, c.H, c.W, c.bl_fx, c.bl_fx_sq, mp.disparity,
-                                          mp.disparity_cov, mp.depth, mp.depth_cov, nullptr, mp.match_flow, mp.match_cov,
-                                          p->lanes, s));
-    }
-    Pending pd{m, p->newest_maps, k, with_selector != 0};
-    if (with_selector) {
-        mvKpSelectParams sp{c.H, c.W, c.selector_mode, c.kp_kernel_size, c.kp_mask_width, c.max_depth, c.max_depth_cov,
-                            c.max_match_cov};
-        if (c.selector_mode == MV_KP_NODEPTH && fuse_epi && !up) {
-            // epilogue + selector's first kernel in one launch (one launch and one pass over the maps less on the chain that
-            // bounds a single-sequence stream)
-            MV_TRY(mv_frontend_epilogue_select_lanes(in->flow, in->logcov, 1, c.bl_fx, c.bl_fx_sq, mp.disparity, mp.disparity_cov,
-                                                     mp.depth, mp.depth_cov, nullptr, mp.match_flow, mp.match_cov, nullptr,
-                                                     nullptr, &sp, p->kp_ws, p->kp_ws_bytes, p->cand[k], p->count[k],
-                                                     p->stats[k], p->lanes, s));
-        } else if (c.selector_mode == MV_KP_NODEPTH) {
-            MV_TRY(mv_kp_select_lanes(mp.match_cov, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &sp, p->kp_ws,
-                                      p->kp_ws_bytes, p->cand[k], p->count[k], p->stats[k], p->lanes, s));
-        } else {
-            const Maps& m0 = p->maps[pd.maps_prev];
-            MV_TRY(mv_kp_select_lanes(mp.match_cov, m0.depth, m0.depth_cov, mp.depth, mp.depth_cov, nullptr, nullptr, &sp,
-                                      p->kp_ws, p->kp_ws_bytes, p->cand[k], p->count[k], p->stats[k], p->lanes, s));
-        }
-        MV_HIP(hipMemcpyAsync(p->h_count[k], p->count[k], (size_t)p->lanes * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        if (c.mapping) {
-            // MappingPointSelector works on the PREVIOUS frame's depth maps (KeypointSelector.py:87-100; MACVO.py:315): its count
-            // travels to the host with the tracking selector's
-            const Maps& m0 = p->maps[pd.maps_prev];
-            mvKpSelectParams spm{c.H, c.W, MV_KP_MAPPING, c.kp_kernel_size, c.map_mask_width, c.map_max_depth, c.map_max_depth_cov,
-                                 c.max_match_cov};
-            MV_TRY(mv_kp_select_lanes(nullptr, m0.depth, m0.depth_cov, nullptr, nullptr, nullptr, nullptr, &spm, p->kp_ws,
-                                      p->kp_ws_bytes, p->cand_m[k], p->count_m[k], p->stats_m[k], 1, s));
-            MV_HIP(hipMemcpyAsync(p->h_count_m[k], p->count_m[k], 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        }
-        MV_HIP(hipEventRecord(p->e_cand[k], s));
-        if (timed) MV_HIP(hipEventRecord(p->tv3[ti], s));
-        p->pending.push_back(pd);
-    }
+    if (with_selector) p->pending.push_back(Pending{m, p->newest_maps, k, true, ti});
     p->newest_maps = m;
     p->n_enq = f + 1;
     return MV_OK;
@@ -758,6 +809,7 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
 
 extern "C" int mv_frame_pipe_wait_candidates(mvFramePipe* p, int32_t* n_cand) {
     MV_CHECK_ARG(p && n_cand && !p->pending.empty());
+    MV_TRY(flush_deferred(p));
     const Pending& pd = p->pending.front();
     MV_HIP(hipEventSynchronize(p->e_cand[pd.cand]));
     for (int l = 0; l < p->lanes; ++l) n_cand[l] = p->h_count[pd.cand][4 * l];
@@ -873,6 +925,8 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
     for (int l = 0; l < L; ++l)
         memcpy(p->h_perm[ps] + (size_t)l * cap, perm_host + (size_t)l * cap, (size_t)n_sel[l] * sizeof(int64_t));
     MV_TRY(wait_if_pending(s, p->e_cand[pd.cand]));   // fired: the host has just read this frame's count
+    const int ti = pd.ti;
+    if (ti >= 0) MV_HIP(hipEventRecord(p->tv4[ti], s));
     static int fuse_front = -1;   // MV_PIPE_FUSE_FRONT=0: gather / track / back-projection as three launches + a permutation copy (A/B knob)
     if (fuse_front < 0) { const char* e = getenv("MV_PIPE_FUSE_FRONT"); fuse_front = (e && atoi(e) == 0) ? 0 : 1; }
     const bool perm_in_args = fuse_front && L == 1 && n_max <= 256;
@@ -916,6 +970,7 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
     }
     MV_HIP(hipEventRecord(p->e_backend[k], s));
     p->backend_valid[k] = true;
+    if (ti >= 0) MV_HIP(hipEventRecord(p->tv5[ti], s));
 
     // ---- side stream: world-frame tables from the previous solve's pose (same stream: no event), then the LM solves of all
     // lanes in ONE launch (problem l = rows [l * cap, (l + 1) * cap), dead rows masked by `valid`); the optimised poses become
@@ -923,6 +978,7 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
     hipStream_t ss = p->s_side;
     MV_HIP(hipStreamWaitEvent(ss, p->e_backend[k], 0));
     const float* pose = p->pose[j.pose_from];
+    if (ti >= 0) MV_HIP(hipEventRecord(p->tv6[ti], ss));
     MV_TRY(mv_pose_apply_lanes(pose, b.pos_Tc, b.cov0, L, n_sel, cap, b.pos_Tw, b.rot, b.cov0w, ss));
     MV_HIP(hipEventRecord(p->e_posed[k], ss));
     const size_t N = (size_t)cap;
@@ -934,6 +990,7 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
         MV_HIP(hipMemcpyAsync(j.pose_sink, p->pose[j.pose_to], (size_t)L * 7 * sizeof(float), hipMemcpyDeviceToDevice, ss));
     MV_HIP(hipEventRecord(p->e_pgo, ss));
     MV_HIP(hipEventRecord(p->e_solved[k], ss));
+    if (ti >= 0) MV_HIP(hipEventRecord(p->tv7[ti], ss));
     p->pgo_valid = true;
     p->solved_valid[k] = true;
     return MV_OK;
@@ -997,6 +1054,7 @@ static int submit_or_issue(mvFramePipe* p, FinishJob& j, const int64_t* perm_hos
 // wait_candidates + permutations (per-lane generators of mv_frame_pipe_seed_lanes) + finish in one host call
 extern "C" int mv_frame_pipe_finish_seeded(mvFramePipe* p, float* pose_sink, int32_t* n_cand_out, int32_t* n_sel_out) {
     MV_CHECK_ARG(p && !p->pending.empty() && (int)p->rng.size() == p->lanes);
+    MV_TRY(flush_deferred(p));
     const Pending& pd = p->pending.front();
     MV_HIP(hipEventSynchronize(p->e_cand[pd.cand]));
     FinishJob j{};
@@ -1018,6 +1076,7 @@ extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, co
     MV_CHECK_ARG(p && n_sel && !p->pending.empty());
     for (int l = 0; l < p->lanes; ++l)
         MV_CHECK_ARG(n_sel[l] >= 0 && n_sel[l] <= p->c.num_point && (n_sel[l] == 0 || perm_host));
+    MV_TRY(flush_deferred(p));
     FinishJob j{};
     j.seeded = false;
     MV_TRY(finish_host(p, n_sel, pose_sink, j));
@@ -1120,6 +1179,7 @@ extern "C" int mv_frame_pipe_release(mvFramePipe* p, mvStream_t stream) {
 
 extern "C" int mv_frame_pipe_sync(mvFramePipe* p, mvStream_t stream, int block_host) {
     MV_CHECK_ARG(p);
+    MV_TRY(flush_deferred(p));
     MV_TRY(flush_jobs(p));   // everything finished so far has been issued
     if (block_host == 2) {   // results of the newest FINISHED frame only: its solve (which ran behind its backend kernels)
         if (p->pgo_valid) MV_HIP(hipStreamWaitEvent((hipStream_t)stream, p->e_pgo, 0));
@@ -1130,14 +1190,16 @@ extern "C" int mv_frame_pipe_sync(mvFramePipe* p, mvStream_t stream, int block_h
         MV_HIP(hipStreamSynchronize(p->s_main));
         MV_HIP(hipStreamSynchronize(p->s_back));
         MV_HIP(hipStreamSynchronize(p->s_side));
+        if (p->s_sel) MV_HIP(hipStreamSynchronize(p->s_sel));
         return MV_OK;
     }
     // make `stream` wait for everything enqueued so far
     hipEvent_t e;
     MV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    hipStream_t all[4] = {p->s_vol, p->s_main, p->s_back, p->s_side};
+    hipStream_t all[5] = {p->s_vol, p->s_main, p->s_back, p->s_side, p->s_sel};
     int rc = MV_OK;
     for (hipStream_t q : all) {
+        if (!q) continue;
         if (hipEventRecord(e, q) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, e, 0) != hipSuccess) rc = MV_ERR_LAUNCH;
     }
     (void)hipEventDestroy(e);
@@ -1157,6 +1219,11 @@ extern "C" int mv_frame_pipe_time_volume(mvFramePipe* p, int max_launches) {
         p->tv2.push_back(c2);
         MV_HIP(hipEventCreate(&c3));
         p->tv3.push_back(c3);
+        for (auto* v : {&p->tv4, &p->tv5, &p->tv6, &p->tv7}) {
+            hipEvent_t e;
+            MV_HIP(hipEventCreate(&e));
+            v->push_back(e);
+        }
     }
     p->n_timed = 0;
     p->timed_cap = max_launches;
@@ -1178,9 +1245,28 @@ extern "C" int mv_frame_pipe_timeline(mvFramePipe* p, float* ms, int cap_frames,
     MV_CHECK_ARG(p && n && cap_frames >= 0 && (cap_frames == 0 || ms));
     MV_HIP(hipStreamSynchronize(p->s_vol));
     MV_HIP(hipStreamSynchronize(p->s_main));
+    MV_HIP(hipStreamSynchronize(p->s_back));
+    if (p->s_sel) MV_HIP(hipStreamSynchronize(p->s_sel));
     const int m = p->n_timed < cap_frames ? p->n_timed : cap_frames;
     for (int i = 0; i < m; ++i) {
         hipEvent_t evs[4] = {p->tv0[i], p->tv1[i], p->tv2[i], p->tv3[i]};
+        for (int j = 0; j < 4; ++j)
+            if (hipEventElapsedTime(&ms[4 * i + j], p->tv0[0], evs[j]) != hipSuccess) ms[4 * i + j] = -1.f;
+    }
+    *n = m;
+    return MV_OK;
+}
+
+// ... and the backend side of the same frames: ms[4*i + {0,1,2,3}] = backend start, backend end (backend stream), pose_apply start,
+// solve end (solve stream); -1 where a frame was not finished (or had no keypoints)
+extern "C" int mv_frame_pipe_timeline_backend(mvFramePipe* p, float* ms, int cap_frames, int* n) {
+    MV_CHECK_ARG(p && n && cap_frames >= 0 && (cap_frames == 0 || ms));
+    MV_TRY(flush_jobs(p));
+    MV_HIP(hipStreamSynchronize(p->s_back));
+    MV_HIP(hipStreamSynchronize(p->s_side));
+    const int m = p->n_timed < cap_frames ? p->n_timed : cap_frames;
+    for (int i = 0; i < m; ++i) {
+        hipEvent_t evs[4] = {p->tv4[i], p->tv5[i], p->tv6[i], p->tv7[i]};
         for (int j = 0; j < 4; ++j)
             if (hipEventElapsedTime(&ms[4 * i + j], p->tv0[0], evs[j]) != hipSuccess) ms[4 * i + j] = -1.f;
     }

@@ -823,6 +823,14 @@ class NativeHotPath:
         ops.L.check(self._lib.mv_frame_pipe_timeline(self._pipe, buf, cap, ops.C.byref(n)), "mv_frame_pipe_timeline")
         return [tuple(buf[4 * i: 4 * i + 4]) for i in range(n.value)]
 
+    def timeline_backend_ms(self) -> list:
+        """[(backend start, backend end, pose_apply start, solve end)] per timed frame, same time base as :meth:`timeline_ms`."""
+        cap = 1 << 14
+        buf = (ops.C.c_float * (4 * cap))()
+        n = ops.C.c_int(0)
+        ops.L.check(self._lib.mv_frame_pipe_timeline_backend(self._pipe, buf, cap, ops.C.byref(n)), "mv_frame_pipe_timeline_backend")
+        return [tuple(buf[4 * i: 4 * i + 4]) for i in range(n.value)]
+
     def synchronize(self) -> None:
         if self._pipe is not None:
             ops.L.check(self._lib.mv_frame_pipe_sync(self._pipe, None, 1), "mv_frame_pipe_sync")
