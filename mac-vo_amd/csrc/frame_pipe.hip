@@ -74,6 +74,7 @@ struct Pending {
     int maps, maps_prev, cand;
     bool has_cand;
     int ti;   // timing slot of the frame (mv_frame_pipe_time_volume), -1: not timed
+    long sel_job = -1;   // MV_PIPE_SELECTOR_ON=late: the finish (job) that issues this frame's selector segment; -1: already issued
 };
 
 // The selector segment of a frame (upsampling / epilogue / selector(s) / count copies): everything behind the frame's last lookup.
@@ -99,6 +100,8 @@ struct FinishJob {
     bool seeded;
     std::vector<int64_t> perm;      // explicit permutations [lanes, cap] (asynchronous issue: a copy of the caller's array)
     float* pose_sink;
+    bool has_sel;                   // MV_PIPE_SELECTOR_ON=late: the selector segment of the newest enqueued frame rides behind this backend
+    SelSeg sel;
 };
 
 struct Carver {   // bump allocator over the arena (or a size counter when base == nullptr)
@@ -232,6 +235,7 @@ static int wait_if_pending(hipStream_t s, hipEvent_t e) {
 #define MV_ASYNC_DEFAULT(p) (1)   // measured (640x480, f16x2 volume): one lane 6.01 k vs 5.26 k frames/s, 32 lanes 7.56 k vs 7.54 k
 static int wait_issued(mvFramePipe* p, long n);
 static int flush_deferred(mvFramePipe* p);
+static int issue_selector_segment(mvFramePipe* p, const SelSeg& d);
 static int flush_jobs(mvFramePipe* p);
 static void launch_thread_main(mvFramePipe* p);
 
@@ -548,7 +552,8 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
         // Measured (640x480, f16x2 volume): one lane 5.38 k vs 4.94 k frames/s (period 183 vs 198 us), 32 lanes 7.43 k vs 7.64 k: the
         // default follows the lane count; MV_PIPE_SELECTOR_ON=main|back forces it.
         const char* e = getenv("MV_PIPE_SELECTOR_ON");
-        p->sel_on_back = e ? (strcmp(e, "back") == 0 ? 1 : strcmp(e, "own") == 0 ? 2 : strcmp(e, "vol") == 0 ? 3 : 0) : (p->lanes <= 2 ? 1 : 0);
+        p->sel_on_back = e ? (strcmp(e, "back") == 0 ? 1 : strcmp(e, "own") == 0 ? 2 : strcmp(e, "vol") == 0 ? 3 : strcmp(e, "late") == 0 ? 4 : 0)
+                           : (p->lanes <= 2 ? 1 : 0);
     }
     {
         // Where the operand pack of frame f + 1 runs.  It needs only the feature maps, so it can run beside GEMM(f) on another of
@@ -656,7 +661,7 @@ extern "C" int mv_frame_pipe_enqueue_volume(mvFramePipe* p, const mvFrameInputs*
     MV_TRY(issue_volume(p, in, in_stream));
     // MV_PIPE_SELECTOR_ON=vol: the newest enqueued frame's selector segment goes behind this GEMM on the GEMM's stream — it needs that
     // frame's lookups, which finish about when this GEMM does, and then runs in the gap the GEMM stream idles in anyway, alone on the chip
-    return flush_deferred(p);
+    return p->sel_on_back == 3 ? flush_deferred(p) : MV_OK;
 }
 
 static int issue_selector_segment(mvFramePipe* p, const SelSeg& d) {
@@ -666,7 +671,7 @@ static int issue_selector_segment(mvFramePipe* p, const SelSeg& d) {
     const bool timed = d.timed, with_selector = d.with_selector, up = d.up;
     hipStream_t s = p->s_main;   // (same stream as the lookups: in order behind them)
     if (p->sel_on_back) {   // everything behind the lookups continues on another stream (in order with the backends it must follow)
-        s = p->sel_on_back == 2 ? p->s_sel : p->sel_on_back == 3 ? p->s_vol : p->s_back;
+        s = p->sel_on_back == 2 ? p->s_sel : p->sel_on_back == 3 ? p->s_vol : p->s_back;   // (1 and 4: the backend stream)
         MV_HIP(hipStreamWaitEvent(s, p->e_lk[k], 0));
     }
     // maps slot m and candidate slot k were last read by the backend of frame f - 2 (f - 3 for the maps) on `back`
@@ -744,6 +749,14 @@ static int flush_deferred(mvFramePipe* p) {
     p->deferred_valid = false;
     return issue_selector_segment(p, p->deferred);
 }
+// in front of a wait for / finish of the OLDEST pending frame: its selector segment must have been issued.  MV_PIPE_SELECTOR_ON=late keeps
+// the newest frame's segment for the finish that is about to happen, unless that newest frame IS the oldest pending one; a segment that
+// travelled with an earlier finish has been issued once the launch thread is through with that job.
+static int selector_of_front_issued(mvFramePipe* p) {
+    if (p->sel_on_back != 4 || p->pending.size() <= 1) MV_TRY(flush_deferred(p));
+    const long sj = p->pending.empty() ? -1 : p->pending.front().sel_job;
+    return sj >= 0 ? wait_issued(p, sj + 1) : MV_OK;
+}
 
 extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_stream, int with_selector) {
     MV_CHECK_ARG(p && in && in->fmap1 && in->fmap2);
@@ -795,13 +808,18 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
     SelSeg d{*in, f, k, m, ti, p->newest_maps, timed, with_selector != 0, up,
              p->n_fin - MAX_PENDING + (long)p->pending.size()};
     if (p->sel_on_back) MV_HIP(hipEventRecord(p->e_lk[k], s));   // the segment continues on another stream behind the last lookup
-    if (p->sel_on_back == 3 && with_selector) {
-        p->deferred = d;            // issued behind the next frame's GEMM (mv_frame_pipe_enqueue_volume) or by whoever needs it first
+    // MV_PIPE_SELECTOR_ON=late: with two unfinished frames in front of it (the steady state of a 3-deep pipeline) the segment is
+    // handed to the NEXT finish, which issues it right behind that frame's backend: the backend stream then holds
+    // backend(f - 2), selector(f), backend(f - 1), selector(f + 1) ... — a backend waits behind ONE queued selector segment (whose
+    // lookups are done by then) instead of two that still wait for their lookups (frame latency: see DESIGN, backend timeline)
+    const bool late = p->sel_on_back == 4 && with_selector && p->pending.size() >= 2;
+    if ((p->sel_on_back == 3 && with_selector) || late) {
+        p->deferred = d;            // issued behind the next frame's GEMM (mv_frame_pipe_enqueue_volume) / the next backend, or by whoever needs it first
         p->deferred_valid = true;
     } else {
         MV_TRY(issue_selector_segment(p, d));
     }
-    if (with_selector) p->pending.push_back(Pending{m, p->newest_maps, k, true, ti});
+    if (with_selector) p->pending.push_back(Pending{m, p->newest_maps, k, true, ti, -1});
     p->newest_maps = m;
     p->n_enq = f + 1;
     return MV_OK;
@@ -809,7 +827,7 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
 
 extern "C" int mv_frame_pipe_wait_candidates(mvFramePipe* p, int32_t* n_cand) {
     MV_CHECK_ARG(p && n_cand && !p->pending.empty());
-    MV_TRY(flush_deferred(p));
+    MV_TRY(selector_of_front_issued(p));
     const Pending& pd = p->pending.front();
     MV_HIP(hipEventSynchronize(p->e_cand[pd.cand]));
     for (int l = 0; l < p->lanes; ++l) n_cand[l] = p->h_count[pd.cand][4 * l];
@@ -865,6 +883,13 @@ static int finish_host(mvFramePipe* p, const int32_t* n_sel, float* pose_sink, F
     j.pd = p->pending.front();
     p->pending.pop_front();
     j.g = p->n_fin;
+    j.has_sel = false;
+    if (p->sel_on_back == 4 && p->deferred_valid && !p->pending.empty()) {   // (never the frame being finished: flush_deferred ran first)
+        j.sel = p->deferred;
+        j.has_sel = true;
+        p->deferred_valid = false;
+        p->pending.back().sel_job = j.g;
+    }
     j.n_max = n_max;
     j.pose_sink = pose_sink;
     Backend& b = p->be[j.g & 1];
@@ -1016,7 +1041,8 @@ static void launch_thread_main(mvFramePipe* p) {
             j = std::move(p->jobs.front());
             p->jobs.pop_front();
         }
-        const int rc = finish_issue(p, j, j.seeded ? draw_perms(p, j) : j.perm.data());
+        int rc = finish_issue(p, j, j.seeded ? draw_perms(p, j) : j.perm.data());
+        if (rc == MV_OK && j.has_sel) rc = issue_selector_segment(p, j.sel);
         {
             std::lock_guard<std::mutex> lk(p->mu);
             p->issued = j.g + 1;
@@ -1036,7 +1062,10 @@ static int wait_issued(mvFramePipe* p, long n) {
 static int flush_jobs(mvFramePipe* p) { return wait_issued(p, p->n_fin); }
 
 static int submit_or_issue(mvFramePipe* p, FinishJob& j, const int64_t* perm_host) {
-    if (!p->async_backend) return finish_issue(p, j, j.seeded ? draw_perms(p, j) : perm_host);
+    if (!p->async_backend) {
+        MV_TRY(finish_issue(p, j, j.seeded ? draw_perms(p, j) : perm_host));
+        return j.has_sel ? issue_selector_segment(p, j.sel) : MV_OK;
+    }
     if (!j.seeded && j.n_max > 0) {
         const size_t cap = p->c.num_point > 0 ? p->c.num_point : 1;
         j.perm.assign(perm_host, perm_host + (size_t)p->lanes * cap);
@@ -1054,7 +1083,7 @@ static int submit_or_issue(mvFramePipe* p, FinishJob& j, const int64_t* perm_hos
 // wait_candidates + permutations (per-lane generators of mv_frame_pipe_seed_lanes) + finish in one host call
 extern "C" int mv_frame_pipe_finish_seeded(mvFramePipe* p, float* pose_sink, int32_t* n_cand_out, int32_t* n_sel_out) {
     MV_CHECK_ARG(p && !p->pending.empty() && (int)p->rng.size() == p->lanes);
-    MV_TRY(flush_deferred(p));
+    MV_TRY(selector_of_front_issued(p));
     const Pending& pd = p->pending.front();
     MV_HIP(hipEventSynchronize(p->e_cand[pd.cand]));
     FinishJob j{};
@@ -1076,7 +1105,7 @@ extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, co
     MV_CHECK_ARG(p && n_sel && !p->pending.empty());
     for (int l = 0; l < p->lanes; ++l)
         MV_CHECK_ARG(n_sel[l] >= 0 && n_sel[l] <= p->c.num_point && (n_sel[l] == 0 || perm_host));
-    MV_TRY(flush_deferred(p));
+    MV_TRY(selector_of_front_issued(p));
     FinishJob j{};
     j.seeded = false;
     MV_TRY(finish_host(p, n_sel, pose_sink, j));
