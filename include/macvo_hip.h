@@ -621,6 +621,9 @@ int mv_frame_pipe_wait_tracked(mvFramePipe* p, int32_t* n_valid, int32_t* n_cand
 int mv_frame_pipe_map_points(mvFramePipe* p, const int64_t* perm_host, int n_sel, const float* image_dev,
                              const mvMapStores* stores /* host, or NULL */);
 int mv_frame_pipe_seed_lanes(mvFramePipe* p, const uint64_t* seeds /* [lanes] host */);
+/* host-only (no GPU): `calls` successive torch.randperm(n[i], generator=g)[:k] of ONE generator g = torch.Generator().manual_seed(seed),
+ * as the seeded finish draws them for a lane (Module/KeypointSelector.py:331,404); out [calls, k] (row i: min(k, n[i]) entries) */
+int mv_randperm_heads(uint64_t seed, const int64_t* n, int calls, int k, int64_t* out);
 int mv_frame_pipe_finish_seeded(mvFramePipe* p, float* pose_sink, int32_t* n_cand_out, int32_t* n_sel_out);
 /* register the newest FINISHED frame in a device-resident map (mv_map_append on the pipe's own streams, no copies; lanes = 1):
  * frame_idx = the map index the frame receives (= frames pushed so far), prev_frame = the previous keyframe's index; the

@@ -161,6 +161,7 @@ SIGNATURES = {
     "mv_frame_pipe_sync": (C.c_int, [_P, _P, C.c_int]),
     "mv_frame_pipe_time_volume": (C.c_int, [_P, C.c_int]),
     "mv_frame_pipe_volume_times": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
+    "mv_randperm_heads": (C.c_int, [C.c_uint64, _P, C.c_int, C.c_int, _P]),
     "mv_frame_pipe_timeline": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     "mv_frame_pipe_timeline_backend": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     "mv_frame_pipe_buffer": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),

@@ -687,9 +687,10 @@ extern "C" int mv_corr_volume_packed(const void* packed1, const void* packed2, f
         attr_done = true;
     }
     // MV_SPLIT_WAVES=8: the f16x2 kernel as ONE 8-wave workgroup per CU (two waves per SIMD, each wave one 32-column block).  Built to
-    // hide the fillers of one wave behind the MFMAs of the other; measured it is no faster (74.7 vs 74.4 us alone) — with N(0,1)
-    // operands both forms sit at the chip's POWER limit (all-zero operands, same instruction stream: 55-57 us; every filler class
-    // knocked out: 55 us) — and it costs the co-running small kernels their registers (one-lane pipeline 4.40 k vs 4.84 k frames/s).
+    // hide the fillers of one wave behind the MFMAs of the other; measured it is no faster (74.7 vs 74.4 us alone; all-zero operands
+    // 54.7 vs 57.1 us — the zero-data speed-up is the clock: identical cycle counters, profiles/r03_split_wait_counters.log — and inside
+    // its cycles the matrix pipe is 46 % busy in both forms: what the waves wait for is shared, barriers and the memory system, not issue
+    // slots) and it costs the co-running small kernels their registers (one-lane pipeline 4.40 k vs 4.84 k frames/s).
     static int waves = -1;
     if (waves < 0) { const char* e = getenv("MV_SPLIT_WAVES"); waves = (e && atoi(e) == 8) ? 8 : 4; }
     // column regions: one region's B planes (nc / R sub-tiles x 64 rows x C x 2 B x pieces) <= 4 MB.  Measured at 640x480 (7.4 MB

@@ -1101,6 +1101,20 @@ extern "C" int mv_frame_pipe_finish_seeded(mvFramePipe* p, float* pose_sink, int
     return submit_or_issue(p, j, nullptr);
 }
 
+// Host-only probe of the driver's permutation generator (no GPU, no pipe): `calls` successive `torch.randperm(n[i])[:k]` of one
+// generator seeded with `seed`, written to out[i * k .. i * k + min(k, n[i])) — what mv_frame_pipe_finish_seeded draws for one lane
+// frame after frame.  Lets the CPU test suite pin the generator against torch itself.
+extern "C" int mv_randperm_heads(uint64_t seed, const int64_t* n, int calls, int k, int64_t* out) {
+    MV_CHECK_ARG(n && out && calls >= 0 && k >= 0);
+    std::mt19937 eng((uint32_t)(seed & 0xffffffffull));
+    std::vector<int32_t> scratch;
+    for (int i = 0; i < calls; ++i) {
+        MV_CHECK_ARG(n[i] >= 0 && n[i] < ((int64_t)1 << 31));
+        randperm_head(eng, n[i], k, scratch, out + (size_t)i * k);
+    }
+    return MV_OK;
+}
+
 extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, const int32_t* n_sel, float* pose_sink) {
     MV_CHECK_ARG(p && n_sel && !p->pending.empty());
     for (int l = 0; l < p->lanes; ++l)

@@ -199,3 +199,30 @@ def test_bench_gpus_n_launches_itself_and_gathers(tmp_path):
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["gather_ok"] is True and line["dry_collectives"] is True
     assert [d["rank"] for d in line["rank_ids"]] == [0, 1] and line["track_lengths"] == [5, 5]
     assert line["value"] is None                       # a dry run can never be mistaken for a measurement
+
+
+def test_native_permutation_generator_is_torch_randperm():
+    """The frame driver's per-lane generator (std::mt19937 + partial Fisher-Yates + `discard` of the draws it skips,
+    `mv_frame_pipe_finish_seeded`) against torch itself on the CPU: successive `torch.randperm(n, generator=g)[:k]` of one
+    generator — ragged n from frame to frame, n < k, n = 0 / 1 / 2, 64-bit seeds (torch seeds its engine with the low 32 bits)."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from macvo_amd import _lib as L
+
+    lib = L.load()
+    for seed in (0, 1, 77, 123456789, 2 ** 40 + 5, 2 ** 63 + 11):
+        ns = [8000, 7313, 200, 150, 1, 0, 2, 31, 100000, 4096, 9001]
+        k = 200
+        g = torch.Generator().manual_seed(seed if seed < 2 ** 63 else seed - 2 ** 64)
+        want = [torch.randperm(n, generator=g)[:k] for n in ns]
+        n_arr = np.asarray(ns, dtype=np.int64)
+        out = np.full((len(ns), k), -1, dtype=np.int64)
+        rc = lib.mv_randperm_heads(C.c_uint64(seed), n_arr.ctypes.data, len(ns), k, out.ctypes.data)
+        assert rc == 0
+        for i, (n, w) in enumerate(zip(ns, want)):
+            m = min(k, n)
+            assert np.array_equal(out[i, :m], w.numpy()), (seed, i, n)
+            assert (out[i, m:] == -1).all()
