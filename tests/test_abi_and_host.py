@@ -226,3 +226,35 @@ def test_native_permutation_generator_is_torch_randperm():
             m = min(k, n)
             assert np.array_equal(out[i, :m], w.numpy()), (seed, i, n)
             assert (out[i, m:] == -1).all()
+
+
+def test_bench_roofline_object_contract():
+    """bench.py's `roofline` object (the driver's contract: bound / achieved / peak / unit / frac / traffic) for the three kinds of
+    volume kernel, from synthetic launch times: achieved = algorithmic (or, for the split kernels, executed) work / time, frac =
+    achieved / peak, SURVEY §8(d)'s per-unit work figures."""
+    import importlib.util
+    import types
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n_q, C = 4800, 256
+    flops, nbytes = bench.volume_work(1, n_q, C, 4)
+    assert flops == 2 * 2.0 * n_q * n_q * C and nbytes == 2 * (2.0 * n_q * C * 4 + 4.0 * n_q * n_q)
+    ms = [0.1] * 200                                                   # 100 us per launch
+    for kw, bound, peak, work in (
+        (dict(feat_dtype="f32", layout="chw", volume_precision="exact"), "mfma", bench.PEAK_F32_MFMA_TFLOPS, flops / 1e12),
+        (dict(feat_dtype="f32", layout="chw", volume_precision="f16x2"), "mfma", bench.PEAK_BF16_MFMA_TFLOPS, 3 * flops / 1e12),
+        (dict(feat_dtype="f32", layout="chw", volume_precision="bf16x3"), "mfma", bench.PEAK_BF16_MFMA_TFLOPS, 6 * flops / 1e12),
+        (dict(feat_dtype="f16", layout="hwc", volume_precision="exact"), "hbm", bench.PEAK_HBM_GBS, None),
+    ):
+        r = bench.roofline_of(ms, types.SimpleNamespace(**kw), 1, n_q, C, 20, traffic=123.0)
+        assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us"} <= set(r)
+        assert r["bound"] == bound and r["peak"] == peak and r["traffic"] == 123.0 and r["avg_launch_us"] == 100.0
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+        if work is not None:
+            assert abs(r["achieved"] - work / 1e-4) < 0.02 * r["achieved"] and r["unit"] == "TFLOP/s"
+        else:
+            b16 = bench.volume_work(1, n_q, C, 2)[1]
+            assert abs(r["achieved"] - b16 / 1e-4 / 1e9) < 0.02 * r["achieved"] and r["unit"] == "GB/s"
