@@ -19,7 +19,7 @@ Besides the contract's fields the JSON line carries
                 (Evaluation/MetricsSeq.py:9-16 formula); rte_vs_oracle is BASELINE.json's "pose RTE vs reference"
   config4       a short second measurement at BASELINE configs[4] (32 lanes, B = 64 pairs per GEMM), N = 1 only
   decoder_loop  the HIP lookups / upsamplings interleaved with the PyTorch-ROCm kernels of a stand-in decoder network
-                (mac-vo_amd/decoder_harness.py, loop structure of covhead.py:85-135) next to the back-to-back figure, N = 1 only
+                (tools/decoder_harness.py, loop structure of covhead.py:85-135) next to the back-to-back figure, N = 1 only
 """
 from __future__ import annotations
 
@@ -56,7 +56,7 @@ def parse_args():
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--feat-dtype", choices=["f32", "f16", "bf16"], default="f32")
     ap.add_argument("--layout", choices=["chw", "hwc"], default="chw")
-    ap.add_argument("--volume-precision", choices=["f16x2", "bf16x3", "exact", "split3", "split2"], default="f16x2",
+    ap.add_argument("--volume-precision", choices=["f16x2", "bf16x3", "exact", "split3", "split2"], default=None,
                     help="fp32 features: 'f16x2' (default) = rows scaled by a power of two into fp16's range, two fp16 pieces, three "
                          "products on the 16-bit matrix pipe, fp32 accumulate, scales undone exactly; 'bf16x3' = three bf16 pieces, six "
                          "products — both meet the parity bar of 'exact', not bitwise (the reference runs this GEMM in TF32, "
@@ -65,6 +65,8 @@ def parse_args():
     ap.add_argument("--exact-steps", type=int, default=60, help="steps of the extra legs with the other volume precisions beside the default line; 0 = skip")
     ap.add_argument("--graph", choices=["disp", "reproj", "icp"], default="disp")
     ap.add_argument("--pool", type=int, default=24, help="distinct synthetic frames (closed trajectory) kept in HBM")
+    ap.add_argument("--feat-pool", type=int, default=0, help="distinct feature-map / lookup-coordinate sets among the resident frames "
+                    "(0 = one per frame: every frame reads its own 19.7 MB of features; rounds 1-3 cycled two sets)")
     ap.add_argument("--cpu-frames", type=int, default=120, help="frames timed for the CPU baseline (rank 0, N=1 only)")
     ap.add_argument("--parity-frames", type=int, default=48, help="free-running frames compared with the oracle (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the parity leg")
@@ -152,7 +154,7 @@ def roofline_of(ms, args, lanes, n_q, C, timed_region_launches, traffic=None):
                 "algorithmic_vs_fp32_mfma_peak": round(flops / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                 "note": f"achieved = {int(nprod)} 16-bit piece products per algorithmic fp32 product x algorithmic FLOPs / time, against the dense 16-bit "
                         "MFMA peak (2.5 PFLOP/s; with N(0,1) operands the chip's power limit holds a bare v_mfma_f32_32x32x16_bf16 stream at "
-                        "~1.89 PFLOP/s = 0.76, tools/scratch/mfma16_probe.*; this kernel runs 1.3x faster on all-zero operands with identical cycle "
+                        "~1.89 PFLOP/s = 0.76, profiles/probes/mfma16_probe.*; this kernel runs 1.3x faster on all-zero operands with identical cycle "
                         "counters = the clock, and inside its cycles the matrix pipe is busy 46 % (f16x2) / 63 % (bf16x3), "
                         "profiles/r03_split_wait_counters.log); algorithmic_vs_fp32_mfma_peak = algorithmic fp32 FLOPs / time against the 157.3 TFLOP/s "
                         "fp32-MFMA peak that bounds ANY exact-fp32 form of this GEMM (> 1 = beyond that roofline); the operand pack is a "
@@ -197,6 +199,8 @@ def main():
     from macvo_amd.pipeline import Camera, FrameInputs, HotPath, HotPathConfig, NativeHotPath, stack_lanes
     from tests import synth
 
+    if args.volume_precision is None:
+        args.volume_precision = ops.default_volume_precision()      # the library's one default (f16x2): bench, plugins and drivers agree
     H, W, C = args.height, args.width, args.channels
     h8, w8 = H // 8, W // 8
     n_q = h8 * w8
@@ -209,7 +213,7 @@ def main():
 
     # ---- synthetic, seeded, per-rank sequence (closed trajectory so the pool can be cycled without a seam)
     cam, frames_cpu, truth = synth.make_sequence(args.pool, H, W, C=C, iters=args.iters, seed=1000 + rank, feat_dtype=fdt,
-                                                 pool=2, closed_loop=True)
+                                                 pool=args.feat_pool or args.pool, closed_loop=True)
     if args.layout == "hwc":
         for fr in frames_cpu:
             fr["fmap1"] = fr["fmap1"].permute(0, 2, 3, 1).contiguous()
@@ -518,7 +522,7 @@ def main():
     decoder_loop = None
     if rank == 0 and world == 1 and not args.no_decoder_leg and args.lanes == 1 and args.feat_dtype == "f32" and args.layout == "chw":
         try:
-            from macvo_amd.decoder_harness import DecoderLoopHarness
+            from tools.decoder_harness import DecoderLoopHarness
 
             net = DecoderLoopHarness(dec_dtype=torch.bfloat16, depth=args.iters).to(dev).eval()
             vol = ops.corr_volume(frames[0].fmap1, frames[0].fmap2)

@@ -535,9 +535,9 @@ typedef struct {
     int32_t radius;            /* lookup radius (4) */
     int32_t feat_dtype;        /* MV_F32 | MV_F16 | MV_BF16 */
     int32_t layout;            /* MV_LAYOUT_* of the feature maps */
-    int32_t volume_split;      /* 0 exact fp32 | MV_PACK_BF16X3 (5): fp32 features of either layout packed on the device
-                                  (mv_volume_pack, beside the previous frame's GEMM) + mv_corr_volume_packed, shapes it does not
-                                  cover run the exact kernel | 3 | 2: fp32 HWC features through the round-1 plane split, multiplied
+    int32_t volume_split;      /* 0 exact fp32 | MV_PACK_F16X2 (6, the host side's default) | MV_PACK_BF16X3 (5): fp32 features of either
+                                  layout packed on the device (mv_volume_pack, beside the previous frame's GEMM) +
+                                  mv_corr_volume_packed, shapes it does not cover run the exact kernel | 3 | 2: fp32 HWC features through the round-1 plane split, multiplied
                                   as MV_BF16X3 / MV_BF16X2 */
     int32_t selector_mode;     /* MV_KP_NODEPTH | MV_KP_FULL */
     int32_t kp_kernel_size, kp_mask_width;
@@ -587,6 +587,7 @@ enum {
 };
 
 size_t mv_frame_pipe_arena_bytes(const mvFramePipeConfig* cfg);           /* 0 = invalid configuration */
+int mv_frame_pipe_max_pending(void);   /* how many tracked frames may be enqueued and not yet finished (the slot rotation this library was built with) */
 /* arena: device memory, 256-byte aligned, >= mv_frame_pipe_arena_bytes; must outlive the pipe */
 int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, size_t arena_bytes, mvFramePipe** out);
 void mv_frame_pipe_destroy(mvFramePipe* p);

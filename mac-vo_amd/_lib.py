@@ -142,6 +142,7 @@ SIGNATURES = {
                                           C.c_int, _P]),
     "mv_obs_filter_lanes": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_int, _P, C.c_int, _P, _P, _P]),
     "mv_frame_pipe_arena_bytes": (C.c_size_t, [C.POINTER(mvFramePipeConfig)]),
+    "mv_frame_pipe_max_pending": (C.c_int, []),
     "mv_frame_pipe_create": (C.c_int, [C.POINTER(mvFramePipeConfig), _P, C.c_size_t, C.POINTER(_P)]),
     "mv_frame_pipe_destroy": (None, [_P]),
     "mv_frame_pipe_set_pose": (C.c_int, [_P, _P]),

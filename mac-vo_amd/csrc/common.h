@@ -8,10 +8,10 @@
 
 // live rows per lane of a lane-batched launch (kernel argument, passed by value: no H2D copy, no device table)
 // Volume epilogue stores: non-temporal.  Measured on MI355X: a store-only kernel in the MFMA C layout writes 184 MB in 28.7 us with
-// plain stores and 36.2 us with non-temporal ones (tools/scratch/store_probe.*), but the volume kernels themselves are not bound
+// plain stores and 36.2 us with non-temporal ones (profiles/probes/store_probe.*), but the volume kernels themselves are not bound
 // there (fp32: 193 us either way; 16-bit streaming: 41 us either way) and IN THE PIPELINE, where the lookups / selectors of other
 // frames run beside the volume, non-temporal stores win because 184 MB per frame do not sweep the L2s: fp32 3.38-3.41 k vs
-// 3.31 k frames/s, 16-bit 5.13 k vs 4.83 k, 3 lanes 4.09 k vs 4.05 k (tools/scratch/ab_nt.sh).  -DMV_PLAIN_STORES builds the
+// 3.31 k frames/s, 16-bit 5.13 k vs 4.83 k, 3 lanes 4.09 k vs 4.05 k (profiles/probes/ab_nt.sh).  -DMV_PLAIN_STORES builds the
 // other variant for A/B.
 #ifndef MV_PLAIN_STORES
 #define MV_VOL_STORE(v, p) __builtin_nontemporal_store((v), (p))

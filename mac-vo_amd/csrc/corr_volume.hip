@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void corr_volume_f32_chw(const float* __restri
 // are 256 B apart: every fragment read is ONE base register + immediates (ds_read2st64_b32), 126 registers in total; the
 // register-staged next K step goes to LDS one float4 at a time between the MFMA groups.  The k loop order is unchanged
 // (k ascending per output element): results are bitwise identical to the kernel above.
-// Measured (tools/scratch/gemm3_probe.*): N = 4800, B = 2: 207.2 -> 190 us (72.4 -> 79 % of 157.3 TFLOP/s);
+// Measured (profiles/probes/gemm3_probe.*): N = 4800, B = 2: 207.2 -> 190 us (72.4 -> 79 % of 157.3 TFLOP/s);
 // steady state (B = 16): 78.3 -> 80.4 %, + interleaved stores 81.8 %.  Measured and NOT adopted: 256x128 / 256x256
 // workgroup tiles (78.6 / 76.5 %), BK 8 / 32 / 64 (78.9 / 78.5 / 63 %), 1 / 3 / 4 workgroups per CU (74.6 / 80.5 / 77.8 %),
 // fragment prefetch two groups ahead (no gain), the K stream running across tile boundaries (no cold prologue: no gain),
@@ -989,7 +989,7 @@ __global__ __launch_bounds__(256) void corr_volume_h_hwc(const uint16_t* __restr
 //     sub-tiles (64 x C x 2 B) stream through a 2-slot LDS ring: ~1.1 B loaded per B stored instead of 2.0 for 128x128 tiles
 //     rebuilt per K step, and half the LDS reads;
 //   * the stores of sub-tile j are interleaved with the MFMAs of sub-tile j + 1 (two accumulator sets): in-kernel cycle
-//     stamps (tools/scratch/hstream_probe.*) showed the un-pipelined form spending 1800 of 4800 cycles per sub-tile just
+//     stamps (profiles/probes/hstream_probe.*) showed the un-pipelined form spending 1800 of 4800 cycles per sub-tile just
 //     ISSUING its 32 stores against the write path's back-pressure, with the memory system idle during the other phases;
 //   * one barrier per sub-tile, loads of sub-tile j + 2 in flight while j is multiplied.  The B loads are inline-asm
 //     global_load_dwordx4 with hand-placed s_waitcnt vmcnt(32): hipcc's own wait insertion merges the memory state of every
@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // region.  The list is cut into 8 equal runs, one per XCD (workgroup id % 8 = XCD under round-robin dispatch), and each
     // XCD's run into equal runs for its gridDim / 8 workgroups: what an XCD reads at any time is ONE region's B rows (host picks
     // R so that this is ~1.2 MB, re-read once per band) plus the bands its workgroups are on — resident in its 4 MB L2 while
-    // 23 MB of output stream through it.  Measured (tools/scratch/store_probe.py): L2-hitting reads beside the 184 MB write stream
+    // 23 MB of output stream through it.  Measured (profiles/probes/store_probe.py): L2-hitting reads beside the 184 MB write stream
     // are free, L2-missing ones cost ~7 us per 45 MB — with the plain band-major split the kernel fetched 66-132 MB per launch.
     const int per = nb * nc, T = B * per;        // T < 2^31
     int it, it_end;
@@ -1619,7 +1619,7 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
                     hipLaunchKernelGGL(corr_volume_f32_sched, dim3(slots), block, 0, s, a, b, out, C, N1, vs);
                 } else {
                     // LDS-DMA staging (default): 2 = BK 32 x 2 stages, 3 / 4 = BK 16 x 3 / 4 stages; MV_VOL_DMA=16 -> 3, =0 -> the
-                    // register-staged tile.  Measured (tools/scratch/fvol_probe.py, 640x480, B = 2, alone): register-staged 185.8 us,
+                    // register-staged tile.  Measured (profiles/probes/fvol_probe.py, 640x480, B = 2, alone): register-staged 185.8 us,
                     // BK 16 x 3 stages 182.5 (x 4 stages: 182.5), BK 32 x 2 stages 175.7 us = 0.854 of the fp32 MFMA peak (1280x720: 0.878);
                     // in the frame pipeline 3.43-3.45 k / 3.47-3.54 k / 3.39 k frames/s for BK 32 / BK 16 / register-staged at one lane
                     // (the 128 KB of LDS two BK-32 workgroups hold leave the co-running small kernels 32 KB per CU) and

@@ -39,6 +39,7 @@
 #include "vol_asm.h"
 #include <type_traits>
 #include <algorithm>
+#include <atomic>
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -57,7 +58,8 @@ namespace {
 // F16 (two fp16 pieces, 11 + 11 bits): fp16 has 5 exponent bits, so every ROW (one pixel's feature vector) is first scaled by a
 // power of two 2^sh that puts its largest magnitude into [2^14, 2^15) — exact, and undone exactly by the GEMM's epilogue
 // (v_ldexp_f32 by -(sh_i + sh_j)); the row's `sh` goes into the int32 table behind the units.  With the scale the pieces carry
-// x to 2^-22 |x| + 2^-40 max_k|x_k| whatever the magnitude of the row (|sh| <= 60: rows below 2^-46 or above 2^74 are not rescued).
+// x to 2^-22 |x| + 2^-40 max_k|x_k| whatever the magnitude of the row: `sh` is NOT clamped (round 4) — any finite non-zero row of the fp32
+// range, denormal maxima included (sh up to 14 + 149), lands in [2^14, 2^15), so no row can overflow fp16; v_ldexp_f32 takes the full int.
 template <int NP, bool F16>
 __global__ __launch_bounds__(256) void volume_pack_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                           uint16_t* __restrict__ p1, uint16_t* __restrict__ p2, int B, int C,
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256) void volume_pack_kernel(const float* __restric
         if (kh == 0) wmax[wave][li] = m;
         __syncthreads();
         m = fmaxf(fmaxf(wmax[0][li], wmax[1][li]), fmaxf(wmax[2][li], wmax[3][li]));
-        if (m > 0.f && m < INFINITY) sh = min(60, max(-60, 14 - ilogbf(m)));     // NaN / inf / all-zero rows: unscaled
+        if (m > 0.f && m < INFINITY) sh = 14 - ilogbf(m);                        // NaN / inf / all-zero rows: unscaled
         int* exps = reinterpret_cast<int*>(reinterpret_cast<char*>(out) + (size_t)B * nrb * KS * NP * 1024);
         if (wave == 0 && kh == 0) exps[((size_t)b * nrb + rb_d) * 32 + li_d] = sh;
     }
@@ -211,7 +213,7 @@ struct SplitCfg {
 #else
 #define MV_SPLIT_PROBE_SLACK 0
 #endif
-// Timing probes (tools/scratch/split_variants.sh builds the library with -DMV_SPLIT_PROBE): MV_SPLIT_DBG=<bits> knocks pieces of the
+// Timing probes (profiles/probes/split_variants.sh builds the library with -DMV_SPLIT_PROBE): MV_SPLIT_DBG=<bits> knocks pieces of the
 // kernel out at run time — 1 stores, 2 LDS-DMA, 4 barriers + waits, 8 B-fragment reads — results are then wrong by design.
 #ifdef MV_SPLIT_PROBE
 __constant__ int g_split_dbg = 0;
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 
     // W = how many of this wave's memory operations were issued behind the DMA pieces this half consumes (see SplitCfg).
     //
     // With ONE wave per SIMD every instruction that is not an MFMA has to fit into the 32-cycle shadow of one: measured on this
-    // kernel (tools/scratch/split_variants.sh), each class of filler issued in bursts cost the matrix pipe ~5 % (B-fragment reads,
+    // kernel (profiles/probes/split_variants.sh), each class of filler issued in bursts cost the matrix pipe ~5 % (B-fragment reads,
     // stores, DMA pieces: 122.6 -> 117 / 116 / 115 us when knocked out, 102 us with all of them gone; in-kernel stamps: 49 cycles
     // per MFMA instead of 32).  So the fillers are placed ONE BY ONE behind individual MFMAs ("slots", 2 NQ per k-step):
     //   slots 0 .. 2 NP - 1   one B-fragment read each for the NEXT k-step,
@@ -679,13 +681,18 @@ extern "C" int mv_corr_volume_packed(const void* packed1, const void* packed2, f
     MV_CHECK_ARG(((uintptr_t)packed1 & 15) == 0 && ((uintptr_t)packed2 & 15) == 0);
     if (!mv_corr_volume_packed_supported(B, C, N1, N2, mode)) return MV_ERR_UNSUPPORTED;
     const int np = pieces_of(mode);
-    static bool attr_done = false;
-    if (!attr_done) {
+    // the dynamic-LDS limit is a per-device function attribute: remembered per device ordinal (a process that drives a second GPU must
+    // set it there too); the flag array is only ever written with `true`, so concurrent first calls are benign
+    static std::atomic<bool> attr_done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_done[dev].load(std::memory_order_acquire)) {
         (void)hipFuncSetAttribute((const void*)corr_volume_split_stream<3, false, 16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)corr_volume_split_stream<2, true, 16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)corr_volume_split_stream<2, true, 16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
+        attr_done[dev].store(true, std::memory_order_release);
     }
+    if (cu_count() < 8) return MV_ERR_UNSUPPORTED;   // the persistent grid is a multiple of 8 workgroups (one run per XCD): callers fall back to the exact kernel
     // MV_SPLIT_WAVES=8: the f16x2 kernel as ONE 8-wave workgroup per CU (two waves per SIMD, each wave one 32-column block).  Built to
     // hide the fillers of one wave behind the MFMAs of the other; measured it is no faster (74.7 vs 74.4 us alone; all-zero operands
     // 54.7 vs 57.1 us — the zero-data speed-up is the clock: identical cycle counters, profiles/r03_split_wait_counters.log — and inside

@@ -357,6 +357,8 @@ extern "C" size_t mv_frame_pipe_arena_bytes(const mvFramePipeConfig* cfg) {
     return carve(&tmp, nullptr);
 }
 
+extern "C" int mv_frame_pipe_max_pending(void) { return MAX_PENDING; }
+
 extern "C" void mv_frame_pipe_destroy(mvFramePipe* p) {
     if (!p) return;
     if (p->worker.joinable()) {
@@ -845,6 +847,7 @@ extern "C" int mv_frame_pipe_wait_candidates(mvFramePipe* p, int32_t* n_cand) {
 // (tests/test_gpu_lanes.py::test_native_seeded_lanes_equal_torch_generators).
 extern "C" int mv_frame_pipe_seed_lanes(mvFramePipe* p, const uint64_t* seeds) {
     MV_CHECK_ARG(p && seeds);
+    MV_TRY(flush_jobs(p));   // the launch thread's draw_perms reads rng / perm_host
     p->rng.clear();
     for (int l = 0; l < p->lanes; ++l) p->rng.emplace_back((uint32_t)(seeds[l] & 0xffffffffull));
     const int cap = p->c.num_point > 0 ? p->c.num_point : 1;
@@ -1251,6 +1254,7 @@ extern "C" int mv_frame_pipe_sync(mvFramePipe* p, mvStream_t stream, int block_h
 
 extern "C" int mv_frame_pipe_time_volume(mvFramePipe* p, int max_launches) {
     MV_CHECK_ARG(p && max_launches >= 0 && max_launches <= (1 << 20));
+    MV_TRY(flush_jobs(p));   // finish_issue on the launch thread records into tv3..tv7 (which may reallocate below)
     while ((int)p->tv0.size() < max_launches) {
         hipEvent_t a, b;
         MV_HIP(hipEventCreate(&a));
@@ -1275,6 +1279,7 @@ extern "C" int mv_frame_pipe_time_volume(mvFramePipe* p, int max_launches) {
 
 extern "C" int mv_frame_pipe_volume_times(mvFramePipe* p, float* ms, int cap, int* n) {
     MV_CHECK_ARG(p && n && cap >= 0 && (cap == 0 || ms));
+    MV_TRY(flush_jobs(p));
     MV_HIP(hipStreamSynchronize(p->s_vol));
     const int m = p->n_timed < cap ? p->n_timed : cap;
     for (int i = 0; i < m; ++i) MV_HIP(hipEventElapsedTime(&ms[i], p->tv0[i], p->tv1[i]));
@@ -1286,6 +1291,7 @@ extern "C" int mv_frame_pipe_volume_times(mvFramePipe* p, float* ms, int cap, in
 // all relative to the first timed GEMM start (blocks until everything enqueued so far has finished)
 extern "C" int mv_frame_pipe_timeline(mvFramePipe* p, float* ms, int cap_frames, int* n) {
     MV_CHECK_ARG(p && n && cap_frames >= 0 && (cap_frames == 0 || ms));
+    MV_TRY(flush_jobs(p));   // in the 'late' selector placement tv3 is recorded on the launch thread
     MV_HIP(hipStreamSynchronize(p->s_vol));
     MV_HIP(hipStreamSynchronize(p->s_main));
     MV_HIP(hipStreamSynchronize(p->s_back));

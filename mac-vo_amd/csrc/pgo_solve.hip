@@ -108,7 +108,7 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double (*__restrict__ 
     __syncthreads();
 }
 
-// The 55-value reduction of a build pass, round 3.  In-kernel cycle stamps (tools/scratch/pgo_stamps.py) put the form above — per
+// The 55-value reduction of a build pass, round 3.  In-kernel cycle stamps (profiles/probes/pgo_stamps.py) put the form above — per
 // value four dependent DPP stages (two v_mov_dpp + one v_add_f64 each, with their wait states), eight v_readlane and three more
 // adds — at 13.7 k of the 30 k cycles of an LM step: fp64 has no DPP-fused add, and the readlane -> SGPR -> VALU round trip of 55
 // values is a long dependent instruction stream for the single wave of a SIMD.  Here only the three cheapest stages stay in

@@ -48,12 +48,26 @@ def _u8(t: torch.Tensor | None) -> torch.Tensor | None:
 
 
 # ------------------------------------------------------------------------------------------- A5
+def default_volume_precision() -> str:
+    """THE default arithmetic of the fp32 cost volume — one value for ``corr_volume``, ``pipeline.HotPathConfig``,
+    ``plugins.install_flowformer_hooks`` (hence every ``HIP_*`` frontend plugin, whose YAML key set is the reference's and cannot
+    carry the choice) and ``bench.py``: ``"f16x2"``, the fastest form that keeps the fp32 parity bar
+    (error <= ~2^-21 sum |a||b|, not narrower than the TF32 the reference runs this GEMM in, Frontend.py:275-277); shapes the
+    streaming kernel does not cover fall back to "exact".  ``MACVO_HIP_VOLUME_PRECISION=exact|bf16x3|f16x2`` overrides it."""
+    import os
+
+    v = os.environ.get("MACVO_HIP_VOLUME_PRECISION", "f16x2")
+    if v not in ("exact", "bf16x3", "f16x2"):
+        raise L.MacvoHipError(f"MACVO_HIP_VOLUME_PRECISION={v!r}: expected exact | bf16x3 | f16x2")
+    return v
+
+
 def corr_volume(f1: torch.Tensor, f2: torch.Tensor, layout: str = "chw", out: torch.Tensor | None = None,
-                precision: str = "exact") -> torch.Tensor:
+                precision: str | None = None) -> torch.Tensor:
     """All-pairs cost volume (FlowFormer ``MemoryEncoder.corr``; call site flownet.py:26-27).
 
     layout "chw": f1, f2 ``[B, C, H, W]`` (NCHW);  layout "hwc": ``[B, H, W, C]`` / ``[B, N, C]``.
-    precision (fp32 inputs only): "exact" = fp32 MFMA (bitwise fmaf chain); "f16x2" = rows scaled by a power of two into fp16's
+    precision (fp32 inputs only; None = ``default_volume_precision()``, 16-bit inputs ignore it): "exact" = fp32 MFMA (bitwise fmaf chain); "f16x2" = rows scaled by a power of two into fp16's
     range, two fp16 pieces, three products (error <= ~2^-21 sum |a||b|: inside the parity bar, the fastest form); "bf16x3" = operands packed into three bf16 pieces
     (``volume_pack``) + the streaming six-product kernel on the 16-bit matrix pipe, fp32-class accuracy (same parity bar as
     "exact", not bitwise), either layout, shapes the kernel does not cover fall back to "exact"; "split3" / "split2" = the
@@ -85,6 +99,8 @@ def corr_volume(f1: torch.Tensor, f2: torch.Tensor, layout: str = "chw", out: to
         out = torch.empty((B * N1, 1, H2, W2), dtype=torch.float32, device=f1.device)
     dt = _DT[f1.dtype]
     p1, p2 = f1, f2
+    if precision is None:
+        precision = default_volume_precision() if f1.dtype == torch.float32 else "exact"
     if precision in _PACK_MODE:
         if f1.dtype != torch.float32:
             raise L.MacvoHipError(f"corr_volume: precision='{precision}' splits float32 inputs")

@@ -93,9 +93,11 @@ class HotPathConfig:
     map_max_depth: float = 5.0           # MappingPointSelector args (Config/Experiment/MACVO/MACVO_Fast.yaml)
     map_max_depth_cov: float = 0.005
     map_mask_width: int = 32
-    volume_precision: str = "exact"      # fp32 features: "exact" fp32 MFMA | "bf16x3" packed three-piece split on the 16-bit
-                                         # matrix pipe, six products, fp32-class (same parity bar, not bitwise), either layout |
-                                         # "split3" / "split2" the round-1 tile kernels over pre-split planes (layout "hwc")
+    # fp32 features: "f16x2" (the default everywhere, ops.default_volume_precision(): per-row power-of-two scales + two fp16 pieces,
+    # three products on the 16-bit matrix pipe, error <= ~2^-21 sum |a||b|) | "bf16x3" three bf16 pieces, six products | "exact" fp32
+    # MFMA (bitwise fmaf chain) | "split3" / "split2" the round-1 tile kernels over pre-split planes (layout "hwc").  Shapes the
+    # streaming split kernel does not cover run the exact kernel.  16-bit features ignore it.
+    volume_precision: str = field(default_factory=ops.default_volume_precision)
     async_backend: bool | None = None    # native driver: issue a frame's backend launches from a second host thread (None: the
                                          # library's default / MV_PIPE_ASYNC_BACKEND); identical results either way
 
@@ -514,7 +516,9 @@ class NativeHotPath:
         self._images: list = []
         self._cap = max(self.cfg.num_point, 1)
         self._volume_ahead = os.environ.get("MV_PIPE_VOLUME_AHEAD", "1") != "0"   # A/B knobs of run()
-        self._depth = max(1, min(int(os.environ.get("MV_PIPE_MAX_DEPTH", "3")), int(os.environ.get("MV_PIPE_DEPTH", "3"))))
+        # frames in flight: never more than the slot rotation the library was built with (MV_MAX_PENDING, 3 in the stock build)
+        self._depth = max(1, min(int(ops.L.load().mv_frame_pipe_max_pending()), int(os.environ.get("MV_PIPE_MAX_DEPTH", "3")),
+                                 int(os.environ.get("MV_PIPE_DEPTH", "3"))))
         self.lm = ops.lm_default_params()
         self._pipe = None
         self._arena = None

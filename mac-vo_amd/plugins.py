@@ -179,6 +179,8 @@ class HIP_TwoFrame_PGO(IOptimizer[GraphInput, dict, GraphOutput]):
     completion event.  Results are identical in both modes.
     """
 
+    _autodiff_noted = False
+
     def __init__(self, config: SimpleNamespace) -> None:
         self.config = config
         self.is_parallel_mode = bool(config.parallel)
@@ -189,8 +191,14 @@ class HIP_TwoFrame_PGO(IOptimizer[GraphInput, dict, GraphOutput]):
 
     @staticmethod
     def init_context(config) -> dict:
-        if config.autodiff:
-            raise ValueError("HIP_TwoFrame_PGO implements the analytic-Jacobian graphs only (autodiff: false)")
+        if config.autodiff and not HIP_TwoFrame_PGO._autodiff_noted:
+            # `autodiff: true` (Config/Experiment/MACVO/Paper_Reproduce.yaml:103-109) selects the reference's autograd Jacobians; its
+            # analytic graphs are their verified equivalent (PyposeOptimizers.py:60-73 `verify_jacobian`, Graphs.py:151-231) and are
+            # what the HIP solver implements — accepted, and said once
+            HIP_TwoFrame_PGO._autodiff_noted = True
+            import warnings
+            warnings.warn("HIP_TwoFrame_PGO: autodiff: true — solving with the analytic Jacobians (the reference's verified equivalent)",
+                          stacklevel=2)
         dev = torch.device("cuda" if config.device == "cpu" else config.device)   # the solve itself always runs on the GPU
         return {"graph_type": config.graph_type, "device": dev, "lm": ops.lm_default_params(),
                 "stream": torch.cuda.Stream(device=dev) if config.parallel else None}
@@ -499,7 +507,7 @@ class HIP_CUDAGraph_FlowFormerCovFrontend(HIP_FlowFormerCovFrontend):
 
 
 # ----------------------------------------------------------------------------------------------- FlowFormer hooks
-def install_flowformer_hooks(model, volume_precision: str = "exact") -> list[str]:
+def install_flowformer_hooks(model, volume_precision: str | None = None) -> list[str]:
     """Route the three frontend kernels of ``FlowFormerCov`` through the HIP library by rebinding bound methods on the model
     instance — signatures and result layouts are those of the methods they replace, the network's own code is untouched:
 
@@ -512,9 +520,14 @@ def install_flowformer_hooks(model, volume_precision: str = "exact") -> list[str
       dtype of the feature maps, as the einsum would return it (fp32 features: the kernel's fp32 output as is; 16-bit
       encoder dtypes: one cast, exactly the rounding the einsum's 16-bit output has — flownet.py:27 widens it again).
 
+    ``volume_precision``: None = ``ops.default_volume_precision()`` ("f16x2" unless ``MACVO_HIP_VOLUME_PRECISION`` says otherwise) — the
+    same default as ``pipeline.HotPathConfig`` and ``bench.py``; the plugins' YAML key sets are the reference's, so they take the default.
+
     Every attribute that exists is rebound (the FlowFormer submodule is absent from some checkouts, and a stand-in model may
     carry only part of them); the names of the rebound methods are returned so that a caller can insist on all three."""
     done = []
+    if volume_precision is None:
+        volume_precision = ops.default_volume_precision()
     dec = getattr(model, "memory_decoder", None)
     if dec is not None and hasattr(dec, "encode_flow_token"):
         dec.encode_flow_token = lambda cost_maps, coords: ops.corr_lookup(cost_maps.float(), coords.float(), 4)

@@ -6,7 +6,7 @@ The reference computes ``corr = einsum('bhid,bhjd->bhij')`` (``Module/Network/Fl
 parity bar instead; this file restates what they compute so that the bar can be checked WITHOUT a GPU:
 
 * ``pack_f16x2``  every row (one pixel's feature vector) is scaled by the power of two that puts its largest magnitude into
-  [2^14, 2^15) (|shift| <= 60), then split into two fp16 pieces by successive rounding: x * 2^sh = h0 + h1 + O(2^-22 |x * 2^sh|);
+  [2^14, 2^15) (any finite non-zero row of the fp32 range: the shift is not clamped), then split into two fp16 pieces by successive rounding: x * 2^sh = h0 + h1 + O(2^-22 |x * 2^sh|);
 * ``pack_bf16x3`` three bf16 pieces by successive rounding (no scaling: bf16 has fp32's exponent range);
 * ``corr_volume_split``  the piece products (h0 h0 + h0 h1 + h1 h0, or the six bf16 products with i + j <= 2), every product exact in
   fp32 arithmetic terms (11 x 11 / 8 x 8 bits), accumulated in fp32, the row scales undone exactly afterwards.
@@ -25,7 +25,7 @@ def pack_f16x2(f: np.ndarray):
     m = np.abs(f).max(axis=1)
     sh = np.zeros(f.shape[0], dtype=np.int32)
     ok = (m > 0) & np.isfinite(m)
-    sh[ok] = np.clip(14 - np.floor(np.log2(m[ok].astype(np.float64))).astype(np.int32), -60, 60)
+    sh[ok] = 14 - np.floor(np.log2(m[ok].astype(np.float64))).astype(np.int32)
     x = np.ldexp(f, sh[:, None]).astype(np.float32)
     h0 = x.astype(np.float16)
     h1 = (x - h0.astype(np.float32)).astype(np.float16)

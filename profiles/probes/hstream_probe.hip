@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // region.  The list is cut into 8 equal runs, one per XCD (workgroup id % 8 = XCD under round-robin dispatch), and each
     // XCD's run into equal runs for its gridDim / 8 workgroups: what an XCD reads at any time is ONE region's B rows (host picks
     // R so that this is ~1.2 MB, re-read once per band) plus the bands its workgroups are on — resident in its 4 MB L2 while
-    // 23 MB of output stream through it.  Measured (tools/scratch/store_probe.py): L2-hitting reads beside the 184 MB write stream
+    // 23 MB of output stream through it.  Measured (profiles/probes/store_probe.py): L2-hitting reads beside the 184 MB write stream
     // are free, L2-missing ones cost ~7 us per 45 MB — with the plain band-major split the kernel fetched 66-132 MB per launch.
     const int per = nb * nc, T = B * per;        // T < 2^31
     int it, it_end;

@@ -12,7 +12,7 @@ c=d.get('config4')
 if c: print('   config4',c['value'],c['ms_per_step'],c['roofline']['avg_launch_us'],c.get('timeline'))
 " >> $L 2>&1
 }
-S=$PWD/tools/scratch
+S=$PWD/profiles/probes
 C4=60 run MV_X=0
 C4=60 run MACVO_HIP_LIB=$S/libmacvo_hip_depth4.so MV_PIPE_MAX_DEPTH=4 MV_PIPE_DEPTH=4
 run MACVO_HIP_LIB=$S/libmacvo_hip_depth5.so MV_PIPE_MAX_DEPTH=5 MV_PIPE_DEPTH=5

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Where do the waves of corr_volume_split_stream spend their cycles?  SQ wait / active counters + effective clock (GRBM_GUI_ACTIVE / wall
-# time) for the production kernel, knock-out builds (tools/scratch/split_variants.sh) and zero operands.  PMC passes only.
+# time) for the production kernel, knock-out builds (profiles/probes/split_variants.sh) and zero operands.  PMC passes only.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
@@ -19,7 +19,7 @@ run() {   # tag, lib, mode, extra args
   done
 }
 P=$R/mac-vo_amd/libmacvo_hip.so
-S=$R/tools/scratch
+S=$R/profiles/probes
 run f16x2 $P f16x2
 run f16x2_zeros $P f16x2 --zeros
 run f16x2_k1 $S/libmacvo_hip_split_k1.so f16x2

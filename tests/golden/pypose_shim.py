@@ -181,6 +181,14 @@ def SE3(data):
     return LieTensor(data)
 
 
+def identity_SE3(*lsize, dtype=None, device=None):
+    """pp.identity_SE3(*lsize): identity transforms of shape lsize + (7,) (no batch dim when lsize is empty, which is what
+    StaticMotionModel / MACVO.initialize rely on: Module/MotionModel.py:136-137, Odometry/MACVO.py:160)."""
+    d = torch.zeros(tuple(lsize) + (7,), dtype=dtype or torch.float32, device=device)
+    d[..., 6] = 1.0
+    return LieTensor(d)
+
+
 def cumops(input, dim, ops):
     """pp.cumops: inclusive scan y_k = x_0 (ops) x_1 (ops) ... (ops) x_k by doubling (Hillis-Steele), earlier operand on the
     LEFT — the order in which `pose[0] @ cumops(motions)` rebuilds a trajectory (Module/MapProcessor.py:73-74; the reference
@@ -373,7 +381,7 @@ class _Permissive(types.ModuleType):
 def install():
     """Register the shim as ``pypose`` and its sub-modules in sys.modules."""
     pp = _Permissive("pypose")
-    for n in ("LieTensor", "Parameter", "SE3", "vec2skew", "pixel2point", "point2pixel", "cumops"):
+    for n in ("LieTensor", "Parameter", "SE3", "identity_SE3", "vec2skew", "pixel2point", "point2pixel", "cumops"):
         setattr(pp, n, globals()[n])
     pp.SE3_type = types.SimpleNamespace(Act=lambda pose, p: LieTensor(_raw(pose)).Act(p))
     pp.from_matrix = lambda *a, **k: LieTensor(torch.tensor([[0.0, 0, 0, 0, 0, 0, 1]]))

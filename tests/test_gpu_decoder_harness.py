@@ -1,4 +1,4 @@
-"""The decoder-loop harness (mac-vo_amd/decoder_harness.py): HIP lookups / upsamplings issued between real PyTorch-ROCm
+"""The decoder-loop harness (tools/decoder_harness.py): HIP lookups / upsamplings issued between real PyTorch-ROCm
 kernels on one stream, in the statement order of MemoryCovDecoder.forward (covhead.py:85-135)."""
 import pytest
 import torch
@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("dec_dtype", [torch.float32, torch.bfloat16])
 def test_interleaved_lookups_and_upsampling_match_the_oracle(gpu, dec_dtype):
     from macvo_amd import ops
-    from macvo_amd.decoder_harness import DecoderLoopHarness
+    from tools.decoder_harness import DecoderLoopHarness
     from oracle import corr, frontend
 
     torch.manual_seed(0)
@@ -43,7 +43,7 @@ def test_harness_outputs_drive_the_hot_path(gpu):
     """volume -> 12-iteration decoder loop (stand-in network) -> the native frame driver, frame after frame: the path
     `estimate_pair` -> selector -> covariance -> PGO runs end to end on network-shaped inputs (finite poses, 200 keypoints)."""
     from macvo_amd import ops
-    from macvo_amd.decoder_harness import DecoderLoopHarness
+    from tools.decoder_harness import DecoderLoopHarness
     from macvo_amd.pipeline import Camera, FrameInputs, HotPathConfig, NativeHotPath
     from tests import synth
 

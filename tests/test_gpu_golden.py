@@ -35,7 +35,7 @@ def test_covariance_vs_reference_golden(gpu):
     fc = z["flow_cov_in"].clone().to(gpu)
     out = ops.match_cov(depth, z["kp_int"].to(gpu), fc, None, *K)
     assert torch.equal(fc.cpu(), z["flow_cov_after"])                         # in-place clamp, bit-exact
-    # tolerances = 5 x the measured bound (tools/scratch/cov_tolerance.py: max relative error 2.6e-6 / 1.0e-5 / 4.5e-7 / 2.4e-7):
+    # tolerances = 5 x the measured bound (profiles/probes/cov_tolerance.py: max relative error 2.6e-6 / 1.0e-5 / 4.5e-7 / 2.4e-7):
     # the kernel replays the reference's fp32 op order; what is left is the summation order of the 961-tap reductions
     torch.testing.assert_close(out.cpu(), z["cov_int_flowcov"], rtol=5e-5, atol=1e-7)
     out = ops.match_cov(depth, z["kp_float"].to(gpu), z["flow_cov_in"].clone().to(gpu), None, *K)

@@ -72,6 +72,22 @@ except (KeyError, AssertionError):
     pass
 del od.keypoint.args.bogus
 
+# 3b. all three shipped experiment configs validate with only the type strings swapped — Paper_Reproduce.yaml carries `autodiff: true`
+#     (:103-109): the HIP solver accepts it (analytic Jacobians = the reference's verified equivalent) instead of refusing the file
+import warnings
+swap["CovAwareSelector"] = "HIP_CovAwareSelector"
+for name in ("MACVO_Performant.yaml", "Paper_Reproduce.yaml"):
+    c2, _ = load_config(Path(%(ref)r) / "Config/Experiment/MACVO" / name)
+    o2 = c2.Odometry
+    for sec in (o2.cov.obs, o2.keypoint, o2.mappoint, o2.frontend, o2.optimizer):
+        sec.type = swap[sec.type]
+    OM.MACVO.is_valid_config(o2)
+    if o2.optimizer.args.autodiff:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            c = Module.IOptimizer.get_class(o2.optimizer.type).init_context(NS(**{**vars(o2.optimizer.args), "parallel": False}))
+        assert c["graph_type"] == "icp" and any("analytic" in str(x.message) for x in w)
+
 # 4. instantiate through the reference's registry exactly as MACVO.from_config does (Odometry/MACVO.py:84-92) — the
 #    classes whose constructors need neither a GPU nor network weights
 kp = Module.IKeypointSelector.instantiate(od.keypoint.type, od.keypoint.args)

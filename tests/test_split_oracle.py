@@ -39,13 +39,16 @@ def test_f16x2_pieces_and_scales():
     assert np.all(np.abs(back - f.astype(np.float64)) <= tol)
 
 
-def test_f16x2_dynamic_range_rows():
-    """rows spread over 2^+-40: the error relative to sum |a||b| stays at the fp32 level (the per-row scales carry the range)"""
+@pytest.mark.parametrize("span", [40, 100])
+def test_f16x2_dynamic_range_rows(span):
+    """rows spread over 2^+-40 / 2^+-100 (most of the fp32 range): the error relative to sum |a||b| stays at the fp32 level (the per-row
+    scales carry the range; they are not clamped)"""
     C = 256
     f1, f2 = _feats(128, 128, C, 7)
     g = np.random.default_rng(1)
-    f1 *= (2.0 ** g.integers(-40, 41, size=(128, 1))).astype(np.float32)
-    f2 *= (2.0 ** g.integers(-40, 41, size=(128, 1))).astype(np.float32)
+    e1 = g.integers(-span, span + 1, size=(128, 1))
+    f1 *= (2.0 ** e1).astype(np.float32)
+    f2 *= (2.0 ** np.clip(g.integers(-span, span + 1, size=(128, 1)), -110 - e1.min(), 110 - e1.max())).astype(np.float32)   # products stay finite
     ref = f1.astype(np.float64) @ f2.astype(np.float64).T
     mag = np.abs(f1).astype(np.float64) @ np.abs(f2).astype(np.float64).T
     out = corr_split.corr_volume_split(f1, f2, "f16x2").astype(np.float64)

@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from macvo_amd import ops
 
 
 def _range(name: str):
