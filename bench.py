@@ -68,6 +68,8 @@ def parse_args():
     ap.add_argument("--feat-pool", type=int, default=0, help="distinct feature-map / lookup-coordinate sets among the resident frames "
                     "(0 = one per frame: every frame reads its own 19.7 MB of features; rounds 1-3 cycled two sets)")
     ap.add_argument("--cpu-frames", type=int, default=120, help="frames timed for the CPU baseline (rank 0, N=1 only)")
+    ap.add_argument("--reference-frames", type=int, default=12, help="frames run through the reference's own MACVO loop on the host (parity + cpu_baseline kind "
+                    "'reference'); needs oracle/_ref/pyref (python oracle/build_ref.py in the build container); 0 = skip")
     ap.add_argument("--parity-frames", type=int, default=48, help="free-running frames compared with the oracle (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the parity leg")
     ap.add_argument("--config4-steps", type=int, default=100, help="steps of the extra configs[4] leg (32 lanes); 0 = skip")
@@ -94,7 +96,10 @@ def self_launch(args) -> int:
         port = so.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this stack
-    env.setdefault("OMP_NUM_THREADS", "8")
+    # each rank runs two busy host threads (the caller and the driver's backend launch thread) plus torch's intra-op pool: give every
+    # rank its own slice of the cores this process may use instead of 8 pool threads each on a small host
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, ncores // max(1, args.gpus) - 2))))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, env=env).returncode
@@ -170,11 +175,105 @@ def roofline_of(ms, args, lanes, n_q, C, timed_region_launches, traffic=None):
             **common}
 
 
+
+def volume_lookup_parity(ops, frames, cfr, args, n_q, C, dev, picks):
+    """The parity of the kernels the line TIMES, on the benchmark's own frames and at the line's precision (the
+    free-running keypoints / poses do not depend on the volume or the lookup tokens).  Per picked frame: 96 sampled rows of the
+    volume against a float64 einsum (absolute bar 2e-5 sqrt(C), and the error relative to sum |a||b|), and the tokens of all
+    ``iters`` window lookups against oracle.corr.corr_lookup (= ATen grid_sample, align_corners=True, zero padding) evaluated on the
+    same volume (rtol 1e-5, atol 2e-4)."""
+    from oracle import corr as ocorr
+
+    g = torch.Generator().manual_seed(99)
+    out = {"frames": list(picks), "volume_precision": args.volume_precision, "volume_rows_sampled": 0, "volume_max_abs_err": 0.0,
+           "volume_abs_bar": 2e-5 * C ** 0.5, "volume_max_err_rel_sum_abs": 0.0, "lookup_launches": 0, "lookup_max_abs_err": 0.0,
+           "lookup_tol": "rtol 1e-5, atol 2e-4 vs oracle.corr.corr_lookup (grid_sample) on the same volume"}
+    ok = True
+    for k in picks:
+        fr, fc = frames[k], cfr[k]
+        vol = ops.corr_volume(fr.fmap1, fr.fmap2, layout=args.layout, precision=args.volume_precision if args.feat_dtype == "f32" else None)
+        out["volume_kernel"] = ops.last_volume_kernel()
+        P = fr.fmap1.shape[0]
+        f1 = fc["fmap1"].reshape(P, C, n_q).double()          # cfr is CHW fp32 on the CPU
+        f2 = fc["fmap2"].reshape(P, C, n_q).double()
+        rows = torch.randint(0, P * n_q, (96,), generator=g)
+        got = vol.view(P * n_q, n_q)[rows.to(dev)].cpu().double()
+        b, i = rows // n_q, rows % n_q
+        a = f1[b, :, i]                                        # [96, C]
+        ref = torch.einsum("rc,rcn->rn", a, f2[b])
+        mag = torch.einsum("rc,rcn->rn", a.abs(), f2[b].abs())
+        err = (got - ref).abs()
+        out["volume_rows_sampled"] += int(rows.numel())
+        out["volume_max_abs_err"] = max(out["volume_max_abs_err"], float(err.max()))
+        out["volume_max_err_rel_sum_abs"] = max(out["volume_max_err_rel_sum_abs"], float((err / mag.clamp_min(1e-300)).max()))
+        volc = vol.cpu()
+        for it in range(fr.coords.shape[0]):
+            tok = ops.corr_lookup(vol, fr.coords[it], 4).cpu()
+            rtok = ocorr.corr_lookup(volc, fc["coords"][it], 4)
+            out["lookup_launches"] += 1
+            out["lookup_max_abs_err"] = max(out["lookup_max_abs_err"], float((tok - rtok).abs().max()))
+            ok = ok and bool(torch.allclose(tok, rtok, rtol=1e-5, atol=2e-4))
+    # 16-bit features: the volume itself is computed from the rounded inputs the oracle also sees; the bar scales with their 2^-11 / 2^-8 rounding
+    out["within_bar"] = bool(ok and (out["volume_max_abs_err"] <= out["volume_abs_bar"] or args.feat_dtype != "f32"))
+    return out
+
+
+def reference_loop_leg(cam, cfr, n_frames, cores, graph):
+    """The reference's OWN ``Odometry/MACVO.py`` loop with the reference's own classes (CovAwareSelector_NoDepth, MatchCovariance,
+    TwoFrame_PGO, FlowFormerCovFrontend.estimate_pair + VisualMap, StaticMotionModel, ...) on this host's cores, fed the benchmark's own
+    network outputs (tests/refrun.py in a fresh interpreter; the tree comes from oracle/_ref/pyref, byte-compiled from the reference).
+    Returns (seconds per run_pair, per-frame kept keypoints, poses) or None when the tree is absent."""
+    import subprocess
+    import tempfile
+
+    import numpy as np
+
+    from tests import refrun
+
+    if refrun.reference_root() is None:
+        return None
+    with tempfile.TemporaryDirectory() as tmp:
+        mf, of = os.path.join(tmp, "maps.npz"), os.path.join(tmp, "run.npz")
+        np.savez(mf, flow=torch.stack([f["flow"] for f in cfr[:n_frames]]).numpy(),
+                 cov=torch.stack([torch.exp(f["logcov"] * 2) for f in cfr[:n_frames]]).numpy(), cam=np.array(json.dumps(cam)))
+        cmd = [sys.executable, os.path.join(ROOT, "tests", "refrun.py"), "--mode", "ref", "--case", "synth_fast", "--maps-file", mf, "--mapping", "0",
+               "--graph", graph, "--threads", str(cores), "--out", of]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        if p.returncode != 0:
+            return {"error": (p.stdout[-500:] + p.stderr[-1500:])}
+        r = dict(np.load(of))
+    fs = r["frame_s"]
+    rng = r["map/edge/frame2match/ranges"]
+    kps = [r["map/match//pixel1_uv"][int(rng[t, 0, 0]): int(rng[t, 0, 0]) + int(rng[t, 0, 1])] for t in range(1, n_frames)]
+    return {"s_per_run_pair": float(fs[2:].mean()), "frames": int(n_frames), "kps": kps, "poses": r["map/frames//pose"],
+            "graph": graph}
+
+
+def pin_rank_cores(local_rank: int, local_world: int) -> list:
+    """Confine this rank (the calling thread; the driver's backend launch thread and torch's pool threads are created later and inherit
+    the mask) to its own contiguous slice of the cores the process may use, so that the 2 busy host threads of each of N ranks never
+    share a core with another rank's.  Returns the slice (printed as `host_cores_per_rank`).  No-op for a single rank."""
+    if not hasattr(os, "sched_getaffinity"):
+        return []
+    cores = sorted(os.sched_getaffinity(0))
+    if local_world <= 1 or len(cores) < 2 * local_world:
+        return cores
+    k = len(cores) // local_world
+    mine = cores[local_rank * k:(local_rank + 1) * k]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return cores
+    torch.set_num_threads(max(1, min(8, k - 2)))
+    return mine
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    my_cores = pin_rank_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) if not args.dry_collectives else []
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(self_launch(args))      # one rank per GPU under torch.distributed.run, output handed through
     if args.gpus != world:
@@ -235,7 +334,7 @@ def main():
             return frames
         return [stack_lanes([frames[(t + l) % args.pool] for l in range(lanes)]) for t in range(args.pool)]
 
-    def make_pipe(lanes, seed, precision=None):
+    def make_pipe(lanes, seed, precision=None, keep_extras=False):
         cfg = HotPathConfig(graph_type=args.graph, feature_layout=args.layout,
                             volume_precision=(precision or args.volume_precision) if args.feat_dtype == "f32" else "exact",
                             use_graphs=use_graphs)
@@ -243,7 +342,7 @@ def main():
             # lanes > 1: integer seeds = the driver's native per-lane MT19937 generators (bit-identical to torch.Generator(seed) +
             # torch.randperm; 32 host-side torch.randperm calls per step were the bound of the 32-lane configuration)
             gens = None if lanes == 1 else [seed + l for l in range(lanes)]
-            return NativeHotPath(Camera(**cam), cfg, dev, lanes=lanes, generators=gens)
+            return NativeHotPath(Camera(**cam), cfg, dev, lanes=lanes, generators=gens, keep_extras=keep_extras)
         return HotPath(Camera(**cam), cfg, dev)
 
     def barrier():
@@ -370,11 +469,13 @@ def main():
 
     # HBM traffic of the dominant kernel from a committed rocprofv3 --pmc pass over the same launch configuration
     # (scripts/pmc_gpu.sh -> profiles/*_pmc_corr_volume.json; PMC passes cannot be mixed into this run)
-    traffic = None
+    traffic = traffic_file = None
     try:
         if (H, W, C, args.lanes) == (480, 640, 256, 1) and args.feat_dtype == "f32" and args.volume_precision in ("bf16x3", "f16x2"):
-            path = os.path.join(ROOT, "profiles", f"r03_pmc_corr_volume_split_{args.volume_precision}.json")
+            path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_corr_volume_split_{args.volume_precision}.json") for r in (4, 3))
+                         if os.path.exists(q)), "")
             if os.path.exists(path):
+                traffic_file = os.path.basename(path)
                 pm = json.load(open(path))
                 key = next((k for k in pm if k.startswith("corr_volume_split_stream")), None)
                 if key is not None:
@@ -398,6 +499,9 @@ def main():
     except Exception:  # noqa: BLE001
         traffic = None
     roofline = roofline_of(ms, args, args.lanes, n_q, C, in_region, traffic) if ms else None
+    if roofline is not None:
+        roofline["traffic_source"] = (f"committed rocprofv3 --pmc pass over the same launch configuration (profiles/{traffic_file or '...'}): "
+                                      "PMC passes cannot be mixed into a timed run; NOT measured in this process") if traffic is not None else None
     def isolated_us(lanes, precision):
         """The dominant kernel with the GPU to itself (back-to-back launches, HIP events): what the co-running lookups / selector /
         backend kernels of the neighbouring frames cost it inside the pipeline is the difference to avg_launch_us.  ~60 ms of
@@ -482,14 +586,17 @@ def main():
         # forcing), same CPU generator seed -> keypoints must be identical, poses within 1e-4; RTE per MetricsSeq.py:9-16
         if native and args.volume_precision in ("exact", "bf16x3", "f16x2") and args.feat_dtype == "f32":
             n_par = min(len(ora_track), max(args.parity_frames, 2))
-            hot = make_pipe(1, 0)
+            hot = make_pipe(1, 0, keep_extras=True)
             torch.manual_seed(1234)
             hot.initialize(frames[0])
             sink = torch.zeros((n_par, 7), dtype=torch.float32, device=dev)
             kp_same = 0
+            kept = []        # keypoints that survive the in-bound test and the observation filter = the rows the reference stores
             for t, r in enumerate(hot.run((frames[(1 + k) % args.pool] for k in range(n_par)), pose_sink=sink)):
                 hot.sync_pose()
                 kp_same += int(torch.equal(r.kp0_uv.cpu(), ora_track[t]["kp0_uv"]))
+                if t < 16 and r.n_sel:
+                    kept.append(r.kp0_uv[r.extras["valid"]].cpu().float().numpy())
             torch.cuda.synchronize()
             ident = torch.tensor([[0, 0, 0, 0, 0, 0, 1.0]])
             est = torch.cat([ident, sink.cpu()])
@@ -504,6 +611,48 @@ def main():
                       "formula": "evo RPE translation part, delta = 1 frame (Evaluation/MetricsSeq.py:9-16)",
                       "within_north_star": bool(kp_same == n_par and max(d[0] for d in diffs) <= 1e-4 and max(d[1] for d in diffs) <= 1e-4)}
             del hot
+            # ... and the kernels the line times: volume rows vs fp64 einsum, every lookup's tokens vs the oracle, at the line's precision
+            try:
+                parity["volume_and_lookups"] = volume_lookup_parity(ops, frames, cfr, args, n_q, C, dev, sorted({0, args.pool // 2, args.pool - 1}))
+                parity["within_north_star"] = bool(parity["within_north_star"] and parity["volume_and_lookups"]["within_bar"])
+            except Exception as e:  # noqa: BLE001
+                parity["volume_and_lookups"] = {"error": repr(e)[:300]}
+            # ... and against the REFERENCE ITSELF: its own MACVO loop on this host, same network outputs, same generator seed
+            n_ref = min(args.reference_frames, n_par + 1, args.pool)
+            ref_leg = reference_loop_leg(cam, cfr, n_ref, cores, args.graph) if n_ref >= 3 else None
+            if ref_leg is not None and "error" not in ref_leg:
+                import numpy as np
+
+                nk = min(len(kept), n_ref - 1)
+                same = sum(int(kept[t].shape == ref_leg["kps"][t].shape and np.array_equal(kept[t], ref_leg["kps"][t])) for t in range(nk))
+                rp = torch.from_numpy(ref_leg["poses"][1:n_ref]).double()
+                dref = [se3.pose_error(rp[t], est[t + 1].double()) for t in range(n_ref - 1)]
+                parity["vs_reference_loop"] = {
+                    "what": "the reference's own unmodified Odometry/MACVO.py loop (reference selector / covariance model / TwoFrame_PGO / frontend "
+                            "epilogue / VisualMap, CPU) on the same frames and generator seed, via tests/refrun.py + oracle/_ref/pyref",
+                    "frames": n_ref - 1, "stored_keypoints_bit_exact_frames": same, "frames_compared_keypoints": nk,
+                    "max_pose_dt_m": max(d[0] for d in dref), "max_pose_dr_rad": max(d[1] for d in dref),
+                    "within_north_star": bool(same == nk and max(d[0] for d in dref) <= 1e-4 and max(d[1] for d in dref) <= 1e-4)}
+                # the CPU baseline of kind "reference": the reference's loop covers everything from the network's outputs on (the backend
+                # half + the frontend epilogue); the all-pairs volume and the 12 lookups live in the FlowFormer submodule, which is absent
+                # from the checkout - their share is the torch-CPU restatement of the ops that submodule calls (einsum, grid_sample)
+                from oracle import corr as ocorr
+
+                tv0 = time.perf_counter()
+                for k in range(2):
+                    v = ocorr.corr_volume(cfr[k]["fmap1"].float(), cfr[k]["fmap2"].float(), torch.float32)
+                    for it in range(cfr[k]["coords"].shape[0]):
+                        ocorr.corr_lookup(v, cfr[k]["coords"][it], 4)
+                vl_s = (time.perf_counter() - tv0) / 2
+                port_fps = cpu_baseline["value"]
+                cpu_baseline = {"value": round(1.0 / (ref_leg["s_per_run_pair"] + vl_s), 3), "unit": "stereo frames/s", "cores": cores, "kind": "reference",
+                                "sample": f"{n_ref - 2} run_pair calls of the reference's own MACVO loop on the same {W}x{H} network outputs "
+                                          f"({ref_leg['s_per_run_pair'] * 1e3:.0f} ms each: selector, 2 x covariance model, TwoFrame_PGO, map) + the volume and "
+                                          f"{args.iters} lookups of 2 frames as the torch-CPU ops the absent FlowFormer submodule calls ({vl_s * 1e3:.0f} ms per frame)",
+                                "parts": {"reference_run_pair_s": round(ref_leg["s_per_run_pair"], 4), "volume_lookups_torch_cpu_s": round(vl_s, 4),
+                                          "oracle_port_pipeline_fps": port_fps}}
+            elif ref_leg is not None:
+                parity["vs_reference_loop"] = ref_leg
 
     # ---- configs[4]: batch-32 frames per GPU (B = 64 pairs per GEMM) — a short second measurement, N = 1 only
     config4 = None
@@ -576,6 +725,8 @@ def main():
             "n_gpus": world,
             "ranks_seen": ranks_seen,
             "rank_devices": rank_devices,
+            "host_cores_per_rank": len(my_cores) or None,
+            "host_threads_per_rank": "2 busy (caller + backend launch thread) + a torch pool of %d" % torch.get_num_threads(),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),

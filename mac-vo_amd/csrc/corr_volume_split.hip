@@ -208,6 +208,12 @@ struct SplitCfg {
     static constexpr int WB0_START = clampw(D + NA + EARN), WB1_START = D + EB;
 };
 
+#ifndef MV_SPLIT_DMA_IMM
+#define MV_SPLIT_DMA_IMM 1          // LDS-DMA pieces in groups of four behind one M0 / base (round 4; A/B: profiles/r04_split_variants_ab1.log)
+#endif
+#ifndef MV_SPLIT_VACC
+#define MV_SPLIT_VACC 1             // f16x2: accumulators in VGPRs (asm MFMAs), true ping-pong between the two sets, no v_accvgpr_read
+#endif
 #ifdef MV_SPLIT_PROBE
 #define MV_SPLIT_PROBE_SLACK 2      // the stamp store of the probe build is one more memory operation per item
 #else
@@ -278,42 +284,51 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 
     // ---- B loader (LDS-DMA), two K halves ahead of the MFMAs; all walking state wave-uniform.  A half of a sub-tile is two
     // contiguous runs of HU units (row blocks 2c, 2c + 1); wave w copies units [w D, (w + 1) D) of that 2 HU-unit image to the same
     // position of the slot.
-    int ld_it = it, ld_hh = 0, ld_slot = 0, ld_b, ld_g, ld_band, ld_c, ld_c0, ld_cend;
-    decode(it, ld_b, ld_g, ld_band, ld_c);
-    ld_c0 = reg_c0(ld_g);
-    ld_cend = reg_c0(ld_g + 1);
+    // Walking state (round 4): the loader is EXACTLY two halves = one item ahead of the MFMAs, so the half it fetches inside consumer half
+    // H is half H of the next item — a compile-time constant — and its pointer only moves once per item: + ITEM_STRIDE inside a band
+    // segment (consecutive sub-tiles), back to the region's first sub-tile at a band change, `decode` (64-bit divisions) only at a region /
+    // pair change.  Round 3 walked (pair, region, band, sub-tile) counters behind EVERY half: ~35 SALU and 3-4 taken branches in the
+    // middle of each half's MFMA stream (seen in the ISA), i.e. a ~200-cycle hole per 1536 cycles of matrix work.
+    constexpr size_t ITEM_STRIDE = (size_t)2 * (2 * HU) * 1024;        // one sub-tile = two row blocks of the packed operand
+    int ld_it = it, ld_slot = 0, ld_band, ld_w, ld_seg_end;
     auto src_of = [&](int b, int c) {   // the wave's D units of a half: units [wave D, (wave + 1) D) of the 2 HU-unit slot image
         return reinterpret_cast<const char*>(pk2) + (((size_t)b * nrb2 + 2 * c + (wave * D) / HU) * (2 * HU) + (wave * D) % HU) * 1024;
     };
-    const char* ld_ptr = src_of(ld_b, ld_c);
-    auto advance_loader = [&]() __attribute__((always_inline)) {   // behind the last piece of a half
-        ld_slot = ld_slot == NSLOT - 1 ? 0 : ld_slot + 1;
-        if (ld_hh == 0) {
-            ld_hh = 1;
-        } else if (ld_it + 1 < it_end) {         // past the end of the run the last half is simply fetched again
-            ld_hh = 0;
+    const char* ld_ptr;                 // first half of the item being fetched
+    const char* ld_ptr0;                // ... of the first sub-tile of its (pair, region)
+    auto loader_decode = [&]() __attribute__((always_inline)) {      // rare: run start, region / pair change
+        int b_, g_, c_;
+        decode(ld_it, b_, g_, ld_band, c_);
+        const int c0_ = reg_c0(g_);
+        ld_w = reg_c0(g_ + 1) - c0_;
+        ld_ptr0 = src_of(b_, c0_);
+        ld_ptr = ld_ptr0 + (size_t)(c_ - c0_) * ITEM_STRIDE;
+        ld_seg_end = min(it_end, ld_it + (c0_ + ld_w - c_));
+    };
+    loader_decode();
+    auto next_item = [&]() __attribute__((always_inline)) {          // behind the last piece of an item's SECOND half
+        if (ld_it + 1 < it_end) {                // past the end of the run the last item is simply fetched again
             ++ld_it;
-            if (++ld_c == ld_cend) {             // next band of the region / next region / next pair
-                if (++ld_band == nb) {
-                    ld_band = 0;
-                    if (++ld_g == R) {
-                        ld_g = 0;
-                        ++ld_b;
-                    }
-                    ld_c0 = reg_c0(ld_g);
-                    ld_cend = reg_c0(ld_g + 1);
+            ld_ptr += ITEM_STRIDE;
+            if (ld_it == ld_seg_end) {           // (uniform, once per segment)
+                if (++ld_band < nb) {            // next band of the region: the same sub-tiles again
+                    ld_ptr = ld_ptr0;
+                    ld_seg_end = min(it_end, ld_it + ld_w);
+                } else {
+                    loader_decode();
                 }
-                ld_c = ld_c0;
             }
-            ld_ptr = src_of(ld_b, ld_c);
         }
     };
-    auto issue_half = [&]() __attribute__((always_inline)) {       // prologue form: the D pieces as one block
-        const char* src = ld_ptr + (size_t)ld_hh * (HU * 1024);
+    auto advance_slot = [&]() __attribute__((always_inline)) { ld_slot = ld_slot == NSLOT - 1 ? 0 : ld_slot + 1; };
+    auto issue_half = [&](auto HH) __attribute__((always_inline)) {       // prologue form: the D pieces as one block
+        constexpr int H = decltype(HH)::value;
+        const char* src = ld_ptr + (size_t)H * (HU * 1024);
         const unsigned dst = lds0 + (unsigned)ld_slot * SLOT_BYTES + (unsigned)(wave * D) * 1024u;
 #pragma unroll
         for (int i = 0; i < D; ++i) glds16_s(lane16, src + i * 1024, dst + (unsigned)i * 1024u);
-        advance_loader();
+        advance_slot();
+        if (H == 1) next_item();
     };
 
     // ---- A fragments: NA coalesced 1-KB units of this wave's row block, whole K, all pieces -> accumulator-file registers.
@@ -427,11 +442,28 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 
         STAMP(H * 3 + 0);
         if (!DBG(4)) wait_vmcnt_barrier<(W > 2 ? W - (MV_SPLIT_PROBE_SLACK) : W)>();    // behind the barrier all four waves' pieces are in, and everyone has left slot - 1
         STAMP(H * 3 + 1);
-        const char* src = ld_ptr + (size_t)ld_hh * (HU * 1024);   // half + 2 -> the slot everyone has just left
+        const char* src = ld_ptr + (size_t)H * (HU * 1024);   // half + 2 (= half H of the next item) -> the slot everyone has just left
         const unsigned dst = lds0 + (unsigned)ld_slot * SLOT_BYTES + (unsigned)(wave * D) * 1024u;
-        auto piece = [&](int pi) __attribute__((always_inline)) {
+        auto piece = [&](int pi) __attribute__((always_inline)) {   // (pi is a constant after unrolling)
+#if MV_SPLIT_DMA_IMM
+            // groups of four pieces share M0 and the scalar base (immediate offsets 0 / 1 / 2 / 3 KB on both addresses): 1 + 3 SALU per
+            // group instead of 8 per piece (M0 save / write / restore + a 64-bit source and a 32-bit destination address each)
+            if (!DBG(2)) {
+                const char* gsrc = src + (pi >> 2) * 4096;
+                switch (pi & 3) {
+                    case 0: glds16_m0(lane16, gsrc, dst + (unsigned)(pi >> 2) * 4096u); break;
+                    case 1: glds16_next<1024>(lane16, gsrc); break;
+                    case 2: glds16_next<2048>(lane16, gsrc); break;
+                    default: glds16_next<3072>(lane16, gsrc); break;
+                }
+            }
+#else
             if (!DBG(2)) glds16_s(lane16, src + pi * 1024, dst + (unsigned)pi * 1024u);
-            if (pi == D - 1) advance_loader();
+#endif
+            if (pi == D - 1) {
+                advance_slot();
+                if (H == 1) next_item();
+            }
         };
         const i32x4* q = smem_sp + (unsigned)slot * (SLOT_BYTES / 16) + lane;
         i32x4 fb[2][JB][NP];                     // [stage][column block][piece]
@@ -464,7 +496,16 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 
                 const int pa = PA[base + qd], pb = PB[base + qd];
                 const i32x4 a = afr[(H * KH + ks) * NP + pa];
                 f32x16& c = jb ? c1 : c0;
-                if (H == 0 && ks == 0 && qd == 0) {      // the first product of an item starts its accumulators (C = 0 operand)
+                if (F16 && NWV == 4 && MV_SPLIT_VACC) {
+                    // accumulators in VGPRs (the builtin puts them into the accumulator file as soon as the kernel's asm names an "a"
+                    // register; every output then costs a v_accvgpr_read, issued as a 32-instruction burst behind the item's last MFMA).
+                    // As asm the two sets (x, y) are plain VGPR tuples, the ping-pong is real and the stores read them directly.
+                    // Hazards hipcc no longer sees: the VALU reads (v_ldexp_f32 of the store path) come >= 4 MFMAs behind the set's last
+                    // write; the flush is behind `s_nop 15; s_nop 7` already; SrcC = vDst back to back needs no wait states.
+                    const i32x4 bq = fb[cur][jb][pb];
+                    if (H == 0 && ks == 0 && qd == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "a"(a), "v"(bq));
+                    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "a"(a), "v"(bq));
+                } else if (H == 0 && ks == 0 && qd == 0) {      // the first product of an item starts its accumulators (C = 0 operand)
                     f32x16 z;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) z[r] = 0.f;
@@ -539,8 +580,8 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 
     int ex[2] = {0, 0}, ey[2] = {0, 0};           // F16: column exponents of the items accumulating in (x0, x1) / (y0, y1)
     int b, g, band, c0i;
     decode(it, b, g, band, c0i);
-    issue_half();                                // halves 0 and 1 of the first item -> slots 0, 1
-    issue_half();
+    issue_half(std::integral_constant<int, 0>{});   // halves 0 and 1 of the first item -> slots 0, 1
+    issue_half(std::integral_constant<int, 1>{});
     issue_a(b, band);                            // behind them: the first item starts on the units of its first k-steps (EARLY START)
     // Rotated loop: a segment's FIRST item sits at the bottom of the previous pass (two instantiations — kernel start / band
     // change — without a branch that would merge the loader's scalar state through phis hipcc then keeps in VGPRs).

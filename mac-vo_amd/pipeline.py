@@ -201,7 +201,7 @@ class HotPath:
             vs.wait_event(self._vol_free[k])
         with torch.cuda.stream(vs):
             self._vols[k] = ops.corr_volume(x.fmap1, x.fmap2, layout=c.feature_layout, out=self._vols[k],
-                                            precision=c.volume_precision)
+                                            precision=c.volume_precision if x.fmap1.dtype == torch.float32 else "exact")
             vol_done = torch.cuda.Event()
             vol_done.record(vs)
         main.wait_event(vol_done)
@@ -548,7 +548,7 @@ class NativeHotPath:
         max_depth = cam.fx * cam.baseline if c.max_depth == "auto" else float(c.max_depth)
         pc = L.mvFramePipeConfig(
             H=cam.H, W=cam.W, C=chans, pairs=pairs, iters=x.coords.shape[0], radius=c.radius, feat_dtype=dt,
-            layout=L.MV_LAYOUT_HWC if hwc else L.MV_LAYOUT_CHW, volume_split={"exact": 0, "split3": 3, "split2": 2, "bf16x3": L.MV_PACK_BF16X3, "f16x2": L.MV_PACK_F16X2}[c.volume_precision],
+            layout=L.MV_LAYOUT_HWC if hwc else L.MV_LAYOUT_CHW, volume_split={"exact": 0, "split3": 3, "split2": 2, "bf16x3": L.MV_PACK_BF16X3, "f16x2": L.MV_PACK_F16X2}[c.volume_precision] if dt == L.MV_F32 else 0,   # 16-bit features: one kernel family, the choice does not apply
             selector_mode=L.MV_KP_NODEPTH if c.selector == "nodepth" else L.MV_KP_FULL,
             kp_kernel_size=c.kp_kernel_size, kp_mask_width=c.kp_mask_width, num_point=c.num_point, edgewidth=c.edgewidth,
             min_num_point=c.min_num_point, graph_type=ops._GRAPH[c.graph_type], filters=c.filters,

@@ -258,14 +258,32 @@ def make_config(case: dict, mode: str):
 
 
 # ------------------------------------------------------------------------------------------------------------ run
-def run_case(name: str, mode: str, n_frames: int | None = None, seed: int = 1234, quiet: bool = True) -> dict:
-    case = CASES[name]
+def maps_from_file(path: str):
+    """network outputs handed over by another process (bench.py: the benchmark's own frames): flow, cov [n,2,2,H,W]; cam = JSON"""
+    z = np.load(path)
+    cam = json.loads(str(z["cam"]))
+    flow, cov = torch.from_numpy(z["flow"]), torch.from_numpy(z["cov"])
+    poses = torch.from_numpy(z["poses"]) if "poses" in z.files else torch.tensor([[0, 0, 0, 0, 0, 0, 1.0]]).repeat(flow.shape[0], 1).double()
+    return cam, [dict(flow=flow[t], cov=cov[t]) for t in range(flow.shape[0])], poses
+
+
+def run_case(name: str, mode: str, n_frames: int | None = None, seed: int = 1234, quiet: bool = True, maps_file: str = "",
+             mapping: int = -1, threads: int = 0, graph: str = "") -> dict:
+    case = dict(CASES[name])
+    if graph:
+        case["graph"] = graph
+    if mapping >= 0:
+        case["mapping"] = bool(mapping)
+    if threads > 0:
+        torch.set_num_threads(threads)
     ref = import_reference()
     if mode == "hip":
         import macvo_amd.interfaces as I
         import macvo_amd.plugins  # noqa: F401  registers the HIP_* classes in the reference's own registries
         assert I.USING_REFERENCE
-    if case["seq"] == "tartanair":
+    if maps_file:
+        cam, maps, poses = maps_from_file(maps_file)
+    elif case["seq"] == "tartanair":
         cam, maps, poses = tartanair_maps()
     else:
         cam, maps, poses = synthetic_maps(n_frames or 8)
@@ -348,6 +366,10 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--golden", action="store_true")
     ap.add_argument("--loud", action="store_true")
+    ap.add_argument("--maps-file", default="", help=".npz with flow / cov [n,2,2,H,W] and a JSON `cam`: replay these network outputs")
+    ap.add_argument("--mapping", type=int, default=-1, help="override the case's dense-mapping flag (0 / 1)")
+    ap.add_argument("--graph", default="", choices=["", "icp", "reproj", "disp"], help="override the case's residual graph")
+    ap.add_argument("--threads", type=int, default=0, help="torch.set_num_threads for the run (0 = torch's default)")
     a = ap.parse_args()
     if a.golden:
         assert os.path.isdir("/root/reference/Odometry"), "--golden runs in the build container (needs /root/reference)"
@@ -362,10 +384,12 @@ def main():
         np.savez_compressed(path, **out)
         print(path, os.path.getsize(path) / 1e6, "MB")
         return
-    r = run_case(a.case, a.mode, n_frames=a.frames or None, quiet=not a.loud)
+    r = run_case(a.case, a.mode, n_frames=a.frames or None, quiet=not a.loud, maps_file=a.maps_file, mapping=a.mapping, threads=a.threads, graph=a.graph)
     if a.out:
         np.savez_compressed(a.out, **r)
     print(json.dumps({"case": a.case, "mode": a.mode, "frames": int(r["n_frames"]), "s_per_frame": float(r["frame_s"][1:].mean()),
+                      "s_per_frame_steady": float(np.sort(r["frame_s"][2:])[: max(1, (len(r["frame_s"]) - 2) * 3 // 4)].mean()) if len(r["frame_s"]) > 3 else None,
+                      "threads": torch.get_num_threads(),
                       "matches": int(r["map/match//pixel1_uv"].shape[0]), "classes": json.loads(str(r["classes"]))}))
 
 

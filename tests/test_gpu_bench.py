@@ -1,0 +1,61 @@
+"""bench.py on the GPU: (1) launched the way the round-end driver launches N > 1 — under ``torch.distributed.run`` — at world size 1, so that
+the RCCL process group, the barrier / all_reduce(MAX) / gather_tracks collectives and the rank bookkeeping of the N-rank path run on real
+hardware in GPUTEST; (2) the line's parity block: the kernels the line times (volume rows vs fp64 einsum, every lookup's
+tokens vs the oracle) and, when the byte-compiled reference tree is present, the reference's own MACVO loop on the same frames."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from tests import refrun
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+QUICK = ["--no-ramp", "--exact-steps", "0", "--config4-steps", "0", "--no-decoder-leg", "--pool", "6"]
+
+
+def _line(p):
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+def test_bench_under_torch_distributed_run_world_1(gpu):
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "12", "--warmup", "3", "--no-cpu-baseline"] + QUICK
+    d = _line(subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env))
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["rank_devices"] == [0]          # the process group was RCCL with one rank
+    assert d["steps"] == 12 and d["warmup"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["host_cores_per_rank"] >= 1
+    r = d["roofline"]
+    assert r["kernel"].startswith("corr_volume_split_stream<f16x2>")                        # the library's one default precision
+    assert 0 < r["frac"] < 1 and r["launches_in_timed_region"] == 12
+
+
+@pytest.mark.gpu
+def test_bench_line_parity_covers_the_kernels_it_times(gpu):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--cpu-frames", "6", "--parity-frames", "6",
+           "--reference-frames", "6"] + QUICK
+    d = _line(subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT))
+    par = d["parity"]
+    assert par["keypoints_bit_exact_frames"] == par["frames"] and par["max_pose_dt_m"] <= 1e-4 and par["max_pose_dr_rad"] <= 1e-4
+    vl = par["volume_and_lookups"]
+    assert vl["volume_kernel"] == d["roofline"]["kernel"] and vl["volume_precision"] == d["config"]["volume_precision"] == "f16x2"
+    assert vl["volume_rows_sampled"] >= 96 and vl["volume_max_abs_err"] <= vl["volume_abs_bar"] and vl["volume_max_err_rel_sum_abs"] <= 1e-6
+    assert vl["lookup_launches"] == 3 * 12 and vl["within_bar"] and par["within_north_star"]
+    cb = d["cpu_baseline"]
+    if refrun.reference_root() is not None:
+        vr = par["vs_reference_loop"]
+        assert "error" not in vr, vr
+        assert vr["stored_keypoints_bit_exact_frames"] == vr["frames_compared_keypoints"] >= 4
+        assert vr["max_pose_dt_m"] <= 1e-4 and vr["max_pose_dr_rad"] <= 1e-4 and vr["within_north_star"]
+        assert cb["kind"] == "reference" and cb["parts"]["reference_run_pair_s"] > 0
+    else:
+        assert cb["kind"] == "port"
+    assert d["roofline"]["traffic_source"] is None or "NOT measured in this process" in d["roofline"]["traffic_source"]

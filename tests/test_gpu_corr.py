@@ -18,7 +18,7 @@ def test_corr_volume_f32_chw(gpu, shape):
     B, C, H, W = shape
     f1, f2 = _feats(B, C, H, W, seed=0)
     ref64 = corr.corr_volume(f1, f2, torch.float64)
-    out = ops.corr_volume(f1.to(gpu), f2.to(gpu), layout="chw").cpu()
+    out = ops.corr_volume(f1.to(gpu), f2.to(gpu), layout="chw", precision="exact").cpu()
     assert out.shape == (B * H * W, 1, H, W) and out.dtype == torch.float32
     # fp32 fma chain over C products of N(0,1): tolerance 1e-5 relative to the row scale sqrt(C)
     scale = float(C) ** 0.5
@@ -36,7 +36,7 @@ def test_corr_volume_asymmetric_identity(gpu):
     N = H * W
     f1 = torch.eye(C).reshape(1, C, H, W).contiguous()          # f1[c, i] = delta(c, i)
     f2 = torch.arange(C * N, dtype=torch.float32).reshape(1, C, H, W) / 7.0
-    out = ops.corr_volume(f1.to(gpu), f2.to(gpu)).cpu().reshape(N, N)
+    out = ops.corr_volume(f1.to(gpu), f2.to(gpu), precision="exact").cpu().reshape(N, N)
     assert torch.equal(out, f2.reshape(C, N))                    # out[i, j] = f2[i, j]
 
 
@@ -71,7 +71,7 @@ def test_corr_volume_f32_split3(gpu, shape):
     err = (out.double() - ref64).abs()
     scale = (f1.double().abs().reshape(B, C, -1).permute(0, 2, 1).unsqueeze(2) * f2.double().abs().reshape(B, C, -1).permute(0, 2, 1).unsqueeze(1)).sum(-1)
     assert (err / scale.reshape(err.shape).clamp_min(1e-30)).max().item() <= 1e-6     # relative to sum |a||b|
-    exact = ops.corr_volume(a1, a2, layout="hwc").cpu()
+    exact = ops.corr_volume(a1, a2, layout="hwc", precision="exact").cpu()
     e_exact = (exact.double() - ref64).abs()
     assert err.max() <= 1.5 * e_exact.max() + 1e-6                                     # no worse than the exact fp32 path
 
@@ -112,7 +112,7 @@ def test_corr_volume_16bit(gpu, dtype, layout, shape):
     f1, f2 = _feats(B, C, H, W, seed=4, dtype=dtype)
     ref64 = corr.corr_volume(f1, f2, torch.float64)
     if layout == "chw":
-        out = ops.corr_volume(f1.to(gpu), f2.to(gpu), layout="chw")
+        out = ops.corr_volume(f1.to(gpu), f2.to(gpu), layout="chw", precision="exact")
     else:
         out = ops.corr_volume(f1.permute(0, 2, 3, 1).contiguous().to(gpu), f2.permute(0, 2, 3, 1).contiguous().to(gpu),
                               layout="hwc")
@@ -156,7 +156,7 @@ for B, C, H, W in ((2, 256, 60, 80), (1, 256, 64, 64), (3, 256, 59, 64)):
     g = torch.Generator().manual_seed(12)
     f1 = torch.randn(B, C, H, W, generator=g).cuda()
     f2 = torch.randn(B, C, H, W, generator=g).cuda()
-    out = ops.corr_volume(f1, f2, layout="chw")
+    out = ops.corr_volume(f1, f2, layout="chw", precision="exact")
     print(hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest())
 """
 

@@ -89,7 +89,7 @@ def test_corr_volume_split_parity(gpu, shape, layout, mode):
     assert err <= 2e-5 * float(C) ** 0.5, err
     ref32 = corr.corr_volume(f1, f2, torch.float32)
     assert err <= 4 * (ref32.double() - ref64).abs().max().item() + 1e-6      # and not worse than a float32 einsum on the CPU
-    exact = ops.corr_volume(a1.to(gpu), a2.to(gpu), layout=layout).cpu()
+    exact = ops.corr_volume(a1.to(gpu), a2.to(gpu), layout=layout, precision="exact").cpu()
     assert err <= 1.5 * (exact.double() - ref64).abs().max().item() + 1e-6     # ... nor than the exact fp32 MFMA path
 
 
