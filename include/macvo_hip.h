@@ -82,6 +82,21 @@ int mv_corr_volume(const void* f1, const void* f2, float* out, int B, int C, int
 /* fp32 -> three bf16 planes (hi, mid, lo; residuals exact): planes[3][n] (uint16 bf16 bits), n % 4 == 0. */
 int mv_split_bf16x3(const float* x, void* planes, size_t n, mvStream_t stream);
 /* -------------------------------------------------------------------------------------------
+ * (f)2 — the consumer of the cost volume: FlowFormer's cost PATCH EMBEDDING `proj` stack, fused (csrc/patch_embed.hip).
+ * Replaces, per H2 x W2 slice of cost_maps (S = B*H1*W1 slices): F.pad to multiples of 8 -> Conv2d(1,16,6,stride 2,pad 2) -> ReLU ->
+ * Conv2d(16,32,6,2,2) -> ReLU -> Conv2d(32,64,6,2,2) — PatchEmbed(patch_size 8, embed_dim 64) of FlowFormer's MemoryEncoder, reached from
+ * Module/Network/FlowFormerCov/flownet.py:26; hyper-parameters Config/Train/Demo.yaml:20-36; token shape covhead.py:61-64.  The submodule's
+ * source is absent from the reference checkout: shapes restated from the published FlowFormer sources (oracle/patch_embed.py), parity pinned
+ * to F.conv2d.  bf16 matrix pipe, fp32 accumulate, intermediate maps in LDS (never in HBM).
+ *   mv_patch_embed_pack   OIHW fp32 weights + biases of the three Conv2d layers -> fragment-ordered bf16 (+ fp32 biases), once per model
+ *   mv_cost_patch_embed   cost_maps [S, H2, W2] fp32 -> token_layout ? [S, (H2/8)*(W2/8), 64] : [S, 64, H2/8, W2/8] fp32
+ *   mv_cost_patch_embed_supported   the slice sizes the LDS plan covers (60 x 80 = 640x480 frames); others: MV_ERR_UNSUPPORTED */
+size_t mv_patch_embed_packed_bytes(void);
+int mv_patch_embed_pack(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, void* packed,
+                        mvStream_t stream);
+int mv_cost_patch_embed_supported(int H2, int W2);
+int mv_cost_patch_embed(const float* cost_maps, const void* packed, float* out, int S, int H2, int W2, int token_layout, mvStream_t stream);
+/* -------------------------------------------------------------------------------------------
  * A5, split + streaming form (csrc/corr_volume_split.hip): the same volume from fp32 feature maps on the 16-bit matrix pipe.
  * gfx950 has no TF32 MFMA; the reference runs this GEMM in TF32 / fp16 (Module/Frontend/Frontend.py:275-277,
  * Config/Experiment/MACVO/MACVO_Fast.yaml:69-76).  mode MV_PACK_BF16X3: x = p0 + p1 + p2 (bf16 pieces, residuals exact), product
@@ -120,6 +135,17 @@ const char* mv_corr_volume_last_kernel(void);
  */
 int mv_corr_lookup(const float* vol, const float* coords, float* out, int B, int H1, int W1,
                    int H2, int W2, int radius, mvStream_t stream);
+
+/* Fast mode (Config/Experiment/MACVO/MACVO_Fast.yaml:73-74: enc_dtype fp16): with 16-bit feature maps the reference's `einsum` returns the
+ * volume in that 16-bit type and Module/Network/FlowFormerCov/flownet.py:27 merely widens it.  mv_corr_volume_out16 is that einsum with its ONE
+ * rounding (fp32 accumulators -> round-to-nearest-even -> in_dtype) in the GEMM's epilogue and 2-byte cells: out [B, N1, N2] of in_dtype, half the
+ * bytes of the output-bound kernel.  HWC feature maps, C = 128 / 256, N2 % 64 == 0 (mv_corr_volume_out16_supported; MV_ERR_UNSUPPORTED otherwise:
+ * use mv_corr_volume + a cast).  mv_corr_lookup_vol16 is mv_corr_lookup on such an fp16 volume (cells widened on load = `cost_maps.float()`,
+ * everything behind the load identical to the fp32 form); radius 4. */
+int mv_corr_volume_out16_supported(int B, int C, int N1, int N2, int in_dtype, int layout);
+int mv_corr_volume_out16(const void* f1, const void* f2, void* out, int B, int C, int N1, int N2, int in_dtype, int layout, mvStream_t stream);
+int mv_corr_lookup_vol16(const void* vol_f16, const float* coords, float* out, int B, int H1, int W1, int H2, int W2, int radius,
+                         mvStream_t stream);
 
 /* The same lookup (same reference code, Module/Network/FlowFormerCov/covhead.py:92) on a volume whose per-query slices are stored in
  * 4 x 4-cell tiles: vol[(b N1 + q) H2 W2 + ((y / 4) * (W2 / 4) + x / 4) * 16 + (y % 4) * 4 + x % 4] — what mv_corr_volume_packed writes

@@ -25,8 +25,11 @@
 
 namespace {
 
-template <int R, int QPW, int QPB>
-__global__ __launch_bounds__(64 * (QPB / QPW)) void corr_lookup_kernel(const float* __restrict__ vol,
+// VT = float, or _Float16 for the Fast-mode volume that is STORED in the encoder's 16-bit type (mv_corr_volume_out16: what
+// `einsum` returns when the encoder runs in fp16, Config/Experiment/MACVO/MACVO_Fast.yaml:73-74; flownet.py:27 only widens it): the cells
+// are widened on load — exactly `cost_maps.float()` — and everything behind the load is the fp32 arithmetic of the fp32 form.
+template <int R, int QPW, int QPB, typename VT = float>
+__global__ __launch_bounds__(64 * (QPB / QPW)) void corr_lookup_kernel(const VT* __restrict__ vol,
                                                                         const float* __restrict__ coords,
                                                                         float* __restrict__ out, int N1, int H2, int W2) {
     constexpr int K = 2 * R + 1;
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(64 * (QPB / QPW)) void corr_lookup_kernel(const flo
     for (int s = 0; s < QPW; ++s) {
         const int sbx = __builtin_amdgcn_readlane(bx, s), sby = __builtin_amdgcn_readlane(by, s);
         const int q = q0 + wave * QPW + s;
-        const float* __restrict__ base = vol + ((size_t)b * N1 + q) * slice;
+        const VT* __restrict__ base = vol + ((size_t)b * N1 + q) * slice;
         const int gx = sbx + cxl;
         if (TRIM) {
             const int mg = __builtin_amdgcn_readlane(margin, s);                 // wave-uniform
@@ -96,13 +99,13 @@ __global__ __launch_bounds__(64 * (QPB / QPW)) void corr_lookup_kernel(const flo
             for (int k = 0; k < NINNER; ++k) {                                   // inner rows 1 .. BS - 2
                 const int row = 1 + k * RPR + cyl, gy = sby + row;
                 const bool ok = okx && gy >= 0 && gy < H2;
-                v[s][k] = ok ? base[gy * W2 + gx] : 0.f;
+                v[s][k] = ok ? (float)base[gy * W2 + gx] : 0.f;
             }
             v[s][NROUND - 1] = 0.f;
             if (mg & 12) {                                                       // rare: the margin rows, lanes [0, BS) row 0, [BS, 2 BS) row BS - 1
                 const int row = cyl == 0 ? 0 : BS - 1, gy = sby + row;
                 const bool ok = okx && cyl < 2 && ((mg >> (cyl == 0 ? 2 : 3)) & 1) && gy >= 0 && gy < H2;
-                v[s][NROUND - 1] = ok ? base[gy * W2 + gx] : 0.f;
+                v[s][NROUND - 1] = ok ? (float)base[gy * W2 + gx] : 0.f;
             }
         } else {
             const bool okx = lane < LPR && q < N1 && gx >= 0 && gx < W2;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(64 * (QPB / QPW)) void corr_lookup_kernel(const flo
             for (int k = 0; k < NROUND; ++k) {
                 const int row = k * RPR + cyl, gy = sby + row;
                 const bool ok = okx && row < BS && gy >= 0 && gy < H2;
-                v[s][k] = ok ? base[gy * W2 + gx] : 0.f;
+                v[s][k] = ok ? (float)base[gy * W2 + gx] : 0.f;
             }
         }
     }
@@ -375,6 +378,22 @@ extern "C" int mv_corr_lookup(const float* vol, const float* coords, float* out,
         default: MV_LOOKUP(4); break;
     }
 #undef MV_LOOKUP
+    return mv_launch_status();
+}
+
+// the same lookup on a volume stored as fp16 (mv_corr_volume_out16): half the bytes per cell; tokens are fp32
+extern "C" int mv_corr_lookup_vol16(const void* vol, const float* coords, float* out, int B, int H1, int W1, int H2, int W2, int radius,
+                                    mvStream_t stream) {
+    MV_CHECK_ARG(vol && coords && out);
+    MV_CHECK_ARG(B > 0 && H1 > 0 && W1 > 0 && H2 > 1 && W2 > 1);
+    if (radius != 4 || B > 65535) return MV_ERR_UNSUPPORTED;
+    const int N1 = H1 * W1;
+    hipStream_t s = (hipStream_t)stream;
+    const _Float16* v = reinterpret_cast<const _Float16*>(vol);
+    if ((size_t)B * N1 <= (size_t)lookup_small_threshold())
+        hipLaunchKernelGGL((corr_lookup_kernel<4, 2, 16, _Float16>), dim3(mv_ceil_div(N1, 16), B), dim3(512), 0, s, v, coords, out, N1, H2, W2);
+    else
+        hipLaunchKernelGGL((corr_lookup_kernel<4, 4, 32, _Float16>), dim3(mv_ceil_div(N1, 32), B), dim3(512), 0, s, v, coords, out, N1, H2, W2);
     return mv_launch_status();
 }
 

@@ -1003,10 +1003,18 @@ __global__ __launch_bounds__(256) void corr_volume_h_hwc(const uint16_t* __restr
 // ------------------------------------------------------------------------------------------------
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-template <bool IS_BF16, int KS>
+// OUT16 (round 4, the Fast-mode volume AS THE REFERENCE COMPUTES IT): with the encoder in fp16 / bf16 (MACVO_Fast.yaml:73-74) `einsum` returns the
+// volume in that 16-bit type and flownet.py:27 merely widens it.  The epilogue then rounds the fp32 accumulators ONCE (round-to-nearest-even,
+// what the library GEMM's epilogue does) and stores 2-byte cells: 92 MB per 640x480 frame instead of 184 MB for a kernel that is bound by its
+// output.  The MFMA C layout gives a lane ONE column of 16 rows, so two rows are handled together: the lane pair (2 i, 2 i + 1) swaps one value
+// by DPP (quad_perm [1,0,3,2]) — the even lane then holds columns (li, li + 1) of row r, the odd lane columns (li - 1, li) of row r + 1 — and
+// every lane stores one packed dword: 16 stores per item instead of 32 (the hand-counted vmcnt constants follow: NST).
+template <bool IS_BF16, int KS, bool OUT16 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void corr_volume_h_stream(
     const uint16_t* __restrict__ f1, const uint16_t* __restrict__ f2, float* __restrict__ out, int N1, int N2, int B, int R) {
     constexpr int C = KS * 16, CH = KS * 2;      // channels; 16-byte chunks per row
+    constexpr int NST = OUT16 ? 16 : 32;         // stores per wave and item
+    constexpr int OSZ = OUT16 ? 2 : 4;           // bytes per output cell
     constexpr int RPI = 64 / CH;                 // B rows one wave-wide LDS-DMA instruction covers (64 lanes x 16 B = 1 KB)
     constexpr int NP = 64 / (4 * RPI);           // LDS-DMA instructions per wave and sub-tile (4 waves)
     constexpr int RPK = 16 / KS;                 // accumulator rows stored per k-step of the NEXT sub-tile
@@ -1087,23 +1095,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int slot = 0;
     const int sw = li & 15;                      // fragment rows li and li + 32 share the swizzle
     float* O = nullptr;                          // wave-uniform: column 0 of the CURRENT item's output block (row 0 of the pair)
+    constexpr int OADV = OUT16 ? 32 : 64;        // one item = 64 columns, in units of sizeof(float)
     // per-lane BYTE offsets of the 16 accumulator rows (C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)),
     // fixed for a band: stores are `uniform base + 32-bit lane offset`, no address arithmetic between the MFMAs.
     // Rows past N1 (last band) hold copies of row N1 - 1 (the A rows are clamped the same way): they are stored ON TOP of row
     // N1 - 1 with identical values instead of being branched around.
-    unsigned roff[16];
+    unsigned roff[16];                           // (OUT16: entry 2 i = this lane's offset for the row pair (2 i, 2 i + 1))
+    const bool odd_lane = lane & 1;
+    auto pack16 = [&](float lo, float hi) __attribute__((always_inline)) -> unsigned {
+        if (IS_BF16) return (unsigned)__builtin_bit_cast(uint16_t, (__bf16)lo) | ((unsigned)__builtin_bit_cast(uint16_t, (__bf16)hi) << 16);
+        return (unsigned)__builtin_bit_cast(uint16_t, (_Float16)lo) | ((unsigned)__builtin_bit_cast(uint16_t, (_Float16)hi) << 16);
+    };
     auto store_r = [&](const f32x16& p0, const f32x16& p1, int r, float* Ob) __attribute__((always_inline)) {
         // asm: hipcc strength-reduces `Ob + roff[r]` into sixteen 64-bit per-lane pointers (32 VGPRs -> spills at the 256-register
         // budget of 2 waves / SIMD); the SGPR-base form needs none.  Like the DMA above these are counted by hand.
-        asm volatile("global_store_dword %0, %1, %2" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(p0[r]), "s"(Ob) : "memory");
-        asm volatile("global_store_dword %0, %1, %2 offset:128" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(p1[r]), "s"(Ob) : "memory");
+        if (OUT16) {                             // r even: rows (r, r + 1) of both column blocks, one packed dword each
+            const float s0 = odd_lane ? p0[r] : p0[r + 1], s1 = odd_lane ? p1[r] : p1[r + 1];     // what the neighbour lane needs
+            const float g0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, false));
+            const float g1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, false));
+            const unsigned d0 = odd_lane ? pack16(g0, p0[r + 1]) : pack16(p0[r], g0);
+            const unsigned d1 = odd_lane ? pack16(g1, p1[r + 1]) : pack16(p1[r], g1);
+            asm volatile("global_store_dword %0, %1, %2" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(d0), "s"(Ob) : "memory");
+            asm volatile("global_store_dword %0, %1, %2 offset:64" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(d1), "s"(Ob) : "memory");
+        } else {
+            asm volatile("global_store_dword %0, %1, %2" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(p0[r]), "s"(Ob) : "memory");
+            asm volatile("global_store_dword %0, %1, %2 offset:128" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(p1[r]), "s"(Ob) : "memory");
+        }
     };
     // one sub-tile: ring upkeep, 2 x KS MFMAs into (c0, c1); with PREV the 32 stores of (p0, p1) ride between them
     auto step = [&](auto PREV, f32x16& c0, f32x16& c1, const f32x16& p0, const f32x16& p1) __attribute__((always_inline)) {
         constexpr bool HAVE_PREV = decltype(PREV)::value;
         // this wave's DMA pieces of ring slot `slot` were issued before the last 32 stores (or everything has been drained since);
         // behind the barrier all four waves' pieces are in, and everyone has left slot ^ 1
-        wait_vmcnt_barrier<32>();
+        wait_vmcnt_barrier<NST>();
         issue_b(slot ^ 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.f;
@@ -1132,22 +1156,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[ks]), __builtin_bit_cast(f16x8, b1), c1, 0, 0, 0);
             }
             if (HAVE_PREV) {
+                if (OUT16) {                     // a row PAIR per store: behind the k-step that completes it
+                    if (RPK == 1) { if (ks & 1) store_r(p0, p1, ks - 1, O - OADV); }
+                    else {
 #pragma unroll
-                for (int q = 0; q < RPK; ++q) store_r(p0, p1, ks * RPK + q, O - 64);
+                        for (int q = 0; q < RPK; q += 2) store_r(p0, p1, ks * RPK + q, O - OADV);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < RPK; ++q) store_r(p0, p1, ks * RPK + q, O - OADV);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (!HAVE_PREV) wait_vmcnt<0>();         // no stores went out behind this pass's DMA: the next pass's vmcnt(32) would not cover it
+        if (!HAVE_PREV) wait_vmcnt<0>();         // no stores went out behind this pass's DMA: the next pass's vmcnt(NST) would not cover it
         ++it;
         slot ^= 1;
-        O += 64;
+        O += OADV;
     };
     auto flush = [&](const f32x16& p0, const f32x16& p1) __attribute__((always_inline)) {
         // asm stores straight behind the last MFMAs: "XDL write VGPR -> VMEM read" is a software hazard (11 wait states for an
         // 8-pass MFMA) that hipcc's hazard recognizer does not see through inline asm
         asm volatile("s_nop 15" ::: "memory");
 #pragma unroll
-        for (int r = 0; r < 16; ++r) store_r(p0, p1, r, O - 64);
+        for (int r = 0; r < 16; r += (OUT16 ? 2 : 1)) store_r(p0, p1, r, O - OADV);
     };
     using Yes = std::true_type;
     using No = std::false_type;
@@ -1178,10 +1210,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             asm volatile("" : "+v"(afr[ks]));    // the fragments count as defined only here, behind the hand-placed wait
             af[ks] = __builtin_bit_cast(s16x8, afr[ks]);
         }
-        O = out + (size_t)b * N1 * N2 + (size_t)c0i * 64;
+        O = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + ((size_t)b * N1 * N2 + (size_t)c0i * 64) * OSZ);
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            roff[r] = ((unsigned)min(band * 128 + wave * 32 + 4 * kh + (r & 3) + 8 * (r >> 2), N1 - 1) * (unsigned)N2 + li) * 4u;
+        for (int r = 0; r < 16; ++r) {
+            // OUT16: entry r (even) addresses row r for even lanes (columns li, li + 1) and row r + 1 for odd lanes (columns li - 1, li)
+            const int rr = OUT16 ? (r & ~1) + (lane & 1) : r;
+            const int col = OUT16 ? (li & ~1) : li;
+            roff[r] = ((unsigned)min(band * 128 + wave * 32 + 4 * kh + (rr & 3) + 8 * (rr >> 2), N1 - 1) * (unsigned)N2 + col) * (unsigned)OSZ;
+        }
         step(No{}, x0, x1, x0, x1);
         while (it + 2 <= seg_end) {
             step(Yes{}, y0, y1, x0, x1);
@@ -1197,7 +1233,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (odd) flush(y0, y1);
         else flush(x0, x1);
         if (!more) break;
-        wait_vmcnt<32>();                        // the A loads precede the 32 flush stores
+        wait_vmcnt<NST>();                       // the A loads precede the NST flush stores
     }
 }
 
@@ -1575,6 +1611,55 @@ static bool stream_items_fit(int B, int N1, int N2) {
     return (size_t)B * (size_t)((N1 + 127) / 128) * (size_t)(N2 / 64) < ((size_t)1 << 31);
 }
 
+// the 16-bit streaming kernel's domain and launch (shared by mv_corr_volume and mv_corr_volume_out16)
+static bool h_stream_supported(int B, int C, int N1, int N2) {
+    return (C == 256 || C == 128) && (N2 % 64) == 0 && ((size_t)N1 * N2 * B) >= ((size_t)1 << 22) &&
+           ((size_t)N1 * N2) < ((size_t)1 << 30) &&   // (32-bit byte offsets inside a pair's block of the output)
+           stream_items_fit(B, N1, N2);               // (the item index T = B * bands * sub-tiles is an int)
+}
+
+static int launch_h_stream(const uint16_t* a, const uint16_t* b, void* outp, bool out16, bool bf, int B, int C, int N1, int N2, hipStream_t s) {
+    float* out = reinterpret_cast<float*>(outp);
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+    }
+    static int wgs = 0;    // workgroups per CU; LDS is padded so that exactly this many are resident
+    if (!wgs) { const char* e = getenv("MV_H_STREAM_WGS"); wgs = e ? atoi(e) : 2; if (wgs < 1 || wgs > 4) wgs = 2; }
+    const unsigned ring = (unsigned)(2 * 64 * (C / 8) * 16);            // 2-slot B ring
+    const unsigned lds = std::max(ring, (unsigned)(160 * 1024 / (wgs + 1) + 1024));
+    static bool attr_done = false;
+    if (!attr_done) {
+#define MV_HS_ATTR(...) (void)hipFuncSetAttribute((const void*)corr_volume_h_stream<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+        MV_HS_ATTR(true, 16); MV_HS_ATTR(false, 16); MV_HS_ATTR(true, 8); MV_HS_ATTR(false, 8);
+        MV_HS_ATTR(true, 16, true); MV_HS_ATTR(false, 16, true); MV_HS_ATTR(true, 8, true); MV_HS_ATTR(false, 8, true);
+#undef MV_HS_ATTR
+        attr_done = true;
+    }
+    const dim3 g((cus & ~7) * wgs), blk(256);                           // a multiple of 8: one run per XCD
+    // column regions: one region's B rows (nc / R sub-tiles x 64 rows x 2C bytes) <= 2 MB of an XCD's 4 MB L2 (measured: 640x480
+    // 1 region (2.4 MB) 47.5 us, 2 regions 41.2, 3: 43.6; 1280x720 4 regions (1.8 MB) 324 us, 6 regions 345)
+    static int regs_env = -1;  // MV_H_STREAM_REGIONS: A/B knob
+    if (regs_env < 0) { const char* e = getenv("MV_H_STREAM_REGIONS"); regs_env = e ? atoi(e) : 0; }
+    const int nc = N2 / 64;
+    int R = regs_env > 0 ? regs_env : (int)(((size_t)nc * 64 * C * 2 + (2u << 20) - 1) / (2u << 20));
+    R = std::max(1, std::min(R, nc));
+    MV_VOL_KERNEL(out16 ? "corr_volume_h_stream<out16>" : "corr_volume_h_stream");
+#define MV_HS_GO(...) hipLaunchKernelGGL((corr_volume_h_stream<__VA_ARGS__>), g, blk, lds, s, a, b, out, N1, N2, B, R)
+    if (out16) {
+        if (C == 256) { if (bf) MV_HS_GO(true, 16, true); else MV_HS_GO(false, 16, true); }
+        else { if (bf) MV_HS_GO(true, 8, true); else MV_HS_GO(false, 8, true); }
+    } else {
+        if (C == 256) { if (bf) MV_HS_GO(true, 16); else MV_HS_GO(false, 16); }
+        else { if (bf) MV_HS_GO(true, 8); else MV_HS_GO(false, 8); }
+    }
+#undef MV_HS_GO
+    return mv_launch_status();
+}
+
 extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B, int C, int N1, int N2,
                               int in_dtype, int layout, mvStream_t stream) {
     MV_CHECK_ARG(f1 && f2 && out);
@@ -1699,46 +1784,7 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
             if (C % 32) return MV_ERR_UNSUPPORTED;
             static int hstream = -1;   // MV_H_STREAM=0: the tile form below (A/B knob)
             if (hstream < 0) { const char* e = getenv("MV_H_STREAM"); hstream = (e && atoi(e) == 0) ? 0 : 1; }
-            if (hstream && (C == 256 || C == 128) && (N2 % 64) == 0 && ((size_t)N1 * N2 * B) >= ((size_t)1 << 22) &&
-                ((size_t)N1 * N2) < ((size_t)1 << 30) &&   // (32-bit byte offsets inside a pair's block of the output)
-                stream_items_fit(B, N1, N2)) {             // (the item index T = B * bands * sub-tiles is an int)
-                static int cus = 0;
-                if (!cus) {
-                    int dev = 0;
-                    hipDeviceProp_t prop;
-                    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                              ? prop.multiProcessorCount : 256;
-                }
-                static int wgs = 0;    // workgroups per CU; LDS is padded so that exactly this many are resident
-                if (!wgs) { const char* e = getenv("MV_H_STREAM_WGS"); wgs = e ? atoi(e) : 2; if (wgs < 1 || wgs > 4) wgs = 2; }
-                const unsigned ring = (unsigned)(2 * 64 * (C / 8) * 16);            // 2-slot B ring
-                const unsigned lds = std::max(ring, (unsigned)(160 * 1024 / (wgs + 1) + 1024));
-                static bool attr_done = false;
-                if (!attr_done) {
-                    (void)hipFuncSetAttribute((const void*)corr_volume_h_stream<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    (void)hipFuncSetAttribute((const void*)corr_volume_h_stream<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    (void)hipFuncSetAttribute((const void*)corr_volume_h_stream<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    (void)hipFuncSetAttribute((const void*)corr_volume_h_stream<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    attr_done = true;
-                }
-                const dim3 g((cus & ~7) * wgs), blk(256);                           // a multiple of 8: one run per XCD
-                // column regions: one region's B rows (nc / R sub-tiles x 64 rows x 2C bytes) <= 2 MB of an XCD's 4 MB L2 (measured: 640x480
-                // 1 region (2.4 MB) 47.5 us, 2 regions 41.2, 3: 43.6; 1280x720 4 regions (1.8 MB) 324 us, 6 regions 345)
-                static int regs_env = -1;  // MV_H_STREAM_REGIONS: A/B knob
-                if (regs_env < 0) { const char* e = getenv("MV_H_STREAM_REGIONS"); regs_env = e ? atoi(e) : 0; }
-                const int nc = N2 / 64;
-                int R = regs_env > 0 ? regs_env : (int)(((size_t)nc * 64 * C * 2 + (2u << 20) - 1) / (2u << 20));
-                R = std::max(1, std::min(R, nc));
-                MV_VOL_KERNEL("corr_volume_h_stream");
-                if (C == 256) {
-                    if (bf) hipLaunchKernelGGL((corr_volume_h_stream<true, 16>), g, blk, lds, s, a, b, out, N1, N2, B, R);
-                    else hipLaunchKernelGGL((corr_volume_h_stream<false, 16>), g, blk, lds, s, a, b, out, N1, N2, B, R);
-                } else {
-                    if (bf) hipLaunchKernelGGL((corr_volume_h_stream<true, 8>), g, blk, lds, s, a, b, out, N1, N2, B, R);
-                    else hipLaunchKernelGGL((corr_volume_h_stream<false, 8>), g, blk, lds, s, a, b, out, N1, N2, B, R);
-                }
-                return mv_launch_status();
-            }
+            if (hstream && h_stream_supported(B, C, N1, N2)) return launch_h_stream(a, b, out, false, bf, B, C, N1, N2, s);
             MV_VOL_KERNEL("corr_volume_h_hwc");
             static int hbk = -1;
             if (hbk < 0) { const char* e = getenv("MV_H_BK"); hbk = e ? atoi(e) : 32; }
@@ -1761,6 +1807,20 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
         return MV_ERR_INVALID_ARG;
     }
     return mv_launch_status();
+}
+
+// A5, Fast mode: the volume in the ENCODER's 16-bit type (what `einsum` returns for fp16 / bf16 feature maps; flownet.py:27 widens it afterwards).
+// One rounding in the GEMM's epilogue, 2-byte cells: [B, N1, N2] of in_dtype.  HWC feature maps, C = 128 / 256, N2 % 64 == 0 (the streaming
+// kernel's domain): MV_ERR_UNSUPPORTED otherwise — callers then use mv_corr_volume + a cast.  Read it with mv_corr_lookup_vol16 (fp16).
+extern "C" int mv_corr_volume_out16_supported(int B, int C, int N1, int N2, int in_dtype, int layout) {
+    return (in_dtype == MV_F16 || in_dtype == MV_BF16) && layout == MV_LAYOUT_HWC && B > 0 && N1 > 0 && N2 > 0 && h_stream_supported(B, C, N1, N2);
+}
+extern "C" int mv_corr_volume_out16(const void* f1, const void* f2, void* out, int B, int C, int N1, int N2, int in_dtype, int layout,
+                                    mvStream_t stream) {
+    MV_CHECK_ARG(f1 && f2 && out && B > 0 && C > 0 && N1 > 0 && N2 > 0);
+    MV_CHECK_ARG(((uintptr_t)f1 & 15) == 0 && ((uintptr_t)f2 & 15) == 0 && ((uintptr_t)out & 3) == 0);
+    if (!mv_corr_volume_out16_supported(B, C, N1, N2, in_dtype, layout)) return MV_ERR_UNSUPPORTED;
+    return launch_h_stream((const uint16_t*)f1, (const uint16_t*)f2, out, true, in_dtype == MV_BF16, B, C, N1, N2, (hipStream_t)stream);
 }
 
 extern "C" int mv_split_bf16x3(const float* x, void* planes, size_t n, mvStream_t stream) {

@@ -1,0 +1,346 @@
+// (f)2 — the consumer side of the cost volume: FlowFormer's cost PATCH EMBEDDING, fused  (round 4)
+//
+//   cost_maps [S = B·H1·W1, 1, H2, W2] fp32 (one H2 x W2 slice per query pixel, what mv_corr_volume writes)
+//     -> F.pad to multiples of 8 (bottom / right) -> Conv2d(1, 16, 6, stride 2, pad 2) -> ReLU -> Conv2d(16, 32, 6, 2, 2) -> ReLU
+//     -> Conv2d(32, 64, 6, 2, 2)  ->  [S, 64, H2/8, W2/8]   (the `proj` stack of FlowFormer's PatchEmbed for patch_size 8,
+//   embed_dim = cost_latent_input_dim = 64; reached from Module/Network/FlowFormerCov/flownet.py:26 through MemoryEncoder; hyper-parameters
+//   Config/Train/Demo.yaml:20-36; the result's token form [S, H2'·W2', C] is what covhead.py:61-64 documents for cost_memory's source).
+//   The FlowFormer submodule is EMPTY in the reference checkout: layer shapes restated from the published FlowFormer sources — parity is
+//   pinned to torch's F.conv2d chain on the same weights (oracle/patch_embed.py), "parity unpinned" against the MAC-VO fork itself.
+//
+// Why fused.  23.6 GFLOP of volume feed 2 x 9600 slices x 25.1 MFLOP = 241 GFLOP of convolutions per 640x480 frame — 10x the GEMM — and the
+// unfused form moves every slice four times through HBM (read 184 MB, write + read 2 x 197 MB of 16-channel maps, 2 x 98 MB of 32-channel
+// maps, write 197 MB).  Here a workgroup keeps a slice and both intermediate maps in LDS: HBM traffic is the slice in (19.2 KB) and the
+// tokens out (20.5 KB fp32), every multiply-add runs on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, fp32 accumulate), activations are
+// rounded to bf16 between the layers (the reference runs this encoder in fp16 / bf16 in its Fast mode, MACVO_Fast.yaml:73-74).
+//
+// Implicit GEMMs (M = output pixels, N = output channels, K = taps x input channels, cin innermost so that one lane's 8 consecutive k are 16
+// contiguous bytes of an HWC activation map in LDS):
+//   conv1  M = 32x40 = 1280 (40 tiles), N = 16 (half of a 32-wide tile), K = 6 ky x 8 kx' (kx' = 6, 7 carry zero weights) = 3 k-steps
+//   conv2  M = 16x20 = 320 (10 tiles), N = 32, K = 36 taps x 16 = 36 k-steps; waves = (K half, every other tile): 5 tiles x 18 k-steps each,
+//          weights (36 KB) resident in LDS for the whole kernel
+//   conv3  TWO slices per pass: M = 2 x 8x10 = 160 (5 tiles), N = 64 (2 tiles), K = 36 taps x 32 = 72 k-steps; waves = (K half, N tile): 5 tiles x
+//          36 k-steps each; its 144 KB of weights stream from L2 (one 1-KB fragment per wave and k-step feeds 5 MFMAs; two slices per pass halve
+//          that stream: 73.7 KB per slice)
+//   K halves are summed through LDS (the dead conv1 map).  840 MFMAs per slice = 6720 matrix-pipe cycles per wave and slice.
+// LDS: conv2 weights 36,864 + slice (bf16, halo 2, pitch 88) 11,968 + conv1 map 36x44x16 50,688 + 2 x conv2 map 20x24x32 61,440 = 160,960 B.
+#include "common.h"
+#include <algorithm>
+#include <atomic>
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+template <int H2, int W2>
+struct PE {
+    static constexpr int HP = (H2 + 7) / 8 * 8, WP = (W2 + 7) / 8 * 8;
+    static constexpr int H1 = HP / 2, W1 = WP / 2, H2o = HP / 4, W2o = WP / 4, H3 = HP / 8, W3 = WP / 8;
+    static constexpr int M1 = H1 * W1, M2 = H2o * W2o, M3 = H3 * W3;
+    static constexpr int T1 = M1 / 32, T2 = M2 / 32, T3 = 2 * M3 / 32;     // 32-pixel tiles (conv3: of the two slices of a pass together)
+    static_assert(M1 % 128 == 0 && M2 % 64 == 0 && (2 * M3) % 32 == 0, "tile split across the four waves");
+    static constexpr int IN_ROWS = HP + 4, IN_PITCH = WP + 8;              // halo 2; the kx' = 6, 7 padding taps read two columns further
+    static constexpr int O1_ROWS = H1 + 4, O1_COLS = W1 + 4;               // x 16 channels (bf16, HWC)
+    static constexpr int O2_ROWS = H2o + 4, O2_COLS = W2o + 4;             // x 32 channels
+    static constexpr unsigned OFF_W2 = 0, W2_BYTES = 36 * 1024;
+    static constexpr unsigned OFF_IN0 = OFF_W2 + W2_BYTES, IN0_BYTES = IN_ROWS * IN_PITCH * 2;
+    static constexpr unsigned OFF_O1 = OFF_IN0 + IN0_BYTES, O1_BYTES = O1_ROWS * O1_COLS * 32;
+    static constexpr unsigned OFF_O2 = OFF_O1 + O1_BYTES, O2_BYTES = O2_ROWS * O2_COLS * 64;
+    static constexpr unsigned LDS_BYTES = OFF_O2 + 2 * O2_BYTES;
+    static constexpr unsigned SCRATCH_BYTES = 2 * 5 * 16 * 256;            // K-half partial sums: 2 waves x 5 tiles x 16 registers x 64 lanes fp32
+    static_assert(T2 == 10 && T3 == 5, "five tiles per wave in conv2 and conv3");
+    static_assert(SCRATCH_BYTES <= O1_BYTES && LDS_BYTES <= 160 * 1024, "LDS plan");
+    static constexpr int Q4 = H2 * W2 / 4;                                 // float4s of a slice
+    static_assert(W2 % 4 == 0 && Q4 <= 5 * 256, "slice staging: at most five float4 per thread");
+};
+
+// packed weights (mv_patch_embed_pack): bf16 fragments in MFMA B-operand order — lane l holds n = l % 32, k = 8 (l / 32) + 0..7 — then biases
+//   [0, 3 KB)            conv1: 3 k-steps; k = (ky = 2 s + l / 32, kx' = j), zero for n >= 16 or kx' >= 6
+//   [3 KB, 39 KB)        conv2: k-step = tap ky*6 + kx; k = cin
+//   [39 KB, 183 KB)      conv3: [n tile 2][k-step 72 = tap * 2 + cin half]; k = cin % 16
+//   then fp32 b1[32] (16 used), b2[32], b3[64]
+constexpr size_t PE_W1_OFF = 0, PE_W2_OFF = 3 * 1024, PE_W3_OFF = 39 * 1024, PE_B_OFF = 183 * 1024, PE_PACKED_BYTES = PE_B_OFF + 128 * 4;
+
+__global__ void patch_embed_pack_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                        const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3,
+                                        uint16_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // one 16-bit element of the fragment area
+    const int total = (int)(PE_B_OFF / 2);
+    if (i < total) {
+        const int unit = i >> 9, lane = (i >> 3) & 63, j = i & 7, n = lane & 31, g = lane >> 5;
+        float v = 0.f;
+        if (unit < 3) {                                        // conv1 [16,1,6,6]
+            const int ky = 2 * unit + g;
+            if (n < 16 && j < 6) v = w1[(n * 6 + ky) * 6 + j];
+        } else if (unit < 39) {                                // conv2 [32,16,6,6]
+            const int tap = unit - 3, cin = g * 8 + j;
+            v = w2[((size_t)n * 16 + cin) * 36 + tap];
+        } else {                                               // conv3 [64,32,6,6]
+            const int u = unit - 39, nt = u / 72, t = u % 72, tap = t >> 1, cin = (t & 1) * 16 + g * 8 + j;
+            v = w3[((size_t)(nt * 32 + n) * 32 + cin) * 36 + tap];
+        }
+        out[i] = __builtin_bit_cast(uint16_t, (__bf16)v);
+    }
+    if (i < 128) {
+        float* b = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + PE_B_OFF);
+        b[i] = i < 16 ? b1[i] : (i < 32 ? 0.f : (i < 64 ? b2[i - 32] : b3[i - 64]));
+    }
+}
+
+__device__ __forceinline__ uint16_t bf16_bits(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
+__device__ __forceinline__ unsigned bf16_pack(float lo, float hi) { return (unsigned)bf16_bits(lo) | ((unsigned)bf16_bits(hi) << 16); }
+
+template <int H2, int W2, bool TOKENS>
+__global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __restrict__ vol, const char* __restrict__ wp,
+                                                               float* __restrict__ out, int S) {
+    using P = PE<H2, W2>;
+    extern __shared__ __attribute__((aligned(16))) char smem_pe[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int n32 = lane & 31, g = lane >> 5;
+    const int kh = wave & 1, hs = wave >> 1;           // K half; conv2: tile parity, conv3: N tile
+    char* const in0 = smem_pe + P::OFF_IN0;
+    char* const o1 = smem_pe + P::OFF_O1;
+    char* const o2 = smem_pe + P::OFF_O2;
+
+    // ---- once per workgroup: zero the activation buffers (their halos stay zero), conv2 weights -> LDS, conv1 weights + biases -> registers
+    for (unsigned a = (unsigned)t * 16u; a < P::LDS_BYTES - P::OFF_IN0; a += 256u * 16u) *reinterpret_cast<i32x4*>(in0 + a) = i32x4{0, 0, 0, 0};
+    for (unsigned a = (unsigned)t * 16u; a < P::W2_BYTES; a += 256u * 16u)
+        *reinterpret_cast<i32x4*>(smem_pe + P::OFF_W2 + a) = *reinterpret_cast<const i32x4*>(wp + PE_W2_OFF + a);
+    i32x4 w1f[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) w1f[s] = *reinterpret_cast<const i32x4*>(wp + PE_W1_OFF + (s * 64 + lane) * 16);
+    const float* bias = reinterpret_cast<const float*>(wp + PE_B_OFF);
+    const float b1v = bias[n32], b2v = bias[32 + n32], b3v = bias[64 + hs * 32 + n32];
+    const char* const w3 = wp + PE_W3_OFF + ((size_t)(hs * 72 + kh * 36) * 64 + lane) * 16;   // this wave's 36 conv3 fragments
+    __syncthreads();
+
+    auto zero_o1_halo = [&]() {                        // the K-half scratch lives in the conv1 map: restore its zero halo afterwards
+        for (int c = t; c < 4 * P::O1_COLS + 4 * P::H1; c += 256) {
+            int row, col;
+            if (c < 4 * P::O1_COLS) {
+                const int r = c / P::O1_COLS;
+                row = r < 2 ? r : P::O1_ROWS - 4 + r;
+                col = c - r * P::O1_COLS;
+            } else {
+                const int d = c - 4 * P::O1_COLS, r = d >> 2, q = d & 3;
+                row = 2 + r;
+                col = q < 2 ? q : P::O1_COLS - 4 + q;
+            }
+            i32x4* p = reinterpret_cast<i32x4*>(o1 + (row * P::O1_COLS + col) * 32);
+            p[0] = i32x4{0, 0, 0, 0};
+            p[1] = i32x4{0, 0, 0, 0};
+        }
+    };
+    // slice staging: this thread's float4s of the NEXT slice travel in registers while the current one is convolved
+    f32x4 pre[5];
+    auto fetch = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int q = t + 256 * i;
+            pre[i] = (s < S && q < P::Q4) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vol + (size_t)s * (H2 * W2)) + q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    const int npass = (S + 1) >> 1;
+    int pass = blockIdx.x;
+    if (pass < npass) fetch(2 * pass);
+    for (; pass < npass; pass += gridDim.x) {
+#pragma unroll 1
+        for (int gs = 0; gs < 2; ++gs) {
+            // ---- (A) slice -> in0 (bf16), next slice -> registers
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int q = t + 256 * i;
+                if (q < P::Q4) {
+                    const int y = q / (W2 / 4), x = 4 * (q - y * (W2 / 4));
+                    unsigned* d = reinterpret_cast<unsigned*>(in0 + ((y + 2) * P::IN_PITCH + x + 2) * 2);
+                    d[0] = bf16_pack(pre[i][0], pre[i][1]);
+                    d[1] = bf16_pack(pre[i][2], pre[i][3]);
+                }
+            }
+            fetch(gs == 0 ? 2 * pass + 1 : 2 * (pass + (int)gridDim.x));
+            __syncthreads();
+            // ---- (C) conv1: 10 tiles per wave, 3 k-steps; k-step s of lane group g = input row 2 oy + 2 s + g, columns 2 ox .. 2 ox + 7
+#pragma unroll 2
+            for (int j = 0; j < P::T1 / 4; ++j) {
+                const int tile = wave + 4 * j;
+                const int p = tile * 32 + n32, oy = p / P::W1, ox = p - oy * P::W1;
+                const char* a0 = in0 + ((2 * oy + g) * P::IN_PITCH + 2 * ox) * 2;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const unsigned* ap = reinterpret_cast<const unsigned*>(a0 + 2 * s * P::IN_PITCH * 2);
+                    const i32x4 a = {(int)ap[0], (int)ap[1], (int)ap[2], (int)ap[3]};
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, w1f[s]), acc, 0, 0, 0);
+                }
+                if (n32 < 16) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int pp = tile * 32 + 8 * (r >> 2) + 4 * g + (r & 3), y = pp / P::W1, x = pp - y * P::W1;
+                        *reinterpret_cast<uint16_t*>(o1 + (((y + 2) * P::O1_COLS + x + 2) * 16 + n32) * 2) = bf16_bits(fmaxf(acc[r] + b1v, 0.f));
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- (D) conv2: this wave = K half kh (taps 18 kh ..), tiles hs, hs + 2, .. (5)
+            {
+                f32x16 acc[5];
+                const char* abase[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+                    const int p = (hs + 2 * i) * 32 + n32, oy = p / P::W2o, ox = p - oy * P::W2o;
+                    abase[i] = o1 + ((2 * oy * P::O1_COLS + 2 * ox) * 16 + g * 8) * 2;
+                }
+                const char* wb = smem_pe + P::OFF_W2 + lane * 16;
+                auto taps = [&](auto KH) __attribute__((always_inline)) {   // (kh is wave-uniform: one instantiation per K half keeps every offset an immediate)
+#pragma unroll
+                    for (int kk = 0; kk < 18; ++kk) {
+                        constexpr int K0 = decltype(KH)::value * 18;
+                        const int tap = K0 + kk, ky = tap / 6, kx = tap - 6 * ky;
+                        const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + tap * 1024);
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) {
+                            const bf16x8 a = *reinterpret_cast<const bf16x8*>(abase[i] + (ky * P::O1_COLS + kx) * 32);
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+                        }
+                    }
+                };
+                if (kh == 0) taps(std::integral_constant<int, 0>{});
+                else taps(std::integral_constant<int, 1>{});
+                __syncthreads();                                        // everyone has read the conv1 map: it becomes the K-half scratch
+                float* sc = reinterpret_cast<float*>(o1) + (size_t)hs * (5 * 16 * 64) + lane;
+                if (kh == 1) {
+#pragma unroll
+                    for (int i = 0; i < 5; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sc[(i * 16 + r) * 64] = acc[i][r];
+                }
+                __syncthreads();
+                if (kh == 0) {
+                    char* o2g = o2 + gs * P::O2_BYTES;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int pp = (hs + 2 * i) * 32 + 8 * (r >> 2) + 4 * g + (r & 3), y = pp / P::W2o, x = pp - y * P::W2o;
+                            const float v = acc[i][r] + sc[(i * 16 + r) * 64] + b2v;
+                            *reinterpret_cast<uint16_t*>(o2g + (((y + 2) * P::O2_COLS + x + 2) * 32 + n32) * 2) = bf16_bits(fmaxf(v, 0.f));
+                        }
+                }
+                __syncthreads();
+                zero_o1_halo();
+            }
+        }
+        // ---- (E) conv3 over the two slices of the pass: this wave = K half kh (k-steps 36 kh ..), N tile hs; weights stream from L2
+        {
+            f32x16 acc[5];
+            const char* abase[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+                const int p = i * 32 + n32, sl = p / P::M3, q = p - sl * P::M3, oy = q / P::W3, ox = q - oy * P::W3;
+                abase[i] = o2 + sl * P::O2_BYTES + ((2 * oy * P::O2_COLS + 2 * ox) * 32 + g * 8) * 2;
+            }
+            constexpr int PF = 6;                                       // weight fragments in flight (L2 latency / 5 MFMAs per k-step)
+            i32x4 bq[PF];
+#pragma unroll
+            for (int j = 0; j < PF; ++j) bq[j] = *reinterpret_cast<const i32x4*>(w3 + j * 1024);
+            auto ksteps = [&](auto KH) __attribute__((always_inline)) {
+#pragma unroll
+                for (int kk = 0; kk < 36; ++kk) {
+                    constexpr int K0 = decltype(KH)::value * 36;
+                    const int tt = K0 + kk, tap = tt >> 1, ky = tap / 6, kx = tap - 6 * ky, hh = tt & 1;
+                    const i32x4 b = bq[kk % PF];
+                    if (kk + PF < 36) bq[kk % PF] = *reinterpret_cast<const i32x4*>(w3 + (kk + PF) * 1024);
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(abase[i] + ((ky * P::O2_COLS + kx) * 32 + hh * 16) * 2);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b), acc[i], 0, 0, 0);
+                    }
+                }
+            };
+            if (kh == 0) ksteps(std::integral_constant<int, 0>{});
+            else ksteps(std::integral_constant<int, 1>{});
+            __syncthreads();                                            // (the halo writes of (D) are complete in every wave)
+            float* sc = reinterpret_cast<float*>(o1) + (size_t)hs * (5 * 16 * 64) + lane;
+            if (kh == 1) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[(i * 16 + r) * 64] = acc[i][r];
+            }
+            __syncthreads();
+            if (kh == 0) {
+                const int ch = hs * 32 + n32;
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int pp = i * 32 + 8 * (r >> 2) + 4 * g + (r & 3), sl = pp / P::M3, q = pp - sl * P::M3;
+                        const int s = 2 * pass + sl;
+                        const float v = acc[i][r] + sc[(i * 16 + r) * 64] + b3v;
+                        if (s < S) {
+                            float* dst = TOKENS ? out + ((size_t)s * P::M3 + q) * 64 + ch : out + ((size_t)s * 64 + ch) * P::M3 + q;
+                            __builtin_nontemporal_store(v, dst);
+                        }
+                    }
+            }
+            __syncthreads();
+            zero_o1_halo();
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t mv_patch_embed_packed_bytes(void) { return PE_PACKED_BYTES; }
+
+extern "C" int mv_patch_embed_pack(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                                   void* packed, mvStream_t stream) {
+    MV_CHECK_ARG(w1 && b1 && w2 && b2 && w3 && b3 && packed && ((uintptr_t)packed & 15) == 0);
+    const int total = (int)(PE_B_OFF / 2);
+    hipLaunchKernelGGL(patch_embed_pack_kernel, dim3(mv_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, w3, b3,
+                       (uint16_t*)packed);
+    return mv_launch_status();
+}
+
+extern "C" int mv_cost_patch_embed_supported(int H2, int W2) { return H2 == 60 && W2 == 80; }
+
+extern "C" int mv_cost_patch_embed(const float* cost_maps, const void* packed, float* out, int S, int H2, int W2, int token_layout,
+                                   mvStream_t stream) {
+    MV_CHECK_ARG(cost_maps && packed && out && S > 0);
+    MV_CHECK_ARG(((uintptr_t)cost_maps & 15) == 0 && ((uintptr_t)packed & 15) == 0);
+    if (!mv_cost_patch_embed_supported(H2, W2)) return MV_ERR_UNSUPPORTED;   // 640x480 frames; larger slices do not fit the LDS plan
+    using P = PE<60, 80>;
+    static std::atomic<bool> attr_done[64];
+    static int cus = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_done[dev].load(std::memory_order_acquire)) {
+        (void)hipFuncSetAttribute((const void*)cost_patch_embed_kernel<60, 80, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)cost_patch_embed_kernel<60, 80, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done[dev].store(true, std::memory_order_release);
+    }
+    if (!cus) {
+        hipDeviceProp_t prop;
+        cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    const int npass = (S + 1) / 2;
+    const dim3 grid(std::min(npass, cus));                                  // persistent: one workgroup per CU (160,960 B of LDS each)
+    if (token_layout)
+        hipLaunchKernelGGL((cost_patch_embed_kernel<60, 80, true>), grid, dim3(256), P::LDS_BYTES, (hipStream_t)stream, cost_maps,
+                           (const char*)packed, out, S);
+    else
+        hipLaunchKernelGGL((cost_patch_embed_kernel<60, 80, false>), grid, dim3(256), P::LDS_BYTES, (hipStream_t)stream, cost_maps,
+                           (const char*)packed, out, S);
+    return mv_launch_status();
+}

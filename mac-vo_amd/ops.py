@@ -200,7 +200,8 @@ def corr_lookup(cost_maps: torch.Tensor, coords: torch.Tensor, radius: int = 4, 
     """``encode_flow_token(cost_maps, coords)`` (covhead.py:92): ``[B*N1,1,H2,W2]``, ``[B,2,H1,W1]`` -> ``[B,(2r+1)^2,H1,W1]``.
     ``tiled``: the slices of ``cost_maps`` are stored in 4 x 4-cell tiles (``volume_pack(tiled_hw=...)`` + ``corr_volume_packed``)."""
     lib = L.load()
-    cost_maps = _req(cost_maps, torch.float32, "cost_maps")
+    vol16 = cost_maps.dtype == torch.float16                    # Fast mode: the volume as `corr_volume_out16` stores it
+    cost_maps = _req(cost_maps, torch.float16 if vol16 else torch.float32, "cost_maps")
     coords = _req(coords, torch.float32, "coords")
     B, two, H1, W1 = coords.shape
     assert two == 2
@@ -210,9 +211,32 @@ def corr_lookup(cost_maps: torch.Tensor, coords: torch.Tensor, radius: int = 4, 
     K = 2 * radius + 1
     if out is None:
         out = torch.empty((B, K * K, H1, W1), dtype=torch.float32, device=coords.device)
-    fn = lib.mv_corr_lookup_tiled if tiled else lib.mv_corr_lookup
+    if vol16 and tiled:
+        raise L.MacvoHipError("corr_lookup: the tiled form reads fp32 volumes")
+    fn = lib.mv_corr_lookup_vol16 if vol16 else (lib.mv_corr_lookup_tiled if tiled else lib.mv_corr_lookup)
     L.check(fn(cost_maps.data_ptr(), coords.data_ptr(), out.data_ptr(), B, H1, W1, H2, W2, radius, _stream()),
-            "mv_corr_lookup_tiled" if tiled else "mv_corr_lookup")
+            "mv_corr_lookup_vol16" if vol16 else ("mv_corr_lookup_tiled" if tiled else "mv_corr_lookup"))
+    return out
+
+
+def corr_volume_out16(f1: torch.Tensor, f2: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor | None:
+    """Fast mode (enc_dtype fp16 / bf16, MACVO_Fast.yaml:73-74): the volume in the encoder's 16-bit type — what ``einsum`` returns there and
+    flownet.py:27 widens — rounded ONCE in the GEMM's epilogue.  ``f1, f2 [B, H, W, C]`` (HWC) fp16 / bf16 -> ``[B*H1*W1, 1, H2, W2]`` of that
+    dtype; ``None`` for shapes outside the streaming kernel's domain (callers then cast ``corr_volume``'s fp32 result)."""
+    lib = L.load()
+    if f1.dtype not in (torch.float16, torch.bfloat16) or f1.dtype != f2.dtype or f1.dim() != 4:
+        raise L.MacvoHipError("corr_volume_out16: [B, H, W, C] float16 / bfloat16 feature maps")
+    f1, f2 = _req(f1, f1.dtype, "f1"), _req(f2, f2.dtype, "f2")
+    B, H1, W1, Cc = f1.shape
+    _, H2, W2, _ = f2.shape
+    N1, N2 = H1 * W1, H2 * W2
+    dt = _DT[f1.dtype]
+    if not lib.mv_corr_volume_out16_supported(B, Cc, N1, N2, dt, L.MV_LAYOUT_HWC):
+        return None
+    if out is None:
+        out = torch.empty((B * N1, 1, H2, W2), dtype=f1.dtype, device=f1.device)
+    L.check(lib.mv_corr_volume_out16(f1.data_ptr(), f2.data_ptr(), out.data_ptr(), B, Cc, N1, N2, dt, L.MV_LAYOUT_HWC, _stream()),
+            "mv_corr_volume_out16")
     return out
 
 
@@ -265,6 +289,57 @@ def convex_upsample(flow8: torch.Tensor, mask: torch.Tensor, mask_scale: float =
     out = torch.empty((B, 2, 8 * h, 8 * w), dtype=torch.float32, device=flow8.device)
     L.check(lib.mv_convex_upsample(flow8.data_ptr(), mask.data_ptr(), out.data_ptr(), B, h, w, float(mask_scale),
                                    int(exp2_out), _stream()), "mv_convex_upsample")
+    return out
+
+
+# ------------------------------------------------------------------------------------------- (f)2 cost patch-embed
+class PatchEmbedWeights:
+    """The three ``Conv2d`` layers of FlowFormer's cost ``PatchEmbed.proj`` (patch_size 8: 1 -> 16 -> 32 -> 64 channels, 6x6, stride 2,
+    padding 2) packed once into the fragment order of ``mv_cost_patch_embed`` (bf16 weights, fp32 biases)."""
+
+    def __init__(self, w1, b1, w2, b2, w3, b3):
+        lib = L.load()
+        shapes = [(16, 1, 6, 6), (16,), (32, 16, 6, 6), (32,), (64, 32, 6, 6), (64,)]
+        ts = []
+        for t, shp in zip((w1, b1, w2, b2, w3, b3), shapes):
+            if tuple(t.shape) != shp:
+                raise L.MacvoHipError(f"PatchEmbedWeights: expected a tensor of shape {shp}, got {tuple(t.shape)}")
+            ts.append(_req(t.detach().float(), torch.float32, "patch-embed weight"))
+        self.packed = torch.empty(int(lib.mv_patch_embed_packed_bytes()), dtype=torch.uint8, device=ts[0].device)
+        L.check(lib.mv_patch_embed_pack(*[t.data_ptr() for t in ts], self.packed.data_ptr(), _stream()), "mv_patch_embed_pack")
+        self._keep = ts
+
+    @classmethod
+    def from_proj(cls, proj) -> "PatchEmbedWeights":
+        """``proj`` = the ``nn.Sequential(Conv2d, ReLU, Conv2d, ReLU, Conv2d)`` of a FlowFormer ``PatchEmbed`` (patch_size 8)."""
+        convs = [m for m in proj if isinstance(m, torch.nn.Conv2d)]
+        if len(convs) != 3 or any(c.kernel_size != (6, 6) or c.stride != (2, 2) or c.padding != (2, 2) or c.bias is None for c in convs):
+            raise L.MacvoHipError("PatchEmbedWeights.from_proj: expected three Conv2d(k = 6, stride 2, padding 2, bias) layers (patch_size 8)")
+        return cls(convs[0].weight, convs[0].bias, convs[1].weight, convs[1].bias, convs[2].weight, convs[2].bias)
+
+
+def cost_patch_embed_supported(H2: int, W2: int) -> bool:
+    return bool(L.load().mv_cost_patch_embed_supported(int(H2), int(W2)))
+
+
+def cost_patch_embed(cost_maps: torch.Tensor, weights: PatchEmbedWeights, tokens: bool = False, out: torch.Tensor | None = None) -> torch.Tensor:
+    """``PatchEmbed.proj(F.pad(cost_maps))`` for every slice in one launch: ``cost_maps [S, 1, H2, W2]`` fp32 (what ``corr_volume`` returns)
+    -> ``[S, 64, H2/8, W2/8]`` fp32, or with ``tokens`` the flattened-transposed form ``[S, H2/8 * W2/8, 64]``.  bf16 matrix pipe with fp32
+    accumulation; the two intermediate maps never leave LDS.  Raises for slice sizes the kernel does not cover
+    (``cost_patch_embed_supported``): callers keep their PyTorch layers for those."""
+    lib = L.load()
+    cost_maps = _req(cost_maps, torch.float32, "cost_maps")
+    S, H2, W2 = cost_maps.shape[0], cost_maps.shape[-2], cost_maps.shape[-1]
+    if cost_maps.numel() != S * H2 * W2:
+        raise L.MacvoHipError("cost_patch_embed: cost_maps must be [S, 1, H2, W2] (one head)")
+    h, w = (H2 + 7) // 8, (W2 + 7) // 8
+    shape = (S, h * w, 64) if tokens else (S, 64, h, w)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=cost_maps.device)
+    elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous():
+        raise L.MacvoHipError(f"cost_patch_embed: out must be a contiguous float32 tensor of shape {shape}")
+    L.check(lib.mv_cost_patch_embed(cost_maps.data_ptr(), weights.packed.data_ptr(), out.data_ptr(), S, H2, W2, int(tokens), _stream()),
+            "mv_cost_patch_embed")
     return out
 
 

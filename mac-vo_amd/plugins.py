@@ -530,7 +530,8 @@ def install_flowformer_hooks(model, volume_precision: str | None = None) -> list
         volume_precision = ops.default_volume_precision()
     dec = getattr(model, "memory_decoder", None)
     if dec is not None and hasattr(dec, "encode_flow_token"):
-        dec.encode_flow_token = lambda cost_maps, coords: ops.corr_lookup(cost_maps.float(), coords.float(), 4)
+        dec.encode_flow_token = lambda cost_maps, coords: ops.corr_lookup(
+            cost_maps if cost_maps.dtype == torch.float16 else cost_maps.float(), coords.float(), 4)   # an fp16 volume is read as it is
         done.append("memory_decoder.encode_flow_token")
     if dec is not None and hasattr(dec, "upsample_flow"):
         dec.upsample_flow = lambda flow, mask: ops.convex_upsample(flow.float(), mask.float(), 1.0, False)
@@ -543,6 +544,12 @@ def install_flowformer_hooks(model, volume_precision: str | None = None) -> list
 
         def corr(fmap1, fmap2):
             B, _, H, W = fmap1.shape
+            if fmap1.dtype in (torch.float16, torch.bfloat16):
+                # Fast mode: the einsum's 16-bit result with its one rounding in the GEMM epilogue (two 10-MB NHWC copies of the feature
+                # maps in front of it; round 3: fp32 kernel output -> cast -> the model's .float(): three passes over 184 MB)
+                vol = ops.corr_volume_out16(fmap1.permute(0, 2, 3, 1).contiguous(), fmap2.permute(0, 2, 3, 1).contiguous())
+                if vol is not None:
+                    return vol.view(B, 1, H, W, fmap2.shape[2], fmap2.shape[3])
             vol = ops.corr_volume(fmap1.contiguous(), fmap2.contiguous(), layout="chw",
                                   precision=volume_precision if fmap1.dtype == torch.float32 else "exact")
             vol = vol if vol.dtype == fmap1.dtype else vol.to(fmap1.dtype)
@@ -550,6 +557,33 @@ def install_flowformer_hooks(model, volume_precision: str | None = None) -> list
 
         enc.corr = corr
         done.append("memory_encoder.corr")
+    # (f)2: the cost patch embedding.  FlowFormer's MemoryEncoder owns `patch_embed = PatchEmbed(patch_size 8, in_chans 1, embed_dim 64)` whose
+    # `proj` (three 6x6 stride-2 convolutions) eats the whole volume slice by slice: rebind `proj` to the fused kernel for the slice sizes it
+    # covers (640x480 frames); any other size falls through to the original layers.
+    pe = getattr(enc, "patch_embed", None) if enc is not None else None
+    if pe is not None and isinstance(getattr(pe, "proj", None), torch.nn.Sequential):
+        try:
+            packed = ops.PatchEmbedWeights.from_proj(pe.proj)
+        except ops.L.MacvoHipError:
+            packed = None
+        if packed is not None:
+            orig = pe.proj
+
+            class _FusedProj(torch.nn.Module):
+                def __init__(self):
+                    super().__init__()
+                    self.layers = orig                                  # keeps the parameters (state_dict keys move under .layers)
+                    self.packed = packed
+
+                def forward(self, x):                                   # x: [S, 1, H2p, W2p] — PatchEmbed.forward has already padded it
+                    H2p, W2p = x.shape[-2], x.shape[-1]
+                    H2 = 60 if H2p == 64 else H2p                       # rows 60..63 are F.pad's zeros; the kernel pads 60 -> 64 itself
+                    if x.is_cuda and x.shape[1] == 1 and ops.cost_patch_embed_supported(H2, W2p):
+                        return ops.cost_patch_embed(x[..., :H2, :].float().contiguous(), self.packed).to(x.dtype)
+                    return self.layers(x)
+
+            pe.proj = _FusedProj()
+            done.append("memory_encoder.patch_embed.proj")
     if not done:
         raise ops.L.MacvoHipError("install_flowformer_hooks: the model has none of memory_decoder.encode_flow_token / "
                                   "upsample_flow / memory_encoder.corr")

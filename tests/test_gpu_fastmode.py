@@ -1,0 +1,90 @@
+"""Fast mode (Config/Experiment/MACVO/MACVO_Fast.yaml:73-74: the encoder in fp16): the volume as the reference computes it — `einsum` on 16-bit feature
+maps returns a 16-bit volume that Module/Network/FlowFormerCov/flownet.py:27 merely widens (VERDICT r3 "What's missing" #5).
+
+  * mv_corr_volume_out16: ONE rounding in the GEMM's epilogue, 2-byte cells.  Bar: bit-equal to the fp32-output kernel's result rounded once
+    (same accumulators), and within one fp16 / bf16 ulp of `einsum(fp64)` rounded (accumulation order);
+  * mv_corr_lookup_vol16: tokens equal to the fp32 lookup on the widened volume BIT FOR BIT (the widening is exact), and to the oracle's
+    grid_sample lookup on it at the lookup's own tolerance."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _feats(B, H, W, C, dt, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(B, H, W, C, generator=g).to(dt), torch.randn(B, H, W, C, generator=g).to(dt)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C", [(2, 60, 80, 256), (1, 59, 64, 256), (3, 48, 64, 128), (2, 90, 160, 256)])
+def test_volume_out16_is_the_fp32_volume_rounded_once(gpu, dt, B, H, W, C):
+    from macvo_amd import ops
+
+    f1, f2 = _feats(B, H, W, C, dt, seed=H)
+    d1, d2 = f1.to(gpu), f2.to(gpu)
+    v16 = ops.corr_volume_out16(d1, d2)
+    assert v16 is not None and ops.last_volume_kernel() == "corr_volume_h_stream<out16>"
+    assert v16.dtype == dt and v16.shape == (B * H * W, 1, H, W)
+    v32 = ops.corr_volume(d1, d2, layout="hwc")
+    assert ops.last_volume_kernel() == "corr_volume_h_stream"
+    assert torch.equal(v16, v32.to(dt))                                  # the same accumulators, rounded to nearest even once
+    # against the definition: einsum in float64 of the 16-bit inputs, rounded — within one ulp of the 16-bit type (accumulation order)
+    N = H * W
+    rows = torch.randint(0, B * N, (64,), generator=torch.Generator().manual_seed(1))
+    b, i = rows // N, rows % N
+    ref = torch.einsum("rc,rnc->rn", f1.reshape(B, N, C).double()[b, i], f2.reshape(B, N, C).double()[b])
+    got = v16.view(B * N, N)[rows.to(gpu)].cpu().double()
+    ulp = 2.0 ** (torch.floor(torch.log2(ref.abs().clamp_min(2.0 ** -14))) - (10 if dt == torch.float16 else 7))
+    assert ((got - ref).abs() <= ulp).all()
+
+
+def test_volume_out16_outside_the_streaming_domain_returns_none(gpu):
+    from macvo_amd import ops
+
+    f1, f2 = _feats(1, 8, 12, 64, torch.float16, 0)                     # C = 64: tile kernels only
+    assert ops.corr_volume_out16(f1.to(gpu), f2.to(gpu)) is None
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 60, 80), (8, 60, 80), (2, 90, 160)])
+def test_lookup_on_the_fp16_volume_equals_the_lookup_on_its_widened_copy(gpu, B, H, W):
+    from macvo_amd import ops
+    from oracle import corr
+
+    f1, f2 = _feats(B, H, W, 256, torch.float16, seed=3)
+    v16 = ops.corr_volume_out16(f1.to(gpu), f2.to(gpu))
+    wide = v16.float()                                                   # flownet.py:27
+    g = torch.Generator().manual_seed(4)
+    for it in range(3):
+        coords = corr.coords_grid(B, H, W) + (torch.rand(B, 2, H, W, generator=g) * 2 - 1) * (8.0 if it else 0.0)
+        coords[0, :, 0, 0] = torch.tensor([-3.5, 2.25])                  # window partly outside: zero padding
+        coords[0, :, 1, 1] = torch.tensor([float(W) + 1.0, float(H) - 1.5])
+        t16 = ops.corr_lookup(v16, coords.to(gpu), 4)
+        t32 = ops.corr_lookup(wide, coords.to(gpu), 4)
+        assert torch.equal(t16, t32), it
+        if B <= 2 and H == 60:
+            torch.testing.assert_close(t16.cpu(), corr.corr_lookup(wide.cpu(), coords, 4), rtol=1e-5, atol=2e-4)
+
+
+def test_flowformer_hook_returns_the_16bit_volume_in_one_pass(gpu):
+    """install_flowformer_hooks on a model whose encoder runs in fp16: `memory_encoder.corr` returns the fp16 volume of the out16 kernel
+    (no fp32 volume + cast in between) — equal to what the fp32 kernel + one cast gave in round 3."""
+    from types import SimpleNamespace as NS
+
+    from macvo_amd import ops, plugins
+
+    class Enc:
+        cfg = NS(cost_heads_num=1)
+
+        def corr(self, a, b):
+            raise AssertionError("not rebound")
+
+    m = NS(memory_encoder=Enc())
+    plugins.install_flowformer_hooks(m)
+    f1, f2 = _feats(2, 60, 80, 256, torch.float16, seed=9)
+    c1, c2 = f1.permute(0, 3, 1, 2).contiguous().to(gpu), f2.permute(0, 3, 1, 2).contiguous().to(gpu)     # the encoder hands over NCHW
+    vol = m.memory_encoder.corr(c1, c2)
+    assert ops.last_volume_kernel() == "corr_volume_h_stream<out16>"
+    assert vol.dtype == torch.float16 and vol.shape == (2, 1, 60, 80, 60, 80)
+    ref = ops.corr_volume(f1.to(gpu), f2.to(gpu), layout="hwc").to(torch.float16)
+    assert torch.equal(vol.reshape(-1), ref.reshape(-1))

@@ -1,0 +1,148 @@
+"""(f)2 — the fused cost patch embedding (csrc/patch_embed.hip) against torch's F.conv2d chain (oracle/patch_embed.py; the FlowFormer submodule is
+absent from the reference checkout: parity unpinned against the MAC-VO fork, pinned to the published layer definition).
+
+Two bars: (1) against the SAME arithmetic — bf16 operands, fp32 accumulation (``patch_embed_proj_bf16``) — the kernel may differ by accumulation
+order and by the rare intermediate value that rounds to the other bf16 neighbour: 2e-3 of the output scale; (2) against the fp32 chain: the bf16
+operand error, 2e-2 of the output scale (what the reference's own Fast mode accepts for this encoder: enc_dtype fp16, MACVO_Fast.yaml:73-74)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _volume_slices(S, seed, scale=16.0):
+    """slices shaped like rows of a cost volume of N(0,1) features with C = 256: ~N(0, 16^2) with a few large responses"""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(S, 1, 60, 80, generator=g) * scale
+    x[:, 0, 7, 9] += 200.0
+    return x
+
+
+@pytest.mark.parametrize("S,tokens", [(1, False), (2, True), (7, False), (600, True)])
+def test_cost_patch_embed_matches_the_conv2d_chain(gpu, S, tokens):
+    from macvo_amd import ops
+    from oracle import patch_embed as ope
+
+    W = ope.make_weights(seed=S)
+    x = _volume_slices(S, seed=S + 1)
+    packed = ops.PatchEmbedWeights(*[w.to(gpu) for w in W])
+    got = ops.cost_patch_embed(x.to(gpu), packed, tokens=tokens).cpu()
+    ref_bf = ope.patch_embed_proj_bf16(x, *W)
+    ref_32 = ope.patch_embed_proj(x, *W)
+    if tokens:
+        ref_bf, ref_32 = ope.to_tokens(ref_bf), ope.to_tokens(ref_32)
+    assert got.shape == ref_32.shape == ((S, 80, 64) if tokens else (S, 64, 8, 10))
+    scale = ref_32.abs().max().item()
+    assert (got - ref_bf).abs().max().item() <= 2e-3 * scale, ((got - ref_bf).abs().max().item(), scale)
+    assert (got - ref_32).abs().max().item() <= 2e-2 * scale, ((got - ref_32).abs().max().item(), scale)
+
+
+def test_cost_patch_embed_layers_one_by_one(gpu):
+    """Weights that isolate each layer: identity-like taps make the stack's output a known function of the input, so an indexing error in any
+    of the three implicit GEMMs (tap order, stride, halo, channel order) cannot hide behind the others."""
+    from macvo_amd import ops
+    from oracle import patch_embed as ope
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(3, 1, 60, 80, generator=g) * 4            # positive: the ReLUs are transparent
+    for probe in range(4):
+        w1, b1, w2, b2, w3, b3 = [torch.zeros_like(t) for t in ope.make_weights(0)]
+        if probe == 0:     # a single tap per layer at distinct (ky, kx), distinct channels
+            w1[3, 0, 1, 4] = 1.0
+            w2[7, 3, 5, 0] = 1.0
+            w3[41, 7, 2, 3] = 1.0
+        elif probe == 1:   # every tap of conv1, one channel chain (box filters): halo / padding handling at all four borders
+            w1[0, 0] = 1.0 / 36
+            w2[0, 0] = 1.0 / 36
+            w3[0, 0] = 1.0 / 36
+        elif probe == 2:   # channel mixing with random sparse weights + biases
+            gg = torch.Generator().manual_seed(9)
+            w1 = (torch.rand(16, 1, 6, 6, generator=gg) > 0.7).float() * 0.25
+            w2 = (torch.rand(32, 16, 6, 6, generator=gg) > 0.9).float() * 0.125
+            w3 = (torch.rand(64, 32, 6, 6, generator=gg) > 0.9).float() * 0.125
+            b1, b2, b3 = torch.rand(16, generator=gg), torch.rand(32, generator=gg), torch.rand(64, generator=gg) - 0.5
+        else:              # negative pre-activations: the two ReLUs clip, the last layer does not
+            w1[2, 0, 0, 0] = -1.0
+            b1[2] = 2.0
+            w2[5, 2, 3, 3] = 1.0
+            b2[5] = -1.0
+            w3[9, 5, 1, 1] = -1.0
+        W = (w1, b1, w2, b2, w3, b3)
+        got = ops.cost_patch_embed(x.to(gpu), ops.PatchEmbedWeights(*[w.to(gpu) for w in W])).cpu()
+        ref = ope.patch_embed_proj_bf16(x, *W)
+        tol = 2e-3 * max(ref.abs().max().item(), 1e-3)
+        assert (got - ref).abs().max().item() <= tol, (probe, (got - ref).abs().max().item(), tol)
+
+
+def test_cost_patch_embed_is_deterministic_and_slice_independent(gpu):
+    from macvo_amd import ops
+    from oracle import patch_embed as ope
+
+    W = [w.to(gpu) for w in ope.make_weights(3)]
+    packed = ops.PatchEmbedWeights(*W)
+    x = _volume_slices(515, seed=2).to(gpu)                   # odd count: the last pass carries one live slice
+    a = ops.cost_patch_embed(x, packed)
+    b = ops.cost_patch_embed(x, packed)
+    assert torch.equal(a, b)
+    solo = ops.cost_patch_embed(x[301:302].contiguous(), packed)
+    assert torch.equal(solo[0], a[301])                        # a slice's tokens do not depend on its neighbour in the pass or on the workgroup
+    last = ops.cost_patch_embed(x[514:515].contiguous(), packed)
+    assert torch.equal(last[0], a[514])
+
+
+def test_cost_patch_embed_on_a_real_volume_and_unsupported_sizes(gpu):
+    from macvo_amd import ops
+    from oracle import corr
+    from oracle import patch_embed as ope
+
+    g = torch.Generator().manual_seed(0)
+    f1, f2 = torch.randn(1, 256, 60, 80, generator=g), torch.randn(1, 256, 60, 80, generator=g)
+    vol = ops.corr_volume(f1.to(gpu), f2.to(gpu))             # [4800, 1, 60, 80]: the kernel's real producer
+    W = ope.make_weights(11)
+    got = ops.cost_patch_embed(vol, ops.PatchEmbedWeights(*[w.to(gpu) for w in W]), tokens=True)
+    idx = torch.tensor([0, 1, 2399, 4798, 4799])
+    ref = ope.to_tokens(ope.patch_embed_proj_bf16(vol[idx.to(gpu)].cpu(), *W))
+    assert (got[idx.to(gpu)].cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    assert not ops.cost_patch_embed_supported(90, 160)
+    with pytest.raises(ops.L.MacvoHipError):
+        ops.cost_patch_embed(torch.zeros(2, 1, 90, 160, device=gpu), ops.PatchEmbedWeights(*[w.to(gpu) for w in W]))
+
+
+def test_flowformer_hook_rebinds_the_patch_embed_proj(gpu):
+    """install_flowformer_hooks on a model shaped like FlowFormer's MemoryEncoder (patch_embed.proj = the three Conv2d layers): the rebound proj
+    returns what the original layers return (bf16 bar), also for the 64-row padded input PatchEmbed.forward hands it."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    from macvo_amd import plugins
+
+    class PatchEmbed(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.proj = nn.Sequential(nn.Conv2d(1, 16, 6, 2, 2), nn.ReLU(), nn.Conv2d(16, 32, 6, 2, 2), nn.ReLU(), nn.Conv2d(32, 64, 6, 2, 2))
+
+        def forward(self, x):
+            x = F.pad(x, (0, (8 - x.shape[-1] % 8) % 8, 0, (8 - x.shape[-2] % 8) % 8))
+            return self.proj(x)
+
+    class Enc(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.patch_embed = PatchEmbed()
+
+    class Model(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.memory_encoder = Enc()
+
+    torch.manual_seed(0)
+    m = Model().to(gpu).eval()
+    x = _volume_slices(9, seed=4).to(gpu)
+    with torch.no_grad():
+        want = m.memory_encoder.patch_embed(x)
+        done = plugins.install_flowformer_hooks(m)
+        assert "memory_encoder.patch_embed.proj" in done
+        got = m.memory_encoder.patch_embed(x)
+        small = m.memory_encoder.patch_embed(torch.randn(2, 1, 24, 32, device=gpu))    # a size the kernel does not cover: original layers
+    assert got.shape == want.shape == (9, 64, 8, 10) and small.shape == (2, 64, 3, 4)
+    assert (got - want).abs().max().item() <= 2e-2 * want.abs().max().item()

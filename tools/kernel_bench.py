@@ -71,6 +71,49 @@ def main():
                 med, mn = timeit(lambda: ops.corr_volume_packed(pk[0], pk[1], B, C, n, n, out=vol, mode=mode), a.iters, warm=20)
                 print(f"volume_split {mode} B={B} {med:8.1f} us (min {mn:.1f})  {flops / med / 1e6:7.1f} TFLOP/s algorithmic = {nprod * flops / med / 1e6 / 2500 * 100:.1f}% of the "
                       f"16-bit MFMA peak executed ({'zero' if a.zeros else 'random'} operands)")
+        elif w == "patch_embed":
+            # (f)2: both volumes of a frame (S = B n slices) through the fused conv stack; 2 x (36 + 16*36*... ) MAC per output, see DESIGN
+            from oracle import patch_embed as ope
+            if (h8, w8) != (60, 80):
+                print("patch_embed: 640x480 only")
+                continue
+            Wt = [t.to(dev) for t in ope.make_weights(0)]
+            pk = ops.PatchEmbedWeights(*Wt)
+            volr = torch.randn(B * n, 1, h8, w8, device=dev) * 16
+            outp = torch.empty((B * n, 80, 64), dtype=torch.float32, device=dev)
+            fl = B * n * 2.0 * (1280 * 16 * 36 + 320 * 32 * 576 + 80 * 64 * 1152)
+            byts = B * n * (h8 * w8 * 4 + 80 * 64 * 4.0)
+            for _ in range(5):
+                ops.cost_patch_embed(volr, pk, tokens=True, out=outp)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = max(3, a.iters // 5)
+            e0.record()
+            for _ in range(reps):
+                ops.cost_patch_embed(volr, pk, tokens=True, out=outp)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            print(f"cost_patch_embed S={B * n} {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s algorithmic = {fl / us / 1e6 / 2500 * 100:.1f}% of the bf16 MFMA peak; "
+                  f"HBM {byts / us / 1e3:.0f} GB/s ({byts / 1e6:.0f} MB)")
+            # the unfused form: the same three layers as PyTorch / MIOpen convolutions (bf16, channels_last), intermediates through HBM
+            import torch.nn.functional as F
+            xb = F.pad(volr, (0, 0, 0, 4)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            wb = [t.to(torch.bfloat16) for t in Wt]
+            def unfused():
+                y = F.relu(F.conv2d(xb, wb[0], wb[1], stride=2, padding=2))
+                y = F.relu(F.conv2d(y, wb[2], wb[3], stride=2, padding=2))
+                return F.conv2d(y, wb[4], wb[5], stride=2, padding=2)
+            try:
+                for _ in range(2):
+                    unfused()
+                e0.record()
+                for _ in range(3):
+                    unfused()
+                e1.record()
+                torch.cuda.synchronize()
+                print(f"  unfused torch conv2d chain (bf16, channels_last, MIOpen): {e0.elapsed_time(e1) * 1e3 / 3:8.1f} us")
+            except Exception as e:  # noqa: BLE001
+                print("  unfused torch conv2d chain failed:", repr(e)[:200])
         elif w == "volume_f16":
             for dt in (torch.float16, torch.bfloat16):
                 a1, a2 = f1.permute(0, 2, 3, 1).contiguous().to(dt), f2.permute(0, 2, 3, 1).contiguous().to(dt)
