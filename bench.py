@@ -62,6 +62,9 @@ def parse_args():
                          "products — both meet the parity bar of 'exact', not bitwise (the reference runs this GEMM in TF32, "
                          "Frontend.py:275-277); 'exact' = fp32 MFMA (bitwise fmaf chain).  The other two are reported as `other_precisions` "
                          "beside the default line; split3 / split2 = round-1 tile kernels (need --layout hwc)")
+    ap.add_argument("--volume-store", choices=["fp32", "encoder"], default="fp32",
+                    help="16-bit features (--feat-dtype f16 --layout hwc): 'encoder' stores the volume in fp16 with one rounding in the GEMM epilogue, as the "
+                         "reference's Fast mode computes it (einsum of fp16 maps; flownet.py:26-27), and the lookups read the 2-byte cells")
     ap.add_argument("--exact-steps", type=int, default=60, help="steps of the extra legs with the other volume precisions beside the default line; 0 = skip")
     ap.add_argument("--graph", choices=["disp", "reproj", "icp"], default="disp")
     ap.add_argument("--pool", type=int, default=24, help="distinct synthetic frames (closed trajectory) kept in HBM")
@@ -136,14 +139,16 @@ def dry_collectives(args, rank, world) -> None:
     dist.destroy_process_group()
 
 
-def volume_work(lanes, n_q, C, esz):
-    """Algorithmic work of one cost-volume launch: 2*N^2*C FLOP and 2*N*C*s + 4*N^2 bytes per pair."""
+def volume_work(lanes, n_q, C, esz, osz=4):
+    """Algorithmic work of one cost-volume launch: 2*N^2*C FLOP and 2*N*C*s + 4*N^2 bytes per pair (osz = 2: the Fast-mode
+    volume stored in the encoder's 16-bit type, what the reference's fp16 einsum writes)."""
     pairs = 2 * lanes
-    return pairs * 2.0 * n_q * n_q * C, pairs * (2.0 * n_q * C * esz + 4.0 * n_q * n_q)
+    return pairs * 2.0 * n_q * n_q * C, pairs * (2.0 * n_q * C * esz + float(osz) * n_q * n_q)
 
 
 def roofline_of(ms, args, lanes, n_q, C, timed_region_launches, traffic=None):
-    flops, nbytes = volume_work(lanes, n_q, C, 4 if args.feat_dtype == "f32" else 2)
+    enc16 = args.feat_dtype == "f16" and getattr(args, "volume_store", "fp32") == "encoder" and args.layout == "hwc" and C in (128, 256)
+    flops, nbytes = volume_work(lanes, n_q, C, 4 if args.feat_dtype == "f32" else 2, 2 if enc16 else 4)
     avg_s = sum(ms) / len(ms) / 1e3
     common = {"avg_launch_us": round(avg_s * 1e6, 2), "launches": len(ms), "launches_in_timed_region": timed_region_launches,
               "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes}
@@ -171,7 +176,7 @@ def roofline_of(ms, args, lanes, n_q, C, timed_region_launches, traffic=None):
                 "kernel": "corr_volume_f32_mixed_dma" if args.layout == "chw" else "corr_volume_f32_hwc", **common}
     ach = nbytes / avg_s / 1e9
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
-            "traffic": traffic, "kernel": "corr_volume_h_stream" if (args.layout == "hwc" and C in (128, 256)) else "corr_volume_h_" + args.layout,
+            "traffic": traffic, "kernel": ("corr_volume_h_stream<out16>" if enc16 else "corr_volume_h_stream") if (args.layout == "hwc" and C in (128, 256)) else "corr_volume_h_" + args.layout,
             **common}
 
 
@@ -337,7 +342,7 @@ def main():
     def make_pipe(lanes, seed, precision=None, keep_extras=False):
         cfg = HotPathConfig(graph_type=args.graph, feature_layout=args.layout,
                             volume_precision=(precision or args.volume_precision) if args.feat_dtype == "f32" else "exact",
-                            use_graphs=use_graphs)
+                            volume_store=args.volume_store, use_graphs=use_graphs)
         if native:
             # lanes > 1: integer seeds = the driver's native per-lane MT19937 generators (bit-identical to torch.Generator(seed) +
             # torch.randperm; 32 host-side torch.randperm calls per step were the bound of the 32-lane configuration)
@@ -489,7 +494,7 @@ def main():
                     if key is not None:
                         traffic = pm[key]["_derived"]["traffic_bytes_per_launch"]
                         break
-        if (H, W, C, args.lanes) == (480, 640, 256, 1) and args.feat_dtype in ("f16", "bf16") and args.layout == "hwc":
+        if (H, W, C, args.lanes) == (480, 640, 256, 1) and args.feat_dtype in ("f16", "bf16") and args.layout == "hwc" and args.volume_store == "fp32":
             path = os.path.join(ROOT, "profiles", "r02_pmc_corr_volume_16bit_stream.json")
             if os.path.exists(path):
                 pm = json.load(open(path))

@@ -45,10 +45,11 @@ enum {
                           frontend runs this GEMM in (allow_tf32, Module/Frontend/Frontend.py:275-277); layout HWC only */
     MV_PACK_BF16X3 = 5,/* `mode` of mv_volume_pack / mv_corr_volume_packed: fp32 operands split into three bf16 pieces and
                           written in MFMA-fragment order; six piece products, fp32 accumulate (fp32-class, as MV_BF16X3) */
-    MV_PACK_F16X2 = 6  /* the same with two fp16 pieces (11 + 11 bits) of every value after an exact power-of-two scaling of its
+    MV_PACK_F16X2 = 6, /* the same with two fp16 pieces (11 + 11 bits) of every value after an exact power-of-two scaling of its
                           ROW (one pixel's feature vector) into fp16's range, three piece products, the scales undone exactly in
                           the epilogue: |error| <= ~2^-21 sum_k |a_k||b_k| — inside the exact path's parity bar, half the matrix
-                          work of MV_PACK_BF16X3; rows whose largest magnitude is outside [2^-46, 2^74] are not rescued */
+                          work of MV_PACK_BF16X3; the row scale is not clamped: any finite row of the fp32 range is carried */
+    MV_VOL_ENC16 = 16  /* mvFramePipeConfig.volume_split only: 16-bit features, volume stored in the features' fp16 type */
 };
 
 /* feature-map memory layouts accepted by mv_corr_volume */
@@ -561,7 +562,9 @@ typedef struct {
     int32_t radius;            /* lookup radius (4) */
     int32_t feat_dtype;        /* MV_F32 | MV_F16 | MV_BF16 */
     int32_t layout;            /* MV_LAYOUT_* of the feature maps */
-    int32_t volume_split;      /* 0 exact fp32 | MV_PACK_F16X2 (6, the host side's default) | MV_PACK_BF16X3 (5): fp32 features of either
+    int32_t volume_split;      /* MV_VOL_ENC16 (16): fp16 features, volume STORED in fp16 as the reference's Fast mode computes it
+                                  (mv_corr_volume_out16 + mv_corr_lookup_vol16; shapes outside that kernel's domain keep fp32 cells) |
+                                  0 exact fp32 | MV_PACK_F16X2 (6, the host side's default) | MV_PACK_BF16X3 (5): fp32 features of either
                                   layout packed on the device (mv_volume_pack, beside the previous frame's GEMM) +
                                   mv_corr_volume_packed, shapes it does not cover run the exact kernel | 3 | 2: fp32 HWC features through the round-1 plane split, multiplied
                                   as MV_BF16X3 / MV_BF16X2 */

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libmacvo_hip.so")
 
 MV_OK = 0
 MV_F32, MV_F16, MV_BF16, MV_BF16X3, MV_BF16X2, MV_PACK_BF16X3, MV_PACK_F16X2 = 0, 1, 2, 3, 4, 5, 6
+MV_VOL_ENC16 = 16
 MV_LAYOUT_CHW, MV_LAYOUT_HWC = 0, 1
 MV_KP_NODEPTH, MV_KP_FULL, MV_KP_MAPPING = 0, 1, 2
 MV_GRAPH_ICP, MV_GRAPH_REPROJ, MV_GRAPH_DISP = 0, 1, 2

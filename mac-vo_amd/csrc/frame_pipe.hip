@@ -134,6 +134,7 @@ struct mvFramePipe {
     void* pk[2][2];
     size_t pk_bytes;
     bool packed;
+    bool vol16;        // volume_split = MV_VOL_ENC16 on a shape the out16 kernel covers: 2-byte cells (Fast mode as the reference computes it)
     bool tiled;        // MV_PIPE_TILED=1 && packed: operand 2 packed in 4 x 4-tile order -> the volume is tiled for mv_corr_lookup_tiled
                        // (the driver owns both the producer and the consumer of the volume; MV_FB_VOLUME then shows that layout)
     int pack_on;       // 0 = on the GEMM's stream (in front of it), 1 = backend stream, 2 = decoder-side stream
@@ -335,8 +336,9 @@ static int check_config(const mvFramePipeConfig* c) {
     MV_CHECK_ARG(c->graph_type >= MV_GRAPH_ICP && c->graph_type <= MV_GRAPH_DISP);
     MV_CHECK_ARG(c->mapping == 0 || (c->mapping == 1 && c->pairs == 2 && c->map_num_point > 0 && c->map_mask_width >= 0));
     MV_CHECK_ARG(c->volume_split == 0 || c->volume_split == 2 || c->volume_split == 3 || c->volume_split == MV_PACK_BF16X3 ||
-                 c->volume_split == MV_PACK_F16X2);
-    MV_CHECK_ARG(!c->volume_split || c->feat_dtype == MV_F32);
+                 c->volume_split == MV_PACK_F16X2 || c->volume_split == MV_VOL_ENC16);
+    MV_CHECK_ARG(!c->volume_split || c->volume_split == MV_VOL_ENC16 || c->feat_dtype == MV_F32);
+    MV_CHECK_ARG(c->volume_split != MV_VOL_ENC16 || (c->feat_dtype == MV_F16 && c->radius == 4));   // (the lookup reads fp16 cells)
     MV_CHECK_ARG(!(c->volume_split == 2 || c->volume_split == 3) || c->layout == MV_LAYOUT_HWC);   // (the packed form takes either layout)
     return MV_OK;
 }
@@ -538,6 +540,8 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
     p->n_volbuf = volbufs_from_env();
     p->packed = (cfg->volume_split == MV_PACK_BF16X3 || cfg->volume_split == MV_PACK_F16X2) &&
                 mv_corr_volume_packed_supported(cfg->pairs, cfg->C, p->n8, p->n8, cfg->volume_split);
+    // shapes outside the out16 kernel's domain keep the fp32-stored volume of the same 16-bit GEMM
+    p->vol16 = cfg->volume_split == MV_VOL_ENC16 && mv_corr_volume_out16_supported(cfg->pairs, cfg->C, p->n8, p->n8, cfg->feat_dtype, cfg->layout);
     {
         // Tiled volume for the batched lookups, MV_PIPE_TILED=1.  Measured (640x480, 32 lanes, f16x2): the tiled lookup
         // alone is 15 % faster (B = 64: 114 -> 97 us: the same bytes in half as many, aligned 64-byte requests), the 32-lane step
@@ -602,6 +606,12 @@ extern "C" int mv_frame_pipe_set_pose(mvFramePipe* p, const float* pose7_host) {
 }
 
 // ------------------------------------------------------------------------------------------------ frontend half
+typedef int (*mvLookupFn)(const float*, const float*, float*, int, int, int, int, int, int, mvStream_t);
+static int lookup_vol16_as_float_ptr(const float* vol, const float* coords, float* out, int B, int H1, int W1, int H2, int W2, int radius, mvStream_t s) {
+    return mv_corr_lookup_vol16(vol, coords, out, B, H1, W1, H2, W2, radius, s);      // (the arena pointer is typed float*; the cells are fp16)
+}
+static mvLookupFn lookup_of(const mvFramePipe* p) { return p->vol16 ? lookup_vol16_as_float_ptr : (p->tiled ? mv_corr_lookup_tiled : mv_corr_lookup); }
+
 // volume GEMM of frame n_vol on its own stream; a buffer is rewritten only after the lookups that read it have finished
 static int issue_volume(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_stream) {
     const mvFramePipeConfig& c = p->c;
@@ -642,6 +652,8 @@ static int issue_volume(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_s
         MV_TRY(mv_split_bf16x3((const float*)in->fmap2, p->planes[1], nel, p->s_vol));
         MV_TRY(mv_corr_volume(p->planes[0], p->planes[1], p->vol[k], B, c.C, p->n8, p->n8,
                               c.volume_split == 2 ? MV_BF16X2 : MV_BF16X3, MV_LAYOUT_HWC, p->s_vol));
+    } else if (p->vol16) {
+        MV_TRY(mv_corr_volume_out16(in->fmap1, in->fmap2, p->vol[k], B, c.C, p->n8, p->n8, c.feat_dtype, c.layout, p->s_vol));
     } else {
         MV_TRY(mv_corr_volume(in->fmap1, in->fmap2, p->vol[k], B, c.C, p->n8, p->n8, c.feat_dtype, c.layout, p->s_vol));
     }
@@ -793,15 +805,13 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
     if (p->lookups_on_main) {
         MV_HIP(hipStreamWaitEvent(s, p->e_vol_done[kv], 0));   // also orders `s` after e_in (the GEMM stream waited for it)
         for (int it = 0; it < c.iters; ++it)
-            MV_TRY((p->tiled ? mv_corr_lookup_tiled : mv_corr_lookup)(p->vol[kv], in->coords + it * coord_stride, p->tok[it & 1], B, p->h8,
-                                                                      p->w8, p->h8, p->w8, c.radius, s));
+            MV_TRY(lookup_of(p)(p->vol[kv], in->coords + it * coord_stride, p->tok[it & 1], B, p->h8, p->w8, p->h8, p->w8, c.radius, s));
         MV_HIP(hipEventRecord(p->e_vol_free[kv], s));
         p->vol_free_valid[kv] = true;
         if (timed) MV_HIP(hipEventRecord(p->tv2[ti], s));
     } else {
         for (int it = 0; it < c.iters; ++it)
-            MV_TRY((p->tiled ? mv_corr_lookup_tiled : mv_corr_lookup)(p->vol[kv], in->coords + it * coord_stride, p->tok[it & 1], B, p->h8,
-                                                                      p->w8, p->h8, p->w8, c.radius, p->s_vol));
+            MV_TRY(lookup_of(p)(p->vol[kv], in->coords + it * coord_stride, p->tok[it & 1], B, p->h8, p->w8, p->h8, p->w8, c.radius, p->s_vol));
         MV_HIP(hipEventRecord(p->e_vol_done[kv], p->s_vol));   // volume AND its lookups done
         MV_HIP(hipStreamWaitEvent(s, p->e_vol_done[kv], 0));   // also orders `s` after e_in
         p->vol_free_valid[kv] = false;                         // vol[k] / tok are only touched on s_vol: stream order suffices

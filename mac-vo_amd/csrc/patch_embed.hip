@@ -151,6 +151,8 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
     for (; pass < npass; pass += gridDim.x) {
 #pragma unroll 1
         for (int gs = 0; gs < 2; ++gs) {
+            int gv = g;                                 // the epilogues' address arithmetic starts from this copy: opaque per iteration, so that hipcc
+            asm volatile("" : "+v"(gv));                // does not hoist ~100 loop-invariant addresses out of the slice loop (it spilled 131 registers)
             // ---- (A) slice -> in0 (bf16), next slice -> registers
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
@@ -165,25 +167,40 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
             fetch(gs == 0 ? 2 * pass + 1 : 2 * (pass + (int)gridDim.x));
             __syncthreads();
             // ---- (C) conv1: 10 tiles per wave, 3 k-steps; k-step s of lane group g = input row 2 oy + 2 s + g, columns 2 ox .. 2 ox + 7
-#pragma unroll 2
-            for (int j = 0; j < P::T1 / 4; ++j) {
-                const int tile = wave + 4 * j;
-                const int p = tile * 32 + n32, oy = p / P::W1, ox = p - oy * P::W1;
-                const char* a0 = in0 + ((2 * oy + g) * P::IN_PITCH + 2 * ox) * 2;
-                f32x16 acc;
+            {
+                // the A fragments of tile j + 1 are fetched while tile j is multiplied and stored (hipcc otherwise reuses ONE register quad for
+                // every fragment: ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, i.e. a full LDS latency in front of each MFMA)
+                auto a_of = [&](int j, i32x4 (&a)[3]) __attribute__((always_inline)) {
+                    const int p = (wave + 4 * j) * 32 + n32, oy = p / P::W1, ox = p - oy * P::W1;
+                    const char* a0 = in0 + ((2 * oy + g) * P::IN_PITCH + 2 * ox) * 2;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                    for (int s = 0; s < 3; ++s) {
+                        const unsigned* ap = reinterpret_cast<const unsigned*>(a0 + 2 * s * P::IN_PITCH * 2);
+                        a[s] = i32x4{(int)ap[0], (int)ap[1], (int)ap[2], (int)ap[3]};
+                    }
+                };
+                i32x4 afr[2][3];
+                a_of(0, afr[0]);
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    const unsigned* ap = reinterpret_cast<const unsigned*>(a0 + 2 * s * P::IN_PITCH * 2);
-                    const i32x4 a = {(int)ap[0], (int)ap[1], (int)ap[2], (int)ap[3]};
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, w1f[s]), acc, 0, 0, 0);
-                }
-                if (n32 < 16) {
+                for (int j = 0; j < P::T1 / 4; ++j) {
+                    if (j + 1 < P::T1 / 4) a_of(j + 1, afr[(j + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int tile = wave + 4 * j;
+                    f32x16 acc;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int pp = tile * 32 + 8 * (r >> 2) + 4 * g + (r & 3), y = pp / P::W1, x = pp - y * P::W1;
-                        *reinterpret_cast<uint16_t*>(o1 + (((y + 2) * P::O1_COLS + x + 2) * 16 + n32) * 2) = bf16_bits(fmaxf(acc[r] + b1v, 0.f));
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 3; ++s)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[j & 1][s]), __builtin_bit_cast(bf16x8, w1f[s]), acc, 0, 0, 0);
+                    if (n32 < 16) {
+                        // accumulator registers 4 q .. 4 q + 3 of a lane are four CONSECUTIVE pixels of one output row (W1 % 4 == 0): one address per quad
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int pp = tile * 32 + 8 * q + 4 * gv, y = pp / P::W1, x = pp - y * P::W1;
+                            uint16_t* d = reinterpret_cast<uint16_t*>(o1 + (((y + 2) * P::O1_COLS + x + 2) * 16 + n32) * 2);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) d[e * 16] = bf16_bits(fmaxf(acc[4 * q + e] + b1v, 0.f));
+                        }
                     }
                 }
             }
@@ -201,16 +218,23 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
                 }
                 const char* wb = smem_pe + P::OFF_W2 + lane * 16;
                 auto taps = [&](auto KH) __attribute__((always_inline)) {   // (kh is wave-uniform: one instantiation per K half keeps every offset an immediate)
+                    constexpr int K0 = decltype(KH)::value * 18, PFA = 2;        // fragments are fetched PFA k-steps ahead of their MFMAs
+                    bf16x8 af[PFA + 1][5], bf[PFA + 1];
+                    auto fetch_k = [&](int kk) __attribute__((always_inline)) {
+                        const int tap = K0 + kk, ky = tap / 6, kx = tap - 6 * ky, q = kk % (PFA + 1);
+                        bf[q] = *reinterpret_cast<const bf16x8*>(wb + tap * 1024);
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) af[q][i] = *reinterpret_cast<const bf16x8*>(abase[i] + (ky * P::O1_COLS + kx) * 32);
+                    };
+#pragma unroll
+                    for (int kk = 0; kk < PFA; ++kk) fetch_k(kk);
 #pragma unroll
                     for (int kk = 0; kk < 18; ++kk) {
-                        constexpr int K0 = decltype(KH)::value * 18;
-                        const int tap = K0 + kk, ky = tap / 6, kx = tap - 6 * ky;
-                        const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + tap * 1024);
+                        if (kk + PFA < 18) fetch_k(kk + PFA);
+                        __builtin_amdgcn_sched_barrier(0);                       // keep the prefetch ahead of the MFMAs (hipcc sinks it back otherwise)
 #pragma unroll
-                        for (int i = 0; i < 5; ++i) {
-                            const bf16x8 a = *reinterpret_cast<const bf16x8*>(abase[i] + (ky * P::O1_COLS + kx) * 32);
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
-                        }
+                        for (int i = 0; i < 5; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk % (PFA + 1)][i], bf[kk % (PFA + 1)], acc[i], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 };
                 if (kh == 0) taps(std::integral_constant<int, 0>{});
@@ -229,10 +253,14 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
 #pragma unroll
                     for (int i = 0; i < 5; ++i)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int pp = (hs + 2 * i) * 32 + 8 * (r >> 2) + 4 * g + (r & 3), y = pp / P::W2o, x = pp - y * P::W2o;
-                            const float v = acc[i][r] + sc[(i * 16 + r) * 64] + b2v;
-                            *reinterpret_cast<uint16_t*>(o2g + (((y + 2) * P::O2_COLS + x + 2) * 32 + n32) * 2) = bf16_bits(fmaxf(v, 0.f));
+                        for (int q = 0; q < 4; ++q) {
+                            const int pp = (hs + 2 * i) * 32 + 8 * q + 4 * gv, y = pp / P::W2o, x = pp - y * P::W2o;
+                            uint16_t* d = reinterpret_cast<uint16_t*>(o2g + (((y + 2) * P::O2_COLS + x + 2) * 32 + n32) * 2);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int r = 4 * q + e;
+                                d[e * 32] = bf16_bits(fmaxf(acc[i][r] + sc[(i * 16 + r) * 64] + b2v, 0.f));
+                            }
                         }
                 }
                 __syncthreads();
@@ -241,6 +269,8 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
         }
         // ---- (E) conv3 over the two slices of the pass: this wave = K half kh (k-steps 36 kh ..), N tile hs; weights stream from L2
         {
+            int gv = g;
+            asm volatile("" : "+v"(gv));
             f32x16 acc[5];
             const char* abase[5];
 #pragma unroll
@@ -255,17 +285,24 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
 #pragma unroll
             for (int j = 0; j < PF; ++j) bq[j] = *reinterpret_cast<const i32x4*>(w3 + j * 1024);
             auto ksteps = [&](auto KH) __attribute__((always_inline)) {
+                constexpr int K0 = decltype(KH)::value * 36, PFA = 2;
+                bf16x8 af[PFA + 1][5];
+                auto fetch_a = [&](int kk) __attribute__((always_inline)) {
+                    const int tt = K0 + kk, tap = tt >> 1, ky = tap / 6, kx = tap - 6 * ky, hh = tt & 1;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) af[kk % (PFA + 1)][i] = *reinterpret_cast<const bf16x8*>(abase[i] + ((ky * P::O2_COLS + kx) * 32 + hh * 16) * 2);
+                };
+#pragma unroll
+                for (int kk = 0; kk < PFA; ++kk) fetch_a(kk);
 #pragma unroll
                 for (int kk = 0; kk < 36; ++kk) {
-                    constexpr int K0 = decltype(KH)::value * 36;
-                    const int tt = K0 + kk, tap = tt >> 1, ky = tap / 6, kx = tap - 6 * ky, hh = tt & 1;
                     const i32x4 b = bq[kk % PF];
-                    if (kk + PF < 36) bq[kk % PF] = *reinterpret_cast<const i32x4*>(w3 + (kk + PF) * 1024);
+                    if (kk + PFA < 36) fetch_a(kk + PFA);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) {
-                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(abase[i] + ((ky * P::O2_COLS + kx) * 32 + hh * 16) * 2);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b), acc[i], 0, 0, 0);
-                    }
+                    for (int i = 0; i < 5; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk % (PFA + 1)][i], __builtin_bit_cast(bf16x8, b), acc[i], 0, 0, 0);
+                    if (kk + PF < 36) bq[kk % PF] = *reinterpret_cast<const i32x4*>(w3 + (kk + PF) * 1024);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             };
             if (kh == 0) ksteps(std::integral_constant<int, 0>{});
@@ -281,16 +318,19 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
             __syncthreads();
             if (kh == 0) {
                 const int ch = hs * 32 + n32;
+                float* const opass = out + (size_t)2 * pass * (P::M3 * 64);       // (uniform) first token of the pass's first slice
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int pp = i * 32 + 8 * (r >> 2) + 4 * g + (r & 3), sl = pp / P::M3, q = pp - sl * P::M3;
-                        const int s = 2 * pass + sl;
-                        const float v = acc[i][r] + sc[(i * 16 + r) * 64] + b3v;
-                        if (s < S) {
-                            float* dst = TOKENS ? out + ((size_t)s * P::M3 + q) * 64 + ch : out + ((size_t)s * 64 + ch) * P::M3 + q;
-                            __builtin_nontemporal_store(v, dst);
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const int pp = i * 32 + 8 * qd + 4 * gv, sl = pp / P::M3, q = pp - sl * P::M3;    // four consecutive tokens of one slice (M3 % 4 == 0)
+                        if (2 * pass + sl < S) {
+                            float* d = opass + (TOKENS ? (sl * P::M3 + q) * 64 + ch : (sl * 64 + ch) * P::M3 + q);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int r = 4 * qd + e;
+                                __builtin_nontemporal_store(acc[i][r] + sc[(i * 16 + r) * 64] + b3v, d + (TOKENS ? e * 64 : e));
+                            }
                         }
                     }
             }

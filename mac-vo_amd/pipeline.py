@@ -98,6 +98,10 @@ class HotPathConfig:
     # MFMA (bitwise fmaf chain) | "split3" / "split2" the round-1 tile kernels over pre-split planes (layout "hwc").  Shapes the
     # streaming split kernel does not cover run the exact kernel.  16-bit features ignore it.
     volume_precision: str = field(default_factory=ops.default_volume_precision)
+    # 16-bit features: "fp32" = fp32 cells (rounds 1-3) | "encoder" = the volume in the features' fp16 type, one rounding in the GEMM's epilogue —
+    # what the reference's Fast mode computes (einsum of fp16 maps, flownet.py:26-27; MACVO_Fast.yaml:73-74) at half the bytes; the lookups read
+    # the 2-byte cells.  fp16 features in layout "hwc" with C = 128 / 256 (native driver); anything else keeps fp32 cells.
+    volume_store: str = "fp32"
     async_backend: bool | None = None    # native driver: issue a frame's backend launches from a second host thread (None: the
                                          # library's default / MV_PIPE_ASYNC_BACKEND); identical results either way
 
@@ -548,7 +552,7 @@ class NativeHotPath:
         max_depth = cam.fx * cam.baseline if c.max_depth == "auto" else float(c.max_depth)
         pc = L.mvFramePipeConfig(
             H=cam.H, W=cam.W, C=chans, pairs=pairs, iters=x.coords.shape[0], radius=c.radius, feat_dtype=dt,
-            layout=L.MV_LAYOUT_HWC if hwc else L.MV_LAYOUT_CHW, volume_split={"exact": 0, "split3": 3, "split2": 2, "bf16x3": L.MV_PACK_BF16X3, "f16x2": L.MV_PACK_F16X2}[c.volume_precision] if dt == L.MV_F32 else 0,   # 16-bit features: one kernel family, the choice does not apply
+            layout=L.MV_LAYOUT_HWC if hwc else L.MV_LAYOUT_CHW, volume_split={"exact": 0, "split3": 3, "split2": 2, "bf16x3": L.MV_PACK_BF16X3, "f16x2": L.MV_PACK_F16X2}[c.volume_precision] if dt == L.MV_F32 else (L.MV_VOL_ENC16 if (c.volume_store == "encoder" and dt == L.MV_F16 and c.radius == 4) else 0),   # 16-bit features: one kernel family
             selector_mode=L.MV_KP_NODEPTH if c.selector == "nodepth" else L.MV_KP_FULL,
             kp_kernel_size=c.kp_kernel_size, kp_mask_width=c.kp_mask_width, num_point=c.num_point, edgewidth=c.edgewidth,
             min_num_point=c.min_num_point, graph_type=ops._GRAPH[c.graph_type], filters=c.filters,

@@ -25,7 +25,8 @@ class OracleHotPath:
         d = dict(num_point=200, edgewidth=32, match_cov_default=0.25, selector="nodepth", kp_kernel_size=7,
                  kp_mask_width=32, max_match_cov=100.0, max_depth_cov=250.0, max_depth="auto", cov_kernel_size=31,
                  min_flow_cov=0.25, min_depth_cov=0.05, graph_type="disp", min_num_point=10, radius=4,
-                 mapping=False, map_num_point=2000, map_max_depth=5.0, map_max_depth_cov=0.005, map_mask_width=32)
+                 mapping=False, map_num_point=2000, map_max_depth=5.0, map_max_depth_cov=0.005, map_mask_width=32,
+                 volume_store="fp32")   # "encoder": Fast mode, the einsum's fp16 result widened (flownet.py:26-27 with enc_dtype fp16)
         d.update(cfg or {})
         self.cfg = d
         self.maps_prev = None
@@ -37,6 +38,8 @@ class OracleHotPath:
     def frontend(self, x: dict) -> dict:
         f1, f2 = x["fmap1"].float(), x["fmap2"].float()
         vol = corr.corr_volume(f1, f2, torch.float32)
+        if self.cfg["volume_store"] == "encoder":
+            vol = vol.to(torch.float16).float()
         for it in range(x["coords"].shape[0]):
             self.last_tokens = corr.corr_lookup(vol, x["coords"][it], self.cfg["radius"])
         if x.get("flow8") is not None:                                                 # covhead.py:119-135

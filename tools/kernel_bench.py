@@ -32,6 +32,12 @@ def timeit(fn, iters, warm=5):
     return statistics.median(ts), min(ts)
 
 
+def synth_coords(B, h8, w8, dev):
+    g = torch.Generator().manual_seed(1)
+    base = torch.stack([torch.arange(w8).float()[None].expand(h8, w8), torch.arange(h8).float()[:, None].expand(h8, w8)])[None]
+    return (base + (torch.rand(B, 2, h8, w8, generator=g) * 2 - 1) * 8).to(dev)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="*", default=["volume_f32", "volume_f16", "lookup", "select", "cov", "pgo"])
@@ -120,6 +126,21 @@ def main():
                 byts = B * (2.0 * n * C * 2 + 4.0 * n * n)
                 med, mn = timeit(lambda: ops.corr_volume(a1, a2, "hwc", out=vol), a.iters)
                 print(f"volume_{str(dt)[6:]}_hwc B={B} {med:8.1f} us (min {mn:.1f})  {byts / med / 1e3:7.1f} GB/s  {byts / med / 1e3 / 8000 * 100:.1f}% of HBM peak")
+                v16 = ops.corr_volume_out16(a1, a2)
+                if v16 is not None:
+                    b16 = B * (2.0 * n * C * 2 + 2.0 * n * n)
+                    med, mn = timeit(lambda: ops.corr_volume_out16(a1, a2, out=v16), a.iters)
+                    print(f"volume_{str(dt)[6:]}_hwc_out16 B={B} {med:8.1f} us (min {mn:.1f})  {b16 / med / 1e3:7.1f} GB/s  {b16 / med / 1e3 / 8000 * 100:.1f}% of HBM peak ({b16 / 1e6:.0f} MB)")
+                    if dt == torch.float16:
+                        co = synth_coords(B, h8, w8, dev)
+                        tok = ops.corr_lookup(v16, co, 4)
+                        med, mn = timeit(lambda: ops.corr_lookup(v16, co, 4, out=tok), a.iters)
+                        print(f"lookup_vol16 B={B} {med:8.1f} us (min {mn:.1f})")
+                        v32 = v16.float()
+                        med, mn = timeit(lambda: ops.corr_lookup(v32, co, 4, out=tok), a.iters)
+                        print(f"lookup_vol32 B={B} {med:8.1f} us (min {mn:.1f})")
+                        del v32
+                    del v16
                 c1, c2 = f1.to(dt), f2.to(dt)
                 med, mn = timeit(lambda: ops.corr_volume(c1, c2, "chw", out=vol), a.iters)
                 print(f"volume_{str(dt)[6:]}_chw B={B} {med:8.1f} us (min {mn:.1f})  {byts / med / 1e3:7.1f} GB/s")
