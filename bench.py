@@ -273,6 +273,63 @@ def pin_rank_cores(local_rank: int, local_world: int) -> list:
     return mine
 
 
+def patch_embed_leg(ops, vol, dev, reps=10):
+    """(f)2, SURVEY §8(f) rank 2: the cost patch embedding of one frame (both volumes: S = 9600 slices of 60 x 80) through the fused kernel, next to
+    the same three layers as PyTorch / MIOpen bf16 convolutions (intermediate maps through HBM).  Random Conv2d-default weights (no checkpoint).
+    Algorithmic work per slice: 2 x (1280x16x36 + 320x32x576 + 80x64x1152) = 25.07 MFLOP; HBM: the slice in + the tokens out."""
+    import torch.nn.functional as F
+
+    from oracle import patch_embed as ope
+
+    S, H2, W2 = vol.shape[0], vol.shape[-2], vol.shape[-1]
+    if not ops.cost_patch_embed_supported(H2, W2):
+        return None
+    Wt = [t.to(dev) for t in ope.make_weights(0)]
+    pk = ops.PatchEmbedWeights(*Wt)
+    out = torch.empty((S, (H2 + 7) // 8 * ((W2 + 7) // 8), 64), dtype=torch.float32, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        ops.cost_patch_embed(vol, pk, tokens=True, out=out)
+    e0.record()
+    for _ in range(reps):
+        ops.cost_patch_embed(vol, pk, tokens=True, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    fl = S * 2.0 * (1280 * 16 * 36 + 320 * 32 * 576 + 80 * 64 * 1152)
+    byts = S * (H2 * W2 * 4 + out.shape[1] * 64 * 4.0)
+    leg = {"what": f"cost patch embedding of one frame's volumes (S = {S} slices {H2}x{W2} -> {out.shape[1]} tokens x 64), fused kernel mv_cost_patch_embed: bf16 MFMA, fp32 "
+                   "accumulate, both intermediate maps in LDS", "us_per_frame": round(us, 1), "algorithmic_gflop": round(fl / 1e9, 1),
+           "roofline": {"bound": "mfma", "achieved": round(fl / us / 1e6, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / us / 1e6 / PEAK_BF16_MFMA_TFLOPS, 4),
+                        "traffic": None, "kernel": "cost_patch_embed_kernel<60,80>", "algorithmic_hbm_bytes": byts, "hbm_GBps": round(byts / us / 1e3, 1)}}
+    try:
+        # parity of what was just timed: a few slices against the conv2d chain in the same arithmetic (bf16 operands, fp32 accumulation)
+        idx = torch.tensor([0, S // 2, S - 1])
+        ref = ope.to_tokens(ope.patch_embed_proj_bf16(vol[idx.to(dev)].cpu(), *[t.cpu() for t in Wt]))
+        err = float((out[idx.to(dev)].cpu() - ref).abs().max())
+        leg["parity"] = {"max_abs_err_vs_conv2d_chain_bf16": err, "scale": float(ref.abs().max()), "within_bar": bool(err <= 2e-3 * float(ref.abs().max())),
+                         "note": "FlowFormer submodule absent from the reference checkout: pinned to torch's F.conv2d on the published layer shapes"}
+        xb = F.pad(vol, (0, (8 - W2 % 8) % 8, 0, (8 - H2 % 8) % 8)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        wb = [t.to(torch.bfloat16) for t in Wt]
+
+        def unfused():
+            y = F.relu(F.conv2d(xb, wb[0], wb[1], stride=2, padding=2))
+            y = F.relu(F.conv2d(y, wb[2], wb[3], stride=2, padding=2))
+            return F.conv2d(y, wb[4], wb[5], stride=2, padding=2)
+
+        for _ in range(2):
+            unfused()
+        e0.record()
+        for _ in range(3):
+            unfused()
+        e1.record()
+        torch.cuda.synchronize()
+        leg["unfused_miopen_bf16_us_per_frame"] = round(e0.elapsed_time(e1) * 1e3 / 3, 1)
+    except Exception as e:  # noqa: BLE001
+        leg["unfused_error"] = repr(e)[:200]
+    return leg
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -713,6 +770,12 @@ def main():
             decoder_loop = {"error": repr(e)[:300]}
 
     # what RCCL actually connected: world size as the process group reports it + every rank's device (one all_gather of 2 ints)
+    patch_embed = None
+    if rank == 0 and world == 1 and not args.no_decoder_leg and args.lanes == 1 and args.feat_dtype == "f32":
+        try:
+            patch_embed = patch_embed_leg(ops, ops.corr_volume(frames[0].fmap1, frames[0].fmap2, layout=args.layout), dev)
+        except Exception as e:  # noqa: BLE001 - a measurement leg must not take the benchmark line down
+            patch_embed = {"error": repr(e)[:300]}
     ranks_seen, rank_devices = 1, [torch.cuda.current_device()]
     if dist is not None:
         ranks_seen = dist.get_world_size()
@@ -763,6 +826,7 @@ def main():
             "parity": parity,
             "config4": config4,
             "decoder_loop": decoder_loop,
+            "patch_embed": patch_embed,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

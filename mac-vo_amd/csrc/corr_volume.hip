@@ -1006,9 +1006,11 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // OUT16 (round 4, the Fast-mode volume AS THE REFERENCE COMPUTES IT): with the encoder in fp16 / bf16 (MACVO_Fast.yaml:73-74) `einsum` returns the
 // volume in that 16-bit type and flownet.py:27 merely widens it.  The epilogue then rounds the fp32 accumulators ONCE (round-to-nearest-even,
 // what the library GEMM's epilogue does) and stores 2-byte cells: 92 MB per 640x480 frame instead of 184 MB for a kernel that is bound by its
-// output.  The MFMA C layout gives a lane ONE column of 16 rows, so two rows are handled together: the lane pair (2 i, 2 i + 1) swaps one value
-// by DPP (quad_perm [1,0,3,2]) — the even lane then holds columns (li, li + 1) of row r, the odd lane columns (li - 1, li) of row r + 1 — and
-// every lane stores one packed dword: 16 stores per item instead of 32 (the hand-counted vmcnt constants follow: NST).
+// output.  The MFMA C layout gives a lane ONE column per accumulator set; here the two sets of a wave take the EVEN and the ODD columns of the
+// 64-column sub-tile (B fragment rows 2 li and 2 li + 1 instead of li and li + 32; the ring's XOR swizzle keys on row / 2 so that the reads stay
+// conflict-free), so a lane holds columns (2 li, 2 li + 1) of its 16 rows: one v_cvt_pk + ONE dword store per row, 32 lanes = one full 128-byte
+// line, 16 stores per item instead of 32 (the hand-counted vmcnt constants follow: NST).  (First form, measured and dropped: columns li / li + 32,
+// row pairs swapped between neighbouring lanes by DPP, 64-byte half-line nt stores — 63 us against 40 us for the fp32 kernel.)
 template <bool IS_BF16, int KS, bool OUT16 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void corr_volume_h_stream(
     const uint16_t* __restrict__ f1, const uint16_t* __restrict__ f2, float* __restrict__ out, int N1, int N2, int B, int R) {
@@ -1069,7 +1071,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         const int row = (p * 4 + wave) * RPI + lane / CH, pos = lane % CH;
-        lane_src[p] = (unsigned)(row * C + ((pos ^ (row & 15)) << 3));
+        lane_src[p] = (unsigned)(row * C + ((pos ^ ((OUT16 ? row >> 1 : row) & 15)) << 3));
     }
     auto issue_b = [&](int slot) __attribute__((always_inline)) {   // item ld_it -> ring slot, then advance
 #pragma unroll
@@ -1100,8 +1102,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // fixed for a band: stores are `uniform base + 32-bit lane offset`, no address arithmetic between the MFMAs.
     // Rows past N1 (last band) hold copies of row N1 - 1 (the A rows are clamped the same way): they are stored ON TOP of row
     // N1 - 1 with identical values instead of being branched around.
-    unsigned roff[16];                           // (OUT16: entry 2 i = this lane's offset for the row pair (2 i, 2 i + 1))
-    const bool odd_lane = lane & 1;
+    unsigned roff[16];
     auto pack16 = [&](float lo, float hi) __attribute__((always_inline)) -> unsigned {
         if (IS_BF16) return (unsigned)__builtin_bit_cast(uint16_t, (__bf16)lo) | ((unsigned)__builtin_bit_cast(uint16_t, (__bf16)hi) << 16);
         return (unsigned)__builtin_bit_cast(uint16_t, (_Float16)lo) | ((unsigned)__builtin_bit_cast(uint16_t, (_Float16)hi) << 16);
@@ -1109,14 +1110,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto store_r = [&](const f32x16& p0, const f32x16& p1, int r, float* Ob) __attribute__((always_inline)) {
         // asm: hipcc strength-reduces `Ob + roff[r]` into sixteen 64-bit per-lane pointers (32 VGPRs -> spills at the 256-register
         // budget of 2 waves / SIMD); the SGPR-base form needs none.  Like the DMA above these are counted by hand.
-        if (OUT16) {                             // r even: rows (r, r + 1) of both column blocks, one packed dword each
-            const float s0 = odd_lane ? p0[r] : p0[r + 1], s1 = odd_lane ? p1[r] : p1[r + 1];     // what the neighbour lane needs
-            const float g0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, false));
-            const float g1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, false));
-            const unsigned d0 = odd_lane ? pack16(g0, p0[r + 1]) : pack16(p0[r], g0);
-            const unsigned d1 = odd_lane ? pack16(g1, p1[r + 1]) : pack16(p1[r], g1);
-            asm volatile("global_store_dword %0, %1, %2" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(d0), "s"(Ob) : "memory");
-            asm volatile("global_store_dword %0, %1, %2 offset:64" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(d1), "s"(Ob) : "memory");
+        if (OUT16) {                             // columns (2 li, 2 li + 1) of row r: one packed dword, a full line per 32 lanes
+            const unsigned d = pack16(p0[r], p1[r]);
+            asm volatile("global_store_dword %0, %1, %2" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(d), "s"(Ob) : "memory");
         } else {
             asm volatile("global_store_dword %0, %1, %2" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(p0[r]), "s"(Ob) : "memory");
             asm volatile("global_store_dword %0, %1, %2 offset:128" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(p1[r]), "s"(Ob) : "memory");
@@ -1131,8 +1127,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         issue_b(slot ^ 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.f;
-        const i32x4* q0 = smem_hs + slot * SLOT + li * CH;
-        const i32x4* q1 = q0 + 32 * CH;
+        const i32x4* q0 = smem_hs + slot * SLOT + (OUT16 ? 2 * li : li) * CH;      // OUT16: even / odd columns (rows 2 li, 2 li + 1 of the B sub-tile)
+        const i32x4* q1 = q0 + (OUT16 ? 1 : 32) * CH;
         constexpr int PF = 2;                    // B fragments are fetched PF k-steps ahead of the MFMAs that use them
         i32x4 fb0[PF + 1], fb1[PF + 1];
 #pragma unroll
@@ -1156,16 +1152,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[ks]), __builtin_bit_cast(f16x8, b1), c1, 0, 0, 0);
             }
             if (HAVE_PREV) {
-                if (OUT16) {                     // a row PAIR per store: behind the k-step that completes it
-                    if (RPK == 1) { if (ks & 1) store_r(p0, p1, ks - 1, O - OADV); }
-                    else {
 #pragma unroll
-                        for (int q = 0; q < RPK; q += 2) store_r(p0, p1, ks * RPK + q, O - OADV);
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < RPK; ++q) store_r(p0, p1, ks * RPK + q, O - OADV);
-                }
+                for (int q = 0; q < RPK; ++q) store_r(p0, p1, ks * RPK + q, O - OADV);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1179,7 +1167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // 8-pass MFMA) that hipcc's hazard recognizer does not see through inline asm
         asm volatile("s_nop 15" ::: "memory");
 #pragma unroll
-        for (int r = 0; r < 16; r += (OUT16 ? 2 : 1)) store_r(p0, p1, r, O - OADV);
+        for (int r = 0; r < 16; ++r) store_r(p0, p1, r, O - OADV);
     };
     using Yes = std::true_type;
     using No = std::false_type;
@@ -1212,12 +1200,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         O = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + ((size_t)b * N1 * N2 + (size_t)c0i * 64) * OSZ);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            // OUT16: entry r (even) addresses row r for even lanes (columns li, li + 1) and row r + 1 for odd lanes (columns li - 1, li)
-            const int rr = OUT16 ? (r & ~1) + (lane & 1) : r;
-            const int col = OUT16 ? (li & ~1) : li;
-            roff[r] = ((unsigned)min(band * 128 + wave * 32 + 4 * kh + (rr & 3) + 8 * (rr >> 2), N1 - 1) * (unsigned)N2 + col) * (unsigned)OSZ;
-        }
+        for (int r = 0; r < 16; ++r)             // (OUT16: the lane's dword holds columns 2 li, 2 li + 1)
+            roff[r] = ((unsigned)min(band * 128 + wave * 32 + 4 * kh + (r & 3) + 8 * (r >> 2), N1 - 1) * (unsigned)N2 + (OUT16 ? 2 * li : li)) * (unsigned)OSZ;
         step(No{}, x0, x1, x0, x1);
         while (it + 2 <= seg_end) {
             step(Yes{}, y0, y1, x0, x1);

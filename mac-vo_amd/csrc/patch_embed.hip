@@ -23,7 +23,8 @@
 //          36 k-steps each; its 144 KB of weights stream from L2 (one 1-KB fragment per wave and k-step feeds 5 MFMAs; two slices per pass halve
 //          that stream: 73.7 KB per slice)
 //   K halves are summed through LDS (the dead conv1 map).  840 MFMAs per slice = 6720 matrix-pipe cycles per wave and slice.
-// LDS: conv2 weights 36,864 + slice (bf16, halo 2, pitch 88) 11,968 + conv1 map 36x44x16 50,688 + 2 x conv2 map 20x24x32 61,440 = 160,960 B.
+// LDS: conv2 weights 36,864 + slice (bf16, halo 2, pitch 88) 11,968 + conv1 map 36x44x16 50,688 + 2 x conv2 map 20x24x32 61,440 = 160,960 B;
+// the two maps are stored [8-channel chunk][column parity][row][column / 2][16 B] (see PE).
 #include "common.h"
 #include <algorithm>
 #include <atomic>
@@ -44,8 +45,18 @@ struct PE {
     static constexpr int T1 = M1 / 32, T2 = M2 / 32, T3 = 2 * M3 / 32;     // 32-pixel tiles (conv3: of the two slices of a pass together)
     static_assert(M1 % 128 == 0 && M2 % 64 == 0 && (2 * M3) % 32 == 0, "tile split across the four waves");
     static constexpr int IN_ROWS = HP + 4, IN_PITCH = WP + 8;              // halo 2; the kx' = 6, 7 padding taps read two columns further
-    static constexpr int O1_ROWS = H1 + 4, O1_COLS = W1 + 4;               // x 16 channels (bf16, HWC)
+    static constexpr int O1_ROWS = H1 + 4, O1_COLS = W1 + 4;               // x 16 channels (bf16)
     static constexpr int O2_ROWS = H2o + 4, O2_COLS = W2o + 4;             // x 32 channels
+    // Activation maps in LDS are stored [8-channel chunk][column parity][row][column / 2][8 channels = 16 B] (round 4, second pass): a
+    // stride-2 convolution's fragment read — 32 lanes = 32 consecutive output pixels, one tap, one chunk — then walks CONSECUTIVE 16-byte
+    // cells of one parity plane (bank-conflict-free up to the row wrap) instead of cells 64 / 128 bytes apart (HWC: 4-way conflicts in conv2,
+    // 8-way in conv3, measured as 85 % of the kernel's time being LDS-bound).  Same bytes, same sizes.
+    static_assert(O1_COLS % 2 == 0 && O2_COLS % 2 == 0, "column-parity planes");
+    static constexpr int O1_XH = O1_COLS / 2, O2_XH = O2_COLS / 2;
+    static constexpr unsigned O1_PLANE = O1_ROWS * O1_XH * 16, O2_PLANE = O2_ROWS * O2_XH * 16;   // one (chunk, parity) plane
+    // byte offset of 8-channel chunk c of padded cell (row, col)
+    static constexpr unsigned o1_cell(int c, int row, int col) { return (unsigned)(c * 2 + (col & 1)) * O1_PLANE + (unsigned)(row * O1_XH + (col >> 1)) * 16; }
+    static constexpr unsigned o2_cell(int c, int row, int col) { return (unsigned)(c * 2 + (col & 1)) * O2_PLANE + (unsigned)(row * O2_XH + (col >> 1)) * 16; }
     static constexpr unsigned OFF_W2 = 0, W2_BYTES = 36 * 1024;
     static constexpr unsigned OFF_IN0 = OFF_W2 + W2_BYTES, IN0_BYTES = IN_ROWS * IN_PITCH * 2;
     static constexpr unsigned OFF_O1 = OFF_IN0 + IN0_BYTES, O1_BYTES = O1_ROWS * O1_COLS * 32;
@@ -131,9 +142,8 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
                 row = 2 + r;
                 col = q < 2 ? q : P::O1_COLS - 4 + q;
             }
-            i32x4* p = reinterpret_cast<i32x4*>(o1 + (row * P::O1_COLS + col) * 32);
-            p[0] = i32x4{0, 0, 0, 0};
-            p[1] = i32x4{0, 0, 0, 0};
+            *reinterpret_cast<i32x4*>(o1 + P::o1_cell(0, row, col)) = i32x4{0, 0, 0, 0};
+            *reinterpret_cast<i32x4*>(o1 + P::o1_cell(1, row, col)) = i32x4{0, 0, 0, 0};
         }
     };
     // slice staging: this thread's float4s of the NEXT slice travel in registers while the current one is convolved
@@ -197,9 +207,11 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int pp = tile * 32 + 8 * q + 4 * gv, y = pp / P::W1, x = pp - y * P::W1;
-                            uint16_t* d = reinterpret_cast<uint16_t*>(o1 + (((y + 2) * P::O1_COLS + x + 2) * 16 + n32) * 2);
+                            // x is a multiple of 4: cells x + 2 + e alternate between the two parity planes, two 16-byte steps apart
+                            char* d = o1 + P::o1_cell(n32 >> 3, y + 2, x + 2) + (n32 & 7) * 2;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) d[e * 16] = bf16_bits(fmaxf(acc[4 * q + e] + b1v, 0.f));
+                            for (int e = 0; e < 4; ++e)
+                                *reinterpret_cast<uint16_t*>(d + (e & 1) * P::O1_PLANE + (e >> 1) * 16) = bf16_bits(fmaxf(acc[4 * q + e] + b1v, 0.f));
                         }
                     }
                 }
@@ -214,7 +226,7 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
                     const int p = (hs + 2 * i) * 32 + n32, oy = p / P::W2o, ox = p - oy * P::W2o;
-                    abase[i] = o1 + ((2 * oy * P::O1_COLS + 2 * ox) * 16 + g * 8) * 2;
+                    abase[i] = o1 + P::o1_cell(g, 2 * oy, 2 * ox);       // chunk g of padded cell (2 oy, 2 ox); tap (ky, kx) = cell (2 oy + ky, 2 ox + kx)
                 }
                 const char* wb = smem_pe + P::OFF_W2 + lane * 16;
                 auto taps = [&](auto KH) __attribute__((always_inline)) {   // (kh is wave-uniform: one instantiation per K half keeps every offset an immediate)
@@ -224,7 +236,7 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
                         const int tap = K0 + kk, ky = tap / 6, kx = tap - 6 * ky, q = kk % (PFA + 1);
                         bf[q] = *reinterpret_cast<const bf16x8*>(wb + tap * 1024);
 #pragma unroll
-                        for (int i = 0; i < 5; ++i) af[q][i] = *reinterpret_cast<const bf16x8*>(abase[i] + (ky * P::O1_COLS + kx) * 32);
+                        for (int i = 0; i < 5; ++i) af[q][i] = *reinterpret_cast<const bf16x8*>(abase[i] + P::o1_cell(0, ky, kx));
                     };
 #pragma unroll
                     for (int kk = 0; kk < PFA; ++kk) fetch_k(kk);
@@ -255,11 +267,12 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int pp = (hs + 2 * i) * 32 + 8 * q + 4 * gv, y = pp / P::W2o, x = pp - y * P::W2o;
-                            uint16_t* d = reinterpret_cast<uint16_t*>(o2g + (((y + 2) * P::O2_COLS + x + 2) * 32 + n32) * 2);
+                            char* d = o2g + P::o2_cell(n32 >> 3, y + 2, x + 2) + (n32 & 7) * 2;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const int r = 4 * q + e;
-                                d[e * 32] = bf16_bits(fmaxf(acc[i][r] + sc[(i * 16 + r) * 64] + b2v, 0.f));
+                                *reinterpret_cast<uint16_t*>(d + (e & 1) * P::O2_PLANE + (e >> 1) * 16) =
+                                    bf16_bits(fmaxf(acc[i][r] + sc[(i * 16 + r) * 64] + b2v, 0.f));
                             }
                         }
                 }
@@ -278,7 +291,7 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
                 const int p = i * 32 + n32, sl = p / P::M3, q = p - sl * P::M3, oy = q / P::W3, ox = q - oy * P::W3;
-                abase[i] = o2 + sl * P::O2_BYTES + ((2 * oy * P::O2_COLS + 2 * ox) * 32 + g * 8) * 2;
+                abase[i] = o2 + sl * P::O2_BYTES + P::o2_cell(g, 2 * oy, 2 * ox);   // chunk (2 hh + g) of cell (2 oy + ky, 2 ox + kx) per k-step
             }
             constexpr int PF = 6;                                       // weight fragments in flight (L2 latency / 5 MFMAs per k-step)
             i32x4 bq[PF];
@@ -290,7 +303,7 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
                 auto fetch_a = [&](int kk) __attribute__((always_inline)) {
                     const int tt = K0 + kk, tap = tt >> 1, ky = tap / 6, kx = tap - 6 * ky, hh = tt & 1;
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) af[kk % (PFA + 1)][i] = *reinterpret_cast<const bf16x8*>(abase[i] + ((ky * P::O2_COLS + kx) * 32 + hh * 16) * 2);
+                    for (int i = 0; i < 5; ++i) af[kk % (PFA + 1)][i] = *reinterpret_cast<const bf16x8*>(abase[i] + P::o2_cell(2 * hh, ky, kx));
                 };
 #pragma unroll
                 for (int kk = 0; kk < PFA; ++kk) fetch_a(kk);

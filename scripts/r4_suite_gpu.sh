@@ -14,7 +14,7 @@ for V in "f16hwc_fp32:--feat-dtype f16 --layout hwc" "f16hwc_enc16:--feat-dtype 
   timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --config4-steps 0 --no-decoder-leg --exact-steps 0 $A 2>&1 | tail -1 > gpurun_out/r04_bench_480p_${T}_line.json
 done
 bash scripts/profile_gpu.sh r04_bench --config4-steps 0 --no-decoder-leg --exact-steps 0 >> $L 2>&1
-tail -1 gpurun_out/prof_r04_bench/bench.log | grep '^{' > gpurun_out/r04_bench_profiled_line.json
+grep '^{"metric' gpurun_out/prof_r04_bench/bench.log | tail -1 > gpurun_out/r04_bench_profiled_line.json
 MV_SPLIT_MODE=f16x2 bash scripts/pmc_gpu.sh r04_split_f16x2 volume_split >> $L 2>&1
 bash scripts/pmc_gpu.sh r04_patch_embed patch_embed >> $L 2>&1
 bash scripts/profile_kernels_gpu.sh r04_kernels volume_split volume_f16 patch_embed lookup pgo >> $L 2>&1

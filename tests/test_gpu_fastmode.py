@@ -117,7 +117,11 @@ def test_frame_driver_with_the_volume_stored_in_the_encoder_dtype(gpu):
         rh = hot.step(ins[t])
         torch.cuda.synchronize()
         assert ops.last_volume_kernel() == "corr_volume_h_stream<out16>"
-        torch.testing.assert_close(hot.last_tokens.cpu(), ora.last_tokens, rtol=1e-5, atol=3e-4)
+        # a cell whose fp32 sum lies next to an fp16 rounding boundary may round to the other neighbour on the GPU (accumulation order): one fp16 ulp of
+        # the cell = 2^-11 relative, <= 0.03 for |cell| < 64; a token is a convex combination of four cells
+        tok, ref_tok = hot.last_tokens.cpu(), ora.last_tokens
+        assert (tok - ref_tok).abs().max().item() <= 2.0 ** -10 * max(1.0, ref_tok.abs().max().item())
+        assert ((tok - ref_tok).abs() > 3e-4).float().mean().item() < 0.02          # ... and it is rare
         assert torch.equal(rh.kp0_uv.cpu(), ro["kp0_uv"])
         dt, dr = se3.pose_error(ro["pose"].double(), rh.pose.cpu().double())
         assert dt <= 1e-4 and dr <= 1e-4, (t, dt, dr)
