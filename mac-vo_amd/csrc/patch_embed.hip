@@ -16,14 +16,16 @@
 //
 // Implicit GEMMs (M = output pixels, N = output channels, K = taps x input channels, cin innermost so that one lane's 8 consecutive k are 16
 // contiguous bytes of an HWC activation map in LDS):
-//   conv1  M = 32x40 = 1280 (40 tiles), N = 16 (half of a 32-wide tile), K = 6 ky x 8 kx' (kx' = 6, 7 carry zero weights) = 3 k-steps
+//   conv1  M = 32x40 = 1280 (80 tiles of 16 pixels, v_mfma_f32_16x16x32_bf16), N = 16, K = 8 ky x 8 kx' (taps >= 6 carry zero weights) = 2 k-steps
 //   conv2  M = 16x20 = 320 (10 tiles), N = 32, K = 36 taps x 16 = 36 k-steps; waves = (K half, every other tile): 5 tiles x 18 k-steps each,
 //          weights (36 KB) resident in LDS for the whole kernel
 //   conv3  TWO slices per pass: M = 2 x 8x10 = 160 (5 tiles), N = 64 (2 tiles), K = 36 taps x 32 = 72 k-steps; waves = (K half, N tile): 5 tiles x
 //          36 k-steps each; its 144 KB of weights stream from L2 (one 1-KB fragment per wave and k-step feeds 5 MFMAs; two slices per pass halve
 //          that stream: 73.7 KB per slice)
-//   K halves are summed through LDS (the dead conv1 map).  840 MFMAs per slice = 6720 matrix-pipe cycles per wave and slice.
-// LDS: conv2 weights 36,864 + slice (bf16, halo 2, pitch 88) 11,968 + conv1 map 36x44x16 50,688 + 2 x conv2 map 20x24x32 61,440 = 160,960 B;
+//   K halves are summed through LDS (the dead conv1 map), each wave of a pair finishing half of the outputs.  720 32x32x16 + 160 16x16x32 MFMAs per
+//   slice = 6400 matrix-pipe cycles per wave and slice.
+// LDS: conv2 weights 36,864 + slice (bf16, halo 2 (+2 rows / +4 columns for the padding taps), pitch 88) 12,320 + conv1 map 36x44x16 50,688 + 2 x conv2
+// map 20x24x32 61,440 = 161,312 B;
 // the two maps are stored [8-channel chunk][column parity][row][column / 2][16 B] (see PE).
 #include "common.h"
 #include <algorithm>
@@ -42,9 +44,9 @@ struct PE {
     static constexpr int HP = (H2 + 7) / 8 * 8, WP = (W2 + 7) / 8 * 8;
     static constexpr int H1 = HP / 2, W1 = WP / 2, H2o = HP / 4, W2o = WP / 4, H3 = HP / 8, W3 = WP / 8;
     static constexpr int M1 = H1 * W1, M2 = H2o * W2o, M3 = H3 * W3;
-    static constexpr int T1 = M1 / 32, T2 = M2 / 32, T3 = 2 * M3 / 32;     // 32-pixel tiles (conv3: of the two slices of a pass together)
-    static_assert(M1 % 128 == 0 && M2 % 64 == 0 && (2 * M3) % 32 == 0, "tile split across the four waves");
-    static constexpr int IN_ROWS = HP + 4, IN_PITCH = WP + 8;              // halo 2; the kx' = 6, 7 padding taps read two columns further
+    static constexpr int T1 = M1 / 16, T2 = M2 / 32, T3 = 2 * M3 / 32;     // conv1: 16-pixel tiles (16x16x32 MFMA); conv2 / conv3: 32-pixel tiles (conv3: of the two slices of a pass)
+    static_assert(M1 % 64 == 0 && M2 % 64 == 0 && (2 * M3) % 32 == 0, "tile split across the four waves");
+    static constexpr int IN_ROWS = HP + 6, IN_PITCH = WP + 8;              // halo 2; the zero-weight padding taps (ky, kx' = 6, 7) read two rows / columns further
     static constexpr int O1_ROWS = H1 + 4, O1_COLS = W1 + 4;               // x 16 channels (bf16)
     static constexpr int O2_ROWS = H2o + 4, O2_COLS = W2o + 4;             // x 32 channels
     // Activation maps in LDS are stored [8-channel chunk][column parity][row][column / 2][8 channels = 16 B] (round 4, second pass): a
@@ -53,14 +55,16 @@ struct PE {
     // 8-way in conv3, measured as 85 % of the kernel's time being LDS-bound).  Same bytes, same sizes.
     static_assert(O1_COLS % 2 == 0 && O2_COLS % 2 == 0, "column-parity planes");
     static constexpr int O1_XH = O1_COLS / 2, O2_XH = O2_COLS / 2;
-    static constexpr unsigned O1_PLANE = O1_ROWS * O1_XH * 16, O2_PLANE = O2_ROWS * O2_XH * 16;   // one (chunk, parity) plane
+    // one (chunk, parity) plane, + one 16-byte cell: without it the planes of a pixel's 2 / 4 channel chunks start on the same bank and the
+    // epilogues' ds_write_b16 (32 lanes = 32 channels of one pixel) were 8-way conflicted
+    static constexpr unsigned O1_PLANE = O1_ROWS * O1_XH * 16 + 16, O2_PLANE = O2_ROWS * O2_XH * 16 + 16;
     // byte offset of 8-channel chunk c of padded cell (row, col)
     static constexpr unsigned o1_cell(int c, int row, int col) { return (unsigned)(c * 2 + (col & 1)) * O1_PLANE + (unsigned)(row * O1_XH + (col >> 1)) * 16; }
     static constexpr unsigned o2_cell(int c, int row, int col) { return (unsigned)(c * 2 + (col & 1)) * O2_PLANE + (unsigned)(row * O2_XH + (col >> 1)) * 16; }
     static constexpr unsigned OFF_W2 = 0, W2_BYTES = 36 * 1024;
     static constexpr unsigned OFF_IN0 = OFF_W2 + W2_BYTES, IN0_BYTES = IN_ROWS * IN_PITCH * 2;
-    static constexpr unsigned OFF_O1 = OFF_IN0 + IN0_BYTES, O1_BYTES = O1_ROWS * O1_COLS * 32;
-    static constexpr unsigned OFF_O2 = OFF_O1 + O1_BYTES, O2_BYTES = O2_ROWS * O2_COLS * 64;
+    static constexpr unsigned OFF_O1 = OFF_IN0 + IN0_BYTES, O1_BYTES = 4 * (O1_ROWS * (O1_COLS / 2) * 16 + 16);      // 2 chunks x 2 parity planes
+    static constexpr unsigned OFF_O2 = OFF_O1 + O1_BYTES, O2_BYTES = 8 * (O2_ROWS * (O2_COLS / 2) * 16 + 16);      // 4 chunks x 2 parity planes
     static constexpr unsigned LDS_BYTES = OFF_O2 + 2 * O2_BYTES;
     static constexpr unsigned SCRATCH_BYTES = 2 * 5 * 16 * 256;            // K-half partial sums: 2 waves x 5 tiles x 16 registers x 64 lanes fp32
     static_assert(T2 == 10 && T3 == 5, "five tiles per wave in conv2 and conv3");
@@ -70,7 +74,7 @@ struct PE {
 };
 
 // packed weights (mv_patch_embed_pack): bf16 fragments in MFMA B-operand order — lane l holds n = l % 32, k = 8 (l / 32) + 0..7 — then biases
-//   [0, 3 KB)            conv1: 3 k-steps; k = (ky = 2 s + l / 32, kx' = j), zero for n >= 16 or kx' >= 6
+//   [0, 3 KB)            conv1 (16x16x32 fragments: lane l = channel l % 16): 2 k-steps; k = (ky = 4 s + l / 16, kx' = j), zero for ky, kx' >= 6
 //   [3 KB, 39 KB)        conv2: k-step = tap ky*6 + kx; k = cin
 //   [39 KB, 183 KB)      conv3: [n tile 2][k-step 72 = tap * 2 + cin half]; k = cin % 16
 //   then fp32 b1[32] (16 used), b2[32], b3[64]
@@ -84,9 +88,9 @@ __global__ void patch_embed_pack_kernel(const float* __restrict__ w1, const floa
     if (i < total) {
         const int unit = i >> 9, lane = (i >> 3) & 63, j = i & 7, n = lane & 31, g = lane >> 5;
         float v = 0.f;
-        if (unit < 3) {                                        // conv1 [16,1,6,6]
-            const int ky = 2 * unit + g;
-            if (n < 16 && j < 6) v = w1[(n * 6 + ky) * 6 + j];
+        if (unit < 3) {                                        // conv1 [16,1,6,6]: B operand of v_mfma_f32_16x16x32: lane l = channel l % 16, k = 8 (l / 16) + j
+            const int n16 = lane & 15, ky = 4 * unit + (lane >> 4);      // k-step `unit` (2 used): k = (ky = 4 unit + l / 16, kx' = j); ky, kx' >= 6: zero
+            if (unit < 2 && ky < 6 && j < 6) v = w1[(n16 * 6 + ky) * 6 + j];
         } else if (unit < 39) {                                // conv2 [32,16,6,6]
             const int tap = unit - 3, cin = g * 8 + j;
             v = w2[((size_t)n * 16 + cin) * 36 + tap];
@@ -122,11 +126,11 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
     for (unsigned a = (unsigned)t * 16u; a < P::LDS_BYTES - P::OFF_IN0; a += 256u * 16u) *reinterpret_cast<i32x4*>(in0 + a) = i32x4{0, 0, 0, 0};
     for (unsigned a = (unsigned)t * 16u; a < P::W2_BYTES; a += 256u * 16u)
         *reinterpret_cast<i32x4*>(smem_pe + P::OFF_W2 + a) = *reinterpret_cast<const i32x4*>(wp + PE_W2_OFF + a);
-    i32x4 w1f[3];
+    i32x4 w1f[2];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) w1f[s] = *reinterpret_cast<const i32x4*>(wp + PE_W1_OFF + (s * 64 + lane) * 16);
+    for (int s = 0; s < 2; ++s) w1f[s] = *reinterpret_cast<const i32x4*>(wp + PE_W1_OFF + (s * 64 + lane) * 16);
     const float* bias = reinterpret_cast<const float*>(wp + PE_B_OFF);
-    const float b1v = bias[n32], b2v = bias[32 + n32], b3v = bias[64 + hs * 32 + n32];
+    const float b1v = bias[lane & 15], b2v = bias[32 + n32], b3v = bias[64 + hs * 32 + n32];
     const char* const w3 = wp + PE_W3_OFF + ((size_t)(hs * 72 + kh * 36) * 64 + lane) * 16;   // this wave's 36 conv3 fragments
     __syncthreads();
 
@@ -178,42 +182,39 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
             __syncthreads();
             // ---- (C) conv1: 10 tiles per wave, 3 k-steps; k-step s of lane group g = input row 2 oy + 2 s + g, columns 2 ox .. 2 ox + 7
             {
-                // the A fragments of tile j + 1 are fetched while tile j is multiplied and stored (hipcc otherwise reuses ONE register quad for
-                // every fragment: ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, i.e. a full LDS latency in front of each MFMA)
-                auto a_of = [&](int j, i32x4 (&a)[3]) __attribute__((always_inline)) {
-                    const int p = (wave + 4 * j) * 32 + n32, oy = p / P::W1, ox = p - oy * P::W1;
-                    const char* a0 = in0 + ((2 * oy + g) * P::IN_PITCH + 2 * ox) * 2;
+                // v_mfma_f32_16x16x32_bf16: tile = 16 consecutive output pixels x 16 channels, K = 2 x 32 = (ky 0..7) x (kx' 0..7), taps >= 6 carry zero
+                // weights.  Every lane ends with FOUR consecutive pixels of ONE channel (C layout: column = lane % 16, rows 4 (lane / 16) + 0..3):
+                // all 64 lanes take part in the epilogue (the 32x32 form used half of them and twice the outputs per lane).
+                // The A fragments of tile j + 1 are fetched while tile j is multiplied and stored (hipcc otherwise reuses ONE register quad for every
+                // fragment: ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, i.e. a full LDS latency in front of each MFMA).
+                const int n16 = lane & 15, g4 = lane >> 4;
+                int g4v = g4;
+                asm volatile("" : "+v"(g4v));
+                auto a_of = [&](int j, i32x4 (&a)[2]) __attribute__((always_inline)) {
+                    const int p = (wave + 4 * j) * 16 + n16, oy = p / P::W1, ox = p - oy * P::W1;
+                    const char* a0 = in0 + ((2 * oy + g4) * P::IN_PITCH + 2 * ox) * 2;
 #pragma unroll
-                    for (int s = 0; s < 3; ++s) {
-                        const unsigned* ap = reinterpret_cast<const unsigned*>(a0 + 2 * s * P::IN_PITCH * 2);
+                    for (int s = 0; s < 2; ++s) {
+                        const unsigned* ap = reinterpret_cast<const unsigned*>(a0 + 4 * s * P::IN_PITCH * 2);
                         a[s] = i32x4{(int)ap[0], (int)ap[1], (int)ap[2], (int)ap[3]};
                     }
                 };
-                i32x4 afr[2][3];
+                i32x4 afr[2][2];
                 a_of(0, afr[0]);
-#pragma unroll
+                char* const dch = o1 + (n16 >> 3) * 2 * P::O1_PLANE + (n16 & 7) * 2;
+#pragma unroll 4
                 for (int j = 0; j < P::T1 / 4; ++j) {
                     if (j + 1 < P::T1 / 4) a_of(j + 1, afr[(j + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);
-                    const int tile = wave + 4 * j;
-                    f32x16 acc;
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                    for (int s = 0; s < 2; ++s)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[j & 1][s]), __builtin_bit_cast(bf16x8, w1f[s]), acc, 0, 0, 0);
+                    const int pp = (wave + 4 * j) * 16 + 4 * g4v, y = pp / P::W1, x = pp - y * P::W1;     // four consecutive pixels of one row (W1 % 4 == 0)
+                    char* d = dch + P::o1_cell(0, y + 2, x + 2);
 #pragma unroll
-                    for (int s = 0; s < 3; ++s)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[j & 1][s]), __builtin_bit_cast(bf16x8, w1f[s]), acc, 0, 0, 0);
-                    if (n32 < 16) {
-                        // accumulator registers 4 q .. 4 q + 3 of a lane are four CONSECUTIVE pixels of one output row (W1 % 4 == 0): one address per quad
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int pp = tile * 32 + 8 * q + 4 * gv, y = pp / P::W1, x = pp - y * P::W1;
-                            // x is a multiple of 4: cells x + 2 + e alternate between the two parity planes, two 16-byte steps apart
-                            char* d = o1 + P::o1_cell(n32 >> 3, y + 2, x + 2) + (n32 & 7) * 2;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                *reinterpret_cast<uint16_t*>(d + (e & 1) * P::O1_PLANE + (e >> 1) * 16) = bf16_bits(fmaxf(acc[4 * q + e] + b1v, 0.f));
-                        }
-                    }
+                    for (int e = 0; e < 4; ++e)
+                        *reinterpret_cast<uint16_t*>(d + (e & 1) * P::O1_PLANE + (e >> 1) * 16) = bf16_bits(fmaxf(acc[e] + b1v, 0.f));
                 }
             }
             __syncthreads();
@@ -252,30 +253,44 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
                 if (kh == 0) taps(std::integral_constant<int, 0>{});
                 else taps(std::integral_constant<int, 1>{});
                 __syncthreads();                                        // everyone has read the conv1 map: it becomes the K-half scratch
-                float* sc = reinterpret_cast<float*>(o1) + (size_t)hs * (5 * 16 * 64) + lane;
-                if (kh == 1) {
+                // K halves summed through LDS, SYMMETRICALLY: of a wave pair's 80 (tile, register) values the kh = 0 wave finishes the first 40 and the
+                // kh = 1 wave the last 40; each hands the other 40 partial sums (slot = index % 40 of the writer's region) — no wave idles through
+                // the other's epilogue (the one-sided form had two waves waiting for ~480 VALU instructions of the other two).
+                float* const scw = reinterpret_cast<float*>(o1) + (size_t)(hs * 2 + kh) * (40 * 64) + lane;         // this wave writes here
+                const float* const scr = reinterpret_cast<const float*>(o1) + (size_t)(hs * 2 + (kh ^ 1)) * (40 * 64) + lane;   // ... and reads its partner's
+                auto hand_over = [&](auto KH) __attribute__((always_inline)) {
 #pragma unroll
                     for (int i = 0; i < 5; ++i)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) sc[(i * 16 + r) * 64] = acc[i][r];
-                }
+                        for (int r = 0; r < 16; ++r) {
+                            constexpr int MINE_LO = decltype(KH)::value * 40;
+                            const int idx = i * 16 + r;
+                            if (idx < MINE_LO || idx >= MINE_LO + 40) scw[(idx % 40) * 64] = acc[i][r];
+                        }
+                };
+                if (kh == 0) hand_over(std::integral_constant<int, 0>{});
+                else hand_over(std::integral_constant<int, 1>{});
                 __syncthreads();
-                if (kh == 0) {
-                    char* o2g = o2 + gs * P::O2_BYTES;
+                char* o2g = o2 + gs * P::O2_BYTES;
+                auto finish = [&](auto KH) __attribute__((always_inline)) {
 #pragma unroll
                     for (int i = 0; i < 5; ++i)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
+                            constexpr int MINE_LO = decltype(KH)::value * 40;
+                            if (i * 16 + 4 * q < MINE_LO || i * 16 + 4 * q >= MINE_LO + 40) continue;       // (quads do not straddle the split: 40 % 4 == 0)
                             const int pp = (hs + 2 * i) * 32 + 8 * q + 4 * gv, y = pp / P::W2o, x = pp - y * P::W2o;
                             char* d = o2g + P::o2_cell(n32 >> 3, y + 2, x + 2) + (n32 & 7) * 2;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const int r = 4 * q + e;
+                                const int r = 4 * q + e, idx = i * 16 + r;
                                 *reinterpret_cast<uint16_t*>(d + (e & 1) * P::O2_PLANE + (e >> 1) * 16) =
-                                    bf16_bits(fmaxf(acc[i][r] + sc[(i * 16 + r) * 64] + b2v, 0.f));
+                                    bf16_bits(fmaxf(acc[i][r] + scr[(idx % 40) * 64] + b2v, 0.f));
                             }
                         }
-                }
+                };
+                if (kh == 0) finish(std::integral_constant<int, 0>{});
+                else finish(std::integral_constant<int, 1>{});
                 __syncthreads();
                 zero_o1_halo();
             }
@@ -321,32 +336,43 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
             if (kh == 0) ksteps(std::integral_constant<int, 0>{});
             else ksteps(std::integral_constant<int, 1>{});
             __syncthreads();                                            // (the halo writes of (D) are complete in every wave)
-            float* sc = reinterpret_cast<float*>(o1) + (size_t)hs * (5 * 16 * 64) + lane;
-            if (kh == 1) {
+            float* const scw = reinterpret_cast<float*>(o1) + (size_t)(hs * 2 + kh) * (40 * 64) + lane;          // symmetric hand-over as in conv2
+            const float* const scr = reinterpret_cast<const float*>(o1) + (size_t)(hs * 2 + (kh ^ 1)) * (40 * 64) + lane;
+            auto hand_over = [&](auto KH) __attribute__((always_inline)) {
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sc[(i * 16 + r) * 64] = acc[i][r];
-            }
+                    for (int r = 0; r < 16; ++r) {
+                        constexpr int MINE_LO = decltype(KH)::value * 40;
+                        const int idx = i * 16 + r;
+                        if (idx < MINE_LO || idx >= MINE_LO + 40) scw[(idx % 40) * 64] = acc[i][r];
+                    }
+            };
+            if (kh == 0) hand_over(std::integral_constant<int, 0>{});
+            else hand_over(std::integral_constant<int, 1>{});
             __syncthreads();
-            if (kh == 0) {
-                const int ch = hs * 32 + n32;
-                float* const opass = out + (size_t)2 * pass * (P::M3 * 64);       // (uniform) first token of the pass's first slice
+            const int ch = hs * 32 + n32;
+            float* const opass = out + (size_t)2 * pass * (P::M3 * 64);           // (uniform) first token of the pass's first slice
+            auto finish = [&](auto KH) __attribute__((always_inline)) {
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
 #pragma unroll
                     for (int qd = 0; qd < 4; ++qd) {
+                        constexpr int MINE_LO = decltype(KH)::value * 40;
+                        if (i * 16 + 4 * qd < MINE_LO || i * 16 + 4 * qd >= MINE_LO + 40) continue;
                         const int pp = i * 32 + 8 * qd + 4 * gv, sl = pp / P::M3, q = pp - sl * P::M3;    // four consecutive tokens of one slice (M3 % 4 == 0)
                         if (2 * pass + sl < S) {
                             float* d = opass + (TOKENS ? (sl * P::M3 + q) * 64 + ch : (sl * 64 + ch) * P::M3 + q);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const int r = 4 * qd + e;
-                                __builtin_nontemporal_store(acc[i][r] + sc[(i * 16 + r) * 64] + b3v, d + (TOKENS ? e * 64 : e));
+                                const int r = 4 * qd + e, idx = i * 16 + r;
+                                __builtin_nontemporal_store(acc[i][r] + scr[(idx % 40) * 64] + b3v, d + (TOKENS ? e * 64 : e));
                             }
                         }
                     }
-            }
+            };
+            if (kh == 0) finish(std::integral_constant<int, 0>{});
+            else finish(std::integral_constant<int, 1>{});
             __syncthreads();
             zero_o1_halo();
         }
