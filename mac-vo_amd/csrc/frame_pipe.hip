@@ -557,6 +557,9 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
         // period — to the backend stream, behind an event on the frame's last lookup; the next frame's lookups start meanwhile.
         // Measured (640x480, f16x2 volume): one lane 5.38 k vs 4.94 k frames/s (period 183 vs 198 us), 32 lanes 7.43 k vs 7.64 k: the
         // default follows the lane count; MV_PIPE_SELECTOR_ON=main|back forces it.
+        // [r4] `late` needs two unfinished frames in front of the new one, i.e. a 3-deep pipeline; the default depth for <= 2 lanes is now 2
+        // (pipeline.py; profiles/r04_latency_ab.log: the same frame rate within the box's +-3 %, GEMM start -> pose 1.18 -> 0.82 ms), where
+        // `late` and `back` are the same schedule.
         const char* e = getenv("MV_PIPE_SELECTOR_ON");
         p->sel_on_back = e ? (strcmp(e, "back") == 0 ? 1 : strcmp(e, "own") == 0 ? 2 : strcmp(e, "vol") == 0 ? 3 : strcmp(e, "late") == 0 ? 4 : 0)
                            : (p->lanes <= 2 ? 1 : 0);
