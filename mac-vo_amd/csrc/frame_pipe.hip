@@ -172,6 +172,7 @@ struct mvFramePipe {
     long n_vol;            // volume GEMMs issued (n_enq <= n_vol <= n_enq + 1: at most one GEMM ahead of its frame's decoder side)
     hipEvent_t e_in_of[MAX_VOL];   // per volume buffer: the input-ready event its GEMM waited for (the decoder side re-uses it)
     int lookups_on_main;   // default 1; MV_PIPE_LOOKUPS_ON=vol is the measured alternative
+    int serial_lookups;    // MV_PIPE_SERIAL_LOOKUPS: the packed GEMM of frame f waits for the lookups of frame f - 1
     int pose_cur;
     int prior_slot;        // pose slot the newest finished frame started from (its motion-model prior)
     hipEvent_t e_map;
@@ -582,6 +583,8 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
     {
         const char* e = getenv("MV_PIPE_LOOKUPS_ON");
         p->lookups_on_main = (e && strcmp(e, "vol") == 0) ? 0 : 1;
+        const char* e2 = getenv("MV_PIPE_SERIAL_LOOKUPS");
+        p->serial_lookups = e2 ? atoi(e2) : 0;
     }
     const int rc = create_impl(p);
     if (rc != MV_OK) {
@@ -647,6 +650,11 @@ static int issue_volume(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_s
             MV_HIP(hipEventRecord(p->e_packed[f & 1], sp));
             MV_HIP(hipStreamWaitEvent(p->s_vol, p->e_packed[f & 1], 0));
         }
+        // MV_PIPE_SERIAL_LOOKUPS=1 (A/B, round 4): the GEMM waits for the previous frame's lookups.  A one-wave-per-SIMD MFMA stream and the
+        // lookups' waves do not share a SIMD to any gain (period = GEMM alone + lookup chain alone either way); run back to back,
+        // each has the chip to itself and the GEMM's in-pipeline time is its alone-time.  The pack stays in front of the wait (it overlaps the lookups).
+        if (p->serial_lookups && f >= 1 && p->vol_free_valid[(f - 1) % p->n_volbuf])
+            MV_TRY(wait_if_pending(p->s_vol, p->e_vol_free[(f - 1) % p->n_volbuf]));
         if (timed) MV_HIP(hipEventRecord(p->tv0[p->n_timed], p->s_vol));   // the GEMM alone: behind the pack, wherever that ran
         MV_TRY(mv_corr_volume_packed(pk[0], pk[1], p->vol[k], B, c.C, p->n8, p->n8, c.volume_split, p->s_vol));
     } else if (c.volume_split == 2 || c.volume_split == 3) {
