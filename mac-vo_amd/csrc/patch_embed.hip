@@ -18,14 +18,14 @@
 // contiguous bytes of an HWC activation map in LDS):
 //   conv1  M = 32x40 = 1280 (80 tiles of 16 pixels, v_mfma_f32_16x16x32_bf16), N = 16, K = 8 ky x 8 kx' (taps >= 6 carry zero weights) = 2 k-steps
 //   conv2  M = 16x20 = 320 (10 tiles), N = 32, K = 36 taps x 16 = 36 k-steps; waves = (K half, every other tile): 5 tiles x 18 k-steps each,
-//          weights (36 KB) resident in LDS for the whole kernel
+//          each wave keeps the weight fragments of its K half (18 KB) in registers for the whole kernel
 //   conv3  TWO slices per pass: M = 2 x 8x10 = 160 (5 tiles), N = 64 (2 tiles), K = 36 taps x 32 = 72 k-steps; waves = (K half, N tile): 5 tiles x
 //          36 k-steps each; its 144 KB of weights stream from L2 (one 1-KB fragment per wave and k-step feeds 5 MFMAs; two slices per pass halve
 //          that stream: 73.7 KB per slice)
 //   K halves are summed through LDS (the dead conv1 map), each wave of a pair finishing half of the outputs.  720 32x32x16 + 160 16x16x32 MFMAs per
 //   slice = 6400 matrix-pipe cycles per wave and slice.
-// LDS: conv2 weights 36,864 + slice (bf16, halo 2 (+2 rows / +4 columns for the padding taps), pitch 88) 12,320 + conv1 map 36x44x16 50,688 + 2 x conv2
-// map 20x24x32 61,440 = 161,312 B;
+// LDS: slice (bf16, halo 2 (+2 rows / +4 columns for the padding taps), pitch 88) 12,320 + conv1 map 4 planes x 36 rows x 26 cells 59,968 + 2 x conv2 map
+// 8 planes x 20 rows x 13 cells 33,408 = 139,104 B;
 // the two maps are stored [8-channel chunk][column parity][row][column / 2][16 B] (see PE).
 #include "common.h"
 #include <algorithm>
@@ -54,17 +54,21 @@ struct PE {
     // cells of one parity plane (bank-conflict-free up to the row wrap) instead of cells 64 / 128 bytes apart (HWC: 4-way conflicts in conv2,
     // 8-way in conv3, measured as 85 % of the kernel's time being LDS-bound).  Same bytes, same sizes.
     static_assert(O1_COLS % 2 == 0 && O2_COLS % 2 == 0, "column-parity planes");
-    static constexpr int O1_XH = O1_COLS / 2, O2_XH = O2_COLS / 2;
+    // Row pitch of a plane in 16-byte cells.  A fragment read's 16-lane service groups span up to three output rows; the next output row
+    // is 2 x pitch cells further, and the groups tile all 16 bank quads exactly when 2 x pitch = 4 (mod 16) for 20-pixel rows (conv2) and
+    // = 10 (mod 16) for 10-pixel rows (conv3) — simulated over every tile alignment: 2.0 / 2.4 LDS cycles per 32 lanes against 3.6 / 5.6 for
+    // the tight pitches 22 / 12 (the room comes from keeping conv2's weights in registers instead of LDS).
+    static constexpr int pad_xh(int lo, int r) { int x = lo; while (x % 8 != r) ++x; return x; }
+    static constexpr int O1_XH = pad_xh(O1_COLS / 2, 2), O2_XH = pad_xh(O2_COLS / 2, 5);
     // one (chunk, parity) plane, + one 16-byte cell: without it the planes of a pixel's 2 / 4 channel chunks start on the same bank and the
     // epilogues' ds_write_b16 (32 lanes = 32 channels of one pixel) were 8-way conflicted
     static constexpr unsigned O1_PLANE = O1_ROWS * O1_XH * 16 + 16, O2_PLANE = O2_ROWS * O2_XH * 16 + 16;
     // byte offset of 8-channel chunk c of padded cell (row, col)
     static constexpr unsigned o1_cell(int c, int row, int col) { return (unsigned)(c * 2 + (col & 1)) * O1_PLANE + (unsigned)(row * O1_XH + (col >> 1)) * 16; }
     static constexpr unsigned o2_cell(int c, int row, int col) { return (unsigned)(c * 2 + (col & 1)) * O2_PLANE + (unsigned)(row * O2_XH + (col >> 1)) * 16; }
-    static constexpr unsigned OFF_W2 = 0, W2_BYTES = 36 * 1024;
-    static constexpr unsigned OFF_IN0 = OFF_W2 + W2_BYTES, IN0_BYTES = IN_ROWS * IN_PITCH * 2;
-    static constexpr unsigned OFF_O1 = OFF_IN0 + IN0_BYTES, O1_BYTES = 4 * (O1_ROWS * (O1_COLS / 2) * 16 + 16);      // 2 chunks x 2 parity planes
-    static constexpr unsigned OFF_O2 = OFF_O1 + O1_BYTES, O2_BYTES = 8 * (O2_ROWS * (O2_COLS / 2) * 16 + 16);      // 4 chunks x 2 parity planes
+    static constexpr unsigned OFF_IN0 = 0, IN0_BYTES = IN_ROWS * IN_PITCH * 2;
+    static constexpr unsigned OFF_O1 = OFF_IN0 + IN0_BYTES, O1_BYTES = 4 * O1_PLANE;      // 2 chunks x 2 parity planes
+    static constexpr unsigned OFF_O2 = OFF_O1 + O1_BYTES, O2_BYTES = 8 * O2_PLANE;      // 4 chunks x 2 parity planes
     static constexpr unsigned LDS_BYTES = OFF_O2 + 2 * O2_BYTES;
     static constexpr unsigned SCRATCH_BYTES = 2 * 5 * 16 * 256;            // K-half partial sums: 2 waves x 5 tiles x 16 registers x 64 lanes fp32
     static_assert(T2 == 10 && T3 == 5, "five tiles per wave in conv2 and conv3");
@@ -124,8 +128,11 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
 
     // ---- once per workgroup: zero the activation buffers (their halos stay zero), conv2 weights -> LDS, conv1 weights + biases -> registers
     for (unsigned a = (unsigned)t * 16u; a < P::LDS_BYTES - P::OFF_IN0; a += 256u * 16u) *reinterpret_cast<i32x4*>(in0 + a) = i32x4{0, 0, 0, 0};
-    for (unsigned a = (unsigned)t * 16u; a < P::W2_BYTES; a += 256u * 16u)
-        *reinterpret_cast<i32x4*>(smem_pe + P::OFF_W2 + a) = *reinterpret_cast<const i32x4*>(wp + PE_W2_OFF + a);
+    // conv2's B fragments of this wave's K half stay in registers for the whole kernel (18 x 4 VGPRs): no LDS traffic for them, and the 36 KB
+    // they used to occupy pay for the conflict-free row pitches above
+    i32x4 w2f[18];
+#pragma unroll
+    for (int kk = 0; kk < 18; ++kk) w2f[kk] = *reinterpret_cast<const i32x4*>(wp + PE_W2_OFF + ((size_t)(kh * 18 + kk) * 64 + lane) * 16);
     i32x4 w1f[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) w1f[s] = *reinterpret_cast<const i32x4*>(wp + PE_W1_OFF + (s * 64 + lane) * 16);
@@ -159,6 +166,21 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
             pre[i] = (s < S && q < P::Q4) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vol + (size_t)s * (H2 * W2)) + q) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
+    // conv1 addressing (see the conv1 phase): fragment base in the slice and store base in the conv1 map for this wave's tiles 0..4
+    static_assert(P::T1 % 20 == 0 && (20 * 16) % P::W1 == 0, "conv1: five tiles per wave span whole output rows");
+    const char* c1_a[5];
+    char* c1_d[5];
+    {
+        const int n16 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+        for (int r5 = 0; r5 < 5; ++r5) {
+            const int tile = wave + 4 * r5;
+            const int p = tile * 16 + n16, oy = p / P::W1, ox = p - oy * P::W1;
+            c1_a[r5] = in0 + ((2 * oy + g4) * P::IN_PITCH + 2 * ox) * 2;
+            const int pp = tile * 16 + 4 * g4, y = pp / P::W1, x = pp - y * P::W1;      // four consecutive pixels of one row (W1 % 4 == 0)
+            c1_d[r5] = o1 + (n16 >> 3) * 2 * P::O1_PLANE + (n16 & 7) * 2 + P::o1_cell(0, y + 2, x + 2);
+        }
+    }
     const int npass = (S + 1) >> 1;
     int pass = blockIdx.x;
     if (pass < npass) fetch(2 * pass);
@@ -185,37 +207,29 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
                 // v_mfma_f32_16x16x32_bf16: tile = 16 consecutive output pixels x 16 channels, K = 2 x 32 = (ky 0..7) x (kx' 0..7), taps >= 6 carry zero
                 // weights.  Every lane ends with FOUR consecutive pixels of ONE channel (C layout: column = lane % 16, rows 4 (lane / 16) + 0..3):
                 // all 64 lanes take part in the epilogue (the 32x32 form used half of them and twice the outputs per lane).
-                // The A fragments of tile j + 1 are fetched while tile j is multiplied and stored (hipcc otherwise reuses ONE register quad for every
-                // fragment: ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, i.e. a full LDS latency in front of each MFMA).
-                const int n16 = lane & 15, g4 = lane >> 4;
-                int g4v = g4;
-                asm volatile("" : "+v"(g4v));
-                auto a_of = [&](int j, i32x4 (&a)[2]) __attribute__((always_inline)) {
-                    const int p = (wave + 4 * j) * 16 + n16, oy = p / P::W1, ox = p - oy * P::W1;
-                    const char* a0 = in0 + ((2 * oy + g4) * P::IN_PITCH + 2 * ox) * 2;
+                // Tile j of this wave = pixels (wave + 4 j) 16 ..: 20 tiles = 8 output rows (320 pixels) further per 5 tiles, so the fragment and the
+                // store address of tile j = 5 m + r are those of tile r plus m constant strides: ten addresses computed ONCE per kernel (c1_a / c1_d)
+                // replace two divisions by W1 per tile — the conv1 phase was ~900 VALU instructions per slice for 40 MFMAs.
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const unsigned* ap = reinterpret_cast<const unsigned*>(a0 + 4 * s * P::IN_PITCH * 2);
-                        a[s] = i32x4{(int)ap[0], (int)ap[1], (int)ap[2], (int)ap[3]};
+                for (int m = 0; m < P::T1 / 20; ++m)
+#pragma unroll
+                    for (int r5 = 0; r5 < 5; ++r5) {
+                        const char* a0 = c1_a[r5] + m * (16 * P::IN_PITCH * 2);
+                        i32x4 af[2];
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            const unsigned* ap = reinterpret_cast<const unsigned*>(a0 + 4 * s * P::IN_PITCH * 2);
+                            af[s] = i32x4{(int)ap[0], (int)ap[1], (int)ap[2], (int)ap[3]};
+                        }
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int s = 0; s < 2; ++s)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[s]), __builtin_bit_cast(bf16x8, w1f[s]), acc, 0, 0, 0);
+                        char* d = c1_d[r5] + m * (8 * P::O1_XH * 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            *reinterpret_cast<uint16_t*>(d + (e & 1) * P::O1_PLANE + (e >> 1) * 16) = bf16_bits(fmaxf(acc[e] + b1v, 0.f));
                     }
-                };
-                i32x4 afr[2][2];
-                a_of(0, afr[0]);
-                char* const dch = o1 + (n16 >> 3) * 2 * P::O1_PLANE + (n16 & 7) * 2;
-#pragma unroll 4
-                for (int j = 0; j < P::T1 / 4; ++j) {
-                    if (j + 1 < P::T1 / 4) a_of(j + 1, afr[(j + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[j & 1][s]), __builtin_bit_cast(bf16x8, w1f[s]), acc, 0, 0, 0);
-                    const int pp = (wave + 4 * j) * 16 + 4 * g4v, y = pp / P::W1, x = pp - y * P::W1;     // four consecutive pixels of one row (W1 % 4 == 0)
-                    char* d = dch + P::o1_cell(0, y + 2, x + 2);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        *reinterpret_cast<uint16_t*>(d + (e & 1) * P::O1_PLANE + (e >> 1) * 16) = bf16_bits(fmaxf(acc[e] + b1v, 0.f));
-                }
             }
             __syncthreads();
             // ---- (D) conv2: this wave = K half kh (taps 18 kh ..), tiles hs, hs + 2, .. (5)
@@ -229,13 +243,11 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
                     const int p = (hs + 2 * i) * 32 + n32, oy = p / P::W2o, ox = p - oy * P::W2o;
                     abase[i] = o1 + P::o1_cell(g, 2 * oy, 2 * ox);       // chunk g of padded cell (2 oy, 2 ox); tap (ky, kx) = cell (2 oy + ky, 2 ox + kx)
                 }
-                const char* wb = smem_pe + P::OFF_W2 + lane * 16;
                 auto taps = [&](auto KH) __attribute__((always_inline)) {   // (kh is wave-uniform: one instantiation per K half keeps every offset an immediate)
                     constexpr int K0 = decltype(KH)::value * 18, PFA = 2;        // fragments are fetched PFA k-steps ahead of their MFMAs
-                    bf16x8 af[PFA + 1][5], bf[PFA + 1];
+                    bf16x8 af[PFA + 1][5];
                     auto fetch_k = [&](int kk) __attribute__((always_inline)) {
                         const int tap = K0 + kk, ky = tap / 6, kx = tap - 6 * ky, q = kk % (PFA + 1);
-                        bf[q] = *reinterpret_cast<const bf16x8*>(wb + tap * 1024);
 #pragma unroll
                         for (int i = 0; i < 5; ++i) af[q][i] = *reinterpret_cast<const bf16x8*>(abase[i] + P::o1_cell(0, ky, kx));
                     };
@@ -246,7 +258,7 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
                         if (kk + PFA < 18) fetch_k(kk + PFA);
                         __builtin_amdgcn_sched_barrier(0);                       // keep the prefetch ahead of the MFMAs (hipcc sinks it back otherwise)
 #pragma unroll
-                        for (int i = 0; i < 5; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk % (PFA + 1)][i], bf[kk % (PFA + 1)], acc[i], 0, 0, 0);
+                        for (int i = 0; i < 5; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk % (PFA + 1)][i], __builtin_bit_cast(bf16x8, w2f[kk]), acc[i], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 };
