@@ -44,8 +44,8 @@ struct PE {
     static constexpr int HP = (H2 + 7) / 8 * 8, WP = (W2 + 7) / 8 * 8;
     static constexpr int H1 = HP / 2, W1 = WP / 2, H2o = HP / 4, W2o = WP / 4, H3 = HP / 8, W3 = WP / 8;
     static constexpr int M1 = H1 * W1, M2 = H2o * W2o, M3 = H3 * W3;
-    static constexpr int T1 = M1 / 16, T2 = M2 / 32, T3 = 2 * M3 / 32;     // conv1: 16-pixel tiles (16x16x32 MFMA); conv2 / conv3: 32-pixel tiles (conv3: of the two slices of a pass)
-    static_assert(M1 % 64 == 0 && M2 % 64 == 0 && (2 * M3) % 32 == 0, "tile split across the four waves");
+    static constexpr int T1 = M1 / 16, T2 = M2 / 16, T3 = M3 / 16;         // 16-pixel tiles (v_mfma_f32_16x16x32_bf16 everywhere)
+    static_assert(M1 % 64 == 0 && T2 == 20 && T3 == 5, "five tiles per wave in conv2 (a quarter of the map) and conv3 (one slice)");
     static constexpr int IN_ROWS = HP + 6, IN_PITCH = WP + 8;              // halo 2; the zero-weight padding taps (ky, kx' = 6, 7) read two rows / columns further
     static constexpr int O1_ROWS = H1 + 4, O1_COLS = W1 + 4;               // x 16 channels (bf16)
     static constexpr int O2_ROWS = H2o + 4, O2_COLS = W2o + 4;             // x 32 channels
@@ -60,27 +60,29 @@ struct PE {
     // the tight pitches 22 / 12 (the room comes from keeping conv2's weights in registers instead of LDS).
     static constexpr int pad_xh(int lo, int r) { int x = lo; while (x % 8 != r) ++x; return x; }
     static constexpr int O1_XH = pad_xh(O1_COLS / 2, 2), O2_XH = pad_xh(O2_COLS / 2, 5);
-    // one (chunk, parity) plane, + one 16-byte cell: without it the planes of a pixel's 2 / 4 channel chunks start on the same bank and the
-    // epilogues' ds_write_b16 (32 lanes = 32 channels of one pixel) were 8-way conflicted
-    static constexpr unsigned O1_PLANE = O1_ROWS * O1_XH * 16 + 16, O2_PLANE = O2_ROWS * O2_XH * 16 + 16;
+    // one (chunk, parity) plane.  A 16x16x32 fragment read has its four 16-lane groups in four DIFFERENT planes (lane / 16 = chunk / parity): the plane
+    // stride decides whether they collide.  Simulated over every tile (4.0 LDS cycles per 64 lanes = conflict-free): conv1 map, pitch 26: no pad -> 4.0,
+    // + 16 B -> 8.0; conv2 map, pitch 13: + 64 B -> 4.0, every other pad -> 8.0.
+    static constexpr unsigned O1_PLANE = O1_ROWS * O1_XH * 16, O2_PLANE = O2_ROWS * O2_XH * 16 + 64;
+    static_assert(O1_PLANE % 256 == 128 && O2_PLANE % 256 == 128, "plane strides as simulated (both land on half a bank row)");
     // byte offset of 8-channel chunk c of padded cell (row, col)
     static constexpr unsigned o1_cell(int c, int row, int col) { return (unsigned)(c * 2 + (col & 1)) * O1_PLANE + (unsigned)(row * O1_XH + (col >> 1)) * 16; }
     static constexpr unsigned o2_cell(int c, int row, int col) { return (unsigned)(c * 2 + (col & 1)) * O2_PLANE + (unsigned)(row * O2_XH + (col >> 1)) * 16; }
     static constexpr unsigned OFF_IN0 = 0, IN0_BYTES = IN_ROWS * IN_PITCH * 2;
     static constexpr unsigned OFF_O1 = OFF_IN0 + IN0_BYTES, O1_BYTES = 4 * O1_PLANE;      // 2 chunks x 2 parity planes
     static constexpr unsigned OFF_O2 = OFF_O1 + O1_BYTES, O2_BYTES = 8 * O2_PLANE;      // 4 chunks x 2 parity planes
-    static constexpr unsigned LDS_BYTES = OFF_O2 + 2 * O2_BYTES;
-    static constexpr unsigned SCRATCH_BYTES = 2 * 5 * 16 * 256;            // K-half partial sums: 2 waves x 5 tiles x 16 registers x 64 lanes fp32
-    static_assert(T2 == 10 && T3 == 5, "five tiles per wave in conv2 and conv3");
-    static_assert(SCRATCH_BYTES <= O1_BYTES && LDS_BYTES <= 160 * 1024, "LDS plan");
+    static constexpr unsigned OFF_W2B = OFF_O2 + 2 * O2_BYTES, W2B_BYTES = 18 * 1024;   // conv2 weight fragments of channel tile 1 (tile 0: registers)
+    static constexpr unsigned LDS_BYTES = OFF_W2B + W2B_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS plan");
     static constexpr int Q4 = H2 * W2 / 4;                                 // float4s of a slice
     static_assert(W2 % 4 == 0 && Q4 <= 5 * 256, "slice staging: at most five float4 per thread");
 };
 
-// packed weights (mv_patch_embed_pack): bf16 fragments in MFMA B-operand order — lane l holds n = l % 32, k = 8 (l / 32) + 0..7 — then biases
+// packed weights (mv_patch_embed_pack): bf16 fragments in the B-operand order of v_mfma_f32_16x16x32 — lane l holds channel l % 16 of its 16-channel
+// tile, k = 8 (l / 16) + 0..7 — then biases
 //   [0, 3 KB)            conv1 (16x16x32 fragments: lane l = channel l % 16): 2 k-steps; k = (ky = 4 s + l / 16, kx' = j), zero for ky, kx' >= 6
-//   [3 KB, 39 KB)        conv2: k-step = tap ky*6 + kx; k = cin
-//   [39 KB, 183 KB)      conv3: [n tile 2][k-step 72 = tap * 2 + cin half]; k = cin % 16
+//   [3 KB, 39 KB)        conv2: [channel tile 2][k-step 18]; k = (tap 2 ks + l / 32, cin 8 (l / 16 % 2) + j)
+//   [39 KB, 183 KB)      conv3: [channel tile 4][tap 36]; k = cin 8 (l / 16) + j
 //   then fp32 b1[32] (16 used), b2[32], b3[64]
 constexpr size_t PE_W1_OFF = 0, PE_W2_OFF = 3 * 1024, PE_W3_OFF = 39 * 1024, PE_B_OFF = 183 * 1024, PE_PACKED_BYTES = PE_B_OFF + 128 * 4;
 
@@ -90,17 +92,18 @@ __global__ void patch_embed_pack_kernel(const float* __restrict__ w1, const floa
     const int i = blockIdx.x * blockDim.x + threadIdx.x;       // one 16-bit element of the fragment area
     const int total = (int)(PE_B_OFF / 2);
     if (i < total) {
-        const int unit = i >> 9, lane = (i >> 3) & 63, j = i & 7, n = lane & 31, g = lane >> 5;
+        const int unit = i >> 9, lane = (i >> 3) & 63, j = i & 7;
         float v = 0.f;
         if (unit < 3) {                                        // conv1 [16,1,6,6]: B operand of v_mfma_f32_16x16x32: lane l = channel l % 16, k = 8 (l / 16) + j
             const int n16 = lane & 15, ky = 4 * unit + (lane >> 4);      // k-step `unit` (2 used): k = (ky = 4 unit + l / 16, kx' = j); ky, kx' >= 6: zero
             if (unit < 2 && ky < 6 && j < 6) v = w1[(n16 * 6 + ky) * 6 + j];
-        } else if (unit < 39) {                                // conv2 [32,16,6,6]
-            const int tap = unit - 3, cin = g * 8 + j;
-            v = w2[((size_t)n * 16 + cin) * 36 + tap];
-        } else {                                               // conv3 [64,32,6,6]
-            const int u = unit - 39, nt = u / 72, t = u % 72, tap = t >> 1, cin = (t & 1) * 16 + g * 8 + j;
-            v = w3[((size_t)(nt * 32 + n) * 32 + cin) * 36 + tap];
+        } else if (unit < 39) {                                // conv2 [32,16,6,6]: unit = 3 + nt * 18 + ks; lane = channel nt * 16 + l % 16; k = 8 (l / 16) + j
+            const int u = unit - 3, nt = u / 18, ks = u - nt * 18, n16 = lane & 15, g4 = lane >> 4;
+            const int tap = 2 * ks + (g4 >> 1), cin = (g4 & 1) * 8 + j;        // a k-step = two neighbouring taps x 16 input channels
+            v = w2[((size_t)(nt * 16 + n16) * 16 + cin) * 36 + tap];
+        } else {                                               // conv3 [64,32,6,6]: unit = 39 + nt * 36 + tap; k = input channel 8 (l / 16) + j
+            const int u = unit - 39, nt = u / 36, tap = u - nt * 36, n16 = lane & 15, cin = (lane >> 4) * 8 + j;
+            v = w3[((size_t)(nt * 16 + n16) * 32 + cin) * 36 + tap];
         }
         out[i] = __builtin_bit_cast(uint16_t, (__bf16)v);
     }
@@ -120,43 +123,31 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
     extern __shared__ __attribute__((aligned(16))) char smem_pe[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int n32 = lane & 31, g = lane >> 5;
-    const int kh = wave & 1, hs = wave >> 1;           // K half; conv2: tile parity, conv3: N tile
+    const int n16 = lane & 15, g4 = lane >> 4;
+    const int mh = wave & 1, np = wave >> 1;           // conv3: slice of the pass, pair of 16-channel tiles
     char* const in0 = smem_pe + P::OFF_IN0;
     char* const o1 = smem_pe + P::OFF_O1;
     char* const o2 = smem_pe + P::OFF_O2;
 
-    // ---- once per workgroup: zero the activation buffers (their halos stay zero), conv2 weights -> LDS, conv1 weights + biases -> registers
-    for (unsigned a = (unsigned)t * 16u; a < P::LDS_BYTES - P::OFF_IN0; a += 256u * 16u) *reinterpret_cast<i32x4*>(in0 + a) = i32x4{0, 0, 0, 0};
-    // conv2's B fragments of this wave's K half stay in registers for the whole kernel (18 x 4 VGPRs): no LDS traffic for them, and the 36 KB
-    // they used to occupy pay for the conflict-free row pitches above
+    // ---- once per workgroup: zero the activation buffers (their halos stay zero); conv1 / conv2 weights + biases -> registers
+    for (unsigned a = (unsigned)t * 16u; a < P::OFF_W2B; a += 256u * 16u) *reinterpret_cast<i32x4*>(smem_pe + a) = i32x4{0, 0, 0, 0};
+    // conv2's B fragments: channel tile 0 (18 k-steps x 4 VGPRs) stays in registers for the whole kernel, tile 1 in LDS (all 36 in registers spilled;
+    // all 36 in LDS cost the 36 KB that now pay for the conflict-free row pitches above)
     i32x4 w2f[18];
 #pragma unroll
-    for (int kk = 0; kk < 18; ++kk) w2f[kk] = *reinterpret_cast<const i32x4*>(wp + PE_W2_OFF + ((size_t)(kh * 18 + kk) * 64 + lane) * 16);
+    for (int ks = 0; ks < 18; ++ks) w2f[ks] = *reinterpret_cast<const i32x4*>(wp + PE_W2_OFF + ((size_t)ks * 64 + lane) * 16);
+    for (unsigned a = (unsigned)t * 16u; a < P::W2B_BYTES; a += 256u * 16u)
+        *reinterpret_cast<i32x4*>(smem_pe + P::OFF_W2B + a) = *reinterpret_cast<const i32x4*>(wp + PE_W2_OFF + 18 * 1024 + a);
     i32x4 w1f[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) w1f[s] = *reinterpret_cast<const i32x4*>(wp + PE_W1_OFF + (s * 64 + lane) * 16);
     const float* bias = reinterpret_cast<const float*>(wp + PE_B_OFF);
-    const float b1v = bias[lane & 15], b2v = bias[32 + n32], b3v = bias[64 + hs * 32 + n32];
-    const char* const w3 = wp + PE_W3_OFF + ((size_t)(hs * 72 + kh * 36) * 64 + lane) * 16;   // this wave's 36 conv3 fragments
+    const float b1v = bias[n16];
+    const float b2v[2] = {bias[32 + n16], bias[48 + n16]};
+    const float b3v[2] = {bias[64 + np * 32 + n16], bias[80 + np * 32 + n16]};
+    const char* const w3 = wp + PE_W3_OFF + ((size_t)(2 * np) * 36 * 64 + lane) * 16;   // this wave's 2 x 36 conv3 fragments: (j, tap) at + (j * 36 + tap) KB
     __syncthreads();
 
-    auto zero_o1_halo = [&]() {                        // the K-half scratch lives in the conv1 map: restore its zero halo afterwards
-        for (int c = t; c < 4 * P::O1_COLS + 4 * P::H1; c += 256) {
-            int row, col;
-            if (c < 4 * P::O1_COLS) {
-                const int r = c / P::O1_COLS;
-                row = r < 2 ? r : P::O1_ROWS - 4 + r;
-                col = c - r * P::O1_COLS;
-            } else {
-                const int d = c - 4 * P::O1_COLS, r = d >> 2, q = d & 3;
-                row = 2 + r;
-                col = q < 2 ? q : P::O1_COLS - 4 + q;
-            }
-            *reinterpret_cast<i32x4*>(o1 + P::o1_cell(0, row, col)) = i32x4{0, 0, 0, 0};
-            *reinterpret_cast<i32x4*>(o1 + P::o1_cell(1, row, col)) = i32x4{0, 0, 0, 0};
-        }
-    };
     // slice staging: this thread's float4s of the NEXT slice travel in registers while the current one is convolved
     f32x4 pre[5];
     auto fetch = [&](int s) {
@@ -171,7 +162,6 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
     const char* c1_a[5];
     char* c1_d[5];
     {
-        const int n16 = lane & 15, g4 = lane >> 4;
 #pragma unroll
         for (int r5 = 0; r5 < 5; ++r5) {
             const int tile = wave + 4 * r5;
@@ -187,7 +177,7 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
     for (; pass < npass; pass += gridDim.x) {
 #pragma unroll 1
         for (int gs = 0; gs < 2; ++gs) {
-            int gv = g;                                 // the epilogues' address arithmetic starts from this copy: opaque per iteration, so that hipcc
+            int gv = g4;                                // the epilogues' address arithmetic starts from this copy: opaque per iteration, so that hipcc
             asm volatile("" : "+v"(gv));                // does not hoist ~100 loop-invariant addresses out of the slice loop (it spilled 131 registers)
             // ---- (A) slice -> in0 (bf16), next slice -> registers
 #pragma unroll
@@ -232,161 +222,118 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
                     }
             }
             __syncthreads();
-            // ---- (D) conv2: this wave = K half kh (taps 18 kh ..), tiles hs, hs + 2, .. (5)
+            // ---- (D) conv2 (v_mfma_f32_16x16x32_bf16): this wave = output rows 4 wave .. 4 wave + 3 (five 16-pixel tiles) x both 16-channel tiles; a k-step =
+            // two neighbouring taps (2 ks, 2 ks + 1: same ky, kx = 2 (ks % 3) + h) x 16 input channels: lane group l / 16 = (h, channel chunk) reads chunk
+            // (l / 16) % 2 of the parity-h plane, so the tap offset is the same immediate for every lane.  No K split: nothing to sum across waves.
             {
-                f32x16 acc[5];
+                f32x4 acc[5][2];
                 const char* abase[5];
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-                    const int p = (hs + 2 * i) * 32 + n32, oy = p / P::W2o, ox = p - oy * P::W2o;
-                    abase[i] = o1 + P::o1_cell(g, 2 * oy, 2 * ox);       // chunk g of padded cell (2 oy, 2 ox); tap (ky, kx) = cell (2 oy + ky, 2 ox + kx)
+                    acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const int p = (5 * wave + i) * 16 + n16, oy = p / P::W2o, ox = p - oy * P::W2o;
+                    abase[i] = o1 + P::o1_cell(g4 & 1, 2 * oy, 2 * ox) + (g4 >> 1) * P::O1_PLANE;
                 }
-                auto taps = [&](auto KH) __attribute__((always_inline)) {   // (kh is wave-uniform: one instantiation per K half keeps every offset an immediate)
-                    constexpr int K0 = decltype(KH)::value * 18, PFA = 2;        // fragments are fetched PFA k-steps ahead of their MFMAs
-                    bf16x8 af[PFA + 1][5];
-                    auto fetch_k = [&](int kk) __attribute__((always_inline)) {
-                        const int tap = K0 + kk, ky = tap / 6, kx = tap - 6 * ky, q = kk % (PFA + 1);
+                constexpr int PFA = 2;                                  // fragments are fetched PFA k-steps ahead of their MFMAs
+                bf16x8 af[PFA + 1][5], bf1[PFA + 1];
+                const char* const wb1 = smem_pe + P::OFF_W2B + lane * 16;
+                auto fetch_k = [&](int ks) __attribute__((always_inline)) {
+                    bf1[ks % (PFA + 1)] = *reinterpret_cast<const bf16x8*>(wb1 + ks * 1024);
 #pragma unroll
-                        for (int i = 0; i < 5; ++i) af[q][i] = *reinterpret_cast<const bf16x8*>(abase[i] + P::o1_cell(0, ky, kx));
-                    };
+                    for (int i = 0; i < 5; ++i)
+                        af[ks % (PFA + 1)][i] = *reinterpret_cast<const bf16x8*>(abase[i] + ((ks / 3) * P::O1_XH + ks % 3) * 16);
+                };
 #pragma unroll
-                    for (int kk = 0; kk < PFA; ++kk) fetch_k(kk);
+                for (int ks = 0; ks < PFA; ++ks) fetch_k(ks);
 #pragma unroll
-                    for (int kk = 0; kk < 18; ++kk) {
-                        if (kk + PFA < 18) fetch_k(kk + PFA);
-                        __builtin_amdgcn_sched_barrier(0);                       // keep the prefetch ahead of the MFMAs (hipcc sinks it back otherwise)
+                for (int ks = 0; ks < 18; ++ks) {
+                    if (ks + PFA < 18) fetch_k(ks + PFA);
+                    __builtin_amdgcn_sched_barrier(0);                  // keep the prefetch ahead of the MFMAs (hipcc sinks it back otherwise)
 #pragma unroll
-                        for (int i = 0; i < 5; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk % (PFA + 1)][i], __builtin_bit_cast(bf16x8, w2f[kk]), acc[i], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
+                    for (int i = 0; i < 5; ++i) {
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks % (PFA + 1)][i], __builtin_bit_cast(bf16x8, w2f[ks]), acc[i][0], 0, 0, 0);
+                        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks % (PFA + 1)][i], bf1[ks % (PFA + 1)], acc[i][1], 0, 0, 0);
                     }
-                };
-                if (kh == 0) taps(std::integral_constant<int, 0>{});
-                else taps(std::integral_constant<int, 1>{});
-                __syncthreads();                                        // everyone has read the conv1 map: it becomes the K-half scratch
-                // K halves summed through LDS, SYMMETRICALLY: of a wave pair's 80 (tile, register) values the kh = 0 wave finishes the first 40 and the
-                // kh = 1 wave the last 40; each hands the other 40 partial sums (slot = index % 40 of the writer's region) — no wave idles through
-                // the other's epilogue (the one-sided form had two waves waiting for ~480 VALU instructions of the other two).
-                float* const scw = reinterpret_cast<float*>(o1) + (size_t)(hs * 2 + kh) * (40 * 64) + lane;         // this wave writes here
-                const float* const scr = reinterpret_cast<const float*>(o1) + (size_t)(hs * 2 + (kh ^ 1)) * (40 * 64) + lane;   // ... and reads its partner's
-                auto hand_over = [&](auto KH) __attribute__((always_inline)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // epilogue: a lane holds four consecutive pixels (rows 4 (l / 16) + 0..3 of the tile) of channel nt * 16 + l % 16
+                char* const o2g = o2 + gs * P::O2_BYTES + (n16 >> 3) * 2 * P::O2_PLANE + (n16 & 7) * 2;
 #pragma unroll
-                    for (int i = 0; i < 5; ++i)
+                for (int i = 0; i < 5; ++i) {
+                    const int pp = (5 * wave + i) * 16 + 4 * gv, y = pp / P::W2o, x = pp - y * P::W2o;
+                    char* d = o2g + P::o2_cell(0, y + 2, x + 2);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            constexpr int MINE_LO = decltype(KH)::value * 40;
-                            const int idx = i * 16 + r;
-                            if (idx < MINE_LO || idx >= MINE_LO + 40) scw[(idx % 40) * 64] = acc[i][r];
-                        }
-                };
-                if (kh == 0) hand_over(std::integral_constant<int, 0>{});
-                else hand_over(std::integral_constant<int, 1>{});
-                __syncthreads();
-                char* o2g = o2 + gs * P::O2_BYTES;
-                auto finish = [&](auto KH) __attribute__((always_inline)) {
+                    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int i = 0; i < 5; ++i)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            constexpr int MINE_LO = decltype(KH)::value * 40;
-                            if (i * 16 + 4 * q < MINE_LO || i * 16 + 4 * q >= MINE_LO + 40) continue;       // (quads do not straddle the split: 40 % 4 == 0)
-                            const int pp = (hs + 2 * i) * 32 + 8 * q + 4 * gv, y = pp / P::W2o, x = pp - y * P::W2o;
-                            char* d = o2g + P::o2_cell(n32 >> 3, y + 2, x + 2) + (n32 & 7) * 2;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const int r = 4 * q + e, idx = i * 16 + r;
-                                *reinterpret_cast<uint16_t*>(d + (e & 1) * P::O2_PLANE + (e >> 1) * 16) =
-                                    bf16_bits(fmaxf(acc[i][r] + scr[(idx % 40) * 64] + b2v, 0.f));
-                            }
-                        }
-                };
-                if (kh == 0) finish(std::integral_constant<int, 0>{});
-                else finish(std::integral_constant<int, 1>{});
-                __syncthreads();
-                zero_o1_halo();
+                        for (int e = 0; e < 4; ++e)
+                            *reinterpret_cast<uint16_t*>(d + (nt * 4 + (e & 1)) * P::O2_PLANE + (e >> 1) * 16) = bf16_bits(fmaxf(acc[i][nt][e] + b2v[nt], 0.f));
+                }
             }
         }
-        // ---- (E) conv3 over the two slices of the pass: this wave = K half kh (k-steps 36 kh ..), N tile hs; weights stream from L2
+        __syncthreads();                                                // both conv2 maps of the pass are complete
+        // ---- (E) conv3 over the two slices of the pass: this wave = slice mh (its 80 tokens = five 16-pixel tiles) x channel tiles 2 np, 2 np + 1; a k-step =
+        // one tap x 32 input channels (lane group l / 16 = channel chunk); 2 x 36 weight fragments per wave and pass stream from L2
         {
-            int gv = g;
+            int gv = g4;
             asm volatile("" : "+v"(gv));
-            f32x16 acc[5];
+            f32x4 acc[5][2];
             const char* abase[5];
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-                const int p = i * 32 + n32, sl = p / P::M3, q = p - sl * P::M3, oy = q / P::W3, ox = q - oy * P::W3;
-                abase[i] = o2 + sl * P::O2_BYTES + P::o2_cell(g, 2 * oy, 2 * ox);   // chunk (2 hh + g) of cell (2 oy + ky, 2 ox + kx) per k-step
+                acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int q = i * 16 + n16, oy = q / P::W3, ox = q - oy * P::W3;
+                abase[i] = o2 + mh * P::O2_BYTES + P::o2_cell(g4, 2 * oy, 2 * ox);
             }
-            constexpr int PF = 6;                                       // weight fragments in flight (L2 latency / 5 MFMAs per k-step)
-            i32x4 bq[PF];
+            constexpr int PF = 8, PFA = 2;                              // weight fragment pairs in flight (L2 latency); activation fragments ahead
+            i32x4 bq[PF][2];
 #pragma unroll
-            for (int j = 0; j < PF; ++j) bq[j] = *reinterpret_cast<const i32x4*>(w3 + j * 1024);
-            auto ksteps = [&](auto KH) __attribute__((always_inline)) {
-                constexpr int K0 = decltype(KH)::value * 36, PFA = 2;
-                bf16x8 af[PFA + 1][5];
-                auto fetch_a = [&](int kk) __attribute__((always_inline)) {
-                    const int tt = K0 + kk, tap = tt >> 1, ky = tap / 6, kx = tap - 6 * ky, hh = tt & 1;
+            for (int kk = 0; kk < PF; ++kk)
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) af[kk % (PFA + 1)][i] = *reinterpret_cast<const bf16x8*>(abase[i] + P::o2_cell(2 * hh, ky, kx));
-                };
+                for (int j = 0; j < 2; ++j) bq[kk][j] = *reinterpret_cast<const i32x4*>(w3 + (size_t)(j * 36 + kk) * 1024);
+            bf16x8 af[PFA + 1][5];
+            auto fetch_a = [&](int tap) __attribute__((always_inline)) {
 #pragma unroll
-                for (int kk = 0; kk < PFA; ++kk) fetch_a(kk);
+                for (int i = 0; i < 5; ++i) af[tap % (PFA + 1)][i] = *reinterpret_cast<const bf16x8*>(abase[i] + P::o2_cell(0, tap / 6, tap % 6));
+            };
 #pragma unroll
-                for (int kk = 0; kk < 36; ++kk) {
-                    const i32x4 b = bq[kk % PF];
-                    if (kk + PFA < 36) fetch_a(kk + PFA);
-                    __builtin_amdgcn_sched_barrier(0);
+            for (int kk = 0; kk < PFA; ++kk) fetch_a(kk);
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk % (PFA + 1)][i], __builtin_bit_cast(bf16x8, b), acc[i], 0, 0, 0);
-                    if (kk + PF < 36) bq[kk % PF] = *reinterpret_cast<const i32x4*>(w3 + (kk + PF) * 1024);
-                    __builtin_amdgcn_sched_barrier(0);
+            for (int kk = 0; kk < 36; ++kk) {
+                const i32x4 b0 = bq[kk % PF][0], b1 = bq[kk % PF][1];
+                if (kk + PFA < 36) fetch_a(kk + PFA);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk % (PFA + 1)][i], __builtin_bit_cast(bf16x8, b0), acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk % (PFA + 1)][i], __builtin_bit_cast(bf16x8, b1), acc[i][1], 0, 0, 0);
                 }
-            };
-            if (kh == 0) ksteps(std::integral_constant<int, 0>{});
-            else ksteps(std::integral_constant<int, 1>{});
-            __syncthreads();                                            // (the halo writes of (D) are complete in every wave)
-            float* const scw = reinterpret_cast<float*>(o1) + (size_t)(hs * 2 + kh) * (40 * 64) + lane;          // symmetric hand-over as in conv2
-            const float* const scr = reinterpret_cast<const float*>(o1) + (size_t)(hs * 2 + (kh ^ 1)) * (40 * 64) + lane;
-            auto hand_over = [&](auto KH) __attribute__((always_inline)) {
+                if (kk + PF < 36) {
 #pragma unroll
-                for (int i = 0; i < 5; ++i)
+                    for (int j = 0; j < 2; ++j) bq[kk % PF][j] = *reinterpret_cast<const i32x4*>(w3 + (size_t)(j * 36 + kk + PF) * 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int s_out = 2 * pass + mh;
+            if (s_out < S) {
+                float* const oslice = out + (size_t)s_out * (P::M3 * 64);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        constexpr int MINE_LO = decltype(KH)::value * 40;
-                        const int idx = i * 16 + r;
-                        if (idx < MINE_LO || idx >= MINE_LO + 40) scw[(idx % 40) * 64] = acc[i][r];
-                    }
-            };
-            if (kh == 0) hand_over(std::integral_constant<int, 0>{});
-            else hand_over(std::integral_constant<int, 1>{});
-            __syncthreads();
-            const int ch = hs * 32 + n32;
-            float* const opass = out + (size_t)2 * pass * (P::M3 * 64);           // (uniform) first token of the pass's first slice
-            auto finish = [&](auto KH) __attribute__((always_inline)) {
+                for (int i = 0; i < 5; ++i) {
+                    const int q = i * 16 + 4 * gv;                           // four consecutive tokens
 #pragma unroll
-                for (int i = 0; i < 5; ++i)
+                    for (int j = 0; j < 2; ++j) {
+                        const int ch = (2 * np + j) * 16 + n16;
+                        // plain stores: a wave writes 64-byte halves of a token's 256-byte row (16 channels); with nt stores the halves went to HBM
+                        // separately (WRITE_SIZE 258 MB for 197 MB); the L2 merges them
+                        float* d = oslice + (TOKENS ? q * 64 + ch : ch * P::M3 + q);
+                        if (TOKENS) {
 #pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) {
-                        constexpr int MINE_LO = decltype(KH)::value * 40;
-                        if (i * 16 + 4 * qd < MINE_LO || i * 16 + 4 * qd >= MINE_LO + 40) continue;
-                        const int pp = i * 32 + 8 * qd + 4 * gv, sl = pp / P::M3, q = pp - sl * P::M3;    // four consecutive tokens of one slice (M3 % 4 == 0)
-                        if (2 * pass + sl < S) {
-                            float* d = opass + (TOKENS ? (sl * P::M3 + q) * 64 + ch : (sl * 64 + ch) * P::M3 + q);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const int r = 4 * qd + e, idx = i * 16 + r;
-                                __builtin_nontemporal_store(acc[i][r] + scr[(idx % 40) * 64] + b3v, d + (TOKENS ? e * 64 : e));
-                            }
+                            for (int e = 0; e < 4; ++e) d[e * 64] = acc[i][j][e] + b3v[j];
+                        } else {
+                            *reinterpret_cast<f32x4*>(d) = f32x4{acc[i][j][0] + b3v[j], acc[i][j][1] + b3v[j], acc[i][j][2] + b3v[j], acc[i][j][3] + b3v[j]};
                         }
                     }
-            };
-            if (kh == 0) finish(std::integral_constant<int, 0>{});
-            else finish(std::integral_constant<int, 1>{});
-            __syncthreads();
-            zero_o1_halo();
+                }
+            }
         }
     }
 }
