@@ -129,3 +129,32 @@ def test_local_corr81_matches_index_arithmetic():
     torch.testing.assert_close(fast, slow, rtol=1e-12, atol=1e-12)
     # channel 40 is the zero displacement: mean over C of first * second
     torch.testing.assert_close(fast[:, 40], (a.double() * b.double()).mean(1), rtol=1e-12, atol=1e-12)
+
+
+def test_patch_embed_oracle_matches_a_direct_convolution_and_its_bf16_twin_stays_close():
+    """oracle/patch_embed.py: the F.conv2d chain against an explicit unfold + matmul of the same three layers (independent restatement of stride 2 /
+    padding 2 / the bottom-right F.pad), the token layout, and the bf16-operand twin within bf16's operand error of it."""
+    import torch.nn.functional as F
+
+    from oracle import patch_embed as ope
+
+    W = ope.make_weights(2)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 1, 60, 80, generator=g) * 8
+
+    def conv_direct(inp, w, b):                       # stride 2, padding 2, via unfold: [S, Cin*36, L] x [Cout, Cin*36]
+        S, _, H, Wd = inp.shape
+        cols = F.unfold(inp, kernel_size=6, padding=2, stride=2)
+        out = torch.einsum("ok,skl->sol", w.reshape(w.shape[0], -1), cols) + b[None, :, None]
+        return out.reshape(S, w.shape[0], (H + 4 - 6) // 2 + 1, (Wd + 4 - 6) // 2 + 1)
+
+    y = F.pad(x, (0, 0, 0, 4))                        # 60 -> 64 rows (bottom), 80 columns already a multiple of 8
+    y = conv_direct(conv_direct(conv_direct(y, W[0], W[1]).relu(), W[2], W[3]).relu(), W[4], W[5])
+    ref = ope.patch_embed_proj(x, *W)
+    assert ref.shape == (3, 64, 8, 10)
+    torch.testing.assert_close(ref, y, rtol=1e-4, atol=1e-5)
+    tok = ope.to_tokens(ref)
+    assert tok.shape == (3, 80, 64) and torch.equal(tok[1, 23], ref[1, :, 2, 3])
+    bf = ope.patch_embed_proj_bf16(x, *W)
+    assert (bf - ref).abs().max() <= 2e-2 * ref.abs().max()
+    assert (bf - ref).abs().max() > 0                 # it IS a different arithmetic
