@@ -91,7 +91,8 @@ int mv_split_bf16x3(const float* x, void* planes, size_t n, mvStream_t stream);
  * to F.conv2d.  bf16 matrix pipe, fp32 accumulate, intermediate maps in LDS (never in HBM).
  *   mv_patch_embed_pack   OIHW fp32 weights + biases of the three Conv2d layers -> fragment-ordered bf16 (+ fp32 biases), once per model
  *   mv_cost_patch_embed   cost_maps [S, H2, W2] fp32 -> token_layout ? [S, (H2/8)*(W2/8), 64] : [S, 64, H2/8, W2/8] fp32
- *   mv_cost_patch_embed_supported   the slice sizes the LDS plan covers (60 x 80 = 640x480 frames); others: MV_ERR_UNSUPPORTED */
+ *   mv_cost_patch_embed_supported   the slice sizes the LDS plan covers: 60 x 80 (640x480 frames) and 64 x 80 (the padded slice PatchEmbed.forward hands
+ *                                   to `proj`; 640x512 frames); others: MV_ERR_UNSUPPORTED */
 size_t mv_patch_embed_packed_bytes(void);
 int mv_patch_embed_pack(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, void* packed,
                         mvStream_t stream);

@@ -351,21 +351,18 @@ extern "C" int mv_patch_embed_pack(const float* w1, const float* b1, const float
     return mv_launch_status();
 }
 
-extern "C" int mv_cost_patch_embed_supported(int H2, int W2) { return H2 == 60 && W2 == 80; }
+extern "C" int mv_cost_patch_embed_supported(int H2, int W2) { return (H2 == 60 || H2 == 64) && W2 == 80; }
 
-extern "C" int mv_cost_patch_embed(const float* cost_maps, const void* packed, float* out, int S, int H2, int W2, int token_layout,
-                                   mvStream_t stream) {
-    MV_CHECK_ARG(cost_maps && packed && out && S > 0);
-    MV_CHECK_ARG(((uintptr_t)cost_maps & 15) == 0 && ((uintptr_t)packed & 15) == 0);
-    if (!mv_cost_patch_embed_supported(H2, W2)) return MV_ERR_UNSUPPORTED;   // 640x480 frames; larger slices do not fit the LDS plan
-    using P = PE<60, 80>;
+template <int H2>
+static int launch_patch_embed(const float* cost_maps, const void* packed, float* out, int S, int token_layout, hipStream_t stream) {
+    using P = PE<H2, 80>;
     static std::atomic<bool> attr_done[64];
     static int cus = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_done[dev].load(std::memory_order_acquire)) {
-        (void)hipFuncSetAttribute((const void*)cost_patch_embed_kernel<60, 80, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)cost_patch_embed_kernel<60, 80, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)cost_patch_embed_kernel<H2, 80, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)cost_patch_embed_kernel<H2, 80, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done[dev].store(true, std::memory_order_release);
     }
     if (!cus) {
@@ -373,12 +370,21 @@ extern "C" int mv_cost_patch_embed(const float* cost_maps, const void* packed, f
         cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
     const int npass = (S + 1) / 2;
-    const dim3 grid(std::min(npass, cus));                                  // persistent: one workgroup per CU (160,960 B of LDS each)
+    const dim3 grid(std::min(npass, cus));                                  // persistent: one workgroup per CU (157.5 KB of LDS each)
     if (token_layout)
-        hipLaunchKernelGGL((cost_patch_embed_kernel<60, 80, true>), grid, dim3(256), P::LDS_BYTES, (hipStream_t)stream, cost_maps,
-                           (const char*)packed, out, S);
+        hipLaunchKernelGGL((cost_patch_embed_kernel<H2, 80, true>), grid, dim3(256), P::LDS_BYTES, stream, cost_maps, (const char*)packed, out, S);
     else
-        hipLaunchKernelGGL((cost_patch_embed_kernel<60, 80, false>), grid, dim3(256), P::LDS_BYTES, (hipStream_t)stream, cost_maps,
-                           (const char*)packed, out, S);
+        hipLaunchKernelGGL((cost_patch_embed_kernel<H2, 80, false>), grid, dim3(256), P::LDS_BYTES, stream, cost_maps, (const char*)packed, out, S);
     return mv_launch_status();
+}
+
+extern "C" int mv_cost_patch_embed(const float* cost_maps, const void* packed, float* out, int S, int H2, int W2, int token_layout,
+                                   mvStream_t stream) {
+    MV_CHECK_ARG(cost_maps && packed && out && S > 0);
+    MV_CHECK_ARG(((uintptr_t)cost_maps & 15) == 0 && ((uintptr_t)packed & 15) == 0);
+    // 640x480 frames: 60 x 80 slices (padded to 64 rows inside the kernel) or the already padded 64 x 80 slices PatchEmbed.forward hands to `proj`
+    // (also 640x512 frames); larger slices do not fit the LDS plan
+    if (!mv_cost_patch_embed_supported(H2, W2)) return MV_ERR_UNSUPPORTED;
+    return H2 == 60 ? launch_patch_embed<60>(cost_maps, packed, out, S, token_layout, (hipStream_t)stream)
+                    : launch_patch_embed<64>(cost_maps, packed, out, S, token_layout, (hipStream_t)stream);
 }

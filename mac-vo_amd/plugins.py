@@ -576,10 +576,8 @@ def install_flowformer_hooks(model, volume_precision: str | None = None) -> list
                     self.packed = packed
 
                 def forward(self, x):                                   # x: [S, 1, H2p, W2p] — PatchEmbed.forward has already padded it
-                    H2p, W2p = x.shape[-2], x.shape[-1]
-                    H2 = 60 if H2p == 64 else H2p                       # rows 60..63 are F.pad's zeros; the kernel pads 60 -> 64 itself
-                    if x.is_cuda and x.shape[1] == 1 and ops.cost_patch_embed_supported(H2, W2p):
-                        return ops.cost_patch_embed(x[..., :H2, :].float().contiguous(), self.packed).to(x.dtype)
+                    if x.is_cuda and x.shape[1] == 1 and ops.cost_patch_embed_supported(x.shape[-2], x.shape[-1]):
+                        return ops.cost_patch_embed(x.float().contiguous(), self.packed).to(x.dtype)
                     return self.layers(x)
 
             pe.proj = _FusedProj()

@@ -5,6 +5,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 L=gpurun_out/r04_suite.log; : > $L
 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 >> $L
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" 2>&1 | tail -3 >> $L
 timeout 300 python tools/kernel_bench.py volume_f16 patch_embed --iters 30 2>&1 | grep -v amdgpu.ids >> $L
 timeout 600 python bench.py 2>&1 | tail -1 > gpurun_out/r04_bench_default_line.json
 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | tail -1 > gpurun_out/r04_bench_steps20_line.json

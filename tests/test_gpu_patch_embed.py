@@ -103,6 +103,11 @@ def test_cost_patch_embed_on_a_real_volume_and_unsupported_sizes(gpu):
     idx = torch.tensor([0, 1, 2399, 4798, 4799])
     ref = ope.to_tokens(ope.patch_embed_proj_bf16(vol[idx.to(gpu)].cpu(), *W))
     assert (got[idx.to(gpu)].cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    # 64-row slices (what PatchEmbed.forward hands to `proj` after its F.pad, and real 640x512 frames): rows 60..63 carry DATA here
+    x64 = torch.randn(6, 1, 64, 80, generator=g) * 16
+    got64 = ops.cost_patch_embed(x64.to(gpu), ops.PatchEmbedWeights(*[w.to(gpu) for w in W])).cpu()
+    ref64 = ope.patch_embed_proj_bf16(x64, *W)
+    assert got64.shape == (6, 64, 8, 10) and (got64 - ref64).abs().max().item() <= 2e-3 * ref64.abs().max().item()
     assert not ops.cost_patch_embed_supported(90, 160)
     with pytest.raises(ops.L.MacvoHipError):
         ops.cost_patch_embed(torch.zeros(2, 1, 90, 160, device=gpu), ops.PatchEmbedWeights(*[w.to(gpu) for w in W]))
@@ -144,5 +149,9 @@ def test_flowformer_hook_rebinds_the_patch_embed_proj(gpu):
         assert "memory_encoder.patch_embed.proj" in done
         got = m.memory_encoder.patch_embed(x)
         small = m.memory_encoder.patch_embed(torch.randn(2, 1, 24, 32, device=gpu))    # a size the kernel does not cover: original layers
+        x64 = torch.randn(5, 1, 64, 80, device=gpu) * 8                                # 640x512 frames: rows 60..63 are data, not padding
+        got64 = m.memory_encoder.patch_embed(x64)
+        want64 = m.memory_encoder.patch_embed.proj.layers(x64)
     assert got.shape == want.shape == (9, 64, 8, 10) and small.shape == (2, 64, 3, 4)
     assert (got - want).abs().max().item() <= 2e-2 * want.abs().max().item()
+    assert (got64 - want64).abs().max().item() <= 2e-2 * want64.abs().max().item()
