@@ -88,16 +88,19 @@ int mv_split_bf16x3(const float* x, void* planes, size_t n, mvStream_t stream);
  * Conv2d(16,32,6,2,2) -> ReLU -> Conv2d(32,64,6,2,2) — PatchEmbed(patch_size 8, embed_dim 64) of FlowFormer's MemoryEncoder, reached from
  * Module/Network/FlowFormerCov/flownet.py:26; hyper-parameters Config/Train/Demo.yaml:20-36; token shape covhead.py:61-64.  The submodule's
  * source is absent from the reference checkout: shapes restated from the published FlowFormer sources (oracle/patch_embed.py), parity pinned
- * to F.conv2d.  bf16 matrix pipe, fp32 accumulate, intermediate maps in LDS (never in HBM).
- *   mv_patch_embed_pack   OIHW fp32 weights + biases of the three Conv2d layers -> fragment-ordered bf16 (+ fp32 biases), once per model
- *   mv_cost_patch_embed   cost_maps [S, H2, W2] fp32 -> token_layout ? [S, (H2/8)*(W2/8), 64] : [S, 64, H2/8, W2/8] fp32
+ * to F.conv2d.  16-bit matrix pipe, fp32 accumulate, intermediate maps in LDS (never in HBM).  operand_type = the 16-bit type of weights and
+ * activations: MV_F16 (11 significant bits = TF32's mantissa, and the type MACVO_Fast.yaml:73 runs this encoder in) or MV_BF16 (bf16 encoders).
+ *   mv_patch_embed_pack   OIHW fp32 weights + biases of the three Conv2d layers -> fragment-ordered 16-bit (+ fp32 biases), once per model
+ *   mv_cost_patch_embed   cost_maps [S, H2, W2] fp32 -> token_layout ? [S, (H2/8)*(W2/8), 64] : [S, 64, H2/8, W2/8] fp32; operand_type must be
+ *                         the one `packed` was built with
  *   mv_cost_patch_embed_supported   the slice sizes the LDS plan covers: 60 x 80 (640x480 frames) and 64 x 80 (the padded slice PatchEmbed.forward hands
  *                                   to `proj`; 640x512 frames); others: MV_ERR_UNSUPPORTED */
 size_t mv_patch_embed_packed_bytes(void);
 int mv_patch_embed_pack(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, void* packed,
-                        mvStream_t stream);
+                        int operand_type, mvStream_t stream);
 int mv_cost_patch_embed_supported(int H2, int W2);
-int mv_cost_patch_embed(const float* cost_maps, const void* packed, float* out, int S, int H2, int W2, int token_layout, mvStream_t stream);
+int mv_cost_patch_embed(const float* cost_maps, const void* packed, float* out, int S, int H2, int W2, int token_layout, int operand_type,
+                        mvStream_t stream);
 /* -------------------------------------------------------------------------------------------
  * A5, split + streaming form (csrc/corr_volume_split.hip): the same volume from fp32 feature maps on the 16-bit matrix pipe.
  * gfx950 has no TF32 MFMA; the reference runs this GEMM in TF32 / fp16 (Module/Frontend/Frontend.py:275-277,

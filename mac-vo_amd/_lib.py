@@ -146,9 +146,9 @@ SIGNATURES = {
                                           C.c_int, _P]),
     "mv_obs_filter_lanes": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_int, _P, C.c_int, _P, _P, _P]),
     "mv_patch_embed_packed_bytes": (C.c_size_t, []),
-    "mv_patch_embed_pack": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "mv_patch_embed_pack": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "mv_cost_patch_embed_supported": (C.c_int, [C.c_int, C.c_int]),
-    "mv_cost_patch_embed": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mv_cost_patch_embed": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv_frame_pipe_arena_bytes": (C.c_size_t, [C.POINTER(mvFramePipeConfig)]),
     "mv_frame_pipe_max_pending": (C.c_int, []),
     "mv_frame_pipe_create": (C.c_int, [C.POINTER(mvFramePipeConfig), _P, C.c_size_t, C.POINTER(_P)]),

@@ -36,6 +36,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -88,7 +89,7 @@ constexpr size_t PE_W1_OFF = 0, PE_W2_OFF = 3 * 1024, PE_W3_OFF = 39 * 1024, PE_
 
 __global__ void patch_embed_pack_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
                                         const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3,
-                                        uint16_t* __restrict__ out) {
+                                        uint16_t* __restrict__ out, int f16) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;       // one 16-bit element of the fragment area
     const int total = (int)(PE_B_OFF / 2);
     if (i < total) {
@@ -105,7 +106,7 @@ __global__ void patch_embed_pack_kernel(const float* __restrict__ w1, const floa
             const int u = unit - 39, nt = u / 36, tap = u - nt * 36, n16 = lane & 15, cin = (lane >> 4) * 8 + j;
             v = w3[((size_t)(nt * 16 + n16) * 32 + cin) * 36 + tap];
         }
-        out[i] = __builtin_bit_cast(uint16_t, (__bf16)v);
+        out[i] = f16 ? __builtin_bit_cast(uint16_t, (_Float16)v) : __builtin_bit_cast(uint16_t, (__bf16)v);
     }
     if (i < 128) {
         float* b = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + PE_B_OFF);
@@ -113,10 +114,22 @@ __global__ void patch_embed_pack_kernel(const float* __restrict__ w1, const floa
     }
 }
 
-__device__ __forceinline__ uint16_t bf16_bits(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
-__device__ __forceinline__ unsigned bf16_pack(float lo, float hi) { return (unsigned)bf16_bits(lo) | ((unsigned)bf16_bits(hi) << 16); }
+// the 16-bit operand type of the whole stack: bf16 (F16 = false) or IEEE fp16 (F16 = true; 11 significant bits — TF32's mantissa, and the type the
+// reference's Fast mode runs this encoder in); same fragment layouts, same instruction shape
+template <bool F16>
+__device__ __forceinline__ uint16_t cvt_bits(float v) {
+    if constexpr (F16) return __builtin_bit_cast(uint16_t, (_Float16)v);
+    else return __builtin_bit_cast(uint16_t, (__bf16)v);
+}
+template <bool F16>
+__device__ __forceinline__ unsigned cvt_pack(float lo, float hi) { return (unsigned)cvt_bits<F16>(lo) | ((unsigned)cvt_bits<F16>(hi) << 16); }
+template <bool F16>
+__device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 
-template <int H2, int W2, bool TOKENS>
+template <int H2, int W2, bool TOKENS, bool F16>
 __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __restrict__ vol, const char* __restrict__ wp,
                                                                float* __restrict__ out, int S) {
     using P = PE<H2, W2>;
@@ -186,8 +199,8 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
                 if (q < P::Q4) {
                     const int y = q / (W2 / 4), x = 4 * (q - y * (W2 / 4));
                     unsigned* d = reinterpret_cast<unsigned*>(in0 + ((y + 2) * P::IN_PITCH + x + 2) * 2);
-                    d[0] = bf16_pack(pre[i][0], pre[i][1]);
-                    d[1] = bf16_pack(pre[i][2], pre[i][3]);
+                    d[0] = cvt_pack<F16>(pre[i][0], pre[i][1]);
+                    d[1] = cvt_pack<F16>(pre[i][2], pre[i][3]);
                 }
             }
             fetch(gs == 0 ? 2 * pass + 1 : 2 * (pass + (int)gridDim.x));
@@ -214,11 +227,11 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
                         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int s = 0; s < 2; ++s)
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[s]), __builtin_bit_cast(bf16x8, w1f[s]), acc, 0, 0, 0);
+                            acc = mma16<F16>(__builtin_bit_cast(bf16x8, af[s]), __builtin_bit_cast(bf16x8, w1f[s]), acc);
                         char* d = c1_d[r5] + m * (8 * P::O1_XH * 16);
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            *reinterpret_cast<uint16_t*>(d + (e & 1) * P::O1_PLANE + (e >> 1) * 16) = bf16_bits(fmaxf(acc[e] + b1v, 0.f));
+                            *reinterpret_cast<uint16_t*>(d + (e & 1) * P::O1_PLANE + (e >> 1) * 16) = cvt_bits<F16>(fmaxf(acc[e] + b1v, 0.f));
                     }
             }
             __syncthreads();
@@ -251,8 +264,8 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
                     __builtin_amdgcn_sched_barrier(0);                  // keep the prefetch ahead of the MFMAs (hipcc sinks it back otherwise)
 #pragma unroll
                     for (int i = 0; i < 5; ++i) {
-                        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks % (PFA + 1)][i], __builtin_bit_cast(bf16x8, w2f[ks]), acc[i][0], 0, 0, 0);
-                        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks % (PFA + 1)][i], bf1[ks % (PFA + 1)], acc[i][1], 0, 0, 0);
+                        acc[i][0] = mma16<F16>(af[ks % (PFA + 1)][i], __builtin_bit_cast(bf16x8, w2f[ks]), acc[i][0]);
+                        acc[i][1] = mma16<F16>(af[ks % (PFA + 1)][i], bf1[ks % (PFA + 1)], acc[i][1]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -266,7 +279,7 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
                     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            *reinterpret_cast<uint16_t*>(d + (nt * 4 + (e & 1)) * P::O2_PLANE + (e >> 1) * 16) = bf16_bits(fmaxf(acc[i][nt][e] + b2v[nt], 0.f));
+                            *reinterpret_cast<uint16_t*>(d + (nt * 4 + (e & 1)) * P::O2_PLANE + (e >> 1) * 16) = cvt_bits<F16>(fmaxf(acc[i][nt][e] + b2v[nt], 0.f));
                 }
             }
         }
@@ -304,8 +317,8 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk % (PFA + 1)][i], __builtin_bit_cast(bf16x8, b0), acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk % (PFA + 1)][i], __builtin_bit_cast(bf16x8, b1), acc[i][1], 0, 0, 0);
+                    acc[i][0] = mma16<F16>(af[kk % (PFA + 1)][i], __builtin_bit_cast(bf16x8, b0), acc[i][0]);
+                    acc[i][1] = mma16<F16>(af[kk % (PFA + 1)][i], __builtin_bit_cast(bf16x8, b1), acc[i][1]);
                 }
                 if (kk + PF < 36) {
 #pragma unroll
@@ -343,48 +356,56 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
 extern "C" size_t mv_patch_embed_packed_bytes(void) { return PE_PACKED_BYTES; }
 
 extern "C" int mv_patch_embed_pack(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
-                                   void* packed, mvStream_t stream) {
+                                   void* packed, int operand_type, mvStream_t stream) {
     MV_CHECK_ARG(w1 && b1 && w2 && b2 && w3 && b3 && packed && ((uintptr_t)packed & 15) == 0);
+    MV_CHECK_ARG(operand_type == MV_F16 || operand_type == MV_BF16);
     const int total = (int)(PE_B_OFF / 2);
     hipLaunchKernelGGL(patch_embed_pack_kernel, dim3(mv_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, w3, b3,
-                       (uint16_t*)packed);
+                       (uint16_t*)packed, operand_type == MV_F16 ? 1 : 0);
     return mv_launch_status();
 }
 
 extern "C" int mv_cost_patch_embed_supported(int H2, int W2) { return (H2 == 60 || H2 == 64) && W2 == 80; }
 
-template <int H2>
+template <int H2, bool F16>
 static int launch_patch_embed(const float* cost_maps, const void* packed, float* out, int S, int token_layout, hipStream_t stream) {
     using P = PE<H2, 80>;
     static std::atomic<bool> attr_done[64];
-    static int cus = 0;
+    static std::atomic<int> cus{0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_done[dev].load(std::memory_order_acquire)) {
-        (void)hipFuncSetAttribute((const void*)cost_patch_embed_kernel<H2, 80, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)cost_patch_embed_kernel<H2, 80, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)cost_patch_embed_kernel<H2, 80, true, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)cost_patch_embed_kernel<H2, 80, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done[dev].store(true, std::memory_order_release);
     }
-    if (!cus) {
+    int ncu = cus.load(std::memory_order_relaxed);
+    if (!ncu) {
         hipDeviceProp_t prop;
-        cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        cus.store(ncu, std::memory_order_relaxed);
     }
     const int npass = (S + 1) / 2;
-    const dim3 grid(std::min(npass, cus));                                  // persistent: one workgroup per CU (157.5 KB of LDS each)
+    const dim3 grid(std::min(npass, ncu));                                  // persistent: one workgroup per CU (157.5 KB of LDS each)
     if (token_layout)
-        hipLaunchKernelGGL((cost_patch_embed_kernel<H2, 80, true>), grid, dim3(256), P::LDS_BYTES, stream, cost_maps, (const char*)packed, out, S);
+        hipLaunchKernelGGL((cost_patch_embed_kernel<H2, 80, true, F16>), grid, dim3(256), P::LDS_BYTES, stream, cost_maps, (const char*)packed, out, S);
     else
-        hipLaunchKernelGGL((cost_patch_embed_kernel<H2, 80, false>), grid, dim3(256), P::LDS_BYTES, stream, cost_maps, (const char*)packed, out, S);
+        hipLaunchKernelGGL((cost_patch_embed_kernel<H2, 80, false, F16>), grid, dim3(256), P::LDS_BYTES, stream, cost_maps, (const char*)packed, out, S);
     return mv_launch_status();
 }
 
 extern "C" int mv_cost_patch_embed(const float* cost_maps, const void* packed, float* out, int S, int H2, int W2, int token_layout,
-                                   mvStream_t stream) {
+                                   int operand_type, mvStream_t stream) {
     MV_CHECK_ARG(cost_maps && packed && out && S > 0);
     MV_CHECK_ARG(((uintptr_t)cost_maps & 15) == 0 && ((uintptr_t)packed & 15) == 0);
+    MV_CHECK_ARG(operand_type == MV_F16 || operand_type == MV_BF16);        // must be the type `packed` was built for
     // 640x480 frames: 60 x 80 slices (padded to 64 rows inside the kernel) or the already padded 64 x 80 slices PatchEmbed.forward hands to `proj`
     // (also 640x512 frames); larger slices do not fit the LDS plan
     if (!mv_cost_patch_embed_supported(H2, W2)) return MV_ERR_UNSUPPORTED;
-    return H2 == 60 ? launch_patch_embed<60>(cost_maps, packed, out, S, token_layout, (hipStream_t)stream)
-                    : launch_patch_embed<64>(cost_maps, packed, out, S, token_layout, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (operand_type == MV_F16)
+        return H2 == 60 ? launch_patch_embed<60, true>(cost_maps, packed, out, S, token_layout, st)
+                        : launch_patch_embed<64, true>(cost_maps, packed, out, S, token_layout, st);
+    return H2 == 60 ? launch_patch_embed<60, false>(cost_maps, packed, out, S, token_layout, st)
+                    : launch_patch_embed<64, false>(cost_maps, packed, out, S, token_layout, st);
 }

@@ -295,27 +295,36 @@ def convex_upsample(flow8: torch.Tensor, mask: torch.Tensor, mask_scale: float =
 # ------------------------------------------------------------------------------------------- (f)2 cost patch-embed
 class PatchEmbedWeights:
     """The three ``Conv2d`` layers of FlowFormer's cost ``PatchEmbed.proj`` (patch_size 8: 1 -> 16 -> 32 -> 64 channels, 6x6, stride 2,
-    padding 2) packed once into the fragment order of ``mv_cost_patch_embed`` (bf16 weights, fp32 biases)."""
+    padding 2) packed once into the fragment order of ``mv_cost_patch_embed`` (16-bit weights, fp32 biases).
 
-    def __init__(self, w1, b1, w2, b2, w3, b3):
+    ``operand``: the 16-bit type weights and activations are rounded to — ``"f16"`` (IEEE half: 11 significant bits, the mantissa of the
+    TF32 the reference's fp32 configurations run their convolutions in, Frontend.py:275-277, and the type ``MACVO_Fast.yaml:73`` runs this
+    encoder in) or ``"bf16"`` (for bf16 encoders).  None: by the dtype of ``w1`` — bf16 weights -> "bf16", fp16 / fp32 weights -> "f16"."""
+
+    def __init__(self, w1, b1, w2, b2, w3, b3, operand: str | None = None):
         lib = L.load()
-        shapes = [(16, 1, 6, 6), (16,), (32, 16, 6, 6), (32,), (64, 32, 6, 6), (64,)]
+        if operand is None:
+            operand = "bf16" if w1.dtype == torch.bfloat16 else "f16"
+        if operand not in ("f16", "bf16"):
+            raise L.MacvoHipError(f"PatchEmbedWeights: operand must be 'f16' or 'bf16', got {operand!r}")
+        self.operand = operand
+        self.operand_type = L.MV_F16 if operand == "f16" else L.MV_BF16
         ts = []
-        for t, shp in zip((w1, b1, w2, b2, w3, b3), shapes):
+        for t, shp in zip((w1, b1, w2, b2, w3, b3), ((16, 1, 6, 6), (16,), (32, 16, 6, 6), (32,), (64, 32, 6, 6), (64,))):
             if tuple(t.shape) != shp:
                 raise L.MacvoHipError(f"PatchEmbedWeights: expected a tensor of shape {shp}, got {tuple(t.shape)}")
             ts.append(_req(t.detach().float(), torch.float32, "patch-embed weight"))
         self.packed = torch.empty(int(lib.mv_patch_embed_packed_bytes()), dtype=torch.uint8, device=ts[0].device)
-        L.check(lib.mv_patch_embed_pack(*[t.data_ptr() for t in ts], self.packed.data_ptr(), _stream()), "mv_patch_embed_pack")
+        L.check(lib.mv_patch_embed_pack(*[t.data_ptr() for t in ts], self.packed.data_ptr(), self.operand_type, _stream()), "mv_patch_embed_pack")
         self._keep = ts
 
     @classmethod
-    def from_proj(cls, proj) -> "PatchEmbedWeights":
+    def from_proj(cls, proj, operand: str | None = None) -> "PatchEmbedWeights":
         """``proj`` = the ``nn.Sequential(Conv2d, ReLU, Conv2d, ReLU, Conv2d)`` of a FlowFormer ``PatchEmbed`` (patch_size 8)."""
         convs = [m for m in proj if isinstance(m, torch.nn.Conv2d)]
         if len(convs) != 3 or any(c.kernel_size != (6, 6) or c.stride != (2, 2) or c.padding != (2, 2) or c.bias is None for c in convs):
             raise L.MacvoHipError("PatchEmbedWeights.from_proj: expected three Conv2d(k = 6, stride 2, padding 2, bias) layers (patch_size 8)")
-        return cls(convs[0].weight, convs[0].bias, convs[1].weight, convs[1].bias, convs[2].weight, convs[2].bias)
+        return cls(convs[0].weight, convs[0].bias, convs[1].weight, convs[1].bias, convs[2].weight, convs[2].bias, operand=operand)
 
 
 def cost_patch_embed_supported(H2: int, W2: int) -> bool:
@@ -324,8 +333,8 @@ def cost_patch_embed_supported(H2: int, W2: int) -> bool:
 
 def cost_patch_embed(cost_maps: torch.Tensor, weights: PatchEmbedWeights, tokens: bool = False, out: torch.Tensor | None = None) -> torch.Tensor:
     """``PatchEmbed.proj(F.pad(cost_maps))`` for every slice in one launch: ``cost_maps [S, 1, H2, W2]`` fp32 (what ``corr_volume`` returns)
-    -> ``[S, 64, H2/8, W2/8]`` fp32, or with ``tokens`` the flattened-transposed form ``[S, H2/8 * W2/8, 64]``.  bf16 matrix pipe with fp32
-    accumulation; the two intermediate maps never leave LDS.  Raises for slice sizes the kernel does not cover
+    -> ``[S, 64, H2/8, W2/8]`` fp32, or with ``tokens`` the flattened-transposed form ``[S, H2/8 * W2/8, 64]``.  16-bit matrix pipe
+    (``weights.operand``) with fp32 accumulation; the two intermediate maps never leave LDS.  Raises for slice sizes the kernel does not cover
     (``cost_patch_embed_supported``): callers keep their PyTorch layers for those."""
     lib = L.load()
     cost_maps = _req(cost_maps, torch.float32, "cost_maps")
@@ -338,8 +347,8 @@ def cost_patch_embed(cost_maps: torch.Tensor, weights: PatchEmbedWeights, tokens
         out = torch.empty(shape, dtype=torch.float32, device=cost_maps.device)
     elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous():
         raise L.MacvoHipError(f"cost_patch_embed: out must be a contiguous float32 tensor of shape {shape}")
-    L.check(lib.mv_cost_patch_embed(cost_maps.data_ptr(), weights.packed.data_ptr(), out.data_ptr(), S, H2, W2, int(tokens), _stream()),
-            "mv_cost_patch_embed")
+    L.check(lib.mv_cost_patch_embed(cost_maps.data_ptr(), weights.packed.data_ptr(), out.data_ptr(), S, H2, W2, int(tokens), weights.operand_type,
+                                    _stream()), "mv_cost_patch_embed")
     return out
 
 

@@ -557,11 +557,16 @@ def install_flowformer_hooks(model, volume_precision: str | None = None) -> list
 
         enc.corr = corr
         done.append("memory_encoder.corr")
-    # (f)2: the cost patch embedding.  FlowFormer's MemoryEncoder owns `patch_embed = PatchEmbed(patch_size 8, in_chans 1, embed_dim 64)` whose
+    # (f)2: the cost patch embedding.  FlowFormer's cost encoder owns `patch_embed = PatchEmbed(patch_size 8, in_chans 1, embed_dim 64)` whose
     # `proj` (three 6x6 stride-2 convolutions) eats the whole volume slice by slice: rebind `proj` to the fused kernel for the slice sizes it
     # covers (640x480 frames); any other size falls through to the original layers.
-    pe = getattr(enc, "patch_embed", None) if enc is not None else None
-    if pe is not None and isinstance(getattr(pe, "proj", None), torch.nn.Sequential):
+    pe, pe_name = None, ""
+    if enc is not None:      # public FlowFormer: memory_encoder.cost_perceiver_encoder.patch_embed; accept it directly under the encoder too
+        for name, mod in enc.named_modules():
+            if (name == "patch_embed" or name.endswith(".patch_embed")) and isinstance(getattr(mod, "proj", None), torch.nn.Sequential):
+                pe, pe_name = mod, name
+                break
+    if pe is not None:
         try:
             packed = ops.PatchEmbedWeights.from_proj(pe.proj)
         except ops.L.MacvoHipError:
@@ -581,7 +586,7 @@ def install_flowformer_hooks(model, volume_precision: str | None = None) -> list
                     return self.layers(x)
 
             pe.proj = _FusedProj()
-            done.append("memory_encoder.patch_embed.proj")
+            done.append(f"memory_encoder.{pe_name}.proj")
     if not done:
         raise ops.L.MacvoHipError("install_flowformer_hooks: the model has none of memory_decoder.encode_flow_token / "
                                   "upsample_flow / memory_encoder.corr")

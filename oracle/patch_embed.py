@@ -12,8 +12,9 @@ published FlowFormer sources (core/FlowFormer/LatentCostFormer/encoder.py, ``Pat
 **parity unpinned** against the MAC-VO fork (no source, no weights); pinned to torch's own ``F.conv2d`` on the same weights.  What follows the
 stack in ``PatchEmbed.forward`` (position encoding, two 1x1 convolutions, LayerNorm) stays PyTorch and is not restated here.
 
-``patch_embed_proj_bf16`` additionally rounds the slice, the weights and the two intermediate maps to bfloat16 — the arithmetic of the HIP kernel
-(bf16 operands, fp32 accumulation), so that the kernel can be held to a tight tolerance and the bf16 error itself to a separate, looser one."""
+``patch_embed_proj_bf16 / _f16`` additionally round the slice, the weights and the two intermediate maps to bfloat16 / float16 — the arithmetic
+of the HIP kernel for either operand type (16-bit operands, fp32 accumulation), so that the kernel can be held to a tight tolerance and the
+16-bit error itself to a separate, looser one."""
 from __future__ import annotations
 
 import torch
@@ -44,16 +45,22 @@ def patch_embed_proj(cost_maps: torch.Tensor, w1, b1, w2, b2, w3, b3) -> torch.T
     return F.conv2d(x, w3, b3, stride=2, padding=2)
 
 
-def _bf(x: torch.Tensor) -> torch.Tensor:
-    return x.to(torch.bfloat16).float()
+def patch_embed_proj_16(cost_maps: torch.Tensor, w1, b1, w2, b2, w3, b3, dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """The same stack with 16-bit operands (slice, weights, intermediate maps rounded to ``dtype`` = bfloat16 or float16) and fp32
+    accumulation / biases — the arithmetic of the HIP kernel for ``operand`` "bf16" / "f16"."""
+    r = lambda t: t.to(dtype).float()   # noqa: E731
+    x = r(_pad8(cost_maps.float()))
+    x = r(F.relu(F.conv2d(x, r(w1), b1, stride=2, padding=2)))
+    x = r(F.relu(F.conv2d(x, r(w2), b2, stride=2, padding=2)))
+    return F.conv2d(x, r(w3), b3, stride=2, padding=2)
 
 
 def patch_embed_proj_bf16(cost_maps: torch.Tensor, w1, b1, w2, b2, w3, b3) -> torch.Tensor:
-    """The same stack with bf16 operands (slice, weights, intermediate maps) and fp32 accumulation / biases."""
-    x = _bf(_pad8(cost_maps.float()))
-    x = _bf(F.relu(F.conv2d(x, _bf(w1), b1, stride=2, padding=2)))
-    x = _bf(F.relu(F.conv2d(x, _bf(w2), b2, stride=2, padding=2)))
-    return F.conv2d(x, _bf(w3), b3, stride=2, padding=2)
+    return patch_embed_proj_16(cost_maps, w1, b1, w2, b2, w3, b3, torch.bfloat16)
+
+
+def patch_embed_proj_f16(cost_maps: torch.Tensor, w1, b1, w2, b2, w3, b3) -> torch.Tensor:
+    return patch_embed_proj_16(cost_maps, w1, b1, w2, b2, w3, b3, torch.float16)
 
 
 def to_tokens(y: torch.Tensor) -> torch.Tensor:

@@ -1,13 +1,25 @@
 """(f)2 — the fused cost patch embedding (csrc/patch_embed.hip) against torch's F.conv2d chain (oracle/patch_embed.py; the FlowFormer submodule is
 absent from the reference checkout: parity unpinned against the MAC-VO fork, pinned to the published layer definition).
 
-Two bars: (1) against the SAME arithmetic — bf16 operands, fp32 accumulation (``patch_embed_proj_bf16``) — the kernel may differ by accumulation
-order and by the rare intermediate value that rounds to the other bf16 neighbour: 2e-3 of the output scale; (2) against the fp32 chain: the bf16
-operand error, 2e-2 of the output scale (what the reference's own Fast mode accepts for this encoder: enc_dtype fp16, MACVO_Fast.yaml:73-74)."""
+Both operand types ("f16": IEEE half, the default for fp16 / fp32 encoders; "bf16": for bf16 encoders).  Two bars each: (1) against the SAME
+arithmetic — 16-bit operands, fp32 accumulation (``patch_embed_proj_f16 / _bf16``) — the kernel may differ by accumulation order and by the rare
+intermediate value that rounds to the other 16-bit neighbour: 2e-3 (bf16) / 2.5e-4 (f16) of the output scale; (2) against the fp32 chain: the
+operand error, 2e-2 (bf16) / 2.5e-3 (f16) of the output scale (the reference's Fast mode runs this encoder in fp16, MACVO_Fast.yaml:73-74; its
+fp32 configurations in TF32, Frontend.py:275-277 — fp16's mantissa)."""
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+TWIN_TOL = {"bf16": 2e-3, "f16": 2.5e-4}      # vs the same-arithmetic twin, relative to the output scale
+FP32_TOL = {"bf16": 2e-2, "f16": 2.5e-3}      # vs the fp32 chain
+
+
+def _twin(operand):
+    from oracle import patch_embed as ope
+
+    return ope.patch_embed_proj_bf16 if operand == "bf16" else ope.patch_embed_proj_f16
 
 
 def _volume_slices(S, seed, scale=16.0):
@@ -18,26 +30,28 @@ def _volume_slices(S, seed, scale=16.0):
     return x
 
 
+@pytest.mark.parametrize("operand", ["f16", "bf16"])
 @pytest.mark.parametrize("S,tokens", [(1, False), (2, True), (7, False), (600, True)])
-def test_cost_patch_embed_matches_the_conv2d_chain(gpu, S, tokens):
+def test_cost_patch_embed_matches_the_conv2d_chain(gpu, S, tokens, operand):
     from macvo_amd import ops
     from oracle import patch_embed as ope
 
     W = ope.make_weights(seed=S)
     x = _volume_slices(S, seed=S + 1)
-    packed = ops.PatchEmbedWeights(*[w.to(gpu) for w in W])
+    packed = ops.PatchEmbedWeights(*[w.to(gpu) for w in W], operand=operand)
     got = ops.cost_patch_embed(x.to(gpu), packed, tokens=tokens).cpu()
-    ref_bf = ope.patch_embed_proj_bf16(x, *W)
+    ref_bf = _twin(operand)(x, *W)
     ref_32 = ope.patch_embed_proj(x, *W)
     if tokens:
         ref_bf, ref_32 = ope.to_tokens(ref_bf), ope.to_tokens(ref_32)
     assert got.shape == ref_32.shape == ((S, 80, 64) if tokens else (S, 64, 8, 10))
     scale = ref_32.abs().max().item()
-    assert (got - ref_bf).abs().max().item() <= 2e-3 * scale, ((got - ref_bf).abs().max().item(), scale)
-    assert (got - ref_32).abs().max().item() <= 2e-2 * scale, ((got - ref_32).abs().max().item(), scale)
+    assert (got - ref_bf).abs().max().item() <= TWIN_TOL[operand] * scale, ((got - ref_bf).abs().max().item(), scale)
+    assert (got - ref_32).abs().max().item() <= FP32_TOL[operand] * scale, ((got - ref_32).abs().max().item(), scale)
 
 
-def test_cost_patch_embed_layers_one_by_one(gpu):
+@pytest.mark.parametrize("operand", ["f16", "bf16"])
+def test_cost_patch_embed_layers_one_by_one(gpu, operand):
     """Weights that isolate each layer: identity-like taps make the stack's output a known function of the input, so an indexing error in any
     of the three implicit GEMMs (tap order, stride, halo, channel order) cannot hide behind the others."""
     from macvo_amd import ops
@@ -68,9 +82,9 @@ def test_cost_patch_embed_layers_one_by_one(gpu):
             b2[5] = -1.0
             w3[9, 5, 1, 1] = -1.0
         W = (w1, b1, w2, b2, w3, b3)
-        got = ops.cost_patch_embed(x.to(gpu), ops.PatchEmbedWeights(*[w.to(gpu) for w in W])).cpu()
-        ref = ope.patch_embed_proj_bf16(x, *W)
-        tol = 2e-3 * max(ref.abs().max().item(), 1e-3)
+        got = ops.cost_patch_embed(x.to(gpu), ops.PatchEmbedWeights(*[w.to(gpu) for w in W], operand=operand)).cpu()
+        ref = _twin(operand)(x, *W)
+        tol = TWIN_TOL[operand] * max(ref.abs().max().item(), 1e-3)
         assert (got - ref).abs().max().item() <= tol, (probe, (got - ref).abs().max().item(), tol)
 
 
@@ -99,15 +113,19 @@ def test_cost_patch_embed_on_a_real_volume_and_unsupported_sizes(gpu):
     f1, f2 = torch.randn(1, 256, 60, 80, generator=g), torch.randn(1, 256, 60, 80, generator=g)
     vol = ops.corr_volume(f1.to(gpu), f2.to(gpu))             # [4800, 1, 60, 80]: the kernel's real producer
     W = ope.make_weights(11)
-    got = ops.cost_patch_embed(vol, ops.PatchEmbedWeights(*[w.to(gpu) for w in W]), tokens=True)
+    packed = ops.PatchEmbedWeights(*[w.to(gpu) for w in W])
+    assert packed.operand == "f16"                            # fp32 / fp16 weights: IEEE half operands; bf16 weights: bf16
+    assert ops.PatchEmbedWeights(*[w.to(gpu).bfloat16() for w in W]).operand == "bf16"
+    got = ops.cost_patch_embed(vol, packed, tokens=True)
     idx = torch.tensor([0, 1, 2399, 4798, 4799])
-    ref = ope.to_tokens(ope.patch_embed_proj_bf16(vol[idx.to(gpu)].cpu(), *W))
-    assert (got[idx.to(gpu)].cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    ref = ope.to_tokens(ope.patch_embed_proj_f16(vol[idx.to(gpu)].cpu(), *W))
+    assert (got[idx.to(gpu)].cpu() - ref).abs().max().item() <= TWIN_TOL["f16"] * ref.abs().max().item()
     # 64-row slices (what PatchEmbed.forward hands to `proj` after its F.pad, and real 640x512 frames): rows 60..63 carry DATA here
     x64 = torch.randn(6, 1, 64, 80, generator=g) * 16
-    got64 = ops.cost_patch_embed(x64.to(gpu), ops.PatchEmbedWeights(*[w.to(gpu) for w in W])).cpu()
-    ref64 = ope.patch_embed_proj_bf16(x64, *W)
-    assert got64.shape == (6, 64, 8, 10) and (got64 - ref64).abs().max().item() <= 2e-3 * ref64.abs().max().item()
+    for operand in ("f16", "bf16"):
+        got64 = ops.cost_patch_embed(x64.to(gpu), ops.PatchEmbedWeights(*[w.to(gpu) for w in W], operand=operand)).cpu()
+        ref64 = _twin(operand)(x64, *W)
+        assert got64.shape == (6, 64, 8, 10) and (got64 - ref64).abs().max().item() <= TWIN_TOL[operand] * ref64.abs().max().item()
     assert not ops.cost_patch_embed_supported(90, 160)
     with pytest.raises(ops.L.MacvoHipError):
         ops.cost_patch_embed(torch.zeros(2, 1, 90, 160, device=gpu), ops.PatchEmbedWeights(*[w.to(gpu) for w in W]))
@@ -153,5 +171,5 @@ def test_flowformer_hook_rebinds_the_patch_embed_proj(gpu):
         got64 = m.memory_encoder.patch_embed(x64)
         want64 = m.memory_encoder.patch_embed.proj.layers(x64)
     assert got.shape == want.shape == (9, 64, 8, 10) and small.shape == (2, 64, 3, 4)
-    assert (got - want).abs().max().item() <= 2e-2 * want.abs().max().item()
-    assert (got64 - want64).abs().max().item() <= 2e-2 * want64.abs().max().item()
+    assert (got - want).abs().max().item() <= FP32_TOL["f16"] * want.abs().max().item()      # fp32 layers -> IEEE-half operands
+    assert (got64 - want64).abs().max().item() <= FP32_TOL["f16"] * want64.abs().max().item()

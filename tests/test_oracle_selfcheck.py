@@ -158,3 +158,5 @@ def test_patch_embed_oracle_matches_a_direct_convolution_and_its_bf16_twin_stays
     bf = ope.patch_embed_proj_bf16(x, *W)
     assert (bf - ref).abs().max() <= 2e-2 * ref.abs().max()
     assert (bf - ref).abs().max() > 0                 # it IS a different arithmetic
+    hf = ope.patch_embed_proj_f16(x, *W)
+    assert 0 < (hf - ref).abs().max() <= 2.5e-3 * ref.abs().max() and (hf - ref).abs().max() < (bf - ref).abs().max()

@@ -84,23 +84,24 @@ def main():
                 print("patch_embed: 640x480 only")
                 continue
             Wt = [t.to(dev) for t in ope.make_weights(0)]
-            pk = ops.PatchEmbedWeights(*Wt)
             volr = torch.randn(B * n, 1, h8, w8, device=dev) * 16
             outp = torch.empty((B * n, 80, 64), dtype=torch.float32, device=dev)
             fl = B * n * 2.0 * (1280 * 16 * 36 + 320 * 32 * 576 + 80 * 64 * 1152)
             byts = B * n * (h8 * w8 * 4 + 80 * 64 * 4.0)
-            for _ in range(5):
-                ops.cost_patch_embed(volr, pk, tokens=True, out=outp)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = max(3, a.iters // 5)
-            e0.record()
-            for _ in range(reps):
-                ops.cost_patch_embed(volr, pk, tokens=True, out=outp)
-            e1.record()
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / reps
-            print(f"cost_patch_embed S={B * n} {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s algorithmic = {fl / us / 1e6 / 2500 * 100:.1f}% of the bf16 MFMA peak; "
-                  f"HBM {byts / us / 1e3:.0f} GB/s ({byts / 1e6:.0f} MB)")
+            for operand in ("f16", "bf16"):
+                pk = ops.PatchEmbedWeights(*Wt, operand=operand)
+                for _ in range(5):
+                    ops.cost_patch_embed(volr, pk, tokens=True, out=outp)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = max(3, a.iters // 5)
+                e0.record()
+                for _ in range(reps):
+                    ops.cost_patch_embed(volr, pk, tokens=True, out=outp)
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / reps
+                print(f"cost_patch_embed<{operand}> S={B * n} {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s algorithmic = {fl / us / 1e6 / 2500 * 100:.1f}% of the 16-bit MFMA peak; "
+                      f"HBM {byts / us / 1e3:.0f} GB/s ({byts / 1e6:.0f} MB)")
             # the unfused form: the same three layers as PyTorch / MIOpen convolutions (bf16, channels_last), intermediates through HBM
             import torch.nn.functional as F
             xb = F.pad(volr, (0, 0, 0, 4)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
