@@ -300,6 +300,30 @@ def test_pgo_matches_oracle(gpu, graph):
         assert info[k, 0].item() == pytest.approx(ref.loss, rel=1e-8, abs=1e-12)
 
 
+@pytest.mark.parametrize("nprob_pad", [0, 520])
+@pytest.mark.parametrize("graph", ["disp", "reproj", "icp"])
+def test_pgo_kernel_equals_host_twin(gpu, graph, nprob_pad):
+    """mv_pgo_solve against tests/c_abi/pgo_twin.cpp — the same arithmetic header (csrc/pgo_math.h) and the same reduction trees
+    replayed lane by lane on the host: LM steps and reject counts equal, pose / loss equal to fp64 roundoff (the device's rsqrt is the
+    one operation the host rounds differently).  nprob_pad = 520 pushes the batch over the 512-problem switch to the one-wave
+    throughput variant (the twin follows with nw = 1)."""
+    from macvo_amd import ops
+    from oracle import pgo
+    from tests import pgo_twin
+
+    cases = [dict(n=200, seed=6), dict(n=200, seed=7, outlier_frac=0.1), dict(n=37, seed=8), dict(n=12, seed=9),
+             dict(n=500, seed=10, trans_sigma=0.4, rot_sigma=0.08), dict(n=64, seed=11, outlier_frac=0.3), dict(n=256, seed=1),
+             dict(n=150, seed=21, outlier_frac=0.2, trans_sigma=0.3, rot_sigma=0.05)]
+    probs = [pgo.make_synthetic_problem(**c)[0] for c in cases]
+    probs += [pgo.make_synthetic_problem(n=20 + (k % 7), seed=100 + k)[0] for k in range(nprob_pad)]
+    pose, info = ops.pgo_solve(_to_batch(probs, gpu), graph)
+    pose_t, info_t = pgo_twin.solve(_to_batch(probs, torch.device("cpu")), graph)
+    pose, info = pose.cpu(), info.cpu()
+    assert torch.equal(info[:, 1:3], info_t[:, 1:3]), (info[:8], info_t[:8])
+    torch.testing.assert_close(pose, pose_t, rtol=0, atol=1e-11)
+    torch.testing.assert_close(info[:, 0], info_t[:, 0], rtol=1e-11, atol=1e-13)
+
+
 def test_pgo_recovers_truth_noise_free(gpu):
     from macvo_amd import ops
     from oracle import pgo, se3
