@@ -47,6 +47,16 @@ namespace {
 
 using namespace pgo;
 
+// -DMV_PGO_STAMPS (profiles/probes/pgo_stamps.py builds its own copy of the library with it): s_memtime stamps of problem 0's first
+// 16 LM steps, 8 per step — build start | accumulate | reduction | clamp + damp + Cholesky | SE3 update | trial residual |
+// its reduction | trust region + accept — read back with mv_pgo_probe_stamps.
+#ifdef MV_PGO_STAMPS
+__device__ long long g_pgo_stamps[16 * 8];
+#define PGO_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && steps < 16) g_pgo_stamps[steps * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PGO_STAMP(i) ((void)0)
+#endif
+
 // ---- fp64 wavefront sum with DPP (all lanes must be active); result is wave-uniform -----------------------
 template <int CTRL>
 __device__ __forceinline__ double dpp_add(double v) {
@@ -206,6 +216,7 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
         PointLin lin;
         bool have_unw;     // A_u / g_u are in acc
         double loss_build;
+        PGO_STAMP(0);
         if (cached) {
             if (mine.valid) {
                 accumulate_point<GT, false>(g, lm, P, mine, acc, lin);
@@ -213,6 +224,7 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
 #pragma unroll
                 for (int k = 0; k < NLEAN; ++k) acc[k] = 0.0;
             }
+            PGO_STAMP(1);
             reduce_many<NLEAN, NW>(acc, red_tab, red_part, red_fin);
             loss_build = acc[NLEAN - 1];
             have_unw = false;
@@ -233,6 +245,7 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
         double* Au = acc + 27;
         const double* gu = acc + 48;
 
+        PGO_STAMP(2);
         if (!have_loss) { loss = loss_build; loss0 = loss_build; have_loss = true; }
         last = loss;
         reject_count = 0;
@@ -266,8 +279,10 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
                 for (int j = 0; j < 6; ++j) dg6[j] = Aw[tri(j, j)];
                 if (!chol_solve6(Aw, dg6, gw, D)) break;  // "Linear solver failed. Breaking optimization step..."
 
+                if (reject_count == 0) PGO_STAMP(3);
                 const double tp[3] = {P.t[0], P.t[1], P.t[2]}, qp[4] = {P.q[0], P.q[1], P.q[2], P.q[3]};
                 se3_left_update(P, D);
+                if (reject_count == 0) PGO_STAMP(4);
 
                 // loss at the trial pose (RobustModel.loss: unweighted, uncorrected) — and, for a step's first trial of the lean
                 // form, this point's term of the quality denominator
@@ -278,7 +293,9 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
                         lq[0] = point_loss<GT>(g, lm, P, mine.pw, mine.obs);
                         if (!have_unw) lq[1] = quality_point<GT>(lin, D);
                     }
+                    if (reject_count == 0) PGO_STAMP(5);
                     block_sum<2, NW>(lq, red_tab);
+                    if (reject_count == 0) PGO_STAMP(6);
                     loss = lq[0];
                     quality = have_unw ? tr_quality(D, gu, Au, last, loss) : (last - loss) / -lq[1];
                 } else {
@@ -384,6 +401,7 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
         }
 
         // ------------------------------------------------------------------ StopOnPlateau.step(loss)
+        PGO_STAMP(7);
         steps += 1;
         if (steps >= lm.max_steps) continual = false;
         if ((last - loss) < lm.decreasing) patience_count += 1; else patience_count = 0;
@@ -407,6 +425,12 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
 }
 
 }  // namespace
+
+#ifdef MV_PGO_STAMPS
+extern "C" int mv_pgo_probe_stamps(long long* host_out /* [128] */) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pgo_stamps), sizeof(long long) * 128) == hipSuccess ? MV_OK : MV_ERR_LAUNCH;
+}
+#endif
 
 extern "C" void mv_lm_default_params(mvLMParams* p) {
     if (!p) return;
