@@ -138,10 +138,46 @@ __device__ __forceinline__ void block_sum_wide(double* __restrict__ v /* [N] reg
     __syncthreads();   // `part` / `fin` are rewritten by the next pass
 }
 
-template <int N, int NW>
-__device__ __forceinline__ void reduce_many(double* __restrict__ v, double (*__restrict__ tab)[NRED], double* __restrict__ part,
-                                            double* __restrict__ fin) {
-    if constexpr (NW == 4) {
+// The lean build's reduction (round 4, second half).  In-kernel stamps of the form above on 28 values: 4.8 k cycles of a 13.1 k-cycle LM
+// step — three dependent DPP stages per value (2 v_mov_dpp + v_add_f64 each, with their wait states) are ~420 dependent instructions
+// for the single wave of a SIMD.  With at most 32 values there are enough threads to turn the job around: every thread stores its
+// N values (row k = value k of all 256 threads, rows padded by 64 B so that the 8 rows a wave reads from start 16 banks apart),
+// thread (k, p) = 8 k + p adds the 32 entries p, p + 8, p + 16, .. of row k (four independent accumulators), the 8 partial sums of a
+// row sit in one 8-lane group and take ONE three-stage DPP sum, lane p = 0 writes the total; every thread reads the N totals back.
+constexpr int RED_ROW = 256 + 8;    // doubles per row
+constexpr int RED_ROWS = 28;        // NLEAN (>= NUNW)
+template <int N>
+__device__ __forceinline__ void block_sum_lds(double* __restrict__ v /* [N] registers */, double* __restrict__ buf /* [N][RED_ROW] */,
+                                              double* __restrict__ fin /* [N] */) {
+    static_assert(N <= RED_ROWS && N * 8 <= 256, "one thread per (value, eighth)");
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < N; ++k) buf[k * RED_ROW + t] = v[k];
+    __syncthreads();
+    if (t < N * 8) {
+        const double* row = buf + (t >> 3) * RED_ROW + (t & 7);
+        double a0 = row[0], a1 = row[8], a2 = row[16], a3 = row[24];
+#pragma unroll
+        for (int i = 4; i < 32; i += 4) { a0 += row[8 * i]; a1 += row[8 * (i + 1)]; a2 += row[8 * (i + 2)]; a3 += row[8 * (i + 3)]; }
+        double s = (a0 + a1) + (a2 + a3);
+        s = dpp_add<0xB1>(s);    // quad_perm [1,0,3,2]
+        s = dpp_add<0x4E>(s);    // quad_perm [2,3,0,1]
+        s = dpp_add<0x141>(s);   // row_half_mirror: the other quad of the 8-lane group (whole groups are active: N * 8 threads)
+        if ((t & 7) == 0) fin[t >> 3] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = fin[k];
+    __syncthreads();   // `buf` / `fin` are rewritten by the next pass
+}
+
+// LEAN: the one-point-per-thread passes (28 / 27 values) of the 4-wave variant go through block_sum_lds
+template <int N, int NW, bool LEAN>
+__device__ __forceinline__ void reduce_many(double* __restrict__ v, double* __restrict__ part, double* __restrict__ fin,
+                                            double* __restrict__ lds_rows) {
+    if constexpr (NW == 4 && LEAN) {
+        block_sum_lds<N>(v, lds_rows, fin);
+    } else if constexpr (NW == 4) {
         block_sum_wide<N>(v, part, fin);
     } else {
 #pragma unroll
@@ -153,14 +189,16 @@ template <int GT, int NW>
 __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParams lm) {
     constexpr int PGO_THREADS = 64 * NW;
     __shared__ double red_tab[NW][NRED];
-    __shared__ __attribute__((aligned(16))) double red_part[NW == 4 ? NRED * NW * 8 : 1];
     __shared__ __attribute__((aligned(16))) double red_fin[NW == 4 ? NRED + 1 : 1];
+    __shared__ __attribute__((aligned(16))) double red_rows[NW == 4 ? RED_ROWS * RED_ROW : 1];   // 59 KB (75 KB in all: two workgroups per CU still fit)
+    double* const red_part = red_rows;   // the 55-value form's [NRED][32] partials: a workgroup runs one form or the other
+    static_assert(NRED * 32 <= RED_ROWS * RED_ROW, "red_part aliases red_rows");
     // speculative reject rounds (NW == 4, one point per thread): every point's position / observation for the trial-loss passes, and
     // what each wave found for its trial
     constexpr int SPEC = (NW == 4) ? 1 : 0;
     __shared__ double pt_tab[SPEC ? 6 : 1][SPEC ? 64 * NW : 1];
     __shared__ int pt_valid[SPEC ? 64 * NW : 1];
-    __shared__ double spec_res[SPEC ? NW : 1][10];   // per wave: ok, loss, quality, pose t[3] q[4]
+    __shared__ double spec_res[SPEC ? NW : 1][13];   // per wave: ok, loss, quality, pose t[3] q[4], then the trust region BEHIND its trial: damping, tr_down, branch
     const int prob = blockIdx.x;
     const int tid = threadIdx.x;
     const int beg = a.offsets[prob], end = a.offsets[prob + 1];
@@ -225,8 +263,9 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
                 for (int k = 0; k < NLEAN; ++k) acc[k] = 0.0;
             }
             PGO_STAMP(1);
-            reduce_many<NLEAN, NW>(acc, red_tab, red_part, red_fin);
+            reduce_many<NLEAN, NW, true>(acc, red_part, red_fin, red_rows);
             loss_build = acc[NLEAN - 1];
+            asm volatile("" : "+v"(loss_build));   // (keeps hipcc from merging the two branches' loads into one load through a pointer phi: that put acc[27] and acc[54] into scratch memory)
             have_unw = false;
         } else {
 #pragma unroll
@@ -236,8 +275,9 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
                 load_point<GT>(a, g, lm, i, true, d);
                 if (d.valid) accumulate_point<GT, true>(g, lm, P, d, acc, lin);
             }
-            reduce_many<NRED, NW>(acc, red_tab, red_part, red_fin);
+            reduce_many<NRED, NW, false>(acc, red_part, red_fin, red_rows);
             loss_build = acc[NRED - 1];
+            asm volatile("" : "+v"(loss_build));
             have_unw = true;
         }
         double* Aw = acc;
@@ -325,7 +365,7 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
 #pragma unroll
                             for (int k = 0; k < NUNW; ++k) u[k] = 0.0;
                         }
-                        reduce_many<NUNW, NW>(u, red_tab, red_part, red_fin);
+                        reduce_many<NUNW, NW, true>(u, red_part, red_fin, red_rows);
 #pragma unroll
                         for (int k = 0; k < NUNW; ++k) Au[k] = u[k];
                         have_unw = true;
@@ -367,11 +407,17 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
                     for (int c = 1; c < NW; ++c) loss_w += part[c];
                     quality_w = tr_quality(D, gu, Au, last, loss_w);
                 }
+                // the trust-region update BEHIND this trial, from the replayed state: it IS the true one whenever the walk below gets as
+                // far as this trial (every earlier trial of the round rejected through the predicted branch), so the walk reads it instead
+                // of redoing four dependent updates (two fp64 divisions each) one after the other
+                int branch_w = 0;
+                if (ok) branch_w = tr_update(lm, quality_w, damp_s, trd_s);
                 if (lane == 0) {
                     double* o = spec_res[wv];
                     o[0] = ok ? 1.0 : 0.0; o[1] = loss_w; o[2] = quality_w;
                     o[3] = Pw.t[0]; o[4] = Pw.t[1]; o[5] = Pw.t[2];
                     o[6] = Pw.q[0]; o[7] = Pw.q[1]; o[8] = Pw.q[2]; o[9] = Pw.q[3];
+                    o[10] = damp_s; o[11] = trd_s; o[12] = (double)branch_w;
                 }
                 __syncthreads();
                 // ---- the sequential form's bookkeeping over the four results
@@ -382,7 +428,8 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
                     const double* o = spec_res[i];
                     if (o[0] == 0.0) { leave = true; break; }       // "Linear solver failed"
                     loss = o[1];
-                    const int branch = tr_update(lm, o[2], damping, tr_down);
+                    damping = o[10]; tr_down = o[11];
+                    const int branch = (int)o[12];
                     if (last < loss && reject_count < lm.reject) {   // reject step
                         loss = last;
                         reject_count += 1;

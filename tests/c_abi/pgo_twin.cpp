@@ -40,9 +40,23 @@ double block_sum1(const double* v /* [64 nw] */, int nw) {
     for (int w = 1; w < nw; ++w) s += wave_sum_dpp(v + 64 * w);
     return s;
 }
-// reduce_many: nw == 4 -> block_sum_wide (8-lane partials, 32 of them added by one thread with four accumulators); nw == 1 -> DPP only
-double reduce_many1(const double* v, int nw) {
+// reduce_many: nw == 1 -> DPP only; nw == 4, lean (one point per thread) -> block_sum_lds: thread (k, p) adds entries p, p + 8, .. of
+// the 256 with four accumulators, the 8 partial sums take the three-stage DPP tree; nw == 4 otherwise -> block_sum_wide (8-lane DPP
+// partials, 32 of them added by one thread with four accumulators)
+double reduce_many1(const double* v, int nw, bool lean) {
     if (nw != 4) return wave_sum_dpp(v);
+    if (lean) {
+        double s[8];
+        for (int p = 0; p < 8; ++p) {
+            double a0 = v[p], a1 = v[p + 8], a2 = v[p + 16], a3 = v[p + 24];
+            for (int i = 4; i < 32; i += 4) { a0 += v[p + 8 * i]; a1 += v[p + 8 * (i + 1)]; a2 += v[p + 8 * (i + 2)]; a3 += v[p + 8 * (i + 3)]; }
+            s[p] = (a0 + a1) + (a2 + a3);
+        }
+        double x1[8], x2[8];
+        for (int i = 0; i < 8; ++i) x1[i] = s[i] + s[i ^ 1];
+        for (int i = 0; i < 8; ++i) x2[i] = x1[i] + x1[i ^ 2];
+        return x2[0] + x2[7];
+    }
     double part[32];
     for (int w = 0; w < 4; ++w) {
         double s3[64];
@@ -119,7 +133,7 @@ void solve_one(const PgoArgs& a, const mvLMParams& lm, int prob, int nw) {
         }
         for (int k = 0; k < n_build; ++k) {
             for (int t = 0; t < T; ++t) col[t] = per[(size_t)t * NRED + k];
-            acc[k] = reduce_many1(col.data(), nw);
+            acc[k] = reduce_many1(col.data(), nw, cached);
         }
         loss_build = acc[n_build - 1];
         have_unw = !cached;
@@ -181,7 +195,7 @@ void solve_one(const PgoArgs& a, const mvLMParams& lm, int prob, int nw) {
                             if (mine[t].valid) unweighted_point<GT>(lin[t], &u[(size_t)t * NUNW]);
                         for (int k = 0; k < NUNW; ++k) {
                             for (int t = 0; t < T; ++t) col[t] = u[(size_t)t * NUNW + k];
-                            Au[k] = reduce_many1(col.data(), nw);
+                            Au[k] = reduce_many1(col.data(), nw, true);
                         }
                         have_unw = true;
                     }
@@ -189,7 +203,7 @@ void solve_one(const PgoArgs& a, const mvLMParams& lm, int prob, int nw) {
                     break;
                 }
             } else {
-                double res[4][10];
+                double res[4][13];
                 for (int wv = 0; wv < 4; ++wv) {
                     double dg6[6], damp_s = damping, trd_s = tr_down;
                     for (int j = 0; j < 6; ++j) dg6[j] = Aw[tri(j, j)];
@@ -216,10 +230,13 @@ void solve_one(const PgoArgs& a, const mvLMParams& lm, int prob, int nw) {
                         for (int c = 1; c < 4; ++c) loss_w += part[c];
                         quality_w = tr_quality(D, gu, Au, last, loss_w);
                     }
+                    int branch_w = 0;
+                    if (ok) branch_w = tr_update(lm, quality_w, damp_s, trd_s);
                     double* o = res[wv];
                     o[0] = ok ? 1.0 : 0.0; o[1] = loss_w; o[2] = quality_w;
                     o[3] = Pw.t[0]; o[4] = Pw.t[1]; o[5] = Pw.t[2];
                     o[6] = Pw.q[0]; o[7] = Pw.q[1]; o[8] = Pw.q[2]; o[9] = Pw.q[3];
+                    o[10] = damp_s; o[11] = trd_s; o[12] = (double)branch_w;
                 }
                 bool leave = false;
                 for (int i = 0; i < 4; ++i) {
@@ -227,7 +244,8 @@ void solve_one(const PgoArgs& a, const mvLMParams& lm, int prob, int nw) {
                     const double* o = res[i];
                     if (o[0] == 0.0) { leave = true; break; }
                     loss = o[1];
-                    const int branch = tr_update(lm, o[2], damping, tr_down);
+                    damping = o[10]; tr_down = o[11];
+                    const int branch = (int)o[12];
                     if (last < loss && reject_count < lm.reject) {
                         loss = last;
                         reject_count += 1;
