@@ -53,8 +53,12 @@ using namespace pgo;
 #ifdef MV_PGO_STAMPS
 __device__ long long g_pgo_stamps[16 * 8];
 #define PGO_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && steps < 16) g_pgo_stamps[steps * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// ... and of the first two speculative reject rounds (rows 14, 15; wave 3 = the wave with the longest replay): round start | replay |
+// Cholesky | SE3 update | four 64-point loss passes | quality + trust region + hand-over | walk
+#define PGO_RSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 192 && dbg_rounds >= 1 && dbg_rounds <= 2) g_pgo_stamps[(13 + dbg_rounds) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PGO_STAMP(i) ((void)0)
+#define PGO_RSTAMP(i) ((void)0)
 #endif
 
 // ---- fp64 wavefront sum with DPP (all lanes must be active); result is wave-uniform -----------------------
@@ -337,7 +341,14 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
                     block_sum<2, NW>(lq, red_tab);
                     if (reject_count == 0) PGO_STAMP(6);
                     loss = lq[0];
-                    quality = have_unw ? tr_quality(D, gu, Au, last, loss) : (last - loss) / -lq[1];
+                    if (have_unw) {
+                        double Dq[6];   // (opaque for the same reason: the 42-MAC quadratic form was evaluated — and discarded — in every step)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) { Dq[j] = D[j]; asm volatile("" : "+v"(Dq[j])); }
+                        quality = tr_quality(Dq, gu, Au, last, loss);
+                    } else {
+                        quality = (last - loss) / -lq[1];
+                    }
                 } else {
                     double la[1] = {0.0};
                     for (int i = beg + tid; i < end; i += PGO_THREADS) {
@@ -360,6 +371,9 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
                     if (!have_unw) {   // the step's later trials are scored against the reduced unweighted pair
                         double u[NUNW];
                         if (mine.valid) {
+                            // (opaque: without it hipcc SPECULATES these 99 fp64 operations — they have no side effects — into every LM
+                            // step in front of the Cholesky and selects the results away: seen in the ISA and in the stamps, 1.4 k cycles per step)
+                            asm volatile("" : "+v"(lin.s2));
                             unweighted_point<GT>(lin, u);
                         } else {
 #pragma unroll
@@ -375,6 +389,7 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
                 }
             } else {
                 const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+                PGO_RSTAMP(0);
                 // ---- this wave's trial: the (wv + 1)-th from here, assuming the wv before it are rejected through the predicted branch
                 double dg6[6], damp_s = damping, trd_s = tr_down;
 #pragma unroll
@@ -384,12 +399,15 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
                     for (int j = 0; j < 6; ++j) dg6[j] = fma(dg6[j], damp_s, dg6[j]);
                     if (i < wv) tr_apply(lm, pred_branch, damp_s, trd_s);
                 }
+                PGO_RSTAMP(1);
                 double D[6];
                 const bool ok = chol_solve6(Aw, dg6, gw, D);
+                PGO_RSTAMP(2);
                 Pose Pw = P;
                 double loss_w = 0.0, quality_w = 0.0;
                 if (ok) {
                     se3_left_update(Pw, D);
+                    PGO_RSTAMP(3);
                     double part[NW];
 #pragma unroll
                     for (int c = 0; c < NW; ++c) {
@@ -405,6 +423,7 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
                     loss_w = part[0];
 #pragma unroll
                     for (int c = 1; c < NW; ++c) loss_w += part[c];
+                    PGO_RSTAMP(4);
                     quality_w = tr_quality(D, gu, Au, last, loss_w);
                 }
                 // the trust-region update BEHIND this trial, from the replayed state: it IS the true one whenever the walk below gets as
@@ -420,21 +439,29 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
                     o[10] = damp_s; o[11] = trd_s; o[12] = (double)branch_w;
                 }
                 __syncthreads();
+                PGO_RSTAMP(5);
                 // ---- the sequential form's bookkeeping over the four results
                 bool leave = false;
+                double w_ok[NW], w_loss[NW], w_damp[NW], w_trd[NW], w_br[NW];   // all four results up front: one LDS round trip, not one per trial
+#pragma unroll
+                for (int i = 0; i < NW; ++i) {
+                    const double* o = spec_res[i];
+                    w_ok[i] = o[0]; w_loss[i] = o[1]; w_damp[i] = o[10]; w_trd[i] = o[11]; w_br[i] = o[12];
+                }
+#pragma unroll
                 for (int i = 0; i < NW; ++i) {
 #pragma unroll
                     for (int j = 0; j < 6; ++j) Aw[tri(j, j)] = fma(Aw[tri(j, j)], damping, Aw[tri(j, j)]);
-                    const double* o = spec_res[i];
-                    if (o[0] == 0.0) { leave = true; break; }       // "Linear solver failed"
-                    loss = o[1];
-                    damping = o[10]; tr_down = o[11];
-                    const int branch = (int)o[12];
+                    if (w_ok[i] == 0.0) { leave = true; break; }       // "Linear solver failed"
+                    loss = w_loss[i];
+                    damping = w_damp[i]; tr_down = w_trd[i];
+                    const int branch = (int)w_br[i];
                     if (last < loss && reject_count < lm.reject) {   // reject step
                         loss = last;
                         reject_count += 1;
                         if (branch != pred_branch) { pred_branch = branch; break; }   // the later trials of this round started from other inputs
                     } else {
+                        const double* o = spec_res[i];
                         P.t[0] = o[3]; P.t[1] = o[4]; P.t[2] = o[5];
                         P.q[0] = o[6]; P.q[1] = o[7]; P.q[2] = o[8]; P.q[3] = o[9];
                         pose_finish(P);
@@ -443,6 +470,7 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
                     }
                 }
                 __syncthreads();   // spec_res is rewritten by the next round
+                PGO_RSTAMP(6);
                 if (leave) break;
             }
         }

@@ -21,3 +21,8 @@ names = ["accumulate", "reduction (28 / 55 values)", "clamp+damp+cholesky", "se3
 for k in range(int(info[0, 1].item())):
     r = st[k]
     print(f"step {k}: " + " | ".join(f"{names[i]} {r[i+1]-r[i]}" for i in range(7)) + f" | total {r[7]-r[0]}" + (f" | to next {st[k+1][0]-r[7]}" if k + 1 < 16 and st[k+1][0] else ""))
+rn = ["replay", "cholesky", "se3", "four 64-point loss passes", "quality + TR + hand-over", "walk"]
+for k in (14, 15):
+    r = st[k]
+    if r[0]:
+        print(f"reject round {k - 13} (wave 3): " + " | ".join(f"{rn[i]} {r[i+1]-r[i]}" for i in range(6)) + f" | total {r[6]-r[0]}")
