@@ -37,12 +37,6 @@
 #include "pgo_math.h"
 #include <stdlib.h>
 
-int mv_pgo_solve_v1_cxx(int nprob, const int32_t* offsets, int graph_type, const float* init_pose, const float* intrinsics,
-                        const float* baseline, const float* pos_Tw, const double* cov_Tw, const float* pixel2_uv, const float* pixel2_d,
-                        const float* pixel2_disp, const float* pixel2_disp_cov, const float* pixel2_uv_cov, const double* obs2_covTc,
-                        const uint8_t* valid, int min_points, const mvLMParams* params, double* out_pose, double* out_info,
-                        float* out_pose_f32, mvStream_t stream);
-
 namespace {
 
 using namespace pgo;
@@ -529,14 +523,6 @@ extern "C" int mv_pgo_solve(int nprob, const int32_t* offsets, int graph_type, c
     if (nprob == 0) return MV_OK;
     MV_CHECK_ARG(offsets && init_pose && intrinsics && baseline && pos_Tw && pixel2_uv && out_pose && out_info);
     MV_CHECK_ARG(params->max_steps >= 1 && params->reject >= 0 && params->stop_on_reject >= 0 && params->radius > 0 && params->huber_delta > 0);
-    {
-        static int v1 = -1;     // MV_PGO_V1=1: the round-3 kernel (A/B)
-        if (v1 < 0) { const char* e = getenv("MV_PGO_V1"); v1 = (e && atoi(e) != 0) ? 1 : 0; }
-        if (v1)
-            return mv_pgo_solve_v1_cxx(nprob, offsets, graph_type, init_pose, intrinsics, baseline, pos_Tw, cov_Tw, pixel2_uv, pixel2_d,
-                                       pixel2_disp, pixel2_disp_cov, pixel2_uv_cov, obs2_covTc, valid, min_points, params, out_pose,
-                                       out_info, out_pose_f32, stream);
-    }
     PgoArgs a{offsets, init_pose, intrinsics, baseline, pos_Tw, cov_Tw, pixel2_uv, pixel2_d, pixel2_disp,
               pixel2_disp_cov, pixel2_uv_cov, obs2_covTc, valid, min_points, out_pose, out_info, out_pose_f32, 1};
     {

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (history: ran at commit 5f0b... when the round-3 kernel was still selectable with MV_PGO_V1=1; that knob is gone)
 # Round-4 PGO kernel (explicit FMAs + lean build): parity tests, kernel == host twin, per-phase stamps, alone-times and the bench line against the
 # round-3 kernel (MV_PGO_V1=1).
 cd $GRAFT_REPO_ROOT
