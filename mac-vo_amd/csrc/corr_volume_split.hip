@@ -771,20 +771,26 @@ extern "C" int mv_corr_volume_packed(const void* packed1, const void* packed2, f
     static int wgs_env = -1;
     if (wgs_env < 0) { const char* e = getenv("MV_SPLIT_WGS"); wgs_env = e ? atoi(e) : 0; }
     const dim3 g((wgs_env >= 8 && wgs_env <= cu_count() ? wgs_env : cu_count()) & ~7);
+    // MV_SPLIT_LDS_KB=<n>: the workgroups claim n KB of LDS (more than the ring needs): no other workgroup that uses LDS — lookups, selector,
+    // covariance, solve — can then be placed on a CU that runs a GEMM workgroup, i.e. together with MV_SPLIT_WGS the small kernels get the
+    // remaining CUs to themselves without CU-masked queues (A/B knob)
+    static int lds_kb = -1;
+    if (lds_kb < 0) { const char* e = getenv("MV_SPLIT_LDS_KB"); lds_kb = e ? atoi(e) : 0; if (lds_kb > 160) lds_kb = 160; }
+    auto lds_bytes = [&](size_t need) { return std::max(need, (size_t)lds_kb * 1024); };
     if (mode == MV_PACK_BF16X3) {
         using K = SplitCfg<3, false, 16, 4>;
         mv_note_volume_kernel("corr_volume_split_stream<bf16x3>");
-        hipLaunchKernelGGL((corr_volume_split_stream<3, false, 16, 4>), g, dim3(256), K::NSLOT * K::SLOT_BYTES, (hipStream_t)stream,
+        hipLaunchKernelGGL((corr_volume_split_stream<3, false, 16, 4>), g, dim3(256), lds_bytes(K::NSLOT * K::SLOT_BYTES), (hipStream_t)stream,
                            (const uint16_t*)packed1, (const uint16_t*)packed2, out, N1, N2, B, R);
     } else if (waves == 4) {
         using K = SplitCfg<2, true, 16, 4>;
         mv_note_volume_kernel("corr_volume_split_stream<f16x2>");
-        hipLaunchKernelGGL((corr_volume_split_stream<2, true, 16, 4>), g, dim3(256), K::NSLOT * K::SLOT_BYTES, (hipStream_t)stream,
+        hipLaunchKernelGGL((corr_volume_split_stream<2, true, 16, 4>), g, dim3(256), lds_bytes(K::NSLOT * K::SLOT_BYTES), (hipStream_t)stream,
                            (const uint16_t*)packed1, (const uint16_t*)packed2, out, N1, N2, B, R);
     } else {
         using K = SplitCfg<2, true, 16, 8>;
         mv_note_volume_kernel("corr_volume_split_stream<f16x2>");
-        hipLaunchKernelGGL((corr_volume_split_stream<2, true, 16, 8>), g, dim3(512), K::NSLOT * K::SLOT_BYTES, (hipStream_t)stream,
+        hipLaunchKernelGGL((corr_volume_split_stream<2, true, 16, 8>), g, dim3(512), lds_bytes(K::NSLOT * K::SLOT_BYTES), (hipStream_t)stream,
                            (const uint16_t*)packed1, (const uint16_t*)packed2, out, N1, N2, B, R);
     }
     return mv_launch_status();
