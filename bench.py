@@ -20,6 +20,8 @@ Besides the contract's fields the JSON line carries
   config4       a short second measurement at BASELINE configs[4] (32 lanes, B = 64 pairs per GEMM), N = 1 only
   decoder_loop  the HIP lookups / upsamplings interleaved with the PyTorch-ROCm kernels of a stand-in decoder network
                 (tools/decoder_harness.py, loop structure of covhead.py:85-135) next to the back-to-back figure, N = 1 only
+  end_to_end    images -> poses through the reference's own MACVO loop with a FlowFormerCov-shaped network (random weights, PyTorch-ROCm) as
+                the learned frontend and the HIP plugins behind it, hooked vs unhooked (tools/end_to_end.py in a fresh interpreter), N = 1 only
 """
 from __future__ import annotations
 
@@ -81,6 +83,8 @@ def parse_args():
                     help="host-side frame sequencing: the C++ driver (mv_frame_pipe_*) or the Python loop over the per-op entry points")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events around the volume kernel")
     ap.add_argument("--no-ramp", action="store_true", help="skip the untimed clock-ramp phase")
+    ap.add_argument("--end-to-end-frames", type=int, default=32, help="frames of the end_to_end leg (network included, reference's MACVO loop; the first "
+                    "quarter is warm-up); 0 = skip")
     ap.add_argument("--no-decoder-leg", action="store_true", help="skip the decoder-loop harness leg (HIP lookups / upsamplings interleaved with PyTorch-ROCm kernels)")
     ap.add_argument("--dry-collectives", action="store_true",
                     help="CPU-only plumbing check of the N-rank launch path: gloo backend, no kernels, synthetic tracks through the "
@@ -252,6 +256,18 @@ def reference_loop_leg(cam, cfr, n_frames, cores, graph):
     kps = [r["map/match//pixel1_uv"][int(rng[t, 0, 0]): int(rng[t, 0, 0]) + int(rng[t, 0, 1])] for t in range(1, n_frames)]
     return {"s_per_run_pair": float(fs[2:].mean()), "frames": int(n_frames), "kps": kps, "poses": r["map/frames//pose"],
             "graph": graph}
+
+
+def end_to_end_leg(n_frames: int):
+    """tools/end_to_end.py in a fresh interpreter (the reference's tree is imported there on shims): images -> poses, learned frontend included."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "end_to_end.py"), "--frames", str(n_frames), "--warmup", str(max(3, n_frames // 4))]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    for ln in reversed(p.stdout.splitlines()):
+        if ln.startswith('{"end_to_end"'):
+            return json.loads(ln)["end_to_end"]
+    return {"error": (p.stdout[-300:] + p.stderr[-700:])}
 
 
 def pin_rank_cores(local_rank: int, local_world: int) -> list:
@@ -777,6 +793,12 @@ def main():
             patch_embed = patch_embed_leg(ops, ops.corr_volume(frames[0].fmap1, frames[0].fmap2, layout=args.layout), dev)
         except Exception as e:  # noqa: BLE001 - a measurement leg must not take the benchmark line down
             patch_embed = {"error": repr(e)[:300]}
+    end_to_end = None
+    if rank == 0 and world == 1 and args.end_to_end_frames > 0 and args.lanes == 1 and (H, W) == (480, 640) and not args.no_cpu_baseline:
+        try:
+            end_to_end = end_to_end_leg(args.end_to_end_frames)
+        except Exception as e:  # noqa: BLE001 - a measurement leg must not take the benchmark line down
+            end_to_end = {"error": repr(e)[:300]}
     ranks_seen, rank_devices = 1, [torch.cuda.current_device()]
     if dist is not None:
         ranks_seen = dist.get_world_size()
@@ -828,6 +850,7 @@ def main():
             "config4": config4,
             "decoder_loop": decoder_loop,
             "patch_embed": patch_embed,
+            "end_to_end": end_to_end,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
