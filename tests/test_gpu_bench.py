@@ -13,7 +13,7 @@ import pytest
 from tests import refrun
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-QUICK = ["--no-ramp", "--exact-steps", "0", "--config4-steps", "0", "--no-decoder-leg", "--pool", "6"]
+QUICK = ["--no-ramp", "--exact-steps", "0", "--config4-steps", "0", "--no-decoder-leg", "--pool", "6", "--end-to-end-frames", "0"]
 
 
 def _line(p):
