@@ -561,7 +561,7 @@ def install_flowformer_hooks(model, volume_precision: str | None = None) -> list
     # `proj` (three 6x6 stride-2 convolutions) eats the whole volume slice by slice: rebind `proj` to the fused kernel for the slice sizes it
     # covers (640x480 frames); any other size falls through to the original layers.
     pe, pe_name = None, ""
-    if enc is not None:      # public FlowFormer: memory_encoder.cost_perceiver_encoder.patch_embed; accept it directly under the encoder too
+    if enc is not None and hasattr(enc, "named_modules"):      # public FlowFormer: memory_encoder.cost_perceiver_encoder.patch_embed; accept it directly under the encoder too
         for name, mod in enc.named_modules():
             if (name == "patch_embed" or name.endswith(".patch_embed")) and isinstance(getattr(mod, "proj", None), torch.nn.Sequential):
                 pe, pe_name = mod, name

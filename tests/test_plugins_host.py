@@ -74,3 +74,33 @@ def test_frontend_plugin_registers_and_explains_missing_network():
         plugins.HIP_FlowFormerCovFrontend.is_valid_config(SimpleNamespace(**{**vars(good), "device": "cpu"}))
     with pytest.raises(ImportError, match="S_FlowFormer"):
         plugins.HIP_FlowFormerCovFrontend(good)      # FlowFormer source is an empty submodule in the reference checkout
+
+
+def test_install_flowformer_hooks_on_plain_stand_ins_and_on_the_host_network():
+    """The hook installer walks whatever it is given: a plain object carrying only ``memory_encoder.corr`` (no ``nn.Module`` API — the form
+    tests/test_gpu_fastmode.py uses) gets that one method rebound; the FlowFormerCov-shaped host network gets all four, with the cost patch
+    embedding found under ``memory_encoder.cost_perceiver_encoder`` (on a CPU model the weight pack is refused and ``proj`` stays as it is).
+    Binding is lazy: nothing here touches a GPU."""
+    import os
+    import sys
+    from types import SimpleNamespace as NS
+
+    import torch
+
+    from macvo_amd import plugins
+
+    class Enc:
+        cfg = NS(cost_heads_num=1)
+
+        def corr(self, a, b):
+            raise AssertionError("not rebound")
+
+    assert plugins.install_flowformer_hooks(NS(memory_encoder=Enc())) == ["memory_encoder.corr"]
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import flowformer_host as fh
+
+    torch.manual_seed(0)
+    m = fh.FlowFormerCovHost(fh.demo_cfg(decoder_depth=1)).eval()
+    names = plugins.install_flowformer_hooks(m)
+    assert names[:3] == ["memory_decoder.encode_flow_token", "memory_decoder.upsample_flow", "memory_encoder.corr"]
+    assert isinstance(m.memory_encoder.cost_perceiver_encoder.patch_embed.proj, torch.nn.Sequential)      # CPU weights: not packed, not rebound
