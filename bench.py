@@ -83,7 +83,7 @@ def parse_args():
                     help="host-side frame sequencing: the C++ driver (mv_frame_pipe_*) or the Python loop over the per-op entry points")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events around the volume kernel")
     ap.add_argument("--no-ramp", action="store_true", help="skip the untimed clock-ramp phase")
-    ap.add_argument("--end-to-end-frames", type=int, default=32, help="frames of the end_to_end leg (network included, reference's MACVO loop; the first "
+    ap.add_argument("--end-to-end-frames", type=int, default=40, help="frames of the end_to_end leg (network included, reference's MACVO loop; the first "
                     "quarter is warm-up); 0 = skip")
     ap.add_argument("--no-decoder-leg", action="store_true", help="skip the decoder-loop harness leg (HIP lookups / upsamplings interleaved with PyTorch-ROCm kernels)")
     ap.add_argument("--dry-collectives", action="store_true",
