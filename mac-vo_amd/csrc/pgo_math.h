@@ -59,6 +59,13 @@ struct Geometry {
     double fx, fy, cx, cy, blfx;
 };
 
+// 1: a step's first trial of the lean form BUILDS at the trial pose (28 values + the quality term in one reduction) instead of summing only its
+// loss: an accepted trial — every step but a solve's last, in practice — then already is the next step's build pass.  0: the trial sums its loss
+// and quality term alone and every step builds afresh (A/B; pgo_solve.hip and the host twin follow the same switch).
+#ifndef MV_PGO_FUSED_BUILD
+#define MV_PGO_FUSED_BUILD 1
+#endif
+
 constexpr int NRED = 55;    // full build: A_w 21 + g_w 6 + A_u 21 + g_u 6 + loss 1
 constexpr int NLEAN = 28;   // lean build: A_w 21 + g_w 6 + loss 1
 constexpr int NUNW = 27;    // the unweighted pair A_u 21 + g_u 6 on its own (first rejection of a step)

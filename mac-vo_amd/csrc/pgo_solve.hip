@@ -143,7 +143,7 @@ __device__ __forceinline__ void block_sum_wide(double* __restrict__ v /* [N] reg
 // thread (k, p) = 8 k + p adds the 32 entries p, p + 8, p + 16, .. of row k (four independent accumulators), the 8 partial sums of a
 // row sit in one 8-lane group and take ONE three-stage DPP sum, lane p = 0 writes the total; every thread reads the N totals back.
 constexpr int RED_ROW = 256 + 8;    // doubles per row
-constexpr int RED_ROWS = 28;        // NLEAN (>= NUNW)
+constexpr int RED_ROWS = NLEAN + 1;   // the lean build + the quality term of a fused first trial (>= NUNW)
 template <int N>
 __device__ __forceinline__ void block_sum_lds(double* __restrict__ v /* [N] registers */, double* __restrict__ buf /* [N][RED_ROW] */,
                                               double* __restrict__ fin /* [N] */) {
@@ -244,16 +244,20 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
         if ((int)nv[0] < a.min_points) continual = false;
     }
 
+    // acc: [0, 21) A_w, [21, 27) g_w, then  lean: [27] loss            (A_u, g_u written to [27, 54) on a step's first rejection)
+    //                                        full: [27, 48) A_u, [48, 54) g_u, [54] loss
+    double acc[NRED];
+    PointLin lin;
+    bool have_build = false;   // acc / lin already describe P: the previous step's accepted first trial was built there (MV_PGO_FUSED_BUILD)
     while (continual) {
         // ------------------------------------------------------------------ build pass
-        // acc: [0, 21) A_w, [21, 27) g_w, then  lean: [27] loss            (A_u, g_u written to [27, 54) on a step's first rejection)
-        //                                        full: [27, 48) A_u, [48, 54) g_u, [54] loss
-        double acc[NRED];
-        PointLin lin;
-        bool have_unw;     // A_u / g_u are in acc
-        double loss_build;
+        bool have_unw = !cached;     // A_u / g_u are in acc
+        double loss_build = 0.0;
+        bool built_next = false;
         PGO_STAMP(0);
-        if (cached) {
+        if (have_build) {
+            PGO_STAMP(1);   // (the previous step's accepted trial was this build)
+        } else if (cached) {
             if (mine.valid) {
                 accumulate_point<GT, false>(g, lm, P, mine, acc, lin);
             } else {
@@ -264,7 +268,6 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
             reduce_many<NLEAN, NW, true>(acc, red_part, red_fin, red_rows);
             loss_build = acc[NLEAN - 1];
             asm volatile("" : "+v"(loss_build));   // (keeps hipcc from merging the two branches' loads into one load through a pointer phi: that put acc[27] and acc[54] into scratch memory)
-            have_unw = false;
         } else {
 #pragma unroll
             for (int k = 0; k < NRED; ++k) acc[k] = 0.0;
@@ -276,7 +279,6 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
             reduce_many<NRED, NW, false>(acc, red_part, red_fin, red_rows);
             loss_build = acc[NRED - 1];
             asm volatile("" : "+v"(loss_build));
-            have_unw = true;
         }
         double* Aw = acc;
         const double* gw = acc + 21;
@@ -325,7 +327,31 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
                 // loss at the trial pose (RobustModel.loss: unweighted, uncorrected) — and, for a step's first trial of the lean
                 // form, this point's term of the quality denominator
                 double quality;
-                if (cached) {
+                if (MV_PGO_FUSED_BUILD && cached && !have_unw) {
+                    // a step's first trial, lean form: the BUILD at the trial pose.  Its 28th value is the trial loss, the 29th this point's
+                    // term of the quality denominator (from the J, r the previous build kept); if the trial is accepted — every step but a
+                    // solve's last, in practice — these sums and `nlin` already are the next step's build pass.
+                    // `lin` is overwritten in place (two PointLin per thread next to both sets of sums spilled registers): its last use on
+                    // the accepted path is the quality term; a REJECTED first trial recomputes it at the restored pose (same bits, once per solve).
+                    double nacc[NLEAN + 1];
+                    if (mine.valid) {
+                        nacc[NLEAN] = quality_point<GT>(lin, D);
+                        accumulate_point<GT, false>(g, lm, P, mine, nacc, lin);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < NLEAN + 1; ++k) nacc[k] = 0.0;
+                    }
+                    PGO_STAMP(5);
+                    reduce_many<NLEAN + 1, NW, true>(nacc, red_part, red_fin, red_rows);
+                    PGO_STAMP(6);
+                    loss = nacc[NLEAN - 1];
+                    quality = (last - loss) / -nacc[NLEAN];
+                    if (!(last < loss && reject_count < lm.reject)) {   // accepted (decided again below, on the same values): keep the build
+#pragma unroll
+                        for (int k = 0; k < NLEAN; ++k) acc[k] = nacc[k];
+                        built_next = true;
+                    }
+                } else if (cached) {
                     double lq[2] = {0.0, 0.0};
                     if (mine.valid) {
                         lq[0] = point_loss<GT>(g, lm, P, mine.pw, mine.obs);
@@ -364,6 +390,10 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
                     reject_count += 1;
                     if (!have_unw) {   // the step's later trials are scored against the reduced unweighted pair
                         double u[NUNW];
+                        if (MV_PGO_FUSED_BUILD && cached && mine.valid) {   // `lin` holds the rejected trial pose's J, r: back to the restored pose's
+                            double scratch_acc[NLEAN];
+                            accumulate_point<GT, false>(g, lm, P, mine, scratch_acc, lin);
+                        }
                         if (mine.valid) {
                             // (opaque: without it hipcc SPECULATES these 99 fp64 operations — they have no side effects — into every LM
                             // step in front of the Cholesky and selects the results away: seen in the ISA and in the stamps, 1.4 k cycles per step)
@@ -476,6 +506,7 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
         if ((last - loss) < lm.decreasing) patience_count += 1; else patience_count = 0;
         if (patience_count >= lm.patience) continual = false;
         if (lm.stop_on_reject > 0 && reject_count >= lm.stop_on_reject) continual = false;
+        have_build = built_next;
     }
 
     if (tid == 0) {

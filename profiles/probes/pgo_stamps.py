@@ -17,7 +17,7 @@ buf = np.zeros(128, dtype=np.int64)
 lib.mv_pgo_probe_stamps.argtypes = [C.c_void_p]
 print("rc", lib.mv_pgo_probe_stamps(buf.ctypes.data))
 st = buf.reshape(16, 8)
-names = ["accumulate", "reduction (28 / 55 values)", "clamp+damp+cholesky", "se3 update", "trial residual (+ quality term)", "block_sum2", "TR + accept (+ reject rounds)"]
+names = ["accumulate (skipped behind an accepted fused trial)", "reduction (28 / 55 values)", "clamp+damp+cholesky", "se3 update", "trial: build at the trial pose + quality term", "its 29-value reduction", "TR + accept (+ reject rounds)"]
 for k in range(int(info[0, 1].item())):
     r = st[k]
     print(f"step {k}: " + " | ".join(f"{names[i]} {r[i+1]-r[i]}" for i in range(7)) + f" | total {r[7]-r[0]}" + (f" | to next {st[k+1][0]-r[7]}" if k + 1 < 16 and st[k+1][0] else ""))

@@ -113,12 +113,14 @@ void solve_one(const PgoArgs& a, const mvLMParams& lm, int prob, int nw) {
     }
 
     std::vector<double> per(T * NRED);
+    double acc[NRED];
+    bool have_build = false;
     while (continual) {
-        double acc[NRED];
-        bool have_unw;
-        double loss_build;
+        bool have_unw = !cached;
+        double loss_build = 0.0;
+        bool built_next = false;
         const int n_build = cached ? NLEAN : NRED;
-        for (int t = 0; t < T; ++t) {
+        for (int t = 0; t < T && !have_build; ++t) {
             double* o = &per[(size_t)t * NRED];
             for (int k = 0; k < NRED; ++k) o[k] = 0.0;
             if (cached) {
@@ -131,12 +133,13 @@ void solve_one(const PgoArgs& a, const mvLMParams& lm, int prob, int nw) {
                 }
             }
         }
-        for (int k = 0; k < n_build; ++k) {
-            for (int t = 0; t < T; ++t) col[t] = per[(size_t)t * NRED + k];
-            acc[k] = reduce_many1(col.data(), nw, cached);
+        if (!have_build) {
+            for (int k = 0; k < n_build; ++k) {
+                for (int t = 0; t < T; ++t) col[t] = per[(size_t)t * NRED + k];
+                acc[k] = reduce_many1(col.data(), nw, cached);
+            }
+            loss_build = acc[n_build - 1];
         }
-        loss_build = acc[n_build - 1];
-        have_unw = !cached;
         double* Aw = acc;
         const double* gw = acc + 21;
         double* Au = acc + 27;
@@ -159,7 +162,25 @@ void solve_one(const PgoArgs& a, const mvLMParams& lm, int prob, int nw) {
                 const double tp[3] = {P.t[0], P.t[1], P.t[2]}, qp[4] = {P.q[0], P.q[1], P.q[2], P.q[3]};
                 se3_left_update(P, D);
                 double quality;
-                if (cached) {
+                if (MV_PGO_FUSED_BUILD && cached && !have_unw) {
+                    std::vector<double> nper((size_t)T * (NLEAN + 1), 0.0);
+                    for (int t = 0; t < T; ++t)
+                        if (mine[t].valid) {
+                            nper[(size_t)t * (NLEAN + 1) + NLEAN] = quality_point<GT>(lin[t], D);
+                            accumulate_point<GT, false>(g, lm, P, mine[t], &nper[(size_t)t * (NLEAN + 1)], lin[t]);      // lin in place, as the kernel
+                        }
+                    double nacc[NLEAN + 1];
+                    for (int k = 0; k < NLEAN + 1; ++k) {
+                        for (int t = 0; t < T; ++t) col[t] = nper[(size_t)t * (NLEAN + 1) + k];
+                        nacc[k] = reduce_many1(col.data(), nw, true);
+                    }
+                    loss = nacc[NLEAN - 1];
+                    quality = (last - loss) / -nacc[NLEAN];
+                    if (!(last < loss && reject_count < lm.reject)) {
+                        for (int k = 0; k < NLEAN; ++k) acc[k] = nacc[k];
+                        built_next = true;
+                    }
+                } else if (cached) {
                     std::vector<double> l0(T, 0.0), l1(T, 0.0);
                     for (int t = 0; t < T; ++t)
                         if (mine[t].valid) {
@@ -191,6 +212,9 @@ void solve_one(const PgoArgs& a, const mvLMParams& lm, int prob, int nw) {
                     reject_count += 1;
                     if (!have_unw) {
                         std::vector<double> u((size_t)T * NUNW, 0.0);
+                        if (MV_PGO_FUSED_BUILD && cached)
+                            for (int t = 0; t < T; ++t)
+                                if (mine[t].valid) { double tmp[NLEAN]; accumulate_point<GT, false>(g, lm, P, mine[t], tmp, lin[t]); }   // lin back to the restored pose's
                         for (int t = 0; t < T; ++t)
                             if (mine[t].valid) unweighted_point<GT>(lin[t], &u[(size_t)t * NUNW]);
                         for (int k = 0; k < NUNW; ++k) {
@@ -267,6 +291,7 @@ void solve_one(const PgoArgs& a, const mvLMParams& lm, int prob, int nw) {
         if ((last - loss) < lm.decreasing) patience_count += 1; else patience_count = 0;
         if (patience_count >= lm.patience) continual = false;
         if (lm.stop_on_reject > 0 && reject_count >= lm.stop_on_reject) continual = false;
+        have_build = built_next;
     }
 
     double* o = a.out_pose + 7 * (size_t)prob;
