@@ -84,6 +84,8 @@ def run_variant(ref, refrun, variant: str, args) -> dict:
     dev = torch.device("cuda:0")
     torch.manual_seed(7)
     host = fh.FlowFormerCovHost(fh.demo_cfg(decoder_depth=args.decoder_depth), DT[args.enc], DT[args.dec]).to(dev).eval()
+    if args.channels_last:      # NHWC weights (and, through them, activations): MIOpen's bf16 / fp16 convolutions run in NHWC and otherwise transpose around every call
+        host = host.to(memory_format=torch.channels_last)
     hooks = plugins.install_flowformer_hooks(host) if variant == "hooked" else []
     out = {"hooks": hooks, "network_ms_per_pair_batch": round(network_ms(host, args.height, args.width), 3)}
 
@@ -142,6 +144,7 @@ def main():
     ap.add_argument("--decoder-depth", type=int, default=12)
     ap.add_argument("--mapping", type=int, default=1, help="dense-mapping tail of run_pair (MACVO_Fast.yaml keeps it on)")
     ap.add_argument("--graph", action="store_true", help="HIP_CUDAGraph_FlowFormerCovFrontend (the network captured as a hipGraph) instead of eager launches")
+    ap.add_argument("--channels-last", action="store_true", help="the network's convolution weights in NHWC (torch.channels_last)")
     ap.add_argument("--variants", default="hooked,unhooked")
     args = ap.parse_args()
     assert args.frames > args.warmup + 2
@@ -159,7 +162,7 @@ def main():
                    "weights, PyTorch-ROCm eager (tools/flowformer_host.py) on top of the synthetic scene's fields; selector / covariance / PGO = HIP plugins",
            "config": {"H": args.height, "W": args.width, "enc_dtype": args.enc, "dec_dtype": args.dec, "decoder_depth": args.decoder_depth,
                       "mapping": bool(args.mapping), "frontend": "HIP_CUDAGraph_FlowFormerCovFrontend" if args.graph else "HIP_FlowFormerCovFrontend",
-                      "frames": args.frames, "warmup": args.warmup},
+                      "frames": args.frames, "warmup": args.warmup, "channels_last": bool(args.channels_last)},
            "reference_published": "12.5 frames/s, Fast mode, RTX 6000 Ada, trained weights (README.md:28,117)"}
     for v in args.variants.split(","):
         try:
