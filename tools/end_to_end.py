@@ -147,7 +147,7 @@ def main():
     ap.add_argument("--channels-last", action="store_true", help="the network's convolution weights in NHWC (torch.channels_last)")
     ap.add_argument("--variants", default="hooked,unhooked")
     args = ap.parse_args()
-    assert args.frames > args.warmup + 2
+    assert args.warmup + 2 < args.frames <= 255, "the frame index travels in one 8-bit pixel"
     from tests import refrun
 
     if refrun.reference_root() is None:
