@@ -1,5 +1,5 @@
-// PROBE (round 4, written with the round's GPU budget spent — NOT yet run on hardware; run profiles/probes/lookup_persist_probe.py first thing in
-// round 5): a PERSISTENT, software-pipelined form of the batched 9x9 window lookup (VERDICT r3 next #4, configs[4]).
+// PROBE (round 4; ran once on the MI355X with the round's last GPU seconds: tokens bit-identical, 121-127 us vs 111 us for the shipped kernel at B = 64,
+// profiles/r04_lookup_persist_probe.log — slower as hipcc compiles it): a PERSISTENT, software-pipelined form of the batched 9x9 window lookup (VERDICT r3 next #4, configs[4]).
 //
 // Why.  The committed PMC pass of the batched lookup (profiles/r01_cfg4_b64_pmc_lookup_raw.txt: FETCH 271 MB at B = 64 before the margin trimming
 // of round 3, i.e. ~205 MB now) + 100 MB of token writes in 116 us is ~2.6 TB/s of ACTUAL traffic — not the ~4.3 TB/s DESIGN §8 [r4] states

@@ -1,4 +1,4 @@
-"""PROBE (not yet run on hardware — written after round 4's GPU budget was spent): the persistent, software-pipelined batched lookup of
+"""PROBE (ran once at the end of round 4: bit-identical tokens, 121-127 us vs 111 us shipped — profiles/r04_lookup_persist_probe.log): the persistent, software-pipelined batched lookup of
 lookup_persist_probe.hip against mv_corr_lookup's batched kernel at BASELINE configs[4] (B = 64 pairs): bit-equality of the tokens first, then
 back-to-back launch times.  Build in the container:  bash profiles/probes/lookup_persist_build.sh ;  run on the GPU box:
     python profiles/probes/lookup_persist_probe.py [B]
