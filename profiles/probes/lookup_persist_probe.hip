@@ -217,6 +217,17 @@ extern "C" int probe_lookup_launch(const float* vol, const float* coords, float*
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     if (variant == 0) {
         hipLaunchKernelGGL((corr_lookup_kernel<4, 4, 32>), dim3((N1 + 31) / 32, B), dim3(512), 0, s, vol, coords, out, N1, H2, W2);
+    } else if (variant >= 10) {       // other tilings of the SHIPPED kernel (more queries in flight per CU: fewer threads per query)
+#define LT(QPW, QPB) hipLaunchKernelGGL((corr_lookup_kernel<4, QPW, QPB>), dim3((N1 + QPB - 1) / QPB, B), dim3(64 * (QPB / QPW)), 0, s, vol, coords, out, N1, H2, W2)
+        switch (variant) {
+            case 10: LT(8, 32); break;     // 256 threads, 8 queries per wave
+            case 11: LT(8, 64); break;     // 512 threads
+            case 12: LT(4, 16); break;     // 256 threads, 16-query groups
+            case 13: LT(16, 64); break;    // 256 threads, 16 queries per wave
+            case 14: LT(8, 16); break;     // 128 threads
+            default: LT(2, 16); break;     // 15: the one-frame variant at this batch size
+        }
+#undef LT
     } else if (variant == 1) {
         const int gpb = (N1 + 31) / 32, total = B * gpb;
         const int grid = total < cus * wgs_per_cu ? total : cus * wgs_per_cu;

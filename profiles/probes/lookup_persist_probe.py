@@ -33,7 +33,11 @@ refs = [ops.corr_lookup(vol, c, 4) for c in coords]
 outs = [torch.empty_like(r) for r in refs]
 for variant, wgs, name in ((0, 0, "shipped <4,4,32>, one group per workgroup"), (1, 2, "persistent <4,4,32>, 2 workgroups per CU"),
                            (1, 4, "persistent <4,4,32>, 4 workgroups per CU"), (1, 3, "persistent <4,4,32>, 3 workgroups per CU"),
-                           (2, 1, "persistent <4,8,64>, 1 workgroup per CU"), (2, 2, "persistent <4,8,64>, 2 workgroups per CU")):
+                           (2, 1, "persistent <4,8,64>, 1 workgroup per CU"), (2, 2, "persistent <4,8,64>, 2 workgroups per CU"),
+                           (10, 0, "shipped kernel, tiling <4,8,32> (256 threads)"), (11, 0, "shipped kernel, tiling <4,8,64> (512 threads)"),
+                           (12, 0, "shipped kernel, tiling <4,4,16> (256 threads)"), (13, 0, "shipped kernel, tiling <4,16,64> (256 threads)"),
+                           (14, 0, "shipped kernel, tiling <4,8,16> (128 threads)"), (15, 0, "shipped kernel, tiling <4,2,16> (one-frame form)"),
+                           (0, 0, "shipped <4,4,32> again")):
     for i in range(4):
         outs[i].zero_()
         assert lib.probe_lookup_launch(vol.data_ptr(), coords[i].data_ptr(), outs[i].data_ptr(), B, N, H, W, variant, wgs, zero.data_ptr(), st) == 0
