@@ -101,6 +101,12 @@ int mv_patch_embed_pack(const float* w1, const float* b1, const float* w2, const
 int mv_cost_patch_embed_supported(int H2, int W2);
 int mv_cost_patch_embed(const float* cost_maps, const void* packed, float* out, int S, int H2, int W2, int token_layout, int operand_type,
                         mvStream_t stream);
+/* the same with the slices and / or the tokens in the 16-bit OPERAND type (row (f)2 as SURVEY.md words it: "the volume kept in bf16 / fp16"): in_dtype =
+ * MV_F32 or operand_type — fp16 cells of mv_corr_volume_out16's volume go to the matrix pipe as they are; out_dtype = MV_F32 or operand_type — tokens in the
+ * encoder's dtype (what Conv2d under MACVO_Fast.yaml:73-74's fp16 autocast returns).  No widening pass on either side: 9.6 + 10.2 KB of HBM traffic per
+ * 60 x 80 slice instead of 19.2 + 20.5 KB.  (in MV_F32, out 16-bit) is not built: MV_ERR_UNSUPPORTED.  fp16 conversions saturate at +-65504. */
+int mv_cost_patch_embed_t(const void* cost_maps, int in_dtype, const void* packed, void* out, int out_dtype, int S, int H2, int W2, int token_layout,
+                          int operand_type, mvStream_t stream);
 /* -------------------------------------------------------------------------------------------
  * A5, split + streaming form (csrc/corr_volume_split.hip): the same volume from fp32 feature maps on the 16-bit matrix pipe.
  * gfx950 has no TF32 MFMA; the reference runs this GEMM in TF32 / fp16 (Module/Frontend/Frontend.py:275-277,
@@ -185,10 +191,16 @@ int mv_frontend_epilogue(const float* flow, const float* logcov, int cov_is_log,
  * Module/Network/PWCNet/pwc_cov/gru.py:40-52) and, with exp2_out = 1, the exp(2*cov) of flownet.py:44.
  *   flow [B, 2, h, w] fp32 (1/8 resolution);  mask [B, 576, h, w] fp32 (channel = tap*64 + sy*8 + sx)
  *   out  [B, 2, 8h, 8w] fp32 = sum_tap softmax_tap(mask_scale * mask) * (8 * flow at the tap's 3x3 neighbour, zero pad)
+ *   the softmax weights are exp(m - max) * (1 / sum): one division per sub-pixel
  *   mask_scale: 0.25 for the flow branch (covhead.py:121), 1.0 for the log-sigma branch (scaled inside CovUpdateBlock :41)
  */
 int mv_convex_upsample(const float* flow, const float* mask, float* out, int B, int h, int w,
                        float mask_scale, int exp2_out, mvStream_t stream);
+/* the same with the mask in the decoder's own type: mask_dtype MV_F32 / MV_F16 / MV_BF16 ([B, 576, h, w] of that type, read as it is and
+ * widened in registers — the arithmetic is the fp32 formula on the widened values; Fast mode, Config/Experiment/MACVO/MACVO_Fast.yaml:73-74:
+ * the mask head runs under autocast and no `.float()` copy of the 11 MB mask is made).  flow and out stay fp32. */
+int mv_convex_upsample_m(const float* flow, const void* mask, int mask_dtype, float* out, int B, int h, int w,
+                         float mask_scale, int exp2_out, mvStream_t stream);
 
 /* -------------------------------------------------------------------------------------------
  * A10/A11 + MappingPointSelector  candidate generation for the covariance-aware keypoint selectors.

@@ -109,6 +109,7 @@ SIGNATURES = {
     "mv_frontend_epilogue": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                        _P, _P, _P, _P, _P, _P, _P, _P]),
     "mv_convex_upsample": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P]),
+    "mv_convex_upsample_m": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P]),
     "mv_kp_select_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mv_kp_select": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(mvKpSelectParams), _P, C.c_size_t,
                                _P, _P, _P, _P]),
@@ -149,6 +150,7 @@ SIGNATURES = {
     "mv_patch_embed_pack": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "mv_cost_patch_embed_supported": (C.c_int, [C.c_int, C.c_int]),
     "mv_cost_patch_embed": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mv_cost_patch_embed_t": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv_frame_pipe_arena_bytes": (C.c_size_t, [C.POINTER(mvFramePipeConfig)]),
     "mv_frame_pipe_max_pending": (C.c_int, []),
     "mv_frame_pipe_create": (C.c_int, [C.POINTER(mvFramePipeConfig), _P, C.c_size_t, C.POINTER(_P)]),

@@ -116,9 +116,11 @@ __global__ void patch_embed_pack_kernel(const float* __restrict__ w1, const floa
 
 // the 16-bit operand type of the whole stack: bf16 (F16 = false) or IEEE fp16 (F16 = true; 11 significant bits — TF32's mantissa, and the type the
 // reference's Fast mode runs this encoder in); same fragment layouts, same instruction shape
+// IEEE half SATURATES at +-65504 (one v_med3_f32): a cost cell or an activation beyond fp16's range stays the largest finite value instead of
+// becoming inf and, one layer later, NaN tokens (an un-normalised 256-channel dot product can get there; bf16 has fp32's range and needs nothing)
 template <bool F16>
 __device__ __forceinline__ uint16_t cvt_bits(float v) {
-    if constexpr (F16) return __builtin_bit_cast(uint16_t, (_Float16)v);
+    if constexpr (F16) return __builtin_bit_cast(uint16_t, (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f));
     else return __builtin_bit_cast(uint16_t, (__bf16)v);
 }
 template <bool F16>
@@ -129,10 +131,17 @@ __device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
     else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int H2, int W2, bool TOKENS, bool F16>
-__global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __restrict__ vol, const char* __restrict__ wp,
-                                                               float* __restrict__ out, int S) {
+// IN16 / OUT16: the slice is read / the tokens are written in the OPERAND type (fp16 cells of the `out16` volume -> fp16 tokens for the fp16 encoder of
+// MACVO_Fast.yaml:73-74; bf16 likewise) instead of fp32: the cells go to LDS as they are, no conversion, and HBM traffic is 9.6 + 10.2 KB per
+// slice instead of 19.2 + 20.5 KB
+template <int H2, int W2, bool TOKENS, bool F16, bool IN16, bool OUT16>
+__global__ __launch_bounds__(256) void cost_patch_embed_kernel(const void* __restrict__ vol_, const char* __restrict__ wp,
+                                                               void* __restrict__ out_, int S) {
     using P = PE<H2, W2>;
+    constexpr int EPL = IN16 ? 8 : 4;                                       // cells per 16-byte load
+    constexpr int QN = H2 * W2 / EPL, NPRE = (QN + 255) / 256;
+    static_assert(W2 % EPL == 0 && NPRE <= 5, "slice staging");
+    const char* const vol = reinterpret_cast<const char*>(vol_);
     extern __shared__ __attribute__((aligned(16))) char smem_pe[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -162,12 +171,12 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
     __syncthreads();
 
     // slice staging: this thread's float4s of the NEXT slice travel in registers while the current one is convolved
-    f32x4 pre[5];
+    i32x4 pre[NPRE];
     auto fetch = [&](int s) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < NPRE; ++i) {
             const int q = t + 256 * i;
-            pre[i] = (s < S && q < P::Q4) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vol + (size_t)s * (H2 * W2)) + q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            pre[i] = (s < S && q < QN) ? __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(vol + (size_t)s * (H2 * W2) * (IN16 ? 2 : 4)) + q) : i32x4{0, 0, 0, 0};
         }
     };
     // conv1 addressing (see the conv1 phase): fragment base in the slice and store base in the conv1 map for this wave's tiles 0..4
@@ -194,13 +203,19 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
             asm volatile("" : "+v"(gv));                // does not hoist ~100 loop-invariant addresses out of the slice loop (it spilled 131 registers)
             // ---- (A) slice -> in0 (bf16), next slice -> registers
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
+            for (int i = 0; i < NPRE; ++i) {
                 const int q = t + 256 * i;
-                if (q < P::Q4) {
-                    const int y = q / (W2 / 4), x = 4 * (q - y * (W2 / 4));
+                if (q < QN) {
+                    const int y = q / (W2 / EPL), x = EPL * (q - y * (W2 / EPL));
                     unsigned* d = reinterpret_cast<unsigned*>(in0 + ((y + 2) * P::IN_PITCH + x + 2) * 2);
-                    d[0] = cvt_pack<F16>(pre[i][0], pre[i][1]);
-                    d[1] = cvt_pack<F16>(pre[i][2], pre[i][3]);
+                    if constexpr (IN16) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) d[e] = (unsigned)pre[i][e];
+                    } else {
+                        const f32x4 v = __builtin_bit_cast(f32x4, pre[i]);
+                        d[0] = cvt_pack<F16>(v[0], v[1]);
+                        d[1] = cvt_pack<F16>(v[2], v[3]);
+                    }
                 }
             }
             fetch(gs == 0 ? 2 * pass + 1 : 2 * (pass + (int)gridDim.x));
@@ -327,8 +342,37 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const float* __re
                 __builtin_amdgcn_sched_barrier(0);
             }
             const int s_out = 2 * pass + mh;
-            if (s_out < S) {
-                float* const oslice = out + (size_t)s_out * (P::M3 * 64);
+            if constexpr (OUT16) {
+                // 16-bit tokens.  Channel-major: four consecutive tokens of one channel = one 8-byte store.  Token-major: neighbouring lanes (channels
+                // ch, ch + 1) swap half of their four tokens so that every lane writes two dwords of two channels each (8 lanes = 32 contiguous bytes
+                // of a token, as many as the fp32 form's 16-lane groups cover)
+                uint16_t* const oslice = reinterpret_cast<uint16_t*>(out_) + (size_t)s_out * (P::M3 * 64);
+                const bool odd = n16 & 1;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const int q = i * 16 + 4 * gv;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int ch = (2 * np + j) * 16 + n16;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + b3v[j];
+                        if constexpr (TOKENS) {
+                            const float r0 = __shfl_xor(odd ? v[0] : v[2], 1, 64), r1 = __shfl_xor(odd ? v[1] : v[3], 1, 64);
+                            if (s_out < S) {
+                                unsigned* d = reinterpret_cast<unsigned*>(oslice + (q + (odd ? 2 : 0)) * 64 + (ch & ~1));
+                                d[0] = odd ? cvt_pack<F16>(r0, v[2]) : cvt_pack<F16>(v[0], r0);
+                                d[32] = odd ? cvt_pack<F16>(r1, v[3]) : cvt_pack<F16>(v[1], r1);
+                            }
+                        } else if (s_out < S) {
+                            unsigned* d = reinterpret_cast<unsigned*>(oslice + ch * P::M3 + q);
+                            d[0] = cvt_pack<F16>(v[0], v[1]);
+                            d[1] = cvt_pack<F16>(v[2], v[3]);
+                        }
+                    }
+                }
+            } else if (s_out < S) {
+                float* const oslice = reinterpret_cast<float*>(out_) + (size_t)s_out * (P::M3 * 64);
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
                     const int q = i * 16 + 4 * gv;                           // four consecutive tokens
@@ -367,45 +411,64 @@ extern "C" int mv_patch_embed_pack(const float* w1, const float* b1, const float
 
 extern "C" int mv_cost_patch_embed_supported(int H2, int W2) { return (H2 == 60 || H2 == 64) && W2 == 80; }
 
-template <int H2, bool F16>
-static int launch_patch_embed(const float* cost_maps, const void* packed, float* out, int S, int token_layout, hipStream_t stream) {
+template <int H2, bool F16, bool IN16, bool OUT16>
+static int launch_patch_embed(const void* cost_maps, const void* packed, void* out, int S, int token_layout, hipStream_t stream) {
     using P = PE<H2, 80>;
     static std::atomic<bool> attr_done[64];
-    static std::atomic<int> cus{0};
+    static std::atomic<int> cus[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_done[dev].load(std::memory_order_acquire)) {
-        (void)hipFuncSetAttribute((const void*)cost_patch_embed_kernel<H2, 80, true, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)cost_patch_embed_kernel<H2, 80, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)cost_patch_embed_kernel<H2, 80, true, F16, IN16, OUT16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)cost_patch_embed_kernel<H2, 80, false, F16, IN16, OUT16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done[dev].store(true, std::memory_order_release);
     }
-    int ncu = cus.load(std::memory_order_relaxed);
+    int ncu = cus[dev].load(std::memory_order_relaxed);
     if (!ncu) {
         hipDeviceProp_t prop;
         ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-        cus.store(ncu, std::memory_order_relaxed);
+        cus[dev].store(ncu, std::memory_order_relaxed);
     }
     const int npass = (S + 1) / 2;
     const dim3 grid(std::min(npass, ncu));                                  // persistent: one workgroup per CU (157.5 KB of LDS each)
     if (token_layout)
-        hipLaunchKernelGGL((cost_patch_embed_kernel<H2, 80, true, F16>), grid, dim3(256), P::LDS_BYTES, stream, cost_maps, (const char*)packed, out, S);
+        hipLaunchKernelGGL((cost_patch_embed_kernel<H2, 80, true, F16, IN16, OUT16>), grid, dim3(256), P::LDS_BYTES, stream, cost_maps, (const char*)packed, out, S);
     else
-        hipLaunchKernelGGL((cost_patch_embed_kernel<H2, 80, false, F16>), grid, dim3(256), P::LDS_BYTES, stream, cost_maps, (const char*)packed, out, S);
+        hipLaunchKernelGGL((cost_patch_embed_kernel<H2, 80, false, F16, IN16, OUT16>), grid, dim3(256), P::LDS_BYTES, stream, cost_maps, (const char*)packed, out, S);
     return mv_launch_status();
+}
+
+template <bool F16, bool IN16, bool OUT16>
+static int launch_patch_embed_h(const void* cost_maps, const void* packed, void* out, int S, int H2, int token_layout, hipStream_t st) {
+    return H2 == 60 ? launch_patch_embed<60, F16, IN16, OUT16>(cost_maps, packed, out, S, token_layout, st)
+                    : launch_patch_embed<64, F16, IN16, OUT16>(cost_maps, packed, out, S, token_layout, st);
+}
+
+extern "C" int mv_cost_patch_embed_t(const void* cost_maps, int in_dtype, const void* packed, void* out, int out_dtype, int S, int H2, int W2,
+                                     int token_layout, int operand_type, mvStream_t stream) {
+    MV_CHECK_ARG(cost_maps && packed && out && S > 0);
+    MV_CHECK_ARG(((uintptr_t)cost_maps & 15) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)out & 15) == 0);
+    MV_CHECK_ARG(operand_type == MV_F16 || operand_type == MV_BF16);        // must be the type `packed` was built for
+    // a 16-bit slice / token type is the operand type itself (the cells go to the matrix pipe as they are)
+    MV_CHECK_ARG(in_dtype == MV_F32 || in_dtype == operand_type);
+    MV_CHECK_ARG(out_dtype == MV_F32 || out_dtype == operand_type);
+    // 640x480 frames: 60 x 80 slices (padded to 64 rows inside the kernel) or the already padded 64 x 80 slices PatchEmbed.forward hands to `proj`
+    // (also 640x512 frames); larger slices do not fit the LDS plan
+    if (!mv_cost_patch_embed_supported(H2, W2)) return MV_ERR_UNSUPPORTED;
+    if (in_dtype == MV_F32 && out_dtype != MV_F32) return MV_ERR_UNSUPPORTED;   // fp32 volume -> 16-bit tokens: no caller (the volume hook returns the encoder dtype)
+    hipStream_t st = (hipStream_t)stream;
+    const bool f16 = operand_type == MV_F16, in16 = in_dtype != MV_F32, out16 = out_dtype != MV_F32;
+    if (f16) {
+        if (!in16) return launch_patch_embed_h<true, false, false>(cost_maps, packed, out, S, H2, token_layout, st);
+        return out16 ? launch_patch_embed_h<true, true, true>(cost_maps, packed, out, S, H2, token_layout, st)
+                     : launch_patch_embed_h<true, true, false>(cost_maps, packed, out, S, H2, token_layout, st);
+    }
+    if (!in16) return launch_patch_embed_h<false, false, false>(cost_maps, packed, out, S, H2, token_layout, st);
+    return out16 ? launch_patch_embed_h<false, true, true>(cost_maps, packed, out, S, H2, token_layout, st)
+                 : launch_patch_embed_h<false, true, false>(cost_maps, packed, out, S, H2, token_layout, st);
 }
 
 extern "C" int mv_cost_patch_embed(const float* cost_maps, const void* packed, float* out, int S, int H2, int W2, int token_layout,
                                    int operand_type, mvStream_t stream) {
-    MV_CHECK_ARG(cost_maps && packed && out && S > 0);
-    MV_CHECK_ARG(((uintptr_t)cost_maps & 15) == 0 && ((uintptr_t)packed & 15) == 0);
-    MV_CHECK_ARG(operand_type == MV_F16 || operand_type == MV_BF16);        // must be the type `packed` was built for
-    // 640x480 frames: 60 x 80 slices (padded to 64 rows inside the kernel) or the already padded 64 x 80 slices PatchEmbed.forward hands to `proj`
-    // (also 640x512 frames); larger slices do not fit the LDS plan
-    if (!mv_cost_patch_embed_supported(H2, W2)) return MV_ERR_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
-    if (operand_type == MV_F16)
-        return H2 == 60 ? launch_patch_embed<60, true>(cost_maps, packed, out, S, token_layout, st)
-                        : launch_patch_embed<64, true>(cost_maps, packed, out, S, token_layout, st);
-    return H2 == 60 ? launch_patch_embed<60, false>(cost_maps, packed, out, S, token_layout, st)
-                    : launch_patch_embed<64, false>(cost_maps, packed, out, S, token_layout, st);
+    return mv_cost_patch_embed_t(cost_maps, MV_F32, packed, out, MV_F32, S, H2, W2, token_layout, operand_type, stream);
 }

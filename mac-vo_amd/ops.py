@@ -280,15 +280,18 @@ def frontend_epilogue(flow: torch.Tensor, cov: torch.Tensor, baseline: float, fx
 
 def convex_upsample(flow8: torch.Tensor, mask: torch.Tensor, mask_scale: float = 1.0, exp2_out: bool = False) -> torch.Tensor:
     """RAFT / FlowFormer ``upsample_flow`` (covhead.py:124-126,133-135): ``[B,2,h,w], [B,576,h,w] -> [B,2,8h,8w]``;
-    ``exp2_out`` fuses the ``exp(2 * cov)`` of flownet.py:44."""
+    ``exp2_out`` fuses the ``exp(2 * cov)`` of flownet.py:44.  ``mask`` may be fp32, fp16 or bf16 (the decoder's autocast type in Fast mode);
+    the result is the fp32 formula on the widened values."""
     lib = L.load()
     flow8 = _req(flow8, torch.float32, "flow8")
-    mask = _req(mask, torch.float32, "mask")
+    if mask.dtype not in _DT:
+        raise TypeError(f"mask: fp32 / fp16 / bf16 expected, got {mask.dtype}")
+    mask = _req(mask, mask.dtype, "mask")       # a 16-bit mask is read as it is (no widened copy) and widened in registers
     B, two, h, w = flow8.shape
     assert two == 2 and mask.shape == (B, 576, h, w)
     out = torch.empty((B, 2, 8 * h, 8 * w), dtype=torch.float32, device=flow8.device)
-    L.check(lib.mv_convex_upsample(flow8.data_ptr(), mask.data_ptr(), out.data_ptr(), B, h, w, float(mask_scale),
-                                   int(exp2_out), _stream()), "mv_convex_upsample")
+    L.check(lib.mv_convex_upsample_m(flow8.data_ptr(), mask.data_ptr(), _DT[mask.dtype], out.data_ptr(), B, h, w, float(mask_scale),
+                                     int(exp2_out), _stream()), "mv_convex_upsample_m")
     return out
 
 
@@ -331,24 +334,36 @@ def cost_patch_embed_supported(H2: int, W2: int) -> bool:
     return bool(L.load().mv_cost_patch_embed_supported(int(H2), int(W2)))
 
 
-def cost_patch_embed(cost_maps: torch.Tensor, weights: PatchEmbedWeights, tokens: bool = False, out: torch.Tensor | None = None) -> torch.Tensor:
-    """``PatchEmbed.proj(F.pad(cost_maps))`` for every slice in one launch: ``cost_maps [S, 1, H2, W2]`` fp32 (what ``corr_volume`` returns)
-    -> ``[S, 64, H2/8, W2/8]`` fp32, or with ``tokens`` the flattened-transposed form ``[S, H2/8 * W2/8, 64]``.  16-bit matrix pipe
-    (``weights.operand``) with fp32 accumulation; the two intermediate maps never leave LDS.  Raises for slice sizes the kernel does not cover
-    (``cost_patch_embed_supported``): callers keep their PyTorch layers for those."""
+def cost_patch_embed(cost_maps: torch.Tensor, weights: PatchEmbedWeights, tokens: bool = False, out: torch.Tensor | None = None,
+                     out_dtype: torch.dtype | None = None) -> torch.Tensor:
+    """``PatchEmbed.proj(F.pad(cost_maps))`` for every slice in one launch: ``cost_maps [S, 1, H2, W2]`` (fp32 as ``corr_volume`` returns it, or the
+    16-bit cells of ``corr_volume_out16`` when that type is ``weights.operand``) -> ``[S, 64, H2/8, W2/8]``, or with ``tokens`` the flattened-transposed
+    form ``[S, H2/8 * W2/8, 64]``.  Result dtype: ``out_dtype`` / ``out.dtype`` if given, else the input's (what ``Conv2d`` returns) — fp32 or the operand
+    type.  16-bit matrix pipe (``weights.operand``) with fp32 accumulation; the two intermediate maps never leave LDS, a 16-bit slice goes to the matrix
+    pipe as it is and nothing is widened on either side.  Raises for slice sizes the kernel does not cover (``cost_patch_embed_supported``) and for
+    dtype combinations it does not build: callers keep their PyTorch layers for those."""
     lib = L.load()
-    cost_maps = _req(cost_maps, torch.float32, "cost_maps")
+    op_dtype = torch.float16 if weights.operand == "f16" else torch.bfloat16
+    if cost_maps.dtype not in (torch.float32, op_dtype):
+        raise L.MacvoHipError(f"cost_patch_embed: cost_maps must be float32 or the operand type {op_dtype}, got {cost_maps.dtype}")
+    cost_maps = _req(cost_maps, cost_maps.dtype, "cost_maps")
     S, H2, W2 = cost_maps.shape[0], cost_maps.shape[-2], cost_maps.shape[-1]
     if cost_maps.numel() != S * H2 * W2:
         raise L.MacvoHipError("cost_patch_embed: cost_maps must be [S, 1, H2, W2] (one head)")
     h, w = (H2 + 7) // 8, (W2 + 7) // 8
     shape = (S, h * w, 64) if tokens else (S, 64, h, w)
+    if out is not None:
+        out_dtype = out.dtype
+    elif out_dtype is None:
+        out_dtype = cost_maps.dtype
+    if out_dtype not in (torch.float32, op_dtype) or (out_dtype != torch.float32 and cost_maps.dtype == torch.float32):
+        raise L.MacvoHipError(f"cost_patch_embed: {cost_maps.dtype} slices -> {out_dtype} tokens is not built (operand {op_dtype})")
     if out is None:
-        out = torch.empty(shape, dtype=torch.float32, device=cost_maps.device)
-    elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous():
-        raise L.MacvoHipError(f"cost_patch_embed: out must be a contiguous float32 tensor of shape {shape}")
-    L.check(lib.mv_cost_patch_embed(cost_maps.data_ptr(), weights.packed.data_ptr(), out.data_ptr(), S, H2, W2, int(tokens), weights.operand_type,
-                                    _stream()), "mv_cost_patch_embed")
+        out = torch.empty(shape, dtype=out_dtype, device=cost_maps.device)
+    elif tuple(out.shape) != shape or not out.is_contiguous():
+        raise L.MacvoHipError(f"cost_patch_embed: out must be a contiguous tensor of shape {shape}")
+    L.check(lib.mv_cost_patch_embed_t(cost_maps.data_ptr(), _DT[cost_maps.dtype], weights.packed.data_ptr(), out.data_ptr(), _DT[out_dtype], S, H2, W2,
+                                      int(tokens), weights.operand_type, _stream()), "mv_cost_patch_embed_t")
     return out
 
 

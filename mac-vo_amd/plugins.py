@@ -23,6 +23,8 @@ from __future__ import annotations
 import math
 from types import SimpleNamespace
 
+import os
+
 import torch
 
 from . import ops
@@ -507,7 +509,56 @@ class HIP_CUDAGraph_FlowFormerCovFrontend(HIP_FlowFormerCovFrontend):
 
 
 # ----------------------------------------------------------------------------------------------- FlowFormer hooks
-def install_flowformer_hooks(model, volume_precision: str | None = None) -> list[str]:
+class _FusedProjForward:
+    """``forward`` of a FlowFormer ``PatchEmbed.proj`` (``nn.Sequential`` of three 6x6 stride-2 ``Conv2d``) through ``mv_cost_patch_embed_t``.
+
+    * The Sequential itself is left in place (``proj.forward`` is rebound, nothing is re-parented): ``state_dict`` keys, ``.to()``, ``load_state_dict``
+      keep working, and the packed 16-bit weight fragments are rebuilt whenever a parameter's storage or version counter changes.
+    * Default numerics policy: the fused kernel rounds slices, weights and both intermediate maps to a 16-bit type, so it is used when the encoder
+      already runs in one — fp16 / bf16 slices (autocast, ``MACVO_Fast.yaml:73-74``) with operands of that same type, cells read and tokens written in
+      it, no widening on either side.  fp32 slices (``Paper_Reproduce``-style configurations: PyTorch-ROCm convolutions are full fp32) keep the
+      original layers unless ``force`` (``install_flowformer_hooks(fuse_patch_embed=True)`` / ``MACVO_HIP_PATCH_EMBED=1``) opts in to IEEE-half
+      operands (11 significant bits, ~2.5e-4 of the output scale; conversions saturate at +-65504 instead of overflowing).
+    * Training / autograd: falls through to the layers whenever a gradient could be required."""
+
+    def __init__(self, proj: torch.nn.Sequential, force: bool = False):
+        self.proj, self.force = proj, force
+        self._packed: dict = {}        # operand -> (key, PatchEmbedWeights)
+
+    def _key(self):
+        def version(p):
+            try:
+                return p._version
+            except RuntimeError:        # inference tensors (a model built under torch.inference_mode) carry no version counter; they cannot be
+                return -1               # updated in place either, so storage + dtype identify them
+        return tuple((p.data_ptr(), version(p), p.dtype) for p in self.proj.parameters())
+
+    def repack(self, operand: str = "f16"):
+        key = self._key()
+        hit = self._packed.get(operand)
+        if hit is None or hit[0] != key:
+            hit = (key, ops.PatchEmbedWeights.from_proj(self.proj, operand=operand))
+            self._packed[operand] = hit
+        return hit[1]
+
+    def __call__(self, x):                                      # x: [S, 1, H2p, W2p] — PatchEmbed.forward has already padded it
+        layers = torch.nn.Sequential.forward
+        if not (x.is_cuda and x.dim() == 4 and x.shape[1] == 1 and ops.cost_patch_embed_supported(x.shape[-2], x.shape[-1])):
+            return layers(self.proj, x)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.proj.parameters())):
+            return layers(self.proj, x)
+        if x.dtype == torch.float16:
+            operand = "f16"
+        elif x.dtype == torch.bfloat16:
+            operand = "bf16"
+        elif x.dtype == torch.float32 and self.force:
+            operand = "f16"
+        else:
+            return layers(self.proj, x)
+        return ops.cost_patch_embed(x, self.repack(operand))    # result in x.dtype, as Conv2d returns it
+
+
+def install_flowformer_hooks(model, volume_precision: str | None = None, fuse_patch_embed: bool | None = None) -> list[str]:
     """Route the three frontend kernels of ``FlowFormerCov`` through the HIP library by rebinding bound methods on the model
     instance — signatures and result layouts are those of the methods they replace, the network's own code is untouched:
 
@@ -523,6 +574,10 @@ def install_flowformer_hooks(model, volume_precision: str | None = None) -> list
     ``volume_precision``: None = ``ops.default_volume_precision()`` ("f16x2" unless ``MACVO_HIP_VOLUME_PRECISION`` says otherwise) — the
     same default as ``pipeline.HotPathConfig`` and ``bench.py``; the plugins' YAML key sets are the reference's, so they take the default.
 
+    * ``memory_encoder...patch_embed.proj`` — the cost patch embedding's three convolutions (row (f)2) -> ``ops.cost_patch_embed``
+      (``_FusedProjForward``).  ``fuse_patch_embed``: None = for 16-bit slices only (the encoder's own precision is kept; fp32 slices stay on the
+      PyTorch layers), True = also for fp32 slices (IEEE-half operands), False = never; ``MACVO_HIP_PATCH_EMBED=1|0`` sets the default.
+
     Every attribute that exists is rebound (the FlowFormer submodule is absent from some checkouts, and a stand-in model may
     carry only part of them); the names of the rebound methods are returned so that a caller can insist on all three."""
     done = []
@@ -534,7 +589,8 @@ def install_flowformer_hooks(model, volume_precision: str | None = None) -> list
             cost_maps if cost_maps.dtype == torch.float16 else cost_maps.float(), coords.float(), 4)   # an fp16 volume is read as it is
         done.append("memory_decoder.encode_flow_token")
     if dec is not None and hasattr(dec, "upsample_flow"):
-        dec.upsample_flow = lambda flow, mask: ops.convex_upsample(flow.float(), mask.float(), 1.0, False)
+        dec.upsample_flow = lambda flow, mask: ops.convex_upsample(      # a 16-bit mask (autocast) is read as it is: no widened 22-MB copy
+            flow.float(), mask if mask.dtype in (torch.float16, torch.bfloat16) else mask.float(), 1.0, False)
         done.append("memory_decoder.upsample_flow")
     enc = getattr(model, "memory_encoder", None)
     if enc is not None and hasattr(enc, "corr"):
@@ -558,34 +614,27 @@ def install_flowformer_hooks(model, volume_precision: str | None = None) -> list
         enc.corr = corr
         done.append("memory_encoder.corr")
     # (f)2: the cost patch embedding.  FlowFormer's cost encoder owns `patch_embed = PatchEmbed(patch_size 8, in_chans 1, embed_dim 64)` whose
-    # `proj` (three 6x6 stride-2 convolutions) eats the whole volume slice by slice: rebind `proj` to the fused kernel for the slice sizes it
-    # covers (640x480 frames); any other size falls through to the original layers.
+    # `proj` (three 6x6 stride-2 convolutions) eats the whole volume slice by slice: `proj.forward` is rebound to the fused kernel for the slice
+    # sizes it covers; any other size, dtype or mode falls through to the original layers.
+    if fuse_patch_embed is None:
+        env = os.environ.get("MACVO_HIP_PATCH_EMBED", "auto").lower()
+        fuse_patch_embed = {"1": True, "on": True, "true": True, "0": False, "off": False, "false": False}.get(env)
     pe, pe_name = None, ""
-    if enc is not None and hasattr(enc, "named_modules"):      # public FlowFormer: memory_encoder.cost_perceiver_encoder.patch_embed; accept it directly under the encoder too
+    if fuse_patch_embed is not False and enc is not None and hasattr(enc, "named_modules"):
+        # public FlowFormer: memory_encoder.cost_perceiver_encoder.patch_embed; accept it directly under the encoder too
         for name, mod in enc.named_modules():
             if (name == "patch_embed" or name.endswith(".patch_embed")) and isinstance(getattr(mod, "proj", None), torch.nn.Sequential):
                 pe, pe_name = mod, name
                 break
     if pe is not None:
+        fused = _FusedProjForward(pe.proj, force=fuse_patch_embed is True)
         try:
-            packed = ops.PatchEmbedWeights.from_proj(pe.proj)
+            fused.repack()                                  # validates the layer shapes now; a stack that is not patch_size 8 keeps its layers
         except ops.L.MacvoHipError:
-            packed = None
-        if packed is not None:
-            orig = pe.proj
-
-            class _FusedProj(torch.nn.Module):
-                def __init__(self):
-                    super().__init__()
-                    self.layers = orig                                  # keeps the parameters (state_dict keys move under .layers)
-                    self.packed = packed
-
-                def forward(self, x):                                   # x: [S, 1, H2p, W2p] — PatchEmbed.forward has already padded it
-                    if x.is_cuda and x.shape[1] == 1 and ops.cost_patch_embed_supported(x.shape[-2], x.shape[-1]):
-                        return ops.cost_patch_embed(x.float().contiguous(), self.packed).to(x.dtype)
-                    return self.layers(x)
-
-            pe.proj = _FusedProj()
+            fused = None
+        if fused is not None:
+            # an instance attribute shadows nn.Sequential.forward: the module, its parameters and its state_dict keys stay where they were
+            pe.proj.forward = fused
             done.append(f"memory_encoder.{pe_name}.proj")
     if not done:
         raise ops.L.MacvoHipError("install_flowformer_hooks: the model has none of memory_decoder.encode_flow_token / "

@@ -321,6 +321,28 @@ def test_convex_upsample(gpu, B, h, w):
     assert (up[..., 8:-8, 8:-8] - 4.0).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,h,w", [(2, 60, 80), (1, 7, 9), (1, 90, 160), (3, 16, 24), (1, 1, 1), (1, 5, 13)])
+def test_convex_upsample_16bit_mask(gpu, dtype, B, h, w):
+    """Fast mode (MACVO_Fast.yaml:73-74): the mask arrives in the decoder's autocast type and is read as it is — the result must be the
+    fp32 kernel's on the widened mask, bit for bit (same arithmetic on the same fp32 values), for even and odd plane sizes (dword pairs /
+    16-bit loads) and through the half-width launch of small frames."""
+    from macvo_amd import ops
+
+    g = torch.Generator().manual_seed(32)
+    flow8 = (torch.randn(B, 2, h, w, generator=g) * 3).to(gpu)
+    mask = (torch.randn(B, 576, h, w, generator=g) * 4).to(dtype).to(gpu)
+    for scale, e2 in ((0.25, False), (1.0, True)):
+        fl = flow8 * (0.02 if e2 else 1.0)
+        a = ops.convex_upsample(fl, mask, mask_scale=scale, exp2_out=e2)
+        b = ops.convex_upsample(fl, mask.float(), mask_scale=scale, exp2_out=e2)
+        assert torch.equal(a, b)
+    # an odd element offset into the storage (2-byte aligned only): the pair path must not be taken blindly
+    buf = torch.zeros(mask.numel() + 1, dtype=dtype, device=gpu)
+    buf[1:] = mask.flatten()
+    assert torch.equal(ops.convex_upsample(flow8, buf[1:].view_as(mask), 0.25), ops.convex_upsample(flow8, mask.float(), 0.25))
+
+
 @pytest.mark.parametrize("shape", [(1, 32, 112, 160), (2, 196, 7, 10), (1, 128, 14, 20), (2, 96, 28, 40), (1, 64, 56, 80),
                                    (1, 16, 33, 47), (1, 3, 5, 5), (3, 8, 1, 1)])
 def test_local_corr81(gpu, shape):

@@ -30,7 +30,7 @@ def test_interleaved_lookups_and_upsampling_match_the_oracle(gpu, dec_dtype):
         # every lookup saw the coordinates the previous iteration's GRU produced (not stale, not early)
         want = corr.corr_lookup(vol_cpu, tr["coords"].cpu(), 4)
         torch.testing.assert_close(tr["tokens"].cpu(), want, rtol=1e-5, atol=2e-4)
-        up = frontend.upsample_flow(tr["flow8"].cpu(), 0.25 * tr["up_mask"].cpu())
+        up = frontend.upsample_flow(tr["flow8"].cpu(), 0.25 * tr["up_mask"].float().cpu())       # the kernel read the bf16 mask as it is
         torch.testing.assert_close(tr["flow_up"].cpu(), up, rtol=2e-5, atol=2e-5)
         if it:
             assert not torch.equal(tr["coords"], net.trace[it - 1]["coords"])

@@ -160,16 +160,111 @@ def test_flowformer_hook_rebinds_the_patch_embed_proj(gpu):
 
     torch.manual_seed(0)
     m = Model().to(gpu).eval()
+    keys = list(m.state_dict().keys())
     x = _volume_slices(9, seed=4).to(gpu)
+    proj = m.memory_encoder.patch_embed.proj
+    layers = lambda t: nn.Sequential.forward(proj, t)      # noqa: E731 - the original layers, whatever proj.forward is bound to
     with torch.no_grad():
         want = m.memory_encoder.patch_embed(x)
         done = plugins.install_flowformer_hooks(m)
+        assert "memory_encoder.patch_embed.proj" in done
+        assert isinstance(proj, nn.Sequential) and list(m.state_dict().keys()) == keys       # nothing re-parented
+        # default policy: fp32 slices keep the fp32 layers (no silent rounding of an fp32 model to 16-bit operands) ...
+        assert torch.equal(m.memory_encoder.patch_embed(x), want)
+        # ... 16-bit slices go through the fused kernel in their own type, cells in and tokens out
+        for dt, operand in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
+            m16 = Model().to(gpu).eval()
+            m16.load_state_dict(m.state_dict())
+            m16 = m16.to(dt)
+            want16 = m16.memory_encoder.patch_embed(x.to(dt))
+            plugins.install_flowformer_hooks(m16)
+            got16 = m16.memory_encoder.patch_embed(x.to(dt))
+            assert got16.dtype == dt and got16.shape == want16.shape
+            # both sides round the same 16-bit weights / cells; the layers also round every conv output to 16 bits, the kernel only the
+            # intermediate maps and the tokens: bar = the operand bar + one output rounding
+            bar = (FP32_TOL[operand] + (2 ** -8 if operand == "bf16" else 2 ** -11)) * want16.float().abs().max().item()
+            assert (got16.float() - want16.float()).abs().max().item() <= bar, operand
+    # opt-in for fp32 models: IEEE-half operands
+    torch.manual_seed(0)
+    m = Model().to(gpu).eval()
+    proj = m.memory_encoder.patch_embed.proj
+    with torch.no_grad():
+        done = plugins.install_flowformer_hooks(m, fuse_patch_embed=True)
         assert "memory_encoder.patch_embed.proj" in done
         got = m.memory_encoder.patch_embed(x)
         small = m.memory_encoder.patch_embed(torch.randn(2, 1, 24, 32, device=gpu))    # a size the kernel does not cover: original layers
         x64 = torch.randn(5, 1, 64, 80, device=gpu) * 8                                # 640x512 frames: rows 60..63 are data, not padding
         got64 = m.memory_encoder.patch_embed(x64)
-        want64 = m.memory_encoder.patch_embed.proj.layers(x64)
-    assert got.shape == want.shape == (9, 64, 8, 10) and small.shape == (2, 64, 3, 4)
-    assert (got - want).abs().max().item() <= FP32_TOL["f16"] * want.abs().max().item()      # fp32 layers -> IEEE-half operands
-    assert (got64 - want64).abs().max().item() <= FP32_TOL["f16"] * want64.abs().max().item()
+        want64 = layers(x64)
+        assert got.shape == want.shape == (9, 64, 8, 10) and small.shape == (2, 64, 3, 4)
+        assert (got - want).abs().max().item() <= FP32_TOL["f16"] * want.abs().max().item()      # fp32 layers -> IEEE-half operands
+        assert not torch.equal(got, want)                                                       # ... and it really was the kernel
+        assert (got64 - want64).abs().max().item() <= FP32_TOL["f16"] * want64.abs().max().item()
+        # a weight update after hooking (load_state_dict, optimizer step, .to()): the packed fragments follow (they were a stale snapshot)
+        sd = {k: v * 0.5 for k, v in m.state_dict().items()}
+        m.load_state_dict(sd)
+        want_half = layers(F.pad(x, (0, 0, 0, 4)))
+        got_half = m.memory_encoder.patch_embed(x)
+        assert (got_half - want_half).abs().max().item() <= FP32_TOL["f16"] * want_half.abs().max().item()
+        assert (got_half - got).abs().max().item() > 0.05 * got.abs().max().item()
+    # autograd: a call that could need gradients runs the layers (the kernel is inference-only)
+    xg = x[:2].clone().requires_grad_(True)
+    y = m.memory_encoder.patch_embed(xg)
+    assert y.requires_grad and torch.equal(y, layers(F.pad(xg, (0, 0, 0, 4))))
+
+
+@pytest.mark.parametrize("operand,dt", [("f16", torch.float16), ("bf16", torch.bfloat16)])
+@pytest.mark.parametrize("tokens", [False, True])
+def test_cost_patch_embed_16bit_cells_in_16bit_tokens_out(gpu, operand, dt, tokens):
+    """Row (f)2 as SURVEY words it: the volume stays 16-bit between its producer and this consumer.  (1) 16-bit cells in, fp32 out == the fp32-cell
+    kernel on the widened cells, bit for bit (the cells reach the matrix pipe as the same 16-bit values either way).  (2) 16-bit tokens == that fp32
+    result rounded once to the token type (RNE), bit for bit — both layouts (the token-major form swaps halves between neighbouring lanes).  (3) and
+    the whole thing against the oracle's same-arithmetic twin."""
+    from macvo_amd import ops
+    from oracle import patch_embed as ope
+
+    W = ope.make_weights(seed=21)
+    packed = ops.PatchEmbedWeights(*[w.to(gpu) for w in W], operand=operand)
+    for S, H2 in ((1, 60), (301, 60), (6, 64)):
+        g = torch.Generator().manual_seed(S)
+        x16 = (torch.randn(S, 1, H2, 80, generator=g) * 16).to(dt).to(gpu)
+        f32 = ops.cost_patch_embed(x16.float(), packed, tokens=tokens)
+        mixed = ops.cost_patch_embed(x16, packed, tokens=tokens, out_dtype=torch.float32)
+        assert mixed.dtype == torch.float32 and torch.equal(mixed, f32)
+        t16 = ops.cost_patch_embed(x16, packed, tokens=tokens)
+        assert t16.dtype == dt and torch.equal(t16, f32.to(dt)), (S, H2)
+        ref = _twin(operand)(x16.float().cpu(), *W)
+        ref = ope.to_tokens(ref) if tokens else ref
+        assert (f32.cpu() - ref).abs().max().item() <= TWIN_TOL[operand] * ref.abs().max().item()
+    with pytest.raises(ops.L.MacvoHipError):      # a 16-bit type that is not the operand type, and fp32 cells -> 16-bit tokens: not built, said loudly
+        ops.cost_patch_embed(x16.to(torch.bfloat16 if dt == torch.float16 else torch.float16), packed)
+    with pytest.raises(ops.L.MacvoHipError):
+        ops.cost_patch_embed(x16.float(), packed, out_dtype=dt)
+
+
+def test_cost_patch_embed_saturates_instead_of_overflowing_fp16(gpu):
+    """an un-normalised 256-channel dot product can exceed fp16's range.  Cells and activations beyond +-65504 saturate (finite
+    tokens, equal to the twin on clamped values) instead of turning into inf and, a layer later, NaN."""
+    from macvo_amd import ops
+    from oracle import patch_embed as ope
+
+    W = ope.make_weights(seed=4, scale=1.0)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(4, 1, 60, 80, generator=g) * 16
+    x[0, 0, 10:14, 20:30] = 3.0e5          # cells beyond fp16
+    x[1, 0, 30, 40] = -1.0e6
+    x[2] *= 3000.0                         # a whole slice whose conv activations leave fp16's range
+    packed = ops.PatchEmbedWeights(*[w.to(gpu) for w in W], operand="f16")
+    got = ops.cost_patch_embed(x.to(gpu), packed).cpu()
+    assert torch.isfinite(got).all()
+    # the twin with the same saturation at every 16-bit rounding
+    sat = lambda t: t.clamp(-65504.0, 65504.0).half().float()      # noqa: E731
+    import torch.nn.functional as F
+    w1, b1, w2, b2, w3, b3 = W
+    r = lambda t: t.half().float()      # noqa: E731
+    y = sat(F.pad(x, (0, 0, 0, 4)))
+    y = sat(F.relu(F.conv2d(y, r(w1), b1, stride=2, padding=2)))
+    y = sat(F.relu(F.conv2d(y, r(w2), b2, stride=2, padding=2)))
+    ref = F.conv2d(y, r(w3), b3, stride=2, padding=2)
+    assert (got - ref).abs().max().item() <= TWIN_TOL["f16"] * ref.abs().max().item()
+    assert got[3].abs().max() < 1e3 and got[2].abs().max() > 1e4      # the ordinary slice is untouched by its neighbours' magnitudes

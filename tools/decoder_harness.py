@@ -171,17 +171,17 @@ class DecoderLoopHarness(nn.Module):
                 fcov_net, delta_cov, cov_mask = self.cov_update(fcov_net, inp_cat)                # :117
             with _range("Flow Upsample"):
                 flow_c1 = flow_c1 + delta_flow.float()                                            # :121-126, fp32
-                um = up_mask.float().contiguous()
+                um = up_mask.contiguous()            # the mask in the decoder's own dtype: mv_convex_upsample_m widens it in registers (no 11 -> 22 MB copy)
                 flow_up = hip(ops.convex_upsample, flow_c1 - coords0, um, mask_scale=0.25)
                 if self.trace is not None:
                     self.trace[-1].update(flow8=(flow_c1 - coords0).clone(), up_mask=um.clone(), flow_up=flow_up.clone())
             with _range("Cov Upsample"):
                 cov_c1 = cov_c1 + delta_cov.float()                                               # :130-135, fp32
                 last = it == self.depth - 1
-                cm = cov_mask.float().contiguous()
+                cm = cov_mask.contiguous()
                 cov_up = hip(ops.convex_upsample, cov_c1 - cov_c0, cm, mask_scale=1.0, exp2_out=last)
         # what the hot path takes over (pipeline.FrameInputs, the 1/8-resolution alternative): last iteration's fields + masks
-        self.last = dict(flow8=(flow_c1 - coords0).contiguous(), cov8=(cov_c1 - cov_c0).contiguous(), up_mask=um, cov_mask=cm)
+        self.last = dict(flow8=(flow_c1 - coords0).contiguous(), cov8=(cov_c1 - cov_c0).contiguous(), up_mask=um.float(), cov_mask=cm.float())   # FrameInputs' contract: fp32 masks
         return (flow_up, flow_c1 - coords0), (cov_up, cov_c1 - cov_c0)
 
     def hip_times_us(self) -> dict:

@@ -102,6 +102,20 @@ def main():
                 us = e0.elapsed_time(e1) * 1e3 / reps
                 print(f"cost_patch_embed<{operand}> S={B * n} {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s algorithmic = {fl / us / 1e6 / 2500 * 100:.1f}% of the 16-bit MFMA peak; "
                       f"HBM {byts / us / 1e3:.0f} GB/s ({byts / 1e6:.0f} MB)")
+                # Fast mode (row (f)2): 16-bit cells in, 16-bit tokens out — half the HBM bytes, no conversion in the staging
+                dt16 = torch.float16 if operand == "f16" else torch.bfloat16
+                vol16, out16 = volr.to(dt16), torch.empty((B * n, 80, 64), dtype=dt16, device=dev)
+                for _ in range(5):
+                    ops.cost_patch_embed(vol16, pk, tokens=True, out=out16)
+                e0.record()
+                for _ in range(reps):
+                    ops.cost_patch_embed(vol16, pk, tokens=True, out=out16)
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / reps
+                print(f"cost_patch_embed<{operand}, 16-bit in/out> S={B * n} {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s algorithmic = {fl / us / 1e6 / 2500 * 100:.1f}% of the 16-bit MFMA "
+                      f"peak; HBM {byts / 2 / us / 1e3:.0f} GB/s ({byts / 2e6:.0f} MB)")
+                del vol16, out16
             # the unfused form: the same three layers as PyTorch / MIOpen convolutions (bf16, channels_last), intermediates through HBM
             import torch.nn.functional as F
             xb = F.pad(volr, (0, 0, 0, 4)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
@@ -166,8 +180,20 @@ def main():
             fl = torch.randn(B, 2, h8, w8, generator=g).to(dev)
             mk = torch.randn(B, 576, h8, w8, generator=g).to(dev)
             byts = B * (578 * n * 4 + 2 * 64 * n * 4.0)
-            med, mn = timeit(lambda: ops.convex_upsample(fl, mk, 0.25), a.iters)
-            print(f"convex_upsample B={B} {med:8.1f} us (min {mn:.1f})  {byts / med / 1e3:7.1f} GB/s  {byts / med / 1e3 / 8000 * 100:.1f}% of HBM peak")
+            for mdt in (torch.float32, torch.bfloat16):
+                mkd = mk.to(mdt)
+                byts = B * ((576 * mkd.element_size() + 8) * n + 2 * 64 * n * 4.0)
+                for _ in range(5):
+                    ops.convex_upsample(fl, mkd, 0.25)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = 4 * a.iters
+                e0.record()
+                for _ in range(reps):          # back to back: the figure is the kernel's period, not a launch + event round trip
+                    ops.convex_upsample(fl, mkd, 0.25)
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / reps
+                print(f"convex_upsample B={B} mask {str(mdt)[6:]} {us:8.2f} us back to back  {byts / us / 1e3:7.1f} GB/s  {byts / us / 1e3 / 8000 * 100:.1f}% of HBM peak ({byts / 1e6:.1f} MB)")
         elif w == "select":
             fc = synth.flow_cov_maps(H, W, 2).to(dev)
             d0, d0c = [t.to(dev) for t in synth.depth_maps(H, W, 3)]
