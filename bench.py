@@ -85,7 +85,12 @@ def parse_args():
     ap.add_argument("--no-ramp", action="store_true", help="skip the untimed clock-ramp phase")
     ap.add_argument("--end-to-end-frames", type=int, default=40, help="frames of the end_to_end leg (network included, reference's MACVO loop; the first "
                     "quarter is warm-up); 0 = skip")
+    ap.add_argument("--plugin-frames", type=int, default=12, help="distinct frames handed to the plugin_path leg (replayed 3 x through the reference's MACVO loop with "
+                    "the HIP plugins); 0 = skip")
     ap.add_argument("--no-decoder-leg", action="store_true", help="skip the decoder-loop harness leg (HIP lookups / upsamplings interleaved with PyTorch-ROCm kernels)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST ONLY (N > 1 ranks on a 1-GPU box): every rank drives device 0 and the collectives run over gloo — real kernels, real gather_tracks, real "
+                         "core pinning, no RCCL; the line is marked and its value is not a scaling measurement")
     ap.add_argument("--dry-collectives", action="store_true",
                     help="CPU-only plumbing check of the N-rank launch path: gloo backend, no kernels, synthetic tracks through the "
                          "same barrier / gather_tracks / max-over-ranks code; the line it prints is marked and is NOT a measurement")
@@ -318,6 +323,26 @@ def patch_embed_leg(ops, vol, dev, reps=10):
                    "accumulate, both intermediate maps in LDS", "us_per_frame": round(us, 1), "algorithmic_gflop": round(fl / 1e9, 1),
            "roofline": {"bound": "mfma", "achieved": round(fl / us / 1e6, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / us / 1e6 / PEAK_BF16_MFMA_TFLOPS, 4),
                         "traffic": None, "kernel": "cost_patch_embed_kernel<60,80>", "algorithmic_hbm_bytes": byts, "hbm_GBps": round(byts / us / 1e3, 1)}}
+    # Fast mode (row (f)2 as SURVEY words it): fp16 cells in (the out16 volume), fp16 tokens out — no widening pass on either side
+    try:
+        v16 = vol.half()
+        o16 = torch.empty_like(out, dtype=torch.float16)
+        for _ in range(3):
+            ops.cost_patch_embed(v16, pk, tokens=True, out=o16)
+        e0.record()
+        for _ in range(reps):
+            ops.cost_patch_embed(v16, pk, tokens=True, out=o16)
+        e1.record()
+        torch.cuda.synchronize()
+        us16 = e0.elapsed_time(e1) * 1e3 / reps
+        same = bool(torch.equal(o16, ops.cost_patch_embed(v16.float(), pk, tokens=True).half()))
+        leg["fast_mode"] = {"what": "fp16 cells in, fp16 tokens out (mv_cost_patch_embed_t)", "us_per_frame": round(us16, 1), "achieved": round(fl / us16 / 1e6, 1),
+                            "frac": round(fl / us16 / 1e6 / PEAK_BF16_MFMA_TFLOPS, 4), "algorithmic_hbm_bytes": byts / 2, "hbm_GB_per_frame": round(byts / 2e9, 4),
+                            "hbm_GBps": round(byts / 2 / us16 / 1e3, 1), "kernel": "cost_patch_embed_kernel<60,80,f16 in,f16 out>",
+                            "tokens_equal_fp32_form_rounded_once": same}
+        del v16, o16
+    except Exception as e:  # noqa: BLE001
+        leg["fast_mode"] = {"error": repr(e)[:200]}
     try:
         # parity of what was just timed: a few slices against the conv2d chain in the same arithmetic (16-bit operands, fp32 accumulation)
         idx = torch.tensor([0, S // 2, S - 1])
@@ -347,6 +372,170 @@ def patch_embed_leg(ops, vol, dev, reps=10):
     return leg
 
 
+def kernels_leg(ops, frames, cam, args, dev, volume_roofline, patch_embed, n_q, C):
+    """one roofline entry per SURVEY §8(d) kernel in the line the driver parses.  Every kernel ALONE on the GPU, launched back
+    to back between two HIP events on the launch stream (>= 100 launches after >= 20 untimed ones; the figure is the kernel's period, so a
+    launch-bound kernel shows up as such), algorithmic bytes / FLOPs exactly as §8(d) defines them, peak from MI355X_MICROARCH.md."""
+    import statistics as st
+
+    from tests import synth
+
+    H, W = args.height, args.width
+    h8, w8 = H // 8, W // 8
+
+    def period_us(fn, n=100, warm=20):
+        for _ in range(warm):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n
+
+    def hbm(name, us, nbytes, note=None, **extra):
+        d = {"us": round(us, 2), "bound": "hbm", "algorithmic_bytes": nbytes, "achieved": round(nbytes / us / 1e3, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+             "frac": round(nbytes / us / 1e3 / PEAK_HBM_GBS, 4), **extra}
+        if note:
+            d["note"] = note
+        out[name] = d
+
+    out: dict = {}
+    fr = frames[0]
+    # volume: the line's own roofline object (HIP events inside the pipe) + alone
+    if volume_roofline is not None:
+        out["volume"] = {"kernel": volume_roofline.get("kernel"), "us": volume_roofline.get("isolated_avg_launch_us", volume_roofline["avg_launch_us"]),
+                         "us_in_pipe": volume_roofline["avg_launch_us"], "bound": volume_roofline["bound"], "peak": volume_roofline["peak"], "unit": volume_roofline["unit"],
+                         "algorithmic_flops": volume_roofline["algorithmic_flops_per_launch"], "algorithmic_bytes": volume_roofline["algorithmic_bytes_per_launch"],
+                         "executed_flops": volume_roofline.get("executed_flops_per_launch"),
+                         "frac": volume_roofline.get("isolated_frac", volume_roofline["frac"]), "frac_in_pipe": volume_roofline["frac"]}
+    if args.feat_dtype != "f32" or args.layout != "chw":
+        return out
+    vol = ops.corr_volume(fr.fmap1, fr.fmap2)
+    P = fr.fmap1.shape[0]                                                 # 2 pairs
+    tok = torch.empty((P, 81, h8, w8), dtype=torch.float32, device=dev)
+    it = [0]
+
+    def lk():
+        ops.corr_lookup(vol, fr.coords[it[0] % fr.coords.shape[0]], 4, out=tok)
+        it[0] += 1
+
+    look_bytes = P * (n_q * 100 * 4 + n_q * 8 + n_q * 81 * 4.0)           # §8(d): N (10 x 10 cells) 4 + N 8 + N 81 4 per pair
+    hbm("lookup_B2", period_us(lk, 240), look_bytes, kernel="corr_lookup_kernel (one frame: 2 pairs)")
+    # Fast mode: the same lookup on 2-byte cells
+    try:
+        h1, h2 = fr.fmap1.permute(0, 2, 3, 1).contiguous().half(), fr.fmap2.permute(0, 2, 3, 1).contiguous().half()
+        v16 = ops.corr_volume_out16(h1, h2)
+        if v16 is not None:
+            hbm("volume_out16", period_us(lambda: ops.corr_volume_out16(h1, h2, out=v16)), P * (2.0 * n_q * C * 2 + 2.0 * n_q * n_q),
+                kernel="corr_volume_h_stream<out16> (fp16 features -> fp16 cells: MACVO_Fast.yaml:73-74)")
+            hbm("lookup_B2_vol16", period_us(lambda: ops.corr_lookup(v16, fr.coords[0], 4, out=tok), 240), P * (n_q * 100 * 2 + n_q * 8 + n_q * 81 * 4.0),
+                kernel="corr_lookup on fp16 cells")
+        del h1, h2, v16
+    except Exception as e:  # noqa: BLE001
+        out["volume_out16"] = {"error": repr(e)[:200]}
+    del vol
+    # convex upsampling: one call of the decoder loop (B = 2 fields), fp32 mask as covhead.py:121-135 hands it over, and the bf16 mask read as it is
+    g = torch.Generator().manual_seed(3)
+    fl8 = torch.randn(P, 2, h8, w8, generator=g).to(dev)
+    mk = torch.randn(P, 576, h8, w8, generator=g).to(dev)
+    ub = P * n_q * (576 * 4 + 8 + 128 * 4.0)
+    hbm("convex_upsample", period_us(lambda: ops.convex_upsample(fl8, mk, 0.25), 240), ub, kernel="convex_upsample_kernel<f32 mask>")
+    mk16 = mk.bfloat16()
+    hbm("convex_upsample_bf16_mask", period_us(lambda: ops.convex_upsample(fl8, mk16, 0.25), 240), P * n_q * (576 * 2 + 8 + 128 * 4.0), kernel="convex_upsample_kernel<bf16 mask>")
+    del mk, mk16
+    # patch embedding: from its own leg
+    if patch_embed and "roofline" in patch_embed:
+        r = patch_embed["roofline"]
+        out["patch_embed"] = {"us": patch_embed["us_per_frame"], "bound": "mfma", "algorithmic_flops": patch_embed["algorithmic_gflop"] * 1e9, "algorithmic_bytes": r["algorithmic_hbm_bytes"],
+                              "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"], "kernel": r["kernel"]}
+        if "fast_mode" in patch_embed:
+            f = patch_embed["fast_mode"]
+            out["patch_embed_fast_mode"] = {"us": f["us_per_frame"], "bound": "mfma", "algorithmic_flops": patch_embed["algorithmic_gflop"] * 1e9,
+                                            "algorithmic_bytes": f["algorithmic_hbm_bytes"], "achieved": f["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": f["frac"],
+                                            "kernel": f["kernel"]}
+    # selector, covariance, solve: latency-bound by §8(d)'s own account ("report us"); the HBM fraction is printed for completeness
+    fc = synth.flow_cov_maps(H, W, 2).to(dev)
+    hbm("selector", period_us(lambda: ops.kp_select("nodepth", H, W, flow_cov=fc, kernel_size=7, mask_width=32, max_match_cov=100.0)), 4.0 * H * W * 3 + H * W,
+        note="CovAwareSelector_NoDepth candidate stage (kp_nms + kp_finish; the count D2H + host randperm + gather follow in `finish`): latency-bound, §8(d) asks for us",
+        kernel="kp_nms_kernel + kp_finish_kernel")
+    depth = synth.depth_maps(H, W, 3)[0].to(dev)
+    kp = synth.keypoints(200, H, W, 5).float().to(dev)
+    fcv = (torch.ones(200, 3) * 0.25).to(dev)
+    K = (cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    hbm("covariance", period_us(lambda: ops.match_cov(depth, kp, fcv, None, *K)), 200 * (31 * 31 * 4 + 28 + 72.0), note="MatchCovariance, N = 200, 31 x 31 window: latency-bound",
+        kernel="match_cov_kernel")
+    try:
+        from oracle import pgo as opgo
+        from tests.test_gpu_backend import _to_batch
+
+        prob, _ = opgo.make_synthetic_problem(n=200, seed=6)
+        batch = _to_batch([prob], dev)
+        us = period_us(lambda: ops.pgo_solve(batch, args.graph), 60, 10)
+        pose, info = ops.pgo_solve(batch, args.graph)
+        steps = int(info[0, 0].item()) if info.dim() == 2 else int(info[0].item())
+        out["solve"] = {"us": round(us, 2), "bound": "latency", "algorithmic_bytes_per_lm_iteration": 200 * 15 * 8, "lm_steps": steps,
+                        "kernel": "pgo_solve_kernel (one problem, one workgroup: dependent fp64 chain; §8(d): report us/solve)", "frac": None}
+        big = _to_batch([prob] * 4096, dev)
+        usb = period_us(lambda: ops.pgo_solve(big, args.graph), 10, 3)
+        out["solve_batched_4096"] = {"us": round(usb, 1), "solves_per_s": round(4096 / usb * 1e6), "bound": "latency", "frac": None}
+        del big
+    except Exception as e:  # noqa: BLE001
+        out["solve"] = {"error": repr(e)[:200]}
+    # configs[4]: the batched lookup, B = 64 pairs on a 5.9-GB volume
+    if (H, W) == (480, 640):
+        try:
+            f1 = torch.randn(64, C, h8, w8, device=dev)
+            f2 = torch.randn(64, C, h8, w8, device=dev)
+            vb = ops.corr_volume(f1, f2)
+            del f1, f2
+            co = fr.coords[0].repeat(32, 1, 1, 1)
+            tb = torch.empty((64, 81, h8, w8), dtype=torch.float32, device=dev)
+            hbm("lookup_B64", period_us(lambda: ops.corr_lookup(vb, co, 4, out=tb), 40, 8), 64 * (n_q * 100 * 4 + n_q * 8 + n_q * 81 * 4.0), kernel="corr_lookup_kernel (configs[4]: 64 pairs)")
+            del vb, tb, co
+        except Exception as e:  # noqa: BLE001
+            out["lookup_B64"] = {"error": repr(e)[:200]}
+    torch.cuda.empty_cache()
+    return out
+
+
+def plugin_path_leg(cam, cfr, n_frames, graph):
+    """VERDICT r4 missing #4: the cost of the drop-in path itself.  The reference's unmodified ``Odometry/MACVO.py`` loop with the HIP plugins behind its
+    registries (``type: HIP_*``) and a replay network, on the benchmark's own network outputs: steady-state ms per ``run_pair`` (first 5 frames
+    dropped) and, from a second run under cProfile, the three largest host costs per frame."""
+    import subprocess
+    import tempfile
+
+    import numpy as np
+
+    from tests import refrun
+
+    if refrun.reference_root() is None:
+        return None
+    n_frames = min(n_frames, len(cfr))
+    with tempfile.TemporaryDirectory() as tmp:
+        mf = os.path.join(tmp, "maps.npz")
+        np.savez(mf, flow=torch.stack([f["flow"] for f in cfr[:n_frames]]).numpy(),
+                 cov=torch.stack([torch.exp(f["logcov"] * 2) for f in cfr[:n_frames]]).numpy(), cam=np.array(json.dumps(cam)))
+        base = [sys.executable, os.path.join(ROOT, "tests", "refrun.py"), "--mode", "hip", "--case", "synth_fast", "--maps-file", mf, "--mapping", "0", "--graph", graph,
+                "--repeat-maps", "3"]
+        res = {}
+        for tag, extra in (("timed", []), ("profiled", ["--cprofile"])):
+            p = subprocess.run(base + extra, capture_output=True, text=True, timeout=300)
+            ln = [x for x in p.stdout.splitlines() if x.startswith('{"case"')]
+            if p.returncode != 0 or not ln:
+                return {"error": tag + ": " + (p.stdout[-300:] + p.stderr[-900:])}
+            res[tag] = json.loads(ln[-1])
+    t = res["timed"]
+    return {"what": "tests/refrun.py --mode hip: the reference's own MACVO.run_pair loop (Odometry/MACVO.py:173-337, unmodified) with HIP_FlowFormerCovFrontend (replay network: "
+                    "the benchmark's own flow / sigma maps), HIP_CovAwareSelector_NoDepth, HIP_MatchCovariance, HIP_TwoFrame_PGO; one torch.cuda.synchronize per frame",
+            "frames": t["frames"], "dropped_first": 5, "ms_per_run_pair": round(t["s_per_frame_after5"] * 1e3, 3), "ms_per_run_pair_median": round(t["s_per_frame_median"] * 1e3, 3),
+            "classes": t["classes"], "host_top3_ms_per_frame": res["profiled"].get("host_top"),
+            "note": "host_top3 from a second run under cProfile (tottime, own time of the function; the profiler inflates Python-heavy entries)"}
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -360,16 +549,20 @@ def main():
     if args.dry_collectives:
         return dry_collectives(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP hot path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if args.share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also exercises RCCL at world = 1)
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if torch.cuda.device_count() <= local_rank:
+        if torch.cuda.device_count() <= dev_index:
             raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
-        dist_mod.init_process_group(backend="nccl", device_id=dev)
+        if args.share_gpu:
+            dist_mod.init_process_group(backend="gloo")
+        else:
+            dist_mod.init_process_group(backend="nccl", device_id=dev)
         dist = dist_mod
 
     from macvo_amd import ops
@@ -424,6 +617,8 @@ def main():
             return NativeHotPath(Camera(**cam), cfg, dev, lanes=lanes, generators=gens, keep_extras=keep_extras)
         return HotPath(Camera(**cam), cfg, dev)
 
+    coll_dev = torch.device("cpu") if args.share_gpu else dev      # gloo (test mode): scalar collectives on host tensors
+
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -459,7 +654,7 @@ def main():
         t_idx += warmup
         gather_tracks(torch.zeros((steps * lanes, 7), dtype=torch.float32, device=dev), stamps.repeat_interleave(lanes), dist)
         if dist is not None:  # warm the collectives used in / around the timed region (RCCL sets channels up lazily)
-            dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=dev), op=dist.ReduceOp.MAX)
+            dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=coll_dev), op=dist.ReduceOp.MAX)
         n_ev = max(steps, MIN_TIMED_LAUNCHES) if with_events else 0
         torch.cuda.synchronize()
         barrier()
@@ -484,7 +679,7 @@ def main():
             print("[bench trace] step-finished times (us): " + " ".join(f"{x * 1e6:.0f}" for x in trace[:40]) +
                   f" | run() returned {t_run * 1e6:.0f} | gather issued {t_gather * 1e6:.0f} | synchronized {elapsed * 1e6:.0f}", file=sys.stderr)
         if dist is not None:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         assert torch.isfinite(all_poses).all(), "non-finite pose in the benchmark stream"
@@ -538,7 +733,10 @@ def main():
 
         ops.corr_volume = timed_corr_volume
 
-    elapsed, _, ms, in_region = measure(args.lanes, args.steps, args.warmup, 1234 + rank, not args.no_kernel_events)
+    elapsed, main_poses, ms, in_region = measure(args.lanes, args.steps, args.warmup, 1234 + rank, not args.no_kernel_events)
+    # every rank's gathered track: finite and not the zero padding (a rank that tracked nothing would show up here, not in `value`)
+    rank_tracks_finite = [bool(torch.isfinite(main_poses[r]).all() and float(main_poses[r, :, 3:].abs().sum()) > 0) for r in range(main_poses.shape[0])]
+    del main_poses
     main_timeline = dict(last_timeline)
     if vol_events:
         torch.cuda.synchronize()
@@ -793,19 +991,33 @@ def main():
             patch_embed = patch_embed_leg(ops, ops.corr_volume(frames[0].fmap1, frames[0].fmap2, layout=args.layout), dev)
         except Exception as e:  # noqa: BLE001 - a measurement leg must not take the benchmark line down
             patch_embed = {"error": repr(e)[:300]}
+    kernels = plugin_path = None
+    if rank == 0 and world == 1 and not args.no_decoder_leg and args.lanes == 1:
+        try:
+            kernels = kernels_leg(ops, frames, cam, args, dev, roofline, patch_embed, n_q, C)
+        except Exception as e:  # noqa: BLE001 - a measurement leg must not take the benchmark line down
+            kernels = {"error": repr(e)[:300]}
+    if rank == 0 and world == 1 and args.lanes == 1 and args.plugin_frames > 0 and not args.no_cpu_baseline and args.feat_dtype == "f32":
+        try:
+            plugin_path = plugin_path_leg(cam, cfr, args.plugin_frames, args.graph)
+            if plugin_path and "error" not in plugin_path and cpu_baseline and cpu_baseline.get("parts"):
+                plugin_path["reference_cpu_ms_per_run_pair"] = round(cpu_baseline["parts"]["reference_run_pair_s"] * 1e3, 2)
+        except Exception as e:  # noqa: BLE001
+            plugin_path = {"error": repr(e)[:300]}
     end_to_end = None
     if rank == 0 and world == 1 and args.end_to_end_frames > 0 and args.lanes == 1 and (H, W) == (480, 640) and not args.no_cpu_baseline:
         try:
             end_to_end = end_to_end_leg(args.end_to_end_frames)
         except Exception as e:  # noqa: BLE001 - a measurement leg must not take the benchmark line down
             end_to_end = {"error": repr(e)[:300]}
-    ranks_seen, rank_devices = 1, [torch.cuda.current_device()]
+    ranks_seen, rank_devices, rank_cores, rank_pose_ok = 1, [torch.cuda.current_device()], [my_cores], [True]
     if dist is not None:
         ranks_seen = dist.get_world_size()
-        mine = torch.tensor([rank, torch.cuda.current_device()], dtype=torch.int64, device=dev)
-        got = torch.empty((ranks_seen, 2), dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(got, mine)
-        rank_devices = [int(d) for _, d in sorted((int(r), int(d)) for r, d in got.cpu().tolist())]
+        got = [None] * ranks_seen
+        dist.all_gather_object(got, {"rank": rank, "device": torch.cuda.current_device(), "cores": my_cores, "steps_done": args.steps})
+        got = sorted(got, key=lambda d: d["rank"])
+        rank_devices = [int(d["device"]) for d in got]
+        rank_cores = [d["cores"] for d in got]
     if rank == 0:
         total_frames = world * args.steps * args.lanes
         cfgname = {1: "configs[1]", 32: "configs[4]"}.get(args.lanes, f"{args.lanes}-lane variant of configs[1]")
@@ -817,6 +1029,9 @@ def main():
             "ranks_seen": ranks_seen,
             "rank_devices": rank_devices,
             "host_cores_per_rank": len(my_cores) or None,
+            "rank_core_slices": [[c[0], c[-1]] if c else None for c in rank_cores],
+            "rank_pose_tracks_finite": rank_tracks_finite,
+            "share_gpu_test_mode": bool(args.share_gpu),
             "host_threads_per_rank": "2 busy (caller + backend launch thread) + a torch pool of %d" % torch.get_num_threads(),
             "steps": args.steps,
             "warmup": args.warmup,
@@ -850,7 +1065,11 @@ def main():
             "config4": config4,
             "decoder_loop": decoder_loop,
             "patch_embed": patch_embed,
+            "kernels": kernels,
+            "plugin_path": plugin_path,
             "end_to_end": end_to_end,
+            "multi_gpu_note": "no scaling curve has been measured by the builder (1-GPU boxes only): N > 1 is covered by a world-2 gloo test, a world-1 RCCL test and a "
+                              "2-rank test sharing one GPU (tests/test_gpu_bench.py)",
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -26,6 +26,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int DT> struct MaskElem;
 template <> struct MaskElem<MV_F32> { typedef float T; static __device__ __forceinline__ float widen(float v) { return v; } };
@@ -140,9 +141,13 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __res
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 float* dst = out + ((size_t)(b * 2 + c) * 8 * h + (8 * py[j] + sy)) * W8 + 8 * px[j] + sx0;
+                if constexpr (NSX == 2) {
+                    *reinterpret_cast<f32x2*>(dst) = f32x2{o[c][0], o[c][1]};
+                } else {
 #pragma unroll
-                for (int q = 0; q < NSX / 4; ++q)
-                    reinterpret_cast<f32x4*>(dst)[q] = f32x4{o[c][4 * q], o[c][4 * q + 1], o[c][4 * q + 2], o[c][4 * q + 3]};
+                    for (int q = 0; q < NSX / 4; ++q)
+                        reinterpret_cast<f32x4*>(dst)[q] = f32x4{o[c][4 * q], o[c][4 * q + 1], o[c][4 * q + 2], o[c][4 * q + 3]};
+                }
             }
         }
     }
@@ -161,17 +166,24 @@ template <int DT>
 int dispatch(const float* flow, const void* mask, float* out, int B, int h, int w, float mask_scale, int exp2_out,
              hipStream_t stream) {
     const int hw = h * w;
-    // 16-bit masks: two pixels per lane (dword loads) when every plane starts on a dword
-    const bool pair = DT != MV_F32 && hw % 2 == 0 && ((uintptr_t)mask & 3) == 0;
-    // enough waves for every SIMD of the chip (1024): half-width sub-column groups when the frame is small
-    const long waves8 = (long)mv_ceil_div(hw, pair ? 128 : 64) * 8 * B;
     static const int forced = getenv("MV_UPS_NSX") ? atoi(getenv("MV_UPS_NSX")) : 0;   // A/B only
-    const bool half = forced ? forced == 4 : waves8 < 2048;
-    if (pair)
-        return half ? launch<DT, 2, 4>(flow, mask, out, B, h, w, mask_scale, exp2_out, stream)
-                    : launch<DT, 2, 8>(flow, mask, out, B, h, w, mask_scale, exp2_out, stream);
-    return half ? launch<DT, 1, 4>(flow, mask, out, B, h, w, mask_scale, exp2_out, stream)
-                : launch<DT, 1, 8>(flow, mask, out, B, h, w, mask_scale, exp2_out, stream);
+    static const int forced_px = getenv("MV_UPS_PX") ? atoi(getenv("MV_UPS_PX")) : 0;  // A/B only
+    if constexpr (DT != MV_F32) {
+        // 16-bit masks: two pixels per lane (dword loads) when every plane starts on a dword
+        const bool pair = (forced_px ? forced_px == 2 : true) && hw % 2 == 0 && ((uintptr_t)mask & 3) == 0;
+        if (pair) {
+            const int nsx = forced ? forced : 4;
+            return nsx == 2 ? launch<DT, 2, 2>(flow, mask, out, B, h, w, mask_scale, exp2_out, stream)
+                 : nsx == 4 ? launch<DT, 2, 4>(flow, mask, out, B, h, w, mask_scale, exp2_out, stream)
+                            : launch<DT, 2, 8>(flow, mask, out, B, h, w, mask_scale, exp2_out, stream);
+        }
+    }
+    // enough waves for every SIMD of the chip (1024): half-width sub-column groups when the frame is small
+    const long waves8 = (long)mv_ceil_div(hw, 64) * 8 * B;
+    const int nsx = forced ? forced : (waves8 < 2048 ? 4 : 8);
+    return nsx == 2 ? launch<DT, 1, 2>(flow, mask, out, B, h, w, mask_scale, exp2_out, stream)
+         : nsx == 4 ? launch<DT, 1, 4>(flow, mask, out, B, h, w, mask_scale, exp2_out, stream)
+                    : launch<DT, 1, 8>(flow, mask, out, B, h, w, mask_scale, exp2_out, stream);
 }
 
 }  // namespace

@@ -49,11 +49,13 @@ def gather_tracks(poses: torch.Tensor, time_ns: torch.Tensor | None = None, dist
 
 
 def _all_gather(dist, out: torch.Tensor, mine: torch.Tensor) -> None:
-    if mine.is_cuda:   # RCCL over xGMI (backend "nccl")
+    if mine.is_cuda and dist.get_backend() != "gloo":   # RCCL over xGMI (backend "nccl")
         dist.all_gather_into_tensor(out, mine.contiguous())
-    else:              # gloo: list form
-        parts = [torch.empty_like(mine) for _ in range(out.shape[0])]
-        dist.all_gather(parts, mine.contiguous())
+    else:              # gloo: list form, on host tensors (gloo has no device all_gather: device tracks are staged through the host —
+        #                the 2-ranks-on-one-GPU test and CPU tests only; 36 B per frame)
+        src = mine.contiguous().cpu()
+        parts = [torch.empty_like(src) for _ in range(out.shape[0])]
+        dist.all_gather(parts, src)
         out.copy_(torch.stack(parts).view_as(out))
 
 

@@ -268,7 +268,7 @@ def maps_from_file(path: str):
 
 
 def run_case(name: str, mode: str, n_frames: int | None = None, seed: int = 1234, quiet: bool = True, maps_file: str = "",
-             mapping: int = -1, threads: int = 0, graph: str = "") -> dict:
+             mapping: int = -1, threads: int = 0, graph: str = "", repeat_maps: int = 1, cprofile: bool = False) -> dict:
     case = dict(CASES[name])
     if graph:
         case["graph"] = graph
@@ -289,6 +289,8 @@ def run_case(name: str, mode: str, n_frames: int | None = None, seed: int = 1234
         cam, maps, poses = synthetic_maps(n_frames or 8)
     if n_frames:
         maps, poses = maps[:n_frames], poses[:n_frames]
+    if repeat_maps > 1:      # a longer stream for steady-state timing: the same network outputs again (the loop does not care that the scene repeats)
+        maps, poses = maps * repeat_maps, poses.repeat(repeat_maps, 1)
     frames = make_stereo_frames(ref, cam, maps, poses)
     cfg = make_config(case, mode)
     ref.OM.MACVO.is_valid_config(cfg.Odometry)                     # the reference's own validator, before anything is added to the config
@@ -306,14 +308,31 @@ def run_case(name: str, mode: str, n_frames: int | None = None, seed: int = 1234
             torch.cuda.synchronize()
         stamps.append(time.perf_counter())
 
+    prof = None
+    if cprofile:
+        import cProfile
+
+        prof = cProfile.Profile()
     with tempfile.TemporaryDirectory() as tmp:
         box = ref.Sandbox(Path(tmp))
+        if prof is not None:
+            prof.enable()
         system.receive_frames(frames, box, on_frame_finished=on_frame)
+        if prof is not None:
+            prof.disable()
         assert system.terminated and os.path.exists(box.path("tensor_map.npz")), \
             "receive_frames swallowed an exception (Odometry/Interface.py:62-70): see the log above"
         tm = dict(np.load(box.path("tensor_map.npz")))
         out = {f"map/{k}": v for k, v in tm.items()}
         out["poses_npy"] = np.load(box.path("poses.npy"))
+    if prof is not None:
+        import pstats
+
+        st = pstats.Stats(prof)
+        skip = ("marshal", "builtins.exec", "importlib", "_imp.", "open_code", "posix.stat", "builtins.compile", "_io.")    # one-time imports, not per-frame costs
+        rows = sorted(((v[2], v[0], k) for k, v in st.stats.items() if not any(w in k[2] or w in k[0] for w in skip)), reverse=True)[:3]   # (tottime, calls, (file, line, name))
+        out["host_top"] = np.array(json.dumps([{"fn": f"{os.path.basename(k[0])}:{k[1]}:{k[2]}", "ms_per_frame": round(tt * 1e3 / max(1, len(frames) - 1), 3),
+                                                "calls_per_frame": round(nc / max(1, len(frames) - 1), 1)} for tt, nc, k in rows]))
     out["frame_s"] = np.diff(np.array(stamps))
     out["gt_poses"] = poses.numpy()
     out["n_frames"] = np.array(len(frames))
@@ -370,6 +389,8 @@ def main():
     ap.add_argument("--mapping", type=int, default=-1, help="override the case's dense-mapping flag (0 / 1)")
     ap.add_argument("--graph", default="", choices=["", "icp", "reproj", "disp"], help="override the case's residual graph")
     ap.add_argument("--threads", type=int, default=0, help="torch.set_num_threads for the run (0 = torch's default)")
+    ap.add_argument("--repeat-maps", type=int, default=1, help="replay the network outputs this many times in a row (steady-state timing)")
+    ap.add_argument("--cprofile", action="store_true", help="run the loop under cProfile and report the three largest host costs (own time) per frame")
     a = ap.parse_args()
     if a.golden:
         assert os.path.isdir("/root/reference/Odometry"), "--golden runs in the build container (needs /root/reference)"
@@ -384,11 +405,15 @@ def main():
         np.savez_compressed(path, **out)
         print(path, os.path.getsize(path) / 1e6, "MB")
         return
-    r = run_case(a.case, a.mode, n_frames=a.frames or None, quiet=not a.loud, maps_file=a.maps_file, mapping=a.mapping, threads=a.threads, graph=a.graph)
+    r = run_case(a.case, a.mode, n_frames=a.frames or None, quiet=not a.loud, maps_file=a.maps_file, mapping=a.mapping, threads=a.threads, graph=a.graph,
+                 repeat_maps=a.repeat_maps, cprofile=a.cprofile)
     if a.out:
         np.savez_compressed(a.out, **r)
     print(json.dumps({"case": a.case, "mode": a.mode, "frames": int(r["n_frames"]), "s_per_frame": float(r["frame_s"][1:].mean()),
                       "s_per_frame_steady": float(np.sort(r["frame_s"][2:])[: max(1, (len(r["frame_s"]) - 2) * 3 // 4)].mean()) if len(r["frame_s"]) > 3 else None,
+                      "s_per_frame_after5": float(r["frame_s"][5:].mean()) if len(r["frame_s"]) > 6 else None,
+                      "s_per_frame_median": float(np.median(r["frame_s"][1:])),
+                      "host_top": json.loads(str(r["host_top"])) if "host_top" in r else None,
                       "threads": torch.get_num_threads(),
                       "matches": int(r["map/match//pixel1_uv"].shape[0]), "classes": json.loads(str(r["classes"]))}))
 

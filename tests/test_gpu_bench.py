@@ -13,7 +13,7 @@ import pytest
 from tests import refrun
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-QUICK = ["--no-ramp", "--exact-steps", "0", "--config4-steps", "0", "--no-decoder-leg", "--pool", "6", "--end-to-end-frames", "0"]
+QUICK = ["--no-ramp", "--exact-steps", "0", "--config4-steps", "0", "--no-decoder-leg", "--pool", "6", "--end-to-end-frames", "0", "--plugin-frames", "0"]
 
 
 def _line(p):
@@ -59,3 +59,23 @@ def test_bench_line_parity_covers_the_kernels_it_times(gpu):
     else:
         assert cb["kind"] == "port"
     assert d["roofline"]["traffic_source"] is None or "NOT measured in this process" in d["roofline"]["traffic_source"]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_sharing_the_gpu(gpu):
+    """VERDICT r4 next #8 — what one GPU allows of the N > 1 path: ``bench.py --gpus 2 --share-gpu`` self-launches two ranks under
+    ``torch.distributed.run`` exactly as the driver's ``--gpus N`` does (rendezvous, OMP_NUM_THREADS derivation, per-rank core pinning), both ranks
+    run the real kernels on device 0, every collective of the timed region (barrier, gather_tracks of two device-resident tracks, all_reduce(MAX) of the
+    clock) crosses a real process boundary over gloo.  Not a scaling measurement (the ranks share one GPU) and the line says so; RCCL itself has still
+    only seen one rank (no multi-GPU box is available to the builder)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "12", "--warmup", "3", "--no-cpu-baseline"] + QUICK
+    d = _line(subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT))
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["rank_devices"] == [0, 0] and d["share_gpu_test_mode"] is True
+    assert d["rank_pose_tracks_finite"] == [True, True]                       # both ranks tracked their own sequence and both tracks arrived
+    assert d["value"] > 0 and d["steps"] == 12 and d["scaling"] == "weak"
+    sl = d["rank_core_slices"]
+    ncores = len(os.sched_getaffinity(0))
+    if ncores >= 4:                                                           # two distinct, disjoint core slices
+        assert sl[0] is not None and sl[1] is not None and sl[0][1] < sl[1][0], sl
+        assert d["host_cores_per_rank"] == ncores // 2
+    assert "no scaling curve" in d["multi_gpu_note"]
