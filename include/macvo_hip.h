@@ -619,7 +619,8 @@ typedef struct {
     const float* cov_mask;  /* [pairs, 576, H/8, W/8] }                                                       */
 } mvFrameInputs;
 
-/* buffers reported by mv_frame_pipe_buffer (element counts, not bytes); each has a leading [lanes] dimension, per-keypoint
+/* buffers reported by mv_frame_pipe_buffer (element counts, not bytes; MV_FB_VOLUME's element is the volume CELL: fp32, or fp16 — 2 bytes —
+ * when the pipe was created with volume_split = MV_VOL_ENC16); each has a leading [lanes] dimension, per-keypoint
  * tables are [lanes, num_point, .] (a lane's live rows = its n_sel), MV_FB_VALS is [11, lanes, num_point] */
 enum {
     MV_FB_VOLUME = 0, MV_FB_TOKENS, MV_FB_DISPARITY, MV_FB_DISPARITY_COV, MV_FB_DEPTH, MV_FB_DEPTH_COV, MV_FB_MATCH_FLOW,

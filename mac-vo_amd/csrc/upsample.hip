@@ -16,12 +16,12 @@
 //   * no early exit: tail lanes read clamped addresses and skip their stores;
 //   * softmax weights with ONE division per sub-pixel (r = 1/sum, then 9 multiplies) instead of nine;
 //   * a lane produces NSX contiguous floats per channel -> dwordx4 stores, a wave writes whole 2-KB row segments;
-//   * 16-bit masks (the decoder's autocast type in Fast mode, MACVO_Fast.yaml:73-74) are read as they are — two pixels per
-//     lane and dword loads where the plane size is even — and widened in registers: the arithmetic is the fp32 formula on
-//     the widened values, no 11 -> 22 MB `.float()` pass in front.
+//   * 16-bit masks (the decoder's autocast type in Fast mode, MACVO_Fast.yaml:73-74) are read as they are (16-bit loads, one
+//     pixel per lane) and widened in registers: the arithmetic is the fp32 formula on the widened values, no 11 -> 22 MB
+//     `.float()` pass in front.  (After the exp fix the kernel is bound by its ~850 VALU instructions per wave and by one
+//     memory round trip, not by bytes: the 16-bit form takes the same 7.4 us as the fp32 one.)
 #include "common.h"
 #include <math.h>
-#include <stdlib.h>
 
 namespace {
 
@@ -162,28 +162,15 @@ int launch(const float* flow, const void* mask, float* out, int B, int h, int w,
     return mv_launch_status();
 }
 
+// Measured on MI355X (profiles/r05_upsample_ab.log; B = 2 fields, back-to-back launches):
+//   fp32 mask   60x80: NSX 2 / 4 / 8 = 7.1 / 7.4 / 8.1 us;  90x160: 16.8 / 18.9 / 18.2 us    -> NSX = 2 (4800 waves at 60x80: 4.7 per SIMD)
+//   16-bit mask 60x80: NSX 2 / 4 = 7.4-7.8 / 7.4 us;        90x160: 15.4-16.8 / 15.1-15.6 us -> NSX = 4
+//   two pixels per lane with dword loads of a 16-bit mask (half the waves, the same loads per wave): 9.3-9.5 us / 17.5-21.9 us -> not built in
 template <int DT>
 int dispatch(const float* flow, const void* mask, float* out, int B, int h, int w, float mask_scale, int exp2_out,
              hipStream_t stream) {
-    const int hw = h * w;
-    static const int forced = getenv("MV_UPS_NSX") ? atoi(getenv("MV_UPS_NSX")) : 0;   // A/B only
-    static const int forced_px = getenv("MV_UPS_PX") ? atoi(getenv("MV_UPS_PX")) : 0;  // A/B only
-    if constexpr (DT != MV_F32) {
-        // 16-bit masks: two pixels per lane (dword loads) when every plane starts on a dword
-        const bool pair = (forced_px ? forced_px == 2 : true) && hw % 2 == 0 && ((uintptr_t)mask & 3) == 0;
-        if (pair) {
-            const int nsx = forced ? forced : 4;
-            return nsx == 2 ? launch<DT, 2, 2>(flow, mask, out, B, h, w, mask_scale, exp2_out, stream)
-                 : nsx == 4 ? launch<DT, 2, 4>(flow, mask, out, B, h, w, mask_scale, exp2_out, stream)
-                            : launch<DT, 2, 8>(flow, mask, out, B, h, w, mask_scale, exp2_out, stream);
-        }
-    }
-    // enough waves for every SIMD of the chip (1024): half-width sub-column groups when the frame is small
-    const long waves8 = (long)mv_ceil_div(hw, 64) * 8 * B;
-    const int nsx = forced ? forced : (waves8 < 2048 ? 4 : 8);
-    return nsx == 2 ? launch<DT, 1, 2>(flow, mask, out, B, h, w, mask_scale, exp2_out, stream)
-         : nsx == 4 ? launch<DT, 1, 4>(flow, mask, out, B, h, w, mask_scale, exp2_out, stream)
-                    : launch<DT, 1, 8>(flow, mask, out, B, h, w, mask_scale, exp2_out, stream);
+    if constexpr (DT == MV_F32) return launch<DT, 1, 2>(flow, mask, out, B, h, w, mask_scale, exp2_out, stream);
+    else return launch<DT, 1, 4>(flow, mask, out, B, h, w, mask_scale, exp2_out, stream);
 }
 
 }  // namespace

@@ -79,3 +79,17 @@ def test_bench_two_ranks_sharing_the_gpu(gpu):
         assert sl[0] is not None and sl[1] is not None and sl[0][1] < sl[1][0], sl
         assert d["host_cores_per_rank"] == ncores // 2
     assert "no scaling curve" in d["multi_gpu_note"]
+
+
+@pytest.mark.gpu
+def test_bench_fast_mode_line_checks_the_fp16_cell_kernels(gpu):
+    """ADVICE r4: with ``--feat-dtype f16 --layout hwc --volume-store encoder`` the pipe runs corr_volume_h_stream<out16> and the lookup on fp16 cells;
+    the line's parity block must exercise THOSE kernels (the pipe's own fp16 volume buffer and token buffer), with the fp16 bar, not the fp32 ones."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--cpu-frames", "2", "--parity-frames", "2", "--reference-frames", "0",
+           "--feat-dtype", "f16", "--layout", "hwc", "--volume-store", "encoder"] + QUICK
+    d = _line(subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT))
+    vl = d["parity"]["volume_and_lookups"]
+    assert "error" not in vl, vl
+    assert vl["volume_cell_dtype"] == "f16" and vl["volume_kernel"].startswith("corr_volume_h_stream<out16>"), vl
+    assert vl["volume_rows_sampled"] >= 96 and vl["volume_within_bar"] and vl["within_bar"] and vl["pipe_tokens_checked"] == 3
+    assert d["roofline"]["kernel"] == "corr_volume_h_stream<out16>" and d["roofline"]["bound"] == "hbm"
