@@ -88,6 +88,8 @@ def parse_args():
     ap.add_argument("--plugin-frames", type=int, default=12, help="distinct frames handed to the plugin_path leg (replayed 3 x through the reference's MACVO loop with "
                     "the HIP plugins); 0 = skip")
     ap.add_argument("--no-decoder-leg", action="store_true", help="skip the decoder-loop harness leg (HIP lookups / upsamplings interleaved with PyTorch-ROCm kernels)")
+    ap.add_argument("--host-randperm", action="store_true", help="one lane: draw the keypoint permutations with torch.randperm on the Python side (global CPU generator) "
+                    "instead of the driver's native MT19937 + partial Fisher-Yates (bit-identical draws)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="TEST ONLY (N > 1 ranks on a 1-GPU box): every rank drives device 0 and the collectives run over gloo — real kernels, real gather_tracks, real "
                          "core pinning, no RCCL; the line is marked and its value is not a scaling measurement")
@@ -635,7 +637,10 @@ def main():
         if native:
             # lanes > 1: integer seeds = the driver's native per-lane MT19937 generators (bit-identical to torch.Generator(seed) +
             # torch.randperm; 32 host-side torch.randperm calls per step were the bound of the 32-lane configuration)
-            gens = None if lanes == 1 else [seed + l for l in range(lanes)]
+            # lanes == 1 (round 5): the same native generator, seeded like the reference's `torch.manual_seed(seed)` — the line's parity block runs
+            # this very mechanism against the oracle / the reference loop on torch's global generator (keypoints bit-exact); --host-randperm
+            # restores torch.randperm on the Python side (45 us of host time per frame inside the selector -> backend gap)
+            gens = None if (lanes == 1 and args.host_randperm) else [seed + l for l in range(lanes)]
             return NativeHotPath(Camera(**cam), cfg, dev, lanes=lanes, generators=gens, keep_extras=keep_extras)
         return HotPath(Camera(**cam), cfg, dev)
 
@@ -682,7 +687,11 @@ def main():
         barrier()
         torch.cuda.synchronize()
         if native and n_ev:
-            hot.time_volume(n_ev)   # HIP-event pairs around the volume GEMM, recorded by the driver on its GEMM stream
+            # HIP-event pairs around the volume GEMM, recorded by the driver on its GEMM stream.  Only those (round 5): the six timeline events per
+            # frame on the other three streams are barrier packets inside the launch chains that bound a one-lane pipe; the timeline is collected in a
+            # separate untimed pass below
+            hot.time_detail(bool(os.environ.get("MV_BENCH_TIMELINE_IN_REGION")))
+            hot.time_volume(n_ev)
         t0 = time.perf_counter()
         # software-pipelined stream (frame t+1's frontend is queued before frame t's host randperm); K full run_pairs
         trace = [] if os.environ.get("MV_BENCH_TRACE") else None   # host time of every finished step (diagnostics, stderr)
@@ -714,7 +723,15 @@ def main():
                     pass
             ms = hot.volume_times_ms()
             # where a step's time goes, from the HIP events the driver records on its own streams (tools/lane_timeline.py):
-            # GEMM start -> next GEMM start = period; the part of it the GEMM stream idles; how far the decoder-side chain lags
+            # GEMM start -> next GEMM start = period; the part of it the GEMM stream idles; how far the decoder-side chain lags.
+            # Untimed pass over the same stream with all eight events per frame.
+            if not os.environ.get("MV_BENCH_TIMELINE_IN_REGION"):
+                n_tl = min(200, n_ev)
+                hot.time_detail(True)
+                hot.time_volume(n_tl)
+                t_idx += max(extra, 0)
+                for _ in hot.run(batches[(t_idx + k) % args.pool] for k in range(n_tl)):
+                    pass
             tl = hot.timeline_ms()
             if len(tl) > 12:
                 import statistics as st
@@ -885,7 +902,7 @@ def main():
         # forcing), same CPU generator seed -> keypoints must be identical, poses within 1e-4; RTE per MetricsSeq.py:9-16
         if native and args.volume_precision in ("exact", "bf16x3", "f16x2") and args.feat_dtype == "f32":
             n_par = min(len(ora_track), max(args.parity_frames, 2))
-            hot = make_pipe(1, 0, keep_extras=True)
+            hot = make_pipe(1, 1234, keep_extras=True)       # native generator seeded 1234 (or, --host-randperm, the global generator below)
             torch.manual_seed(1234)
             hot.initialize(frames[0])
             sink = torch.zeros((n_par, 7), dtype=torch.float32, device=dev)
@@ -1085,6 +1102,9 @@ def main():
                                    f"+ epilogue + CovAwareSelector_NoDepth(200) + 2x MatchCovariance(31x31) + TwoFrame_PGO({args.graph})",
                        "lanes": args.lanes, "feature_dtype": args.feat_dtype, "feature_layout": args.layout,
                        "volume_precision": args.volume_precision, "hip_graphs": use_graphs, "host_driver": args.driver, "backend_launch_thread": (os.environ.get("MV_PIPE_ASYNC_BACKEND", "1") != "0") if args.driver == "native" else False,
+                       "keypoint_permutations": ("torch.randperm on the Python side (global CPU generator)" if (args.host_randperm or not native) else
+                                                 "driver-native MT19937 + partial Fisher-Yates seeded like torch.manual_seed (bit-identical to torch.randperm: "
+                                                 "the parity block runs this mechanism against the oracle and the reference loop on torch's global generator)"),
                        "clock_ramp_s": 0.0 if args.no_ramp else RAMP_SECONDS,
                        "excluded": "learned FlowFormer layers (source + weights absent from the reference checkout)",
                        "parallelism": f"{world * args.lanes} independent sequence(s), {args.lanes} per GPU; one all_gather of poses + timestamps"},

@@ -381,6 +381,23 @@ int mv_pgo_solve(int nprob, const int32_t* offsets, int graph_type, const float*
                  const double* obs2_covTc, const uint8_t* valid, int min_points,
                  const mvLMParams* params /* host */, double* out_pose, double* out_info,
                  float* out_pose_f32, mvStream_t stream);
+/* mv_pgo_solve with the rest of the backend folded into the same launch (Module/OutlierFilter.py:91-141, Odometry/MACVO.py:273-281,
+ * Optimizer.py:81-102).  Before a problem's rows are read its workgroup
+ *   (1) filter_flags >= 0: runs the observation filters of mv_obs_filter_lanes over the problem's rows (inbound, cov_Tc = cov1, obs2_covTc = cov2, the
+ *       [11, nprob, cap] value table `vals`; cap = rows per problem) and writes `valid_out` / `count_out` [nprob] — the solve then reads valid_out;
+ *       filter_flags < 0: `valid` is an input as in mv_pgo_solve;
+ *   (2) rotates the first n_live[prob] rows into the world frame with the problem's init_pose — pos_Tw = T p_cam (fp32 PyPose SE3 Act), cov_Tw = R cov_Tc
+ *       R^T (fp64), out_rot [nprob, 9] = R — mv_pose_apply_lanes' arithmetic, written to pos_Tw / cov_Tw (cov_Tc / cov_Tw may both be NULL).
+ * Same bits as the separate kernels.  pose_sink (or NULL): a second fp32 copy of the optimised poses [nprob, 7].  nprob <= MV_MAX_LANES; offsets must be
+ * the static table {0, cap, 2 cap, ...} when the filters are folded in.  n_live: host int32 [nprob]. */
+int mv_pgo_solve_posed(int nprob, const int32_t* offsets, const int32_t* n_live, int cap, int graph_type, const float* init_pose,
+                       const float* intrinsics, const float* baseline, const float* pos_Tc, const double* cov_Tc,
+                       float* pos_Tw, double* cov_Tw, double* out_rot, const float* pixel2_uv, const float* pixel2_d,
+                       const float* pixel2_disp, const float* pixel2_disp_cov, const float* pixel2_uv_cov,
+                       const double* obs2_covTc, int filter_flags, float filter_min_depth, float filter_max_depth,
+                       const uint8_t* inbound, const float* vals, uint8_t* valid, int32_t* count_out, int min_points,
+                       const mvLMParams* params, double* out_pose, double* out_info, float* out_pose_f32, float* pose_sink,
+                       mvStream_t stream);
 
 /* -------------------------------------------------------------------------------------------
  * A23  PWC-Net local correlation, forward (the reference's only hand-written CUDA kernel; non-default matcher path).
@@ -526,6 +543,16 @@ int mv_kp_front_lanes(const int32_t* cand, size_t cand_lane_stride, const int64_
                       float fx, float fy, float cx, float cy, int64_t* out_kp0_uv /* [lanes, cap, 2] */, float* out_kp0,
                       float* out_kp1, uint8_t* out_inbound, float* out_vals /* [11, lanes, cap] */, float* out_sigma0,
                       float* out_sigma1, float* out_pos_Tc /* [lanes, cap, 3] */, mvStream_t stream);
+/* The pose-INDEPENDENT half of a frame's backend in one launch: mv_kp_front_lanes + mv_match_cov_pair_lanes (patch variance, no
+ * rotation) — Odometry/MACVO.py:197-262, Module/Covariance/Project2to3.py:124-181 — with the same results bit for bit.  A wave = one keypoint of one of
+ * the two keypoint sets.  cov_params: H, W, intrinsics, kernel size and clamps (use_patch_var must be 1).  The observation filters that follow are the
+ * prologue of mv_pgo_solve_posed. */
+int mv_backend_front_lanes(const int32_t* cand, size_t cand_lane_stride, const int64_t* perm_dev, const int64_t* perm_host, int lanes,
+                           const int32_t* n_live, int cap, const float* match_flow, const float* match_cov, const float* depth0,
+                           const float* disp0, const float* sdisp0, const float* sdd0, const float* depth1, const float* disp1,
+                           const float* sdisp1, const float* sdd1, int edge, float match_cov_default, const mvMatchCovParams* cov_params,
+                           int64_t* out_kp0_uv, float* out_kp0, float* out_kp1, uint8_t* out_inbound, float* out_vals, float* out_sigma0,
+                           float* out_sigma1, float* out_pos_Tc, double* out_cov0, double* out_cov1, mvStream_t stream);
 int mv_kp_track_lanes(const int64_t* kp0_uv, int lanes, const int32_t* n_live /* host */, int cap, const float* match_flow,
                       const float* match_cov, const float* depth0, const float* disp0, const float* sdisp0,
                       const float* sdd0, const float* depth1, const float* disp1, const float* sdisp1, const float* sdd1,
@@ -690,6 +717,10 @@ int mv_frame_pipe_sync(mvFramePipe* p, mvStream_t stream, int block_host);
  * stream they run on (0 = off; restarts the count), and read the elapsed milliseconds back (blocks on that stream) */
 int mv_frame_pipe_time_volume(mvFramePipe* p, int max_launches);
 int mv_frame_pipe_volume_times(mvFramePipe* p, float* ms, int cap, int* n);
+/* on = 0: a timed frame records ONLY the event pair around its volume GEMM (what the roofline needs), not the six timeline events on the other three
+ * streams — each is a barrier packet on a stream whose launch chain bounds a one-lane pipe; mv_frame_pipe_timeline[_backend] then report no frames.
+ * Default 1.  bench.py times the contract's K steps with 0 and collects the timeline in a separate untimed pass. */
+int mv_frame_pipe_time_detail(mvFramePipe* p, int on);
 /* per timed frame: {GEMM start, GEMM end, last lookup done, selector done} in ms since the first timed GEMM start */
 int mv_frame_pipe_timeline(mvFramePipe* p, float* ms, int cap_frames, int* n);
 /* ... and {backend start, backend end, pose_apply start, solve end} of the same frames (-1: not finished / no keypoints) */

@@ -121,6 +121,10 @@ SIGNATURES = {
     "mv_lm_default_params": (None, [C.POINTER(mvLMParams)]),
     "mv_pgo_solve": (C.c_int, [C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int,
                                C.POINTER(mvLMParams), _P, _P, _P, _P]),
+    "mv_pgo_solve_posed": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int] + [_P] * 14 + [C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, C.c_int,
+                                     C.POINTER(mvLMParams)] + [_P] * 5),
+    "mv_backend_front_lanes": (C.c_int, [_P, C.c_size_t, _P, _P, C.c_int, _P, C.c_int] + [_P] * 10 + [C.c_int, C.c_float, C.POINTER(mvMatchCovParams)] +
+                               [_P] * 11),
     "mv_backproject": (C.c_int, [_P, _P, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_int,
                                  _P, _P, _P, _P]),
     "mv_obs_filter": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P, _P]),
@@ -172,6 +176,7 @@ SIGNATURES = {
     "mv_frame_pipe_sync": (C.c_int, [_P, _P, C.c_int]),
     "mv_frame_pipe_time_volume": (C.c_int, [_P, C.c_int]),
     "mv_frame_pipe_volume_times": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
+    "mv_frame_pipe_time_detail": (C.c_int, [_P, C.c_int]),
     "mv_randperm_heads": (C.c_int, [C.c_uint64, _P, C.c_int, C.c_int, _P]),
     "mv_frame_pipe_timeline": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     "mv_frame_pipe_timeline_backend": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),

@@ -24,6 +24,8 @@
 // cross-stream hazards are closed with events (see `enqueue` / `finish`).
 #include "common.h"
 #include <atomic>
+#include <chrono>
+#include <stdio.h>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -100,6 +102,7 @@ struct FinishJob {
     bool seeded;
     std::vector<int64_t> perm;      // explicit permutations [lanes, cap] (asynchronous issue: a copy of the caller's array)
     float* pose_sink;
+    double t_count = 0, t_submit = 0;   // host clock (us): candidate count seen / job queued (MV_PIPE_HOST_STATS)
     bool has_sel;                   // MV_PIPE_SELECTOR_ON=late: the selector segment of the newest enqueued frame rides behind this backend
     SelSeg sel;
 };
@@ -152,6 +155,7 @@ struct mvFramePipe {
     float* pose[3];   // [lanes, 7]
     float *intr, *bl;   // [lanes, 4], [lanes]
     int32_t* offs;    // [lanes + 1]: lane l owns rows [l * cap, (l + 1) * cap) of the backend tables
+    int fuse_backend; // 1 (default): backend = mv_backend_front_lanes + mv_pgo_solve_posed, two launches; MV_PIPE_FUSE_BACKEND=0: the five-launch form
     // host
     int32_t* h_count[N_CAND];      // pinned
     int64_t* h_perm[N_PERM];  // pinned
@@ -205,6 +209,7 @@ struct mvFramePipe {
     std::vector<hipEvent_t> tv0, tv1, tv2, tv3;   // GEMM start / end, last lookup done, selector done (timeline hook)
     std::vector<hipEvent_t> tv4, tv5, tv6, tv7;   // backend start / end (backend stream), pose_apply start / solve end (solve stream)
     int n_timed, timed_cap;
+    int time_detail;   // 1 (default): a timed frame also records the six timeline events tv2..tv7 on three streams; 0: only the pair around its GEMM
     // Backend launch thread (round 3).  A one-lane stream is bound by the HOST: ~38 launches per frame at ~4 us each on one thread
     // (tools/host_breakdown.py: 172 us of host time per frame, 6 us of it waiting for the GPU).  With `async_backend` the ~10
     // launches of `finish` + the permutation draw are issued by this thread while the caller's thread already enqueues the next
@@ -221,6 +226,11 @@ struct mvFramePipe {
     std::condition_variable cv_job, cv_done;
     std::deque<FinishJob> jobs;
     long issued;            // finishes whose launches have all been issued (guarded by mu)
+    std::atomic<long> n_submitted{0};   // jobs ever queued: what the launch thread spins on
+    std::atomic<bool> stop_flag{false};
+    double spin_us;         // how long the launch thread spins for the next job before it sleeps (MV_PIPE_LAUNCH_SPIN_US, default 250)
+    int host_stats;         // MV_PIPE_HOST_STATS=1: mean host latencies of the selector-count -> backend-launch chain, printed by destroy
+    double st_n = 0, st_count_to_submit = 0, st_submit_to_pick = 0, st_pick_to_issued = 0, st_wait = 0;
     bool stop;
     int async_rc;           // first error of an asynchronously issued job, reported by the next call
 };
@@ -369,9 +379,14 @@ extern "C" void mv_frame_pipe_destroy(mvFramePipe* p) {
             std::lock_guard<std::mutex> lk(p->mu);
             p->stop = true;
         }
+        p->stop_flag.store(true, std::memory_order_relaxed);
         p->cv_job.notify_all();
         p->worker.join();   // (drains the queue first)
     }
+    if (p->host_stats && p->st_n > 0)
+        fprintf(stderr, "[mv_frame_pipe host stats] finishes %.0f: wait for the candidate count %.1f us, count seen -> job queued %.1f us, queued -> picked up by the "
+                        "launch thread %.1f us, picked up -> every launch issued %.1f us (means per frame)\n",
+                p->st_n, p->st_wait / p->st_n, p->st_count_to_submit / p->st_n, p->st_submit_to_pick / p->st_n, p->st_pick_to_issued / p->st_n);
     (void)hipStreamSynchronize(p->s_vol);
     (void)hipStreamSynchronize(p->s_main);
     (void)hipStreamSynchronize(p->s_back);
@@ -522,6 +537,8 @@ static int create_impl(mvFramePipe* p) {
     MV_HIP(hipMemcpyAsync(p->intr, intr.data(), intr.size() * sizeof(float), hipMemcpyHostToDevice, p->s_main));
     MV_HIP(hipMemcpyAsync(p->bl, bl.data(), bl.size() * sizeof(float), hipMemcpyHostToDevice, p->s_main));
     MV_HIP(hipMemcpyAsync(p->offs, offs.data(), offs.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->s_main));
+    { const char* e = getenv("MV_PIPE_FUSE_BACKEND"); p->fuse_backend = (e && atoi(e) == 0) ? 0 : 1; }
+    p->time_detail = 1;
     MV_HIP(hipStreamSynchronize(p->s_main));   // the host vectors die here
     return MV_OK;
 }
@@ -597,6 +614,8 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
         const int want = cfg->async_backend ? cfg->async_backend : (e ? (atoi(e) ? 1 : -1) : MV_ASYNC_DEFAULT(p));
         p->async_backend = want > 0 ? 1 : 0;
         if (hipGetDevice(&p->device) != hipSuccess) p->async_backend = 0;
+        { const char* e3 = getenv("MV_PIPE_LAUNCH_SPIN_US"); p->spin_us = e3 ? atof(e3) : 250.0; }
+        { const char* e4 = getenv("MV_PIPE_HOST_STATS"); p->host_stats = e4 ? atoi(e4) : 0; }
         if (p->async_backend) p->worker = std::thread(launch_thread_main, p);
     }
     *out = p;
@@ -800,7 +819,7 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
     const bool ahead = p->n_vol != f;
     if (!ahead) MV_TRY(issue_volume(p, in, in_stream));
     const int kv = (int)(f % p->n_volbuf);   // volume buffer of this frame (k = its candidate / backend slot)
-    const int ti = p->vol_timed[kv];
+    const int ti = p->time_detail ? p->vol_timed[kv] : -1;   // timeline slot (the GEMM's own event pair was recorded by issue_volume)
     const bool timed = ti >= 0;
 
     // ---- decoder side on `main`, overlapping the next frame's GEMM.  (MV_PIPE_LOOKUPS_ON=vol keeps the lookups on the
@@ -995,7 +1014,19 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
     static int pose_split = -1;   // MV_PIPE_POSE_SPLIT=0: the whole backend behind the previous solve, as before (A/B knob)
     if (pose_split < 0) { const char* e = getenv("MV_PIPE_POSE_SPLIT"); pose_split = (e && atoi(e) == 0) ? 0 : 1; }
     if (!pose_split && p->pgo_valid) MV_TRY(wait_if_pending(s, p->e_pgo));
-    if (fuse_front) {
+    const bool fused = p->fuse_backend && fuse_front;
+    mvMatchCovParams cp{c.H, c.W, c.cov_kernel_size, 1, c.fx, c.fy, c.cx, c.cy, c.min_flow_cov_sq, c.min_depth_cov};
+    if (fused) {
+        // gather + track + back-projection + both covariance models + observation filters = ONE launch
+        MV_TRY(mv_backend_front_lanes(p->cand[pd.cand], (size_t)p->plane, b.perm, perm_in_args ? p->h_perm[ps] : nullptr, L, n_sel, cap,
+                                      m1.match_flow, m1.match_cov, m0.depth, m0.disparity, m0.disparity_cov, m0.depth_cov, m1.depth, m1.disparity,
+                                      m1.disparity_cov, m1.depth_cov, c.edgewidth, c.match_cov_default, &cp, b.kp0, b.kp0f, b.kp1, b.inbound, b.vals,
+                                      b.sigma0, b.sigma1, b.pos_Tc, b.cov0, b.cov1, s));
+        // (the observation filters: prologue of the solve's launch below; mapping mode needs the count on the host first and keeps the launch)
+        if (c.mapping)
+            MV_TRY(mv_obs_filter_lanes(b.inbound, b.cov0, b.cov1, b.vals, c.filters, c.filter_min_depth, c.max_depth, L, n_sel, cap,
+                                       b.valid, b.n_valid, s));
+    } else if (fuse_front) {
         MV_TRY(mv_kp_front_lanes(p->cand[pd.cand], (size_t)p->plane, b.perm, perm_in_args ? p->h_perm[ps] : nullptr, L, n_sel, cap,
                                  m1.match_flow, m1.match_cov, m0.depth, m0.disparity, m0.disparity_cov, m0.depth_cov, m1.depth,
                                  m1.disparity, m1.disparity_cov, m1.depth_cov, c.H, c.W, c.edgewidth, c.match_cov_default, c.fx, c.fy,
@@ -1007,11 +1038,12 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
         MV_TRY(mv_backproject_lanes(b.kp0f, b.vals, 1, (size_t)cap, c.fx, c.fy, c.cx, c.cy, nullptr, L, n_sel, cap, b.pos_Tc,
                                     nullptr, nullptr, s));
     }
-    mvMatchCovParams cp{c.H, c.W, c.cov_kernel_size, 1, c.fx, c.fy, c.cx, c.cy, c.min_flow_cov_sq, c.min_depth_cov};
-    MV_TRY(mv_match_cov_pair_lanes(m0.depth, b.kp0f, b.sigma0, nullptr, b.cov0, nullptr, m1.depth, b.kp1, b.sigma1, b.cov1, &cp,
-                                   L, n_sel, cap, s));
-    MV_TRY(mv_obs_filter_lanes(b.inbound, b.cov0, b.cov1, b.vals, c.filters, c.filter_min_depth, c.max_depth, L, n_sel, cap,
-                               b.valid, b.n_valid, s));
+    if (!fused) {
+        MV_TRY(mv_match_cov_pair_lanes(m0.depth, b.kp0f, b.sigma0, nullptr, b.cov0, nullptr, m1.depth, b.kp1, b.sigma1, b.cov1, &cp,
+                                       L, n_sel, cap, s));
+        MV_TRY(mv_obs_filter_lanes(b.inbound, b.cov0, b.cov1, b.vals, c.filters, c.filter_min_depth, c.max_depth, L, n_sel, cap,
+                                   b.valid, b.n_valid, s));
+    }
     if (c.mapping) {   // the mapping decision of this frame (MACVO.py:303-307) needs the observation count on the host
         MV_HIP(hipMemcpyAsync(p->h_nvalid[k], b.n_valid, (size_t)L * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         MV_HIP(hipEventRecord(p->e_nvalid[k], s));
@@ -1028,17 +1060,29 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
     MV_HIP(hipStreamWaitEvent(ss, p->e_backend[k], 0));
     const float* pose = p->pose[j.pose_from];
     if (ti >= 0) MV_HIP(hipEventRecord(p->tv6[ti], ss));
-    MV_TRY(mv_pose_apply_lanes(pose, b.pos_Tc, b.cov0, L, n_sel, cap, b.pos_Tw, b.rot, b.cov0w, ss));
-    MV_HIP(hipEventRecord(p->e_posed[k], ss));
     const size_t N = (size_t)cap;
     const size_t LN = (size_t)L * N;   // value table is [11, lanes, cap]: each of its rows is one concatenated per-point column
-    MV_TRY(mv_pgo_solve(L, p->offs, c.graph_type, pose, p->intr, p->bl, b.pos_Tw, b.cov0w, b.kp1, b.vals + 4 * LN,
-                        b.vals + 5 * LN, b.vals + 6 * LN, b.sigma1, b.cov1, b.valid, c.min_num_point, &c.lm, b.pose64, b.info,
-                        p->pose[j.pose_to], ss));
-    if (j.pose_sink)
-        MV_HIP(hipMemcpyAsync(j.pose_sink, p->pose[j.pose_to], (size_t)L * 7 * sizeof(float), hipMemcpyDeviceToDevice, ss));
-    MV_HIP(hipEventRecord(p->e_pgo, ss));
-    MV_HIP(hipEventRecord(p->e_solved[k], ss));
+    if (p->fuse_backend) {
+        // ... and the pose-dependent half = ONE launch: the rotation into the world frame is the solve kernel's prologue, the caller's pose
+        // sink its second output (the 28-byte device-to-device copy was a DMA node on the critical stream).  No e_posed: the world-frame
+        // tables are consumed behind e_solved (mv_frame_pipe_map_append).
+        MV_TRY(mv_pgo_solve_posed(L, p->offs, n_sel, cap, c.graph_type, pose, p->intr, p->bl, b.pos_Tc, b.cov0, b.pos_Tw, b.cov0w, b.rot, b.kp1,
+                                  b.vals + 4 * LN, b.vals + 5 * LN, b.vals + 6 * LN, b.sigma1, b.cov1, c.mapping ? -1 : c.filters, c.filter_min_depth,
+                                  c.max_depth, b.inbound, b.vals, b.valid, b.n_valid, c.min_num_point, &c.lm, b.pose64, b.info,
+                                  p->pose[j.pose_to], j.pose_sink, ss));
+        MV_HIP(hipEventRecord(p->e_solved[k], ss));
+        MV_HIP(hipEventRecord(p->e_pgo, ss));
+    } else {
+        MV_TRY(mv_pose_apply_lanes(pose, b.pos_Tc, b.cov0, L, n_sel, cap, b.pos_Tw, b.rot, b.cov0w, ss));
+        MV_HIP(hipEventRecord(p->e_posed[k], ss));
+        MV_TRY(mv_pgo_solve(L, p->offs, c.graph_type, pose, p->intr, p->bl, b.pos_Tw, b.cov0w, b.kp1, b.vals + 4 * LN,
+                            b.vals + 5 * LN, b.vals + 6 * LN, b.sigma1, b.cov1, b.valid, c.min_num_point, &c.lm, b.pose64, b.info,
+                            p->pose[j.pose_to], ss));
+        if (j.pose_sink)
+            MV_HIP(hipMemcpyAsync(j.pose_sink, p->pose[j.pose_to], (size_t)L * 7 * sizeof(float), hipMemcpyDeviceToDevice, ss));
+        MV_HIP(hipEventRecord(p->e_pgo, ss));
+        MV_HIP(hipEventRecord(p->e_solved[k], ss));
+    }
     if (ti >= 0) MV_HIP(hipEventRecord(p->tv7[ti], ss));
     p->pgo_valid = true;
     p->solved_valid[k] = true;
@@ -1054,10 +1098,26 @@ static const int64_t* draw_perms(mvFramePipe* p, const FinishJob& j) {
 }
 
 // ------------------------------------------------------------------------------------------------ backend launch thread
+static inline double now_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 static void launch_thread_main(mvFramePipe* p) {
     (void)hipSetDevice(p->device);
+    long taken = 0;
     for (;;) {
         FinishJob j;
+        // A job arrives once per frame period (~150 us) and sits on the frame's critical chain (selector count -> backend): waking a thread that
+        // sleeps on a condition variable costs 30-60 us of it.  Spin on the submission counter for up to MV spin_us first (one period and a half),
+        // sleep only when the stream has really gone quiet.
+        if (p->spin_us > 0) {
+            const double t_end = now_us() + p->spin_us;
+            int it = 0;
+            while (p->n_submitted.load(std::memory_order_acquire) == taken && !p->stop_flag.load(std::memory_order_relaxed)) {
+                __builtin_ia32_pause();
+                if ((++it & 255) == 0 && now_us() > t_end) break;
+            }
+        }
         {
             std::unique_lock<std::mutex> lk(p->mu);
             p->cv_job.wait(lk, [&] { return p->stop || !p->jobs.empty(); });
@@ -1065,7 +1125,11 @@ static void launch_thread_main(mvFramePipe* p) {
             j = std::move(p->jobs.front());
             p->jobs.pop_front();
         }
+        ++taken;
+        const double t_pick = now_us();
+        if (p->host_stats) { p->st_n += 1; p->st_submit_to_pick += t_pick - j.t_submit; p->st_count_to_submit += j.t_submit - j.t_count; }
         int rc = finish_issue(p, j, j.seeded ? draw_perms(p, j) : j.perm.data());
+        if (p->host_stats) p->st_pick_to_issued += now_us() - t_pick;
         if (rc == MV_OK && j.has_sel) rc = issue_selector_segment(p, j.sel);
         {
             std::lock_guard<std::mutex> lk(p->mu);
@@ -1095,11 +1159,13 @@ static int submit_or_issue(mvFramePipe* p, FinishJob& j, const int64_t* perm_hos
         j.perm.assign(perm_host, perm_host + (size_t)p->lanes * cap);
     }
     int rc;
+    j.t_submit = now_us();
     {
         std::lock_guard<std::mutex> lk(p->mu);
         rc = p->async_rc;
         p->jobs.push_back(std::move(j));
     }
+    p->n_submitted.fetch_add(1, std::memory_order_release);
     p->cv_job.notify_one();
     return rc;
 }
@@ -1109,9 +1175,12 @@ extern "C" int mv_frame_pipe_finish_seeded(mvFramePipe* p, float* pose_sink, int
     MV_CHECK_ARG(p && !p->pending.empty() && (int)p->rng.size() == p->lanes);
     MV_TRY(selector_of_front_issued(p));
     const Pending& pd = p->pending.front();
+    const double t_w0 = p->host_stats ? now_us() : 0.0;
     MV_HIP(hipEventSynchronize(p->e_cand[pd.cand]));
     FinishJob j{};
     j.seeded = true;
+    j.t_count = now_us();
+    if (p->host_stats) p->st_wait += j.t_count - t_w0;
     int32_t nsel[MV_MAX_LANES];
     for (int l = 0; l < p->lanes; ++l) {
         const int64_t n = p->h_count[pd.cand][4 * l];
@@ -1176,7 +1245,7 @@ extern "C" int mv_frame_pipe_map_append(mvFramePipe* p, const mvMapStores* store
     f.baseline = baseline;
     f.time_ns = time_ns;
     f.out_frame_idx = nullptr;
-    MV_HIP(hipStreamWaitEvent(p->s_back, p->e_posed[g & 1], 0));   // pos_Tw / cov0_world come from the side stream
+    MV_HIP(hipStreamWaitEvent(p->s_back, p->fuse_backend ? p->e_solved[g & 1] : p->e_posed[g & 1], 0));   // pos_Tw / cov0_world come from the side stream
     MV_TRY(mv_map_append(&f, stores, p->s_back));
     MV_HIP(hipEventRecord(p->e_map, p->s_back));
     // the backend tables must outlive the append: later backends run on the same stream (ordered); the optimised pose goes
@@ -1298,6 +1367,13 @@ extern "C" int mv_frame_pipe_time_volume(mvFramePipe* p, int max_launches) {
     return MV_OK;
 }
 
+extern "C" int mv_frame_pipe_time_detail(mvFramePipe* p, int on) {
+    MV_CHECK_ARG(p);
+    MV_TRY(flush_jobs(p));
+    p->time_detail = on ? 1 : 0;
+    return MV_OK;
+}
+
 extern "C" int mv_frame_pipe_volume_times(mvFramePipe* p, float* ms, int cap, int* n) {
     MV_CHECK_ARG(p && n && cap >= 0 && (cap == 0 || ms));
     MV_TRY(flush_jobs(p));
@@ -1313,6 +1389,7 @@ extern "C" int mv_frame_pipe_volume_times(mvFramePipe* p, float* ms, int cap, in
 extern "C" int mv_frame_pipe_timeline(mvFramePipe* p, float* ms, int cap_frames, int* n) {
     MV_CHECK_ARG(p && n && cap_frames >= 0 && (cap_frames == 0 || ms));
     MV_TRY(flush_jobs(p));   // in the 'late' selector placement tv3 is recorded on the launch thread
+    if (!p->time_detail) { *n = 0; return MV_OK; }   // only the GEMM pairs were recorded
     MV_HIP(hipStreamSynchronize(p->s_vol));
     MV_HIP(hipStreamSynchronize(p->s_main));
     MV_HIP(hipStreamSynchronize(p->s_back));
@@ -1332,6 +1409,7 @@ extern "C" int mv_frame_pipe_timeline(mvFramePipe* p, float* ms, int cap_frames,
 extern "C" int mv_frame_pipe_timeline_backend(mvFramePipe* p, float* ms, int cap_frames, int* n) {
     MV_CHECK_ARG(p && n && cap_frames >= 0 && (cap_frames == 0 || ms));
     MV_TRY(flush_jobs(p));
+    if (!p->time_detail) { *n = 0; return MV_OK; }
     MV_HIP(hipStreamSynchronize(p->s_back));
     MV_HIP(hipStreamSynchronize(p->s_side));
     const int m = p->n_timed < cap_frames ? p->n_timed : cap_frames;

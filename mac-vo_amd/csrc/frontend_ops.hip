@@ -8,6 +8,9 @@
 // mv_kp_track replaces Odometry/MACVO.py:198-232 (kp1 = kp0 + flow[kp0], strict border filter of
 //   Utility/Point.py:5-13, and the ten retrieve_pixels gathers of Module/Frontend/Frontend.py:103-118).
 #include "common.h"
+#include "match_cov_dev.h"
+#include "pose_apply_dev.h"
+#include "obs_filter_dev.h"
 #include <math.h>
 
 namespace {
@@ -157,15 +160,6 @@ __global__ __launch_bounds__(256) void kp_front_kernel(const int32_t* __restrict
     pos_Tc[3 * n + 2] = ((v - cy) * d) / fy;
 }
 
-// pp.SO3.matrix() in the pose dtype (fp32): columns are SO3_Act(q, e_i)  (PyPose: self.Act(I).T)
-__device__ __forceinline__ void quat_act_f32(const float* q, const float* p, float* o) {
-    float uv0 = q[1] * p[2] - q[2] * p[1], uv1 = q[2] * p[0] - q[0] * p[2], uv2 = q[0] * p[1] - q[1] * p[0];
-    uv0 += uv0; uv1 += uv1; uv2 += uv2;
-    o[0] = (p[0] + q[3] * uv0) + (q[1] * uv2 - q[2] * uv1);
-    o[1] = (p[1] + q[3] * uv1) + (q[2] * uv0 - q[0] * uv2);
-    o[2] = (p[2] + q[3] * uv2) + (q[0] * uv1 - q[1] * uv0);
-}
-
 __global__ __launch_bounds__(256) void backproject_kernel(const float* __restrict__ kp_uv,
                                                           const float* __restrict__ depth_vals, int depth_stride,
                                                           float fx, float fy, float cx, float cy,
@@ -234,42 +228,14 @@ __global__ __launch_bounds__(256) void pose_apply_kernel(const float* __restrict
         if (cov_rot) cov_rot += 9 * ln;
         if (rot) rot += 9 * lane;
     }
-    const float t[3] = {pose[0], pose[1], pose[2]}, q[4] = {pose[3], pose[4], pose[5], pose[6]};
     double R[9];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float e[3] = {c == 0 ? 1.f : 0.f, c == 1 ? 1.f : 0.f, c == 2 ? 1.f : 0.f};
-        float col[3];
-        quat_act_f32(q, e, col);
-        R[0 * 3 + c] = (double)col[0];
-        R[1 * 3 + c] = (double)col[1];
-        R[2 * 3 + c] = (double)col[2];
-    }
+    mv_pose_rotation(pose, R);
     if (n == 0 && rot) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) rot[i] = R[i];
     }
     if (n >= N) return;
-    if (pos_Tw && pos_Tc) {
-        const float p[3] = {pos_Tc[3 * n], pos_Tc[3 * n + 1], pos_Tc[3 * n + 2]};
-        float r[3];
-        quat_act_f32(q, p, r);
-        pos_Tw[3 * n] = r[0] + t[0]; pos_Tw[3 * n + 1] = r[1] + t[1]; pos_Tw[3 * n + 2] = r[2] + t[2];
-    }
-    if (cov_rot && cov) {
-        double c[9], tm[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) c[i] = cov[(size_t)n * 9 + i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) tm[3 * i + j] = (R[3 * i] * c[j] + R[3 * i + 1] * c[3 + j]) + R[3 * i + 2] * c[6 + j];
-        double* o = cov_rot + (size_t)n * 9;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) o[3 * i + j] = (tm[3 * i] * R[3 * j] + tm[3 * i + 1] * R[3 * j + 1]) + tm[3 * i + 2] * R[3 * j + 2];
-    }
+    mv_pose_apply_row(pose, R, n, pos_Tc, cov, pos_Tw, cov_rot);
 }
 
 // Dense-mapping tail of run_pair (Odometry/MACVO.py:315-325,334): per selected map pixel gather depth and depth variance,
@@ -318,52 +284,69 @@ __global__ __launch_bounds__(256) void obs_filter_kernel(const uint8_t* __restri
                                                          const float* __restrict__ vals, int flags,
                                                          float min_depth, float max_depth, int cap, mvLaneCounts cnt,
                                                          uint8_t* __restrict__ valid, int32_t* __restrict__ count) {
-    // one workgroup per lane (blockIdx.x): N <= a few thousand observations.  Tables are [lanes, ., cap]; rows in
-    // [n_live, cap) are written as invalid so that a capacity-strided solve (mv_pgo_solve with static offsets) skips them.
-    const int lane = blockIdx.x;
-    const int N = cnt.n[lane];
-    {
-        const size_t ln = (size_t)lane * cap;
-        if (inbound) inbound += ln;
-        if (cov1) cov1 += 9 * ln;
-        if (cov2) cov2 += 9 * ln;
-        if (vals) vals += ln;   // SoA table [11, lanes, cap]
-        valid += ln;
-        count += lane;
-    }
-    const size_t vs = (size_t)gridDim.x * cap;
-    __shared__ int total;
-    if (threadIdx.x == 0) total = 0;
-    // LikelyFrontOfCamFilter: if ANY pixel1_d_cov is the -1 placeholder the filter lets every row pass (:133-136)
-    int has_placeholder = 0;
-    if (flags & 4)
-        for (int n = threadIdx.x; n < N; n += blockDim.x) has_placeholder |= (vals[3 * vs + n] == -1.f);
-    const bool front_off = __syncthreads_or(has_placeholder) != 0;
-    int local = 0;
-    for (int n = threadIdx.x; n < N; n += blockDim.x) {
-        bool ok = inbound ? inbound[n] != 0 : true;
-        if (ok && (flags & 1)) {  // CovarianceSanityFilter (OutlierFilter.py:91-100)
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const double a = cov1[(size_t)n * 9 + k], b = cov2[(size_t)n * 9 + k];
-                ok = ok && isfinite(a) && isfinite(b);
+    obs_filter_body(inbound, cov1, cov2, vals, flags, min_depth, max_depth, cap, cnt.n[blockIdx.x], blockIdx.x, gridDim.x, valid, count);
+}
+
+// VERDICT r4 next #3 — the pose-INDEPENDENT half of a frame's backend in ONE launch: gather + track + back-projection (kp_front_kernel) and
+// both 31 x 31 covariance models (match_cov_kernel).  Odometry/MACVO.py:197-262.  On the backend stream of a one-lane pipeline these were launches of
+// <= 200-point work whose boundaries (each a dependent dispatch beside a GEMM that owns every CU) cost more than their arithmetic.
+//   grid (ceil(n_max / 4), 2 keypoint sets, lanes), 4 waves: a wave = one keypoint of one set.  Every wave re-derives the keypoint's tracked
+//   position and match sigma itself (five uniform loads: cheaper than a hand-over through memory); the set-0 wave's lane 0 writes the tracking
+//   tables, each wave its own sigma row and covariance.
+// The observation filters need every covariance of the lane.  A first version ran them in the last workgroup to finish (ticket counter, __threadfence):
+// bit-identical, but SLOWER in the pipe (5.17-5.21 k vs 5.41-5.56 k frames/s, profiles/r05_pipe_ab.log) — an agent-scope release / acquire on this
+// 8-XCD part writes back and invalidates the L2s, 200 times per frame, under the GEMM that runs beside it (its launches went from 87-94 to 98-103 us).
+// The filters are now the PROLOGUE of the lane's solve workgroup (mv_pgo_solve_posed), behind the kernel boundary that already exists.
+// Same expressions, same order, same bits as the separate kernels.
+template <bool PERM_IN_ARGS>
+__global__ __launch_bounds__(256) void backend_front_kernel(const int32_t* __restrict__ cand, size_t cand_lane_stride, const int64_t* __restrict__ perm,
+                                                            PermArg pa, int cap, mvLaneCounts cnt, int64_t* out_uv, TrackArgs a, float fx, float fy,
+                                                            float cx, float cy, float* pos_Tc, const float* depth_map0, const float* depth_map1,
+                                                            double* out_cov0, double* out_cov1, mvMatchCovParams cp) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int set = blockIdx.y, pl = blockIdx.z;
+    const int N = cnt.n[pl];
+    if (n < N) {       // (wave-uniform)
+        const int32_t* cand_l = cand + (size_t)pl * cand_lane_stride;
+        const long pi = PERM_IN_ARGS ? (long)pa.idx[n] : (long)perm[(size_t)pl * cap + n];
+        const int lin = cand_l[pi];
+        const int u0 = lin % a.W, v0 = lin / a.W;
+        TrackArgs al = a;
+        track_lane_offsets(al, pl, cap);
+        const size_t ln = (size_t)pl * cap;
+        float u, v, suu, svv, suv;
+        if (set == 0) {
+            if (lane == 0) {     // kp_front_kernel's body; sigma1 is the set-1 wave's row
+                out_uv[2 * (ln + n) + 0] = u0;
+                out_uv[2 * (ln + n) + 1] = v0;
+                kp_track_one(n, u0, v0, al.match_flow, al.match_cov, al.depth0, al.disp0, al.sdisp0, al.sdd0, al.depth1, al.disp1, al.sdisp1, al.sdd1,
+                             al.H, al.W, al.edge, al.match_cov_default, al.out_kp0, al.out_kp1, al.out_inbound, al.out_vals, (size_t)gridDim.z * cap,
+                             nullptr, nullptr);
+                al.out_sigma0[3 * n + 2] = 0.f;                                   // ([3n], [3n + 1]: written (clamped) by the covariance model below)
+                const float uf = (float)u0, vf = (float)v0, d = al.out_vals[n];
+                float* pt = pos_Tc + 3 * (ln + n);
+                pt[0] = d;
+                pt[1] = ((uf - cx) * d) / fx;
+                pt[2] = ((vf - cy) * d) / fy;
             }
+            u = (float)u0; v = (float)v0;                                         // kp0 carries the constant quantisation sigma (MACVO.py:228-229)
+            suu = a.match_cov_default; svv = a.match_cov_default; suv = 0.f;
+        } else {
+            const int plane = al.H * al.W;
+            const bool ok0 = u0 >= 0 && u0 < al.W && v0 >= 0 && v0 < al.H;
+            const int i0 = ok0 ? v0 * al.W + u0 : 0;
+            u = (float)u0 + al.match_flow[i0];                                    // kp_track_one's u1, v1 and match sigma, re-derived
+            v = (float)v0 + al.match_flow[plane + i0];
+            suu = al.match_cov ? al.match_cov[i0] : -1.f;
+            svv = al.match_cov ? al.match_cov[plane + i0] : -1.f;
+            suv = al.match_cov ? al.match_cov[2 * plane + i0] : -1.f;
+            if (lane == 0) al.out_sigma1[3 * n + 2] = suv;                        // ([3n], [3n + 1]: written clamped by the covariance model below)
         }
-        if (ok && (flags & 6)) {
-            const float d1 = vals[n], d2 = vals[4 * vs + n], c1 = vals[3 * vs + n], c2 = vals[7 * vs + n];
-            if (flags & 2)  // SimpleDepthFilter (:103-121)
-                ok = !((d1 < min_depth) || (d1 > max_depth) || (d2 < min_depth) || (d2 > max_depth));
-            if (ok && (flags & 4) && !front_off)  // LikelyFrontOfCamFilter (:124-141)
-                ok = ((d1 - sqrtf(c1) * 2.f) > 0.f) && ((d2 - sqrtf(c2) * 2.f) > 0.f);
-        }
-        valid[n] = ok;
-        local += ok;
+        const mvcov::CovSet S{set ? depth_map1 : depth_map0, nullptr, set ? a.out_sigma1 : a.out_sigma0, nullptr, nullptr, set ? out_cov1 : out_cov0,
+                              nullptr, nullptr};
+        mvcov::match_cov_wave_vals(S, cp, cap, pl, n, u, v, suu, svv, suv);
     }
-    for (int n = N + threadIdx.x; n < cap; n += blockDim.x) valid[n] = 0;
-    local = wave_sum(local);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&total, local);
-    __syncthreads();
-    if (threadIdx.x == 0) count[0] = total;
 }
 
 }  // namespace
@@ -451,6 +434,44 @@ extern "C" int mv_kp_front_lanes(const int32_t* cand, size_t cand_lane_stride, c
         pa.idx[0] = 0;
         hipLaunchKernelGGL(kp_front_kernel<false>, grid, block, 0, (hipStream_t)stream, cand, cand_lane_stride, perm_dev, pa, cap, c,
                            out_kp0_uv, ta, fx, fy, cx, cy, out_pos_Tc);
+    }
+    return mv_launch_status();
+}
+
+extern "C" int mv_backend_front_lanes(const int32_t* cand, size_t cand_lane_stride, const int64_t* perm_dev, const int64_t* perm_host, int lanes,
+                                      const int32_t* n_live, int cap, const float* match_flow, const float* match_cov, const float* depth0,
+                                      const float* disp0, const float* sdisp0, const float* sdd0, const float* depth1, const float* disp1,
+                                      const float* sdisp1, const float* sdd1, int edge, float match_cov_default, const mvMatchCovParams* cov_params,
+                                      int64_t* out_kp0_uv, float* out_kp0, float* out_kp1, uint8_t* out_inbound, float* out_vals, float* out_sigma0,
+                                      float* out_sigma1, float* out_pos_Tc, double* out_cov0, double* out_cov1, mvStream_t stream) {
+    MV_CHECK_ARG(cov_params && edge >= 0);
+    const mvMatchCovParams cp = *cov_params;
+    MV_CHECK_ARG(cp.H > 0 && cp.W > 0 && cp.kernel_size >= 1 && (cp.kernel_size & 1) && cp.use_patch_var);
+    if (cp.kernel_size > mvcov::MAX_K) return MV_ERR_UNSUPPORTED;
+    mvLaneCounts c{};
+    int n_max = 0;
+    const int rc = check_lanes(lanes, n_live, cap, c, n_max);
+    if (rc != MV_OK) return rc;
+    if (n_max == 0) return MV_OK;
+    MV_CHECK_ARG(cand && (perm_dev || perm_host) && match_flow && depth0 && depth1 && out_kp0_uv && out_kp1 && out_inbound && out_vals &&
+                 out_sigma0 && out_sigma1 && out_pos_Tc && out_cov0 && out_cov1);
+    const TrackArgs ta{match_flow, match_cov, depth0, disp0, sdisp0, sdd0, depth1, disp1, sdisp1, sdd1, cp.H, cp.W, edge, match_cov_default,
+                       out_kp0, out_kp1, out_inbound, out_vals, out_sigma0, out_sigma1};
+    const dim3 grid(mv_ceil_div(n_max, 4), 2, lanes), block(256);
+    if (perm_host && lanes == 1 && n_max <= 256) {     // the permutation rides in the kernel arguments
+        PermArg pa;
+        for (int i = 0; i < n_max; ++i) {
+            MV_CHECK_ARG(perm_host[i] >= 0 && perm_host[i] <= 0x7fffffffLL);
+            pa.idx[i] = (int32_t)perm_host[i];
+        }
+        hipLaunchKernelGGL(backend_front_kernel<true>, grid, block, 0, (hipStream_t)stream, cand, cand_lane_stride, nullptr, pa, cap, c, out_kp0_uv, ta,
+                           cp.fx, cp.fy, cp.cx, cp.cy, out_pos_Tc, depth0, depth1, out_cov0, out_cov1, cp);
+    } else {
+        MV_CHECK_ARG(perm_dev);
+        PermArg pa;
+        pa.idx[0] = 0;
+        hipLaunchKernelGGL(backend_front_kernel<false>, grid, block, 0, (hipStream_t)stream, cand, cand_lane_stride, perm_dev, pa, cap, c, out_kp0_uv, ta,
+                           cp.fx, cp.fy, cp.cx, cp.cy, out_pos_Tc, depth0, depth1, out_cov0, out_cov1, cp);
     }
     return mv_launch_status();
 }

@@ -46,6 +46,24 @@ struct PgoArgs {
     double* out_info;
     float* out_pose_f32;
     int spec;   // speculative reject rounds: 1 on, 0 off (MV_PGO_SPEC), 2 = on + round / trial counts into out_info[3] (debugging)
+    // mv_pgo_solve_posed: the pose-dependent remainder of the backend folded into this launch (all null / zero otherwise).  The first
+    // apply_live[prob] rows of a problem are rotated into the world frame with the problem's init_pose before any row is read:
+    // pos_Tw = T p_cam, cov_Tw = R cov_Tc R^T, rot = R (pose_apply_dev.h); pose_sink: a second fp32 copy of the optimised pose
+    const float* apply_pos_Tc;
+    const double* apply_cov_Tc;
+    float* apply_pos_Tw;
+    double* apply_cov_Tw;
+    double* apply_rot;
+    float* pose_sink;
+    int32_t apply_live[MV_MAX_LANES];
+    // ... and the observation filters of the problem's rows (obs_filter_dev.h) in front of that: filter_flags >= 0 -> valid_out / count_out written
+    int filter_flags;
+    float filter_min_depth, filter_max_depth;
+    int filter_cap;
+    const uint8_t* filter_inbound;
+    const float* filter_vals;
+    uint8_t* valid_out;
+    int32_t* count_out;
 };
 
 struct Pose {

@@ -35,6 +35,8 @@
 // Problems with more points than threads (and the one-wave throughput variant's > 64) keep the full 55-value build.
 #include "common.h"
 #include "pgo_math.h"
+#include "pose_apply_dev.h"
+#include "obs_filter_dev.h"
 #include <stdlib.h>
 
 namespace {
@@ -207,6 +209,26 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
     g.fx = (double)a.intrinsics[4 * prob]; g.fy = (double)a.intrinsics[4 * prob + 1];
     g.cx = (double)a.intrinsics[4 * prob + 2]; g.cy = (double)a.intrinsics[4 * prob + 3];
     g.blfx = g.fx * (double)a.baseline[prob];  // K[0,0] * bl in fp64 of the fp32 buffers
+
+    if (a.valid_out) {      // mv_pgo_solve_posed: the lane's observation filters (obs_filter_kernel's body; PGO_THREADS == 256), then ...
+        obs_filter_body(a.filter_inbound, a.apply_cov_Tc, a.obs2_covTc, a.filter_vals, a.filter_flags, a.filter_min_depth, a.filter_max_depth,
+                        a.filter_cap, a.apply_live[prob], prob, gridDim.x, a.valid_out, a.count_out);
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (a.apply_pos_Tc) {   // ... pose_apply_kernel's rows of this problem; the solve reads both back (same workgroup)
+        const float* pose = a.init_pose + 7 * prob;
+        double R[9];
+        mv_pose_rotation(pose, R);
+        if (tid == 0 && a.apply_rot) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) a.apply_rot[9 * prob + i] = R[i];
+        }
+        const int live = a.apply_live[prob];
+        for (int i = tid; i < live; i += PGO_THREADS) mv_pose_apply_row(pose, R, beg + i, a.apply_pos_Tc, a.apply_cov_Tc, a.apply_pos_Tw, a.apply_cov_Tw);
+        __threadfence_block();
+        __syncthreads();
+    }
 
     Pose P;
 #pragma unroll
@@ -521,6 +543,11 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
             of[0] = (float)P.t[0]; of[1] = (float)P.t[1]; of[2] = (float)P.t[2];
             of[3] = (float)P.q[0]; of[4] = (float)P.q[1]; of[5] = (float)P.q[2]; of[6] = (float)P.q[3];
         }
+        if (a.pose_sink) {
+            float* of = a.pose_sink + 7 * (size_t)prob;
+            of[0] = (float)P.t[0]; of[1] = (float)P.t[1]; of[2] = (float)P.t[2];
+            of[3] = (float)P.q[0]; of[4] = (float)P.q[1]; of[5] = (float)P.q[2]; of[6] = (float)P.q[3];
+        }
     }
 }
 
@@ -544,18 +571,60 @@ extern "C" void mv_lm_default_params(mvLMParams* p) {
     p->reject = 16; p->max_steps = 10; p->patience = 2; p->stop_on_reject = 1;
 }
 
-extern "C" int mv_pgo_solve(int nprob, const int32_t* offsets, int graph_type, const float* init_pose,
-                            const float* intrinsics, const float* baseline, const float* pos_Tw, const double* cov_Tw,
-                            const float* pixel2_uv, const float* pixel2_d, const float* pixel2_disp,
-                            const float* pixel2_disp_cov, const float* pixel2_uv_cov, const double* obs2_covTc,
-                            const uint8_t* valid, int min_points, const mvLMParams* params, double* out_pose,
-                            double* out_info, float* out_pose_f32, mvStream_t stream) {
+struct PoseApplyArgs {   // mv_pgo_solve_posed's extra arguments (all null for the plain solve)
+    const float* pos_Tc;
+    const double* cov_Tc;
+    double* out_rot;
+    float* pose_sink;
+    const int32_t* n_live;
+    int filter_flags = -1;
+    float filter_min_depth = 0.f, filter_max_depth = 0.f;
+    int cap = 0;
+    const uint8_t* inbound = nullptr;
+    const float* vals = nullptr;
+    uint8_t* valid_out = nullptr;
+    int32_t* count_out = nullptr;
+};
+
+static int pgo_solve_impl(int nprob, const int32_t* offsets, int graph_type, const float* init_pose,
+                          const float* intrinsics, const float* baseline, const float* pos_Tw, const double* cov_Tw,
+                          const float* pixel2_uv, const float* pixel2_d, const float* pixel2_disp,
+                          const float* pixel2_disp_cov, const float* pixel2_uv_cov, const double* obs2_covTc,
+                          const uint8_t* valid, int min_points, const mvLMParams* params, double* out_pose,
+                          double* out_info, float* out_pose_f32, const PoseApplyArgs& pa, mvStream_t stream) {
     MV_CHECK_ARG(nprob >= 0 && params);
     if (nprob == 0) return MV_OK;
     MV_CHECK_ARG(offsets && init_pose && intrinsics && baseline && pos_Tw && pixel2_uv && out_pose && out_info);
     MV_CHECK_ARG(params->max_steps >= 1 && params->reject >= 0 && params->stop_on_reject >= 0 && params->radius > 0 && params->huber_delta > 0);
     PgoArgs a{offsets, init_pose, intrinsics, baseline, pos_Tw, cov_Tw, pixel2_uv, pixel2_d, pixel2_disp,
               pixel2_disp_cov, pixel2_uv_cov, obs2_covTc, valid, min_points, out_pose, out_info, out_pose_f32, 1};
+    a.pose_sink = pa.pose_sink;
+    if (pa.pos_Tc) {
+        MV_CHECK_ARG(nprob <= MV_MAX_LANES && pa.n_live);
+        a.apply_pos_Tc = pa.pos_Tc;
+        a.apply_cov_Tc = pa.cov_Tc;
+        a.apply_pos_Tw = const_cast<float*>(pos_Tw);        // the solve's own input tables are the outputs of the fold
+        a.apply_cov_Tw = pa.cov_Tc ? const_cast<double*>(cov_Tw) : nullptr;
+        a.apply_rot = pa.out_rot;
+        for (int l = 0; l < nprob; ++l) {
+            MV_CHECK_ARG(pa.n_live[l] >= 0);
+            a.apply_live[l] = pa.n_live[l];
+        }
+        if (pa.filter_flags >= 0) {
+            MV_CHECK_ARG(pa.valid_out && pa.count_out && pa.cap >= 0 && (!(pa.filter_flags & 1) || (pa.cov_Tc && obs2_covTc)) &&
+                         (!(pa.filter_flags & 6) || pa.vals));
+            a.filter_flags = pa.filter_flags;
+            a.filter_min_depth = pa.filter_min_depth;
+            a.filter_max_depth = pa.filter_max_depth;
+            a.filter_cap = pa.cap;
+            a.filter_inbound = pa.inbound;
+            a.filter_vals = pa.vals;
+            a.valid_out = pa.valid_out;
+            a.count_out = pa.count_out;
+            a.valid = pa.valid_out;      // what the solve reads
+            for (int l = 0; l < nprob; ++l) MV_CHECK_ARG(pa.n_live[l] <= pa.cap);
+        }
+    }
     {
         static int spec = -1;   // MV_PGO_SPEC=0: every trial of the reject loop sequentially (A/B knob)
         if (spec < 0) { const char* e = getenv("MV_PGO_SPEC"); spec = e ? atoi(e) : 1; }
@@ -587,4 +656,34 @@ extern "C" int mv_pgo_solve(int nprob, const int32_t* offsets, int graph_type, c
     }
 #undef MV_PGO
     return mv_launch_status();
+}
+
+extern "C" int mv_pgo_solve(int nprob, const int32_t* offsets, int graph_type, const float* init_pose,
+                            const float* intrinsics, const float* baseline, const float* pos_Tw, const double* cov_Tw,
+                            const float* pixel2_uv, const float* pixel2_d, const float* pixel2_disp,
+                            const float* pixel2_disp_cov, const float* pixel2_uv_cov, const double* obs2_covTc,
+                            const uint8_t* valid, int min_points, const mvLMParams* params, double* out_pose,
+                            double* out_info, float* out_pose_f32, mvStream_t stream) {
+    return pgo_solve_impl(nprob, offsets, graph_type, init_pose, intrinsics, baseline, pos_Tw, cov_Tw, pixel2_uv, pixel2_d, pixel2_disp,
+                          pixel2_disp_cov, pixel2_uv_cov, obs2_covTc, valid, min_points, params, out_pose, out_info, out_pose_f32,
+                          PoseApplyArgs{nullptr, nullptr, nullptr, nullptr, nullptr}, stream);
+}
+
+extern "C" int mv_pgo_solve_posed(int nprob, const int32_t* offsets, const int32_t* n_live, int cap, int graph_type, const float* init_pose,
+                                  const float* intrinsics, const float* baseline, const float* pos_Tc, const double* cov_Tc,
+                                  float* pos_Tw, double* cov_Tw, double* out_rot, const float* pixel2_uv, const float* pixel2_d,
+                                  const float* pixel2_disp, const float* pixel2_disp_cov, const float* pixel2_uv_cov,
+                                  const double* obs2_covTc, int filter_flags, float filter_min_depth, float filter_max_depth,
+                                  const uint8_t* inbound, const float* vals, uint8_t* valid, int32_t* count_out, int min_points,
+                                  const mvLMParams* params, double* out_pose, double* out_info, float* out_pose_f32, float* pose_sink,
+                                  mvStream_t stream) {
+    MV_CHECK_ARG(pos_Tc && pos_Tw && n_live && (!cov_Tc || cov_Tw));
+    MV_CHECK_ARG(nprob < 512);   // (the 256-thread solve variant: the filter body is written for it)
+    PoseApplyArgs pa{pos_Tc, cov_Tc, out_rot, pose_sink, n_live};
+    if (filter_flags >= 0) {
+        pa.filter_flags = filter_flags; pa.filter_min_depth = filter_min_depth; pa.filter_max_depth = filter_max_depth; pa.cap = cap;
+        pa.inbound = inbound; pa.vals = vals; pa.valid_out = valid; pa.count_out = count_out;
+    }
+    return pgo_solve_impl(nprob, offsets, graph_type, init_pose, intrinsics, baseline, pos_Tw, cov_Tw, pixel2_uv, pixel2_d, pixel2_disp,
+                          pixel2_disp_cov, pixel2_uv_cov, obs2_covTc, valid, min_points, params, out_pose, out_info, out_pose_f32, pa, stream);
 }

@@ -818,6 +818,10 @@ class NativeHotPath:
         """Record a HIP-event pair around each of the next ``max_launches`` volume GEMMs (on the stream they run on)."""
         ops.L.check(self._lib.mv_frame_pipe_time_volume(self._pipe, int(max_launches)), "mv_frame_pipe_time_volume")
 
+    def time_detail(self, on: bool) -> None:
+        """``False``: timed frames record only the event pair around their GEMM (no timeline events on the other streams)."""
+        ops.L.check(self._lib.mv_frame_pipe_time_detail(self._pipe, int(bool(on))), "mv_frame_pipe_time_detail")
+
     def volume_times_ms(self) -> list:
         cap = self._pc_timed = 1 << 16
         buf = (ops.C.c_float * cap)()

@@ -319,3 +319,57 @@ def test_native_split_volume_equals_python_driver_and_oracle(gpu, mode):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.split())
     assert all(o[0] == f"corr_volume_split_stream<{mode}>" for o in outs) and len({o[1] for o in outs}) == 1, outs
+
+
+@pytest.mark.parametrize("lanes,graph", [(1, "disp"), (1, "icp"), (3, "reproj")])
+def test_fused_backend_equals_the_five_launch_form(gpu, monkeypatch, lanes, graph):
+    """the backend of a frame as TWO launches — mv_backend_front_lanes (gather + track + back-projection + both covariance
+    models + observation filters; the lane's last workgroup filters) and mv_pgo_solve_posed (rotation into the world frame as the solve's
+    prologue, pose sink as its second output) — against the five-launch form (MV_PIPE_FUSE_BACKEND=0) on the same frames and seeds: EVERY
+    backend table the pipe exposes is bit-identical over its live rows, frame after frame, and so are the poses."""
+    from macvo_amd.pipeline import Camera, HotPathConfig, NativeHotPath, stack_lanes
+
+    H, W, C, n_frames = 192, 256, 32, 7
+    cam, frames, _ = synth.make_sequence(n_frames + lanes, H, W, C=C, iters=2, seed=11)
+    ins = _inputs(frames, gpu)
+    batches = ins if lanes == 1 else [stack_lanes([ins[(t + l) % len(ins)] for l in range(lanes)]) for t in range(n_frames)]
+    names = {"KP0": (torch.int64, (2,)), "KP0F": (torch.float32, (2,)), "KP1": (torch.float32, (2,)), "INBOUND": (torch.uint8, ()),
+             "SIGMA0": (torch.float32, (3,)), "SIGMA1": (torch.float32, (3,)), "POS_TC": (torch.float32, (3,)), "POS_TW": (torch.float32, (3,)),
+             "COV0": (torch.float64, (9,)), "COV0W": (torch.float64, (9,)), "COV1": (torch.float64, (9,)), "VALID": (torch.uint8, ())}
+    runs = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("MV_PIPE_FUSE_BACKEND", fuse)
+        hot = NativeHotPath(Camera(**cam), HotPathConfig(num_point=60, graph_type=graph), gpu, lanes=lanes,
+                            generators=None if lanes == 1 else [5 + l for l in range(lanes)])
+        hot.initialize(batches[0])
+        torch.manual_seed(3)
+        rec = []
+        sink = torch.zeros((n_frames - 1, lanes, 7) if lanes > 1 else (n_frames - 1, 7), device=gpu)
+        for t in range(1, n_frames):
+            hot.enqueue_frontend(batches[t])
+            res = hot.finish(None, sink[t - 1])
+            hot.sync_all()
+            torch.cuda.synchronize()
+            res = res if isinstance(res, list) else [res]
+            cap = hot._cap
+            d = {"n_sel": [r.n_sel for r in res]}
+            for nm, (dt, tail) in names.items():
+                v = hot._view(nm, 0, dt, (lanes, cap) + tail)
+                d[nm] = [v[l, : res[l].n_sel].clone() for l in range(lanes)]
+            vals = hot._view("VALS", 0, torch.float32, (11, lanes, cap))
+            d["VALS"] = [vals[:, l, : res[l].n_sel].clone() for l in range(lanes)]
+            for nm, dt, shp in (("ROT", torch.float64, (lanes, 9)), ("NVALID", torch.int32, (lanes,)), ("POSE64", torch.float64, (lanes, 7)),
+                                ("INFO", torch.float64, (lanes, 4)), ("POSE", torch.float32, (lanes, 7))):
+                d[nm] = [hot._view(nm, 0, dt, shp).clone()]
+            rec.append(d)
+        runs[fuse] = (rec, sink.clone())
+        del hot
+    a, b = runs["0"], runs["1"]
+    assert torch.equal(a[1], b[1]) and float(b[1].abs().sum()) > 0          # the pose sink: the solve's second output == the D2D copy
+    for t, (da, db) in enumerate(zip(a[0], b[0])):
+        assert da["n_sel"] == db["n_sel"] and min(da["n_sel"]) > 0
+        for k in da:
+            if k == "n_sel":
+                continue
+            for l, (x, y) in enumerate(zip(da[k], db[k])):
+                assert torch.equal(x, y), (t, k, l)
