@@ -341,12 +341,13 @@ def patch_embed_leg(ops, vol, dev, reps=10):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
-    fl = S * 2.0 * (1280 * 16 * 36 + 320 * 32 * 576 + 80 * 64 * 1152)
+    hp_, wp_ = (H2 + 7) // 8 * 8, (W2 + 7) // 8 * 8
+    fl = S * 2.0 * (hp_ * wp_ // 4 * 16 * 36 + hp_ * wp_ // 16 * 32 * 576 + hp_ * wp_ // 64 * 64 * 1152)      # the three layers' multiply-adds on the padded slice
     byts = S * (H2 * W2 * 4 + out.shape[1] * 64 * 4.0)
     leg = {"what": f"cost patch embedding of one frame's volumes (S = {S} slices {H2}x{W2} -> {out.shape[1]} tokens x 64), fused kernel mv_cost_patch_embed: 16-bit MFMA ({pk.operand} operands), fp32 "
                    "accumulate, both intermediate maps in LDS", "us_per_frame": round(us, 1), "algorithmic_gflop": round(fl / 1e9, 1),
            "roofline": {"bound": "mfma", "achieved": round(fl / us / 1e6, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / us / 1e6 / PEAK_BF16_MFMA_TFLOPS, 4),
-                        "traffic": None, "kernel": "cost_patch_embed_kernel<60,80>", "algorithmic_hbm_bytes": byts, "hbm_GBps": round(byts / us / 1e3, 1)}}
+                        "traffic": None, "kernel": ("cost_patch_embed_kernel<%d,%d>" if (H2, W2) in ((60, 80), (64, 80)) else "cost_patch_embed_strip_kernel<%d,%d>") % (H2, W2), "algorithmic_hbm_bytes": byts, "hbm_GBps": round(byts / us / 1e3, 1)}}
     # Fast mode (row (f)2 as SURVEY words it): fp16 cells in (the out16 volume), fp16 tokens out — no widening pass on either side
     try:
         v16 = vol.half()
@@ -362,7 +363,7 @@ def patch_embed_leg(ops, vol, dev, reps=10):
         same = bool(torch.equal(o16, ops.cost_patch_embed(v16.float(), pk, tokens=True).half()))
         leg["fast_mode"] = {"what": "fp16 cells in, fp16 tokens out (mv_cost_patch_embed_t)", "us_per_frame": round(us16, 1), "achieved": round(fl / us16 / 1e6, 1),
                             "frac": round(fl / us16 / 1e6 / PEAK_BF16_MFMA_TFLOPS, 4), "algorithmic_hbm_bytes": byts / 2, "hbm_GB_per_frame": round(byts / 2e9, 4),
-                            "hbm_GBps": round(byts / 2 / us16 / 1e3, 1), "kernel": "cost_patch_embed_kernel<60,80,f16 in,f16 out>",
+                            "hbm_GBps": round(byts / 2 / us16 / 1e3, 1), "kernel": leg["roofline"]["kernel"][:-1] + ",f16 in,f16 out>",
                             "tokens_equal_fp32_form_rounded_once": same}
         del v16, o16
     except Exception as e:  # noqa: BLE001

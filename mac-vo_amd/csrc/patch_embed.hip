@@ -30,13 +30,11 @@
 #include "common.h"
 #include <algorithm>
 #include <atomic>
+#include <stdlib.h>
 #include <type_traits>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#include "patch_embed_dev.h"
+using namespace pe;
 
 namespace {
 
@@ -79,14 +77,6 @@ struct PE {
     static_assert(W2 % 4 == 0 && Q4 <= 5 * 256, "slice staging: at most five float4 per thread");
 };
 
-// packed weights (mv_patch_embed_pack): bf16 fragments in the B-operand order of v_mfma_f32_16x16x32 — lane l holds channel l % 16 of its 16-channel
-// tile, k = 8 (l / 16) + 0..7 — then biases
-//   [0, 3 KB)            conv1 (16x16x32 fragments: lane l = channel l % 16): 2 k-steps; k = (ky = 4 s + l / 16, kx' = j), zero for ky, kx' >= 6
-//   [3 KB, 39 KB)        conv2: [channel tile 2][k-step 18]; k = (tap 2 ks + l / 32, cin 8 (l / 16 % 2) + j)
-//   [39 KB, 183 KB)      conv3: [channel tile 4][tap 36]; k = cin 8 (l / 16) + j
-//   then fp32 b1[32] (16 used), b2[32], b3[64]
-constexpr size_t PE_W1_OFF = 0, PE_W2_OFF = 3 * 1024, PE_W3_OFF = 39 * 1024, PE_B_OFF = 183 * 1024, PE_PACKED_BYTES = PE_B_OFF + 128 * 4;
-
 __global__ void patch_embed_pack_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
                                         const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3,
                                         uint16_t* __restrict__ out, int f16) {
@@ -96,7 +86,10 @@ __global__ void patch_embed_pack_kernel(const float* __restrict__ w1, const floa
         const int unit = i >> 9, lane = (i >> 3) & 63, j = i & 7;
         float v = 0.f;
         if (unit < 3) {                                        // conv1 [16,1,6,6]: B operand of v_mfma_f32_16x16x32: lane l = channel l % 16, k = 8 (l / 16) + j
-            const int n16 = lane & 15, ky = 4 * unit + (lane >> 4);      // k-step `unit` (2 used): k = (ky = 4 unit + l / 16, kx' = j); ky, kx' >= 6: zero
+            // k-step `unit` (2 used): k = (ky, kx' = j) with ky = 4 (g & 1) + (g >> 1) + 2 unit for lane group g = l / 16 (round 5; was 4 unit + g): the two
+            // lane groups that share a ds_read_b32 service group (g = 0, 1 / 2, 3) then read input rows FOUR apart = 16 banks apart for every row pitch with
+            // pitch / 2 = 4 (mod 8) dwords, instead of neighbouring rows 12 banks apart (2-way conflicts on every conv1 fragment read); ky, kx' >= 6: zero
+            const int n16 = lane & 15, g = lane >> 4, ky = 4 * (g & 1) + (g >> 1) + 2 * unit;
             if (unit < 2 && ky < 6 && j < 6) v = w1[(n16 * 6 + ky) * 6 + j];
         } else if (unit < 39) {                                // conv2 [32,16,6,6]: unit = 3 + nt * 18 + ks; lane = channel nt * 16 + l % 16; k = 8 (l / 16) + j
             const int u = unit - 3, nt = u / 18, ks = u - nt * 18, n16 = lane & 15, g4 = lane >> 4;
@@ -112,23 +105,6 @@ __global__ void patch_embed_pack_kernel(const float* __restrict__ w1, const floa
         float* b = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + PE_B_OFF);
         b[i] = i < 16 ? b1[i] : (i < 32 ? 0.f : (i < 64 ? b2[i - 32] : b3[i - 64]));
     }
-}
-
-// the 16-bit operand type of the whole stack: bf16 (F16 = false) or IEEE fp16 (F16 = true; 11 significant bits — TF32's mantissa, and the type the
-// reference's Fast mode runs this encoder in); same fragment layouts, same instruction shape
-// IEEE half SATURATES at +-65504 (one v_med3_f32): a cost cell or an activation beyond fp16's range stays the largest finite value instead of
-// becoming inf and, one layer later, NaN tokens (an un-normalised 256-channel dot product can get there; bf16 has fp32's range and needs nothing)
-template <bool F16>
-__device__ __forceinline__ uint16_t cvt_bits(float v) {
-    if constexpr (F16) return __builtin_bit_cast(uint16_t, (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f));
-    else return __builtin_bit_cast(uint16_t, (__bf16)v);
-}
-template <bool F16>
-__device__ __forceinline__ unsigned cvt_pack(float lo, float hi) { return (unsigned)cvt_bits<F16>(lo) | ((unsigned)cvt_bits<F16>(hi) << 16); }
-template <bool F16>
-__device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
-    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
 // IN16 / OUT16: the slice is read / the tokens are written in the OPERAND type (fp16 cells of the `out16` volume -> fp16 tokens for the fp16 encoder of
@@ -188,7 +164,7 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const void* __res
         for (int r5 = 0; r5 < 5; ++r5) {
             const int tile = wave + 4 * r5;
             const int p = tile * 16 + n16, oy = p / P::W1, ox = p - oy * P::W1;
-            c1_a[r5] = in0 + ((2 * oy + g4) * P::IN_PITCH + 2 * ox) * 2;
+            c1_a[r5] = in0 + ((2 * oy + 4 * (g4 & 1) + (g4 >> 1)) * P::IN_PITCH + 2 * ox) * 2;   // ky of k-step 0 (see mv_patch_embed_pack)
             const int pp = tile * 16 + 4 * g4, y = pp / P::W1, x = pp - y * P::W1;      // four consecutive pixels of one row (W1 % 4 == 0)
             c1_d[r5] = o1 + (n16 >> 3) * 2 * P::O1_PLANE + (n16 & 7) * 2 + P::o1_cell(0, y + 2, x + 2);
         }
@@ -236,7 +212,7 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const void* __res
                         i32x4 af[2];
 #pragma unroll
                         for (int s = 0; s < 2; ++s) {
-                            const unsigned* ap = reinterpret_cast<const unsigned*>(a0 + 4 * s * P::IN_PITCH * 2);
+                            const unsigned* ap = reinterpret_cast<const unsigned*>(a0 + 2 * s * P::IN_PITCH * 2);
                             af[s] = i32x4{(int)ap[0], (int)ap[1], (int)ap[2], (int)ap[3]};
                         }
                         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -409,7 +385,14 @@ extern "C" int mv_patch_embed_pack(const float* w1, const float* b1, const float
     return mv_launch_status();
 }
 
-extern "C" int mv_cost_patch_embed_supported(int H2, int W2) { return (H2 == 60 || H2 == 64) && W2 == 80; }
+// patch_embed_v2.hip: the strip-mined kernel for the other slice sizes
+int mv_cost_patch_embed_strip(const void* cost_maps, int in16, const void* packed, void* out, int out16, int S, int H2, int W2, int token_layout, int f16,
+                              mvStream_t stream);
+int mv_cost_patch_embed_strip_supported(int H2, int W2);
+
+static bool whole_slice_plan(int H2, int W2) { return (H2 == 60 || H2 == 64) && W2 == 80; }   // this file's kernel: two whole slices per pass
+
+extern "C" int mv_cost_patch_embed_supported(int H2, int W2) { return whole_slice_plan(H2, W2) || mv_cost_patch_embed_strip_supported(H2, W2); }
 
 template <int H2, bool F16, bool IN16, bool OUT16>
 static int launch_patch_embed(const void* cost_maps, const void* packed, void* out, int S, int token_layout, hipStream_t stream) {
@@ -458,6 +441,10 @@ extern "C" int mv_cost_patch_embed_t(const void* cost_maps, int in_dtype, const 
     if (in_dtype == MV_F32 && out_dtype != MV_F32) return MV_ERR_UNSUPPORTED;   // fp32 volume -> 16-bit tokens: no caller (the volume hook returns the encoder dtype)
     hipStream_t st = (hipStream_t)stream;
     const bool f16 = operand_type == MV_F16, in16 = in_dtype != MV_F32, out16 = out_dtype != MV_F32;
+    const char* pe_env = getenv("MV_PE_STRIP");                       // A/B (read per call: tests toggle it): 1 = the strip-mined kernel also where the
+    const bool strip_all = pe_env && atoi(pe_env) == 1;               // whole-slice plan exists
+    if (!whole_slice_plan(H2, W2) || strip_all)
+        return mv_cost_patch_embed_strip(cost_maps, in16, packed, out, out16, S, H2, W2, token_layout, f16, stream);
     if (f16) {
         if (!in16) return launch_patch_embed_h<true, false, false>(cost_maps, packed, out, S, H2, token_layout, st);
         return out16 ? launch_patch_embed_h<true, true, true>(cost_maps, packed, out, S, H2, token_layout, st)

@@ -126,9 +126,10 @@ def test_cost_patch_embed_on_a_real_volume_and_unsupported_sizes(gpu):
         got64 = ops.cost_patch_embed(x64.to(gpu), ops.PatchEmbedWeights(*[w.to(gpu) for w in W], operand=operand)).cpu()
         ref64 = _twin(operand)(x64, *W)
         assert got64.shape == (6, 64, 8, 10) and (got64 - ref64).abs().max().item() <= TWIN_TOL[operand] * ref64.abs().max().item()
-    assert not ops.cost_patch_embed_supported(90, 160)
+    assert ops.cost_patch_embed_supported(90, 160) and ops.cost_patch_embed_supported(80, 80)      # round 5: the strip-mined kernel
+    assert not ops.cost_patch_embed_supported(24, 32)
     with pytest.raises(ops.L.MacvoHipError):
-        ops.cost_patch_embed(torch.zeros(2, 1, 90, 160, device=gpu), ops.PatchEmbedWeights(*[w.to(gpu) for w in W]))
+        ops.cost_patch_embed(torch.zeros(2, 1, 24, 32, device=gpu), ops.PatchEmbedWeights(*[w.to(gpu) for w in W]))
 
 
 def test_flowformer_hook_rebinds_the_patch_embed_proj(gpu):
@@ -268,3 +269,91 @@ def test_cost_patch_embed_saturates_instead_of_overflowing_fp16(gpu):
     ref = F.conv2d(y, r(w3), b3, stride=2, padding=2)
     assert (got - ref).abs().max().item() <= TWIN_TOL["f16"] * ref.abs().max().item()
     assert got[3].abs().max() < 1e3 and got[2].abs().max() > 1e4      # the ordinary slice is untouched by its neighbours' magnitudes
+
+
+def _slices(S, H2, W2, seed, scale=16.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(S, 1, H2, W2, generator=g) * scale
+    x[:, 0, H2 // 3, W2 // 5] += 200.0
+    x[:, 0, H2 - 1, W2 - 1] -= 150.0          # the last cell: the padded rows / columns behind it must read as zeros
+    x[:, 0, 0, 0] += 120.0
+    return x
+
+
+@pytest.mark.parametrize("operand", ["f16", "bf16"])
+@pytest.mark.parametrize("H2,W2,S,tokens", [(80, 80, 5, False), (80, 80, 300, True), (90, 160, 3, True), (90, 160, 2, False), (90, 160, 700, True),
+                                            (96, 160, 4, True), (60, 80, 9, True), (64, 80, 6, False)])
+def test_strip_mined_kernel_any_slice_size(gpu, monkeypatch, operand, H2, W2, S, tokens):
+    """the slice sizes the whole-slice plan does not cover — 80 x 80 (the reference's 640 x 640 fixture: 100 tokens, 6.25 tiles) and
+    90 x 160 (1280 x 720, BASELINE configs[2]: three strips of four token rows, halo rows recomputed), plus the padded 96 x 160 — through
+    patch_embed_v2.hip against the conv2d chain in the same arithmetic and in fp32; and the same kernel forced onto 60 / 64 x 80 (MV_PE_STRIP=1)."""
+    from macvo_amd import ops
+    from oracle import patch_embed as ope
+
+    monkeypatch.setenv("MV_PE_STRIP", "1")
+    W = ope.make_weights(seed=H2 + S)
+    x = _slices(S, H2, W2, seed=S + 2)
+    packed = ops.PatchEmbedWeights(*[w.to(gpu) for w in W], operand=operand)
+    got = ops.cost_patch_embed(x.to(gpu), packed, tokens=tokens).cpu()
+    idx = torch.arange(S) if S <= 16 else torch.tensor([0, 1, S // 3, S // 2, S - 2, S - 1])
+    ref_16 = _twin(operand)(x[idx], *W)
+    ref_32 = ope.patch_embed_proj(x[idx], *W)
+    if tokens:
+        ref_16, ref_32 = ope.to_tokens(ref_16), ope.to_tokens(ref_32)
+    h, w = (H2 + 7) // 8, (W2 + 7) // 8
+    assert got.shape == ((S, h * w, 64) if tokens else (S, 64, h, w))
+    scale = ref_32.abs().max().item()
+    assert (got[idx] - ref_16).abs().max().item() <= TWIN_TOL[operand] * scale, ((got[idx] - ref_16).abs().max().item(), scale)
+    assert (got[idx] - ref_32).abs().max().item() <= FP32_TOL[operand] * scale
+    # deterministic; a slice's tokens do not depend on its neighbours or on which workgroup / strip order produced them
+    assert torch.equal(ops.cost_patch_embed(x.to(gpu), packed, tokens=tokens).cpu(), got)
+    solo = ops.cost_patch_embed(x[S // 2: S // 2 + 1].to(gpu), packed, tokens=tokens).cpu()
+    assert torch.equal(solo[0], got[S // 2])
+
+
+@pytest.mark.parametrize("H2,W2", [(80, 80), (90, 160)])
+def test_strip_mined_kernel_16bit_cells_and_tokens(gpu, H2, W2):
+    """the Fast-mode form of the new sizes: fp16 cells in / fp16 tokens out == the fp32-cell form on the widened cells, rounded once (both layouts)."""
+    from macvo_amd import ops
+    from oracle import patch_embed as ope
+
+    W = ope.make_weights(seed=3)
+    for operand, dt in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+        packed = ops.PatchEmbedWeights(*[w.to(gpu) for w in W], operand=operand)
+        x16 = _slices(7, H2, W2, seed=11).to(dt).to(gpu)
+        for tokens in (False, True):
+            f32 = ops.cost_patch_embed(x16.float(), packed, tokens=tokens)
+            assert torch.equal(ops.cost_patch_embed(x16, packed, tokens=tokens, out_dtype=torch.float32), f32)
+            t16 = ops.cost_patch_embed(x16, packed, tokens=tokens)
+            assert t16.dtype == dt and torch.equal(t16, f32.to(dt))
+        ref = _twin(operand)(x16.float().cpu(), *W)
+        assert (ops.cost_patch_embed(x16.float(), packed).cpu() - ref).abs().max().item() <= TWIN_TOL[operand] * ref.abs().max().item()
+
+
+def test_strip_mined_layers_one_by_one_at_720p(gpu):
+    """single taps per layer at distinct (ky, kx) / channels on a 90 x 160 slice: an indexing error in any of the three implicit GEMMs, in the strip
+    windows' row origins or in the recomputed halo rows cannot hide (positive inputs: the ReLUs are transparent)."""
+    from macvo_amd import ops
+    from oracle import patch_embed as ope
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 1, 90, 160, generator=g) * 4
+    for probe in range(3):
+        w1, b1, w2, b2, w3, b3 = [torch.zeros_like(t) for t in ope.make_weights(0)]
+        if probe == 0:
+            w1[3, 0, 1, 4] = 1.0; w2[7, 3, 5, 0] = 1.0; w3[41, 7, 2, 3] = 1.0
+        elif probe == 1:
+            w1[0, 0] = 1.0 / 36; w2[0, 0] = 1.0 / 36; w3[0, 0] = 1.0 / 36
+        else:
+            gg = torch.Generator().manual_seed(9)
+            w1 = (torch.rand(16, 1, 6, 6, generator=gg) > 0.7).float() * 0.25
+            w2 = (torch.rand(32, 16, 6, 6, generator=gg) > 0.9).float() * 0.125
+            w3 = (torch.rand(64, 32, 6, 6, generator=gg) > 0.9).float() * 0.125
+            b1, b2, b3 = torch.rand(16, generator=gg), torch.rand(32, generator=gg), torch.rand(64, generator=gg) - 0.5
+        W = (w1, b1, w2, b2, w3, b3)
+        for tokens in (False, True):
+            got = ops.cost_patch_embed(x.to(gpu), ops.PatchEmbedWeights(*[w.to(gpu) for w in W], operand="f16"), tokens=tokens).cpu()
+            ref = ope.patch_embed_proj_f16(x, *W)
+            ref = ope.to_tokens(ref) if tokens else ref
+            tol = TWIN_TOL["f16"] * max(ref.abs().max().item(), 1e-3)
+            assert (got - ref).abs().max().item() <= tol, (probe, tokens, (got - ref).abs().max().item(), tol)
