@@ -730,17 +730,11 @@ extern "C" int mv_corr_volume_packed(const void* packed1, const void* packed2, f
     if (!attr_done[dev].load(std::memory_order_acquire)) {
         (void)hipFuncSetAttribute((const void*)corr_volume_split_stream<3, false, 16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)corr_volume_split_stream<2, true, 16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)corr_volume_split_stream<2, true, 16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done[dev].store(true, std::memory_order_release);
     }
     if (cu_count() < 8) return MV_ERR_UNSUPPORTED;   // the persistent grid is a multiple of 8 workgroups (one run per XCD): callers fall back to the exact kernel
-    // MV_SPLIT_WAVES=8: the f16x2 kernel as ONE 8-wave workgroup per CU (two waves per SIMD, each wave one 32-column block).  Built to
-    // hide the fillers of one wave behind the MFMAs of the other; measured it is no faster (74.7 vs 74.4 us alone; all-zero operands
-    // 54.7 vs 57.1 us — the zero-data speed-up is the clock: identical cycle counters, profiles/r03_split_wait_counters.log — and inside
-    // its cycles the matrix pipe is 46 % busy in both forms: what the waves wait for is shared, barriers and the memory system, not issue
-    // slots) and it costs the co-running small kernels their registers (one-lane pipeline 4.40 k vs 4.84 k frames/s).
-    static int waves = -1;
-    if (waves < 0) { const char* e = getenv("MV_SPLIT_WAVES"); waves = (e && atoi(e) == 8) ? 8 : 4; }
+    // (round-3 / round-4 A/B forms, removed in round 5: the f16x2 kernel as one 8-wave workgroup per CU — no faster alone, 4.40 k vs 4.84 k frames/s in the
+    // pipe —; fewer persistent workgroups; workgroups claiming 160 KB of LDS to keep LDS-using kernels off their CUs — both slower.  DESIGN.md changelog.)
     // column regions: one region's B planes (nc / R sub-tiles x 64 rows x C x 2 B x pieces) <= 4 MB.  Measured at 640x480 (7.4 MB
     // of B planes per pair, all of it Infinity-Cache resident): R = 1 / 2 / 3 / 4 / 6 -> 117 / 110 / 113 / 114 / 116 us: fewer, longer
     // band segments (each segment change reloads 192 KB of A fragments per workgroup, ~3 us) against L2 hits on the B sub-tiles
@@ -766,31 +760,17 @@ extern "C" int mv_corr_volume_packed(const void* packed1, const void* packed2, f
         }
     }
 #endif
-    // one workgroup per CU, a multiple of 8: one run per XCD.  MV_SPLIT_WGS=<n>: fewer persistent workgroups (A/B knob for streams
-    // confined to a CU subset, MV_PIPE_SMALL_CUS)
-    static int wgs_env = -1;
-    if (wgs_env < 0) { const char* e = getenv("MV_SPLIT_WGS"); wgs_env = e ? atoi(e) : 0; }
-    const dim3 g((wgs_env >= 8 && wgs_env <= cu_count() ? wgs_env : cu_count()) & ~7);
-    // MV_SPLIT_LDS_KB=<n>: the workgroups claim n KB of LDS (more than the ring needs): no other workgroup that uses LDS — lookups, selector,
-    // covariance, solve — can then be placed on a CU that runs a GEMM workgroup, i.e. together with MV_SPLIT_WGS the small kernels get the
-    // remaining CUs to themselves without CU-masked queues (A/B knob)
-    static int lds_kb = -1;
-    if (lds_kb < 0) { const char* e = getenv("MV_SPLIT_LDS_KB"); lds_kb = e ? atoi(e) : 0; if (lds_kb > 160) lds_kb = 160; }
-    auto lds_bytes = [&](size_t need) { return std::max(need, (size_t)lds_kb * 1024); };
+    const dim3 g(cu_count() & ~7);   // one workgroup per CU, a multiple of 8: one run per XCD
+    auto lds_bytes = [&](size_t need) { return need; };
     if (mode == MV_PACK_BF16X3) {
         using K = SplitCfg<3, false, 16, 4>;
         mv_note_volume_kernel("corr_volume_split_stream<bf16x3>");
         hipLaunchKernelGGL((corr_volume_split_stream<3, false, 16, 4>), g, dim3(256), lds_bytes(K::NSLOT * K::SLOT_BYTES), (hipStream_t)stream,
                            (const uint16_t*)packed1, (const uint16_t*)packed2, out, N1, N2, B, R);
-    } else if (waves == 4) {
+    } else {
         using K = SplitCfg<2, true, 16, 4>;
         mv_note_volume_kernel("corr_volume_split_stream<f16x2>");
         hipLaunchKernelGGL((corr_volume_split_stream<2, true, 16, 4>), g, dim3(256), lds_bytes(K::NSLOT * K::SLOT_BYTES), (hipStream_t)stream,
-                           (const uint16_t*)packed1, (const uint16_t*)packed2, out, N1, N2, B, R);
-    } else {
-        using K = SplitCfg<2, true, 16, 8>;
-        mv_note_volume_kernel("corr_volume_split_stream<f16x2>");
-        hipLaunchKernelGGL((corr_volume_split_stream<2, true, 16, 8>), g, dim3(512), lds_bytes(K::NSLOT * K::SLOT_BYTES), (hipStream_t)stream,
                            (const uint16_t*)packed1, (const uint16_t*)packed2, out, N1, N2, B, R);
     }
     return mv_launch_status();

@@ -176,7 +176,6 @@ struct mvFramePipe {
     long n_vol;            // volume GEMMs issued (n_enq <= n_vol <= n_enq + 1: at most one GEMM ahead of its frame's decoder side)
     hipEvent_t e_in_of[MAX_VOL];   // per volume buffer: the input-ready event its GEMM waited for (the decoder side re-uses it)
     int lookups_on_main;   // default 1; MV_PIPE_LOOKUPS_ON=vol is the measured alternative
-    int serial_lookups;    // MV_PIPE_SERIAL_LOOKUPS: the packed GEMM of frame f waits for the lookups of frame f - 1
     int pose_cur;
     int prior_slot;        // pose slot the newest finished frame started from (its motion-model prior)
     hipEvent_t e_map;
@@ -252,11 +251,10 @@ static int flush_jobs(mvFramePipe* p);
 static void launch_thread_main(mvFramePipe* p);
 
 static int volbufs_from_env() {
-    // 3 (default): with a GEMM issued one frame ahead (mv_frame_pipe_enqueue_volume) the buffer it rewrites was last read by
-    // the lookups of frame t - 1, long finished; with 2 it waits for frame t's lookups, which run beside the previous GEMM at a
-    // third of their isolated speed (measured 272 vs 245 us per frame).  MV_PIPE_VOL_BUFS=2 is the A/B knob.
-    const char* e = getenv("MV_PIPE_VOL_BUFS");
-    return (e && atoi(e) == 2) ? 2 : 3;
+    // 3: with a GEMM issued one frame ahead (mv_frame_pipe_enqueue_volume) the buffer it rewrites was last read by the lookups of frame t - 1, long
+    // finished; with 2 (rounds 1-2; an A/B knob until round 5) it waited for frame t's lookups, which run beside the previous GEMM at a third of their
+    // isolated speed (measured 272 vs 245 us per frame)
+    return 3;
 }
 
 static size_t carve(mvFramePipe* p, char* base) {
@@ -432,60 +430,13 @@ static int create_impl(mvFramePipe* p) {
     int lo = 0, hi = 0;
     MV_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));   // hi = numerically lowest = highest priority
     // the GEMM and the decoder side run at normal priority; the short pose-dependent kernels go first when slots free up
-    // Spatial partitioning experiment (MV_PIPE_SMALL_CUS=<n>, default 0 = off): the GEMM stream is confined to 256 - n
-    // compute units (hipExtStreamCreateWithCUMask) and the three streams of latency-bound kernels to the other n, so that
-    // they stop slowing each other down.  Measured: n = 32 / 48 / 64 -> 0.83 / 0.81 / 0.75 ms per frame (interleaved mask,
-    // n = 32: 0.60) against 0.323 unpartitioned: the small kernels are grids of 300-600 workgroups sized for the whole
-    // chip and need far longer on an eighth of it than the GEMM gains from being left alone (233 vs 219 us).
-    int n_small = 0;
-    {
-        const char* e = getenv("MV_PIPE_SMALL_CUS");
-        if (e) n_small = atoi(e);
-    }
-    int n_cu = 0;
-    {
-        int dev = 0;
-        MV_HIP(hipGetDevice(&dev));
-        MV_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
-    if (n_small > 0 && n_small < n_cu && n_cu <= 1024) {
-        uint32_t big[32] = {0}, small[32] = {0};
-        const char* il = getenv("MV_PIPE_CU_INTERLEAVE");   // 1: every (n_cu / n_small)-th CU belongs to the small set
-        const int stride = (il && atoi(il) == 1) ? n_cu / n_small : 0;
-        for (int i = 0; i < n_cu; ++i) {
-            const bool is_small = stride ? (i % stride == stride - 1 && i / stride < n_small) : (i >= n_cu - n_small);
-            (is_small ? small : big)[i >> 5] |= 1u << (i & 31);
-        }
-        const uint32_t words = (uint32_t)((n_cu + 31) / 32);
-        MV_HIP(hipExtStreamCreateWithCUMask(&p->s_vol, words, big));
-        MV_HIP(hipExtStreamCreateWithCUMask(&p->s_main, words, small));
-        MV_HIP(hipExtStreamCreateWithCUMask(&p->s_back, words, small));
-        MV_HIP(hipExtStreamCreateWithCUMask(&p->s_side, words, small));
-    } else {
-        // MV_PIPE_GEMM_RESERVE=<n> (default 0): mask the GEMM's stream off n compute units so that kernels which cannot be
-        // placed beside four 104-register GEMM waves per SIMD (the selector's finishing workgroup, the LM solve) always find
-        // a free CU.  Measured: the selector then finishes 80 us earlier, but ANY CU mask costs the GEMM 12 % (218 -> 248 us,
-        // independent of n = 2, 4, 8 — presumably the round-robin workgroup -> XCD assignment its tile order relies on is
-        // lost), so the frame gets slower (0.354 vs 0.320 ms).
-        int reserve = 0;
-        {
-            const char* e = getenv("MV_PIPE_GEMM_RESERVE");
-            if (e) reserve = atoi(e);
-        }
-        if (reserve > 0 && reserve < n_cu && n_cu <= 1024) {
-            uint32_t big[32] = {0};
-            for (int i = 0; i < n_cu - reserve; ++i) big[i >> 5] |= 1u << (i & 31);
-            MV_HIP(hipExtStreamCreateWithCUMask(&p->s_vol, (uint32_t)((n_cu + 31) / 32), big));
-        } else {
-            MV_HIP(hipStreamCreateWithPriority(&p->s_vol, hipStreamNonBlocking, 0));
-        }
-        {
-            const char* e = getenv("MV_PIPE_MAIN_PRIO");   // A/B knob: queue priority of the lookups / epilogue / selector stream
-            MV_HIP(hipStreamCreateWithPriority(&p->s_main, hipStreamNonBlocking, (e && strcmp(e, "hi") == 0) ? hi : 0));
-        }
-        MV_HIP(hipStreamCreateWithPriority(&p->s_back, hipStreamNonBlocking, hi));
-        MV_HIP(hipStreamCreateWithPriority(&p->s_side, hipStreamNonBlocking, hi));
-    }
+    // (rounds 3-4 A/B, removed in round 5: confining the GEMM / the small kernels to disjoint CU sets with hipExtStreamCreateWithCUMask — any mask cost the
+    // GEMM 12 % and the small kernels, grids sized for the whole chip, far more: 0.60-0.83 vs 0.32 ms per frame — and a raised queue priority for the
+    // decoder-side stream: no gain.  profiles/r03_*; DESIGN.md changelog.)
+    MV_HIP(hipStreamCreateWithPriority(&p->s_vol, hipStreamNonBlocking, 0));
+    MV_HIP(hipStreamCreateWithPriority(&p->s_main, hipStreamNonBlocking, 0));
+    MV_HIP(hipStreamCreateWithPriority(&p->s_back, hipStreamNonBlocking, hi));
+    MV_HIP(hipStreamCreateWithPriority(&p->s_side, hipStreamNonBlocking, hi));
     if (p->sel_on_back == 2) MV_HIP(hipStreamCreateWithPriority(&p->s_sel, hipStreamNonBlocking, hi));
     auto mk = [](hipEvent_t* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming); };
     for (auto& e : p->e_in) MV_HIP(mk(&e));
@@ -600,8 +551,6 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
     {
         const char* e = getenv("MV_PIPE_LOOKUPS_ON");
         p->lookups_on_main = (e && strcmp(e, "vol") == 0) ? 0 : 1;
-        const char* e2 = getenv("MV_PIPE_SERIAL_LOOKUPS");
-        p->serial_lookups = e2 ? atoi(e2) : 0;
     }
     const int rc = create_impl(p);
     if (rc != MV_OK) {
@@ -669,11 +618,7 @@ static int issue_volume(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_s
             MV_HIP(hipEventRecord(p->e_packed[f & 1], sp));
             MV_HIP(hipStreamWaitEvent(p->s_vol, p->e_packed[f & 1], 0));
         }
-        // MV_PIPE_SERIAL_LOOKUPS=1 (A/B, round 4): the GEMM waits for the previous frame's lookups.  A one-wave-per-SIMD MFMA stream and the
-        // lookups' waves do not share a SIMD to any gain (period = GEMM alone + lookup chain alone either way); run back to back,
-        // each has the chip to itself and the GEMM's in-pipeline time is its alone-time.  The pack stays in front of the wait (it overlaps the lookups).
-        if (p->serial_lookups && f >= 1 && p->vol_free_valid[(f - 1) % p->n_volbuf])
-            MV_TRY(wait_if_pending(p->s_vol, p->e_vol_free[(f - 1) % p->n_volbuf]));
+        // (round-4 A/B, removed: the GEMM waiting for the previous frame's lookups — each then has the chip to itself — cost 21 % of the frame rate)
         if (timed) MV_HIP(hipEventRecord(p->tv0[p->n_timed], p->s_vol));   // the GEMM alone: behind the pack, wherever that ran
         MV_TRY(mv_corr_volume_packed(pk[0], pk[1], p->vol[k], B, c.C, p->n8, p->n8, c.volume_split, p->s_vol));
     } else if (c.volume_split == 2 || c.volume_split == 3) {
@@ -739,8 +684,7 @@ static int issue_selector_segment(mvFramePipe* p, const SelSeg& d) {
     }
     if (p->release_valid) MV_TRY(wait_if_pending(s, p->e_release));   // ... and by consumers of result views (mv_frame_pipe_release)
     Maps& mp = p->maps[m];
-    static int fuse_epi = -1;   // MV_PIPE_FUSE_EPI=0: epilogue and selector as separate launches (A/B knob)
-    if (fuse_epi < 0) { const char* e = getenv("MV_PIPE_FUSE_EPI"); fuse_epi = (e && atoi(e) == 0) ? 0 : 1; }
+    constexpr bool fuse_epi = true;   // epilogue + the selector's first kernel in one launch (the separate form was an A/B knob of rounds 2-4)
     if (up) {
         MV_TRY(mv_convex_upsample(in->flow8, in->up_mask, p->up_flow, B, p->h8, p->w8, 0.25f, 0, s));
         MV_TRY(mv_convex_upsample(in->cov8, in->cov_mask, p->up_cov, B, p->h8, p->w8, 1.0f, 1, s));
@@ -995,26 +939,20 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
     MV_TRY(wait_if_pending(s, p->e_cand[pd.cand]));   // fired: the host has just read this frame's count
     const int ti = pd.ti;
     if (ti >= 0) MV_HIP(hipEventRecord(p->tv4[ti], s));
-    static int fuse_front = -1;   // MV_PIPE_FUSE_FRONT=0: gather / track / back-projection as three launches + a permutation copy (A/B knob)
-    if (fuse_front < 0) { const char* e = getenv("MV_PIPE_FUSE_FRONT"); fuse_front = (e && atoi(e) == 0) ? 0 : 1; }
-    const bool perm_in_args = fuse_front && L == 1 && n_max <= 256;
+    const bool perm_in_args = L == 1 && n_max <= 256;   // one lane: the permutation rides in the kernel arguments (no pinned staging copy, no H2D node)
     if (!perm_in_args) {
         const size_t perm_bytes = ((size_t)(L - 1) * cap + n_sel[L - 1]) * sizeof(int64_t);
         MV_HIP(hipMemcpyAsync(b.perm, p->h_perm[ps], perm_bytes, hipMemcpyHostToDevice, s));
         MV_HIP(hipEventRecord(p->e_perm[ps], s));
         p->perm_valid[ps] = true;
     }
-    if (!fuse_front) MV_TRY(mv_kp_gather_lanes(p->cand[pd.cand], (size_t)p->plane, b.perm, L, n_sel, cap, c.W, b.kp0, s));
     // Pose-INDEPENDENT part first: it overlaps the previous frames' solves.  The chain solve(t-1) -> backend(t) -> solve(t) is the
     // sequential dependency of visual odometry and, beside a GEMM that never pauses, it was the period of a single-sequence
     // stream (track 19 + back-projection 9 + covariances 48 + filters 21 + solve 108 us + launch gaps and two stream hops =
     // ~290 us).  Only the rotation into the world frame needs the previous pose (MACVO.py:273-281): it runs as one tiny kernel on
     // the SOLVE's stream right behind the previous solve, so the critical chain is solve -> mv_pose_apply_lanes -> solve on one
     // in-order stream.
-    static int pose_split = -1;   // MV_PIPE_POSE_SPLIT=0: the whole backend behind the previous solve, as before (A/B knob)
-    if (pose_split < 0) { const char* e = getenv("MV_PIPE_POSE_SPLIT"); pose_split = (e && atoi(e) == 0) ? 0 : 1; }
-    if (!pose_split && p->pgo_valid) MV_TRY(wait_if_pending(s, p->e_pgo));
-    const bool fused = p->fuse_backend && fuse_front;
+    const bool fused = p->fuse_backend != 0;
     mvMatchCovParams cp{c.H, c.W, c.cov_kernel_size, 1, c.fx, c.fy, c.cx, c.cy, c.min_flow_cov_sq, c.min_depth_cov};
     if (fused) {
         // gather + track + back-projection + both covariance models + observation filters = ONE launch
@@ -1026,17 +964,11 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
         if (c.mapping)
             MV_TRY(mv_obs_filter_lanes(b.inbound, b.cov0, b.cov1, b.vals, c.filters, c.filter_min_depth, c.max_depth, L, n_sel, cap,
                                        b.valid, b.n_valid, s));
-    } else if (fuse_front) {
+    } else {   // MV_PIPE_FUSE_BACKEND=0: the five-launch form (the reference point of the bitwise test)
         MV_TRY(mv_kp_front_lanes(p->cand[pd.cand], (size_t)p->plane, b.perm, perm_in_args ? p->h_perm[ps] : nullptr, L, n_sel, cap,
                                  m1.match_flow, m1.match_cov, m0.depth, m0.disparity, m0.disparity_cov, m0.depth_cov, m1.depth,
                                  m1.disparity, m1.disparity_cov, m1.depth_cov, c.H, c.W, c.edgewidth, c.match_cov_default, c.fx, c.fy,
                                  c.cx, c.cy, b.kp0, b.kp0f, b.kp1, b.inbound, b.vals, b.sigma0, b.sigma1, b.pos_Tc, s));
-    } else {
-        MV_TRY(mv_kp_track_lanes(b.kp0, L, n_sel, cap, m1.match_flow, m1.match_cov, m0.depth, m0.disparity, m0.disparity_cov,
-                                 m0.depth_cov, m1.depth, m1.disparity, m1.disparity_cov, m1.depth_cov, c.H, c.W, c.edgewidth,
-                                 c.match_cov_default, b.kp0f, b.kp1, b.inbound, b.vals, b.sigma0, b.sigma1, s));
-        MV_TRY(mv_backproject_lanes(b.kp0f, b.vals, 1, (size_t)cap, c.fx, c.fy, c.cx, c.cy, nullptr, L, n_sel, cap, b.pos_Tc,
-                                    nullptr, nullptr, s));
     }
     if (!fused) {
         MV_TRY(mv_match_cov_pair_lanes(m0.depth, b.kp0f, b.sigma0, nullptr, b.cov0, nullptr, m1.depth, b.kp1, b.sigma1, b.cov1, &cp,

@@ -187,32 +187,6 @@ print(hashlib.sha1(a.cpu().numpy().tobytes()).hexdigest())
     assert len(set(shas)) == 1, shas
 
 
-def test_f16x2_eight_wave_form_is_bitwise_the_four_wave_form(gpu):
-    """MV_SPLIT_WAVES=8 (one 8-wave workgroup per CU, two waves per SIMD, A fragments split over both register files) multiplies the
-    same pieces in the same order: the volumes must agree bit for bit — which also guards the hand-placed waits of that form and
-    the register-file placement of its asm loads (a moved fragment shows up as garbage)."""
-    import os, subprocess, sys
-
-    code = r'''
-import hashlib, sys, torch
-sys.path.insert(0, sys.argv[1])
-from macvo_amd import ops
-for B, H, W in ((2, 60, 80), (3, 59, 64), (1, 16, 24)):
-    g = torch.Generator().manual_seed(9)
-    f1 = torch.randn(B, 256, H, W, generator=g).cuda(); f2 = torch.randn(B, 256, H, W, generator=g).cuda()
-    f1[0, :, 0, 0] *= 1e5
-    a = ops.corr_volume(f1, f2, precision="f16x2")
-    print(hashlib.sha1(a.cpu().numpy().tobytes()).hexdigest())
-'''
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    shas = []
-    for waves in ("4", "8"):
-        r = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, MV_SPLIT_WAVES=waves), capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        shas.append(r.stdout.split())
-    assert len(shas[0]) == 3 and shas[0] == shas[1], shas
-
-
 @pytest.mark.parametrize("mode", ["f16x2", "bf16x3"])
 @pytest.mark.parametrize("B,H,W", [(2, 60, 80), (6, 24, 32), (1, 8, 8)])
 def test_tiled_volume_and_tiled_lookup_equal_the_row_major_forms(gpu, mode, B, H, W):
