@@ -1221,197 +1221,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// fp32, CHW operands, square volumes: STREAMING form (round 2, MV_VOL_STREAM=1).  The shape of the 16-bit streaming kernel above
-// for the MFMA-bound case: persistent 4-wave workgroups, two per CU (a single wave per SIMD tops out at ~80 % of the MFMA rate —
-// measured with everything but the MFMAs removed — so two waves share each SIMD);
-//   * item = 128 rows x 64 columns; a wave keeps the whole-K A fragments of its 32 rows in registers (C / 2 VGPRs: lane
-//     (row, kh) holds k = 2 ks + kh, exactly the v_mfma_f32_32x32x2f32 A operand) and owns 32 x 64 outputs (2 accumulators);
-//   * B streams through a 2-slot LDS ring by LDS-DMA, one slot per K HALF (128 k x 64 columns x 4 B = 32 KB): while half h is
-//     multiplied (128 MFMAs per wave, 8 k cycles) the other slot is refilled, 8 1-KB pieces per wave issued between the first
-//     MFMAs; two barriers per item instead of sixteen per tile;
-//   * the 32 stores of an item are issued behind its last MFMA; the SIMD's other wave has the pipe meanwhile;
-//   * results are the bits of the tile kernels: the same instruction over the same ascending k pairs.
-// Edge (N = 4800 = 37.5 x 128): rows past N repeat row N - 1, in the operands and in the store addresses, so the duplicates
-// land on their original with identical values (1.3 % extra MFMAs).  N % 64 == 0 keeps the columns whole.
-// ------------------------------------------------------------------------------------------------
-
-template <int C>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void corr_volume_f32_stream(
-    const float* __restrict__ f1, const float* __restrict__ f2, float* __restrict__ out, int N, int B, int R) {
-    constexpr int KP = C / 2, KPH = KP / 2;      // k pairs; per ring slot
-    constexpr int SLOTF = (C / 2) * 64;          // floats per slot: C / 2 k rows x 64 columns
-    constexpr int NPC = SLOTF * 4 / 1024 / 4;    // 1-KB DMA pieces per wave and slot (8)
-    static_assert(KPH > NPC + 1, "interleave plan: pieces behind k pairs 0..NPC-1, loader walk behind NPC");
-    extern __shared__ __attribute__((aligned(16))) float smem_fs[];
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int kh = lane >> 5, li = lane & 31;
-    const int nb = (N + 127) >> 7, nc = N >> 6;
-    const int per = nb * nc, T = B * per;
-    int it, it_end;
-    {
-        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, nj = gridDim.x >> 3;
-        const long lo = (long)x * T / 8, hi = ((long)x + 1) * T / 8;
-        it = (int)(lo + (hi - lo) * j / nj);
-        it_end = (int)(lo + (hi - lo) * (j + 1) / nj);
-    }
-    if (it >= it_end) return;
-    auto reg_c0 = [&](int g) { return (int)((long)g * nc / R); };
-    auto decode = [&](int i, int& b, int& g, int& band, int& c) {
-        b = i / per;
-        int rem = i - b * per;
-        g = 0;
-        while (g + 1 < R && rem >= nb * reg_c0(g + 1)) ++g;
-        rem -= nb * reg_c0(g);
-        const int w = reg_c0(g + 1) - reg_c0(g);
-        band = rem / w;
-        c = reg_c0(g) + (rem - band * w);
-        b = __builtin_amdgcn_readfirstlane(b);
-        g = __builtin_amdgcn_readfirstlane(g);
-        band = __builtin_amdgcn_readfirstlane(band);
-        c = __builtin_amdgcn_readfirstlane(c);
-    };
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem_fs);
-    // ---- B loader (LDS-DMA): walks (item, K half) one step ahead of the MFMAs, all state wave-uniform ----
-    int ld_it = it, ld_b, ld_g, ld_band, ld_c, ld_c0, ld_cend, ld_h = 0;
-    decode(it, ld_b, ld_g, ld_band, ld_c);
-    ld_c0 = reg_c0(ld_g);
-    ld_cend = reg_c0(ld_g + 1);
-    bool ld_live = true;                         // false once the run's last half has been issued
-    // a piece = 4 k rows x 64 columns: lane -> row lane / 16, columns 4 (lane % 16) ..
-    const unsigned pc_vo = (unsigned)(((lane >> 4) * N + 4 * (lane & 15)) * 4);
-    const float* pc_src = nullptr;               // per half: source of this wave's piece 0 / LDS byte address of it
-    unsigned pc_dst = 0;
-    auto arm = [&]() __attribute__((always_inline)) {
-        pc_src = f2 + ((size_t)ld_b * C + ld_h * (C / 2) + 4 * wave * NPC) * N + (size_t)ld_c * 64;
-        pc_dst = lds0 + (unsigned)(ld_h * SLOTF + wave * NPC * 256) * 4u;
-    };
-    auto piece = [&](int p) __attribute__((always_inline)) {
-        if (ld_live) glds16_s(pc_vo, pc_src + (size_t)(4 * p) * N, pc_dst + (unsigned)p * 1024u);
-    };
-    auto advance = [&]() __attribute__((always_inline)) {           // behind the last piece of a half
-        if (ld_h == 0) {
-            ld_h = 1;
-        } else {
-            ld_h = 0;
-            if (ld_it + 1 >= it_end) {
-                ld_live = false;
-            } else {
-                ++ld_it;
-                if (++ld_c == ld_cend) {
-                    if (++ld_band == nb) {
-                        ld_band = 0;
-                        if (++ld_g == R) {
-                            ld_g = 0;
-                            ++ld_b;
-                        }
-                        ld_c0 = reg_c0(ld_g);
-                        ld_cend = reg_c0(ld_g + 1);
-                    }
-                    ld_c = ld_c0;
-                }
-            }
-        }
-        arm();
-    };
-    // ---- A fragments: ordinary (compiler-tracked) loads.  An asm load's destination counts as written at the end of the
-    // statement, and under register pressure hipcc parks such values elsewhere right away — before the data has landed (seen with
-    // an earlier form: the first items after a band change came out with the previous band's rows). ----
-    float af[KP];
-    auto load_a = [&](int b, int band) __attribute__((always_inline)) {
-        const int row = min(band * 128 + wave * 32 + li, N - 1);
-        // buffer loads: descriptor + one 32-bit lane offset + a scalar offset per k pair (a global_load would carry a 64-bit
-        // per-lane address for each of the C / 2 loads: 2 x 128 VGPRs of addresses and a spilled fragment array)
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f1 + (size_t)b * C * N), 0, C * N * 4, 0x00020000);
-        const int vo = (kh * N + row) * 4;
-#pragma clang loop unroll(full)
-        for (int ks = 0; ks < KP; ++ks) af[ks] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, 2 * ks * N * 4, 0));
-    };
-    unsigned roff[16];                           // per-lane byte offsets of the 16 accumulator rows (C/D layout), fixed for a band
-    float* O = nullptr;                          // column 0 of the current item's block, row 0 of the pair
-    f32x16 c0, c1;
-    // one K half: 2 x KPH MFMAs; the other ring slot is refilled behind the first ones
-    auto half = [&](auto HH) __attribute__((always_inline)) {
-        constexpr int H = decltype(HH)::value;
-        // H = 0: this wave's pieces of slot 0 went out before the previous item's 32 stores; H = 1: nothing was issued behind the
-        // pieces of slot 1.  Behind the barrier all four waves' pieces are in and the other slot is free.
-        wait_vmcnt_barrier<(H == 0 ? 32 : 0)>();
-        const float* q = smem_fs + H * SLOTF + kh * 64 + li;
-        constexpr int PF = 2;
-        float fb[PF + 1][2];
-#pragma unroll
-        for (int ks = 0; ks < PF; ++ks) {
-            fb[ks][0] = q[ks * 128];
-            fb[ks][1] = q[ks * 128 + 32];
-        }
-#pragma clang loop unroll(full)
-        for (int ks = 0; ks < KPH; ++ks) {
-            const float a = af[H * KPH + ks];
-            if (H == 0 && ks == 0) {
-                f32x16 z;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, fb[0][0], z, 0, 0, 0);
-            } else {
-                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, fb[ks % (PF + 1)][0], c0, 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks < NPC) piece(ks);
-            if (ks == NPC) advance();
-            __builtin_amdgcn_sched_barrier(0);
-            if (H == 0 && ks == 0) {
-                f32x16 z;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, fb[0][1], z, 0, 0, 0);
-            } else {
-                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, fb[ks % (PF + 1)][1], c1, 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks + PF < KPH) {
-                fb[(ks + PF) % (PF + 1)][0] = q[(ks + PF) * 128];
-                fb[(ks + PF) % (PF + 1)][1] = q[(ks + PF) * 128 + 32];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    using H0 = std::integral_constant<int, 0>;
-    using H1 = std::integral_constant<int, 1>;
-    int cur_key = -1;
-    arm();
-#pragma unroll
-    for (int p = 0; p < NPC; ++p) piece(p);      // prologue: first half of the first item into slot 0
-    advance();
-    for (; it < it_end; ++it) {
-        int b, g, band, c;
-        decode(it, b, g, band, c);
-        const int key = b * nb + band;
-        if (key != cur_key) {                    // band change: A fragments, store rows
-            load_a(b, band);
-#pragma clang loop unroll(full)
-            for (int ks = 0; ks < KP; ++ks) asm volatile("" : "+v"(af[ks]));   // hipcc's wait for them lands here, inside the branch
-            cur_key = key;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                roff[r] = ((unsigned)min(band * 128 + wave * 32 + 4 * kh + (r & 3) + 8 * (r >> 2), N - 1) * (unsigned)N + li) * 4u;
-        }
-        O = out + (size_t)b * N * N + (size_t)c * 64;
-        half(H0{});
-        half(H1{});
-        // The asm stores below read the accumulators straight behind the last MFMAs.  hipcc's hazard recognizer does not look
-        // into inline asm, and "XDL write VGPR -> VMEM read of it" is a software hazard on CDNA (18 wait states for a 16-pass
-        // MFMA): without the s_nops the last MFMA's block was stored before it had been written (seen: 0.3 % wrong elements,
-        // all in the second column block).
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {           // asm: uniform base + 32-bit lane offset (see the 16-bit kernel); counted by hand
-            asm volatile("global_store_dword %0, %1, %2" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(c0[r]), "s"(O) : "memory");
-            asm volatile("global_store_dword %0, %1, %2 offset:128" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(c1[r]), "s"(O) : "memory");
-        }
-    }
-    wait_vmcnt<0>();                             // nothing of this workgroup may still be in flight towards its LDS when it retires
-}
+// (round 2: an fp32 STREAMING form of this GEMM — persistent workgroups, whole-K A fragments in registers, B through an LDS-DMA ring in K halves —
+// was built, gave the tile kernels' bits and ran 193 us against their 186: measured and not adopted, removed in round 5.  DESIGN.md changelog.)
 
 // ------------------------------------------------------------------------------------------------
 // 16-bit operands, CHW ([C][N]): K-major.  The tile is staged K-major in LDS ([BK][128]) and each lane
@@ -1659,27 +1470,6 @@ extern "C" int mv_corr_volume(const void* f1, const void* f2, float* out, int B,
         const float* a = (const float*)f1;
         const float* b = (const float*)f2;
         if (layout == MV_LAYOUT_CHW) {
-            static int fstream = -1;   // MV_VOL_STREAM=1: streaming form (A/B knob while it is being measured)
-            if (fstream < 0) { const char* e = getenv("MV_VOL_STREAM"); fstream = (e && atoi(e) > 0) ? 1 : 0; }
-            if (fstream && N1 == N2 && C == 256 && (N1 % 64) == 0 && N1 >= 256 && ((size_t)N1 * N2) < ((size_t)1 << 30) &&
-                stream_items_fit(B, N1, N2)) {
-                static int cus = 0;
-                if (!cus) {
-                    int dev = 0;
-                    hipDeviceProp_t prop;
-                    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                              ? prop.multiProcessorCount : 256;
-                    (void)hipFuncSetAttribute((const void*)corr_volume_f32_stream<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                }
-                static int regs_env = -1;
-                if (regs_env < 0) { const char* e = getenv("MV_VOL_STREAM_REGIONS"); regs_env = e ? atoi(e) : 0; }
-                const int nc = N1 / 64;
-                int R = regs_env > 0 ? regs_env : (int)(((size_t)nc * 64 * C * 4 + (2u << 20) - 1) / (2u << 20));
-                R = std::max(1, std::min(R, nc));
-                MV_VOL_KERNEL("corr_volume_f32_stream");
-                hipLaunchKernelGGL((corr_volume_f32_stream<256>), dim3((cus & ~7) * 2), block, 64 * 1024, s, a, b, out, N1, B, R);
-                return mv_launch_status();
-            }
             VolSched vs;
             const int slots = sched_slots();
             if (slots > 0 && N1 == N2 && (C % 32) == 0 && make_vol_sched(N1, B, slots, vs)) {

@@ -169,27 +169,11 @@ def test_corr_volume_f32_staging_variants_are_bitwise_equal(gpu):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     shas = []
     for flag in ("32", "16", "4", "0"):
-        env = dict(os.environ, MV_VOL_DMA=flag, MV_VOL_STREAM="0")
+        env = dict(os.environ, MV_VOL_DMA=flag)
         r = subprocess.run([sys.executable, "-c", _F32_STREAM_VS_TILES, root], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         shas.append(r.stdout.split())
     assert len(shas[0]) == 3 and all(x == shas[0] for x in shas[1:]), shas
-
-
-def test_corr_volume_f32_streaming_form_is_bitwise_the_mixed_tile_form(gpu):
-    """The opt-in fp32 streaming kernel (MV_VOL_STREAM=1: A fragments in registers, LDS-DMA ring in K halves, asm stores behind the
-    last MFMA with the hazard no-ops) against the default mixed-tile kernel: same instruction, same ascending k pairs -> same
-    bits.  Shapes: 37.5 bands (rows past N repeat row N - 1), whole bands, three pairs with a half band."""
-    import os, subprocess, sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    shas = []
-    for flag in ("1", "0"):
-        env = dict(os.environ, MV_VOL_STREAM=flag)
-        r = subprocess.run([sys.executable, "-c", _F32_STREAM_VS_TILES, root], env=env, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        shas.append(r.stdout.split())
-    assert len(shas[0]) == 3 and shas[0] == shas[1], shas
 
 
 def _coords(B, H, W, seed, spread=8.0):
