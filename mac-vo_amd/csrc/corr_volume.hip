@@ -21,6 +21,7 @@
 //     8- or 16-deep register ring, no barriers) measured 395 / 628 us vs 250 us: the LDS tile is worth keeping.)
 #include "common.h"
 #include "vol_asm.h"
+#include <atomic>
 #include <type_traits>
 #include <stdlib.h>
 #include <string.h>
@@ -1415,24 +1416,27 @@ static bool h_stream_supported(int B, int C, int N1, int N2) {
 
 static int launch_h_stream(const uint16_t* a, const uint16_t* b, void* outp, bool out16, bool bf, int B, int C, int N1, int N2, hipStream_t s) {
     float* out = reinterpret_cast<float*>(outp);
-    static int cus = 0;
+    // CU count and the kernels' LDS attribute: per device ordinal (a process-wide static mishandled a second GPU)
+    static std::atomic<int> cus_dev[64];
+    static std::atomic<bool> attr_dev[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int cus = cus_dev[dev].load(std::memory_order_relaxed);
     if (!cus) {
-        int dev = 0;
         hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount : 256;
+        cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        cus_dev[dev].store(cus, std::memory_order_relaxed);
     }
     static int wgs = 0;    // workgroups per CU; LDS is padded so that exactly this many are resident
     if (!wgs) { const char* e = getenv("MV_H_STREAM_WGS"); wgs = e ? atoi(e) : 2; if (wgs < 1 || wgs > 4) wgs = 2; }
     const unsigned ring = (unsigned)(2 * 64 * (C / 8) * 16);            // 2-slot B ring
     const unsigned lds = std::max(ring, (unsigned)(160 * 1024 / (wgs + 1) + 1024));
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (!attr_dev[dev].load(std::memory_order_acquire)) {
 #define MV_HS_ATTR(...) (void)hipFuncSetAttribute((const void*)corr_volume_h_stream<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
         MV_HS_ATTR(true, 16); MV_HS_ATTR(false, 16); MV_HS_ATTR(true, 8); MV_HS_ATTR(false, 8);
         MV_HS_ATTR(true, 16, true); MV_HS_ATTR(false, 16, true); MV_HS_ATTR(true, 8, true); MV_HS_ATTR(false, 8, true);
 #undef MV_HS_ATTR
-        attr_done = true;
+        attr_dev[dev].store(true, std::memory_order_release);
     }
     const dim3 g((cus & ~7) * wgs), blk(256);                           // a multiple of 8: one run per XCD
     // column regions: one region's B rows (nc / R sub-tiles x 64 rows x 2C bytes) <= 2 MB of an XCD's 4 MB L2 (measured: 640x480

@@ -645,15 +645,17 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 
     wait_vmcnt<0>();                             // nothing of this workgroup may still be in flight towards its LDS when it retires
 }
 
-static int cu_count() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
+static int cu_count() {   // of the CURRENT device (cached per ordinal: a process may drive GPUs of different sizes)
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (!n) {
         hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount : 256;
+        n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        cus[dev].store(n, std::memory_order_relaxed);
     }
-    return cus;
+    return n;
 }
 
 }  // namespace
@@ -711,7 +713,8 @@ extern "C" int mv_volume_pack_tiled(const float* f1, const float* f2, void* pack
 
 // shapes the streaming GEMM covers (the caller falls back to the exact fp32 kernel otherwise — never less accurate)
 extern "C" int mv_corr_volume_packed_supported(int B, int C, int N1, int N2, int mode) {
-    return pieces_of(mode) != 0 && C == 256 && B > 0 && B <= 65535 && N1 >= 32 && N2 >= 64 && (N2 % 64) == 0 &&
+    // (cu_count() >= 8: the persistent grid is a multiple of 8 workgroups, one run per XCD — part of "supported" so that callers fall back BEFORE they pack)
+    return cu_count() >= 8 && pieces_of(mode) != 0 && C == 256 && B > 0 && B <= 65535 && N1 >= 32 && N2 >= 64 && (N2 % 64) == 0 &&
            ((size_t)N1 * N2) < ((size_t)1 << 30) &&                                               // 32-bit byte offsets inside a pair's block
            (size_t)B * (size_t)((N1 + 127) / 128) * (size_t)(N2 / 64) < ((size_t)1 << 31);        // int item index
 }
