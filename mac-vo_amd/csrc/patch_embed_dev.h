@@ -43,4 +43,44 @@ __device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
 template <bool F16>
 __device__ __forceinline__ f32x4 mma16t(bf16x8 act, bf16x8 wgt, f32x4 c) { return mma16<F16>(wgt, act, c); }
 
+// LDS plan of the whole-slice kernels (patch_embed.hip: two slices per pass; patch_embed_v3.hip: producer / consumer wave groups) for 60 / 64 x 80 slices
+template <int H2, int W2>
+struct PE {
+    static constexpr int HP = (H2 + 7) / 8 * 8, WP = (W2 + 7) / 8 * 8;
+    static constexpr int H1 = HP / 2, W1 = WP / 2, H2o = HP / 4, W2o = WP / 4, H3 = HP / 8, W3 = WP / 8;
+    static constexpr int M1 = H1 * W1, M2 = H2o * W2o, M3 = H3 * W3;
+    static constexpr int T1 = M1 / 16, T2 = M2 / 16, T3 = M3 / 16;         // 16-pixel tiles (v_mfma_f32_16x16x32_bf16 everywhere)
+    static_assert(M1 % 64 == 0 && T2 == 20 && T3 == 5, "five tiles per wave in conv2 (a quarter of the map) and conv3 (one slice)");
+    static constexpr int IN_ROWS = HP + 6, IN_PITCH = WP + 8;              // halo 2; the zero-weight padding taps (ky, kx' = 6, 7) read two rows / columns further
+    static constexpr int O1_ROWS = H1 + 4, O1_COLS = W1 + 4;               // x 16 channels (bf16)
+    static constexpr int O2_ROWS = H2o + 4, O2_COLS = W2o + 4;             // x 32 channels
+    // Activation maps in LDS are stored [8-channel chunk][column parity][row][column / 2][8 channels = 16 B] (round 4, second pass): a
+    // stride-2 convolution's fragment read — 32 lanes = 32 consecutive output pixels, one tap, one chunk — then walks CONSECUTIVE 16-byte
+    // cells of one parity plane (bank-conflict-free up to the row wrap) instead of cells 64 / 128 bytes apart (HWC: 4-way conflicts in conv2,
+    // 8-way in conv3, measured as 85 % of the kernel's time being LDS-bound).  Same bytes, same sizes.
+    static_assert(O1_COLS % 2 == 0 && O2_COLS % 2 == 0, "column-parity planes");
+    // Row pitch of a plane in 16-byte cells.  A fragment read's 16-lane service groups span up to three output rows; the next output row
+    // is 2 x pitch cells further, and the groups tile all 16 bank quads exactly when 2 x pitch = 4 (mod 16) for 20-pixel rows (conv2) and
+    // = 10 (mod 16) for 10-pixel rows (conv3) — simulated over every tile alignment: 2.0 / 2.4 LDS cycles per 32 lanes against 3.6 / 5.6 for
+    // the tight pitches 22 / 12 (the room comes from keeping conv2's weights in registers instead of LDS).
+    static constexpr int pad_xh(int lo, int r) { int x = lo; while (x % 8 != r) ++x; return x; }
+    static constexpr int O1_XH = pad_xh(O1_COLS / 2, 2), O2_XH = pad_xh(O2_COLS / 2, 5);
+    // one (chunk, parity) plane.  A 16x16x32 fragment read has its four 16-lane groups in four DIFFERENT planes (lane / 16 = chunk / parity): the plane
+    // stride decides whether they collide.  Simulated over every tile (4.0 LDS cycles per 64 lanes = conflict-free): conv1 map, pitch 26: no pad -> 4.0,
+    // + 16 B -> 8.0; conv2 map, pitch 13: + 64 B -> 4.0, every other pad -> 8.0.
+    static constexpr unsigned O1_PLANE = O1_ROWS * O1_XH * 16, O2_PLANE = O2_ROWS * O2_XH * 16 + 64;
+    static_assert(O1_PLANE % 256 == 128 && O2_PLANE % 256 == 128, "plane strides as simulated (both land on half a bank row)");
+    // byte offset of 8-channel chunk c of padded cell (row, col)
+    static constexpr unsigned o1_cell(int c, int row, int col) { return (unsigned)(c * 2 + (col & 1)) * O1_PLANE + (unsigned)(row * O1_XH + (col >> 1)) * 16; }
+    static constexpr unsigned o2_cell(int c, int row, int col) { return (unsigned)(c * 2 + (col & 1)) * O2_PLANE + (unsigned)(row * O2_XH + (col >> 1)) * 16; }
+    static constexpr unsigned OFF_IN0 = 0, IN0_BYTES = IN_ROWS * IN_PITCH * 2;
+    static constexpr unsigned OFF_O1 = OFF_IN0 + IN0_BYTES, O1_BYTES = 4 * O1_PLANE;      // 2 chunks x 2 parity planes
+    static constexpr unsigned OFF_O2 = OFF_O1 + O1_BYTES, O2_BYTES = 8 * O2_PLANE;      // 4 chunks x 2 parity planes
+    static constexpr unsigned OFF_W2B = OFF_O2 + 2 * O2_BYTES, W2B_BYTES = 18 * 1024;   // conv2 weight fragments of channel tile 1 (tile 0: registers)
+    static constexpr unsigned LDS_BYTES = OFF_W2B + W2B_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS plan");
+    static constexpr int Q4 = H2 * W2 / 4;                                 // float4s of a slice
+    static_assert(W2 % 4 == 0 && Q4 <= 5 * 256, "slice staging: at most five float4 per thread");
+};
+
 }  // namespace pe
