@@ -224,27 +224,41 @@ __global__ __launch_bounds__(256) void cost_patch_embed_strip_kernel(const void*
 
         // ---- (B) conv1: row groups round robin over the waves; a group = G1 rows = TG1 tiles; K = 2 x 32 = (ky 0..7) x (kx' 0..7), taps >= 6 carry zero weights
         {
+            // software-pipelined by hand (see patch_embed_v3.hip): the fragment of the NEXT tile is read before this tile's store — hipcc keeps LDS reads
+            // behind earlier LDS writes it cannot disambiguate, which serialised the tiles into one LDS round trip each
             const int ngroups = (st.c1n + P::G1 - 1) / P::G1;
+            auto load_tile = [&](int g, int j, i32x4* af) __attribute__((always_inline)) {
+                const char* a0 = in0 + (2 * g * P::G1) * (P::IN_PITCH * 2) + c1_a[j];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const unsigned* ap = reinterpret_cast<const unsigned*>(a0 + 2 * s * P::IN_PITCH * 2);
+                    af[s] = i32x4{(int)ap[0], (int)ap[1], (int)ap[2], (int)ap[3]};
+                }
+            };
+            i32x4 afr[2][2];
+            if (wave < ngroups) load_tile(wave, 0, afr[0]);
             for (int g = wave; g < ngroups; g += 4) {
-                const char* abase = in0 + (2 * g * P::G1) * (P::IN_PITCH * 2);
                 char* dbase = o1 + ((st.c1lo - st.r0_1 + g * P::G1) * P::O1_XH) * 16;
 #pragma unroll
                 for (int j = 0; j < P::TG1; ++j) {
-                    i32x4 af[2];
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const unsigned* ap = reinterpret_cast<const unsigned*>(abase + c1_a[j] + 2 * s * P::IN_PITCH * 2);
-                        af[s] = i32x4{(int)ap[0], (int)ap[1], (int)ap[2], (int)ap[3]};
-                    }
+                    // next tile: j + 1 of this group, or tile 0 of this wave's next group
+                    i32x4* const mine = afr[j & 1];
+                    i32x4* const next = afr[(j + 1) & 1];
+                    if (j + 1 < P::TG1) load_tile(g, j + 1, next);
+                    else if (g + 4 < ngroups) load_tile(g + 4, 0, next);
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) acc = mma16t<F16>(__builtin_bit_cast(bf16x8, af[s]), __builtin_bit_cast(bf16x8, w1f[s]), acc);
+                    for (int s = 0; s < 2; ++s) acc = mma16t<F16>(__builtin_bit_cast(bf16x8, mine[s]), __builtin_bit_cast(bf16x8, w1f[s]), acc);
                     if (P::G1 == 1 || g * P::G1 + c1_rr[j] < st.c1n) {
                         unsigned* d = reinterpret_cast<unsigned*>(dbase + c1_d[j]);
                         const unsigned lo = cvt_pack<F16>(fmaxf(acc[0] + b1v[0], 0.f), fmaxf(acc[1] + b1v[1], 0.f));
                         const unsigned hi = cvt_pack<F16>(fmaxf(acc[2] + b1v[2], 0.f), fmaxf(acc[3] + b1v[3], 0.f));
                         *reinterpret_cast<unsigned long long*>(d) = (unsigned long long)lo | ((unsigned long long)hi << 32);
                     }
+                }
+                if (P::TG1 & 1) {   // an odd tile count flips the ring parity for the next group: move the prefetched fragment to slot 0
+                    afr[0][0] = afr[1][0];
+                    afr[0][1] = afr[1][1];
                 }
             }
         }
