@@ -93,3 +93,25 @@ def test_bench_fast_mode_line_checks_the_fp16_cell_kernels(gpu):
     assert vl["volume_cell_dtype"] == "f16" and vl["volume_kernel"].startswith("corr_volume_h_stream<out16>"), vl
     assert vl["volume_rows_sampled"] >= 96 and vl["volume_within_bar"] and vl["within_bar"] and vl["pipe_tokens_checked"] == 3
     assert d["roofline"]["kernel"] == "corr_volume_h_stream<out16>" and d["roofline"]["bound"] == "hbm"
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_a_roofline_per_kernel(gpu):
+    """`kernels{}` — one entry per SURVEY §8(d) kernel, measured alone (HIP events, back to back) in the run itself, with the
+    algorithmic bytes / FLOPs the fractions are computed from — and the patch-embedding leg with its Fast-mode (16-bit in / out) form."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--no-cpu-baseline", "--no-ramp", "--exact-steps", "0", "--config4-steps", "0",
+           "--pool", "6", "--end-to-end-frames", "0", "--plugin-frames", "0"]
+    d = _line(subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT))
+    k = d["kernels"]
+    assert "error" not in k, k
+    for name in ("volume", "lookup_B2", "lookup_B64", "volume_out16", "lookup_B2_vol16", "convex_upsample", "convex_upsample_bf16_mask", "patch_embed",
+                 "patch_embed_fast_mode", "selector", "covariance", "solve"):
+        assert name in k and "error" not in k[name], (name, k.get(name))
+        assert k[name]["us"] > 0
+        if k[name].get("frac") is not None:
+            assert 0 < k[name]["frac"] < 1, (name, k[name])
+    assert k["convex_upsample"]["algorithmic_bytes"] == 2 * 4800 * (576 * 4 + 8 + 512) and k["convex_upsample"]["us"] < 15          # (r4: 23-26 us)
+    assert k["lookup_B2"]["algorithmic_bytes"] == 2 * (4800 * 100 * 4 + 4800 * 8 + 4800 * 81 * 4)
+    pe = d["patch_embed"]
+    assert pe["parity"]["within_bar"] and pe["fast_mode"]["tokens_equal_fp32_form_rounded_once"] and pe["fast_mode"]["hbm_GB_per_frame"] <= 0.2
+    assert d["decoder_loop"]["hip_us_interleaved"]["convex_upsample"] < 25
