@@ -16,7 +16,7 @@ for f in glob.glob(f"gpurun_out/pmc_{tag}_*/**/*counter_collection.csv", recursi
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k, v in agg.items():
-    if not any(s in k for s in ("corr_", "pgo", "kp_", "match_cov", "lookup", "upsample", "patch_embed_kernel", "patch_embed_strip_kernel", "backend_front")):
+    if not any(s in k for s in ("corr_", "pgo", "kp_", "match_cov", "lookup", "upsample", "patch_embed_kernel", "patch_embed_strip_kernel", "patch_embed_pipelined_kernel", "backend_front")):
         continue
     name = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip() or k[:60]
     m = {c: sum(x) / len(x) for c, x in sorted(v.items())}
