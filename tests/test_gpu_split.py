@@ -161,6 +161,14 @@ def test_corr_volume_split_fullsize_sampled_rows_and_properties(gpu, B, H, W, mo
     b = B - 1
     solo = ops.corr_volume(d1[b:b + 1].contiguous(), d2[b:b + 1].contiguous(), precision=mode)
     assert torch.equal(solo, vol[b * N:(b + 1) * N])
+    del solo
+    # ... and EVERY cell against the exact fp32 MFMA kernel (the hand-placed waits / the M0 contract of the LDS-DMA groups are invisible to hipcc; a
+    # corrupted fragment would show up in some band of some pair, not necessarily in the sampled rows): both are within 2e-5 sqrt(C) of the fp64 product
+    exact = ops.corr_volume(d1, d2, precision="exact")
+    worst = 0.0
+    for r0 in range(0, B * N, 4 * N):                       # chunked: the difference of two 5.9-GB volumes is not materialised at once
+        worst = max(worst, float((vol[r0:r0 + 4 * N] - exact[r0:r0 + 4 * N]).abs().max()))
+    assert worst <= 4e-5 * C ** 0.5, worst
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
