@@ -299,6 +299,17 @@ def end_to_end_leg(n_frames: int):
     return {"error": (p.stdout[-300:] + p.stderr[-700:])}
 
 
+def schedule_note(lanes: int) -> str:
+    """Which stream layout / depth the native driver runs this pipe shape with (the library's own rule, csrc/frame_pipe.hip)."""
+    from macvo_amd import _lib
+
+    depth = int(os.environ.get("MV_PIPE_DEPTH", _lib.load().mv_frame_pipe_default_depth(lanes, 0)))
+    alt = lanes <= 2 and os.environ.get("MV_PIPE_LAYOUT", "alt") != "classic" and "MV_PIPE_SELECTOR_ON" not in os.environ
+    return (f"{depth} tracked frames in flight + the volume GEMM one frame ahead; " +
+            ("four streams: GEMM | even frames' lookups + selector | odd frames' lookups + selector | backend + solve; GEMM on all but 32 CUs" if alt else
+             "four streams: GEMM | lookups + selector | backend | solve" if lanes > 2 else "four streams: GEMM | lookups | selector + backend | solve"))
+
+
 def pin_rank_cores(local_rank: int, local_world: int) -> list:
     """Confine this rank (the calling thread; the driver's backend launch thread and torch's pool threads are created later and inherit
     the mask) to its own contiguous slice of the cores the process may use, so that the 2 busy host threads of each of N ranks never
@@ -789,12 +800,13 @@ def main():
     traffic = traffic_file = None
     try:
         if (H, W, C, args.lanes) == (480, 640, 256, 1) and args.feat_dtype == "f32" and args.volume_precision in ("bf16x3", "f16x2"):
-            path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_corr_volume_split_{args.volume_precision}.json") for r in (4, 3))
+            path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_corr_volume_split_{args.volume_precision}.json") for r in (5, 4, 3))
                          if os.path.exists(q)), "")
             if os.path.exists(path):
                 traffic_file = os.path.basename(path)
                 pm = json.load(open(path))
-                key = next((k for k in pm if k.startswith("corr_volume_split_stream")), None)
+                want = "corr_volume_split_stream<2, true" if args.volume_precision == "f16x2" else "corr_volume_split_stream<3, false"
+                key = next((k for k in pm if k.startswith(want)), None)
                 if key is not None:
                     traffic = pm[key]["_derived"]["traffic_bytes_per_launch"]
         if (H, W, C, args.lanes) == (480, 640, 256, 1) and args.feat_dtype == "f32" and args.volume_precision == "exact":
@@ -1107,6 +1119,7 @@ def main():
                                                  "driver-native MT19937 + partial Fisher-Yates seeded like torch.manual_seed (bit-identical to torch.randperm: "
                                                  "the parity block runs this mechanism against the oracle and the reference loop on torch's global generator)"),
                        "clock_ramp_s": 0.0 if args.no_ramp else RAMP_SECONDS,
+                       "frame_schedule": schedule_note(args.lanes) if native else "python loop over the per-op entry points",
                        "excluded": "learned FlowFormer layers (source + weights absent from the reference checkout)",
                        "parallelism": f"{world * args.lanes} independent sequence(s), {args.lanes} per GPU; one all_gather of poses + timestamps"},
             "roofline": roofline,

@@ -130,6 +130,10 @@ int mv_volume_pack_tiled(const float* f1, const float* f2, void* packed1, void* 
 int mv_corr_volume_packed_supported(int B, int C, int N1, int N2, int mode);
 int mv_corr_volume_packed(const void* packed1, const void* packed2, float* out, int B, int C, int N1, int N2, int mode,
                           mvStream_t stream);
+/* the same launch with `free_cus` compute units (rounded down to a multiple of 8) left without a persistent workgroup, for a caller that runs kernels
+ * BESIDE the GEMM which cannot share a SIMD with its waves (mv_frame_pipe_*: the LM solve's workgroup).  Same bits for every value; 0 = mv_corr_volume_packed. */
+int mv_corr_volume_packed_shared(const void* packed1, const void* packed2, float* out, int B, int C, int N1, int N2, int mode, int free_cus,
+                                 mvStream_t stream);
 
 /* Diagnostics: name of the kernel the calling thread's last mv_corr_volume dispatched ("" before the first call); the
  * string is static.  Used by the dispatch tests and by bench.py to name the kernel its roofline line is about. */
@@ -661,6 +665,9 @@ enum {
 
 size_t mv_frame_pipe_arena_bytes(const mvFramePipeConfig* cfg);           /* 0 = invalid configuration */
 int mv_frame_pipe_max_pending(void);   /* how many tracked frames may be enqueued and not yet finished (the slot rotation this library was built with) */
+/* how many tracked frames the host should keep in flight for this pipe shape (the stream layout the driver will pick for `lanes` sequences with / without
+ * the dense-mapping tail): 3 for the two-decoder-stream layout of one- and two-lane pipes and for batched pipes, 2 for the classic one-lane layout */
+int mv_frame_pipe_default_depth(int lanes, int mapping);
 /* arena: device memory, 256-byte aligned, >= mv_frame_pipe_arena_bytes; must outlive the pipe */
 int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, size_t arena_bytes, mvFramePipe** out);
 void mv_frame_pipe_destroy(mvFramePipe* p);

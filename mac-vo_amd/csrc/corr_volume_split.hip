@@ -721,7 +721,15 @@ extern "C" int mv_corr_volume_packed_supported(int B, int C, int N1, int N2, int
 
 extern "C" int mv_corr_volume_packed(const void* packed1, const void* packed2, float* out, int B, int C, int N1, int N2, int mode,
                                      mvStream_t stream) {
-    MV_CHECK_ARG(packed1 && packed2 && out);
+    return mv_corr_volume_packed_shared(packed1, packed2, out, B, C, N1, N2, mode, 0, stream);
+}
+
+// ... leaving `free_cus` CUs (rounded down to a multiple of 8: one per XCD and run) without a persistent workgroup.  For a caller that runs other kernels
+// BESIDE the GEMM (the frame driver): the f16x2 waves hold 376 of a SIMD's 512 registers, so a workgroup that needs more than the rest (the LM solve: 400+) can
+// only start on a CU without a GEMM workgroup — with none free it waits for the gap between two GEMMs.  Same bits for any value.
+extern "C" int mv_corr_volume_packed_shared(const void* packed1, const void* packed2, float* out, int B, int C, int N1, int N2, int mode,
+                                            int free_cus, mvStream_t stream) {
+    MV_CHECK_ARG(packed1 && packed2 && out && free_cus >= 0);
     MV_CHECK_ARG(((uintptr_t)packed1 & 15) == 0 && ((uintptr_t)packed2 & 15) == 0);
     if (!mv_corr_volume_packed_supported(B, C, N1, N2, mode)) return MV_ERR_UNSUPPORTED;
     const int np = pieces_of(mode);
@@ -763,7 +771,9 @@ extern "C" int mv_corr_volume_packed(const void* packed1, const void* packed2, f
         }
     }
 #endif
-    const dim3 g(cu_count() & ~7);   // one workgroup per CU, a multiple of 8: one run per XCD
+    // one workgroup per CU, a multiple of 8 (one run per XCD), minus the CUs the caller keeps free
+    const int full = cu_count() & ~7, keep = free_cus & ~7;
+    const dim3 g(full - keep >= 8 ? full - keep : 8);
     auto lds_bytes = [&](size_t need) { return need; };
     if (mode == MV_PACK_BF16X3) {
         using K = SplitCfg<3, false, 16, 4>;

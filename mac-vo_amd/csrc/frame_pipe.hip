@@ -56,7 +56,7 @@ namespace {
 #ifndef MV_MAX_PENDING
 #define MV_MAX_PENDING 3
 #endif
-constexpr int MAX_PENDING = MV_MAX_PENDING, N_MAPS = MAX_PENDING + 2, N_CAND = MAX_PENDING + 1, N_PERM = 4, N_INEV = 8, MAX_VOL = 3;
+constexpr int MAX_PENDING = MV_MAX_PENDING, N_MAPS = MAX_PENDING + 2, N_CAND = MAX_PENDING + 1, N_PERM = 4, N_INEV = 8, MAX_VOL = 5, MAX_LK = 3;
 
 struct Maps {
     float *disparity, *disparity_cov, *depth, *depth_cov, *match_flow, *match_cov;
@@ -77,6 +77,7 @@ struct Pending {
     bool has_cand;
     int ti;   // timing slot of the frame (mv_frame_pipe_time_volume), -1: not timed
     long sel_job = -1;   // MV_PIPE_SELECTOR_ON=late: the finish (job) that issues this frame's selector segment; -1: already issued
+    long f = -1;         // frame index (alt layout: the backend waits for the previous frame's selector segment by its event)
 };
 
 // The selector segment of a frame (upsampling / epilogue / selector(s) / count copies): everything behind the frame's last lookup.
@@ -130,7 +131,7 @@ struct mvFramePipe {
     // device buffers
     float* vol[MAX_VOL];
     int n_volbuf;   // 2, or 3 (MV_PIPE_VOL_BUFS=3: a GEMM issued ahead then waits for the lookups of frame t-1 instead of t)
-    float* tok[2];
+    float* tok[2 * MAX_LK];   // two alternating token buffers per decoder-side stream
     void* planes[2];   // bf16x3 split planes of fmap1 / fmap2 (volume_split3)
     // volume_split = MV_PACK_BF16X3: packed three-piece operands of the streaming split GEMM, two sets (the pack of frame f + 1 may
     // run beside the GEMM of frame f); `packed` = the shape is covered by the streaming kernel (exact fp32 kernel otherwise)
@@ -161,6 +162,14 @@ struct mvFramePipe {
     int64_t* h_perm[N_PERM];  // pinned
     // streams / events
     hipStream_t s_vol, s_main, s_back, s_side;
+    hipStream_t s_lk[MAX_LK];   // decoder-side streams: frame f's lookups run on s_lk[f % n_lk]; s_lk[0] = s_main
+    int n_lk;
+    int alt;                     // the two-decoder-stream layout: see mv_frame_pipe_create
+    int free_cus;                // CUs the volume GEMM leaves without a persistent workgroup (mv_corr_volume_packed_shared)
+    hipEvent_t e_seg[N_INEV];    // alt: end of frame f's selector segment, slot f % N_INEV (the next frame's segment runs on the other decoder-side stream)
+    bool seg_valid[N_INEV];
+    int alt_indep;               // alt: consecutive frames' segments may overlap (own selector workspace each; NODEPTH selector, no upsampling)
+    void* kp_ws2;                // ... the odd frames' workspace
     hipStream_t s_sel;   // MV_PIPE_SELECTOR_ON=own: a fifth stream for the selector segment (nullptr otherwise)
     SelSeg deferred;     // MV_PIPE_SELECTOR_ON=vol: the newest frame's selector segment, not issued yet
     bool deferred_valid;
@@ -250,11 +259,27 @@ static int issue_selector_segment(mvFramePipe* p, const SelSeg& d);
 static int flush_jobs(mvFramePipe* p);
 static void launch_thread_main(mvFramePipe* p);
 
-static int volbufs_from_env() {
+// 1 = the round-5 layout for one- and two-lane pipes (two decoder-side streams; see mv_frame_pipe_create).  MV_PIPE_LAYOUT=classic | alt; an explicit
+// placement knob of the classic layout (MV_PIPE_SELECTOR_ON, MV_PIPE_LOOKUPS_ON=vol) selects the classic layout
+static int layout_alt(int lanes, int mapping) {
+    const char* e = getenv("MV_PIPE_LAYOUT");
+    if (e && strcmp(e, "classic") == 0) return 0;
+    const char* lk = getenv("MV_PIPE_LOOKUPS_ON");
+    if (lanes > 2 || mapping || (lk && strcmp(lk, "vol") == 0) || getenv("MV_PIPE_SELECTOR_ON")) return 0;
+    return 1;
+}
+
+// tracked frames the host should keep in flight (pipeline.NativeHotPath.run): the alt layout and batched pipes want 3, the classic one-lane pipe 2
+extern "C" int mv_frame_pipe_default_depth(int lanes, int mapping) { return (lanes > 2 || layout_alt(lanes, mapping)) ? 3 : 2; }
+
+static int volbufs_for(int lanes, int mapping) {
     // 3: with a GEMM issued one frame ahead (mv_frame_pipe_enqueue_volume) the buffer it rewrites was last read by the lookups of frame t - 1, long
     // finished; with 2 (rounds 1-2; an A/B knob until round 5) it waited for frame t's lookups, which run beside the previous GEMM at a third of their
     // isolated speed (measured 272 vs 245 us per frame)
-    return 3;
+    // alt layout: three tracked frames in flight + the GEMM one ahead = 4 (measured 6.95 k vs 6.74 k frames/s at 300 steps, the same at 20)
+    const char* e = getenv("MV_PIPE_VOL_BUFS");
+    const int v = e ? atoi(e) : (layout_alt(lanes, mapping) ? 4 : 3);
+    return v < 3 ? 3 : v > MAX_VOL ? MAX_VOL : v;
 }
 
 static size_t carve(mvFramePipe* p, char* base) {
@@ -263,7 +288,7 @@ static size_t carve(mvFramePipe* p, char* base) {
     const size_t L = p->lanes;
     const size_t plane = p->plane, n8 = p->n8, B = c.pairs, N = c.num_point > 0 ? c.num_point : 1;
     for (int k = 0; k < p->n_volbuf; ++k) p->vol[k] = a.take<float>(B * n8 * n8);
-    for (int k = 0; k < 2; ++k) p->tok[k] = a.take<float>(B * p->KK * n8);
+    for (int k = 0; k < 2 * (L <= 2 ? MAX_LK : 1); ++k) p->tok[k] = a.take<float>(B * p->KK * n8);
     for (int k = 0; k < 2; ++k)
         p->planes[k] = (c.volume_split == 2 || c.volume_split == 3) ? (void*)a.take<uint16_t>(3 * B * n8 * c.C) : nullptr;
     p->pk_bytes = p->packed ? mv_volume_pack_bytes((int)B, c.C, (int)n8, c.volume_split) : 0;
@@ -283,6 +308,7 @@ static size_t carve(mvFramePipe* p, char* base) {
     }
     p->kp_ws_bytes = L * mv_kp_select_workspace_bytes(c.H, c.W);
     p->kp_ws = a.take<char>(p->kp_ws_bytes);
+    p->kp_ws2 = L <= 2 ? a.take<char>(p->kp_ws_bytes) : nullptr;
     for (int k = 0; k < N_CAND; ++k) {
         p->cand[k] = a.take<int32_t>(L * plane);
         p->count[k] = a.take<int32_t>(L * 4);
@@ -362,7 +388,7 @@ extern "C" size_t mv_frame_pipe_arena_bytes(const mvFramePipeConfig* cfg) {
     tmp.n8 = tmp.h8 * tmp.w8;
     tmp.KK = (2 * cfg->radius + 1) * (2 * cfg->radius + 1);
     tmp.lanes = cfg->pairs / 2;
-    tmp.n_volbuf = volbufs_from_env();
+    tmp.n_volbuf = volbufs_for(tmp.lanes, cfg->mapping);
     tmp.packed = (cfg->volume_split == MV_PACK_BF16X3 || cfg->volume_split == MV_PACK_F16X2) &&
                  mv_corr_volume_packed_supported(cfg->pairs, cfg->C, tmp.n8, tmp.n8, cfg->volume_split);
     return carve(&tmp, nullptr);
@@ -386,7 +412,7 @@ extern "C" void mv_frame_pipe_destroy(mvFramePipe* p) {
                         "launch thread %.1f us, picked up -> every launch issued %.1f us (means per frame)\n",
                 p->st_n, p->st_wait / p->st_n, p->st_count_to_submit / p->st_n, p->st_submit_to_pick / p->st_n, p->st_pick_to_issued / p->st_n);
     (void)hipStreamSynchronize(p->s_vol);
-    (void)hipStreamSynchronize(p->s_main);
+    for (int k = 0; k < MAX_LK; ++k) if (p->s_lk[k]) (void)hipStreamSynchronize(p->s_lk[k]);
     (void)hipStreamSynchronize(p->s_back);
     (void)hipStreamSynchronize(p->s_side);
     if (p->s_sel) (void)hipStreamSynchronize(p->s_sel);
@@ -398,6 +424,7 @@ extern "C" void mv_frame_pipe_destroy(mvFramePipe* p) {
     for (int k = 0; k < 2; ++k) { ev(p->e_backend[k]); ev(p->e_posed[k]); ev(p->e_solved[k]); }
     ev(p->e_pgo);
     for (int k = 0; k < N_CAND; ++k) ev(p->e_lk[k]);
+    for (auto e : p->e_seg) ev(e);
     ev(p->e_maptail);
     for (int k = 0; k < 2; ++k) { ev(p->e_nvalid[k]); if (p->h_nvalid[k]) (void)hipHostFree(p->h_nvalid[k]); }
     for (int k = 0; k < N_CAND; ++k) if (p->h_count_m[k]) (void)hipHostFree(p->h_count_m[k]);
@@ -418,8 +445,8 @@ extern "C" void mv_frame_pipe_destroy(mvFramePipe* p) {
     for (int k = 0; k < N_CAND; ++k) if (p->h_count[k]) (void)hipHostFree(p->h_count[k]);
     for (auto h : p->h_perm) if (h) (void)hipHostFree(h);
     if (p->s_vol) (void)hipStreamDestroy(p->s_vol);
-    if (p->s_main) (void)hipStreamDestroy(p->s_main);
-    if (p->s_back) (void)hipStreamDestroy(p->s_back);
+    for (int k = 0; k < MAX_LK; ++k) if (p->s_lk[k]) (void)hipStreamDestroy(p->s_lk[k]);   // (s_lk[0] = s_main)
+    if (p->s_back && p->s_back != p->s_side) (void)hipStreamDestroy(p->s_back);
     if (p->s_side) (void)hipStreamDestroy(p->s_side);
     if (p->s_sel) (void)hipStreamDestroy(p->s_sel);
     delete p;
@@ -435,8 +462,12 @@ static int create_impl(mvFramePipe* p) {
     // decoder-side stream: no gain.  profiles/r03_*; DESIGN.md changelog.)
     MV_HIP(hipStreamCreateWithPriority(&p->s_vol, hipStreamNonBlocking, 0));
     MV_HIP(hipStreamCreateWithPriority(&p->s_main, hipStreamNonBlocking, 0));
-    MV_HIP(hipStreamCreateWithPriority(&p->s_back, hipStreamNonBlocking, hi));
+    p->s_lk[0] = p->s_main;
+    for (int k = 1; k < p->n_lk; ++k) MV_HIP(hipStreamCreateWithPriority(&p->s_lk[k], hipStreamNonBlocking, 0));
+    // (creation order matters on this stack: with `side` created before `back` the same schedule ran 15 % slower, profiles/r05_pipe_ab.log)
+    if (!p->alt) MV_HIP(hipStreamCreateWithPriority(&p->s_back, hipStreamNonBlocking, hi));
     MV_HIP(hipStreamCreateWithPriority(&p->s_side, hipStreamNonBlocking, hi));
+    if (p->alt) p->s_back = p->s_side;   // backend + solve of a frame in order on ONE stream: the fourth queue belongs to the odd frames' decoder side
     if (p->sel_on_back == 2) MV_HIP(hipStreamCreateWithPriority(&p->s_sel, hipStreamNonBlocking, hi));
     auto mk = [](hipEvent_t* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming); };
     for (auto& e : p->e_in) MV_HIP(mk(&e));
@@ -456,6 +487,7 @@ static int create_impl(mvFramePipe* p) {
     }
     MV_HIP(mk(&p->e_pgo));
     for (int k = 0; k < N_CAND; ++k) MV_HIP(mk(&p->e_lk[k]));
+    for (auto& e : p->e_seg) MV_HIP(mk(&e));
     MV_HIP(mk(&p->e_maptail));
     for (int k = 0; k < 2; ++k) {
         MV_HIP(mk(&p->e_nvalid[k]));
@@ -476,6 +508,7 @@ static int create_impl(mvFramePipe* p) {
     }
     // constants: selector workspace zeroed once (mv_kp_select leaves it zeroed), identity pose, PGO scalars, offsets table
     MV_HIP(hipMemsetAsync(p->kp_ws, 0, p->kp_ws_bytes, p->s_main));
+    if (p->kp_ws2) MV_HIP(hipMemsetAsync(p->kp_ws2, 0, p->kp_ws_bytes, p->s_main));
     const int L = p->lanes;
     std::vector<float> ident((size_t)L * 7, 0.f), intr((size_t)L * 4), bl((size_t)L, c.baseline);
     std::vector<int32_t> offs((size_t)L + 1);
@@ -506,7 +539,7 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
     p->n8 = p->h8 * p->w8;
     p->KK = (2 * cfg->radius + 1) * (2 * cfg->radius + 1);
     p->lanes = cfg->pairs / 2;
-    p->n_volbuf = volbufs_from_env();
+    p->n_volbuf = volbufs_for(p->lanes, cfg->mapping);
     p->packed = (cfg->volume_split == MV_PACK_BF16X3 || cfg->volume_split == MV_PACK_F16X2) &&
                 mv_corr_volume_packed_supported(cfg->pairs, cfg->C, p->n8, p->n8, cfg->volume_split);
     // shapes outside the out16 kernel's domain keep the fp32-stored volume of the same 16-bit GEMM
@@ -551,6 +584,29 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
     {
         const char* e = getenv("MV_PIPE_LOOKUPS_ON");
         p->lookups_on_main = (e && strcmp(e, "vol") == 0) ? 0 : 1;
+    }
+    {
+        // Decoder-side streams (round 5).  The 12 dependent lookups of a frame are latency-bound (5.8 us each alone, 13-15 us per launch beside the GEMM): on
+        // ONE stream they are 160-175 us per frame, and that stream — busy all the time — was the period of a one-lane pipe.  Consecutive frames' decoder
+        // sides are independent (own volume buffer, coordinates, token buffers, maps slot, candidate slot), so frame f's lookups run on stream f % n_lk.
+        //   * A FIFTH queue is not an option on this stack: with one more stream every configuration ran at 3.4-3.8 k frames/s instead of 5.9 k (GEMM 89 ->
+        //     132 us; also with GPU_MAX_HW_QUEUES=8; profiles/r05_pipe_ab.log, and the same finding in round 2) — MV_PIPE_LOOKUP_STREAMS stays as that A/B.
+        //   * The alt layout keeps FOUR:   vol: pack + GEMM | main: even frames' lookups + selector segment | a second decoder-side stream: the odd
+        //     frames' | side: backend + solve of every frame, in order (the chain solve -> solve is sequential anyway; the backend no longer overlaps it).
+        //     Consecutive selector segments may overlap (own selector workspace per parity); the backend waits for the previous frame's segment by event.
+        const char* e = getenv("MV_PIPE_LOOKUP_STREAMS");
+        const int want = e ? atoi(e) : 1;
+        p->n_lk = (p->lanes <= 2 && p->sel_on_back != 0 && p->lookups_on_main) ? (want < 1 ? 1 : want > MAX_LK ? MAX_LK : want) : 1;
+        p->alt = layout_alt(p->lanes, cfg->mapping);
+        if (p->alt) { p->sel_on_back = 0; p->n_lk = 2; }
+        // ... and in that layout the GEMM leaves 32 CUs (4 per XCD) without a persistent workgroup: backend + solve share ONE stream there, and the solve's
+        // workgroup (400+ registers) cannot sit beside a GEMM wave — with no CU free it waited for the gap between two GEMMs (73 of its 127 us).  Measured
+        // (profiles/r05_pipe_ab.log): 0 / 8 / 16 / 32 / 48 / 64 free = 6.26 / 6.34 / 6.68 / 6.84 / 6.87 / 6.82 k frames/s; in the classic layout no gain (r3, r5).
+        const char* ef = getenv("MV_PIPE_FREE_CUS");
+        p->free_cus = ef ? atoi(ef) : (p->alt ? 32 : 0);
+        if (p->free_cus < 0) p->free_cus = 0;
+        const char* ei = getenv("MV_PIPE_ALT_INDEP");
+        p->alt_indep = p->alt && !(ei && atoi(ei) == 0);
     }
     const int rc = create_impl(p);
     if (rc != MV_OK) {
@@ -620,7 +676,7 @@ static int issue_volume(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_s
         }
         // (round-4 A/B, removed: the GEMM waiting for the previous frame's lookups — each then has the chip to itself — cost 21 % of the frame rate)
         if (timed) MV_HIP(hipEventRecord(p->tv0[p->n_timed], p->s_vol));   // the GEMM alone: behind the pack, wherever that ran
-        MV_TRY(mv_corr_volume_packed(pk[0], pk[1], p->vol[k], B, c.C, p->n8, p->n8, c.volume_split, p->s_vol));
+        MV_TRY(mv_corr_volume_packed_shared(pk[0], pk[1], p->vol[k], B, c.C, p->n8, p->n8, c.volume_split, p->free_cus, p->s_vol));
     } else if (c.volume_split == 2 || c.volume_split == 3) {
         const size_t nel = (size_t)B * p->n8 * c.C;
         MV_TRY(mv_split_bf16x3((const float*)in->fmap1, p->planes[0], nel, p->s_vol));
@@ -658,7 +714,7 @@ static int issue_selector_segment(mvFramePipe* p, const SelSeg& d) {
     const mvFrameInputs* in = &d.in;
     const int k = d.k, m = d.m, ti = d.ti, B = c.pairs;
     const bool timed = d.timed, with_selector = d.with_selector, up = d.up;
-    hipStream_t s = p->s_main;   // (same stream as the lookups: in order behind them)
+    hipStream_t s = p->s_lk[d.f % p->n_lk];   // (same stream as the frame's lookups: in order behind them)
     if (p->sel_on_back) {   // everything behind the lookups continues on another stream (in order with the backends it must follow)
         s = p->sel_on_back == 2 ? p->s_sel : p->sel_on_back == 3 ? p->s_vol : p->s_back;   // (1 and 4: the backend stream)
         MV_HIP(hipStreamWaitEvent(s, p->e_lk[k], 0));
@@ -683,6 +739,13 @@ static int issue_selector_segment(mvFramePipe* p, const SelSeg& d) {
         MV_TRY(wait_if_pending(s, p->e_backend[(p->n_fin - 1) & 1]));
     }
     if (p->release_valid) MV_TRY(wait_if_pending(s, p->e_release));   // ... and by consumers of result views (mv_frame_pipe_release)
+    // alt: the previous frame's segment ran on the OTHER decoder-side stream; this one reads its maps (FULL selector, and the backend's gathers
+    // behind e_cand) and shares the selector workspace / upsampling buffers with it
+    // (alt_indep: NODEPTH selector without upsampling reads nothing of the previous frame and has its own workspace — the segments may overlap and
+    // the BACKEND waits for the previous frame's segment instead, finish_issue)
+    const bool indep = p->alt_indep && !up && c.selector_mode == MV_KP_NODEPTH;
+    if (p->alt && !indep && d.f > 0 && p->seg_valid[(d.f - 1) % N_INEV]) MV_TRY(wait_if_pending(s, p->e_seg[(d.f - 1) % N_INEV]));
+    void* const kp_ws = (indep && (d.f & 1)) ? p->kp_ws2 : p->kp_ws;
     Maps& mp = p->maps[m];
     constexpr bool fuse_epi = true;   // epilogue + the selector's first kernel in one launch (the separate form was an A/B knob of rounds 2-4)
     if (up) {
@@ -705,10 +768,10 @@ static int issue_selector_segment(mvFramePipe* p, const SelSeg& d) {
             // bounds a single-sequence stream)
             MV_TRY(mv_frontend_epilogue_select_lanes(in->flow, in->logcov, 1, c.bl_fx, c.bl_fx_sq, mp.disparity, mp.disparity_cov,
                                                      mp.depth, mp.depth_cov, nullptr, mp.match_flow, mp.match_cov, nullptr,
-                                                     nullptr, &sp, p->kp_ws, p->kp_ws_bytes, p->cand[k], p->count[k],
+                                                     nullptr, &sp, kp_ws, p->kp_ws_bytes, p->cand[k], p->count[k],
                                                      p->stats[k], p->lanes, s));
         } else if (c.selector_mode == MV_KP_NODEPTH) {
-            MV_TRY(mv_kp_select_lanes(mp.match_cov, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &sp, p->kp_ws,
+            MV_TRY(mv_kp_select_lanes(mp.match_cov, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &sp, kp_ws,
                                       p->kp_ws_bytes, p->cand[k], p->count[k], p->stats[k], p->lanes, s));
         } else {
             const Maps& m0 = p->maps[pd.maps_prev];
@@ -728,6 +791,10 @@ static int issue_selector_segment(mvFramePipe* p, const SelSeg& d) {
         }
         MV_HIP(hipEventRecord(p->e_cand[k], s));
         if (timed) MV_HIP(hipEventRecord(p->tv3[ti], s));
+    }
+    if (p->alt) {
+        MV_HIP(hipEventRecord(p->e_seg[d.f % N_INEV], s));
+        p->seg_valid[d.f % N_INEV] = true;
     }
     return MV_OK;
 }
@@ -770,7 +837,9 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
     // GEMM's stream instead — no cross-stream event in front of the first lookup, GEMM undisturbed at 215 us — measured
     // 0.3256 vs 0.3197 ms per frame: behind a 215-us kernel each of the 12 launch boundaries costs ~9 us.)
     const size_t coord_stride = (size_t)B * 2 * p->n8;
-    hipStream_t s = p->s_main;
+    const int lk = (int)(f % p->n_lk);
+    hipStream_t s = p->s_lk[lk];
+    float* const* tok = p->tok + 2 * lk;
     if (ahead) {   // the GEMM's input event predates this call: order the decoder side after the caller's stream as of NOW
         hipEvent_t e = p->e_rest[f % N_INEV];
         MV_HIP(hipEventRecord(e, (hipStream_t)in_stream));
@@ -779,13 +848,13 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
     if (p->lookups_on_main) {
         MV_HIP(hipStreamWaitEvent(s, p->e_vol_done[kv], 0));   // also orders `s` after e_in (the GEMM stream waited for it)
         for (int it = 0; it < c.iters; ++it)
-            MV_TRY(lookup_of(p)(p->vol[kv], in->coords + it * coord_stride, p->tok[it & 1], B, p->h8, p->w8, p->h8, p->w8, c.radius, s));
+            MV_TRY(lookup_of(p)(p->vol[kv], in->coords + it * coord_stride, tok[it & 1], B, p->h8, p->w8, p->h8, p->w8, c.radius, s));
         MV_HIP(hipEventRecord(p->e_vol_free[kv], s));
         p->vol_free_valid[kv] = true;
         if (timed) MV_HIP(hipEventRecord(p->tv2[ti], s));
     } else {
         for (int it = 0; it < c.iters; ++it)
-            MV_TRY(lookup_of(p)(p->vol[kv], in->coords + it * coord_stride, p->tok[it & 1], B, p->h8, p->w8, p->h8, p->w8, c.radius, p->s_vol));
+            MV_TRY(lookup_of(p)(p->vol[kv], in->coords + it * coord_stride, tok[it & 1], B, p->h8, p->w8, p->h8, p->w8, c.radius, p->s_vol));
         MV_HIP(hipEventRecord(p->e_vol_done[kv], p->s_vol));   // volume AND its lookups done
         MV_HIP(hipStreamWaitEvent(s, p->e_vol_done[kv], 0));   // also orders `s` after e_in
         p->vol_free_valid[kv] = false;                         // vol[k] / tok are only touched on s_vol: stream order suffices
@@ -805,7 +874,7 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
     } else {
         MV_TRY(issue_selector_segment(p, d));
     }
-    if (with_selector) p->pending.push_back(Pending{m, p->newest_maps, k, true, ti, -1});
+    if (with_selector) p->pending.push_back(Pending{m, p->newest_maps, k, true, ti, -1, f});
     p->newest_maps = m;
     p->n_enq = f + 1;
     return MV_OK;
@@ -937,6 +1006,9 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
     for (int l = 0; l < L; ++l)
         memcpy(p->h_perm[ps] + (size_t)l * cap, perm_host + (size_t)l * cap, (size_t)n_sel[l] * sizeof(int64_t));
     MV_TRY(wait_if_pending(s, p->e_cand[pd.cand]));   // fired: the host has just read this frame's count
+    // alt layout: the previous frame's maps (gathers below) were written by a segment on the other decoder-side stream, which e_cand does not cover.
+    // (Slot f - 1 of e_seg is re-recorded by frame f - 1 + N_INEV, far beyond the frames in flight.)
+    if (p->alt && pd.f > 0) MV_TRY(wait_if_pending(s, p->e_seg[(pd.f - 1) % N_INEV]));
     const int ti = pd.ti;
     if (ti >= 0) MV_HIP(hipEventRecord(p->tv4[ti], s));
     const bool perm_in_args = L == 1 && n_max <= 256;   // one lane: the permutation rides in the kernel arguments (no pinned staging copy, no H2D node)
@@ -1255,7 +1327,7 @@ extern "C" int mv_frame_pipe_sync(mvFramePipe* p, mvStream_t stream, int block_h
     }
     if (block_host) {
         MV_HIP(hipStreamSynchronize(p->s_vol));
-        MV_HIP(hipStreamSynchronize(p->s_main));
+        for (int k = 0; k < p->n_lk; ++k) MV_HIP(hipStreamSynchronize(p->s_lk[k]));
         MV_HIP(hipStreamSynchronize(p->s_back));
         MV_HIP(hipStreamSynchronize(p->s_side));
         if (p->s_sel) MV_HIP(hipStreamSynchronize(p->s_sel));
@@ -1264,7 +1336,8 @@ extern "C" int mv_frame_pipe_sync(mvFramePipe* p, mvStream_t stream, int block_h
     // make `stream` wait for everything enqueued so far
     hipEvent_t e;
     MV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    hipStream_t all[5] = {p->s_vol, p->s_main, p->s_back, p->s_side, p->s_sel};
+    hipStream_t all[4 + MAX_LK] = {p->s_vol, p->s_back, p->s_side, p->s_sel};
+    for (int k = 0; k < p->n_lk; ++k) all[4 + k] = p->s_lk[k];
     int rc = MV_OK;
     for (hipStream_t q : all) {
         if (!q) continue;
@@ -1323,7 +1396,7 @@ extern "C" int mv_frame_pipe_timeline(mvFramePipe* p, float* ms, int cap_frames,
     MV_TRY(flush_jobs(p));   // in the 'late' selector placement tv3 is recorded on the launch thread
     if (!p->time_detail) { *n = 0; return MV_OK; }   // only the GEMM pairs were recorded
     MV_HIP(hipStreamSynchronize(p->s_vol));
-    MV_HIP(hipStreamSynchronize(p->s_main));
+    for (int k = 0; k < p->n_lk; ++k) MV_HIP(hipStreamSynchronize(p->s_lk[k]));
     MV_HIP(hipStreamSynchronize(p->s_back));
     if (p->s_sel) MV_HIP(hipStreamSynchronize(p->s_sel));
     const int m = p->n_timed < cap_frames ? p->n_timed : cap_frames;
@@ -1371,7 +1444,7 @@ extern "C" int mv_frame_pipe_buffer(mvFramePipe* p, int which, int age, void** p
             // age limit: with a GEMM issued ahead (n_vol > n_enq) the buffer of frame f - 1 is being rewritten
             if (!front(p->n_vol > p->n_enq ? 1 : 2)) break;
             *ptr = p->vol[f % p->n_volbuf]; *count = (size_t)c.pairs * p->n8 * p->n8; return MV_OK;
-        case MV_FB_TOKENS: if (!front(1) || c.iters == 0) break; *ptr = p->tok[(c.iters - 1) & 1]; *count = (size_t)c.pairs * p->KK * p->n8; return MV_OK;
+        case MV_FB_TOKENS: if (!front(1) || c.iters == 0) break; *ptr = p->tok[2 * (f % p->n_lk) + ((c.iters - 1) & 1)]; *count = (size_t)c.pairs * p->KK * p->n8; return MV_OK;
         case MV_FB_DISPARITY: if (!front(N_MAPS)) break; *ptr = p->maps[f % N_MAPS].disparity; *count = plane; return MV_OK;
         case MV_FB_DISPARITY_COV: if (!front(N_MAPS)) break; *ptr = p->maps[f % N_MAPS].disparity_cov; *count = plane; return MV_OK;
         case MV_FB_DEPTH: if (!front(N_MAPS)) break; *ptr = p->maps[f % N_MAPS].depth; *count = plane; return MV_OK;

@@ -161,14 +161,15 @@ def volume_pack(f1: torch.Tensor, f2: torch.Tensor, layout: str = "chw", out: "t
 
 
 def corr_volume_packed(pk1: torch.Tensor, pk2: torch.Tensor, B: int, C_: int, N1: int, N2: int, out: torch.Tensor | None = None,
-                       mode: str = "bf16x3") -> torch.Tensor:
+                       mode: str = "bf16x3", free_cus: int = 0) -> torch.Tensor:
     """The cost volume ``[B*N1, 1, 1, N2]`` fp32 from two packed operands (``mv_corr_volume_packed``: six bf16 / three fp16 piece
-    products, fp32 accumulate)."""
+    products, fp32 accumulate).  ``free_cus``: compute units left without a persistent workgroup (``mv_corr_volume_packed_shared``;
+    same bits)."""
     lib = L.load()
     if out is None:
         out = torch.empty((B * N1, 1, 1, N2), dtype=torch.float32, device=pk1.device)
-    L.check(lib.mv_corr_volume_packed(pk1.data_ptr(), pk2.data_ptr(), out.data_ptr(), B, C_, N1, N2, _PACK_MODE[mode], _stream()),
-            "mv_corr_volume_packed")
+    L.check(lib.mv_corr_volume_packed_shared(pk1.data_ptr(), pk2.data_ptr(), out.data_ptr(), B, C_, N1, N2, _PACK_MODE[mode], int(free_cus), _stream()),
+            "mv_corr_volume_packed_shared")
     return out
 
 

@@ -521,10 +521,12 @@ class NativeHotPath:
         self._cap = max(self.cfg.num_point, 1)
         self._volume_ahead = os.environ.get("MV_PIPE_VOLUME_AHEAD", "1") != "0"   # A/B knobs of run()
         # frames in flight: never more than the slot rotation the library was built with (MV_MAX_PENDING, 3 in the stock build)
-        # [r4] default 2 for one- and two-lane pipes: the same frame rate as 3 within the box's +-3 % (5.59-5.85 k vs 5.71-5.81 k), the driver's
-        # 20-step line 4.58-4.78 k vs 4.50-4.62 k, GEMM-start -> pose 1.18 -> 0.82 ms (profiles/r04_latency_ab.log); 3 for batched pipes
-        self._depth = max(1, min(int(ops.L.load().mv_frame_pipe_max_pending()), int(os.environ.get("MV_PIPE_MAX_DEPTH", "3")),
-                                 int(os.environ.get("MV_PIPE_DEPTH", "2" if self.lanes <= 2 else "3"))))
+        # The default follows the stream layout the driver picks (mv_frame_pipe_default_depth): 3 for the round-5 layout of one- and two-lane pipes (even /
+        # odd frames' decoder sides on two streams: a third frame in flight keeps both fed) and for batched pipes, 2 for the classic one-lane layout
+        # ([r4] there 3 bought nothing and cost a period of latency, profiles/r04_latency_ab.log)
+        lib = ops.L.load()
+        self._depth = max(1, min(int(lib.mv_frame_pipe_max_pending()), int(os.environ.get("MV_PIPE_MAX_DEPTH", "3")),
+                                 int(os.environ.get("MV_PIPE_DEPTH", str(lib.mv_frame_pipe_default_depth(self.lanes, int(bool(self.cfg.mapping))))))))
         self.lm = ops.lm_default_params()
         self._pipe = None
         self._arena = None

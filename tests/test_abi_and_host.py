@@ -137,7 +137,9 @@ def test_frame_pipe_config_validation_without_gpu():
 
     n = lib.mv_frame_pipe_arena_bytes(C.byref(cfg()))
     vol = 2 * 4800 * 4800 * 4
-    assert 3 * vol < n < 3 * vol + 100e6 and n % 256 == 0            # three volumes + ~57 MB of maps / scratch
+    assert 4 * vol < n < 4 * vol + 120e6 and n % 256 == 0            # one lane (round-5 layout): four volumes + ~75 MB of maps / token buffers / scratch
+    assert lib.mv_frame_pipe_arena_bytes(C.byref(cfg(mapping=1, map_num_point=100, map_mask_width=32))) < 3 * vol + 120e6   # classic layout: three
+    assert lib.mv_frame_pipe_default_depth(1, 0) == 3 and lib.mv_frame_pipe_default_depth(1, 1) == 2 and lib.mv_frame_pipe_default_depth(32, 0) == 3
     assert lib.mv_frame_pipe_arena_bytes(C.byref(cfg(H=720, W=1280))) > 3 * 2 * 14400 * 14400 * 4
     n32 = lib.mv_frame_pipe_arena_bytes(C.byref(cfg(pairs=64)))       # 32 lanes (batch-32 frames): two volumes of 64 pairs
     assert n32 > 3 * 32 * vol and n32 < 3 * 32 * vol + 32 * 100e6

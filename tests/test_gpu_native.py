@@ -373,3 +373,36 @@ def test_fused_backend_equals_the_five_launch_form(gpu, monkeypatch, lanes, grap
                 continue
             for l, (x, y) in enumerate(zip(da[k], db[k])):
                 assert torch.equal(x, y), (t, k, l)
+
+
+@pytest.mark.parametrize("lanes,selector", [(1, "nodepth"), (1, "full"), (2, "nodepth")])
+def test_two_decoder_stream_layout_equals_the_classic_layout(gpu, monkeypatch, lanes, selector):
+    """Round 5: one- and two-lane pipes run even / odd frames' decoder sides (12 lookups + selector segment) on two streams, backend + solve in order on
+    one, the GEMM on 32 CUs fewer (`MV_PIPE_LAYOUT`, default `alt`).  Same kernels, same arguments: every pose and keypoint must equal the classic
+    four-stream layout's bit for bit over a pipelined stream — with the NODEPTH selector (consecutive selector segments overlap, own workspace each) and with
+    the FULL one (segments ordered by event: it reads the previous frame's depth)."""
+    from macvo_amd.pipeline import Camera, HotPathConfig, NativeHotPath, stack_lanes
+
+    n_pool, n_steps = 8, 120
+    cam, frames, _ = synth.make_sequence(n_pool + lanes, 256, 384, C=256, iters=4, seed=23, closed_loop=True)   # 32 x 48 queries: the packed f16x2 GEMM
+    ins = _inputs(frames, gpu, static=True)
+    pool = ins[:n_pool] if lanes == 1 else [stack_lanes([ins[(t + l) % len(ins)] for l in range(lanes)]) for t in range(n_pool)]
+    outs = {}
+    for layout in ("classic", "alt"):
+        monkeypatch.setenv("MV_PIPE_LAYOUT", layout)
+        hot = NativeHotPath(Camera(**cam), HotPathConfig(selector=selector, num_point=80), gpu, lanes=lanes, generators=[41 + l for l in range(lanes)])
+        assert hot._depth == (3 if layout == "alt" else 2)
+        hot.initialize(pool[0])
+        sink = torch.zeros((n_steps, 7) if lanes == 1 else (n_steps, lanes, 7), device=gpu)
+        kps = []
+        for r in hot.run((pool[(1 + k) % n_pool] for k in range(n_steps)), pose_sink=sink):
+            hot.sync_pose()
+            kps.append(torch.cat([x.kp0_uv for x in (r if isinstance(r, list) else [r])]).clone())
+        torch.cuda.synchronize()
+        outs[layout] = (sink.clone(), kps, hot.last_tokens.clone())
+        del hot
+    a, b = outs["classic"], outs["alt"]
+    assert torch.isfinite(b[0]).all() and b[0].abs().sum() > 0
+    bad = (a[0] != b[0]).reshape(n_steps, -1).any(dim=1).nonzero().flatten()
+    assert bad.numel() == 0, f"first mismatching frames: {bad[:10].tolist()}"
+    assert all(torch.equal(x, y) for x, y in zip(a[1], b[1])) and torch.equal(a[2], b[2])
