@@ -56,7 +56,7 @@ namespace {
 #ifndef MV_MAX_PENDING
 #define MV_MAX_PENDING 3
 #endif
-constexpr int MAX_PENDING = MV_MAX_PENDING, N_MAPS = MAX_PENDING + 2, N_CAND = MAX_PENDING + 1, N_PERM = 4, N_INEV = 8, MAX_VOL = 5, MAX_LK = 3;
+constexpr int MAX_PENDING = MV_MAX_PENDING, N_MAPS = MAX_PENDING + 2, N_CAND = MAX_PENDING + 1, N_PERM = 4, N_INEV = 8, MAX_VOL = 4, MAX_LK = 2;
 
 struct Maps {
     float *disparity, *disparity_cov, *depth, *depth_cov, *match_flow, *match_cov;
@@ -130,7 +130,7 @@ struct mvFramePipe {
     size_t arena_bytes;
     // device buffers
     float* vol[MAX_VOL];
-    int n_volbuf;   // 2, or 3 (MV_PIPE_VOL_BUFS=3: a GEMM issued ahead then waits for the lookups of frame t-1 instead of t)
+    int n_volbuf;   // 3 (classic layout) or 4 (round-5 layout): volbufs_for
     float* tok[2 * MAX_LK];   // two alternating token buffers per decoder-side stream
     void* planes[2];   // bf16x3 split planes of fmap1 / fmap2 (volume_split3)
     // volume_split = MV_PACK_BF16X3: packed three-piece operands of the streaming split GEMM, two sets (the pack of frame f + 1 may
@@ -276,10 +276,8 @@ static int volbufs_for(int lanes, int mapping) {
     // 3: with a GEMM issued one frame ahead (mv_frame_pipe_enqueue_volume) the buffer it rewrites was last read by the lookups of frame t - 1, long
     // finished; with 2 (rounds 1-2; an A/B knob until round 5) it waited for frame t's lookups, which run beside the previous GEMM at a third of their
     // isolated speed (measured 272 vs 245 us per frame)
-    // alt layout: three tracked frames in flight + the GEMM one ahead = 4 (measured 6.95 k vs 6.74 k frames/s at 300 steps, the same at 20)
-    const char* e = getenv("MV_PIPE_VOL_BUFS");
-    const int v = e ? atoi(e) : (layout_alt(lanes, mapping) ? 4 : 3);
-    return v < 3 ? 3 : v > MAX_VOL ? MAX_VOL : v;
+    // alt layout: three tracked frames in flight + the GEMM one ahead = 4 (measured 6.95 k vs 6.74 k frames/s at 300 steps with 3, the same at 20; 5: no gain)
+    return layout_alt(lanes, mapping) ? 4 : 3;
 }
 
 static size_t carve(mvFramePipe* p, char* base) {
@@ -590,23 +588,18 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
         // ONE stream they are 160-175 us per frame, and that stream — busy all the time — was the period of a one-lane pipe.  Consecutive frames' decoder
         // sides are independent (own volume buffer, coordinates, token buffers, maps slot, candidate slot), so frame f's lookups run on stream f % n_lk.
         //   * A FIFTH queue is not an option on this stack: with one more stream every configuration ran at 3.4-3.8 k frames/s instead of 5.9 k (GEMM 89 ->
-        //     132 us; also with GPU_MAX_HW_QUEUES=8; profiles/r05_pipe_ab.log, and the same finding in round 2) — MV_PIPE_LOOKUP_STREAMS stays as that A/B.
+        //     132 us; also with GPU_MAX_HW_QUEUES=8; profiles/r05_pipe_ab.log run 15, and the same finding in round 2; the A/B knob is gone).
         //   * The alt layout keeps FOUR:   vol: pack + GEMM | main: even frames' lookups + selector segment | a second decoder-side stream: the odd
         //     frames' | side: backend + solve of every frame, in order (the chain solve -> solve is sequential anyway; the backend no longer overlaps it).
         //     Consecutive selector segments may overlap (own selector workspace per parity); the backend waits for the previous frame's segment by event.
-        const char* e = getenv("MV_PIPE_LOOKUP_STREAMS");
-        const int want = e ? atoi(e) : 1;
-        p->n_lk = (p->lanes <= 2 && p->sel_on_back != 0 && p->lookups_on_main) ? (want < 1 ? 1 : want > MAX_LK ? MAX_LK : want) : 1;
         p->alt = layout_alt(p->lanes, cfg->mapping);
-        if (p->alt) { p->sel_on_back = 0; p->n_lk = 2; }
+        p->n_lk = p->alt ? 2 : 1;
+        if (p->alt) p->sel_on_back = 0;
         // ... and in that layout the GEMM leaves 32 CUs (4 per XCD) without a persistent workgroup: backend + solve share ONE stream there, and the solve's
         // workgroup (400+ registers) cannot sit beside a GEMM wave — with no CU free it waited for the gap between two GEMMs (73 of its 127 us).  Measured
         // (profiles/r05_pipe_ab.log): 0 / 8 / 16 / 32 / 48 / 64 free = 6.26 / 6.34 / 6.68 / 6.84 / 6.87 / 6.82 k frames/s; in the classic layout no gain (r3, r5).
-        const char* ef = getenv("MV_PIPE_FREE_CUS");
-        p->free_cus = ef ? atoi(ef) : (p->alt ? 32 : 0);
-        if (p->free_cus < 0) p->free_cus = 0;
-        const char* ei = getenv("MV_PIPE_ALT_INDEP");
-        p->alt_indep = p->alt && !(ei && atoi(ei) == 0);
+        p->free_cus = p->alt ? 32 : 0;
+        p->alt_indep = p->alt;   // (ordered segments for every selector: -6 % on the 20-step line, profiles/r05_pipe_ab.log run 18)
     }
     const int rc = create_impl(p);
     if (rc != MV_OK) {
