@@ -6,11 +6,15 @@
 // ~330 us of GPU work (measured: the frame rate did not move when the volume GEMM got 4x faster).  Here the whole
 // enqueue side is C++: ~30 launches per frame at 2-3 us each, two host calls per frame.
 //
-// Four HIP streams (created here, independent of the caller's):
-//   vol    the MFMA-bound cost-volume GEMM of frame t+1 (double-buffered volumes)
+// Four HIP streams (created here, independent of the caller's) — four is the ceiling of this stack (a fifth queue costs a third of the frame rate).
+// Classic layout (>= 3 lanes, mapping):
+//   vol    the MFMA-bound cost-volume GEMM of frame t+1 (rotating volume buffers)
 //   main   decoder side of a frame: 12 window lookups, (convex upsampling,) epilogue, dense selector, count -> host
-//   back   pose-dependent half of frame t: perm H2D, gather, tracking, back-projection, covariances, filter
-//   side   the LM solve (the GPU analogue of the reference's optimizer child process, Optimization/Interface.py:80-96)
+//   back   pose-independent half of frame t's backend: gather, tracking, back-projection, covariances (one launch)
+//   side   filters + rotation into the world frame + LM solve (one launch; the GPU analogue of the reference's optimizer child process,
+//          Optimization/Interface.py:80-96)
+// Round-5 layout (one- and two-lane pipes; `layout_alt` below): vol | main = even frames' decoder side | a second decoder-side stream = odd frames' |
+//   side = backend + solve of every frame, in order; the GEMM leaves 32 CUs without a workgroup (see mv_frame_pipe_create).
 // Frame t+1's frontend is enqueued before frame t's `finish`, so the selector's host round trip (candidate count ->
 // torch.randperm on the CPU, kept for bit-exact indices -> permutation back) never idles the GPU.
 // Stream layouts measured on the bench (ms / frame): this one 0.3235; even / odd frames each entirely on their own
