@@ -725,7 +725,7 @@ extern "C" int mv_corr_volume_packed(const void* packed1, const void* packed2, f
 }
 
 // ... leaving `free_cus` CUs (rounded down to a multiple of 8: one per XCD and run) without a persistent workgroup.  For a caller that runs other kernels
-// BESIDE the GEMM (the frame driver): the f16x2 waves hold 376 of a SIMD's 512 registers, so a workgroup that needs more than the rest (the LM solve: 400+) can
+// BESIDE the GEMM (the frame driver): the f16x2 waves hold 300 of a SIMD's 512 registers, so a workgroup that needs more than the rest (the LM solve: 496, tools/kernel_resources.py) can
 // only start on a CU without a GEMM workgroup — with none free it waits for the gap between two GEMMs.  Same bits for any value.
 extern "C" int mv_corr_volume_packed_shared(const void* packed1, const void* packed2, float* out, int B, int C, int N1, int N2, int mode,
                                             int free_cus, mvStream_t stream) {

@@ -600,7 +600,7 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
         p->n_lk = p->alt ? 2 : 1;
         if (p->alt) p->sel_on_back = 0;
         // ... and in that layout the GEMM leaves 32 CUs (4 per XCD) without a persistent workgroup: backend + solve share ONE stream there, and the solve's
-        // workgroup (400+ registers) cannot sit beside a GEMM wave — with no CU free it waited for the gap between two GEMMs (73 of its 127 us).  Measured
+        // workgroup (496 registers + 77 KB of LDS) cannot sit beside a GEMM wave (300 registers, the LDS ring) — with no CU free it waited for the gap between two GEMMs (73 of its 127 us).  Measured
         // (profiles/r05_pipe_ab.log): 0 / 8 / 16 / 32 / 48 / 64 free = 6.26 / 6.34 / 6.68 / 6.84 / 6.87 / 6.82 k frames/s; in the classic layout no gain (r3, r5).
         p->free_cus = p->alt ? 32 : 0;
         p->alt_indep = p->alt;   // (ordered segments for every selector: -6 % on the 20-step line, profiles/r05_pipe_ab.log run 18)

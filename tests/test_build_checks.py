@@ -28,3 +28,13 @@ def test_strip_mined_patch_embed_index_model(geom):
     for ln in r.stdout.splitlines():          # fragment reads are conflict-free by construction (80 x 80: the clamped last token tile costs conv3 14 %; the
         if "ds_read" in ln:                   # 8-byte stores are 2-way: accepted, see patch_embed_v2.hip)
             assert float(ln.split("x")[-1].split()[0]) <= 1.15, ln
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(ROOT, "mac-vo_amd", "csrc", "build")) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"),
+                    reason="needs the in-tree build (make -C mac-vo_amd/csrc) and the ROCm LLVM tools")
+def test_kernel_register_and_scratch_budgets():
+    """The register / LDS / scratch budgets DESIGN.md's schedule arguments rest on (what fits beside a GEMM wave, which kernels must not spill), read from
+    the built code objects' own metadata (tools/kernel_resources.py --check)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), "--check"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "kernel_resources OK" in r.stdout, r.stdout[-2000:] + r.stderr[-1500:]
+    assert int(r.stdout.split("OK: ")[1].split(" kernels")[0]) >= 150     # every object file of the library was read
