@@ -161,7 +161,12 @@ def roofline_of(ms, args, lanes, n_q, C, timed_region_launches, traffic=None):
     enc16 = args.feat_dtype == "f16" and getattr(args, "volume_store", "fp32") == "encoder" and args.layout == "hwc" and C in (128, 256)
     flops, nbytes = volume_work(lanes, n_q, C, 4 if args.feat_dtype == "f32" else 2, 2 if enc16 else 4)
     avg_s = sum(ms) / len(ms) / 1e3
-    common = {"avg_launch_us": round(avg_s * 1e6, 2), "launches": len(ms), "launches_in_timed_region": timed_region_launches,
+    srt = sorted(ms)
+    common = {"avg_launch_us": round(avg_s * 1e6, 2), "median_launch_us": round(srt[len(srt) // 2] * 1e3, 2), "min_launch_us": round(srt[0] * 1e3, 2),
+              "launch_time_note": "HIP-event pair on the GEMM's stream inside the running pipe: the mean (what `achieved` / `frac` use) includes the launches whose "
+                                  "workgroups waited for CUs held by the other streams' kernels; rocprofv3's kernel duration for the same command is the committed "
+                                  "profiles/r05c_bench_kernel_stats.csv",
+              "launches": len(ms), "launches_in_timed_region": timed_region_launches,
               "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes}
     prec = getattr(args, "_precision", args.volume_precision)
     if args.feat_dtype == "f32" and prec in ("f16x2", "bf16x3", "split3", "split2"):
