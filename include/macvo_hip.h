@@ -402,6 +402,15 @@ int mv_pgo_solve_posed(int nprob, const int32_t* offsets, const int32_t* n_live,
                        const uint8_t* inbound, const float* vals, uint8_t* valid, int32_t* count_out, int min_points,
                        const mvLMParams* params, double* out_pose, double* out_info, float* out_pose_f32, float* pose_sink,
                        mvStream_t stream);
+/* ... of the device-driven frame (round 6): the live-row count of problem l is n_live_dev[l * n_live_stride] in DEVICE memory (<= cap; written by
+ * mv_backend_front_draw_lanes earlier on the stream) — the number of selected keypoints never reaches the host.  Everything else as above. */
+int mv_pgo_solve_posed_dev(int nprob, const int32_t* offsets, const int32_t* n_live_dev, int n_live_stride, int cap, int graph_type,
+                           const float* init_pose, const float* intrinsics, const float* baseline, const float* pos_Tc, const double* cov_Tc,
+                           float* pos_Tw, double* cov_Tw, double* out_rot, const float* pixel2_uv, const float* pixel2_d,
+                           const float* pixel2_disp, const float* pixel2_disp_cov, const float* pixel2_uv_cov, const double* obs2_covTc,
+                           int filter_flags, float filter_min_depth, float filter_max_depth, const uint8_t* inbound, const float* vals,
+                           uint8_t* valid, int32_t* count_out, int min_points, const mvLMParams* params, double* out_pose, double* out_info,
+                           float* out_pose_f32, float* pose_sink, mvStream_t stream);
 
 /* -------------------------------------------------------------------------------------------
  * A23  PWC-Net local correlation, forward (the reference's only hand-written CUDA kernel; non-default matcher path).
@@ -557,6 +566,18 @@ int mv_backend_front_lanes(const int32_t* cand, size_t cand_lane_stride, const i
                            const float* sdisp1, const float* sdd1, int edge, float match_cov_default, const mvMatchCovParams* cov_params,
                            int64_t* out_kp0_uv, float* out_kp0, float* out_kp1, uint8_t* out_inbound, float* out_vals, float* out_sigma0,
                            float* out_sigma1, float* out_pos_Tc, double* out_cov0, double* out_cov1, mvStream_t stream);
+/* mv_backend_front_lanes of the device-driven frame (round 6): `selected_points[torch.randperm(n)[:numPoint]]` (Module/KeypointSelector.py:331,404) without
+ * the host.  n = count_dev[l * count_stride] is read from device memory (where mv_kp_select_lanes left it: count_stride = 4), the permutation head is drawn
+ * inside the launch from lane l's device-resident MT19937 state_in[l] (mv_mt19937_seed; same bits as torch's CPU generator + torch.randperm) and the advanced
+ * generator is written to state_out[l] (a DIFFERENT buffer: every workgroup reads state_in).  out_perm [lanes, cap] int64 = the head, out_live [lanes, 2] =
+ * {min(n, num_point), n}; rows beyond min(n, num_point) of the tables stay untouched.  num_point <= mv_randperm_max_head(). */
+int mv_backend_front_draw_lanes(const int32_t* cand, size_t cand_lane_stride, const int32_t* count_dev, int count_stride, const uint32_t* state_in,
+                                uint32_t* state_out, int num_point, int lanes, int cap, const float* match_flow, const float* match_cov,
+                                const float* depth0, const float* disp0, const float* sdisp0, const float* sdd0, const float* depth1,
+                                const float* disp1, const float* sdisp1, const float* sdd1, int edge, float match_cov_default,
+                                const mvMatchCovParams* cov_params, int64_t* out_perm, int32_t* out_live, int64_t* out_kp0_uv, float* out_kp0,
+                                float* out_kp1, uint8_t* out_inbound, float* out_vals, float* out_sigma0, float* out_sigma1, float* out_pos_Tc,
+                                double* out_cov0, double* out_cov1, mvStream_t stream);
 int mv_kp_track_lanes(const int64_t* kp0_uv, int lanes, const int32_t* n_live /* host */, int cap, const float* match_flow,
                       const float* match_cov, const float* depth0, const float* disp0, const float* sdisp0,
                       const float* sdd0, const float* depth1, const float* disp1, const float* sdisp1, const float* sdd1,
@@ -660,7 +681,9 @@ enum {
     MV_FB_ROT, MV_FB_COV0, MV_FB_COV0W, MV_FB_COV1, MV_FB_VALID, MV_FB_NVALID, MV_FB_POSE64, MV_FB_INFO,   /* backend side */
     MV_FB_POSE,                                                                  /* fp32 [lanes, 7]; age 0 = newest solve's output */
     /* dense-mapping tail of the newest finished frame (mapping = 1; rows = what mv_frame_pipe_map_points was called with) */
-    MV_FB_MAP_UV, MV_FB_MAP_D, MV_FB_MAP_SDD, MV_FB_MAP_TC, MV_FB_MAP_TW, MV_FB_MAP_COV /* fp64 [.,9] */, MV_FB_MAP_COLOR /* u8 [.,3] */
+    MV_FB_MAP_UV, MV_FB_MAP_D, MV_FB_MAP_SDD, MV_FB_MAP_TC, MV_FB_MAP_TW, MV_FB_MAP_COV /* fp64 [.,9] */, MV_FB_MAP_COLOR /* u8 [.,3] */,
+    /* device-driven frame (round 6): the permutation head the front launch drew, int64 [lanes, num_point]; int32 [lanes, 2] = selected keypoints, candidates */
+    MV_FB_PERM, MV_FB_LIVE
 };
 
 size_t mv_frame_pipe_arena_bytes(const mvFramePipeConfig* cfg);           /* 0 = invalid configuration */
@@ -706,6 +729,30 @@ int mv_frame_pipe_seed_lanes(mvFramePipe* p, const uint64_t* seeds /* [lanes] ho
  * as the seeded finish draws them for a lane (Module/KeypointSelector.py:331,404); out [calls, k] (row i: min(k, n[i]) entries) */
 int mv_randperm_heads(uint64_t seed, const int64_t* n, int calls, int k, int64_t* out);
 int mv_frame_pipe_finish_seeded(mvFramePipe* p, float* pose_sink, int32_t* n_cand_out, int32_t* n_sel_out);
+/* Device-resident permutations (round 6).  The same draw — torch.randperm(n)[:k] of an MT19937 seeded like torch.Generator().manual_seed(seed),
+ * Module/KeypointSelector.py:331,404 — made ON THE GPU from a candidate count that never leaves it: no D2H count, no host generator, no H2D permutation.
+ * A lane's generator lives in device memory as mv_randperm_state_words() uint32 words (the 624-word block + the position of the next draw);
+ *   mv_mt19937_seed            fills that representation on the host (copy it to the device);
+ *   mv_randperm_head_lanes     one workgroup per lane: n = n_dev[l * n_stride]; writes out_perm[l * cap + (0 .. min(n, k)))  and
+ *                              out_n_sel[l * n_sel_stride] = min(n, k); advances the lane's generator by max(n - 1, 0) draws (k <= mv_randperm_max_head());
+ *   mv_randperm_heads_emulated host-only (no GPU): the same phase functions (csrc/randperm_dev.h) run thread by thread with `threads` emulated
+ *                              threads — `calls` successive draws of one generator, out [calls, k] like mv_randperm_heads. */
+int mv_randperm_state_words(void);
+int mv_randperm_max_head(void);
+int mv_mt19937_seed(uint64_t seed, uint32_t* state_host);
+int mv_randperm_head_lanes(uint32_t* state, const int32_t* n_dev, int n_stride, int lanes, int k, int cap, int64_t* out_perm, int32_t* out_n_sel,
+                           int n_sel_stride, mvStream_t stream);
+int mv_randperm_heads_emulated(uint64_t seed, const int64_t* n, int calls, int k, int threads, int64_t* out);
+/* The device-driven frame.  mv_frame_pipe_seed_lanes also places the generators in device memory and — unless MV_PIPE_DEVICE_DRAW=0, the dense-mapping tail is on or
+ * num_point > mv_randperm_max_head() — switches the pipe to it (mv_frame_pipe_device_draw() == 1): a frame is then finished with mv_frame_pipe_finish_device,
+ * which never waits: backend + solve are queued behind the frame's selector by event and the front launch (mv_backend_front_draw_lanes) draws the permutation
+ * itself.  Same keypoints, same poses as mv_frame_pipe_finish_seeded.  mv_frame_pipe_finished_counts: the counts of the age-th newest finished frame
+ * (0 or 1), for whoever needs them on the host (blocks until that frame's front launch has run). */
+int mv_frame_pipe_device_draw(const mvFramePipe* p);
+int mv_frame_pipe_finish_device(mvFramePipe* p, float* pose_sink);
+int mv_frame_pipe_finished_counts(mvFramePipe* p, int age, int32_t* n_cand, int32_t* n_sel);
+/* host-side flow control of a device-driven stream: blocks until the front launch of the finish `lag` finishes back (0 = the newest; lag <= 6) has run */
+int mv_frame_pipe_wait_finished(mvFramePipe* p, int lag);
 /* register the newest FINISHED frame in a device-resident map (mv_map_append on the pipe's own streams, no copies; lanes = 1):
  * frame_idx = the map index the frame receives (= frames pushed so far), prev_frame = the previous keyframe's index; the
  * optimised pose is written over the frame's prior once its solve has finished */

@@ -85,7 +85,7 @@ class mvFrameInputs(C.Structure):
 FB_NAMES = ("VOLUME", "TOKENS", "DISPARITY", "DISPARITY_COV", "DEPTH", "DEPTH_COV", "MATCH_FLOW", "MATCH_COV", "CAND",
             "COUNT", "STATS", "KP0", "KP0F", "KP1", "INBOUND", "VALS", "SIGMA0", "SIGMA1", "POS_TC", "POS_TW", "ROT", "COV0",
             "COV0W", "COV1", "VALID", "NVALID", "POSE64", "INFO", "POSE", "MAP_UV", "MAP_D", "MAP_SDD", "MAP_TC", "MAP_TW", "MAP_COV",
-            "MAP_COLOR")
+            "MAP_COLOR", "PERM", "LIVE")
 FB = {n: i for i, n in enumerate(FB_NAMES)}
 
 _P = C.c_void_p
@@ -124,6 +124,10 @@ SIGNATURES = {
                                C.POINTER(mvLMParams), _P, _P, _P, _P]),
     "mv_pgo_solve_posed": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int] + [_P] * 14 + [C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, C.c_int,
                                      C.POINTER(mvLMParams)] + [_P] * 5),
+    "mv_pgo_solve_posed_dev": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int] + [_P] * 14 + [C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, C.c_int,
+                                         C.POINTER(mvLMParams)] + [_P] * 5),
+    "mv_backend_front_draw_lanes": (C.c_int, [_P, C.c_size_t, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int] + [_P] * 10 +
+                                    [C.c_int, C.c_float, C.POINTER(mvMatchCovParams)] + [_P] * 13),
     "mv_backend_front_lanes": (C.c_int, [_P, C.c_size_t, _P, _P, C.c_int, _P, C.c_int] + [_P] * 10 + [C.c_int, C.c_float, C.POINTER(mvMatchCovParams)] +
                                [_P] * 11),
     "mv_backproject": (C.c_int, [_P, _P, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_int,
@@ -180,6 +184,15 @@ SIGNATURES = {
     "mv_frame_pipe_volume_times": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     "mv_frame_pipe_time_detail": (C.c_int, [_P, C.c_int]),
     "mv_randperm_heads": (C.c_int, [C.c_uint64, _P, C.c_int, C.c_int, _P]),
+    "mv_frame_pipe_device_draw": (C.c_int, [_P]),
+    "mv_frame_pipe_finish_device": (C.c_int, [_P, _P]),
+    "mv_frame_pipe_finished_counts": (C.c_int, [_P, C.c_int, _P, _P]),
+    "mv_frame_pipe_wait_finished": (C.c_int, [_P, C.c_int]),
+    "mv_randperm_state_words": (C.c_int, []),
+    "mv_randperm_max_head": (C.c_int, []),
+    "mv_mt19937_seed": (C.c_int, [C.c_uint64, _P]),
+    "mv_randperm_head_lanes": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
+    "mv_randperm_heads_emulated": (C.c_int, [C.c_uint64, _P, C.c_int, C.c_int, C.c_int, _P]),
     "mv_frame_pipe_timeline": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     "mv_frame_pipe_timeline_backend": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     "mv_frame_pipe_buffer": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),

@@ -61,6 +61,7 @@ namespace {
 #define MV_MAX_PENDING 3
 #endif
 constexpr int MAX_PENDING = MV_MAX_PENDING, N_MAPS = MAX_PENDING + 2, N_CAND = MAX_PENDING + 1, N_PERM = 4, N_INEV = 8, MAX_VOL = 4, MAX_LK = 2;
+constexpr int N_BEV = 8;   // ring of per-finish backend events (finish g -> slot g % N_BEV): the device-driven frame waits for the exact finish whose reads free a slot
 
 struct Maps {
     float *disparity, *disparity_cov, *depth, *depth_cov, *match_flow, *match_cov;
@@ -73,6 +74,7 @@ struct Backend {   // every table is [lanes, cap = num_point, ...]; rows beyond 
     uint8_t *inbound, *valid;
     double *rot, *cov0, *cov0w, *cov1, *pose64, *info;
     int32_t* n_valid;
+    int32_t* live_dev;   // [lanes, 2] device-driven frame: selected keypoints = live rows, candidate count (written by the front launch's draw)
     int32_t n_sel[MV_MAX_LANES];
 };
 
@@ -105,6 +107,7 @@ struct FinishJob {
     int32_t n_sel[MV_MAX_LANES];
     int64_t n_cand[MV_MAX_LANES];   // seeded: candidate count per lane (the permutation is drawn by whoever issues the job)
     bool seeded;
+    bool device = false;            // device-driven frame: the permutation is drawn inside the front launch, n_sel is an upper bound (num_point)
     std::vector<int64_t> perm;      // explicit permutations [lanes, cap] (asynchronous issue: a copy of the caller's array)
     float* pose_sink;
     double t_count = 0, t_submit = 0;   // host clock (us): candidate count seen / job queued (MV_PIPE_HOST_STATS)
@@ -178,12 +181,12 @@ struct mvFramePipe {
     SelSeg deferred;     // MV_PIPE_SELECTOR_ON=vol: the newest frame's selector segment, not issued yet
     bool deferred_valid;
     hipEvent_t e_rest[N_INEV];   // inputs of the decoder side (coords, flow, ...) when the GEMM was issued ahead of them
-    hipEvent_t e_in[N_INEV], e_vol_done[MAX_VOL], e_vol_free[MAX_VOL], e_cand[N_CAND], e_backend[2], e_pgo, e_perm[N_PERM];
+    hipEvent_t e_in[N_INEV], e_vol_done[MAX_VOL], e_vol_free[MAX_VOL], e_cand[N_CAND], e_backend[N_BEV], e_pgo, e_perm[N_PERM];
     hipEvent_t e_release;     // the consumer's reads of result views enqueued so far (mv_frame_pipe_release)
     bool release_valid;
     hipEvent_t e_posed[2];    // backend slot k: world-frame tables written (side stream, in front of the solve)
     hipEvent_t e_solved[2];   // backend slot k: its solve has finished reading the tables
-    bool vol_free_valid[MAX_VOL], backend_valid[2], pgo_valid, perm_valid[N_PERM], solved_valid[2];
+    bool vol_free_valid[MAX_VOL], backend_valid[N_BEV], pgo_valid, perm_valid[N_PERM], solved_valid[2];
     // state
     long n_enq, n_fin;
     long n_vol;            // volume GEMMs issued (n_enq <= n_vol <= n_enq + 1: at most one GEMM ahead of its frame's decoder side)
@@ -216,6 +219,11 @@ struct mvFramePipe {
     std::vector<int32_t> perm_scratch;   // identity array of the partial Fisher-Yates, reused
     std::vector<int64_t> perm_host;      // [lanes, cap]
     std::vector<int32_t> nsel_host;
+    // Device-driven frame (round 6, mv_frame_pipe_seed_lanes with MV_PIPE_DEVICE_DRAW != 0): the same generators live in DEVICE memory and the permutation head is
+    // drawn inside the backend's front launch (randperm_dev.h) from the count the selector left in device memory — no D2H count, no host wait, no host draw, no
+    // H2D permutation: enqueue + finish of a frame are a fixed chain of launches.  Two state buffers: finish g reads rp_state[g & 1], writes rp_state[(g + 1) & 1].
+    uint32_t* rp_state[2];   // [lanes, mv_randperm_state_words()]
+    int dev_draw;
     // optional timing of the dominant kernel (bench.py roofline): event pairs around each volume GEMM on its stream
     int vol_timed[MAX_VOL];      // timing slot of the GEMM that filled each volume buffer (-1: not timed)
     std::vector<hipEvent_t> tv0, tv1, tv2, tv3;   // GEMM start / end, last lookup done, selector done (timeline hook)
@@ -232,6 +240,7 @@ struct mvFramePipe {
     // Cross-thread event edges: e_cand and e_release are recorded by the caller BEFORE the job is queued; e_backend is consumed by
     // the caller's enqueue only after `issued` says the launch thread has recorded it.
     int async_backend;
+    int async_explicit;     // the caller / MV_PIPE_ASYNC_BACKEND chose (the device-driven pipe otherwise drops the launch thread: see mv_frame_pipe_seed_lanes)
     int device;
     std::thread worker;
     std::mutex mu;
@@ -336,7 +345,9 @@ static size_t carve(mvFramePipe* p, char* base) {
         b.pose64 = a.take<double>(L * 7);
         b.info = a.take<double>(L * 4);
         b.n_valid = a.take<int32_t>(L);
+        b.live_dev = a.take<int32_t>(2 * L);
     }
+    for (int k = 0; k < 2; ++k) p->rp_state[k] = a.take<uint32_t>(L * (size_t)mv_randperm_state_words());
     if (c.mapping) {
         const size_t MP = c.map_num_point > 0 ? c.map_num_point : 1;
         for (int k = 0; k < N_CAND; ++k) {
@@ -423,7 +434,8 @@ extern "C" void mv_frame_pipe_destroy(mvFramePipe* p) {
     for (auto e : p->e_rest) ev(e);
     for (int k = 0; k < MAX_VOL; ++k) { ev(p->e_vol_done[k]); ev(p->e_vol_free[k]); }
     for (int k = 0; k < N_CAND; ++k) ev(p->e_cand[k]);
-    for (int k = 0; k < 2; ++k) { ev(p->e_backend[k]); ev(p->e_posed[k]); ev(p->e_solved[k]); }
+    for (int k = 0; k < 2; ++k) { ev(p->e_posed[k]); ev(p->e_solved[k]); }
+    for (auto e : p->e_backend) ev(e);
     ev(p->e_pgo);
     for (int k = 0; k < N_CAND; ++k) ev(p->e_lk[k]);
     for (auto e : p->e_seg) ev(e);
@@ -482,8 +494,8 @@ static int create_impl(mvFramePipe* p) {
         MV_HIP(mk(&p->e_cand[k]));
         MV_HIP(hipHostMalloc((void**)&p->h_count[k], (size_t)p->lanes * 4 * sizeof(int32_t), hipHostMallocDefault));
     }
+    for (auto& e : p->e_backend) MV_HIP(mk(&e));
     for (int k = 0; k < 2; ++k) {
-        MV_HIP(mk(&p->e_backend[k]));
         MV_HIP(mk(&p->e_posed[k]));
         MV_HIP(mk(&p->e_solved[k]));
     }
@@ -615,6 +627,7 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
         const char* e = getenv("MV_PIPE_ASYNC_BACKEND");
         const int want = cfg->async_backend ? cfg->async_backend : (e ? (atoi(e) ? 1 : -1) : MV_ASYNC_DEFAULT(p));
         p->async_backend = want > 0 ? 1 : 0;
+        p->async_explicit = (cfg->async_backend || e) ? 1 : 0;
         if (hipGetDevice(&p->device) != hipSuccess) p->async_backend = 0;
         { const char* e3 = getenv("MV_PIPE_LAUNCH_SPIN_US"); p->spin_us = e3 ? atof(e3) : 250.0; }
         { const char* e4 = getenv("MV_PIPE_HOST_STATS"); p->host_stats = e4 ? atoi(e4) : 0; }
@@ -731,9 +744,13 @@ static int issue_selector_segment(mvFramePipe* p, const SelSeg& d) {
             std::lock_guard<std::mutex> lk(p->mu);
             issued = p->issued;
         }
-        if (issued > 0) MV_TRY(wait_if_pending(s, p->e_backend[(issued - 1) & 1]));
-    } else if (p->n_fin > 0 && p->backend_valid[(p->n_fin - 1) & 1]) {
-        MV_TRY(wait_if_pending(s, p->e_backend[(p->n_fin - 1) & 1]));
+        // (device-driven frame: a finish is issued right behind its frame's enqueue, so "the newest issued backend" would be the PREVIOUS frame's and the
+        // segments would run one after the other; the ring holds the exact finish — frame f - 4's, long done — instead)
+        const long w = p->dev_draw ? d.need_issued - 1 : issued - 1;
+        if (w >= 0 && w < issued) MV_TRY(wait_if_pending(s, p->e_backend[w % N_BEV]));
+    } else if (p->n_fin > 0) {
+        const long w = p->dev_draw ? d.need_issued - 1 : p->n_fin - 1;
+        if (w >= 0 && p->backend_valid[w % N_BEV]) MV_TRY(wait_if_pending(s, p->e_backend[w % N_BEV]));
     }
     if (p->release_valid) MV_TRY(wait_if_pending(s, p->e_release));   // ... and by consumers of result views (mv_frame_pipe_release)
     // alt: the previous frame's segment ran on the OTHER decoder-side stream; this one reads its maps (FULL selector, and the backend's gathers
@@ -775,7 +792,8 @@ static int issue_selector_segment(mvFramePipe* p, const SelSeg& d) {
             MV_TRY(mv_kp_select_lanes(mp.match_cov, m0.depth, m0.depth_cov, mp.depth, mp.depth_cov, nullptr, nullptr, &sp,
                                       p->kp_ws, p->kp_ws_bytes, p->cand[k], p->count[k], p->stats[k], p->lanes, s));
         }
-        MV_HIP(hipMemcpyAsync(p->h_count[k], p->count[k], (size_t)p->lanes * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        if (!p->dev_draw)   // (the device-driven frame reads the count where it is)
+            MV_HIP(hipMemcpyAsync(p->h_count[k], p->count[k], (size_t)p->lanes * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         if (c.mapping) {
             // MappingPointSelector works on the PREVIOUS frame's depth maps (KeypointSelector.py:87-100; MACVO.py:315): its count
             // travels to the host with the tracking selector's
@@ -882,6 +900,8 @@ extern "C" int mv_frame_pipe_wait_candidates(mvFramePipe* p, int32_t* n_cand) {
     MV_TRY(selector_of_front_issued(p));
     const Pending& pd = p->pending.front();
     MV_HIP(hipEventSynchronize(p->e_cand[pd.cand]));
+    if (p->dev_draw)   // (the device-driven pipe has no per-frame count copy)
+        MV_HIP(hipMemcpy(p->h_count[pd.cand], p->count[pd.cand], (size_t)p->lanes * 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
     for (int l = 0; l < p->lanes; ++l) n_cand[l] = p->h_count[pd.cand][4 * l];
     return MV_OK;
 }
@@ -903,8 +923,39 @@ extern "C" int mv_frame_pipe_seed_lanes(mvFramePipe* p, const uint64_t* seeds) {
     const int cap = p->c.num_point > 0 ? p->c.num_point : 1;
     p->perm_host.assign((size_t)p->lanes * cap, 0);
     p->nsel_host.assign((size_t)p->lanes, 0);
+    {
+        // ... and the same generators in device memory: the device-driven frame (default wherever it applies; MV_PIPE_DEVICE_DRAW=0: the host draw above).
+        // Needs the two-launch backend, a head the device draw covers, and no dense-mapping tail (its second permutation is drawn by the Python side).
+        const char* e = getenv("MV_PIPE_DEVICE_DRAW");
+        const bool want = e ? atoi(e) != 0 : true;
+        p->dev_draw = want && p->fuse_backend && !p->c.mapping && p->c.num_point >= 1 && p->c.num_point <= mv_randperm_max_head() && p->pending.empty();
+        if (p->dev_draw && p->async_backend && !p->async_explicit) {
+            // One host thread.  The launch thread existed to overlap the host's draw + the backend launches with the caller's next enqueue while the caller waited
+            // for candidate counts; a device-driven frame has no wait and no draw, and one thread issues it in ~100 us.  Measured (profiles/r06_device_draw_ab.log):
+            // 300 steps 6.35 k (inline) vs 6.50 k (launch thread) frames/s on a 256-core host; pinned to ONE core 5.58 k inline against 3.93 k for the host-drawn
+            // frame with its two hot threads — the headline no longer moves with the host.
+            MV_TRY(flush_jobs(p));
+            {
+                std::lock_guard<std::mutex> lk(p->mu);
+                p->stop = true;
+            }
+            p->stop_flag.store(true, std::memory_order_relaxed);
+            p->cv_job.notify_all();
+            if (p->worker.joinable()) p->worker.join();
+            p->async_backend = 0;
+        }
+        if (p->dev_draw) {
+            const size_t W = (size_t)mv_randperm_state_words();
+            std::vector<uint32_t> st((size_t)p->lanes * W);
+            for (int l = 0; l < p->lanes; ++l) MV_TRY(mv_mt19937_seed(seeds[l], st.data() + (size_t)l * W));
+            MV_HIP(hipStreamSynchronize(p->s_back));   // (no front launch may be reading a generator)
+            MV_HIP(hipMemcpy(p->rp_state[p->n_fin & 1], st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+    }
     return MV_OK;
 }
+
+extern "C" int mv_frame_pipe_device_draw(const mvFramePipe* p) { return p && p->dev_draw ? 1 : 0; }
 
 static void randperm_head(std::mt19937& eng, int64_t n, int k, std::vector<int32_t>& r, int64_t* out) {
     if (n <= 0) return;
@@ -983,10 +1034,10 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
         MV_HIP(hipEventRecord(p->e_posed[k], p->s_side));
         MV_HIP(hipEventRecord(p->e_pgo, p->s_side));
         MV_HIP(hipEventRecord(p->e_solved[k], p->s_side));
-        MV_HIP(hipEventRecord(p->e_backend[k], s));
+        MV_HIP(hipEventRecord(p->e_backend[g % N_BEV], s));
         p->pgo_valid = true;
         p->solved_valid[k] = true;
-        p->backend_valid[k] = true;
+        p->backend_valid[g % N_BEV] = true;
         p->nvalid_valid[k] = false;   // (mv_frame_pipe_wait_tracked then reports 0 observations: no mapping either)
         return MV_OK;
     }
@@ -999,9 +1050,11 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
     if (p->release_valid) MV_TRY(wait_if_pending(s, p->e_release));
     // permutations [lanes, cap] -> pinned slot -> device (ONE copy; rows beyond a lane's n_sel are never read)
     const int ps = (int)(g % N_PERM);
-    if (p->perm_valid[ps]) MV_HIP(hipEventSynchronize(p->e_perm[ps]));   // long done; keeps the slot reuse provably safe
-    for (int l = 0; l < L; ++l)
-        memcpy(p->h_perm[ps] + (size_t)l * cap, perm_host + (size_t)l * cap, (size_t)n_sel[l] * sizeof(int64_t));
+    if (!j.device) {
+        if (p->perm_valid[ps]) MV_HIP(hipEventSynchronize(p->e_perm[ps]));   // long done; keeps the slot reuse provably safe
+        for (int l = 0; l < L; ++l)
+            memcpy(p->h_perm[ps] + (size_t)l * cap, perm_host + (size_t)l * cap, (size_t)n_sel[l] * sizeof(int64_t));
+    }
     MV_TRY(wait_if_pending(s, p->e_cand[pd.cand]));   // fired: the host has just read this frame's count
     // alt layout: the previous frame's maps (gathers below) were written by a segment on the other decoder-side stream, which e_cand does not cover.
     // (Slot f - 1 of e_seg is re-recorded by frame f - 1 + N_INEV, far beyond the frames in flight.)
@@ -1009,7 +1062,7 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
     const int ti = pd.ti;
     if (ti >= 0) MV_HIP(hipEventRecord(p->tv4[ti], s));
     const bool perm_in_args = L == 1 && n_max <= 256;   // one lane: the permutation rides in the kernel arguments (no pinned staging copy, no H2D node)
-    if (!perm_in_args) {
+    if (!perm_in_args && !j.device) {
         const size_t perm_bytes = ((size_t)(L - 1) * cap + n_sel[L - 1]) * sizeof(int64_t);
         MV_HIP(hipMemcpyAsync(b.perm, p->h_perm[ps], perm_bytes, hipMemcpyHostToDevice, s));
         MV_HIP(hipEventRecord(p->e_perm[ps], s));
@@ -1023,7 +1076,13 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
     // in-order stream.
     const bool fused = p->fuse_backend != 0;
     mvMatchCovParams cp{c.H, c.W, c.cov_kernel_size, 1, c.fx, c.fy, c.cx, c.cy, c.min_flow_cov_sq, c.min_depth_cov};
-    if (fused) {
+    if (j.device) {
+        // device-driven frame: the front launch draws the permutation itself (count and generator in device memory) and publishes the live-row count
+        MV_TRY(mv_backend_front_draw_lanes(p->cand[pd.cand], (size_t)p->plane, p->count[pd.cand], 4, p->rp_state[g & 1], p->rp_state[(g + 1) & 1], c.num_point,
+                                           L, cap, m1.match_flow, m1.match_cov, m0.depth, m0.disparity, m0.disparity_cov, m0.depth_cov, m1.depth, m1.disparity,
+                                           m1.disparity_cov, m1.depth_cov, c.edgewidth, c.match_cov_default, &cp, b.perm, b.live_dev, b.kp0, b.kp0f, b.kp1,
+                                           b.inbound, b.vals, b.sigma0, b.sigma1, b.pos_Tc, b.cov0, b.cov1, s));
+    } else if (fused) {
         // gather + track + back-projection + both covariance models + observation filters = ONE launch
         MV_TRY(mv_backend_front_lanes(p->cand[pd.cand], (size_t)p->plane, b.perm, perm_in_args ? p->h_perm[ps] : nullptr, L, n_sel, cap,
                                       m1.match_flow, m1.match_cov, m0.depth, m0.disparity, m0.disparity_cov, m0.depth_cov, m1.depth, m1.disparity,
@@ -1050,20 +1109,26 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
         MV_HIP(hipEventRecord(p->e_nvalid[k], s));
         p->nvalid_valid[k] = true;
     }
-    MV_HIP(hipEventRecord(p->e_backend[k], s));
-    p->backend_valid[k] = true;
+    MV_HIP(hipEventRecord(p->e_backend[g % N_BEV], s));
+    p->backend_valid[g % N_BEV] = true;
     if (ti >= 0) MV_HIP(hipEventRecord(p->tv5[ti], s));
 
     // ---- side stream: world-frame tables from the previous solve's pose (same stream: no event), then the LM solves of all
     // lanes in ONE launch (problem l = rows [l * cap, (l + 1) * cap), dead rows masked by `valid`); the optimised poses become
     // the next frame's priors (StaticMotionModel)
     hipStream_t ss = p->s_side;
-    MV_HIP(hipStreamWaitEvent(ss, p->e_backend[k], 0));
+    if (ss != s) MV_HIP(hipStreamWaitEvent(ss, p->e_backend[g % N_BEV], 0));   // (alt layout: backend + solve share one in-order stream)
     const float* pose = p->pose[j.pose_from];
     if (ti >= 0) MV_HIP(hipEventRecord(p->tv6[ti], ss));
     const size_t N = (size_t)cap;
     const size_t LN = (size_t)L * N;   // value table is [11, lanes, cap]: each of its rows is one concatenated per-point column
-    if (p->fuse_backend) {
+    if (j.device) {
+        MV_TRY(mv_pgo_solve_posed_dev(L, p->offs, b.live_dev, 2, cap, c.graph_type, pose, p->intr, p->bl, b.pos_Tc, b.cov0, b.pos_Tw, b.cov0w, b.rot, b.kp1,
+                                      b.vals + 4 * LN, b.vals + 5 * LN, b.vals + 6 * LN, b.sigma1, b.cov1, c.filters, c.filter_min_depth, c.max_depth, b.inbound,
+                                      b.vals, b.valid, b.n_valid, c.min_num_point, &c.lm, b.pose64, b.info, p->pose[j.pose_to], j.pose_sink, ss));
+        MV_HIP(hipEventRecord(p->e_solved[k], ss));
+        MV_HIP(hipEventRecord(p->e_pgo, ss));
+    } else if (p->fuse_backend) {
         // ... and the pose-dependent half = ONE launch: the rotation into the world frame is the solve kernel's prologue, the caller's pose
         // sink its second output (the 28-byte device-to-device copy was a DMA node on the critical stream).  No e_posed: the world-frame
         // tables are consumed behind e_solved (mv_frame_pipe_map_append).
@@ -1155,7 +1220,7 @@ static int submit_or_issue(mvFramePipe* p, FinishJob& j, const int64_t* perm_hos
         MV_TRY(finish_issue(p, j, j.seeded ? draw_perms(p, j) : perm_host));
         return j.has_sel ? issue_selector_segment(p, j.sel) : MV_OK;
     }
-    if (!j.seeded && j.n_max > 0) {
+    if (!j.seeded && !j.device && j.n_max > 0) {
         const size_t cap = p->c.num_point > 0 ? p->c.num_point : 1;
         j.perm.assign(perm_host, perm_host + (size_t)p->lanes * cap);
     }
@@ -1174,6 +1239,7 @@ static int submit_or_issue(mvFramePipe* p, FinishJob& j, const int64_t* perm_hos
 // wait_candidates + permutations (per-lane generators of mv_frame_pipe_seed_lanes) + finish in one host call
 extern "C" int mv_frame_pipe_finish_seeded(mvFramePipe* p, float* pose_sink, int32_t* n_cand_out, int32_t* n_sel_out) {
     MV_CHECK_ARG(p && !p->pending.empty() && (int)p->rng.size() == p->lanes);
+    MV_CHECK_ARG(!p->dev_draw);   // (its generators live on the device: mv_frame_pipe_finish_device)
     MV_TRY(selector_of_front_issued(p));
     const Pending& pd = p->pending.front();
     const double t_w0 = p->host_stats ? now_us() : 0.0;
@@ -1193,6 +1259,47 @@ extern "C" int mv_frame_pipe_finish_seeded(mvFramePipe* p, float* pose_sink, int
     }
     MV_TRY(finish_host(p, nsel, pose_sink, j));
     return submit_or_issue(p, j, nullptr);
+}
+
+// The device-driven finish (round 6): nothing to wait for and nothing to draw — the frame's backend + solve are queued behind its selector segment by event, the
+// permutation head is drawn inside the front launch.  The host learns the counts only if it asks (mv_frame_pipe_finished_counts).
+extern "C" int mv_frame_pipe_finish_device(mvFramePipe* p, float* pose_sink) {
+    MV_CHECK_ARG(p && !p->pending.empty() && p->dev_draw);
+    MV_TRY(selector_of_front_issued(p));
+    FinishJob j{};
+    j.seeded = false;
+    j.device = true;
+    j.t_count = j.t_submit = p->host_stats ? now_us() : 0.0;
+    int32_t nsel[MV_MAX_LANES];
+    for (int l = 0; l < p->lanes; ++l) nsel[l] = p->c.num_point;   // upper bound: rows beyond the live ones are masked by `valid`
+    MV_TRY(finish_host(p, nsel, pose_sink, j));
+    return submit_or_issue(p, j, nullptr);
+}
+
+// candidate / selected-keypoint counts of the `age`-th newest FINISHED frame (age 0 or 1), read back from the frame's backend slot: blocks until that
+// frame's front launch has run.  Off the hot path (result views, tests).
+extern "C" int mv_frame_pipe_finished_counts(mvFramePipe* p, int age, int32_t* n_cand, int32_t* n_sel) {
+    MV_CHECK_ARG(p && p->dev_draw && age >= 0 && age <= 1 && p->n_fin - 1 - age >= 0);
+    MV_TRY(flush_jobs(p));
+    const long g = p->n_fin - 1 - age;
+    MV_HIP(hipEventSynchronize(p->e_backend[g % N_BEV]));
+    std::vector<int32_t> h(2 * (size_t)p->lanes);
+    MV_HIP(hipMemcpy(h.data(), p->be[g & 1].live_dev, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int l = 0; l < p->lanes; ++l) {
+        if (n_sel) n_sel[l] = h[2 * l];
+        if (n_cand) n_cand[l] = h[2 * l + 1];
+    }
+    return MV_OK;
+}
+
+// Bound how far the host runs ahead of the GPU in a device-driven stream: blocks until the front launch of the finish `lag` finishes back (0 = the newest) has run.
+extern "C" int mv_frame_pipe_wait_finished(mvFramePipe* p, int lag) {
+    MV_CHECK_ARG(p && lag >= 0 && lag < N_BEV - 1);
+    const long g = p->n_fin - 1 - lag;
+    if (g < 0) return MV_OK;
+    MV_TRY(wait_issued(p, g + 1));
+    MV_HIP(hipEventSynchronize(p->e_backend[g % N_BEV]));
+    return MV_OK;
 }
 
 // Host-only probe of the driver's permutation generator (no GPU, no pipe): `calls` successive `torch.randperm(n[i])[:k]` of one
@@ -1280,7 +1387,6 @@ extern "C" int mv_frame_pipe_map_points(mvFramePipe* p, const int64_t* perm_host
     MV_CHECK_ARG(p && p->c.mapping && p->n_fin > 0 && n_sel >= 0 && n_sel <= p->c.map_num_point && (n_sel == 0 || perm_host));
     MV_TRY(flush_jobs(p));
     const mvFramePipeConfig& c = p->c;
-    const int k = (int)((p->n_fin - 1) & 1);
     hipStream_t s = p->s_back;
     const Maps& m0 = p->maps[p->last_maps_prev];
     if (p->maptail_valid) MV_HIP(hipEventSynchronize(p->e_maptail));   // pinned permutation + map buffers of the previous tail (long done)
@@ -1303,7 +1409,7 @@ extern "C" int mv_frame_pipe_map_points(mvFramePipe* p, const int64_t* perm_host
     p->mp_rows = n_sel;
     MV_HIP(hipEventRecord(p->e_maptail, s));
     p->maptail_valid = true;
-    MV_HIP(hipEventRecord(p->e_backend[k], s));   // the previous frame's maps stay in use until here (the next enqueue waits for this event)
+    MV_HIP(hipEventRecord(p->e_backend[(p->n_fin - 1) % N_BEV], s));   // the previous frame's maps stay in use until here (the next enqueue waits for this event)
     return MV_OK;
 }
 
@@ -1469,6 +1575,8 @@ extern "C" int mv_frame_pipe_buffer(mvFramePipe* p, int which, int age, void** p
         case MV_FB_POSE64: if (!b) break; *ptr = b->pose64; *count = 7 * L; return MV_OK;
         case MV_FB_INFO: if (!b) break; *ptr = b->info; *count = 4 * L; return MV_OK;
         case MV_FB_POSE: if (age > 1) break; *ptr = p->pose[(p->pose_cur + 3 - age) % 3]; *count = 7 * L; return MV_OK;
+        case MV_FB_PERM: if (!b) break; *ptr = b->perm; *count = N; return MV_OK;
+        case MV_FB_LIVE: if (!b || !p->dev_draw) break; *ptr = b->live_dev; *count = 2 * L; return MV_OK;
         case MV_FB_MAP_UV: if (!c.mapping || age) break; *ptr = p->mp_uvf; *count = 2 * (size_t)p->mp_rows; return MV_OK;
         case MV_FB_MAP_D: if (!c.mapping || age) break; *ptr = p->mp_d; *count = (size_t)p->mp_rows; return MV_OK;
         case MV_FB_MAP_SDD: if (!c.mapping || age) break; *ptr = p->mp_sdd; *count = (size_t)p->mp_rows; return MV_OK;

@@ -8,6 +8,7 @@
 // mv_kp_track replaces Odometry/MACVO.py:198-232 (kp1 = kp0 + flow[kp0], strict border filter of
 //   Utility/Point.py:5-13, and the ten retrieve_pixels gathers of Module/Frontend/Frontend.py:103-118).
 #include "common.h"
+#include "randperm_dev.h"
 #include "match_cov_dev.h"
 #include "pose_apply_dev.h"
 #include "obs_filter_dev.h"
@@ -298,18 +299,51 @@ __global__ __launch_bounds__(256) void obs_filter_kernel(const uint8_t* __restri
 // 8-XCD part writes back and invalidates the L2s, 200 times per frame, under the GEMM that runs beside it (its launches went from 87-94 to 98-103 us).
 // The filters are now the PROLOGUE of the lane's solve workgroup (mv_pgo_solve_posed), behind the kernel boundary that already exists.
 // Same expressions, same order, same bits as the separate kernels.
-template <bool PERM_IN_ARGS>
+// Round 6 — PM = 2, the device-driven frame: the keypoint permutation `torch.randperm(count)[:num_point]` (KeypointSelector.py:331,404) is drawn HERE, from the
+// candidate count where the selector left it in device memory and a device-resident MT19937 (randperm_dev.h): no D2H count, no host generator, no H2D
+// permutation, no host wait anywhere in a frame.  Every workgroup draws the head for itself (LDS); workgroup (0, 0, lane) also advances the lane's
+// generator into the other state buffer and publishes the head and the live-row count for the solve (same stream, next launch) and for result views.
+struct DrawArgs {
+    const int32_t* count;      // [lanes, count_stride]: candidate count of lane l at count[l * count_stride]
+    int count_stride;
+    const uint32_t* state_in;  // [lanes, mvrp::MT_STRIDE]
+    uint32_t* state_out;       // [lanes, mvrp::MT_STRIDE], != state_in
+    int k;                     // num_point
+    int64_t* out_perm;         // [lanes, cap]
+    int32_t* out_live;         // [lanes, 2]: selected keypoints = min(count, k), candidate count
+};
+struct DrawLds {
+    mvrp::Scratch s;
+    int32_t head[mvrp::NBUCKET];
+    int32_t out[mvrp::MAX_HEAD];
+};
+template <int PM>   // where the permutation comes from: 0 device memory, 1 the kernel arguments, 2 drawn here
 __global__ __launch_bounds__(256) void backend_front_kernel(const int32_t* __restrict__ cand, size_t cand_lane_stride, const int64_t* __restrict__ perm,
                                                             PermArg pa, int cap, mvLaneCounts cnt, int64_t* out_uv, TrackArgs a, float fx, float fy,
                                                             float cx, float cy, float* pos_Tc, const float* depth_map0, const float* depth_map1,
-                                                            double* out_cov0, double* out_cov1, mvMatchCovParams cp) {
+                                                            double* out_cov0, double* out_cov1, mvMatchCovParams cp, DrawArgs da) {
+    __shared__ __attribute__((aligned(16))) char draw_raw[PM == 2 ? sizeof(DrawLds) : 16];
+    DrawLds& D = *reinterpret_cast<DrawLds*>(draw_raw);
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int set = blockIdx.y, pl = blockIdx.z;
-    const int N = cnt.n[pl];
+    int N;
+    if constexpr (PM == 2) {
+        const int64_t n_cand = da.count[(size_t)pl * da.count_stride];
+        const bool adv = blockIdx.x == 0 && blockIdx.y == 0;
+        N = mv_randperm_head_wg(da.state_in + (size_t)pl * mvrp::MT_STRIDE, adv ? da.state_out + (size_t)pl * mvrp::MT_STRIDE : nullptr, n_cand, da.k,
+                                D.out, D.s, D.head);
+        __syncthreads();
+        if (adv) {
+            for (int i = threadIdx.x; i < N; i += 256) da.out_perm[(size_t)pl * cap + i] = D.out[i];
+            if (threadIdx.x == 0) { da.out_live[2 * pl] = N; da.out_live[2 * pl + 1] = (int32_t)n_cand; }
+        }
+    } else {
+        N = cnt.n[pl];
+    }
     if (n < N) {       // (wave-uniform)
         const int32_t* cand_l = cand + (size_t)pl * cand_lane_stride;
-        const long pi = PERM_IN_ARGS ? (long)pa.idx[n] : (long)perm[(size_t)pl * cap + n];
+        const long pi = PM == 2 ? (long)D.out[n] : PM == 1 ? (long)pa.idx[n] : (long)perm[(size_t)pl * cap + n];
         const int lin = cand_l[pi];
         const int u0 = lin % a.W, v0 = lin / a.W;
         TrackArgs al = a;
@@ -464,15 +498,41 @@ extern "C" int mv_backend_front_lanes(const int32_t* cand, size_t cand_lane_stri
             MV_CHECK_ARG(perm_host[i] >= 0 && perm_host[i] <= 0x7fffffffLL);
             pa.idx[i] = (int32_t)perm_host[i];
         }
-        hipLaunchKernelGGL(backend_front_kernel<true>, grid, block, 0, (hipStream_t)stream, cand, cand_lane_stride, nullptr, pa, cap, c, out_kp0_uv, ta,
-                           cp.fx, cp.fy, cp.cx, cp.cy, out_pos_Tc, depth0, depth1, out_cov0, out_cov1, cp);
+        hipLaunchKernelGGL(backend_front_kernel<1>, grid, block, 0, (hipStream_t)stream, cand, cand_lane_stride, nullptr, pa, cap, c, out_kp0_uv, ta,
+                           cp.fx, cp.fy, cp.cx, cp.cy, out_pos_Tc, depth0, depth1, out_cov0, out_cov1, cp, DrawArgs{});
     } else {
         MV_CHECK_ARG(perm_dev);
         PermArg pa;
         pa.idx[0] = 0;
-        hipLaunchKernelGGL(backend_front_kernel<false>, grid, block, 0, (hipStream_t)stream, cand, cand_lane_stride, perm_dev, pa, cap, c, out_kp0_uv, ta,
-                           cp.fx, cp.fy, cp.cx, cp.cy, out_pos_Tc, depth0, depth1, out_cov0, out_cov1, cp);
+        hipLaunchKernelGGL(backend_front_kernel<0>, grid, block, 0, (hipStream_t)stream, cand, cand_lane_stride, perm_dev, pa, cap, c, out_kp0_uv, ta,
+                           cp.fx, cp.fy, cp.cx, cp.cy, out_pos_Tc, depth0, depth1, out_cov0, out_cov1, cp, DrawArgs{});
     }
+    return mv_launch_status();
+}
+
+// mv_backend_front_lanes of the device-driven frame (round 6): the permutation is drawn inside the launch (backend_front_kernel<2>), the number of live rows
+// never reaches the host — the grid covers `num_point` rows per lane and the waves beyond min(count, num_point) retire at once.
+extern "C" int mv_backend_front_draw_lanes(const int32_t* cand, size_t cand_lane_stride, const int32_t* count_dev, int count_stride, const uint32_t* state_in,
+                                           uint32_t* state_out, int num_point, int lanes, int cap, const float* match_flow, const float* match_cov,
+                                           const float* depth0, const float* disp0, const float* sdisp0, const float* sdd0, const float* depth1,
+                                           const float* disp1, const float* sdisp1, const float* sdd1, int edge, float match_cov_default,
+                                           const mvMatchCovParams* cov_params, int64_t* out_perm, int32_t* out_live, int64_t* out_kp0_uv, float* out_kp0,
+                                           float* out_kp1, uint8_t* out_inbound, float* out_vals, float* out_sigma0, float* out_sigma1, float* out_pos_Tc,
+                                           double* out_cov0, double* out_cov1, mvStream_t stream) {
+    MV_CHECK_ARG(cov_params && edge >= 0 && lanes >= 1 && lanes <= MV_MAX_LANES && cap >= 1 && num_point >= 0 && num_point <= cap && count_stride >= 1);
+    const mvMatchCovParams cp = *cov_params;
+    MV_CHECK_ARG(cp.H > 0 && cp.W > 0 && cp.kernel_size >= 1 && (cp.kernel_size & 1) && cp.use_patch_var);
+    if (cp.kernel_size > mvcov::MAX_K || num_point > mvrp::MAX_HEAD) return MV_ERR_UNSUPPORTED;
+    MV_CHECK_ARG(cand && count_dev && state_in && state_out && state_in != state_out && out_perm && out_live && match_flow && depth0 && depth1 &&
+                 out_kp0_uv && out_kp1 && out_inbound && out_vals && out_sigma0 && out_sigma1 && out_pos_Tc && out_cov0 && out_cov1);
+    const TrackArgs ta{match_flow, match_cov, depth0, disp0, sdisp0, sdd0, depth1, disp1, sdisp1, sdd1, cp.H, cp.W, edge, match_cov_default,
+                       out_kp0, out_kp1, out_inbound, out_vals, out_sigma0, out_sigma1};
+    const dim3 grid(mv_ceil_div(num_point > 0 ? num_point : 1, 4), 2, lanes), block(256);   // (num_point == 0: workgroup (0, 0, l) still advances the generator)
+    PermArg pa;
+    pa.idx[0] = 0;
+    const DrawArgs da{count_dev, count_stride, state_in, state_out, num_point, out_perm, out_live};
+    hipLaunchKernelGGL(backend_front_kernel<2>, grid, block, 0, (hipStream_t)stream, cand, cand_lane_stride, nullptr, pa, cap, mvLaneCounts{}, out_kp0_uv, ta,
+                       cp.fx, cp.fy, cp.cx, cp.cy, out_pos_Tc, depth0, depth1, out_cov0, out_cov1, cp, da);
     return mv_launch_status();
 }
 

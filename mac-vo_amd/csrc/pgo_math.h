@@ -56,6 +56,8 @@ struct PgoArgs {
     double* apply_rot;
     float* pose_sink;
     int32_t apply_live[MV_MAX_LANES];
+    const int32_t* live_dev;   // device-driven frame (mv_pgo_solve_posed_dev): the live-row count of problem l is live_dev[l * live_stride] in device memory
+    int live_stride;           // (written by the backend's front launch on the same stream) instead of apply_live[l]
     // ... and the observation filters of the problem's rows (obs_filter_dev.h) in front of that: filter_flags >= 0 -> valid_out / count_out written
     int filter_flags;
     float filter_min_depth, filter_max_depth;

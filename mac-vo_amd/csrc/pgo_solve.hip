@@ -210,9 +210,10 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
     g.cx = (double)a.intrinsics[4 * prob + 2]; g.cy = (double)a.intrinsics[4 * prob + 3];
     g.blfx = g.fx * (double)a.baseline[prob];  // K[0,0] * bl in fp64 of the fp32 buffers
 
+    const int live_rows = a.live_dev ? a.live_dev[(size_t)prob * a.live_stride] : a.apply_live[prob < MV_MAX_LANES ? prob : 0];
     if (a.valid_out) {      // mv_pgo_solve_posed: the lane's observation filters (obs_filter_kernel's body; PGO_THREADS == 256), then ...
         obs_filter_body(a.filter_inbound, a.apply_cov_Tc, a.obs2_covTc, a.filter_vals, a.filter_flags, a.filter_min_depth, a.filter_max_depth,
-                        a.filter_cap, a.apply_live[prob], prob, gridDim.x, a.valid_out, a.count_out);
+                        a.filter_cap, live_rows, prob, gridDim.x, a.valid_out, a.count_out);
         __threadfence_block();
         __syncthreads();
     }
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
 #pragma unroll
             for (int i = 0; i < 9; ++i) a.apply_rot[9 * prob + i] = R[i];
         }
-        const int live = a.apply_live[prob];
+        const int live = live_rows;
         for (int i = tid; i < live; i += PGO_THREADS) mv_pose_apply_row(pose, R, beg + i, a.apply_pos_Tc, a.apply_cov_Tc, a.apply_pos_Tw, a.apply_cov_Tw);
         __threadfence_block();
         __syncthreads();
@@ -578,6 +579,8 @@ struct PoseApplyArgs {   // mv_pgo_solve_posed's extra arguments (all null for t
     float* pose_sink;
     const int32_t* n_live;
     int filter_flags = -1;
+    const int32_t* live_dev = nullptr;
+    int live_stride = 0;
     float filter_min_depth = 0.f, filter_max_depth = 0.f;
     int cap = 0;
     const uint8_t* inbound = nullptr;
@@ -600,13 +603,15 @@ static int pgo_solve_impl(int nprob, const int32_t* offsets, int graph_type, con
               pixel2_disp_cov, pixel2_uv_cov, obs2_covTc, valid, min_points, out_pose, out_info, out_pose_f32, 1};
     a.pose_sink = pa.pose_sink;
     if (pa.pos_Tc) {
-        MV_CHECK_ARG(nprob <= MV_MAX_LANES && pa.n_live);
+        MV_CHECK_ARG(nprob <= MV_MAX_LANES && (pa.n_live || pa.live_dev));
+        a.live_dev = pa.live_dev;
+        a.live_stride = pa.live_stride;
         a.apply_pos_Tc = pa.pos_Tc;
         a.apply_cov_Tc = pa.cov_Tc;
         a.apply_pos_Tw = const_cast<float*>(pos_Tw);        // the solve's own input tables are the outputs of the fold
         a.apply_cov_Tw = pa.cov_Tc ? const_cast<double*>(cov_Tw) : nullptr;
         a.apply_rot = pa.out_rot;
-        for (int l = 0; l < nprob; ++l) {
+        for (int l = 0; l < nprob && pa.n_live; ++l) {
             MV_CHECK_ARG(pa.n_live[l] >= 0);
             a.apply_live[l] = pa.n_live[l];
         }
@@ -622,7 +627,7 @@ static int pgo_solve_impl(int nprob, const int32_t* offsets, int graph_type, con
             a.valid_out = pa.valid_out;
             a.count_out = pa.count_out;
             a.valid = pa.valid_out;      // what the solve reads
-            for (int l = 0; l < nprob; ++l) MV_CHECK_ARG(pa.n_live[l] <= pa.cap);
+            for (int l = 0; l < nprob && pa.n_live; ++l) MV_CHECK_ARG(pa.n_live[l] <= pa.cap);
         }
     }
     {
@@ -680,6 +685,28 @@ extern "C" int mv_pgo_solve_posed(int nprob, const int32_t* offsets, const int32
     MV_CHECK_ARG(pos_Tc && pos_Tw && n_live && (!cov_Tc || cov_Tw));
     MV_CHECK_ARG(nprob < 512);   // (the 256-thread solve variant: the filter body is written for it)
     PoseApplyArgs pa{pos_Tc, cov_Tc, out_rot, pose_sink, n_live};
+    if (filter_flags >= 0) {
+        pa.filter_flags = filter_flags; pa.filter_min_depth = filter_min_depth; pa.filter_max_depth = filter_max_depth; pa.cap = cap;
+        pa.inbound = inbound; pa.vals = vals; pa.valid_out = valid; pa.count_out = count_out;
+    }
+    return pgo_solve_impl(nprob, offsets, graph_type, init_pose, intrinsics, baseline, pos_Tw, cov_Tw, pixel2_uv, pixel2_d, pixel2_disp,
+                          pixel2_disp_cov, pixel2_uv_cov, obs2_covTc, valid, min_points, params, out_pose, out_info, out_pose_f32, pa, stream);
+}
+
+// mv_pgo_solve_posed of the device-driven frame (round 6): the live-row count of problem l is read from device memory (n_live_dev[l * n_live_stride] <= cap,
+// written by mv_backend_front_draw_lanes earlier on the stream) — the host never learns it.
+extern "C" int mv_pgo_solve_posed_dev(int nprob, const int32_t* offsets, const int32_t* n_live_dev, int n_live_stride, int cap, int graph_type,
+                                      const float* init_pose, const float* intrinsics, const float* baseline, const float* pos_Tc, const double* cov_Tc,
+                                      float* pos_Tw, double* cov_Tw, double* out_rot, const float* pixel2_uv, const float* pixel2_d,
+                                      const float* pixel2_disp, const float* pixel2_disp_cov, const float* pixel2_uv_cov, const double* obs2_covTc,
+                                      int filter_flags, float filter_min_depth, float filter_max_depth, const uint8_t* inbound, const float* vals,
+                                      uint8_t* valid, int32_t* count_out, int min_points, const mvLMParams* params, double* out_pose, double* out_info,
+                                      float* out_pose_f32, float* pose_sink, mvStream_t stream) {
+    MV_CHECK_ARG(pos_Tc && pos_Tw && n_live_dev && n_live_stride >= 1 && (!cov_Tc || cov_Tw));
+    MV_CHECK_ARG(nprob < 512);
+    PoseApplyArgs pa{pos_Tc, cov_Tc, out_rot, pose_sink, nullptr};
+    pa.live_dev = n_live_dev;
+    pa.live_stride = n_live_stride;
     if (filter_flags >= 0) {
         pa.filter_flags = filter_flags; pa.filter_min_depth = filter_min_depth; pa.filter_max_depth = filter_max_depth; pa.cap = cap;
         pa.inbound = inbound; pa.vals = vals; pa.valid_out = valid; pa.count_out = count_out;

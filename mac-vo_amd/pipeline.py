@@ -439,11 +439,33 @@ class _NativeResult:
     """Result of one natively driven frame of one lane.  Every tensor is a VIEW into the pipe's arena: valid until two
     more frames have been finished (slots rotate); clone what must live longer."""
 
-    def __init__(self, hp: "NativeHotPath", lane: int, n_sel: int, n_cand: int):
-        self._hp, self.lane, self.n_sel, self.n_cand = hp, lane, n_sel, n_cand
+    def __init__(self, hp: "NativeHotPath", lane: int, n_sel: "int | None", n_cand: "int | None"):
+        self._hp, self.lane, self._n_sel, self._n_cand = hp, lane, n_sel, n_cand
         self._fin = hp._n_fin          # finish counter at creation: views are resolved against it
-        self.extras: dict = {}
+        self._extras: "dict | None" = None
         self.map_points = None          # mapping mode: ops.MapPoints views of the frame's dense map points
+
+    # Device-driven frames (round 6): the counts never reach the host on their own — the first access reads them back from the frame's backend slot
+    # (blocks until that frame's front launch has run; off the hot path).
+    def _resolve(self) -> None:
+        if self._n_sel is None:
+            self._n_cand, self._n_sel = self._hp._finished_counts(self._fin, self._age(), self.lane)
+
+    @property
+    def n_sel(self) -> int:
+        self._resolve()
+        return self._n_sel
+
+    @property
+    def n_cand(self) -> int:
+        self._resolve()
+        return self._n_cand
+
+    @property
+    def extras(self) -> dict:
+        if self._extras is None:
+            self._extras = self._hp._extras_of(self) if self._hp.keep_extras else {}
+        return self._extras
 
     def _age(self) -> int:
         age = self._hp._n_fin - self._fin
@@ -573,9 +595,15 @@ class NativeHotPath:
         pipe = C.c_void_p()
         L.check(lib.mv_frame_pipe_create(C.byref(pc), self._base, nbytes, C.byref(pipe)), "mv_frame_pipe_create")
         self._pipe, self._lib, self._pc = pipe, lib, pc
+        self.device_driven = False
         if self._native_seeds:
             seeds = (C.c_uint64 * self.lanes)(*[int(g) & 0xFFFFFFFFFFFFFFFF for g in self.generators])
             L.check(lib.mv_frame_pipe_seed_lanes(pipe, seeds), "mv_frame_pipe_seed_lanes")
+            # round 6: the generators also live in device memory and — wherever it applies — the frame is device-driven: the permutation head is drawn
+            # inside the backend's front launch, `finish` never waits for the GPU (csrc/frame_pipe.hip, csrc/randperm_dev.h; MV_PIPE_DEVICE_DRAW=0 restores
+            # the host draw).  Same keypoints, same poses (tests/test_gpu_lanes.py).
+            self.device_driven = bool(lib.mv_frame_pipe_device_draw(pipe))
+        self._counts_cache: dict = {}
         if self._init_pose is not None:
             self._set_pose(self._init_pose)
 
@@ -704,6 +732,10 @@ class NativeHotPath:
         """Host half of a frame: wait for the candidate counts, draw the permutations (CPU generators, lane order), enqueue
         the pose-dependent kernels.  Returns a :class:`_NativeResult` (a list of them, one per lane, for lanes > 1)."""
         L, lib = ops.L, self._lib
+        if self.device_driven:
+            L.check(lib.mv_frame_pipe_release(self._pipe, ops._stream()), "mv_frame_pipe_release")
+            L.check(lib.mv_frame_pipe_finish_device(self._pipe, None if pose_sink is None else pose_sink.data_ptr()), "mv_frame_pipe_finish_device")
+            return self._finished()
         if self._native_seeds:
             L.check(lib.mv_frame_pipe_release(self._pipe, ops._stream()), "mv_frame_pipe_release")
             L.check(lib.mv_frame_pipe_finish_seeded(self._pipe, None if pose_sink is None else pose_sink.data_ptr(), self._ncand, self._nsel),
@@ -768,8 +800,9 @@ class NativeHotPath:
         L, lib = ops.L, self._lib
         self._n_fin += 1
         mp = getattr(self, "_map", None)
+        dd = self.device_driven
         if mp is not None:
-            n_rows = int(self._nsel[0])
+            n_rows = self._cap if dd else int(self._nsel[0])   # (device-driven: an upper bound; the append compacts by the `valid` mask)
             if mp.n_frames + 1 >= mp.cap["frames"] or mp.rows_upper + n_rows >= mp.cap["match"]:
                 self.synchronize()                          # growth re-allocates the stores: rare (capacity doubles), so simply drain
                 mp.reserve(n_rows)
@@ -782,20 +815,37 @@ class NativeHotPath:
         map_pts = self._map_tail(mp) if self.cfg.mapping else None
         out = []
         for l in range(self.lanes):
-            n_sel = self._nsel[l]
-            res = _NativeResult(self, l, n_sel, self._ncand[l])
+            res = _NativeResult(self, l, None if dd else self._nsel[l], None if dd else self._ncand[l])
             res.map_points = map_pts
-            if self.keep_extras and n_sel:
-                f32, f64 = torch.float32, torch.float64
-                vals = self._view("VALS", 0, f32, (11, self.lanes, self._cap))[:, l, :n_sel]
-                tr = ops.TrackedKeypoints(res._rows("KP0F", f32, (2,)), res._rows("KP1", f32, (2,)),
-                                          res._rows("INBOUND", torch.bool), vals,
-                                          res._rows("SIGMA0", f32, (3,)), res._rows("SIGMA1", f32, (3,)))
-                res.extras = dict(tracked=tr, cov0=res._rows("COV0", f64, (3, 3)), cov0_w=res._rows("COV0W", f64, (3, 3)),
-                                  cov1=res._rows("COV1", f64, (3, 3)), valid=res._rows("VALID", torch.bool),
-                                  pos_Tw=res._rows("POS_TW", f32, (3,)), n_cand=self._ncand[l])
+            if self.keep_extras and not dd:
+                res.extras   # noqa: B018  (host-driven frames: build the views now, as before)
             out.append(res)
         return out[0] if self.lanes == 1 else out
+
+    def _extras_of(self, res: "_NativeResult") -> dict:
+        n_sel, l = res.n_sel, res.lane
+        if not n_sel:
+            return {}
+        f32, f64 = torch.float32, torch.float64
+        vals = self._view("VALS", res._age(), f32, (11, self.lanes, self._cap))[:, l, :n_sel]
+        tr = ops.TrackedKeypoints(res._rows("KP0F", f32, (2,)), res._rows("KP1", f32, (2,)),
+                                  res._rows("INBOUND", torch.bool), vals,
+                                  res._rows("SIGMA0", f32, (3,)), res._rows("SIGMA1", f32, (3,)))
+        return dict(tracked=tr, cov0=res._rows("COV0", f64, (3, 3)), cov0_w=res._rows("COV0W", f64, (3, 3)),
+                    cov1=res._rows("COV1", f64, (3, 3)), valid=res._rows("VALID", torch.bool),
+                    pos_Tw=res._rows("POS_TW", f32, (3,)), n_cand=res.n_cand)
+
+    def _finished_counts(self, fin: int, age: int, lane: int):
+        """(n_cand, n_sel) of lane ``lane`` of the frame that was finish number ``fin`` (device-driven frames; blocking read-back)."""
+        got = self._counts_cache.get(fin)
+        if got is None:
+            nc, ns = (ops.C.c_int32 * self.lanes)(), (ops.C.c_int32 * self.lanes)()
+            ops.L.check(self._lib.mv_frame_pipe_finished_counts(self._pipe, age, nc, ns), "mv_frame_pipe_finished_counts")
+            got = (list(nc), list(ns))
+            if len(self._counts_cache) > 64:
+                self._counts_cache.clear()
+            self._counts_cache[fin] = got
+        return got[0][lane], got[1][lane]
 
     def step(self, x: FrameInputs):
         """One ``run_pair`` start to finish (no cross-frame overlap); results are valid on the current stream."""
@@ -860,6 +910,26 @@ class NativeHotPath:
         depth = self._depth if depth is None else depth
         it = iter(frames)
         nxt = next(it, None)
+        if self._pipe is not None and self.device_driven:
+            # Device-driven frames: nothing in a frame waits for the host, so a frame is enqueued and finished in one go (the next frame's GEMM in between, as
+            # in the host-driven order); how far the host runs ahead of the GPU is bounded by the HIP queues, the slot rotation is guarded by events.
+            i = 0
+            # ... and by `lag`: the host stays at most that many finished frames ahead of the GPU's front launches (flow control on an event two frames old, not a
+            # wait on the critical chain).  Measured at 640x480 (profiles/r06_device_draw_ab.log): lag 0 / 1 / 2 / 3 / 4 / 6 / unbounded = 4.13 / 6.01 / 6.51 / 6.46 / 6.34 /
+            # 6.24 / 4.07 k frames/s — with hundreds of frames queued the same kernels take 1.6x as long (deep queues of cross-queue barriers), so the default is 2.
+            lag = int(os.environ.get("MV_PIPE_DD_AHEAD", "2"))
+            while nxt is not None:
+                self.enqueue_frontend(nxt)
+                nxt = next(it, None)
+                if self._volume_ahead and nxt is not None:
+                    self.enqueue_volume(nxt)
+                res = self.finish(None, None if pose_sink is None else pose_sink[i])
+                i += 1
+                if lag >= 0:
+                    ops.L.check(self._lib.mv_frame_pipe_wait_finished(self._pipe, lag), "mv_frame_pipe_wait_finished")
+                yield res
+            self.sync_all()
+            return
         state = {"nxt": nxt, "vol": False, "pending": 0}
 
         def pump():

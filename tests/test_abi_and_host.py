@@ -230,6 +230,37 @@ def test_native_permutation_generator_is_torch_randperm():
             assert (out[i, m:] == -1).all()
 
 
+def test_device_permutation_phases_are_torch_randperm():
+    """Round 6: the DEVICE form of the same draw (csrc/randperm_dev.h: one-step block twist of the 624-word MT19937 state, partial Fisher-Yates restated as a
+    hash lookup of `prev(i, p)` + pointer chains) — its phase functions executed on the host thread by thread (mv_randperm_heads_emulated, any emulated
+    workgroup size) against torch.randperm itself.  The GPU suite runs the same functions as a kernel (tests/test_gpu_device_draw.py)."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from macvo_amd import _lib as L
+
+    lib = L.load()
+    assert lib.mv_randperm_state_words() >= 625 and lib.mv_randperm_max_head() >= 256
+    ns = [8000, 3, 1, 0, 2, 200, 201, 199, 7000, 12345, 50, 100000, 624, 625, 623, 1248, 307200, 511, 512, 513]
+    for seed in (0, 42, 2 ** 33 + 5):
+        for k in (1, 100, 200, 512):
+            for threads in (1, 64, 256, 1024):
+                n_arr = np.asarray(ns, dtype=np.int64)
+                out = np.full((len(ns), k), -1, dtype=np.int64)
+                assert lib.mv_randperm_heads_emulated(C.c_uint64(seed), n_arr.ctypes.data, len(ns), k, threads, out.ctypes.data) == 0
+                g = torch.Generator().manual_seed(seed)
+                for i, n in enumerate(ns):
+                    w = torch.randperm(n, generator=g)[:k].numpy()
+                    assert np.array_equal(out[i, : len(w)], w), (seed, k, threads, i, n)
+                    assert (out[i, len(w):] == -1).all()
+    # the seeded device representation = init_genrand of the low 32 seed bits, position 624 (the first draw steps the block)
+    st = np.zeros(lib.mv_randperm_state_words(), dtype=np.uint32)
+    assert lib.mv_mt19937_seed(C.c_uint64(2 ** 40 + 5), st.ctypes.data) == 0
+    assert st[0] == 5 and st[624] == 624 and st[1] == (1812433253 * (5 ^ (5 >> 30)) + 1) % 2 ** 32
+    assert lib.mv_randperm_heads_emulated(C.c_uint64(0), n_arr.ctypes.data, 1, lib.mv_randperm_max_head() + 1, 64, out.ctypes.data) == -2   # MV_ERR_UNSUPPORTED
+
 def test_bench_roofline_object_contract():
     """bench.py's `roofline` object (the driver's contract: bound / achieved / peak / unit / frac / traffic) for the three kinds of
     volume kernel, from synthetic launch times: achieved = algorithmic (or, for the split kernels, executed) work / time, frac =

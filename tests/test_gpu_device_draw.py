@@ -1,0 +1,176 @@
+"""Round 6 — the device-driven frame: `selected_points[torch.randperm(n)[:numPoint]]` (Module/KeypointSelector.py:331,404) drawn ON THE GPU from a
+device-resident MT19937 (csrc/randperm_dev.h), the candidate count never leaving device memory, `finish` never waiting for the GPU.  Parity bar: the same
+bits as torch's CPU generator + torch.randperm — keypoint indices bit-exact — and, through the frame driver, the same tables and poses as the host-drawn
+frame (which earlier rounds pinned against the oracle and the reference's own loop)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(frames, dev, **kw):
+    from macvo_amd.pipeline import FrameInputs
+
+    return [FrameInputs(**{k: (None if v is None else v.to(dev)) for k, v in fr.items()}, **kw) for fr in frames]
+
+
+@pytest.mark.parametrize("k", [1, 200, 512])
+def test_randperm_head_kernel_is_torch_randperm(gpu, k):
+    """mv_randperm_head_lanes: one workgroup per lane, count read from device memory, generator advanced in place — successive calls of each lane's generator
+    against `torch.Generator().manual_seed(seed)` + `torch.randperm(n)[:k]`, with counts around every edge (0, 1, 2, n <= k, block boundaries of the 624-word
+    twist, a six-figure count)."""
+    from macvo_amd import _lib as L
+
+    lib = L.load()
+    W = lib.mv_randperm_state_words()
+    seeds = [0, 1, 1234, 2 ** 40 + 5]
+    lanes = len(seeds)
+    counts = [[8000, 3, 1, 0, 2, k, k + 1, max(k - 1, 0), 7000, 624, 625, 623, 1248, 100003, 50, 9999],
+              [5, 0, 12345, 1, 1, 300, 8001, 200, 201, 199, 2, 0, 77777, 625, 8000, 8000],
+              [307200, 1, 9000, 512, 513, 511, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7],
+              [8000] * 16]
+    st = np.zeros((lanes, W), dtype=np.uint32)
+    for l, s in enumerate(seeds):
+        L.check(lib.mv_mt19937_seed(C.c_uint64(s), st[l].ctypes.data), "mv_mt19937_seed")
+    state = torch.from_numpy(st.view(np.int32)).to(gpu)
+    gens = [torch.Generator().manual_seed(s) for s in seeds]
+    cap = max(k, 1)
+    for c in range(16):
+        n = torch.tensor([[counts[l][c], -1, -1, -1] for l in range(lanes)], dtype=torch.int32, device=gpu)     # (count_stride = 4, as the selector writes it)
+        out = torch.full((lanes, cap), -7, dtype=torch.int64, device=gpu)
+        nsel = torch.full((lanes,), -1, dtype=torch.int32, device=gpu)
+        L.check(lib.mv_randperm_head_lanes(state.data_ptr(), n.data_ptr(), 4, lanes, k, cap, out.data_ptr(), nsel.data_ptr(), 1, None), "mv_randperm_head_lanes")
+        torch.cuda.synchronize()
+        for l in range(lanes):
+            want = torch.randperm(counts[l][c], generator=gens[l])[:k]
+            assert int(nsel[l]) == want.numel(), (c, l)
+            assert torch.equal(out[l, : want.numel()].cpu(), want), (c, l, counts[l][c])
+            assert (out[l, want.numel():] == -7).all()
+
+
+@pytest.mark.parametrize("lanes,selector,graph,num_point", [(1, "nodepth", "disp", 60), (1, "full", "icp", 200), (3, "nodepth", "reproj", 60), (1, "nodepth", "disp", 500)])
+def test_device_driven_frame_equals_the_host_drawn_frame(gpu, monkeypatch, lanes, selector, graph, num_point):
+    """The whole frame through the driver, device-driven (default for integer seeds) against `MV_PIPE_DEVICE_DRAW=0` (host MT19937 + kernel-argument / H2D
+    permutation, the round-5 form pinned against torch, the oracle and the reference loop): the permutation head, EVERY backend table over its live rows, the
+    counts and the poses are bit-identical, frame after frame (the generator advances by n - 1 draws per frame).  num_point = 500 > candidates covers the
+    n <= k branch of the draw."""
+    from macvo_amd.pipeline import Camera, HotPathConfig, NativeHotPath, stack_lanes
+
+    H, W, Cc, n_frames = 192, 256, 32, 8
+    cam, frames, _ = synth.make_sequence(n_frames + lanes, H, W, C=Cc, iters=2, seed=11)
+    ins = _inputs(frames, gpu)
+    batches = ins if lanes == 1 else [stack_lanes([ins[(t + l) % len(ins)] for l in range(lanes)]) for t in range(n_frames)]
+    names = {"PERM": (torch.int64, ()), "KP0": (torch.int64, (2,)), "KP0F": (torch.float32, (2,)), "KP1": (torch.float32, (2,)), "INBOUND": (torch.uint8, ()),
+             "SIGMA0": (torch.float32, (3,)), "SIGMA1": (torch.float32, (3,)), "POS_TC": (torch.float32, (3,)), "POS_TW": (torch.float32, (3,)),
+             "COV0": (torch.float64, (9,)), "COV0W": (torch.float64, (9,)), "COV1": (torch.float64, (9,)), "VALID": (torch.uint8, ())}
+    runs = {}
+    for dd in ("0", "1"):
+        monkeypatch.setenv("MV_PIPE_DEVICE_DRAW", dd)
+        hot = NativeHotPath(Camera(**cam), HotPathConfig(num_point=num_point, graph_type=graph, selector=selector), gpu, lanes=lanes,
+                            generators=[5 + 7 * l for l in range(lanes)])
+        hot.initialize(batches[0])
+        rec = []
+        sink = torch.zeros((n_frames - 1, lanes, 7) if lanes > 1 else (n_frames - 1, 7), device=gpu)
+        for t in range(1, n_frames):
+            hot.enqueue_frontend(batches[t])
+            res = hot.finish(None, sink[t - 1])
+            assert hot.device_driven == (dd == "1")
+            hot.sync_all()
+            torch.cuda.synchronize()
+            res = res if isinstance(res, list) else [res]
+            cap = hot._cap
+            d = {"n_sel": [r.n_sel for r in res], "n_cand": [r.n_cand for r in res]}
+            for nm, (dt, tail) in names.items():
+                if nm == "PERM" and dd == "0" and lanes == 1 and num_point <= 256:
+                    continue                                   # (host-drawn, one lane: the permutation rides in the kernel arguments)
+                v = hot._view(nm, 0, dt, (lanes, cap) + tail)
+                d[nm] = [v[l, : res[l].n_sel].clone() for l in range(lanes)]
+            vals = hot._view("VALS", 0, torch.float32, (11, lanes, cap))
+            d["VALS"] = [vals[:, l, : res[l].n_sel].clone() for l in range(lanes)]
+            for nm, dt, shp in (("ROT", torch.float64, (lanes, 9)), ("NVALID", torch.int32, (lanes,)), ("POSE64", torch.float64, (lanes, 7)),
+                                ("INFO", torch.float64, (lanes, 4)), ("POSE", torch.float32, (lanes, 7))):
+                d[nm] = [hot._view(nm, 0, dt, shp).clone()]
+            rec.append(d)
+        runs[dd] = (rec, sink.clone())
+        del hot
+    a, b = runs["0"], runs["1"]
+    assert torch.equal(a[1], b[1]) and float(b[1].abs().sum()) > 0
+    for t, (da, db) in enumerate(zip(a[0], b[0])):
+        assert da["n_sel"] == db["n_sel"] and da["n_cand"] == db["n_cand"] and min(da["n_sel"]) > 0, (t, da["n_sel"], db["n_sel"])
+        if num_point == 500:
+            assert max(da["n_cand"]) <= 500                    # fewer candidates than num_point: every candidate is selected, in permuted order
+        for k in db:
+            if k in ("n_sel", "n_cand") or k not in da:
+                continue
+            for l, (x, y) in enumerate(zip(da[k], db[k])):
+                assert torch.equal(x, y), (t, k, l)
+
+
+def test_device_driven_stream_equals_torch_generators(gpu):
+    """A pipelined stream (the driver's run loop: no host wait anywhere) of 3 ragged lanes, device-driven, against the same pipe drawing from
+    `torch.Generator().manual_seed(seed)` on the Python side: keypoints, counts and poses equal frame by frame."""
+    from macvo_amd.pipeline import Camera, FrameInputs, HotPathConfig, NativeHotPath, stack_lanes
+
+    H, W, n_frames, lanes = 240, 320, 30, 3
+    seqs = [synth.make_sequence(8, H, W, C=64, iters=2, seed=400 + l, pool=1, closed_loop=True) for l in range(lanes)]
+    cam = seqs[0][0]
+    seeds = [77, 2 ** 40 + 5, 123456789]
+    one = lambda fr: FrameInputs(**{k: (None if v is None else v.to(gpu)) for k, v in fr.items()})  # noqa: E731
+    pool = [stack_lanes([one(seqs[l][1][t]) for l in range(lanes)]) for t in range(8)]
+    stream = [pool[t % 8] for t in range(n_frames)]
+    outs = []
+    for gens in (seeds, [torch.Generator().manual_seed(int(s)) for s in seeds]):
+        hot = NativeHotPath(Camera(**cam), HotPathConfig(num_point=150), gpu, lanes=lanes, generators=gens)
+        hot.initialize(stream[0])
+        assert hot.device_driven == isinstance(gens[0], int)
+        sink = torch.zeros(n_frames - 1, lanes, 7, device=gpu)
+        rec = []
+        for res in hot.run(stream[1:], pose_sink=sink):
+            hot.sync_pose()
+            rec.append([(r.kp0_uv.clone(), r.n_cand, r.n_sel) for r in res])
+        torch.cuda.synchronize()
+        outs.append((sink.clone(), rec))
+        del hot
+    (sa, ra), (sb, rb) = outs
+    assert len(ra) == n_frames - 1 and torch.equal(sa, sb) and float(sa.abs().sum()) > 0
+    for t in range(n_frames - 1):
+        for l in range(lanes):
+            assert ra[t][l][1:] == rb[t][l][1:] and ra[t][l][1] > 150, (t, l)
+            assert torch.equal(ra[t][l][0], rb[t][l][0]), (t, l)
+
+
+def test_device_driven_run_does_not_wait_for_the_gpu(gpu):
+    """What "device-driven" buys: the host can queue a whole stream while the GPU is still busy with its first frames.  A long stream is enqueued through
+    `run` without touching any result: when `run` returns its last result the driver must not have needed the newest frames' candidate counts — checked
+    by asking how many of the frames' backend events had fired at that moment (a host-drawn pipe has waited for every count but the last `depth`)."""
+    import time
+
+    from macvo_amd.pipeline import Camera, HotPathConfig, NativeHotPath
+
+    cam, frames, _ = synth.make_sequence(8, 480, 640, C=256, iters=12, seed=5, closed_loop=True)
+    ins = _inputs(frames, gpu, static=True)
+    hot = NativeHotPath(Camera(**cam), HotPathConfig(), gpu, generators=[3])
+    hot.initialize(ins[0])
+    for _ in hot.run(ins[1 + k % 7] for k in range(20)):
+        pass
+    torch.cuda.synchronize()
+    assert hot.device_driven
+    n = 60
+    sink = torch.zeros(n, 7, device=gpu)
+    t0 = time.perf_counter()
+    it = hot.run((ins[1 + k % 7] for k in range(n)), pose_sink=sink)
+    res = [next(it) for _ in range(n)]          # every frame enqueued and finished on the host ...
+    t_host = time.perf_counter() - t0
+    done_then = int((sink.abs().sum(dim=1) > 0).sum().item())   # ... (this read synchronises only the default stream: the pipe's streams are non-blocking)
+    for _ in it:
+        pass
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    assert len(res) == n and bool((sink.abs().sum(dim=1) > 0).all())
+    # the host was through well before the GPU: it cannot have waited for per-frame counts
+    assert t_host < 0.8 * t_all or done_then < n - 4, (t_host, t_all, done_then)
