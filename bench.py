@@ -165,7 +165,7 @@ def roofline_of(ms, args, lanes, n_q, C, timed_region_launches, traffic=None):
     common = {"avg_launch_us": round(avg_s * 1e6, 2), "median_launch_us": round(srt[len(srt) // 2] * 1e3, 2), "min_launch_us": round(srt[0] * 1e3, 2),
               "launch_time_note": "HIP-event pair on the GEMM's stream inside the running pipe: the mean (what `achieved` / `frac` use) includes the launches whose "
                                   "workgroups waited for CUs held by the other streams' kernels; rocprofv3's kernel duration for the same command is the committed "
-                                  "profiles/r05c_bench_kernel_stats.csv",
+                                  "profiles/r06_bench_kernel_stats.csv (r05c_* for round 5)",
               "launches": len(ms), "launches_in_timed_region": timed_region_launches,
               "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes}
     prec = getattr(args, "_precision", args.volume_precision)
@@ -177,7 +177,10 @@ def roofline_of(ms, args, lanes, n_q, C, timed_region_launches, traffic=None):
                 "kernel": f"corr_volume_split_stream<{prec}>" if prec in ("bf16x3", "f16x2") else f"{prec} pre-pass + corr_volume_bf16x3_hwc<{int(nprod) // 3 + 1}>",
                 "hbm_write_GBps": round(nbytes / avg_s / 1e9, 1),
                 **common, "executed_flops_per_launch": nprod * flops, "algorithmic_tflops": round(flops / avg_s / 1e12, 2),
+                "frac_algorithmic": round(flops / avg_s / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
                 "algorithmic_vs_fp32_mfma_peak": round(flops / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "frac_note": "frac = EXECUTED 16-bit FLOPs (3 or 6 piece products per fp32 product) / time / peak; frac_algorithmic = SURVEY 8(d)'s algorithmic "
+                             "2 N^2 C B FLOPs / time / the same 2.5 PFLOP/s peak — the figure the round-5 review recomputed (0.10-0.12)",
                 "note": f"achieved = {int(nprod)} 16-bit piece products per algorithmic fp32 product x algorithmic FLOPs / time, against the dense 16-bit "
                         "MFMA peak (2.5 PFLOP/s; with N(0,1) operands the chip's power limit holds a bare v_mfma_f32_32x32x16_bf16 stream at "
                         "~1.89 PFLOP/s = 0.76, profiles/probes/mfma16_probe.*; this kernel runs 1.3x faster on all-zero operands with identical cycle "
@@ -255,6 +258,7 @@ def volume_lookup_parity(ops, frames, cfr, args, n_q, C, dev, picks, make_pipe):
             out["lookup_launches"] += 1
             out["lookup_max_abs_err"] = max(out["lookup_max_abs_err"], float((tok - rtok).abs().max()))
             ok = ok and bool(torch.allclose(tok, rtok, rtol=1e-5, atol=2e-4))
+        hot.close()          # (result objects keep their pipe alive: close it, do not just drop the name — pipeline.NativeHotPath.close)
         del hot, vol
     out["volume_within_bar"] = bool(vol_ok)
     out["within_bar"] = bool(ok and vol_ok)
@@ -310,7 +314,11 @@ def schedule_note(lanes: int) -> str:
 
     depth = int(os.environ.get("MV_PIPE_DEPTH", _lib.load().mv_frame_pipe_default_depth(lanes, 0)))
     alt = lanes <= 2 and os.environ.get("MV_PIPE_LAYOUT", "alt") != "classic" and "MV_PIPE_SELECTOR_ON" not in os.environ
-    return (f"{depth} tracked frames in flight + the volume GEMM one frame ahead; " +
+    dd = os.environ.get("MV_PIPE_DEVICE_DRAW", "1") != "0"
+    head = ("device-driven frames (round 6): a frame's whole launch chain — lookups, selector, backend with the permutation draw inside, solve — is queued by one host "
+            "thread without any wait on the GPU, the volume GEMM one frame ahead, host flow control two finished frames back; " if dd else
+            f"{depth} tracked frames in flight + the volume GEMM one frame ahead (host-drawn permutations: the host waits for each frame's candidate count); ")
+    return (head +
             ("four streams: GEMM | even frames' lookups + selector | odd frames' lookups + selector | backend + solve; GEMM on all but 32 CUs" if alt else
              "four streams: GEMM | lookups + selector | backend | solve" if lanes > 2 else "four streams: GEMM | lookups | selector + backend | solve"))
 
@@ -419,7 +427,7 @@ def kernels_leg(ops, frames, cam, args, dev, volume_roofline, patch_embed, n_q, 
     launch-bound kernel shows up as such), algorithmic bytes / FLOPs exactly as §8(d) defines them, peak from MI355X_MICROARCH.md."""
     import statistics as st
 
-    from tests import synth
+    from tools import synth
 
     H, W = args.height, args.width
     h8, w8 = H // 8, W // 8
@@ -510,7 +518,7 @@ def kernels_leg(ops, frames, cam, args, dev, volume_roofline, patch_embed, n_q, 
         kernel="match_cov_kernel")
     try:
         from oracle import pgo as opgo
-        from tests.test_gpu_backend import _to_batch
+        from tools.synth import pgo_batch as _to_batch
 
         prob, _ = opgo.make_synthetic_problem(n=200, seed=6)
         batch = _to_batch([prob], dev)
@@ -609,7 +617,7 @@ def main():
     from macvo_amd import ops
     from macvo_amd.distributed import gather_tracks
     from macvo_amd.pipeline import Camera, FrameInputs, HotPath, HotPathConfig, NativeHotPath, stack_lanes
-    from tests import synth
+    from tools import synth
 
     if args.volume_precision is None:
         args.volume_precision = ops.default_volume_precision()      # the library's one default (f16x2): bench, plugins and drivers agree
@@ -668,6 +676,8 @@ def main():
             dist.barrier()
 
     last_timeline: dict = {}
+    last_host: dict = {}
+    last_period: dict = {}
 
     def measure(lanes, steps, warmup, seed, with_events, precision=None):
         """W untimed + K timed steps of an L-lane pipe.  Returns (elapsed s, poses, per-launch GEMM ms, launches in region)."""
@@ -712,10 +722,21 @@ def main():
         t0 = time.perf_counter()
         # software-pipelined stream (frame t+1's frontend is queued before frame t's host randperm); K full run_pairs
         trace = [] if os.environ.get("MV_BENCH_TRACE") else None   # host time of every finished step (diagnostics, stderr)
+        h0 = (getattr(hot, "host_issue_s", 0.0), getattr(hot, "host_wait_s", 0.0), getattr(hot, "host_frames", 0))
         for _ in hot.run((batches[(t_idx + k) % args.pool] for k in range(steps)), pose_sink=poses):
             if trace is not None:
                 trace.append(time.perf_counter() - t0)
         t_run = time.perf_counter() - t0
+        last_host.clear()
+        if getattr(hot, "device_driven", False) and hot.host_frames > h0[2]:
+            nf = hot.host_frames - h0[2]
+            last_host.update({"device_driven": True, "host_threads": 1,
+                              "host_issue_us_per_frame": round((hot.host_issue_s - h0[0]) / nf * 1e6, 1),
+                              "host_flow_control_wait_us_per_frame": round((hot.host_wait_s - h0[1]) / nf * 1e6, 1),
+                              "note": "timed pass: host time issuing a frame's launches (enqueue + next GEMM + finish: no wait on the GPU anywhere) and time "
+                                      "blocked in the flow control that keeps the host two finished frames ahead of the GPU (= host slack)"})
+        elif native:
+            last_host.update({"device_driven": False, "host_threads": 2, "run_loop_us_per_frame": round(t_run / steps * 1e6, 1)})
         # the one collective of the job (no-op for N = 1): poses [T,7] + time_ns [T] + T of every rank
         all_poses, _, _ = gather_tracks(poses.reshape(-1, 7), stamps.repeat_interleave(lanes), dist)
         t_gather = time.perf_counter() - t0
@@ -739,6 +760,11 @@ def main():
                 for _ in hot.run(batches[(t_idx + k) % args.pool] for k in range(extra)):
                     pass
             ms = hot.volume_times_ms()
+            starts = hot.volume_starts_ms()[:steps]          # the timed pass itself (not the separate timeline pass below)
+            last_period.clear()
+            if len(starts) >= 8:
+                d = sorted(starts[i + 1] - starts[i] for i in range(len(starts) // 4, len(starts) - 1))
+                last_period.update({"period_us_timed_pass": round(d[len(d) // 2] * 1e3, 1), "gemm_starts_used": len(d)})
             # where a step's time goes, from the HIP events the driver records on its own streams (tools/lane_timeline.py):
             # GEMM start -> next GEMM start = period; the part of it the GEMM stream idles; how far the decoder-side chain lags.
             # Untimed pass over the same stream with all eight events per frame.
@@ -771,6 +797,8 @@ def main():
                         "backend_end_to_pose_apply_us": med([tb[i][2] - tb[i][1] for i in ok]),
                         "pose_apply_plus_solve_us": med([tb[i][3] - tb[i][2] for i in ok]),
                         "gemm_start_to_pose_us": med([tb[i][3] - tl[i][0] for i in ok])})
+        if hasattr(hot, "close"):
+            hot.close()
         del hot
         return elapsed, all_poses, ms, min(steps, len(ms))
 
@@ -794,6 +822,7 @@ def main():
     rank_tracks_finite = [bool(torch.isfinite(main_poses[r]).all() and float(main_poses[r, :, 3:].abs().sum()) > 0) for r in range(main_poses.shape[0])]
     del main_poses
     main_timeline = dict(last_timeline)
+    main_host, main_period = dict(last_host), dict(last_period)
     if vol_events:
         torch.cuda.synchronize()
         ms = [a.elapsed_time(b) for a, b in vol_events[-args.steps:]]
@@ -805,7 +834,7 @@ def main():
     traffic = traffic_file = None
     try:
         if (H, W, C, args.lanes) == (480, 640, 256, 1) and args.feat_dtype == "f32" and args.volume_precision in ("bf16x3", "f16x2"):
-            path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_corr_volume_split_{args.volume_precision}.json") for r in (5, 4, 3))
+            path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_corr_volume_split_{args.volume_precision}.json") for r in (6, 5, 4, 3))
                          if os.path.exists(q)), "")
             if os.path.exists(path):
                 traffic_file = os.path.basename(path)
@@ -944,6 +973,7 @@ def main():
                       "rte_vs_truth": {"hip": metrics.rte(tru, est)["mean"], "oracle": metrics.rte(tru, orc)["mean"]},
                       "formula": "evo RPE translation part, delta = 1 frame (Evaluation/MetricsSeq.py:9-16)",
                       "within_north_star": bool(kp_same == n_par and max(d[0] for d in diffs) <= 1e-4 and max(d[1] for d in diffs) <= 1e-4)}
+            hot.close()       # (`r` of the loop above still references the pipe: without this its four HIP streams linger beside the next legs' pipes)
             del hot
             # ... and the kernels the line times: volume rows vs fp64 einsum, every lookup's tokens vs the oracle, at the line's precision
             try:
@@ -1077,13 +1107,15 @@ def main():
         except Exception as e:  # noqa: BLE001 - a measurement leg must not take the benchmark line down
             end_to_end = {"error": repr(e)[:300]}
     ranks_seen, rank_devices, rank_cores, rank_pose_ok = 1, [torch.cuda.current_device()], [my_cores], [True]
+    rank_host = [main_host or None]
     if dist is not None:
         ranks_seen = dist.get_world_size()
         got = [None] * ranks_seen
-        dist.all_gather_object(got, {"rank": rank, "device": torch.cuda.current_device(), "cores": my_cores, "steps_done": args.steps})
+        dist.all_gather_object(got, {"rank": rank, "device": torch.cuda.current_device(), "cores": my_cores, "steps_done": args.steps, "host": main_host or None})
         got = sorted(got, key=lambda d: d["rank"])
         rank_devices = [int(d["device"]) for d in got]
         rank_cores = [d["cores"] for d in got]
+        rank_host = [d.get("host") for d in got]
     if rank == 0:
         total_frames = world * args.steps * args.lanes
         cfgname = {1: "configs[1]", 32: "configs[4]"}.get(args.lanes, f"{args.lanes}-lane variant of configs[1]")
@@ -1098,7 +1130,15 @@ def main():
             "rank_core_slices": [[c[0], c[-1]] if c else None for c in rank_cores],
             "rank_pose_tracks_finite": rank_tracks_finite,
             "share_gpu_test_mode": bool(args.share_gpu),
-            "host_threads_per_rank": "2 busy (caller + backend launch thread) + a torch pool of %d" % torch.get_num_threads(),
+            "host_threads_per_rank": ("1 busy (device-driven frames: no launch thread)" if main_host.get("device_driven") else "2 busy (caller + backend launch thread)") +
+                                     " + a torch pool of %d" % torch.get_num_threads(),
+            "hot_path_only": True,
+            "hot_path_only_note": "value = the SURVEY 8 hot path with the learned FlowFormer layers' outputs (feature maps, per-iteration coordinates, flow / "
+                                  "covariance maps) resident in HBM; north_star's >= 200 frames/s END TO END is the end_to_end leg below and is NOT met",
+            "end_to_end_fps": ((end_to_end or {}).get("hooked") or {}).get("fps") if isinstance(end_to_end, dict) else None,
+            "period_us_timed_pass": main_period.get("period_us_timed_pass"),
+            "host": main_host or None,
+            "rank_host_issue_us_per_frame": [None if not h else h.get("host_issue_us_per_frame", h.get("run_loop_us_per_frame")) for h in rank_host],
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -1121,8 +1161,11 @@ def main():
                        "lanes": args.lanes, "feature_dtype": args.feat_dtype, "feature_layout": args.layout,
                        "volume_precision": args.volume_precision, "hip_graphs": use_graphs, "host_driver": args.driver, "backend_launch_thread": (os.environ.get("MV_PIPE_ASYNC_BACKEND", "1") != "0") if args.driver == "native" else False,
                        "keypoint_permutations": ("torch.randperm on the Python side (global CPU generator)" if (args.host_randperm or not native) else
-                                                 "driver-native MT19937 + partial Fisher-Yates seeded like torch.manual_seed (bit-identical to torch.randperm: "
-                                                 "the parity block runs this mechanism against the oracle and the reference loop on torch's global generator)"),
+                                                 ("drawn ON THE GPU inside the backend's front launch: device-resident MT19937 (one-step block twist) + hashed partial "
+                                                  "Fisher-Yates, candidate count read from device memory (csrc/randperm_dev.h) — " if main_host.get("device_driven") else
+                                                  "driver-native MT19937 + partial Fisher-Yates on the host — ") +
+                                                 "seeded like torch.manual_seed, bit-identical to torch.randperm: the parity block runs this mechanism against the "
+                                                 "oracle and the reference loop on torch's global generator"),
                        "clock_ramp_s": 0.0 if args.no_ramp else RAMP_SECONDS,
                        "frame_schedule": schedule_note(args.lanes) if native else "python loop over the per-op entry points",
                        "excluded": "learned FlowFormer layers (source + weights absent from the reference checkout)",
@@ -1138,8 +1181,8 @@ def main():
             "kernels": kernels,
             "plugin_path": plugin_path,
             "end_to_end": end_to_end,
-            "multi_gpu_note": "no scaling curve has been measured by the builder (1-GPU boxes only): N > 1 is covered by a world-2 gloo test, a world-1 RCCL test and a "
-                              "2-rank test sharing one GPU (tests/test_gpu_bench.py)",
+            "multi_gpu_note": "no scaling curve has been measured by the builder (1-GPU boxes only): N > 1 is covered by a world-2 gloo test, a world-1 RCCL test and "
+                              "2- and 8-rank rehearsals sharing one GPU (tests/test_gpu_bench.py)",
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -392,8 +392,9 @@ int mv_pgo_solve(int nprob, const int32_t* offsets, int graph_type, const float*
  *       filter_flags < 0: `valid` is an input as in mv_pgo_solve;
  *   (2) rotates the first n_live[prob] rows into the world frame with the problem's init_pose — pos_Tw = T p_cam (fp32 PyPose SE3 Act), cov_Tw = R cov_Tc
  *       R^T (fp64), out_rot [nprob, 9] = R — mv_pose_apply_lanes' arithmetic, written to pos_Tw / cov_Tw (cov_Tc / cov_Tw may both be NULL).
- * Same bits as the separate kernels.  pose_sink (or NULL): a second fp32 copy of the optimised poses [nprob, 7].  nprob <= MV_MAX_LANES; offsets must be
- * the static table {0, cap, 2 cap, ...} when the filters are folded in.  n_live: host int32 [nprob]. */
+ * Same bits as the separate kernels.  pose_sink (or NULL): a second fp32 copy of the optimised poses [nprob, 7].  nprob <= MV_MAX_LANES.  The filters address a problem's
+ * rows through `offsets` like the rest of the launch (rows [offsets[l], offsets[l + 1]), the value table's row stride = offsets[nprob]); the frame driver passes
+ * the static table {0, cap, 2 cap, ...}.  n_live: host int32 [nprob], n_live[l] <= offsets[l + 1] - offsets[l]. */
 int mv_pgo_solve_posed(int nprob, const int32_t* offsets, const int32_t* n_live, int cap, int graph_type, const float* init_pose,
                        const float* intrinsics, const float* baseline, const float* pos_Tc, const double* cov_Tc,
                        float* pos_Tw, double* cov_Tw, double* out_rot, const float* pixel2_uv, const float* pixel2_d,
@@ -771,6 +772,8 @@ int mv_frame_pipe_sync(mvFramePipe* p, mvStream_t stream, int block_host);
  * stream they run on (0 = off; restarts the count), and read the elapsed milliseconds back (blocks on that stream) */
 int mv_frame_pipe_time_volume(mvFramePipe* p, int max_launches);
 int mv_frame_pipe_volume_times(mvFramePipe* p, float* ms, int cap, int* n);
+/* start of each timed GEMM, ms since the first timed one (same events) */
+int mv_frame_pipe_volume_starts(mvFramePipe* p, float* ms, int cap, int* n);
 /* on = 0: a timed frame records ONLY the event pair around its volume GEMM (what the roofline needs), not the six timeline events on the other three
  * streams — each is a barrier packet on a stream whose launch chain bounds a one-lane pipe; mv_frame_pipe_timeline[_backend] then report no frames.
  * Default 1.  bench.py times the contract's K steps with 0 and collects the timeline in a separate untimed pass. */

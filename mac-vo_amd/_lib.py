@@ -182,6 +182,7 @@ SIGNATURES = {
     "mv_frame_pipe_sync": (C.c_int, [_P, _P, C.c_int]),
     "mv_frame_pipe_time_volume": (C.c_int, [_P, C.c_int]),
     "mv_frame_pipe_volume_times": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
+    "mv_frame_pipe_volume_starts": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     "mv_frame_pipe_time_detail": (C.c_int, [_P, C.c_int]),
     "mv_randperm_heads": (C.c_int, [C.c_uint64, _P, C.c_int, C.c_int, _P]),
     "mv_frame_pipe_device_draw": (C.c_int, [_P]),

@@ -39,6 +39,9 @@
 #include <new>
 #include <stdlib.h>
 #include <string.h>
+#if defined(__linux__)
+#include <sched.h>
+#endif
 
 #define MV_HIP(call)                                   \
     do {                                               \
@@ -224,6 +227,7 @@ struct mvFramePipe {
     // H2D permutation: enqueue + finish of a frame are a fixed chain of launches.  Two state buffers: finish g reads rp_state[g & 1], writes rp_state[(g + 1) & 1].
     uint32_t* rp_state[2];   // [lanes, mv_randperm_state_words()]
     int dev_draw;
+    long last_backend_frame = -1;   // frame index of the newest backend issued with keypoints (launch-thread / inline issuer only)
     // optional timing of the dominant kernel (bench.py roofline): event pairs around each volume GEMM on its stream
     int vol_timed[MAX_VOL];      // timing slot of the GEMM that filled each volume buffer (-1: not timed)
     std::vector<hipEvent_t> tv0, tv1, tv2, tv3;   // GEMM start / end, last lookup done, selector done (timeline hook)
@@ -252,6 +256,7 @@ struct mvFramePipe {
     double spin_us;         // how long the launch thread spins for the next job before it sleeps (MV_PIPE_LAUNCH_SPIN_US, default 250)
     int host_stats;         // MV_PIPE_HOST_STATS=1: mean host latencies of the selector-count -> backend-launch chain, printed by destroy
     double st_n = 0, st_count_to_submit = 0, st_submit_to_pick = 0, st_pick_to_issued = 0, st_wait = 0;
+    double st_enq = 0, st_enq_lookups = 0, st_enq_seg = 0, st_vol = 0, st_fin = 0, st_calls = 0;   // us inside enqueue (its lookups / its selector segment), enqueue_volume, finish_device
     bool stop;
     int async_rc;           // first error of an asynchronously issued job, reported by the next call
 };
@@ -263,6 +268,20 @@ static int wait_if_pending(hipStream_t s, hipEvent_t e) {
     if (q == hipSuccess) return MV_OK;
     if (q != hipErrorNotReady) return MV_ERR_LAUNCH;
     return hipStreamWaitEvent(s, e, 0) == hipSuccess ? MV_OK : MV_ERR_LAUNCH;
+}
+
+static int affinity_cores() {
+#if defined(__linux__)
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) return CPU_COUNT(&set);
+#endif
+    const unsigned n = std::thread::hardware_concurrency();
+    return n ? (int)n : 1;
+}
+
+static inline double now_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 #define MV_ASYNC_DEFAULT(p) (1)   // measured (640x480, f16x2 volume): one lane 6.01 k vs 5.26 k frames/s, 32 lanes 7.56 k vs 7.54 k
@@ -420,6 +439,10 @@ extern "C" void mv_frame_pipe_destroy(mvFramePipe* p) {
         p->cv_job.notify_all();
         p->worker.join();   // (drains the queue first)
     }
+    if (p->host_stats && p->st_calls > 0)
+        fprintf(stderr, "[mv_frame_pipe host stats] per frame over %.0f device-driven frames: enqueue %.1f us (lookups %.1f, selector segment %.1f), enqueue_volume %.1f us, "
+                        "finish_device %.1f us\n", p->st_calls, p->st_enq / p->st_calls, p->st_enq_lookups / p->st_calls, p->st_enq_seg / p->st_calls,
+                p->st_vol / p->st_calls, p->st_fin / p->st_calls);
     if (p->host_stats && p->st_n > 0)
         fprintf(stderr, "[mv_frame_pipe host stats] finishes %.0f: wait for the candidate count %.1f us, count seen -> job queued %.1f us, queued -> picked up by the "
                         "launch thread %.1f us, picked up -> every launch issued %.1f us (means per frame)\n",
@@ -629,7 +652,12 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
         p->async_backend = want > 0 ? 1 : 0;
         p->async_explicit = (cfg->async_backend || e) ? 1 : 0;
         if (hipGetDevice(&p->device) != hipSuccess) p->async_backend = 0;
-        { const char* e3 = getenv("MV_PIPE_LAUNCH_SPIN_US"); p->spin_us = e3 ? atof(e3) : 250.0; }
+        {
+            // a spinning launch thread needs a core of its own beside the caller's (and Python's): with fewer than three in the process' affinity mask it
+            // sleeps on the condition variable instead (per-rank core slices of bench --gpus N, 1-2 core hosts)
+            const char* e3 = getenv("MV_PIPE_LAUNCH_SPIN_US");
+            p->spin_us = e3 ? atof(e3) : (affinity_cores() >= 3 ? 250.0 : 0.0);
+        }
         { const char* e4 = getenv("MV_PIPE_HOST_STATS"); p->host_stats = e4 ? atoi(e4) : 0; }
         if (p->async_backend) p->worker = std::thread(launch_thread_main, p);
     }
@@ -713,7 +741,9 @@ extern "C" int mv_frame_pipe_enqueue_volume(mvFramePipe* p, const mvFrameInputs*
     MV_CHECK_ARG(p->n_vol == p->n_enq);                 // at most one GEMM ahead of its frame
     MV_CHECK_ARG(p->lookups_on_main);                   // the alternative layout keeps the lookups behind the GEMM on its stream
     // the volume buffer of frame n_vol was last read by the lookups of frame n_vol - 2: their event exists (frame enqueued)
+    const double t_hs = p->host_stats ? now_us() : 0.0;
     MV_TRY(issue_volume(p, in, in_stream));
+    if (p->host_stats) p->st_vol += now_us() - t_hs;
     // MV_PIPE_SELECTOR_ON=vol: the newest enqueued frame's selector segment goes behind this GEMM on the GEMM's stream — it needs that
     // frame's lookups, which finish about when this GEMM does, and then runs in the gap the GEMM stream idles in anyway, alone on the chip
     return p->sel_on_back == 3 ? flush_deferred(p) : MV_OK;
@@ -839,6 +869,7 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
     MV_CHECK_ARG(!with_selector || p->newest_maps >= 0);   // a tracked frame needs the previous frame's maps
     MV_CHECK_ARG(!with_selector || (int)p->pending.size() < MAX_PENDING);  // slot rotation covers MAX_PENDING tracked frames in flight
     const int B = c.pairs;
+    const double t_hs0 = p->host_stats ? now_us() : 0.0;
     MV_TRY(flush_deferred(p));   // (the previous frame's selector segment, had nobody asked for it yet: frames stay in order)
 
     // ---- volume GEMM (own stream) unless mv_frame_pipe_enqueue_volume already issued it
@@ -875,6 +906,7 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
         p->vol_free_valid[kv] = false;                         // vol[k] / tok are only touched on s_vol: stream order suffices
     }
 
+    const double t_hs1 = p->host_stats ? now_us() : 0.0;
     SelSeg d{*in, f, k, m, ti, p->newest_maps, timed, with_selector != 0, up,
              p->n_fin - MAX_PENDING + (long)p->pending.size()};
     if (p->sel_on_back) MV_HIP(hipEventRecord(p->e_lk[k], s));   // the segment continues on another stream behind the last lookup
@@ -892,6 +924,12 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
     if (with_selector) p->pending.push_back(Pending{m, p->newest_maps, k, true, ti, -1, f});
     p->newest_maps = m;
     p->n_enq = f + 1;
+    if (p->host_stats) {
+        const double t_hs2 = now_us();
+        p->st_enq += t_hs2 - t_hs0;
+        p->st_enq_lookups += t_hs1 - t_hs0;
+        p->st_enq_seg += t_hs2 - t_hs1;
+    }
     return MV_OK;
 }
 
@@ -1046,7 +1084,7 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
     // Slot reuse.  This backend slot's tables were last read by the solve of frame g - 2 (side stream) and by whoever looked at
     // that frame's result views: the former has its event, the latter the event of mv_frame_pipe_release (a consumer that
     // reads views asynchronously on its own stream calls it before it asks for the next frame).
-    if (p->solved_valid[k]) MV_TRY(wait_if_pending(s, p->e_solved[k]));
+    if (p->solved_valid[k] && s != p->s_side) MV_TRY(wait_if_pending(s, p->e_solved[k]));   // (alt layout: backend and solve share one in-order stream)
     if (p->release_valid) MV_TRY(wait_if_pending(s, p->e_release));
     // permutations [lanes, cap] -> pinned slot -> device (ONE copy; rows beyond a lane's n_sel are never read)
     const int ps = (int)(g % N_PERM);
@@ -1058,7 +1096,12 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
     MV_TRY(wait_if_pending(s, p->e_cand[pd.cand]));   // fired: the host has just read this frame's count
     // alt layout: the previous frame's maps (gathers below) were written by a segment on the other decoder-side stream, which e_cand does not cover.
     // (Slot f - 1 of e_seg is re-recorded by frame f - 1 + N_INEV, far beyond the frames in flight.)
-    if (p->alt && pd.f > 0) MV_TRY(wait_if_pending(s, p->e_seg[(pd.f - 1) % N_INEV]));
+    // ... unless the previous frame's backend ran on THIS stream and waited for that segment itself (its e_cand is recorded at the same point): stream order
+    // then covers it, and a pending cross-queue barrier less sits in front of the backend (device-driven frames are issued long before their selector is done;
+    // every unsatisfied barrier at the head of a queue costs the other queues dispatch latency, profiles/r06_device_draw_ab.log)
+    const bool prev_here = p->alt && p->last_backend_frame == pd.f - 1;
+    if (p->alt && pd.f > 0 && !prev_here) MV_TRY(wait_if_pending(s, p->e_seg[(pd.f - 1) % N_INEV]));
+    p->last_backend_frame = pd.f;
     const int ti = pd.ti;
     if (ti >= 0) MV_HIP(hipEventRecord(p->tv4[ti], s));
     const bool perm_in_args = L == 1 && n_max <= 256;   // one lane: the permutation rides in the kernel arguments (no pinned staging copy, no H2D node)
@@ -1164,9 +1207,6 @@ static const int64_t* draw_perms(mvFramePipe* p, const FinishJob& j) {
 }
 
 // ------------------------------------------------------------------------------------------------ backend launch thread
-static inline double now_us() {
-    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
 
 static void launch_thread_main(mvFramePipe* p) {
     (void)hipSetDevice(p->device);
@@ -1180,7 +1220,11 @@ static void launch_thread_main(mvFramePipe* p) {
             const double t_end = now_us() + p->spin_us;
             int it = 0;
             while (p->n_submitted.load(std::memory_order_acquire) == taken && !p->stop_flag.load(std::memory_order_relaxed)) {
+#if defined(__x86_64__) || defined(__i386__)
                 __builtin_ia32_pause();
+#else
+                std::this_thread::yield();
+#endif
                 if ((++it & 255) == 0 && now_us() > t_end) break;
             }
         }
@@ -1273,7 +1317,9 @@ extern "C" int mv_frame_pipe_finish_device(mvFramePipe* p, float* pose_sink) {
     int32_t nsel[MV_MAX_LANES];
     for (int l = 0; l < p->lanes; ++l) nsel[l] = p->c.num_point;   // upper bound: rows beyond the live ones are masked by `valid`
     MV_TRY(finish_host(p, nsel, pose_sink, j));
-    return submit_or_issue(p, j, nullptr);
+    const int rc = submit_or_issue(p, j, nullptr);
+    if (p->host_stats) { p->st_fin += now_us() - j.t_count; p->st_calls += 1; }
+    return rc;
 }
 
 // candidate / selected-keypoint counts of the `age`-th newest FINISHED frame (age 0 or 1), read back from the frame's backend slot: blocks until that
@@ -1488,6 +1534,18 @@ extern "C" int mv_frame_pipe_volume_times(mvFramePipe* p, float* ms, int cap, in
     MV_HIP(hipStreamSynchronize(p->s_vol));
     const int m = p->n_timed < cap ? p->n_timed : cap;
     for (int i = 0; i < m; ++i) MV_HIP(hipEventElapsedTime(&ms[i], p->tv0[i], p->tv1[i]));
+    *n = m;
+    return MV_OK;
+}
+
+// ... and when each timed GEMM STARTED, ms since the first one (the steady-state period of the very pass whose wall time is the bench line's `value`:
+// only the event pairs around the GEMM are recorded in that pass)
+extern "C" int mv_frame_pipe_volume_starts(mvFramePipe* p, float* ms, int cap, int* n) {
+    MV_CHECK_ARG(p && n && cap >= 0 && (cap == 0 || ms));
+    MV_TRY(flush_jobs(p));
+    MV_HIP(hipStreamSynchronize(p->s_vol));
+    const int m = p->n_timed < cap ? p->n_timed : cap;
+    for (int i = 0; i < m; ++i) MV_HIP(hipEventElapsedTime(&ms[i], p->tv0[0], p->tv0[i]));
     *n = m;
     return MV_OK;
 }

@@ -6,21 +6,18 @@
 #include <math.h>
 
 // the observation filters of one pipeline lane, run by one whole workgroup (obs_filter_kernel: blockIdx.x = lane; pgo_solve_kernel's prologue: the lane's solve workgroup)
-__device__ __forceinline__ void obs_filter_body(const uint8_t* inbound, const double* cov1, const double* cov2, const float* vals, int flags,
-                                                float min_depth, float max_depth, int cap, int N, int lane, int lanes, uint8_t* valid,
+__device__ __forceinline__ void obs_filter_rows(const uint8_t* inbound, const double* cov1, const double* cov2, const float* vals, int flags,
+                                                float min_depth, float max_depth, size_t row0, int cap, int N, size_t vs, uint8_t* valid,
                                                 int32_t* count) {
-    // one workgroup per lane: N <= a few thousand observations.  Tables are [lanes, ., cap]; rows in
-    // [n_live, cap) are written as invalid so that a capacity-strided solve (mv_pgo_solve with static offsets) skips them.
+    // one workgroup per lane: N <= a few thousand observations.  The lane's rows are [row0, row0 + cap) of every table (`vals`: SoA [11, vs], vs = rows of
+    // all lanes); rows in [N, cap) are written as invalid so that a capacity-strided solve (mv_pgo_solve with static offsets) skips them.
     {
-        const size_t ln = (size_t)lane * cap;
-        if (inbound) inbound += ln;
-        if (cov1) cov1 += 9 * ln;
-        if (cov2) cov2 += 9 * ln;
-        if (vals) vals += ln;   // SoA table [11, lanes, cap]
-        valid += ln;
-        count += lane;
+        if (inbound) inbound += row0;
+        if (cov1) cov1 += 9 * row0;
+        if (cov2) cov2 += 9 * row0;
+        if (vals) vals += row0;
+        valid += row0;
     }
-    const size_t vs = (size_t)lanes * cap;
     __shared__ int total;
     if (threadIdx.x == 0) total = 0;
     // LikelyFrontOfCamFilter: if ANY pixel1_d_cov is the -1 placeholder the filter lets every row pass (:133-136)
@@ -55,3 +52,9 @@ __device__ __forceinline__ void obs_filter_body(const uint8_t* inbound, const do
     if (threadIdx.x == 0) count[0] = total;
 }
 
+// ... addressed by lane: tables [lanes, cap, .], lane l owns rows [l cap, (l + 1) cap) (obs_filter_kernel)
+__device__ __forceinline__ void obs_filter_body(const uint8_t* inbound, const double* cov1, const double* cov2, const float* vals, int flags,
+                                                float min_depth, float max_depth, int cap, int N, int lane, int lanes, uint8_t* valid,
+                                                int32_t* count) {
+    obs_filter_rows(inbound, cov1, cov2, vals, flags, min_depth, max_depth, (size_t)lane * cap, cap, N, (size_t)lanes * cap, valid, count + lane);
+}

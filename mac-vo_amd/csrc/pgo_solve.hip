@@ -212,8 +212,10 @@ __global__ __launch_bounds__(64 * NW) void pgo_solve_kernel(PgoArgs a, mvLMParam
 
     const int live_rows = a.live_dev ? a.live_dev[(size_t)prob * a.live_stride] : a.apply_live[prob < MV_MAX_LANES ? prob : 0];
     if (a.valid_out) {      // mv_pgo_solve_posed: the lane's observation filters (obs_filter_kernel's body; PGO_THREADS == 256), then ...
-        obs_filter_body(a.filter_inbound, a.apply_cov_Tc, a.obs2_covTc, a.filter_vals, a.filter_flags, a.filter_min_depth, a.filter_max_depth,
-                        a.filter_cap, live_rows, prob, gridDim.x, a.valid_out, a.count_out);
+        // (rows addressed through the SAME offsets table the pose-apply and the solve use — ADVICE r5: a caller with compact offsets used to get the filters of
+        // rows prob * cap; the value table's row stride is the total row count offsets[nprob])
+        obs_filter_rows(a.filter_inbound, a.apply_cov_Tc, a.obs2_covTc, a.filter_vals, a.filter_flags, a.filter_min_depth, a.filter_max_depth, (size_t)beg,
+                        npts, live_rows < npts ? live_rows : npts, (size_t)a.offsets[gridDim.x], a.valid_out, a.count_out + prob);
         __threadfence_block();
         __syncthreads();
     }

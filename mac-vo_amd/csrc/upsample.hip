@@ -50,8 +50,11 @@ template <typename T, int PX> struct PixVec { T v[PX]; };
 // kernel VALU-bound (1238 instructions per wave for 54 loads).  Here: t = x log2(e) with its rounding error recovered by one fma
 // (lo = fma(x, L2E, -t) + x * (log2(e) - L2E)), 2^t by the hardware's v_exp_f32 (1 ulp over its whole range), 2^lo = 1 + lo ln 2 to
 // first order (|lo| < 2^-17 for |x| < 128: the dropped term is < 2^-36): ~1.5 ulp, 6 instructions.
+// x = -inf (an fp16 mask head that overflowed under autocast) or x log2(e) overflowing would make `lo` inf - inf = NaN where expf / torch.softmax give the
+// tap weight 0: arguments below -126 are clamped there — 2^(-126 log2 e) is 0 in fp32 as well; a NaN argument stays NaN (compare + select, not max).
 __device__ __forceinline__ float exp_nonpos(float x) {
     const float L2E = 1.44269502f, L2E_LO = 1.92596303e-8f, LN2 = 0.693147182f;
+    x = x < -126.f ? -126.f : x;
     const float t = x * L2E;
     const float lo = __builtin_fmaf(x, L2E, -t) + x * L2E_LO;
     const float e = __builtin_amdgcn_exp2f(t);

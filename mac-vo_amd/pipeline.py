@@ -22,6 +22,7 @@ The only host synchronisation per frame is the selector's candidate count (neede
 from __future__ import annotations
 
 import os
+import time
 from dataclasses import dataclass, field
 
 import torch
@@ -604,13 +605,24 @@ class NativeHotPath:
             # the host draw).  Same keypoints, same poses (tests/test_gpu_lanes.py).
             self.device_driven = bool(lib.mv_frame_pipe_device_draw(pipe))
         self._counts_cache: dict = {}
+        self.host_issue_s = self.host_wait_s = 0.0
+        self.host_frames = 0
         if self._init_pose is not None:
             self._set_pose(self._init_pose)
 
-    def __del__(self):
+    def close(self) -> None:
+        """Destroy the native pipe NOW (drains its streams, frees its HIP streams / events; the arena goes back to torch's allocator).  Result objects keep a
+        reference to their pipe, so dropping the last NAME of a pipe does not destroy it while any result of it is alive — and a pipe that lingers keeps its four
+        HIP streams: the next pipe's streams then share hardware queues with them (measured: a 32-lane pipe at 6.3 k instead of 7.8 k frames/s behind a lingering
+        one-lane pipe, profiles/probes/r6_queue_history.py).  Views handed out earlier become invalid."""
         if getattr(self, "_pipe", None):
             self._lib.mv_frame_pipe_destroy(self._pipe)
             self._pipe = None
+            self._views.clear()
+            self._arena = None
+
+    def __del__(self):
+        self.close()
 
     def _set_pose(self, pose: torch.Tensor) -> None:
         host = pose.detach().to("cpu", torch.float32).reshape(-1, 7)
@@ -621,6 +633,8 @@ class NativeHotPath:
         ops.L.check(self._lib.mv_frame_pipe_set_pose(self._pipe, host.data_ptr()), "mv_frame_pipe_set_pose")
 
     def _view(self, name: str, age: int, dtype: torch.dtype, shape: tuple) -> torch.Tensor:
+        if self._pipe is None:
+            raise ops.L.MacvoHipError("this pipe has been closed (or was never created): its buffers are gone")
         ops.L.check(self._lib.mv_frame_pipe_buffer(self._pipe, ops.L.FB[name], age, ops.C.byref(self._ptr),
                                                    ops.C.byref(self._cnt)), f"mv_frame_pipe_buffer({name})")
         key = (self._ptr.value, dtype, shape)
@@ -881,6 +895,14 @@ class NativeHotPath:
         ops.L.check(self._lib.mv_frame_pipe_volume_times(self._pipe, buf, cap, ops.C.byref(n)), "mv_frame_pipe_volume_times")
         return list(buf[: n.value])
 
+    def volume_starts_ms(self) -> list:
+        """Start of each timed GEMM, ms since the first timed one."""
+        cap = 1 << 16
+        buf = (ops.C.c_float * cap)()
+        n = ops.C.c_int(0)
+        ops.L.check(self._lib.mv_frame_pipe_volume_starts(self._pipe, buf, cap, ops.C.byref(n)), "mv_frame_pipe_volume_starts")
+        return list(buf[: n.value])
+
     def timeline_ms(self) -> list:
         """[(GEMM start, GEMM end, last lookup done, selector done)] per timed frame, ms since the first timed GEMM start."""
         cap = 1 << 14
@@ -917,16 +939,25 @@ class NativeHotPath:
             # ... and by `lag`: the host stays at most that many finished frames ahead of the GPU's front launches (flow control on an event two frames old, not a
             # wait on the critical chain).  Measured at 640x480 (profiles/r06_device_draw_ab.log): lag 0 / 1 / 2 / 3 / 4 / 6 / unbounded = 4.13 / 6.01 / 6.51 / 6.46 / 6.34 /
             # 6.24 / 4.07 k frames/s — with hundreds of frames queued the same kernels take 1.6x as long (deep queues of cross-queue barriers), so the default is 2.
+            # (Also measured and dropped: flow control on the SELECTOR's event instead of the front launch's — 30 us earlier, i.e. deeper: 5.0 k instead of 5.4 k on
+            # the 20-step line — and the host-drawn frame's order, a frame finished only once its selector is done: 5.0 k / 5.9-6.4 k at 300 steps.)
             lag = int(os.environ.get("MV_PIPE_DD_AHEAD", "2"))
+            clock = time.perf_counter
             while nxt is not None:
+                t0 = clock()
                 self.enqueue_frontend(nxt)
                 nxt = next(it, None)
                 if self._volume_ahead and nxt is not None:
                     self.enqueue_volume(nxt)
                 res = self.finish(None, None if pose_sink is None else pose_sink[i])
+                t1 = clock()
                 i += 1
                 if lag >= 0:
                     ops.L.check(self._lib.mv_frame_pipe_wait_finished(self._pipe, lag), "mv_frame_pipe_wait_finished")
+                # host accounting (bench.py `host_us_per_frame`): time spent issuing a frame vs time spent in the flow-control wait (= ahead of the GPU)
+                self.host_issue_s += t1 - t0
+                self.host_wait_s += clock() - t1
+                self.host_frames += 1
                 yield res
             self.sync_all()
             return

@@ -555,7 +555,15 @@ class _FusedProjForward:
             operand = "f16"
         else:
             return layers(self.proj, x)
-        return ops.cost_patch_embed(x, self.repack(operand))    # result in x.dtype, as Conv2d returns it
+        if x.data_ptr() % 16 or not x.is_contiguous():          # (a sliced / offset view: the kernel wants 16-byte aligned slices)
+            return layers(self.proj, x)
+        try:
+            out = ops.cost_patch_embed(x, self.repack(operand))  # result in x.dtype, as Conv2d returns it outside autocast
+        except ops.L.MacvoHipError:                              # anything the kernel refuses falls through to the layers, as documented
+            return layers(self.proj, x)
+        if torch.is_autocast_enabled():                          # ... and in the autocast dtype under autocast, as the Conv2d stack would
+            out = out.to(torch.get_autocast_gpu_dtype())
+        return out
 
 
 def install_flowformer_hooks(model, volume_precision: str | None = None, fuse_patch_embed: bool | None = None) -> list[str]:

@@ -260,23 +260,7 @@ def test_frontend_epilogue_and_track(gpu):
 
 
 # ------------------------------------------------------------------------------- PGO
-def _to_batch(probs, dev):
-    from macvo_amd import ops
-
-    off = [0]
-    for p in probs:
-        off.append(off[-1] + p.pos_Tw.shape[0])
-    cat = lambda f: torch.cat([f(p) for p in probs]).contiguous().to(dev)  # noqa: E731
-    return ops.PGOBatch(
-        offsets=torch.tensor(off, dtype=torch.int32, device=dev),
-        init_pose=torch.stack([p.init_pose for p in probs]).to(dev),
-        intrinsics=torch.stack([torch.stack([p.K[0, 0], p.K[1, 1], p.K[0, 2], p.K[1, 2]]) for p in probs]).to(dev),
-        baseline=torch.tensor([p.baseline for p in probs], dtype=torch.float32, device=dev),
-        pos_Tw=cat(lambda p: p.pos_Tw), pixel2_uv=cat(lambda p: p.pixel2_uv), cov_Tw=cat(lambda p: p.cov_Tw),
-        pixel2_d=cat(lambda p: p.pixel2_d.squeeze(-1)), pixel2_disp=cat(lambda p: p.pixel2_disp.squeeze(-1)),
-        pixel2_disp_cov=cat(lambda p: p.pixel2_disp_cov.squeeze(-1)), pixel2_uv_cov=cat(lambda p: p.pixel2_uv_cov),
-        obs2_covTc=cat(lambda p: p.obs2_covTc),
-    )
+from tools.synth import pgo_batch as _to_batch  # noqa: E402  (the tests keep the old name)
 
 
 @pytest.mark.parametrize("graph", ["disp", "reproj", "icp"])

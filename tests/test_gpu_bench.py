@@ -82,6 +82,28 @@ def test_bench_two_ranks_sharing_the_gpu(gpu):
 
 
 @pytest.mark.gpu
+def test_bench_eight_ranks_sharing_the_gpu(gpu):
+    """VERDICT r5 next #7 — the 8-rank rehearsal one GPU allows: ``bench.py --gpus 8 --share-gpu`` = eight ranks under ``torch.distributed.run`` exactly as the
+    driver launches ``--gpus 8`` (rendezvous on 127.0.0.1, per-rank core slices, OMP_NUM_THREADS), eight arenas and eight frame drivers on device 0, the
+    timed region's collectives (barrier, two-phase gather_tracks of eight device tracks, all_reduce(MAX)) across eight real processes over gloo.  Asserts:
+    eight disjoint core slices, eight finite tracks, one busy host thread per rank with its issue time per frame in the line.  NOT a scaling measurement."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-gpu", "--steps", "12", "--warmup", "3", "--no-cpu-baseline", "--no-kernel-events"] + QUICK
+    d = _line(subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT))
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["rank_devices"] == [0] * 8 and d["share_gpu_test_mode"] is True
+    assert d["rank_pose_tracks_finite"] == [True] * 8
+    assert d["value"] > 0 and d["steps"] == 12 and d["scaling"] == "weak"
+    ncores = len(os.sched_getaffinity(0))
+    sl = d["rank_core_slices"]
+    if ncores >= 16:
+        assert all(x is not None for x in sl) and all(sl[i][1] < sl[i + 1][0] for i in range(7)), sl
+        assert d["host_cores_per_rank"] == ncores // 8
+    hu = d["rank_host_issue_us_per_frame"]
+    assert len(hu) == 8 and all(h is not None and 0 < h < 5000 for h in hu), hu
+    assert d["host"]["device_driven"] is True and d["host"]["host_threads"] == 1
+    assert "no scaling curve" in d["multi_gpu_note"]
+
+
+@pytest.mark.gpu
 def test_bench_fast_mode_line_checks_the_fp16_cell_kernels(gpu):
     """ADVICE r4: with ``--feat-dtype f16 --layout hwc --volume-store encoder`` the pipe runs corr_volume_h_stream<out16> and the lookup on fp16 cells;
     the line's parity block must exercise THOSE kernels (the pipe's own fp16 volume buffer and token buffer), with the fp16 bar, not the fp32 ones."""

@@ -327,6 +327,29 @@ def test_convex_upsample_16bit_mask(gpu, dtype, B, h, w):
     assert torch.equal(ops.convex_upsample(flow8, buf[1:].view_as(mask), 0.25), ops.convex_upsample(flow8, mask.float(), 0.25))
 
 
+def test_convex_upsample_minus_inf_taps(gpu):
+    """an fp16 mask head that overflows under autocast hands the kernel -inf logits.  torch.softmax gives such a tap weight 0 and the output stays
+    finite; the kernel's short exp must do the same (a NaN logit still poisons its sub-pixel, as in torch)."""
+    from macvo_amd import ops
+    from oracle import frontend
+
+    g = torch.Generator().manual_seed(33)
+    B, h, w = 1, 12, 16
+    flow8 = torch.randn(B, 2, h, w, generator=g) * 3
+    mask = torch.randn(B, 576, h, w, generator=g) * 4
+    mask.view(B, 9, 64, h, w)[:, 3, ::2] = float("-inf")        # tap 3 of every second sub-pixel
+    mask.view(B, 9, 64, h, w)[:, 7, 5, 2:5] = -3.0e38            # ... and logits whose log2(e) multiple overflows
+    for dt in (torch.float32, torch.float16):
+        m = mask.to(dt)
+        ref = frontend.upsample_flow(flow8, m.float())
+        out = ops.convex_upsample(flow8.to(gpu), m.to(gpu), mask_scale=1.0).cpu()
+        assert torch.isfinite(ref).all() and torch.isfinite(out).all()
+        torch.testing.assert_close(out, ref, rtol=1e-5, atol=2e-5)
+    m = mask.clone()
+    m.view(B, 9, 64, h, w)[0, 0, 0, 0, 0] = float("nan")
+    out = ops.convex_upsample(flow8.to(gpu), m.to(gpu), mask_scale=1.0).cpu()
+    assert torch.isnan(out[0, :, 0, 0]).all() and torch.isfinite(out[0, :, 8:, 8:]).all()
+
 @pytest.mark.parametrize("shape", [(1, 32, 112, 160), (2, 196, 7, 10), (1, 128, 14, 20), (2, 96, 28, 40), (1, 64, 56, 80),
                                    (1, 16, 33, 47), (1, 3, 5, 5), (3, 8, 1, 1)])
 def test_local_corr81(gpu, shape):

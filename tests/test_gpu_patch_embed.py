@@ -208,6 +208,15 @@ def test_flowformer_hook_rebinds_the_patch_embed_proj(gpu):
         got_half = m.memory_encoder.patch_embed(x)
         assert (got_half - want_half).abs().max().item() <= FP32_TOL["f16"] * want_half.abs().max().item()
         assert (got_half - got).abs().max().item() > 0.05 * got.abs().max().item()
+        # under autocast the Conv2d stack returns the autocast dtype — so does the fused call on fp32 slices; a sliced view whose storage offset
+        # breaks the kernel's 16-byte alignment falls through to the layers instead of raising
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ac = m.memory_encoder.patch_embed(x)
+        assert ac.dtype == torch.bfloat16 and (ac.float() - got_half).abs().max().item() <= 2 ** -7 * got_half.abs().max().item()
+        buf = torch.zeros(9 * 64 * 80 + 1, device=gpu)
+        buf[1:] = F.pad(x, (0, 0, 0, 4)).flatten()
+        odd = buf[1:].view(9, 1, 64, 80)
+        assert odd.data_ptr() % 16 != 0 and torch.equal(proj(odd), layers(odd))
     # autograd: a call that could need gradients runs the layers (the kernel is inference-only)
     xg = x[:2].clone().requires_grad_(True)
     y = m.memory_encoder.patch_embed(xg)

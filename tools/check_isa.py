@@ -19,7 +19,7 @@ def main() -> int:
     keep = sys.argv[sys.argv.index("--keep") + 1] if "--keep" in sys.argv else None
     with tempfile.TemporaryDirectory() as tmp:
         out = keep or os.path.join(tmp, "split.s")
-        cmd = [os.environ.get("HIPCC", "hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+        cmd = [os.environ.get("HIPCC", "hipcc"), "--offload-arch=" + os.environ.get("ARCH", "gfx950"), "-O3", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
                "-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-unroll-threshold=1000000", "--cuda-device-only", "-S",
                os.path.join(CSRC, "corr_volume_split.hip"), "-o", out]
         r = subprocess.run(cmd, capture_output=True, text=True)

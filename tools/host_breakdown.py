@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from macvo_amd import ops
 from macvo_amd.pipeline import Camera, FrameInputs, HotPathConfig, NativeHotPath
-from tests import synth
+from tools import synth
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 dev = torch.device("cuda")
 cam, frames_cpu, _ = synth.make_sequence(24, 480, 640, C=256, iters=12, seed=1000, pool=2, closed_loop=True)

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from macvo_amd import ops  # noqa: E402
-from tests import synth  # noqa: E402
+from tools import synth  # noqa: E402
 
 
 def timeit(fn, iters, warm=5):
@@ -219,7 +219,7 @@ def main():
                 print(f"match_cov N={npt:5d}    {med:8.1f} us (min {mn:.1f})")
         elif w == "pgo":
             from oracle import pgo
-            from tests.test_gpu_backend import _to_batch
+            from tools.synth import pgo_batch as _to_batch
 
             for nprob in (1, 8, 256, 4096):
                 base = [pgo.make_synthetic_problem(n=200, seed=6 + k)[0] for k in range(min(nprob, 8))]

@@ -16,7 +16,8 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "mac-vo_amd", "csrc", "build")
 LLVM = os.environ.get("ROCM_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
-TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
+ARCH = os.environ.get("ARCH", "gfx950")      # the Makefile's ARCH= (gfx950 is the only target this library is written for)
+TARGET = "hipv4-amdgcn-amd-amdhsa--" + ARCH
 FIELDS = ("vgpr_count", "agpr_count", "sgpr_count", "group_segment_fixed_size", "private_segment_fixed_size", "vgpr_spill_count", "sgpr_spill_count",
           "max_flat_workgroup_size")
 

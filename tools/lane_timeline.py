@@ -3,7 +3,7 @@ period, GEMM duration, idle on the GEMM stream, GEMM end -> last lookup, -> sele
 import os, sys, statistics as st, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from macvo_amd.pipeline import Camera, FrameInputs, HotPathConfig, NativeHotPath, stack_lanes
-from tests import synth
+from tools import synth
 lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else (200 if lanes < 8 else 40)
 pool = 24
