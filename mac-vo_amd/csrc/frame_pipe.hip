@@ -180,6 +180,9 @@ struct mvFramePipe {
     bool seg_valid[N_INEV];
     int alt_indep;               // alt: consecutive frames' segments may overlap (own selector workspace each; NODEPTH selector, no upsampling)
     void* kp_ws2;                // ... the odd frames' workspace
+    int front_on_decoder;        // device-driven alt layout: a frame's front launch (draw + gathers + covariances) runs on the frame's decoder-side stream right
+                                 // behind its selector segment (no cross-queue barrier in front of it); the backend stream carries the solves only
+
     hipStream_t s_sel;   // MV_PIPE_SELECTOR_ON=own: a fifth stream for the selector segment (nullptr otherwise)
     SelSeg deferred;     // MV_PIPE_SELECTOR_ON=vol: the newest frame's selector segment, not issued yet
     bool deferred_valid;
@@ -339,6 +342,7 @@ static size_t carve(mvFramePipe* p, char* base) {
     p->kp_ws_bytes = L * mv_kp_select_workspace_bytes(c.H, c.W);
     p->kp_ws = a.take<char>(p->kp_ws_bytes);
     p->kp_ws2 = L <= 2 ? a.take<char>(p->kp_ws_bytes) : nullptr;
+
     for (int k = 0; k < N_CAND; ++k) {
         p->cand[k] = a.take<int32_t>(L * plane);
         p->count[k] = a.take<int32_t>(L * 4);
@@ -639,6 +643,13 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
         // (profiles/r05_pipe_ab.log): 0 / 8 / 16 / 32 / 48 / 64 free = 6.26 / 6.34 / 6.68 / 6.84 / 6.87 / 6.82 k frames/s; in the classic layout no gain (r3, r5).
         p->free_cus = p->alt ? 32 : 0;
         p->alt_indep = p->alt;   // (ordered segments for every selector: -6 % on the 20-step line, profiles/r05_pipe_ab.log run 18)
+        // Device-driven frames: the front launch (permutation draw + gathers + both covariance models) rides behind the frame's own selector segment on its
+        // decoder-side stream — no cross-queue barrier in front of it — and the fourth stream carries the solves only.  With front + solve in order on one
+        // stream that stream was the bound of a device-driven pipe (a frame's backend started 250 us after its selector had finished: a backlog of front /
+        // solve pairs, each with a pending barrier in front).  Measured (profiles/r06_device_draw_ab.log): 20 steps 5.97 / 5.63 / 6.18 k vs 5.75 / 5.65 / 5.61 k
+        // frames/s, 300 steps 6.83-6.95 k vs 6.60-6.64 k; bit-identical.  MV_PIPE_FRONT_ON=side: the old placement.  (Also measured and dropped: the selector's
+        // FINISHING workgroup moved in front of the backend on the backend's stream — 5.62 k at 300 steps.)
+        { const char* e = getenv("MV_PIPE_FRONT_ON"); p->front_on_decoder = (p->alt && !(e && strcmp(e, "side") == 0)) ? 1 : 0; }
     }
     const int rc = create_impl(p);
     if (rc != MV_OK) {
@@ -1060,7 +1071,11 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
     const int k = (int)(g & 1);
     Backend& b = p->be[k];
     const int32_t* n_sel = j.n_sel;
-    hipStream_t s = p->s_back;
+    // front_on_decoder (device-driven frames of the alt layout): the pose-independent launch goes behind the frame's own selector segment on its decoder-side
+    // stream — in order, so no barrier for the selector; consecutive frames' front launches (other decoder-side stream each) are chained by the ring event of the
+    // previous finish, which also orders the generator's state buffers and covers the previous frame's segment
+    const bool on_dec = j.device && p->front_on_decoder && p->alt && !p->sel_on_back;
+    hipStream_t s = on_dec ? p->s_lk[j.pd.f % p->n_lk] : p->s_back;
     if (n_max == 0) {   // nothing to track in any lane: the poses stay at the motion-model prior (MACVO.py:303-307)
         // The pose slots still rotate (MV_FB_POSE age a = the pose after the a-th newest finish) and the slot's events are
         // refreshed, so that everything keyed on "slot of finish g" (mv_frame_pipe_map_append, result views) sees this frame and
@@ -1093,13 +1108,14 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
         for (int l = 0; l < L; ++l)
             memcpy(p->h_perm[ps] + (size_t)l * cap, perm_host + (size_t)l * cap, (size_t)n_sel[l] * sizeof(int64_t));
     }
-    MV_TRY(wait_if_pending(s, p->e_cand[pd.cand]));   // fired: the host has just read this frame's count
+    if (!on_dec) MV_TRY(wait_if_pending(s, p->e_cand[pd.cand]));   // fired: the host has just read this frame's count (device-driven: a pending barrier)
+    else if (g > 0 && p->backend_valid[(g - 1) % N_BEV]) MV_TRY(wait_if_pending(s, p->e_backend[(g - 1) % N_BEV]));
     // alt layout: the previous frame's maps (gathers below) were written by a segment on the other decoder-side stream, which e_cand does not cover.
     // (Slot f - 1 of e_seg is re-recorded by frame f - 1 + N_INEV, far beyond the frames in flight.)
     // ... unless the previous frame's backend ran on THIS stream and waited for that segment itself (its e_cand is recorded at the same point): stream order
     // then covers it, and a pending cross-queue barrier less sits in front of the backend (device-driven frames are issued long before their selector is done;
     // every unsatisfied barrier at the head of a queue costs the other queues dispatch latency, profiles/r06_device_draw_ab.log)
-    const bool prev_here = p->alt && p->last_backend_frame == pd.f - 1;
+    const bool prev_here = p->alt && p->last_backend_frame == pd.f - 1;   // (on_dec: the previous front launch's event, waited for above, covers it too)
     if (p->alt && pd.f > 0 && !prev_here) MV_TRY(wait_if_pending(s, p->e_seg[(pd.f - 1) % N_INEV]));
     p->last_backend_frame = pd.f;
     const int ti = pd.ti;

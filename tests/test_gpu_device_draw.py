@@ -174,3 +174,35 @@ def test_device_driven_run_does_not_wait_for_the_gpu(gpu, monkeypatch):
     assert len(res) == n and bool((sink.abs().sum(dim=1) > 0).all())
     assert t_host < 0.8 * t_all, (t_host, t_all)     # ... well before the GPU was through with them
     assert hot.host_frames >= n and hot.host_issue_s > 0
+
+
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_front_launch_on_the_decoder_stream_equals_the_backend_stream_form(gpu, monkeypatch, lanes):
+    """`MV_PIPE_FRONT_ON=decoder`: a device-driven frame's front launch (permutation draw + gathers + covariance models) rides behind the frame's own selector
+    segment on its decoder-side stream; the backend stream carries the solves only.  The generator's state buffers and the previous frame's maps are ordered by
+    the ring event of the previous front launch.  Keypoints, counts and poses of a pipelined stream are bit-identical to the default placement."""
+    from macvo_amd.pipeline import Camera, HotPathConfig, NativeHotPath, stack_lanes
+
+    n_pool, n_steps = 8, 120
+    cam, frames, _ = synth.make_sequence(n_pool + lanes, 256, 384, C=256, iters=4, seed=31, closed_loop=True)
+    ins = _inputs(frames, gpu, static=True)
+    pool = ins[:n_pool] if lanes == 1 else [stack_lanes([ins[(t + l) % len(ins)] for l in range(lanes)]) for t in range(n_pool)]
+    outs = {}
+    for where in ("side", "decoder"):          # (decoder = the default)
+        monkeypatch.setenv("MV_PIPE_FRONT_ON", where)
+        hot = NativeHotPath(Camera(**cam), HotPathConfig(num_point=80), gpu, lanes=lanes, generators=[43 + l for l in range(lanes)])
+        hot.initialize(pool[0])
+        sink = torch.zeros((n_steps, 7) if lanes == 1 else (n_steps, lanes, 7), device=gpu)
+        rec = []
+        for r in hot.run((pool[(1 + k) % n_pool] for k in range(n_steps)), pose_sink=sink):
+            hot.sync_pose()
+            rr = r if isinstance(r, list) else [r]
+            rec.append((torch.cat([x.kp0_uv for x in rr]).clone(), [x.n_cand for x in rr], [x.n_sel for x in rr]))
+        torch.cuda.synchronize()
+        assert hot.device_driven
+        outs[where] = (sink.clone(), rec)
+        hot.close()
+    a, b = outs["side"], outs["decoder"]
+    assert torch.isfinite(b[0]).all() and b[0].abs().sum() > 0 and torch.equal(a[0], b[0])
+    for (ka, ca, sa), (kb, cb, sb) in zip(a[1], b[1]):
+        assert ca == cb and sa == sb and min(sa) > 0 and torch.equal(ka, kb)
