@@ -1124,7 +1124,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         constexpr bool HAVE_PREV = decltype(PREV)::value;
         // this wave's DMA pieces of ring slot `slot` were issued before the last 32 stores (or everything has been drained since);
         // behind the barrier all four waves' pieces are in, and everyone has left slot ^ 1
-        wait_vmcnt_barrier<NST>();
+#ifndef MV_HS_PROBE_SLACK
+#define MV_HS_PROBE_SLACK 0       // probe builds only (timing; results are then wrong): that many more stores may be in flight at the barrier
+#endif
+        wait_vmcnt_barrier<NST + MV_HS_PROBE_SLACK>();
         issue_b(slot ^ 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.f;

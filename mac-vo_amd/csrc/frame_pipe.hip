@@ -649,6 +649,8 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
         // solve pairs, each with a pending barrier in front).  Measured (profiles/r06_device_draw_ab.log): 20 steps 5.97 / 5.63 / 6.18 k vs 5.75 / 5.65 / 5.61 k
         // frames/s, 300 steps 6.83-6.95 k vs 6.60-6.64 k; bit-identical.  MV_PIPE_FRONT_ON=side: the old placement.  (Also measured and dropped: the selector's
         // FINISHING workgroup moved in front of the backend on the backend's stream — 5.62 k at 300 steps.)
+        // (Also measured and dropped, same log: THREE decoder-side streams — the fourth stream as the third, a frame's whole chain incl. its solve in order on one
+        // stream, solves chained across streams by event: bit-identical, 5.3 k instead of 6.7 k frames/s at 300 steps.  More concurrency is not what this pipe lacks.)
         { const char* e = getenv("MV_PIPE_FRONT_ON"); p->front_on_decoder = (p->alt && !(e && strcmp(e, "side") == 0)) ? 1 : 0; }
     }
     const int rc = create_impl(p);
@@ -1594,6 +1596,7 @@ extern "C" int mv_frame_pipe_timeline_backend(mvFramePipe* p, float* ms, int cap
     if (!p->time_detail) { *n = 0; return MV_OK; }
     MV_HIP(hipStreamSynchronize(p->s_back));
     MV_HIP(hipStreamSynchronize(p->s_side));
+    for (int k = 0; k < p->n_lk; ++k) MV_HIP(hipStreamSynchronize(p->s_lk[k]));   // (device-driven frames run the front launch on the decoder side)
     const int m = p->n_timed < cap_frames ? p->n_timed : cap_frames;
     for (int i = 0; i < m; ++i) {
         hipEvent_t evs[4] = {p->tv4[i], p->tv5[i], p->tv6[i], p->tv7[i]};

@@ -562,7 +562,7 @@ class _FusedProjForward:
         except ops.L.MacvoHipError:                              # anything the kernel refuses falls through to the layers, as documented
             return layers(self.proj, x)
         if torch.is_autocast_enabled():                          # ... and in the autocast dtype under autocast, as the Conv2d stack would
-            out = out.to(torch.get_autocast_gpu_dtype())
+            out = out.to(torch.get_autocast_dtype("cuda"))
         return out
 
 

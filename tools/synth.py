@@ -152,7 +152,7 @@ def tartanair_sequence(C=32, iters=1):
 
     import numpy as np
 
-    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tartanair_p000.npz"))
+    z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "tartanair_p000.npz"))
     depth = torch.from_numpy(z["depth"])                               # [n,H,W] f32
     flow = (torch.from_numpy(z["flow_u16"].astype(np.float32)) - 32768.0) / 64.0   # [n-1,2,H,W], exact
     fmask = torch.from_numpy(z["flow_mask"])                           # [n-1,H,W] 0 = valid
