@@ -371,7 +371,7 @@ def patch_embed_leg(ops, vol, dev, reps=10):
     leg = {"what": f"cost patch embedding of one frame's volumes (S = {S} slices {H2}x{W2} -> {out.shape[1]} tokens x 64), fused kernel mv_cost_patch_embed: 16-bit MFMA ({pk.operand} operands), fp32 "
                    "accumulate, both intermediate maps in LDS", "us_per_frame": round(us, 1), "algorithmic_gflop": round(fl / 1e9, 1),
            "roofline": {"bound": "mfma", "achieved": round(fl / us / 1e6, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / us / 1e6 / PEAK_BF16_MFMA_TFLOPS, 4),
-                        "traffic": None, "kernel": ("cost_patch_embed_kernel<%d,%d>" if (H2, W2) in ((60, 80), (64, 80)) else "cost_patch_embed_strip_kernel<%d,%d>") % (H2, W2), "algorithmic_hbm_bytes": byts, "hbm_GBps": round(byts / us / 1e3, 1)}}
+                        "traffic": None, "kernel": ("cost_patch_embed_pipelined_kernel<%d,%d>" if (H2, W2) in ((60, 80), (64, 80)) else "cost_patch_embed_strip_kernel<%d,%d>") % (H2, W2), "algorithmic_hbm_bytes": byts, "hbm_GBps": round(byts / us / 1e3, 1)}}
     # Fast mode (row (f)2 as SURVEY words it): fp16 cells in (the out16 volume), fp16 tokens out — no widening pass on either side
     try:
         v16 = vol.half()

@@ -69,6 +69,7 @@ __global__ void patch_embed_pack_kernel(const float* __restrict__ w1, const floa
     }
 }
 
+#ifdef MV_PE_PHASE_REFERENCE   // the phase-by-phase kernel: TEST-ONLY build (tests/pe_phase_ref.py), the bitwise reference of patch_embed_v3.hip
 // IN16 / OUT16: the slice is read / the tokens are written in the OPERAND type (fp16 cells of the `out16` volume -> fp16 tokens for the fp16 encoder of
 // MACVO_Fast.yaml:73-74; bf16 likewise) instead of fp32: the cells go to LDS as they are, no conversion, and HBM traffic is 9.6 + 10.2 KB per
 // slice instead of 19.2 + 20.5 KB
@@ -333,6 +334,8 @@ __global__ __launch_bounds__(256) void cost_patch_embed_kernel(const void* __res
     }
 }
 
+#endif
+
 }  // namespace
 
 extern "C" size_t mv_patch_embed_packed_bytes(void) { return PE_PACKED_BYTES; }
@@ -347,21 +350,42 @@ extern "C" int mv_patch_embed_pack(const float* w1, const float* b1, const float
     return mv_launch_status();
 }
 
+#ifndef MV_PE_PHASE_REFERENCE
 // patch_embed_v2.hip: the strip-mined kernel for the other slice sizes
 int mv_cost_patch_embed_strip(const void* cost_maps, int in16, const void* packed, void* out, int out16, int S, int H2, int W2, int token_layout, int f16,
                               mvStream_t stream);
 int mv_cost_patch_embed_strip_supported(int H2, int W2);
-// patch_embed_v3.hip: the same whole-slice LDS plan, pipelined across slices by two wave groups
+// patch_embed_v3.hip: the whole-slice LDS plan, pipelined across slices by two wave groups
 int mv_cost_patch_embed_pipelined(const void* cost_maps, int in16, const void* packed, void* out, int out16, int S, int H2, int W2, int token_layout, int f16,
                                   mvStream_t stream);
 
-#ifndef MV_PE_PIPELINED_DEFAULT
-#define MV_PE_PIPELINED_DEFAULT 1
-#endif
-static bool whole_slice_plan(int H2, int W2) { return (H2 == 60 || H2 == 64) && W2 == 80; }   // this file's kernel: two whole slices per pass
+static bool whole_slice_plan(int H2, int W2) { return (H2 == 60 || H2 == 64) && W2 == 80; }   // patch_embed_v3.hip: two whole slices in LDS
 
 extern "C" int mv_cost_patch_embed_supported(int H2, int W2) { return whole_slice_plan(H2, W2) || mv_cost_patch_embed_strip_supported(H2, W2); }
 
+extern "C" int mv_cost_patch_embed_t(const void* cost_maps, int in_dtype, const void* packed, void* out, int out_dtype, int S, int H2, int W2,
+                                     int token_layout, int operand_type, mvStream_t stream) {
+    MV_CHECK_ARG(cost_maps && packed && out && S > 0);
+    MV_CHECK_ARG(((uintptr_t)cost_maps & 15) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)out & 15) == 0);
+    MV_CHECK_ARG(operand_type == MV_F16 || operand_type == MV_BF16);        // must be the type `packed` was built for
+    // a 16-bit slice / token type is the operand type itself (the cells go to the matrix pipe as they are)
+    MV_CHECK_ARG(in_dtype == MV_F32 || in_dtype == operand_type);
+    MV_CHECK_ARG(out_dtype == MV_F32 || out_dtype == operand_type);
+    // 640x480 frames: 60 x 80 slices (padded to 64 rows inside the kernel) or the already padded 64 x 80 slices PatchEmbed.forward hands to `proj`
+    // (also 640x512 frames): the pipelined whole-slice kernel; every other supported size: the strip-mined kernel
+    if (!mv_cost_patch_embed_supported(H2, W2)) return MV_ERR_UNSUPPORTED;
+    if (in_dtype == MV_F32 && out_dtype != MV_F32) return MV_ERR_UNSUPPORTED;   // fp32 volume -> 16-bit tokens: no caller (the volume hook returns the encoder dtype)
+    const bool f16 = operand_type == MV_F16, in16 = in_dtype != MV_F32, out16 = out_dtype != MV_F32;
+    const char* pe_env = getenv("MV_PE_STRIP");                       // A/B (read per call: tests toggle it): 1 = the strip-mined kernel also where the
+    const bool strip_all = pe_env && atoi(pe_env) == 1;               // whole-slice plan exists
+    if (!whole_slice_plan(H2, W2) || strip_all)
+        return mv_cost_patch_embed_strip(cost_maps, in16, packed, out, out16, S, H2, W2, token_layout, f16, stream);
+    // (round 6: the phase-by-phase kernel this file used to launch under MV_PE_PIPELINED=0 is a test-only build now — -DMV_PE_PHASE_REFERENCE, tests/pe_phase_ref.py —
+    // where it remains the bitwise reference of the pipelined kernel)
+    return mv_cost_patch_embed_pipelined(cost_maps, in16, packed, out, out16, S, H2, W2, token_layout, f16, stream);
+}
+
+#else   // MV_PE_PHASE_REFERENCE: the test-only library exports the pack entry points above and this one launch
 template <int H2, bool F16, bool IN16, bool OUT16>
 static int launch_patch_embed(const void* cost_maps, const void* packed, void* out, int S, int token_layout, hipStream_t stream) {
     using P = PE<H2, 80>;
@@ -395,27 +419,14 @@ static int launch_patch_embed_h(const void* cost_maps, const void* packed, void*
                     : launch_patch_embed<64, F16, IN16, OUT16>(cost_maps, packed, out, S, token_layout, st);
 }
 
-extern "C" int mv_cost_patch_embed_t(const void* cost_maps, int in_dtype, const void* packed, void* out, int out_dtype, int S, int H2, int W2,
-                                     int token_layout, int operand_type, mvStream_t stream) {
-    MV_CHECK_ARG(cost_maps && packed && out && S > 0);
-    MV_CHECK_ARG(((uintptr_t)cost_maps & 15) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)out & 15) == 0);
-    MV_CHECK_ARG(operand_type == MV_F16 || operand_type == MV_BF16);        // must be the type `packed` was built for
-    // a 16-bit slice / token type is the operand type itself (the cells go to the matrix pipe as they are)
-    MV_CHECK_ARG(in_dtype == MV_F32 || in_dtype == operand_type);
-    MV_CHECK_ARG(out_dtype == MV_F32 || out_dtype == operand_type);
-    // 640x480 frames: 60 x 80 slices (padded to 64 rows inside the kernel) or the already padded 64 x 80 slices PatchEmbed.forward hands to `proj`
-    // (also 640x512 frames); larger slices do not fit the LDS plan
-    if (!mv_cost_patch_embed_supported(H2, W2)) return MV_ERR_UNSUPPORTED;
-    if (in_dtype == MV_F32 && out_dtype != MV_F32) return MV_ERR_UNSUPPORTED;   // fp32 volume -> 16-bit tokens: no caller (the volume hook returns the encoder dtype)
+extern "C" int mv_cost_patch_embed_phase_ref(const void* cost_maps, int in_dtype, const void* packed, void* out, int out_dtype, int S, int H2, int W2,
+                                             int token_layout, int operand_type, mvStream_t stream) {
+    MV_CHECK_ARG(cost_maps && packed && out && S > 0 && (H2 == 60 || H2 == 64) && W2 == 80);
+    MV_CHECK_ARG(operand_type == MV_F16 || operand_type == MV_BF16);
+    MV_CHECK_ARG((in_dtype == MV_F32 || in_dtype == operand_type) && (out_dtype == MV_F32 || out_dtype == operand_type));
+    if (in_dtype == MV_F32 && out_dtype != MV_F32) return MV_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const bool f16 = operand_type == MV_F16, in16 = in_dtype != MV_F32, out16 = out_dtype != MV_F32;
-    const char* pe_env = getenv("MV_PE_STRIP");                       // A/B (read per call: tests toggle it): 1 = the strip-mined kernel also where the
-    const bool strip_all = pe_env && atoi(pe_env) == 1;               // whole-slice plan exists
-    if (!whole_slice_plan(H2, W2) || strip_all)
-        return mv_cost_patch_embed_strip(cost_maps, in16, packed, out, out16, S, H2, W2, token_layout, f16, stream);
-    const char* pl_env = getenv("MV_PE_PIPELINED");                  // A/B (read per call): 0 = the phase-by-phase kernel below, 1 = the two-group pipeline
-    if (pl_env ? atoi(pl_env) == 1 : MV_PE_PIPELINED_DEFAULT)
-        return mv_cost_patch_embed_pipelined(cost_maps, in16, packed, out, out16, S, H2, W2, token_layout, f16, stream);
     if (f16) {
         if (!in16) return launch_patch_embed_h<true, false, false>(cost_maps, packed, out, S, H2, token_layout, st);
         return out16 ? launch_patch_embed_h<true, true, true>(cost_maps, packed, out, S, H2, token_layout, st)
@@ -425,8 +436,11 @@ extern "C" int mv_cost_patch_embed_t(const void* cost_maps, int in_dtype, const 
     return out16 ? launch_patch_embed_h<false, true, true>(cost_maps, packed, out, S, H2, token_layout, st)
                  : launch_patch_embed_h<false, true, false>(cost_maps, packed, out, S, H2, token_layout, st);
 }
+#endif
 
+#ifndef MV_PE_PHASE_REFERENCE
 extern "C" int mv_cost_patch_embed(const float* cost_maps, const void* packed, float* out, int S, int H2, int W2, int token_layout,
                                    int operand_type, mvStream_t stream) {
     return mv_cost_patch_embed_t(cost_maps, MV_F32, packed, out, MV_F32, S, H2, W2, token_layout, operand_type, stream);
 }
+#endif

@@ -371,11 +371,12 @@ def test_strip_mined_layers_one_by_one_at_720p(gpu):
 @pytest.mark.parametrize("operand,dt", [("f16", torch.float16), ("bf16", torch.bfloat16)])
 @pytest.mark.parametrize("H2", [60, 64])
 def test_pipelined_kernel_equals_the_phase_kernel(gpu, monkeypatch, operand, dt, H2):
-    """patch_embed_v3.hip (two wave groups: conv1 + conv2 of slice k beside conv3 of slice k - 1, conv2 maps as the ping-pong) against patch_embed.hip on the
-    same slices: the same 16-bit values meet in the same k order per output, so the tokens are BIT-identical — fp32 and 16-bit cells, both token
+    """patch_embed_v3.hip (two wave groups: conv1 + conv2 of slice k beside conv3 of slice k - 1, conv2 maps as the ping-pong) against the phase-by-phase kernel
+    of patch_embed.hip (round 6: a TEST-ONLY build, -DMV_PE_PHASE_REFERENCE, tests/pe_phase_ref.py — the product library no longer carries it) on the same slices: the same 16-bit values meet in the same k order per output, so the tokens are BIT-identical — fp32 and 16-bit cells, both token
     types, both layouts, slice counts around the persistent grid (1, odd, 256 + tail)."""
     from macvo_amd import ops
     from oracle import patch_embed as ope
+    from tests import pe_phase_ref
 
     W = ope.make_weights(seed=31)
     packed = ops.PatchEmbedWeights(*[w.to(gpu) for w in W], operand=operand)
@@ -383,12 +384,9 @@ def test_pipelined_kernel_equals_the_phase_kernel(gpu, monkeypatch, operand, dt,
         x = _slices(S, H2, 80, seed=S).to(gpu)
         for tokens in (False, True):
             for xin, odt in ((x, None), (x.to(dt), None), (x.to(dt), torch.float32)):
-                monkeypatch.setenv("MV_PE_PIPELINED", "0")
-                a = ops.cost_patch_embed(xin, packed, tokens=tokens, out_dtype=odt)
-                monkeypatch.setenv("MV_PE_PIPELINED", "1")
+                a = pe_phase_ref.cost_patch_embed(xin, packed, tokens=tokens, out_dtype=odt)     # the phase kernel: test-only build of patch_embed.hip
                 b = ops.cost_patch_embed(xin, packed, tokens=tokens, out_dtype=odt)
                 assert a.dtype == b.dtype and torch.equal(a, b), (S, tokens, xin.dtype, odt)
     ref = _twin(operand)(x[:4].cpu(), *W)
-    monkeypatch.setenv("MV_PE_PIPELINED", "1")
     got = ops.cost_patch_embed(x[:4].contiguous(), packed).cpu()
     assert (got - ref).abs().max().item() <= TWIN_TOL[operand] * ref.abs().max().item()

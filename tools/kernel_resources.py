@@ -94,7 +94,6 @@ CHECKS = [
      "f16x2 GEMM: a wave holds <= 304 of its SIMD's 512 registers — 208 stay for the kernels that run beside it (lookups 33, selector 34-117, backend front 53)"),
     (r"^cost_patch_embed_pipelined_kernel<", lambda r: r["private_segment_fixed_size"] == 0 and r["vgpr_spill_count"] == 0 and regs(r) <= 256,
      "pipelined patch embedding: 512-thread workgroup = two waves per SIMD, no spills"),
-    (r"^cost_patch_embed_kernel<", lambda r: r["private_segment_fixed_size"] == 0 and r["vgpr_spill_count"] == 0, "phase patch-embedding kernel: no scratch"),
     (r"^cost_patch_embed_strip_kernel<\d+, \d+, \d+, (true|false), (true|false), true,", lambda r: r["private_segment_fixed_size"] == 0 and r["vgpr_spill_count"] == 0,
      "strip-mined patch embedding with 16-bit cells in (the Fast-mode form): no spills (the fp32-in forms at 90 / 96 x 160 spill 20-26 registers: DESIGN section 4)"),
     (r"^corr_lookup_kernel<4, 2, 16", lambda r: r["private_segment_fixed_size"] == 0 and regs(r) <= 64,
