@@ -702,6 +702,12 @@ def main():
         stamps = torch.arange(steps, dtype=torch.int64, device=dev) * 33_333_333   # synthetic 30 Hz frame timestamps (ns)
         # the contract's W warm-up steps run exactly the timed code path (pose sink included: its first device-to-device copy
         # and the first gather set up lazily)
+        n_ev = max(steps, MIN_TIMED_LAUNCHES) if with_events else 0
+        if native and n_ev:
+            # create the timing events NOW (8 hipEventCreate per timed frame: milliseconds of host time): between the warm-up and the timed region the GPU must not
+            # idle longer than the contract's barrier + synchronize needs — after a few ms of idle the clocks take tens of ms of load to come back (§4)
+            hot.time_volume(n_ev)
+            hot.time_volume(0)
         warm_sink = torch.zeros((max(warmup, 1),) + shape[1:], dtype=torch.float32, device=dev)
         for _ in hot.run((batches[(t_idx + k) % args.pool] for k in range(warmup)), pose_sink=warm_sink):
             pass
@@ -709,7 +715,6 @@ def main():
         gather_tracks(torch.zeros((steps * lanes, 7), dtype=torch.float32, device=dev), stamps.repeat_interleave(lanes), dist)
         if dist is not None:  # warm the collectives used in / around the timed region (RCCL sets channels up lazily)
             dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=coll_dev), op=dist.ReduceOp.MAX)
-        n_ev = max(steps, MIN_TIMED_LAUNCHES) if with_events else 0
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
