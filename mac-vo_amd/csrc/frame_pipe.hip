@@ -1078,6 +1078,9 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
     // previous finish, which also orders the generator's state buffers and covers the previous frame's segment
     const bool on_dec = j.device && p->front_on_decoder && p->alt && !p->sel_on_back;
     hipStream_t s = on_dec ? p->s_lk[j.pd.f % p->n_lk] : p->s_back;
+    if (n_max == 0 && p->dev_draw)
+        MV_HIP(hipMemcpyAsync(p->rp_state[(g + 1) & 1], p->rp_state[g & 1], (size_t)L * (size_t)mv_randperm_state_words() * sizeof(uint32_t),
+                              hipMemcpyDeviceToDevice, s));
     if (n_max == 0) {   // nothing to track in any lane: the poses stay at the motion-model prior (MACVO.py:303-307)
         // The pose slots still rotate (MV_FB_POSE age a = the pose after the a-th newest finish) and the slot's events are
         // refreshed, so that everything keyed on "slot of finish g" (mv_frame_pipe_map_append, result views) sees this frame and
@@ -1105,6 +1108,9 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
     if (p->release_valid) MV_TRY(wait_if_pending(s, p->e_release));
     // permutations [lanes, cap] -> pinned slot -> device (ONE copy; rows beyond a lane's n_sel are never read)
     const int ps = (int)(g % N_PERM);
+    if (!j.device && p->dev_draw)   // a host-permuted finish in a device-driven pipe: the generators move on to the buffer the NEXT finish reads, unchanged
+        MV_HIP(hipMemcpyAsync(p->rp_state[(g + 1) & 1], p->rp_state[g & 1], (size_t)L * (size_t)mv_randperm_state_words() * sizeof(uint32_t),
+                              hipMemcpyDeviceToDevice, s));
     if (!j.device) {
         if (p->perm_valid[ps]) MV_HIP(hipEventSynchronize(p->e_perm[ps]));   // long done; keeps the slot reuse provably safe
         for (int l = 0; l < L; ++l)

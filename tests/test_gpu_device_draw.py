@@ -206,3 +206,69 @@ def test_front_launch_on_the_decoder_stream_equals_the_backend_stream_form(gpu, 
     assert torch.isfinite(b[0]).all() and b[0].abs().sum() > 0 and torch.equal(a[0], b[0])
     for (ka, ca, sa), (kb, cb, sb) in zip(a[1], b[1]):
         assert ca == cb and sa == sb and min(sa) > 0 and torch.equal(ka, kb)
+
+
+def test_host_permuted_finish_inside_a_device_driven_pipe_keeps_the_generator(gpu, monkeypatch):
+    """`mv_frame_pipe_finish` (an explicit host permutation) stays legal in a device-driven pipe: the device generators are carried over unchanged to the state
+    buffer the next device-driven finish reads.  Frames 1 and 3 device-drawn, frame 2 finished with the identity head: frames 1 and 3 select what
+    `torch.Generator(seed)` selects when only those two frames draw from it."""
+    from macvo_amd import ops
+    from macvo_amd.pipeline import Camera, HotPathConfig, NativeHotPath
+
+    cam, frames, _ = synth.make_sequence(5, 240, 320, C=64, iters=2, seed=77)
+    ins = _inputs(frames, gpu)
+    num = 50
+    hot = NativeHotPath(Camera(**cam), HotPathConfig(num_point=num), gpu, generators=[9])
+    hot.initialize(ins[0])
+    lib, Cc = hot._lib, ops.C
+    got = []
+    for t in (1, 2, 3):
+        hot.enqueue_frontend(ins[t])
+        if t == 2:
+            nc = (Cc.c_int32 * 1)()
+            ops.L.check(lib.mv_frame_pipe_wait_candidates(hot._pipe, nc), "wait_candidates")
+            perm = torch.arange(min(num, nc[0]), dtype=torch.int64)
+            ns = (Cc.c_int32 * 1)(perm.numel())
+            ops.L.check(lib.mv_frame_pipe_finish(hot._pipe, perm.data_ptr(), ns, None), "finish")
+            hot._n_fin += 1
+            hot.sync_all()
+            torch.cuda.synchronize()
+            n2 = nc[0]
+            kp2 = hot._view("KP0", 0, torch.int64, (1, num, 2))[0, : perm.numel()].clone()
+        else:
+            r = hot.finish()
+            hot.sync_all()
+            torch.cuda.synchronize()
+            got.append((r.kp0_uv.clone(), r.n_cand))
+    assert hot.device_driven
+    cand2 = hot._view("CAND", 1, torch.int32, (1, 240 * 320))[0, :num].clone()          # frame 2's candidate list (one enqueue back)
+    hot.close()
+    # reference: the same pipe host-drawn from torch generators, with the identity head on frame 2
+    g = torch.Generator().manual_seed(9)
+    monkeypatch.setenv("MV_PIPE_DEVICE_DRAW", "0")
+    ref = NativeHotPath(Camera(**cam), HotPathConfig(num_point=num), gpu, generators=[g])
+    ref.initialize(ins[0])
+    want = []
+    for t in (1, 2, 3):
+        ref.enqueue_frontend(ins[t])
+        if t == 2:
+            nc = (Cc.c_int32 * 1)()
+            ops.L.check(ref._lib.mv_frame_pipe_wait_candidates(ref._pipe, nc), "wait_candidates")
+            assert nc[0] == n2
+            perm = torch.arange(min(num, nc[0]), dtype=torch.int64)
+            ns = (Cc.c_int32 * 1)(perm.numel())
+            ops.L.check(ref._lib.mv_frame_pipe_release(ref._pipe, None), "release")
+            ops.L.check(ref._lib.mv_frame_pipe_finish(ref._pipe, perm.data_ptr(), ns, None), "finish")
+            ref._n_fin += 1
+            ref.sync_all()
+            torch.cuda.synchronize()
+            assert torch.equal(ref._view("KP0", 0, torch.int64, (1, num, 2))[0, : perm.numel()], kp2)
+        else:
+            r = ref.finish()
+            ref.sync_all()
+            torch.cuda.synchronize()
+            want.append((r.kp0_uv.clone(), r.n_cand))
+    ref.close()
+    assert kp2[:, 0].numel() == num and torch.equal(kp2[:, 1] * 320 + kp2[:, 0], cand2.long())      # the identity head = the first candidates, in order
+    for (a, na), (b, nb) in zip(got, want):
+        assert na == nb and na > num and torch.equal(a, b)
