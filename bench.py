@@ -323,22 +323,81 @@ def schedule_note(lanes: int) -> str:
              "four streams: GEMM | lookups + selector | backend | solve" if lanes > 2 else "four streams: GEMM | lookups | selector + backend | solve"))
 
 
-def pin_rank_cores(local_rank: int, local_world: int) -> list:
-    """Confine this rank (the calling thread; the driver's backend launch thread and torch's pool threads are created later and inherit
-    the mask) to its own contiguous slice of the cores the process may use, so that the 2 busy host threads of each of N ranks never
-    share a core with another rank's.  Returns the slice (printed as `host_cores_per_rank`).  No-op for a single rank."""
+def _parse_cpulist(text: str) -> list:
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_local_cores(index: int) -> list:
+    """Host cores on the NUMA node GPU `index` hangs off (sysfs `local_cpulist` of its PCI function), [] when that cannot be read."""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/local_cpulist") as f:
+            return _parse_cpulist(f.read())
+    except Exception:  # noqa: BLE001 - older torch without the pci fields, containers without sysfs, ...
+        return []
+
+
+def thread_siblings(cpu: int) -> tuple:
+    """The hardware threads of the physical core `cpu` belongs to (sysfs), (cpu,) when unknown."""
+    try:
+        with open(f"/sys/devices/system/cpu/cpu{cpu}/topology/thread_siblings_list") as f:
+            return tuple(sorted(_parse_cpulist(f.read())))
+    except Exception:  # noqa: BLE001
+        return (cpu,)
+
+
+def rank_core_slice(local_rank: int, local_world: int, allowed: list, gpu_cores_of, siblings_of=None) -> list:
+    """The slice of `allowed` rank `local_rank` pins itself to.  NUMA-aware (round 6): ranks whose GPUs share a NUMA node split THAT node's PHYSICAL cores among them
+    (the issuing thread's doorbell writes and signal reads stay on the GPU's socket, and no two ranks' busy threads land on hyperthreads of one core); when the
+    topology cannot be read, or a node has fewer than two hardware threads per rank, the plain contiguous split of round 5.  `gpu_cores_of(i)` -> cores local to
+    GPU i, `siblings_of(cpu)` -> the hardware threads of its core (pure function of its arguments: tested on the CPU)."""
+    if local_world <= 1 or len(allowed) < 2 * local_world:
+        return list(allowed)
+    k = len(allowed) // local_world
+    plain = allowed[local_rank * k:(local_rank + 1) * k]
+    aset = set(allowed)
+    nodes = [tuple(c for c in gpu_cores_of(i) if c in aset) for i in range(local_world)]
+    mine = nodes[local_rank]
+    if not mine or any(not n for n in nodes):
+        return plain
+    peers = [i for i in range(local_world) if nodes[i] == mine]
+    sib = siblings_of or (lambda c: (c,))
+    groups, seen = [], set()
+    for c in mine:                       # physical cores of the node, in enumeration order, each with its allowed hardware threads
+        if c in seen:
+            continue
+        g = tuple(t for t in sib(c) if t in aset and t in set(mine)) or (c,)
+        seen.update(g)
+        groups.append(g)
+    per = len(groups) // len(peers)
+    if per < 1 or per * len(groups[0]) < 2:
+        return plain
+    j = peers.index(local_rank)
+    return sorted(t for g in groups[j * per:(j + 1) * per] for t in g)
+
+
+def pin_rank_cores(local_rank: int, local_world: int, share_gpu: bool = False) -> list:
+    """Confine this rank (the calling thread; torch's pool threads are created later and inherit the mask) to its own slice of the cores the process may use, so
+    that the busy host thread of each of N ranks never shares a core with another rank's.  Returns the slice (printed as `host_cores_per_rank`).  No-op for a
+    single rank."""
     if not hasattr(os, "sched_getaffinity"):
         return []
     cores = sorted(os.sched_getaffinity(0))
     if local_world <= 1 or len(cores) < 2 * local_world:
         return cores
-    k = len(cores) // local_world
-    mine = cores[local_rank * k:(local_rank + 1) * k]
+    mine = rank_core_slice(local_rank, local_world, cores, (lambda i: []) if share_gpu else gpu_local_cores, thread_siblings)
     try:
         os.sched_setaffinity(0, mine)
     except OSError:
         return cores
-    torch.set_num_threads(max(1, min(8, k - 2)))
+    torch.set_num_threads(max(1, min(8, len(mine) - 2)))
     return mine
 
 
@@ -590,7 +649,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    my_cores = pin_rank_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) if not args.dry_collectives else []
+    my_cores = pin_rank_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), args.share_gpu) if not args.dry_collectives else []
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(self_launch(args))      # one rank per GPU under torch.distributed.run, output handed through
     if args.gpus != world:
@@ -1132,7 +1191,8 @@ def main():
             "ranks_seen": ranks_seen,
             "rank_devices": rank_devices,
             "host_cores_per_rank": len(my_cores) or None,
-            "rank_core_slices": [[c[0], c[-1]] if c else None for c in rank_cores],
+            "rank_core_slices": [[c[0], c[-1]] if c else None for c in rank_cores],       # (first, last core of the slice; NUMA-local slices are a core range + its hyperthread range)
+            "rank_core_counts": [len(c) if c else None for c in rank_cores],
             "rank_pose_tracks_finite": rank_tracks_finite,
             "share_gpu_test_mode": bool(args.share_gpu),
             "host_threads_per_rank": ("1 busy (device-driven frames: no launch thread)" if main_host.get("device_driven") else "2 busy (caller + backend launch thread)") +

@@ -261,6 +261,31 @@ def test_device_permutation_phases_are_torch_randperm():
     assert st[0] == 5 and st[624] == 624 and st[1] == (1812433253 * (5 ^ (5 >> 30)) + 1) % 2 ** 32
     assert lib.mv_randperm_heads_emulated(C.c_uint64(0), n_arr.ctypes.data, 1, lib.mv_randperm_max_head() + 1, 64, out.ctypes.data) == -2   # MV_ERR_UNSUPPORTED
 
+def test_rank_core_slices_are_numa_local_and_disjoint():
+    """bench.py --gpus N pins each rank to its own host cores (round 6: NUMA-aware).  On the topology of the round's GPU boxes — 2 sockets x 64 cores x 2 threads, node 0 =
+    cpus 0-63 + 128-191, node 1 = 64-127 + 192-255, GPUs 0-3 on node 0, 4-7 on node 1 — every rank gets physical cores of ITS GPU's node with their
+    hyperthreads, the slices are disjoint and cover the machine; an unreadable topology falls back to the plain contiguous split."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod_cores", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    allowed = list(range(256))
+    node = [list(range(0, 64)) + list(range(128, 192)), list(range(64, 128)) + list(range(192, 256))]
+    gpu = lambda i: node[0] if i < 4 else node[1]  # noqa: E731
+    sib = lambda c: (c % 128, c % 128 + 128)  # noqa: E731
+    sl = [bench.rank_core_slice(r, 8, allowed, gpu, sib) for r in range(8)]
+    assert all(len(x) == 32 for x in sl) and len(set().union(*map(set, sl))) == 256
+    for r, x in enumerate(sl):
+        assert set(x) <= set(node[0] if r < 4 else node[1])
+        assert all((c % 128 + 128 in x) and (c % 128 in x) for c in x)          # whole physical cores
+    assert sl[0] == list(range(0, 16)) + list(range(128, 144)) and sl[4] == list(range(64, 80)) + list(range(192, 208))
+    # 2 ranks on a restricted mask, topology unknown -> plain split; one rank -> everything
+    assert bench.rank_core_slice(1, 2, list(range(8)), lambda i: [], None) == [4, 5, 6, 7]
+    assert bench.rank_core_slice(0, 1, list(range(8)), gpu, sib) == list(range(8))
+    assert bench._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+
 def test_bench_roofline_object_contract():
     """bench.py's `roofline` object (the driver's contract: bound / achieved / peak / unit / frac / traffic) for the three kinds of
     volume kernel, from synthetic launch times: achieved = algorithmic (or, for the split kernels, executed) work / time, frac =
