@@ -27,5 +27,5 @@ OUT=gpurun_out/kprof_$T; rm -rf $OUT; mkdir -p $OUT
 cp $(find $OUT -name "*kernel_stats.csv" | head -1) gpurun_out/${T}_bench_kernel_stats.csv 2>/dev/null; grep '^{' $OUT/run.log | tail -1 > gpurun_out/${T}_bench_traced_line.json
 rm -rf $OUT
 head -9 gpurun_out/${T}_bench_kernel_stats.csv | cut -c1-160
-bash scripts/pmc_gpu.sh ${T}_split volume_split > gpurun_out/${T}_pmc_split.log 2>&1; cp gpurun_out/pmc_${T}_split.json gpurun_out/${T}_pmc_corr_volume_split.json 2>/dev/null; tail -4 gpurun_out/${T}_pmc_split.log | cut -c1-300
+bash scripts/pmc_gpu.sh ${T}_split volume_split > gpurun_out/${T}_pmc_split.log 2>&1; cp gpurun_out/pmc_${T}_split.json gpurun_out/${T}_pmc_corr_volume_split_f16x2.json 2>/dev/null; tail -4 gpurun_out/${T}_pmc_split.log | cut -c1-300
 rm -rf gpurun_out/pmc_${T}_split_*
