@@ -1076,7 +1076,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     auto issue_b = [&](int slot) __attribute__((always_inline)) {   // item ld_it -> ring slot, then advance
 #pragma unroll
-        for (int p = 0; p < NP; ++p) glds16(ld_ptr + lane_src[p], lds0 + (unsigned)(slot * SLOT + (p * 4 + wave) * 64) * 16u);
+        for (int p = 0; p < NP; ++p) {
+#ifndef MV_HS_PROBE_NODMA                        // (probe builds: timing only)
+            glds16(ld_ptr + lane_src[p], lds0 + (unsigned)(slot * SLOT + (p * 4 + wave) * 64) * 16u);
+#endif
+        }
         if (ld_it + 1 < it_end) {                // past the end of the run the last item is simply fetched again
             ++ld_it;
             if (++ld_c == ld_cend) {             // next band of the region / next region / next pair
@@ -1113,7 +1117,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // budget of 2 waves / SIMD); the SGPR-base form needs none.  Like the DMA above these are counted by hand.
         if (OUT16) {                             // columns (2 li, 2 li + 1) of row r: one packed dword, a full line per 32 lanes
             const unsigned d = pack16(p0[r], p1[r]);
+#ifdef MV_HS_PROBE_NOSTORE                       // (probe builds: timing only)
+            asm volatile("" ::"v"(d), "v"(roff[r]), "s"(Ob));
+#else
             asm volatile("global_store_dword %0, %1, %2" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(d), "s"(Ob) : "memory");
+#endif
         } else {
             asm volatile("global_store_dword %0, %1, %2" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(p0[r]), "s"(Ob) : "memory");
             asm volatile("global_store_dword %0, %1, %2 offset:128" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(p1[r]), "s"(Ob) : "memory");
@@ -1142,13 +1150,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
+#ifndef MV_HS_PROBE_NOLDS
             if (ks + PF < KS) {
                 fb0[(ks + PF) % (PF + 1)] = q0[((ks + PF) * 2 + kh) ^ sw];
                 fb1[(ks + PF) % (PF + 1)] = q1[((ks + PF) * 2 + kh) ^ sw];
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (hipcc otherwise sinks it back)
             const i32x4 b0 = fb0[ks % (PF + 1)], b1 = fb1[ks % (PF + 1)];
+#ifdef MV_HS_PROBE_NOMFMA
+            asm volatile("" ::"v"(b0), "v"(b1), "v"(af[ks]));
+            if (false) {
+#else
             if (IS_BF16) {
+#endif
                 c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[ks]), __builtin_bit_cast(bf16x8, b0), c0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[ks]), __builtin_bit_cast(bf16x8, b1), c1, 0, 0, 0);
             } else {
