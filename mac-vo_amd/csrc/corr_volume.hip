@@ -1012,6 +1012,12 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // conflict-free), so a lane holds columns (2 li, 2 li + 1) of its 16 rows: one v_cvt_pk + ONE dword store per row, 32 lanes = one full 128-byte
 // line, 16 stores per item instead of 32 (the hand-counted vmcnt constants follow: NST).  (First form, measured and dropped: columns li / li + 32,
 // row pairs swapped between neighbouring lanes by DPP, 64-byte half-line nt stores — 63 us against 40 us for the fp32 kernel.)
+#ifdef MV_HS_STAMPS   // probe builds only: s_memtime stamps of the first 48 items of every wave of the first 32 workgroups -> [wg][wave][item][4]
+__device__ long long* g_hs_stamps = nullptr;
+#define HS_STAMP(i) do { if (stamp_on) st[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HS_STAMP(i) ((void)0)
+#endif
 template <bool IS_BF16, int KS, bool OUT16 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void corr_volume_h_stream(
     const uint16_t* __restrict__ f1, const uint16_t* __restrict__ f2, float* __restrict__ out, int N1, int N2, int B, int R) {
@@ -1024,6 +1030,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int SLOT = 64 * CH;                // ring slot in 16-byte units
     static_assert(NP <= 8 && RPK * KS == 16, "the vmcnt budget below assumes <= 8 loads and 32 stores per sub-tile");
     extern __shared__ __attribute__((aligned(16))) i32x4 smem_hs[];   // B ring: 2 slots x 64 rows x CH chunks
+#ifdef MV_HS_STAMPS
+    const bool stamp_on = g_hs_stamps != nullptr && blockIdx.x < 32;
+    long long st[4] = {0, 0, 0, 0};
+    int n_st = 0;
+#endif
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int kh = lane >> 5, li = lane & 31;
@@ -1074,13 +1085,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int row = (p * 4 + wave) * RPI + lane / CH, pos = lane % CH;
         lane_src[p] = (unsigned)(row * C + ((pos ^ ((OUT16 ? row >> 1 : row) & 15)) << 3));
     }
-    auto issue_b = [&](int slot) __attribute__((always_inline)) {   // item ld_it -> ring slot, then advance
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
+    auto issue_piece = [&](int slot, int p) __attribute__((always_inline)) {   // piece p (constant after unrolling) of item ld_it -> ring slot
 #ifndef MV_HS_PROBE_NODMA                        // (probe builds: timing only)
-            glds16(ld_ptr + lane_src[p], lds0 + (unsigned)(slot * SLOT + (p * 4 + wave) * 64) * 16u);
+        glds16(ld_ptr + lane_src[p], lds0 + (unsigned)(slot * SLOT + (p * 4 + wave) * 64) * 16u);
 #endif
-        }
+    };
+    auto advance_b = [&]() __attribute__((always_inline)) {          // behind the last piece of an item
         if (ld_it + 1 < it_end) {                // past the end of the run the last item is simply fetched again
             ++ld_it;
             if (++ld_c == ld_cend) {             // next band of the region / next region / next pair
@@ -1097,6 +1107,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             ld_ptr = f2 + ((size_t)ld_b * N2 + (size_t)ld_c * 64) * C;
         }
+    };
+    auto issue_b = [&](int slot) __attribute__((always_inline)) {   // prologue form: the NP pieces as one block
+#pragma unroll
+        for (int p = 0; p < NP; ++p) issue_piece(slot, p);
+        advance_b();
     };
     issue_b(0);
     int slot = 0;
@@ -1130,13 +1145,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // one sub-tile: ring upkeep, 2 x KS MFMAs into (c0, c1); with PREV the 32 stores of (p0, p1) ride between them
     auto step = [&](auto PREV, f32x16& c0, f32x16& c1, const f32x16& p0, const f32x16& p1) __attribute__((always_inline)) {
         constexpr bool HAVE_PREV = decltype(PREV)::value;
+        HS_STAMP(0);
         // this wave's DMA pieces of ring slot `slot` were issued before the last 32 stores (or everything has been drained since);
         // behind the barrier all four waves' pieces are in, and everyone has left slot ^ 1
 #ifndef MV_HS_PROBE_SLACK
 #define MV_HS_PROBE_SLACK 0       // probe builds only (timing; results are then wrong): that many more stores may be in flight at the barrier
 #endif
         wait_vmcnt_barrier<NST + MV_HS_PROBE_SLACK>();
-        issue_b(slot ^ 1);
+        HS_STAMP(1);
+        // Round 6: the NP LDS-DMA pieces of the NEXT item are no longer issued as a block in front of the MFMAs (in-kernel stamps, profiles/r06_hs_stamps.log: the
+        // block took 0.62 of an item's 3.1 us — the wave's VMEM queue is still full of the previous item's stores — with the matrix pipe idle) but DPK per k-step behind
+        // the MFMAs of the first SH k-steps; the stores of the previous item follow in the remaining k-steps (twice as many per k-step in the last SH).  The ORDER of this
+        // wave's memory operations is unchanged (all pieces, then all stores), so the hand-counted vmcnt arithmetic is too.
+        constexpr int SH = KS / 4, DPK = NP / SH;
+        static_assert(NP % SH == 0 && SH >= 1, "pieces per k-step");
+        HS_STAMP(2);
 #pragma unroll
         for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.f;
         const i32x4* q0 = smem_hs + slot * SLOT + (OUT16 ? 2 * li : li) * CH;      // OUT16: even / odd columns (rows 2 li, 2 li + 1 of the B sub-tile)
@@ -1170,13 +1193,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[ks]), __builtin_bit_cast(f16x8, b0), c0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[ks]), __builtin_bit_cast(f16x8, b1), c1, 0, 0, 0);
             }
-            if (HAVE_PREV) {
+            if (ks < SH) {
 #pragma unroll
-                for (int q = 0; q < RPK; ++q) store_r(p0, p1, ks * RPK + q, O - OADV);
+                for (int q = 0; q < DPK; ++q) issue_piece(slot ^ 1, ks * DPK + q);
+                if (ks == SH - 1) advance_b();
+            } else if (HAVE_PREV) {
+                const int first = (ks - SH) * RPK + (ks > KS - SH ? (ks - (KS - SH)) * RPK : 0);
+                const int count = ks >= KS - SH ? 2 * RPK : RPK;
+#pragma unroll
+                for (int q = 0; q < count; ++q) store_r(p0, p1, first + q, O - OADV);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (!HAVE_PREV) wait_vmcnt<0>();         // no stores went out behind this pass's DMA: the next pass's vmcnt(NST) would not cover it
+        HS_STAMP(3);
+#ifdef MV_HS_STAMPS
+        if (stamp_on && (threadIdx.x & 63) == 0 && n_st < 48) {
+            long long* o = g_hs_stamps + (((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 48 + n_st) * 4;
+            o[0] = st[0]; o[1] = st[1]; o[2] = st[2]; o[3] = st[3];
+        }
+        ++n_st;
+#endif
         ++it;
         slot ^= 1;
         O += OADV;
@@ -1424,6 +1461,12 @@ void mv_note_volume_kernel(const char* name) { g_last_vol_kernel = name; }   // 
 static bool stream_items_fit(int B, int N1, int N2) {
     return (size_t)B * (size_t)((N1 + 127) / 128) * (size_t)(N2 / 64) < ((size_t)1 << 31);
 }
+
+#ifdef MV_HS_STAMPS
+extern "C" int mv_hs_probe_stamps(long long* dev_buf) {   // (probe builds only) dev_buf: 32 * 4 * 48 * 4 int64, or NULL to switch the stamps off
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_hs_stamps), &dev_buf, sizeof(dev_buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // the 16-bit streaming kernel's domain and launch (shared by mv_corr_volume and mv_corr_volume_out16)
 static bool h_stream_supported(int B, int C, int N1, int N2) {
