@@ -999,7 +999,8 @@ extern "C" int mv_frame_pipe_seed_lanes(mvFramePipe* p, const uint64_t* seeds) {
             const size_t W = (size_t)mv_randperm_state_words();
             std::vector<uint32_t> st((size_t)p->lanes * W);
             for (int l = 0; l < p->lanes; ++l) MV_TRY(mv_mt19937_seed(seeds[l], st.data() + (size_t)l * W));
-            MV_HIP(hipStreamSynchronize(p->s_back));   // (no front launch may be reading a generator)
+            MV_HIP(hipStreamSynchronize(p->s_back));   // (no front launch may be reading a generator: they run on the backend stream or on the
+            for (int k = 0; k < p->n_lk; ++k) MV_HIP(hipStreamSynchronize(p->s_lk[k]));   //  decoder-side streams)
             MV_HIP(hipMemcpy(p->rp_state[p->n_fin & 1], st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
     }

@@ -941,7 +941,7 @@ class NativeHotPath:
             # 6.24 / 4.07 k frames/s — with hundreds of frames queued the same kernels take 1.6x as long (deep queues of cross-queue barriers), so the default is 2.
             # (Also measured and dropped: flow control on the SELECTOR's event instead of the front launch's — 30 us earlier, i.e. deeper: 5.0 k instead of 5.4 k on
             # the 20-step line — and the host-drawn frame's order, a frame finished only once its selector is done: 5.0 k / 5.9-6.4 k at 300 steps.)
-            lag = int(os.environ.get("MV_PIPE_DD_AHEAD", "2"))
+            lag = min(int(os.environ.get("MV_PIPE_DD_AHEAD", "2")), 6)      # (the driver keeps a ring of 8 front-launch events)
             clock = time.perf_counter
             while nxt is not None:
                 t0 = clock()
