@@ -373,6 +373,9 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 
 
     float* O = nullptr;                          // wave-uniform: column 0 of the CURRENT item's output block (row 0 of the pair)
     unsigned roff[16];                           // per-lane byte offsets of the 16 accumulator rows (C/D layout), fixed for a band segment
+#ifdef MV_SPLIT_PROBE_STORE4
+    unsigned toff[4];                            // (probe) lane l -> row 8 g + l / 8, 16-byte column chunk l % 8
+#endif
     // one output store: accumulator row r of column block j; data straight from the accumulator file ("a": the MFMA results never
     // visit a VGPR)
     // F16: the value is first rescaled by 2^-(row exponent + column exponent) (exact: v_ldexp_f32), `ebj` = the column's exponent
@@ -383,8 +386,26 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 
         }
         if (F16) {
             const float v = __builtin_ldexpf(pj[r], nea[r] - ebj);
+#if defined(MV_SPLIT_PROBE_STORE4)   // timing probe (wrong results): the same BYTES in a quarter of the store instructions — one dwordx4 per four accumulator rows
+            if ((r & 3) == 0) {
+                f32x4 v4 = {v, v, v, v};
+                const unsigned off4 = toff[r >> 2];      // rows 8 g .. 8 g + 7 x 32 columns: exactly what the four dword stores of this group cover
+                if (j == 0) asm volatile("global_store_dwordx4 %0, %1, %2" MV_VOL_STORE_ASM_MOD ::"v"(off4), "v"(v4), "s"(Ob) : "memory");
+                else asm volatile("global_store_dwordx4 %0, %1, %2 offset:128" MV_VOL_STORE_ASM_MOD ::"v"(off4), "v"(v4), "s"(Ob) : "memory");
+            } else {
+                asm volatile("" ::"v"(v));
+            }
+#elif defined(MV_SPLIT_PROBE_STORE1OF4)   // timing probe (wrong results): a quarter of the store instructions AND a quarter of the bytes
+            if ((r & 3) == 0) {
+                if (j == 0) asm volatile("global_store_dword %0, %1, %2" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(v), "s"(Ob) : "memory");
+                else asm volatile("global_store_dword %0, %1, %2 offset:128" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(v), "s"(Ob) : "memory");
+            } else {
+                asm volatile("" ::"v"(v));
+            }
+#else
             if (j == 0) asm volatile("global_store_dword %0, %1, %2" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(v), "s"(Ob) : "memory");
             else asm volatile("global_store_dword %0, %1, %2 offset:128" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "v"(v), "s"(Ob) : "memory");
+#endif
         } else {
             if (j == 0) asm volatile("global_store_dword %0, %1, %2" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "a"(pj[r]), "s"(Ob) : "memory");
             else asm volatile("global_store_dword %0, %1, %2 offset:128" MV_VOL_STORE_ASM_MOD ::"v"(roff[r]), "a"(pj[r]), "s"(Ob) : "memory");
@@ -594,6 +615,11 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             roff[r] = ((unsigned)min(band * 128 + wr * 32 + 4 * kh + (r & 3) + 8 * (r >> 2), N1 - 1) * (unsigned)N2 + li) * 4u;
+#ifdef MV_SPLIT_PROBE_STORE4
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+            toff[gq] = ((unsigned)min(band * 128 + wr * 32 + 8 * gq + (lane >> 3), N1 - 1) * (unsigned)N2 + (unsigned)(lane & 7) * 4u) * 4u;
+#endif
     };
     auto row_exponents = [&]() __attribute__((always_inline)) {   // landed with the last A units (second barrier wait of the first item)
         if (F16) {
