@@ -774,6 +774,10 @@ def main():
         gather_tracks(torch.zeros((steps * lanes, 7), dtype=torch.float32, device=dev), stamps.repeat_interleave(lanes), dist)
         if dist is not None:  # warm the collectives used in / around the timed region (RCCL sets channels up lazily)
             dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=coll_dev), op=dist.ReduceOp.MAX)
+        import gc
+
+        gc.collect()          # ... and no cyclic-GC pass inside the ~3.4 ms timed region (a generation-2 pass over this process' objects is a sizeable fraction of it)
+        gc.disable()
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
@@ -794,13 +798,14 @@ def main():
         last_host.clear()
         if getattr(hot, "device_driven", False) and hot.host_frames > h0[2]:
             nf = hot.host_frames - h0[2]
-            last_host.update({"device_driven": True, "host_threads": 1,
+            last_host.update({"device_driven": True, "host_threads": int(getattr(hot, "host_threads", 1)),
                               "host_issue_us_per_frame": round((hot.host_issue_s - h0[0]) / nf * 1e6, 1),
                               "host_flow_control_wait_us_per_frame": round((hot.host_wait_s - h0[1]) / nf * 1e6, 1),
-                              "note": "timed pass: host time issuing a frame's launches (enqueue + next GEMM + finish: no wait on the GPU anywhere) and time "
-                                      "blocked in the flow control that keeps the host two finished frames ahead of the GPU (= host slack)"})
+                              "note": "timed pass: the CALLER's time issuing a frame's launches (enqueue + next GEMM + finish; with host_threads = 2 the two backend launches are "
+                                      "issued by the launch thread; no wait on the GPU anywhere) and time blocked in the flow control that keeps the host two "
+                                      "finished frames ahead of the GPU (= host slack)"})
         elif native:
-            last_host.update({"device_driven": False, "host_threads": 2, "run_loop_us_per_frame": round(t_run / steps * 1e6, 1)})
+            last_host.update({"device_driven": False, "host_threads": int(getattr(hot, "host_threads", 2)), "run_loop_us_per_frame": round(t_run / steps * 1e6, 1)})
         # the one collective of the job (no-op for N = 1): poses [T,7] + time_ns [T] + T of every rank
         all_poses, _, _ = gather_tracks(poses.reshape(-1, 7), stamps.repeat_interleave(lanes), dist)
         t_gather = time.perf_counter() - t0
@@ -808,6 +813,7 @@ def main():
         barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        gc.enable()
         if trace is not None and rank == 0:
             print("[bench trace] step-finished times (us): " + " ".join(f"{x * 1e6:.0f}" for x in trace[:40]) +
                   f" | run() returned {t_run * 1e6:.0f} | gather issued {t_gather * 1e6:.0f} | synchronized {elapsed * 1e6:.0f}", file=sys.stderr)
@@ -1195,7 +1201,8 @@ def main():
             "rank_core_counts": [len(c) if c else None for c in rank_cores],
             "rank_pose_tracks_finite": rank_tracks_finite,
             "share_gpu_test_mode": bool(args.share_gpu),
-            "host_threads_per_rank": ("1 busy (device-driven frames: no launch thread)" if main_host.get("device_driven") else "2 busy (caller + backend launch thread)") +
+            "host_threads_per_rank": ("%d busy (device-driven frames: the caller%s; nothing waits for the GPU)" % (main_host.get("host_threads", 1), " + the backend launch thread" if main_host.get("host_threads", 1) > 1 else "")
+                                      if main_host.get("device_driven") else "2 busy (caller + backend launch thread)") +
                                      " + a torch pool of %d" % torch.get_num_threads(),
             "hot_path_only": True,
             "hot_path_only_note": "value = the SURVEY 8 hot path with the learned FlowFormer layers' outputs (feature maps, per-iteration coordinates, flow / "

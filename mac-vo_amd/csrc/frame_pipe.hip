@@ -180,6 +180,11 @@ struct mvFramePipe {
     bool seg_valid[N_INEV];
     int alt_indep;               // alt: consecutive frames' segments may overlap (own selector workspace each; NODEPTH selector, no upsampling)
     void* kp_ws2;                // ... the odd frames' workspace
+    int lean_chain;              // device-driven frames with the front launch on the decoder side: fewer packets on the frame's chain — no e_cand / e_seg markers behind
+                                 // the selector (nobody waits for them: the front launch follows in order), the volume buffer is released by the front launch's event
+                                 // instead of a marker behind the lookups.  A marker costs the queue ~6 us, a cross-queue barrier ~10 (rocprofv3 trace, r06_chain_gaps.log)
+    bool cand_recorded[N_CAND];  // e_cand[k] holds this frame's selector segment (lean chain: recorded only when somebody asks)
+    hipEvent_t vol_free_ev[MAX_VOL];   // what the GEMM that rewrites volume buffer k waits for (e_vol_free[k], or the ring event of the frame's front launch)
     int front_on_decoder;        // device-driven alt layout: a frame's front launch (draw + gathers + covariances) runs on the frame's decoder-side stream right
                                  // behind its selector segment (no cross-queue barrier in front of it); the backend stream carries the solves only
 
@@ -622,6 +627,7 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
         return MV_ERR_WORKSPACE;
     }
     p->newest_maps = -1;
+    for (auto& r : p->cand_recorded) r = true;
     {
         const char* e = getenv("MV_PIPE_LOOKUPS_ON");
         p->lookups_on_main = (e && strcmp(e, "vol") == 0) ? 0 : 1;
@@ -651,6 +657,7 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
         // FINISHING workgroup moved in front of the backend on the backend's stream — 5.62 k at 300 steps.)
         // (Also measured and dropped, same log: THREE decoder-side streams — the fourth stream as the third, a frame's whole chain incl. its solve in order on one
         // stream, solves chained across streams by event: bit-identical, 5.3 k instead of 6.7 k frames/s at 300 steps.  More concurrency is not what this pipe lacks.)
+        { const char* e = getenv("MV_PIPE_LEAN"); p->lean_chain = (p->alt && !(e && atoi(e) == 0)) ? 1 : 0; }
         { const char* e = getenv("MV_PIPE_FRONT_ON"); p->front_on_decoder = (p->alt && !(e && strcmp(e, "side") == 0)) ? 1 : 0; }
     }
     const int rc = create_impl(p);
@@ -704,7 +711,7 @@ static int issue_volume(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_s
     MV_HIP(hipEventRecord(e_in, (hipStream_t)in_stream));
     p->e_in_of[k] = e_in;
     MV_TRY(wait_if_pending(p->s_vol, e_in));
-    if (p->vol_free_valid[k]) MV_TRY(wait_if_pending(p->s_vol, p->e_vol_free[k]));
+    if (p->vol_free_valid[k]) MV_TRY(wait_if_pending(p->s_vol, p->vol_free_ev[k] ? p->vol_free_ev[k] : p->e_vol_free[k]));
     const bool timed = p->n_timed < p->timed_cap;
     if (timed && !p->packed) MV_HIP(hipEventRecord(p->tv0[p->n_timed], p->s_vol));
     if (p->packed) {
@@ -762,6 +769,20 @@ extern "C" int mv_frame_pipe_enqueue_volume(mvFramePipe* p, const mvFrameInputs*
     return p->sel_on_back == 3 ? flush_deferred(p) : MV_OK;
 }
 
+// lean chain: the markers behind frame f's selector segment were not recorded; whoever needs them (a host-permuted finish, mv_frame_pipe_wait_candidates, a
+// selector segment that depends on the previous one) records them now, on the frame's decoder-side stream — a later point of the same in-order stream
+static int ensure_chain_events(mvFramePipe* p, long f, int cand_slot) {
+    if (cand_slot >= 0 && !p->cand_recorded[cand_slot]) {
+        MV_HIP(hipEventRecord(p->e_cand[cand_slot], p->s_lk[f % p->n_lk]));
+        p->cand_recorded[cand_slot] = true;
+    }
+    if (p->alt && f >= 0 && !p->seg_valid[f % N_INEV]) {
+        MV_HIP(hipEventRecord(p->e_seg[f % N_INEV], p->s_lk[f % p->n_lk]));
+        p->seg_valid[f % N_INEV] = true;
+    }
+    return MV_OK;
+}
+
 static int issue_selector_segment(mvFramePipe* p, const SelSeg& d) {
     const mvFramePipeConfig& c = p->c;
     const mvFrameInputs* in = &d.in;
@@ -801,7 +822,10 @@ static int issue_selector_segment(mvFramePipe* p, const SelSeg& d) {
     // (alt_indep: NODEPTH selector without upsampling reads nothing of the previous frame and has its own workspace — the segments may overlap and
     // the BACKEND waits for the previous frame's segment instead, finish_issue)
     const bool indep = p->alt_indep && !up && c.selector_mode == MV_KP_NODEPTH;
-    if (p->alt && !indep && d.f > 0 && p->seg_valid[(d.f - 1) % N_INEV]) MV_TRY(wait_if_pending(s, p->e_seg[(d.f - 1) % N_INEV]));
+    if (p->alt && !indep && d.f > 0) {
+        MV_TRY(ensure_chain_events(p, d.f - 1, -1));
+        MV_TRY(wait_if_pending(s, p->e_seg[(d.f - 1) % N_INEV]));
+    }
     void* const kp_ws = (indep && (d.f & 1)) ? p->kp_ws2 : p->kp_ws;
     Maps& mp = p->maps[m];
     constexpr bool fuse_epi = true;   // epilogue + the selector's first kernel in one launch (the separate form was an A/B knob of rounds 2-4)
@@ -847,10 +871,17 @@ static int issue_selector_segment(mvFramePipe* p, const SelSeg& d) {
                                       p->kp_ws_bytes, p->cand_m[k], p->count_m[k], p->stats_m[k], 1, s));
             MV_HIP(hipMemcpyAsync(p->h_count_m[k], p->count_m[k], 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         }
-        MV_HIP(hipEventRecord(p->e_cand[k], s));
+        // lean chain (device-driven, front launch in order behind this segment, segments independent): no marker here — e_cand is recorded on demand
+        // (ensure_cand_event) and nothing waits for e_seg
+        const bool lean = p->lean_chain && p->dev_draw && p->front_on_decoder && indep && !p->sel_on_back && !c.mapping;
+        p->cand_recorded[k] = !lean;
+        if (!lean) MV_HIP(hipEventRecord(p->e_cand[k], s));
         if (timed) MV_HIP(hipEventRecord(p->tv3[ti], s));
-    }
-    if (p->alt) {
+        if (p->alt) {
+            if (!lean) MV_HIP(hipEventRecord(p->e_seg[d.f % N_INEV], s));
+            p->seg_valid[d.f % N_INEV] = !lean;
+        }
+    } else if (p->alt) {
         MV_HIP(hipEventRecord(p->e_seg[d.f % N_INEV], s));
         p->seg_valid[d.f % N_INEV] = true;
     }
@@ -908,7 +939,15 @@ extern "C" int mv_frame_pipe_enqueue(mvFramePipe* p, const mvFrameInputs* in, mv
         MV_HIP(hipStreamWaitEvent(s, p->e_vol_done[kv], 0));   // also orders `s` after e_in (the GEMM stream waited for it)
         for (int it = 0; it < c.iters; ++it)
             MV_TRY(lookup_of(p)(p->vol[kv], in->coords + it * coord_stride, tok[it & 1], B, p->h8, p->w8, p->h8, p->w8, c.radius, s));
-        MV_HIP(hipEventRecord(p->e_vol_free[kv], s));
+        // lean chain: this frame's front launch (same stream, behind the lookups) releases the buffer — its ring event exists before the GEMM that rewrites the
+        // buffer is issued (that GEMM belongs to frame f + n_volbuf, enqueued only after this frame has been finished: MAX_PENDING < n_volbuf)
+        const bool lean = p->lean_chain && p->dev_draw && with_selector && c.num_point > 0 && p->n_volbuf > MAX_PENDING;
+        if (lean) {
+            p->vol_free_ev[kv] = p->e_backend[(p->n_fin + (long)p->pending.size()) % N_BEV];
+        } else {
+            MV_HIP(hipEventRecord(p->e_vol_free[kv], s));
+            p->vol_free_ev[kv] = p->e_vol_free[kv];
+        }
         p->vol_free_valid[kv] = true;
         if (timed) MV_HIP(hipEventRecord(p->tv2[ti], s));
     } else {
@@ -950,6 +989,7 @@ extern "C" int mv_frame_pipe_wait_candidates(mvFramePipe* p, int32_t* n_cand) {
     MV_CHECK_ARG(p && n_cand && !p->pending.empty());
     MV_TRY(selector_of_front_issued(p));
     const Pending& pd = p->pending.front();
+    MV_TRY(ensure_chain_events(p, pd.f, pd.cand));
     MV_HIP(hipEventSynchronize(p->e_cand[pd.cand]));
     if (p->dev_draw)   // (the device-driven pipe has no per-frame count copy)
         MV_HIP(hipMemcpy(p->h_count[pd.cand], p->count[pd.cand], (size_t)p->lanes * 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -980,11 +1020,12 @@ extern "C" int mv_frame_pipe_seed_lanes(mvFramePipe* p, const uint64_t* seeds) {
         const char* e = getenv("MV_PIPE_DEVICE_DRAW");
         const bool want = e ? atoi(e) != 0 : true;
         p->dev_draw = want && p->fuse_backend && !p->c.mapping && p->c.num_point >= 1 && p->c.num_point <= mv_randperm_max_head() && p->pending.empty();
-        if (p->dev_draw && p->async_backend && !p->async_explicit) {
-            // One host thread.  The launch thread existed to overlap the host's draw + the backend launches with the caller's next enqueue while the caller waited
-            // for candidate counts; a device-driven frame has no wait and no draw, and one thread issues it in ~100 us.  Measured (profiles/r06_device_draw_ab.log):
-            // 300 steps 6.35 k (inline) vs 6.50 k (launch thread) frames/s on a 256-core host; pinned to ONE core 5.58 k inline against 3.93 k for the host-drawn
-            // frame with its two hot threads — the headline no longer moves with the host.
+        if (p->dev_draw && p->async_backend && !p->async_explicit && affinity_cores() < 3) {
+            // One host thread on small hosts.  The launch thread existed to overlap the host draw + the backend launches with the caller's next enqueue while the caller
+            // waited for candidate counts; a device-driven frame has no wait and no draw, and one thread issues it in ~105-140 us — about the frame period.  With the lean
+            // chain (below) that is the edge: measured (profiles/r06_chain_gaps.log) one thread 6.99 / 6.85 / 6.64 k frames/s at 300 steps with issue times of 115 / 134 /
+            // 143 us, with the launch thread taking the two backend launches (caller 92-103 us) 6.90 / 6.97 / 6.93 k and no low outliers on the 20-step line; pinned to one
+            // or two cores both forms run at 5.9-6.1 k (the host-drawn frame: 3.9 k on one core).  So: the launch thread stays where the process has >= 3 cores.
             MV_TRY(flush_jobs(p));
             {
                 std::lock_guard<std::mutex> lk(p->mu);
@@ -1008,6 +1049,7 @@ extern "C" int mv_frame_pipe_seed_lanes(mvFramePipe* p, const uint64_t* seeds) {
 }
 
 extern "C" int mv_frame_pipe_device_draw(const mvFramePipe* p) { return p && p->dev_draw ? 1 : 0; }
+extern "C" int mv_frame_pipe_host_threads(const mvFramePipe* p) { return p ? (p->async_backend ? 2 : 1) : 0; }   // the caller's (+ the backend launch thread)
 
 static void randperm_head(std::mt19937& eng, int64_t n, int k, std::vector<int32_t>& r, int64_t* out) {
     if (n <= 0) return;
@@ -1093,6 +1135,7 @@ static int finish_issue(mvFramePipe* p, const FinishJob& j, const int64_t* perm_
         MV_HIP(hipEventRecord(p->e_posed[k], p->s_side));
         MV_HIP(hipEventRecord(p->e_pgo, p->s_side));
         MV_HIP(hipEventRecord(p->e_solved[k], p->s_side));
+        MV_TRY(wait_if_pending(s, p->e_cand[pd.cand]));   // (lean chain: this frame's ring event also releases its volume buffer — not before its lookups are through)
         MV_HIP(hipEventRecord(p->e_backend[g % N_BEV], s));
         p->pgo_valid = true;
         p->solved_valid[k] = true;
@@ -1369,6 +1412,7 @@ extern "C" int mv_frame_pipe_wait_finished(mvFramePipe* p, int lag) {
     const long g = p->n_fin - 1 - lag;
     if (g < 0) return MV_OK;
     MV_TRY(wait_issued(p, g + 1));
+    // (polling with hipEventQuery before blocking was measured: no difference — the wait is 10-40 us per frame and two frames back, profiles/r06_chain_gaps.log)
     MV_HIP(hipEventSynchronize(p->e_backend[g % N_BEV]));
     return MV_OK;
 }
@@ -1392,6 +1436,8 @@ extern "C" int mv_frame_pipe_finish(mvFramePipe* p, const int64_t* perm_host, co
     for (int l = 0; l < p->lanes; ++l)
         MV_CHECK_ARG(n_sel[l] >= 0 && n_sel[l] <= p->c.num_point && (n_sel[l] == 0 || perm_host));
     MV_TRY(selector_of_front_issued(p));
+    MV_TRY(ensure_chain_events(p, p->pending.front().f, p->pending.front().cand));       // (lean chain: a host-permuted finish waits for the markers)
+    if (p->pending.front().f > 0) MV_TRY(ensure_chain_events(p, p->pending.front().f - 1, -1));
     FinishJob j{};
     j.seeded = false;
     MV_TRY(finish_host(p, n_sel, pose_sink, j));

@@ -99,7 +99,7 @@ def test_bench_eight_ranks_sharing_the_gpu(gpu):
         assert d["host_cores_per_rank"] == ncores // 8
     hu = d["rank_host_issue_us_per_frame"]
     assert len(hu) == 8 and all(h is not None and 0 < h < 5000 for h in hu), hu
-    assert d["host"]["device_driven"] is True and d["host"]["host_threads"] == 1
+    assert d["host"]["device_driven"] is True and d["host"]["host_threads"] == (2 if ncores // 8 >= 3 else 1)     # (the launch thread needs a core of its own)
     assert "no scaling curve" in d["multi_gpu_note"]
 
 
