@@ -737,6 +737,7 @@ def main():
     last_timeline: dict = {}
     last_host: dict = {}
     last_period: dict = {}
+    last_region: dict = {}
 
     def measure(lanes, steps, warmup, seed, with_events, precision=None):
         """W untimed + K timed steps of an L-lane pipe.  Returns (elapsed s, poses, per-launch GEMM ms, launches in region)."""
@@ -789,11 +790,10 @@ def main():
             hot.time_volume(n_ev)
         t0 = time.perf_counter()
         # software-pipelined stream (frame t+1's frontend is queued before frame t's host randperm); K full run_pairs
-        trace = [] if os.environ.get("MV_BENCH_TRACE") else None   # host time of every finished step (diagnostics, stderr)
+        trace = []   # host time of every finished step (one perf_counter per step: where a hiccup inside the ~3.4 ms region sat is part of the line)
         h0 = (getattr(hot, "host_issue_s", 0.0), getattr(hot, "host_wait_s", 0.0), getattr(hot, "host_frames", 0))
         for _ in hot.run((batches[(t_idx + k) % args.pool] for k in range(steps)), pose_sink=poses):
-            if trace is not None:
-                trace.append(time.perf_counter() - t0)
+            trace.append(time.perf_counter() - t0)
         t_run = time.perf_counter() - t0
         last_host.clear()
         if getattr(hot, "device_driven", False) and hot.host_frames > h0[2]:
@@ -814,7 +814,16 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         gc.enable()
-        if trace is not None and rank == 0:
+        last_region.clear()
+        if trace:
+            gaps = [b - a for a, b in zip([0.0] + trace[:-1], trace)]
+            gmax = max(range(len(gaps)), key=lambda i: gaps[i])
+            srt = sorted(gaps)
+            last_region.update({"elapsed_us": round(elapsed * 1e6, 1), "run_loop_returned_us": round(t_run * 1e6, 1), "gather_issued_us": round(t_gather * 1e6, 1),
+                                "host_step_interval_us": {"median": round(srt[len(srt) // 2] * 1e6, 1), "max": round(gaps[gmax] * 1e6, 1), "max_at_step": gmax},
+                                "note": "host clock inside the timed region: when the run loop returned its last result, when the pose gather was issued (it waits for the "
+                                        "last frames: the drain), when everything was synchronised; the largest interval between two finished steps and where it sat"})
+        if os.environ.get("MV_BENCH_TRACE") and rank == 0:
             print("[bench trace] step-finished times (us): " + " ".join(f"{x * 1e6:.0f}" for x in trace[:40]) +
                   f" | run() returned {t_run * 1e6:.0f} | gather issued {t_gather * 1e6:.0f} | synchronized {elapsed * 1e6:.0f}", file=sys.stderr)
         if dist is not None:
@@ -892,7 +901,7 @@ def main():
     rank_tracks_finite = [bool(torch.isfinite(main_poses[r]).all() and float(main_poses[r, :, 3:].abs().sum()) > 0) for r in range(main_poses.shape[0])]
     del main_poses
     main_timeline = dict(last_timeline)
-    main_host, main_period = dict(last_host), dict(last_period)
+    main_host, main_period, main_region = dict(last_host), dict(last_period), dict(last_region)
     if vol_events:
         torch.cuda.synchronize()
         ms = [a.elapsed_time(b) for a, b in vol_events[-args.steps:]]
@@ -933,6 +942,26 @@ def main():
         traffic = None
     roofline = roofline_of(ms, args, args.lanes, n_q, C, in_region, traffic) if ms else None
     if roofline is not None:
+        # the committed rocprofv3 --kernel-trace --stats summary of this very command (profiles/r06_bench_kernel_stats.csv): the kernel's own duration (first wave in ->
+        # last wave out), which the HIP-event pair above brackets from outside (it also holds the time the launch waited for CUs behind the pack)
+        try:
+            import csv as _csv
+
+            kname = roofline.get("kernel", "")
+            want = "corr_volume_split_stream<2, true" if "f16x2" in kname else ("corr_volume_split_stream<3, false" if "bf16x3" in kname else None)
+            path = os.path.join(ROOT, "profiles", "r06_bench_kernel_stats.csv")
+            if want and args.lanes == 1 and (H, W) == (480, 640) and os.path.exists(path):
+                for row in _csv.DictReader(open(path)):
+                    if want in row["Name"]:
+                        us = float(row["AverageNs"]) / 1e3
+                        fl = roofline["algorithmic_flops_per_launch"]
+                        roofline["rocprofv3_committed"] = {"file": "profiles/r06_bench_kernel_stats.csv", "avg_launch_us": round(us, 2), "calls": int(row["Calls"]),
+                                                           "frac_executed": round(roofline["executed_flops_per_launch"] / us / 1e6 / PEAK_BF16_MFMA_TFLOPS, 4),
+                                                           "frac_algorithmic": round(fl / us / 1e6 / PEAK_BF16_MFMA_TFLOPS, 4),
+                                                           "note": "NOT measured in this process: the committed trace of the same command on a builder box"}
+                        break
+        except Exception:  # noqa: BLE001
+            pass
         roofline["traffic_source"] = (f"committed rocprofv3 --pmc pass over the same launch configuration (profiles/{traffic_file or '...'}): "
                                       "PMC passes cannot be mixed into a timed run; NOT measured in this process") if traffic is not None else None
     def isolated_us(lanes, precision):
@@ -1210,6 +1239,7 @@ def main():
             "end_to_end_fps": ((end_to_end or {}).get("hooked") or {}).get("fps") if isinstance(end_to_end, dict) else None,
             "period_us_timed_pass": main_period.get("period_us_timed_pass"),
             "host": main_host or None,
+            "timed_region": main_region or None,
             "rank_host_issue_us_per_frame": [None if not h else h.get("host_issue_us_per_frame", h.get("run_loop_us_per_frame")) for h in rank_host],
             "steps": args.steps,
             "warmup": args.warmup,

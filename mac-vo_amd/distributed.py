@@ -33,9 +33,9 @@ def gather_tracks(poses: torch.Tensor, time_ns: torch.Tensor | None = None, dist
         time_ns = torch.zeros((T,), dtype=torch.int64, device=dev)
     assert time_ns.shape == (T,) and time_ns.dtype == torch.int64, "time_ns must be [T] int64"
     if dist is None or not dist.is_initialized():
-        return poses[None], time_ns[None], torch.tensor([T], dtype=torch.int64, device=dev)
+        return poses[None], time_ns[None], torch.full((1,), T, dtype=torch.int64, device=dev)     # (a fill launch: no pageable host-to-device copy, no host wait)
     world = dist.get_world_size()
-    mine = torch.tensor([T], dtype=torch.int64, device=dev)
+    mine = torch.full((1,), T, dtype=torch.int64, device=dev)
     lengths = torch.empty((world,), dtype=torch.int64, device=dev)
     _all_gather(dist, lengths, mine)
     t_max = int(lengths.max().item())
