@@ -541,6 +541,10 @@ def kernels_leg(ops, frames, cam, args, dev, volume_roofline, patch_embed, n_q, 
                 kernel="corr_volume_h_stream<out16> (fp16 features -> fp16 cells: MACVO_Fast.yaml:73-74)")
             hbm("lookup_B2_vol16", period_us(lambda: ops.corr_lookup(v16, fr.coords[0], 4, out=tok), 240), P * (n_q * 100 * 2 + n_q * 8 + n_q * 81 * 4.0),
                 kernel="corr_lookup on fp16 cells")
+            vt16 = ops.corr_volume_out16(h1, h2, tiled=True)
+            hbm("lookup_B2_vol16_tiled", period_us(lambda: ops.corr_lookup(vt16, fr.coords[0], 4, out=tok, tiled=True), 240),
+                P * (n_q * 100 * 2 + n_q * 8 + n_q * 81 * 4.0), kernel="corr_lookup_tiled on fp16 cells in 4 x 4 tiles (one 32-B sector each)")
+            del vt16
         del h1, h2, v16
     except Exception as e:  # noqa: BLE001
         out["volume_out16"] = {"error": repr(e)[:200]}
@@ -602,9 +606,20 @@ def kernels_leg(ops, frames, cam, args, dev, volume_roofline, patch_embed, n_q, 
             co = fr.coords[0].repeat(32, 1, 1, 1)
             tb = torch.empty((64, 81, h8, w8), dtype=torch.float32, device=dev)
             hbm("lookup_B64", period_us(lambda: ops.corr_lookup(vb, co, 4, out=tb), 40, 8), 64 * (n_q * 100 * 4 + n_q * 8 + n_q * 81 * 4.0), kernel="corr_lookup_kernel (configs[4]: 64 pairs)")
-            del vb, tb, co
+            del vb
+            # ... and Fast mode's 2-byte cells: row-major and in 4 x 4 tiles
+            h1 = torch.randn(64, h8, w8, C, device=dev).half()
+            h2 = torch.randn(64, h8, w8, C, device=dev).half()
+            b16 = 64 * (n_q * 100 * 2 + n_q * 8 + n_q * 81 * 4.0)
+            v16 = ops.corr_volume_out16(h1, h2)
+            if v16 is not None:
+                hbm("lookup_B64_vol16", period_us(lambda: ops.corr_lookup(v16, co, 4, out=tb), 40, 8), b16, kernel="corr_lookup on fp16 cells (64 pairs)")
+                ops.corr_volume_out16(h1, h2, out=v16, tiled=True)
+                hbm("lookup_B64_vol16_tiled", period_us(lambda: ops.corr_lookup(v16, co, 4, out=tb, tiled=True), 40, 8), b16,
+                    kernel="corr_lookup_tiled on fp16 cells in 4 x 4 tiles (64 pairs)")
+            del v16, h1, h2, tb, co
         except Exception as e:  # noqa: BLE001
-            out["lookup_B64"] = {"error": repr(e)[:200]}
+            out.setdefault("lookup_B64", {"error": repr(e)[:200]})
     torch.cuda.empty_cache()
     return out
 

@@ -25,6 +25,53 @@
 
 namespace {
 
+// One axis entry of a query — what RAFT's normalise + ATen's un-normalise make of (coordinate + offset): the bilinear weight and the clamped
+// cell offset in the staged block | (1 << 8) when the tap's 2-cell span lies inside the block.  The axis passes write the 2 K entries of
+// every query of the wave into LDS; the tap phase reads them back per (tap, query) PAIR.
+struct AxisEntry { float w; int c; };
+
+// Tap phase shared by the lookup kernels (round 6): the wave's QPW * K * K (tap, query) pairs are dealt over its lanes — 324 pairs = 6 rounds
+// of 64 for four queries where "lane = tap, one query after the other" takes 8 rounds of which every second one has 17 live lanes — and a
+// pair fetches its two axis entries with two 8-byte LDS reads where the lane = tap form used four ds_bpermute.  The arithmetic per pair is
+// the ATen bilinear sum of before, term for term.
+template <int K, int QPW, int STRIDE, int CELLS>
+__device__ __forceinline__ void tap_pairs(const float* blk, const AxisEntry (*ax)[2 * K], int lane, float (&res)[(QPW * K * K + 63) / 64]) {
+    constexpr int KK = K * K, NPAIR = QPW * KK, NR = (NPAIR + 63) / 64;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int pair = min(r * 64 + lane, NPAIR - 1);
+        const int s = pair / KK, tap = pair - s * KK;
+        const int ti = tap / K, tj = tap - ti * K;
+        const AxisEntry X = ax[s][ti], Y = ax[s][K + tj];
+        const float w = X.w, n = Y.w;
+        const bool inblk = ((X.c & Y.c) & 256) != 0;
+        const float* p = &blk[s * CELLS + (Y.c & 255) * STRIDE + (X.c & 255)];
+        const float e = 1.f - w, so = 1.f - n;
+        const float vnw = inblk ? p[0] : 0.f, vne = inblk ? p[1] : 0.f;
+        const float vsw = inblk ? p[STRIDE] : 0.f, vse = inblk ? p[STRIDE + 1] : 0.f;
+        // ATen: (nw_val*nw + ne_val*ne) + sw_val*sw + se_val*se with nw = s*e, ne = s*w, sw = n*e, se = n*w
+        float r0 = vnw * (so * e);
+        r0 = r0 + vne * (so * w);
+        r0 = r0 + vsw * (n * e);
+        r0 = r0 + vse * (n * w);
+        res[r] = r0;
+    }
+}
+
+// ... and its results into the transpose buffer: outs[tap][query of the workgroup]
+template <int K, int QPW, int QPB>
+__device__ __forceinline__ void tap_pairs_out(float (*outs)[QPB + 1], int wave, int lane, const float (&res)[(QPW * K * K + 63) / 64]) {
+    constexpr int KK = K * K, NPAIR = QPW * KK, NR = (NPAIR + 63) / 64;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int pair = r * 64 + lane;
+        if (pair < NPAIR) {
+            const int s = pair / KK, tap = pair - s * KK;
+            outs[tap][wave * QPW + s] = res[r];
+        }
+    }
+}
+
 // VT = float, or _Float16 for the Fast-mode volume that is STORED in the encoder's 16-bit type (mv_corr_volume_out16: what
 // `einsum` returns when the encoder runs in fp16, Config/Experiment/MACVO/MACVO_Fast.yaml:73-74; flownet.py:27 only widens it): the cells
 // are widened on load — exactly `cost_maps.float()` — and everything behind the load is the fp32 arithmetic of the fp32 form.
@@ -49,7 +96,6 @@ __global__ __launch_bounds__(64 * (QPB / QPW)) void corr_lookup_kernel(const VT*
     // lookup (configs[4]: 882 -> ~680 B per query), one load round less for the latency-bound one.  Results unchanged bit for bit.
     constexpr bool TRIM = (BS - 2) % RPR == 0;      // inner rows are a whole number of wave-wide loads (r = 4: 10 = 2 x 5)
     constexpr int NINNER = (BS - 2) / RPR;          // ... this many
-    constexpr int TAP_ROUNDS = (KK + 63) / 64;      // 2 for r = 4
     constexpr int QPA = 64 / (2 * K);               // queries one axis pass covers (3 for r = 4)
     constexpr int APASS = (QPW + QPA - 1) / QPA;
     static_assert(QPW <= 32 && (QPW & (QPW - 1)) == 0 && QPB % QPW == 0, "bad lookup tiling");
@@ -124,21 +170,20 @@ __global__ __launch_bounds__(64 * (QPB / QPW)) void corr_lookup_kernel(const VT*
     const bool a_is_y = aa >= K;
     const int aoff = (a_is_y ? aa - K : aa) - R;
     const float adim = a_is_y ? hm1 : wm1;
-    float ax_w[APASS];
-    int ax_c[APASS];   // clamped cell offset in the block | (1 << 8) when the tap's 2-cell span lies inside the block
+    __shared__ AxisEntry ax_all[NWAVE][QPW][2 * K];
+    AxisEntry (*ax)[2 * K] = ax_all[wave];
 #pragma unroll
     for (int ps = 0; ps < APASS; ++ps) {
-        const int s = ps * QPA + asq;   // lanes with s >= QPW compute garbage nobody reads
+        const int s = ps * QPA + asq;   // lanes with s >= QPW compute garbage nobody keeps
         const float qx = __shfl(x, s, 64), qy = __shfl(y, s, 64);
         const int obx = __shfl(bx, s, 64), oby = __shfl(by, s, 64);
         const float cs = (a_is_y ? qy : qx) + (float)aoff;
         const float g = (2.f * cs) / adim - 1.f;          // RAFT bilinear_sampler normalisation
         const float ic = (g + 1.f) * (adim / 2.f);        // ATen grid_sampler_unnormalize, align_corners=True
         const float f0 = floorf(ic);
-        ax_w[ps] = ic - f0;
         const int c = (int)fminf(fmaxf(f0, -2.0e6f), 2.0e6f) - (a_is_y ? oby : obx);
         const bool inb = c >= 0 && c <= BS - 2;
-        ax_c[ps] = min(max(c, 0), BS - 2) | (inb ? 256 : 0);
+        if (asq < QPA && s < QPW) ax[s][aa] = AxisEntry{ic - f0, min(max(c, 0), BS - 2) | (inb ? 256 : 0)};
     }
 
 #pragma unroll
@@ -156,40 +201,11 @@ __global__ __launch_bounds__(64 * (QPB / QPW)) void corr_lookup_kernel(const VT*
     }
     __syncthreads();
 
-    // ---- taps: lane -> (i, j)
-    float res[TAP_ROUNDS][QPW];
-#pragma unroll
-    for (int tr = 0; tr < TAP_ROUNDS; ++tr) {
-        const int tap = tr * 64 + lane;
-        const int ti = tap / K, tj = tap - ti * K;
-#pragma unroll
-        for (int s = 0; s < QPW; ++s) {
-            const int ps = s / QPA, sq = s - ps * QPA;
-            const int srcx = sq * 2 * K + ti, srcy = sq * 2 * K + K + tj;
-            const float w = __shfl(ax_w[ps], srcx, 64), n = __shfl(ax_w[ps], srcy, 64);
-            const int pcx = __shfl(ax_c[ps], srcx, 64), pcy = __shfl(ax_c[ps], srcy, 64);
-            const bool inblk = ((pcx & pcy) & 256) != 0;
-            const float* p = &blk[s * CELLS + (pcy & 255) * BS + (pcx & 255)];
-            const float e = 1.f - w, so = 1.f - n;
-            const float vnw = inblk ? p[0] : 0.f, vne = inblk ? p[1] : 0.f;
-            const float vsw = inblk ? p[BS] : 0.f, vse = inblk ? p[BS + 1] : 0.f;
-            // ATen: (nw_val*nw + ne_val*ne) + sw_val*sw + se_val*se with nw = s*e, ne = s*w, sw = n*e, se = n*w
-            float r0 = vnw * (so * e);
-            r0 = r0 + vne * (so * w);
-            r0 = r0 + vsw * (n * e);
-            r0 = r0 + vse * (n * w);
-            res[tr][s] = r0;
-        }
-    }
+    // ---- taps: (tap, query) pairs over the lanes
+    float res[(QPW * KK + 63) / 64];
+    tap_pairs<K, QPW, BS, CELLS>(blk, ax, lane, res);
     __syncthreads();   // every wave is done reading the staged blocks: the region becomes the output transpose buffer
-#pragma unroll
-    for (int tr = 0; tr < TAP_ROUNDS; ++tr) {
-        const int tap = tr * 64 + lane;
-        if (tap < KK) {
-#pragma unroll
-            for (int s = 0; s < QPW; ++s) outs[tap][wave * QPW + s] = res[tr][s];
-        }
-    }
+    tap_pairs_out<K, QPW, QPB>(outs, wave, lane, res);
     __syncthreads();
 
     // ---- transposed store: each channel row = QPB consecutive queries
@@ -208,14 +224,21 @@ __global__ __launch_bounds__(64 * (QPB / QPW)) void corr_lookup_kernel(const VT*
 // used DRAM bursts.  Staging: a wave-wide load = one tile row of the 4 x 4 tile grid that covers the block (lane = tile column x 16
 // cells); tiles outside the needed cell range or the image are skipped / zero.  The staged block is 16 x 16 cells anchored at the
 // first tile; axis math, tap phase and the transposed store are those of corr_lookup_kernel (r = 4 only), results bit-identical.
-template <int QPW, int QPB>
-__global__ __launch_bounds__(64 * (QPB / QPW)) void corr_lookup_tiled_kernel(const float* __restrict__ vol,
+//
+// VT = _Float16 (round 6): the Fast-mode volume's 2-byte cells in the same tile order (mv_fmap_tile_rows16 permutes operand 2's
+// pixel rows in front of mv_corr_volume_out16).  A tile is then ONE aligned 32-byte sector: a query's block costs ~10.6 sectors = 338 B where
+// the row-major fp16 volume costs 10 row segments of 20 B that straddle sectors (1.6 each: ~512 B).  Staging: a lane fetches two
+// neighbouring cells as one dword, so a wave-wide load covers two tile rows and a query needs two loads; the cells are widened on load
+// (`cost_maps.float()`, exact) and everything behind the load is the fp32 arithmetic above — tokens bit-identical to
+// mv_corr_lookup_vol16 on the row-major volume.
+template <int QPW, int QPB, typename VT = float>
+__global__ __launch_bounds__(64 * (QPB / QPW)) void corr_lookup_tiled_kernel(const VT* __restrict__ vol,
                                                                               const float* __restrict__ coords,
                                                                               float* __restrict__ out, int N1, int H2, int W2) {
     constexpr int R = 4, K = 9, KK = 81;
-    constexpr int BS = 16, CELLS = 256;        // staged block: 4 x 4 tiles of 4 x 4 cells
+    constexpr int BS = 16;                     // staged block: 4 x 4 tiles of 4 x 4 cells ...
+    constexpr int BSP = 18, CELLS = BS * BSP;  // ... at a row stride of 18 floats: the 9 rows a wave's taps read sit in 9 different banks (16: rows y, y + 2 collide)
     constexpr int NWAVE = QPB / QPW, NTHR = 64 * NWAVE;
-    constexpr int TAP_ROUNDS = (KK + 63) / 64;
     constexpr int QPA = 64 / (2 * K);
     constexpr int APASS = (QPW + QPA - 1) / QPA;
     constexpr int BLK_STRIDE = QPW * CELLS;
@@ -245,8 +268,12 @@ __global__ __launch_bounds__(64 * (QPB / QPW)) void corr_lookup_tiled_kernel(con
     const int y_lo = by + ((fry < 0.01f) ? 0 : 1), y_hi = by + ((fry > 0.99f) ? K + 2 : K + 1);
     const int tox = bx >> 2, toy = by >> 2;                          // first tile (floor division: arithmetic shift)
 
-    // ---- stage: per query four wave-wide loads (tile rows), lane = (tile column, cell)
-    const int ti = lane >> 4, cell = lane & 15;
+    // ---- stage.  fp32 cells: per query four wave-wide loads (tile rows), lane = (tile column, cell).  fp16 cells: two loads of two tile
+    //      rows each, lane = (tile row of the pair, tile column, cell pair)
+    constexpr bool H16 = sizeof(VT) == 2;
+    constexpr int NLD = H16 ? 2 : 4;
+    const int ti = H16 ? (lane >> 3) & 3 : lane >> 4, cell = H16 ? (lane & 7) * 2 : lane & 15;
+    const int half_row = H16 ? lane >> 5 : 0;
     float v[QPW][4];
 #pragma unroll
     for (int s = 0; s < QPW; ++s) {
@@ -254,14 +281,21 @@ __global__ __launch_bounds__(64 * (QPB / QPW)) void corr_lookup_tiled_kernel(con
         const int sxl = __builtin_amdgcn_readlane(x_lo, s), sxh = __builtin_amdgcn_readlane(x_hi, s);
         const int syl = __builtin_amdgcn_readlane(y_lo, s), syh = __builtin_amdgcn_readlane(y_hi, s);
         const int q = q0 + wave * QPW + s;
-        const float* __restrict__ base = vol + ((size_t)b * N1 + q) * slice;
+        const VT* __restrict__ base = vol + ((size_t)b * N1 + q) * slice;
         const int tx = stx + ti;
         const bool okx = q < N1 && tx >= 0 && tx < tpr && 4 * tx + 3 >= sxl && 4 * tx <= sxh;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int ty = sty + k;
+        for (int k = 0; k < NLD; ++k) {
+            const int ty = sty + (H16 ? 2 * k + half_row : k);
             const bool ok = okx && ty >= 0 && ty < tpc && 4 * ty + 3 >= syl && 4 * ty <= syh;
-            v[s][k] = ok ? base[((ty * tpr + tx) << 4) + cell] : 0.f;
+            if constexpr (H16) {
+                union { uint32_t u; _Float16 h[2]; } two;
+                two.u = ok ? *reinterpret_cast<const uint32_t*>(base + ((ty * tpr + tx) << 4) + cell) : 0u;
+                v[s][2 * k] = (float)two.h[0];
+                v[s][2 * k + 1] = (float)two.h[1];
+            } else {
+                v[s][k] = ok ? (float)base[((ty * tpr + tx) << 4) + cell] : 0.f;
+            }
         }
     }
 
@@ -271,8 +305,8 @@ __global__ __launch_bounds__(64 * (QPB / QPW)) void corr_lookup_tiled_kernel(con
     const bool a_is_y = aa >= K;
     const int aoff = (a_is_y ? aa - K : aa) - R;
     const float adim = a_is_y ? hm1 : wm1;
-    float ax_w[APASS];
-    int ax_c[APASS];
+    __shared__ AxisEntry ax_all[NWAVE][QPW][2 * K];
+    AxisEntry (*ax)[2 * K] = ax_all[wave];
 #pragma unroll
     for (int ps = 0; ps < APASS; ++ps) {
         const int s = ps * QPA + asq;
@@ -282,50 +316,27 @@ __global__ __launch_bounds__(64 * (QPB / QPW)) void corr_lookup_tiled_kernel(con
         const float g = (2.f * cs) / adim - 1.f;
         const float ic = (g + 1.f) * (adim / 2.f);
         const float f0 = floorf(ic);
-        ax_w[ps] = ic - f0;
         const int c = (int)fminf(fmaxf(f0, -2.0e6f), 2.0e6f) - (a_is_y ? oby : obx);
         const bool inb = c >= 0 && c <= BS - 2;
-        ax_c[ps] = min(max(c, 0), BS - 2) | (inb ? 256 : 0);
+        if (asq < QPA && s < QPW) ax[s][aa] = AxisEntry{ic - f0, min(max(c, 0), BS - 2) | (inb ? 256 : 0)};
     }
 
 #pragma unroll
     for (int s = 0; s < QPW; ++s)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) blk[s * CELLS + (4 * k + (cell >> 2)) * BS + 4 * ti + (cell & 3)] = v[s][k];
+        for (int k = 0; k < NLD; ++k) {
+            if constexpr (H16)      // the pair sits in one cell row of the tile, at an even column: one 8-byte LDS write
+                *reinterpret_cast<float2*>(&blk[s * CELLS + (4 * (2 * k + half_row) + (cell >> 2)) * BSP + 4 * ti + (cell & 3)]) =
+                    make_float2(v[s][2 * k], v[s][2 * k + 1]);
+            else
+                blk[s * CELLS + (4 * k + (cell >> 2)) * BSP + 4 * ti + (cell & 3)] = v[s][k];
+        }
     __syncthreads();
 
-    float res[TAP_ROUNDS][QPW];
-#pragma unroll
-    for (int tr = 0; tr < TAP_ROUNDS; ++tr) {
-        const int tap = tr * 64 + lane;
-        const int tpi = tap / K, tpj = tap - tpi * K;
-#pragma unroll
-        for (int s = 0; s < QPW; ++s) {
-            const int ps = s / QPA, sq = s - ps * QPA;
-            const int srcx = sq * 2 * K + tpi, srcy = sq * 2 * K + K + tpj;
-            const float w = __shfl(ax_w[ps], srcx, 64), n = __shfl(ax_w[ps], srcy, 64);
-            const int pcx = __shfl(ax_c[ps], srcx, 64), pcy = __shfl(ax_c[ps], srcy, 64);
-            const bool inblk = ((pcx & pcy) & 256) != 0;
-            const float* p = &blk[s * CELLS + (pcy & 255) * BS + (pcx & 255)];
-            const float e = 1.f - w, so = 1.f - n;
-            const float vnw = inblk ? p[0] : 0.f, vne = inblk ? p[1] : 0.f;
-            const float vsw = inblk ? p[BS] : 0.f, vse = inblk ? p[BS + 1] : 0.f;
-            float r0 = vnw * (so * e);
-            r0 = r0 + vne * (so * w);
-            r0 = r0 + vsw * (n * e);
-            r0 = r0 + vse * (n * w);
-            res[tr][s] = r0;
-        }
-    }
+    float res[(QPW * KK + 63) / 64];
+    tap_pairs<K, QPW, BSP, CELLS>(blk, ax, lane, res);
     __syncthreads();
-#pragma unroll
-    for (int tr = 0; tr < TAP_ROUNDS; ++tr) {
-        const int tap = tr * 64 + lane;
-        if (tap < KK) {
-#pragma unroll
-            for (int s = 0; s < QPW; ++s) outs[tap][wave * QPW + s] = res[tr][s];
-        }
-    }
+    tap_pairs_out<K, QPW, QPB>(outs, wave, lane, res);
     __syncthreads();
     for (int idx = t; idx < KK * QPB; idx += NTHR) {
         const int k = idx / QPB, c = idx - k * QPB;
@@ -410,5 +421,53 @@ extern "C" int mv_corr_lookup_tiled(const float* vol, const float* coords, float
         hipLaunchKernelGGL((corr_lookup_tiled_kernel<2, 16>), dim3(mv_ceil_div(N1, 16), B), dim3(512), 0, s, vol, coords, out, N1, H2, W2);
     else
         hipLaunchKernelGGL((corr_lookup_tiled_kernel<4, 32>), dim3(mv_ceil_div(N1, 32), B), dim3(512), 0, s, vol, coords, out, N1, H2, W2);
+    return mv_launch_status();
+}
+
+
+// ... and on a TILED volume of fp16 cells: mv_fmap_tile_rows16 on operand 2 + mv_corr_volume_out16 (radius 4, H2 and W2 multiples of 4)
+extern "C" int mv_corr_lookup_tiled_vol16(const void* vol, const float* coords, float* out, int B, int H1, int W1, int H2, int W2, int radius,
+                                          mvStream_t stream) {
+    MV_CHECK_ARG(vol && coords && out);
+    MV_CHECK_ARG(B > 0 && H1 > 0 && W1 > 0 && H2 > 1 && W2 > 1);
+    MV_CHECK_ARG(((uintptr_t)vol & 31) == 0);                            // a tile = one 32-byte sector
+    if (radius != 4 || (H2 % 4) || (W2 % 4) || B > 65535) return MV_ERR_UNSUPPORTED;
+    const int N1 = H1 * W1;
+    hipStream_t s = (hipStream_t)stream;
+    const _Float16* v = reinterpret_cast<const _Float16*>(vol);
+    if ((size_t)B * N1 <= (size_t)lookup_small_threshold())
+        hipLaunchKernelGGL((corr_lookup_tiled_kernel<2, 16, _Float16>), dim3(mv_ceil_div(N1, 16), B), dim3(512), 0, s, v, coords, out, N1, H2, W2);
+    else
+        hipLaunchKernelGGL((corr_lookup_tiled_kernel<4, 32, _Float16>), dim3(mv_ceil_div(N1, 32), B), dim3(512), 0, s, v, coords, out, N1, H2, W2);
+    return mv_launch_status();
+}
+
+// The pixel rows of a 16-bit HWC feature map [B, H, W, C] in 4 x 4-tile order: out[b][(ty * W/4 + tx) * 16 + (y % 4) * 4 + x % 4][:] =
+// f[b][y * W + x][:].  As operand 2 of mv_corr_volume_out16 it makes the unchanged GEMM write every query's slice tiled (each output element
+// is the same k-ordered sum wherever its column sits) — the 16-bit twin of mv_volume_pack_tiled's permutation.  One 16-byte chunk per thread.
+namespace {
+__global__ __launch_bounds__(256) void fmap_tile_rows16_kernel(const uint4* __restrict__ f, uint4* __restrict__ out, int N, int W, int cpr, size_t total) {
+    const int tpr = W >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t rowi = i / cpr;
+        const int ch = (int)(i - rowi * cpr);
+        const size_t b = rowi / N;
+        const int j = (int)(rowi - b * N);
+        const int tile = j >> 4, cell = j & 15;
+        const int ty = tile / tpr, tx = tile - ty * tpr;
+        const int src = (4 * ty + (cell >> 2)) * W + 4 * tx + (cell & 3);
+        out[i] = f[(b * N + src) * cpr + ch];
+    }
+}
+}  // namespace
+
+extern "C" int mv_fmap_tile_rows16(const void* f, void* out, int B, int C, int H, int W, mvStream_t stream) {
+    MV_CHECK_ARG(f && out && f != out && B > 0 && C > 0 && H > 0 && W > 0);
+    MV_CHECK_ARG(((uintptr_t)f & 15) == 0 && ((uintptr_t)out & 15) == 0);
+    if ((C % 8) || (H % 4) || (W % 4)) return MV_ERR_UNSUPPORTED;
+    const int cpr = C / 8;
+    const size_t total = (size_t)B * H * W * cpr;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(fmap_tile_rows16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)f, (uint4*)out, H * W, W, cpr, total);
     return mv_launch_status();
 }

@@ -146,6 +146,7 @@ struct mvFramePipe {
     // volume_split = MV_PACK_BF16X3: packed three-piece operands of the streaming split GEMM, two sets (the pack of frame f + 1 may
     // run beside the GEMM of frame f); `packed` = the shape is covered by the streaming kernel (exact fp32 kernel otherwise)
     void* pk[2][2];
+    void* tile16;      // vol16 && tiled: operand 2 with its pixel rows in 4 x 4-tile order (mv_fmap_tile_rows16; written and read on the GEMM's stream)
     size_t pk_bytes;
     bool packed;
     bool vol16;        // volume_split = MV_VOL_ENC16 on a shape the out16 kernel covers: 2-byte cells (Fast mode as the reference computes it)
@@ -332,6 +333,8 @@ static size_t carve(mvFramePipe* p, char* base) {
     p->pk_bytes = p->packed ? mv_volume_pack_bytes((int)B, c.C, (int)n8, c.volume_split) : 0;
     for (int k = 0; k < 2; ++k)
         for (int o = 0; o < 2; ++o) p->pk[k][o] = p->packed ? (void*)a.take<char>(p->pk_bytes) : nullptr;
+    // (carved for every Fast-mode pipe whose shape the tiled form covers — the sizing call knows the configuration, not MV_PIPE_TILED: 2 % of the volume buffers)
+    p->tile16 = (c.volume_split == MV_VOL_ENC16 && c.radius == 4 && p->h8 % 4 == 0 && p->w8 % 4 == 0) ? (void*)a.take<uint16_t>(B * n8 * c.C) : nullptr;
     p->up_flow = a.take<float>(B * 2 * plane);
     p->up_cov = a.take<float>(B * 2 * plane);
     for (int k = 0; k < N_MAPS; ++k) {   // every map is [lanes, ch, H, W]
@@ -597,7 +600,8 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
         // -> off by default.
         const char* e = getenv("MV_PIPE_TILED");
         const bool want = e ? atoi(e) != 0 : false;
-        p->tiled = want && p->packed && cfg->radius == 4 && (p->h8 % 4) == 0 && (p->w8 % 4) == 0;
+        // [r6] Fast mode's 2-byte cells: a tile is one 32-byte sector (mv_corr_lookup_tiled_vol16: B = 64 alone 115 -> 79 us)
+        p->tiled = want && (p->packed || p->vol16) && cfg->radius == 4 && (p->h8 % 4) == 0 && (p->w8 % 4) == 0;
     }
     {
         // MV_PIPE_SELECTOR_ON=back: the selector segment of a frame (epilogue, NMS, finishing workgroup, count copy: ~60 us beside the
@@ -698,7 +702,13 @@ typedef int (*mvLookupFn)(const float*, const float*, float*, int, int, int, int
 static int lookup_vol16_as_float_ptr(const float* vol, const float* coords, float* out, int B, int H1, int W1, int H2, int W2, int radius, mvStream_t s) {
     return mv_corr_lookup_vol16(vol, coords, out, B, H1, W1, H2, W2, radius, s);      // (the arena pointer is typed float*; the cells are fp16)
 }
-static mvLookupFn lookup_of(const mvFramePipe* p) { return p->vol16 ? lookup_vol16_as_float_ptr : (p->tiled ? mv_corr_lookup_tiled : mv_corr_lookup); }
+static int lookup_tiled_vol16_as_float_ptr(const float* vol, const float* coords, float* out, int B, int H1, int W1, int H2, int W2, int radius, mvStream_t s) {
+    return mv_corr_lookup_tiled_vol16(vol, coords, out, B, H1, W1, H2, W2, radius, s);
+}
+static mvLookupFn lookup_of(const mvFramePipe* p) {
+    if (p->vol16) return p->tiled ? lookup_tiled_vol16_as_float_ptr : lookup_vol16_as_float_ptr;
+    return p->tiled ? mv_corr_lookup_tiled : mv_corr_lookup;
+}
 
 // volume GEMM of frame n_vol on its own stream; a buffer is rewritten only after the lookups that read it have finished
 static int issue_volume(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_stream) {
@@ -742,7 +752,12 @@ static int issue_volume(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_s
         MV_TRY(mv_corr_volume(p->planes[0], p->planes[1], p->vol[k], B, c.C, p->n8, p->n8,
                               c.volume_split == 2 ? MV_BF16X2 : MV_BF16X3, MV_LAYOUT_HWC, p->s_vol));
     } else if (p->vol16) {
-        MV_TRY(mv_corr_volume_out16(in->fmap1, in->fmap2, p->vol[k], B, c.C, p->n8, p->n8, c.feat_dtype, c.layout, p->s_vol));
+        const void* op2 = in->fmap2;
+        if (p->tiled) {
+            MV_TRY(mv_fmap_tile_rows16(in->fmap2, p->tile16, B, c.C, p->h8, p->w8, p->s_vol));
+            op2 = p->tile16;
+        }
+        MV_TRY(mv_corr_volume_out16(in->fmap1, op2, p->vol[k], B, c.C, p->n8, p->n8, c.feat_dtype, c.layout, p->s_vol));
     } else {
         MV_TRY(mv_corr_volume(in->fmap1, in->fmap2, p->vol[k], B, c.C, p->n8, p->n8, c.feat_dtype, c.layout, p->s_vol));
     }

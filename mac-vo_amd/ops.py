@@ -212,18 +212,32 @@ def corr_lookup(cost_maps: torch.Tensor, coords: torch.Tensor, radius: int = 4, 
     K = 2 * radius + 1
     if out is None:
         out = torch.empty((B, K * K, H1, W1), dtype=torch.float32, device=coords.device)
-    if vol16 and tiled:
-        raise L.MacvoHipError("corr_lookup: the tiled form reads fp32 volumes")
-    fn = lib.mv_corr_lookup_vol16 if vol16 else (lib.mv_corr_lookup_tiled if tiled else lib.mv_corr_lookup)
-    L.check(fn(cost_maps.data_ptr(), coords.data_ptr(), out.data_ptr(), B, H1, W1, H2, W2, radius, _stream()),
-            "mv_corr_lookup_vol16" if vol16 else ("mv_corr_lookup_tiled" if tiled else "mv_corr_lookup"))
+    name = "mv_corr_lookup" + ("_tiled" if tiled else "") + ("_vol16" if vol16 else "")
+    L.check(getattr(lib, name)(cost_maps.data_ptr(), coords.data_ptr(), out.data_ptr(), B, H1, W1, H2, W2, radius, _stream()), name)
     return out
 
 
-def corr_volume_out16(f1: torch.Tensor, f2: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor | None:
+def fmap_tile_rows16(f: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """A 16-bit HWC feature map ``[B, H, W, C]`` with its pixel rows in 4 x 4-tile order (``mv_fmap_tile_rows16``): operand 2 of
+    ``corr_volume_out16`` for a tiled Fast-mode volume."""
+    lib = L.load()
+    if f.dtype not in (torch.float16, torch.bfloat16) or f.dim() != 4:
+        raise L.MacvoHipError("fmap_tile_rows16: a [B, H, W, C] float16 / bfloat16 feature map")
+    f = _req(f, f.dtype, "f")
+    B, H, W, Cc = f.shape
+    if out is None:
+        out = torch.empty_like(f)
+    L.check(lib.mv_fmap_tile_rows16(f.data_ptr(), out.data_ptr(), B, Cc, H, W, _stream()), "mv_fmap_tile_rows16")
+    return out
+
+
+def corr_volume_out16(f1: torch.Tensor, f2: torch.Tensor, out: torch.Tensor | None = None, tiled: bool = False,
+                      scratch: torch.Tensor | None = None) -> torch.Tensor | None:
     """Fast mode (enc_dtype fp16 / bf16, MACVO_Fast.yaml:73-74): the volume in the encoder's 16-bit type — what ``einsum`` returns there and
     flownet.py:27 widens — rounded ONCE in the GEMM's epilogue.  ``f1, f2 [B, H, W, C]`` (HWC) fp16 / bf16 -> ``[B*H1*W1, 1, H2, W2]`` of that
-    dtype; ``None`` for shapes outside the streaming kernel's domain (callers then cast ``corr_volume``'s fp32 result)."""
+    dtype; ``None`` for shapes outside the streaming kernel's domain (callers then cast ``corr_volume``'s fp32 result).
+    ``tiled``: every slice in 4 x 4-cell tiles (``fmap_tile_rows16`` on ``f2`` first, into ``scratch`` if given) for
+    ``corr_lookup(..., tiled=True)``."""
     lib = L.load()
     if f1.dtype not in (torch.float16, torch.bfloat16) or f1.dtype != f2.dtype or f1.dim() != 4:
         raise L.MacvoHipError("corr_volume_out16: [B, H, W, C] float16 / bfloat16 feature maps")
@@ -236,6 +250,8 @@ def corr_volume_out16(f1: torch.Tensor, f2: torch.Tensor, out: torch.Tensor | No
         return None
     if out is None:
         out = torch.empty((B * N1, 1, H2, W2), dtype=f1.dtype, device=f1.device)
+    if tiled:
+        f2 = fmap_tile_rows16(f2, out=scratch)
     L.check(lib.mv_corr_volume_out16(f1.data_ptr(), f2.data_ptr(), out.data_ptr(), B, Cc, N1, N2, dt, L.MV_LAYOUT_HWC, _stream()),
             "mv_corr_volume_out16")
     return out

@@ -68,6 +68,70 @@ def test_lookup_on_the_fp16_volume_equals_the_lookup_on_its_widened_copy(gpu, B,
             torch.testing.assert_close(t16.cpu(), corr.corr_lookup(wide.cpu(), coords, 4), rtol=1e-5, atol=2e-4)
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C", [(2, 60, 80, 256), (3, 48, 64, 128), (1, 8, 8, 256)])
+def test_tiled_16bit_volume_is_the_row_major_one_permuted(gpu, dt, B, H, W, C):
+    """`mv_fmap_tile_rows16` puts operand 2's pixel rows in 4 x 4-tile order; the unchanged out16 GEMM then writes every query's slice tiled —
+    each cell the same k-ordered sum with the same one rounding, wherever its column sits: bit-equal to the row-major volume permuted."""
+    from macvo_amd import ops
+
+    f1, f2 = _feats(B, H, W, C, dt, seed=W)
+    d1, d2 = f1.to(gpu), f2.to(gpu)
+    t2 = ops.fmap_tile_rows16(d2)
+    want = f2.view(B, H // 4, 4, W // 4, 4, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)       # [b][ty][tx][4][4][C]
+    assert torch.equal(t2.cpu(), want)
+    v = ops.corr_volume_out16(d1, d2)
+    vt = ops.corr_volume_out16(d1, d2, tiled=True)
+    if v is None:                                                        # 8 x 8: outside the streaming kernel's domain
+        assert vt is None
+        return
+    unt = vt.view(B * H * W, H // 4, W // 4, 4, 4).permute(0, 1, 3, 2, 4).reshape(B * H * W, 1, H, W)
+    assert torch.equal(unt, v)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 60, 80), (4, 48, 64), (14, 60, 80)])
+def test_tiled_lookup_on_fp16_cells_equals_the_row_major_lookup(gpu, B, H, W):
+    """`mv_corr_lookup_tiled_vol16` on the tiled fp16 volume returns `mv_corr_lookup_vol16`'s tokens on the row-major one bit
+    for bit — coordinates inside, across the border, far outside, on / next to integers (the margin-tile predicate), both kernel variants
+    ((14, 60, 80) is above the small-launch threshold) — and so equals the fp32 lookup on the widened volume (flownet.py:27)."""
+    from macvo_amd import ops
+    from oracle import corr
+
+    f1, f2 = _feats(B, H, W, 256, torch.float16, seed=11)
+    d1, d2 = f1.to(gpu), f2.to(gpu)
+    v = ops.corr_volume_out16(d1, d2)
+    vt = ops.corr_volume_out16(d1, d2, tiled=True)
+    assert v is not None and vt is not None
+    wide = v.float()
+    g = torch.Generator().manual_seed(9)
+    eps = torch.tensor([0.0, 1.2e-7, -1.2e-7, 1e-4, -1e-4, 9.9e-3, -9.9e-3, 1.01e-2, -1.01e-2, 0.3, 0.5, -0.4])
+    for it in range(3):
+        pick = torch.randint(0, len(eps), (B, 2, H, W), generator=g)
+        shift = torch.randint(-7, 8, (B, 2, H, W), generator=g).float()
+        coords = corr.coords_grid(B, H, W) + shift + eps[pick] + (torch.rand(B, 2, H, W, generator=g) * 4 - 2) * (it == 2)
+        if it == 1:
+            coords[:, :, 0, 0] = 1000.0                                   # far outside: zeros
+            coords[:, 0, 1, 1] = -3.0                                     # window across the left border
+            coords[:, :, 2, 2] = float("nan")
+        cd = coords.to(gpu)
+        a = ops.corr_lookup(v, cd, 4)
+        b_ = ops.corr_lookup(vt, cd, 4, tiled=True)
+        assert torch.equal(a, b_) or torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b_, nan=7.0)), it
+        if it == 0:
+            assert torch.equal(a, ops.corr_lookup(wide, cd, 4))
+
+
+def test_tiled_fp16_lookup_rejects_what_it_does_not_cover(gpu):
+    from macvo_amd import _lib as L, ops
+
+    vol = torch.zeros(6 * 6, 1, 6, 6, dtype=torch.float16, device=gpu)    # 6 % 4 != 0
+    co = torch.zeros(1, 2, 6, 6, device=gpu)
+    with pytest.raises(L.MacvoHipError):
+        ops.corr_lookup(vol, co, 4, tiled=True)
+    with pytest.raises(L.MacvoHipError):
+        ops.fmap_tile_rows16(torch.zeros(1, 6, 8, 16, dtype=torch.float16, device=gpu))
+
+
 def test_flowformer_hook_returns_the_16bit_volume_in_one_pass(gpu):
     """install_flowformer_hooks on a model whose encoder runs in fp16: `memory_encoder.corr` returns the fp16 volume of the out16 kernel
     (no fp32 volume + cast in between) — equal to what the fp32 kernel + one cast gave in round 3."""
@@ -125,3 +189,47 @@ def test_frame_driver_with_the_volume_stored_in_the_encoder_dtype(gpu):
         assert torch.equal(rh.kp0_uv.cpu(), ro["kp0_uv"])
         dt, dr = se3.pose_error(ro["pose"].double(), rh.pose.cpu().double())
         assert dt <= 1e-4 and dr <= 1e-4, (t, dt, dr)
+
+
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_frame_driver_tiled_fp16_volume_equals_the_row_major_one(gpu, monkeypatch, lanes):
+    """`MV_PIPE_TILED=1` on a Fast-mode pipe: operand 2's pixel rows go through `mv_fmap_tile_rows16` in front of the out16 GEMM and the lookups are
+    `mv_corr_lookup_tiled_vol16` — tokens, keypoints and poses of the same pipe with the row-major fp16 volume, bit for bit."""
+    from macvo_amd.pipeline import Camera, FrameInputs, HotPathConfig, NativeHotPath, stack_lanes
+    from tests import synth
+
+    n_frames = 4
+    seqs = [synth.make_sequence(n_frames, 480, 640, C=256, iters=3, seed=300 + l, pool=1) for l in range(lanes)]
+    cam = seqs[0][0]
+
+    def to16(fr):
+        d = dict(fr, fmap1=fr["fmap1"].permute(0, 2, 3, 1).contiguous().half(), fmap2=fr["fmap2"].permute(0, 2, 3, 1).contiguous().half())
+        return FrameInputs(**{k: v.to(gpu) for k, v in d.items()})
+
+    per_lane = [[to16(seqs[l][1][t]) for l in range(lanes)] for t in range(n_frames)]
+    batched = [fl[0] if lanes == 1 else stack_lanes(fl) for fl in per_lane]
+    torch.cuda.synchronize()
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MV_PIPE_TILED", flag)
+        hot = NativeHotPath(Camera(**cam), HotPathConfig(num_point=100, feature_layout="hwc", volume_store="encoder"), gpu, lanes=lanes,
+                            generators=list(range(5, 5 + lanes)))
+        hot.initialize(batched[0])
+        toks, kps, poses = [], [], []
+        for t in range(1, n_frames):
+            res = hot.step(batched[t])
+            res = res if isinstance(res, (list, tuple)) else [res]
+            toks.append(hot.last_tokens.clone())
+            kps.append([r.kp0_uv.clone() for r in res])
+            poses.append(torch.stack([r.pose for r in res]).clone())
+        torch.cuda.synchronize()
+        outs.append((toks, kps, poses))
+        hot.close()
+        del hot
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a, b)
+    for fa, fb in zip(outs[0][1], outs[1][1]):
+        for a, b in zip(fa, fb):
+            assert torch.equal(a, b)
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(a, b) and a.abs().sum().item() > 0

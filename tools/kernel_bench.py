@@ -156,6 +156,10 @@ def main():
                         tok = ops.corr_lookup(v16, co, 4)
                         med, mn = timeit(lambda: ops.corr_lookup(v16, co, 4, out=tok), a.iters)
                         print(f"lookup_vol16 B={B} {med:8.1f} us (min {mn:.1f})")
+                        vt = ops.corr_volume_out16(a1, a2, tiled=True)
+                        med, mn = timeit(lambda: ops.corr_lookup(vt, co, 4, out=tok, tiled=True), a.iters)
+                        print(f"lookup_vol16_tiled B={B} {med:8.1f} us (min {mn:.1f})")
+                        del vt
                         v32 = v16.float()
                         med, mn = timeit(lambda: ops.corr_lookup(v32, co, 4, out=tok), a.iters)
                         print(f"lookup_vol32 B={B} {med:8.1f} us (min {mn:.1f})")
