@@ -78,6 +78,7 @@ def parse_args():
     ap.add_argument("--parity-frames", type=int, default=48, help="free-running frames compared with the oracle (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the parity leg")
     ap.add_argument("--config4-steps", type=int, default=100, help="steps of the extra configs[4] leg (32 lanes); 0 = skip")
+    ap.add_argument("--fast-mode-steps", type=int, default=200, help="steps of the extra Fast-mode leg (fp16 features, fp16-stored tiled volume: one lane, then 32 lanes for a fifth of them); 0 = skip")
     ap.add_argument("--graphs", action="store_true", help="replay the decoder-side segment (12 lookups + epilogue + selector) as a hipGraph (measured slower than eager launches on ROCm 7.2: 2.46 k vs 2.60 k fps)")
     ap.add_argument("--driver", choices=["native", "python"], default="native",
                     help="host-side frame sequencing: the C++ driver (mv_frame_pipe_*) or the Python loop over the per-op entry points")
@@ -225,7 +226,10 @@ def volume_lookup_parity(ops, frames, cfr, args, n_q, C, dev, picks, make_pipe):
         hot.initialize(frames[(k - 1) % len(frames)])
         hot.step(fr)
         torch.cuda.synchronize()
-        vol = hot._view("VOLUME", 0, torch.float16 if enc16 else torch.float32, (P * n_q, 1, h8, w8))
+        vol_pipe = hot._view("VOLUME", 0, torch.float16 if enc16 else torch.float32, (P * n_q, 1, h8, w8))
+        tiled = bool(getattr(hot, "volume_tiled", False))     # Fast-mode pipes keep the slices in 4 x 4-cell tiles: the row-major view of the same cells for the checks
+        vol = vol_pipe.view(P * n_q, h8 // 4, w8 // 4, 4, 4).permute(0, 1, 3, 2, 4).reshape(P * n_q, 1, h8, w8) if tiled else vol_pipe
+        out["volume_tiled"] = tiled
         pipe_tok = hot.last_tokens.clone()
         out["volume_kernel"] = ops.last_volume_kernel()
         f1 = fc["fmap1"].reshape(P, C, n_q).double()          # cfr is CHW fp32 on the CPU
@@ -253,13 +257,13 @@ def volume_lookup_parity(ops, frames, cfr, args, n_q, C, dev, picks, make_pipe):
         ok = ok and bool(torch.allclose(pipe_tok.cpu(), rlast, rtol=1e-5, atol=2e-4))     # the tokens the pipe's own last lookup wrote
         out["pipe_tokens_checked"] += 1
         for it in range(n_it):
-            tok = ops.corr_lookup(vol, fr.coords[it], 4).cpu()      # the same lookup kernel the pipe runs (fp16-cell form under enc16), on the pipe's buffer
+            tok = ops.corr_lookup(vol_pipe, fr.coords[it], 4, tiled=tiled).cpu()      # the same lookup kernel the pipe runs (fp16-cell / tiled form under enc16), on the pipe's buffer
             rtok = rlast if it == n_it - 1 else ocorr.corr_lookup(volc, fc["coords"][it], 4)
             out["lookup_launches"] += 1
             out["lookup_max_abs_err"] = max(out["lookup_max_abs_err"], float((tok - rtok).abs().max()))
             ok = ok and bool(torch.allclose(tok, rtok, rtol=1e-5, atol=2e-4))
         hot.close()          # (result objects keep their pipe alive: close it, do not just drop the name — pipeline.NativeHotPath.close)
-        del hot, vol
+        del hot, vol, vol_pipe
     out["volume_within_bar"] = bool(vol_ok)
     out["within_bar"] = bool(ok and vol_ok)
     return out
@@ -722,17 +726,33 @@ def main():
 
     frames = [FrameInputs(static=True, **{k: to_dev(v) for k, v in fr.items()}) for fr in frames_cpu]
 
-    def lane_batches(lanes):
+    frames16: list = []
+
+    def fast_frames():
+        """The same frames as the encoder of MACVO_Fast.yaml:73-74 hands them over: fp16 HWC feature maps (built once, for the fast-mode leg)."""
+        if not frames16:
+            for fr in frames_cpu:
+                f1, f2 = fr["fmap1"], fr["fmap2"]
+                if args.layout == "chw":
+                    f1, f2 = f1.permute(0, 2, 3, 1), f2.permute(0, 2, 3, 1)
+                d = dict(fr, fmap1=f1.contiguous().half().to(dev), fmap2=f2.contiguous().half().to(dev))
+                frames16.append(FrameInputs(static=True, **{k: (v if v.is_cuda else to_dev(v)) for k, v in d.items()}))
+        return frames16
+
+    def lane_batches(lanes, fast=False):
         """Step t of an L-lane pipe = frames (t + l) % pool of the closed trajectory, l = 0..L-1: every lane is the same
         kind of sequence at a different phase (consecutive frames per lane), stacked along the pair axis."""
+        src = fast_frames() if fast else frames
         if lanes == 1:
-            return frames
-        return [stack_lanes([frames[(t + l) % args.pool] for l in range(lanes)]) for t in range(args.pool)]
+            return src
+        return [stack_lanes([src[(t + l) % args.pool] for l in range(lanes)]) for t in range(args.pool)]
 
-    def make_pipe(lanes, seed, precision=None, keep_extras=False):
+    def make_pipe(lanes, seed, precision=None, keep_extras=False, fast=False):
         cfg = HotPathConfig(graph_type=args.graph, feature_layout=args.layout,
                             volume_precision=(precision or args.volume_precision) if args.feat_dtype == "f32" else "exact",
                             volume_store=args.volume_store, use_graphs=use_graphs)
+        if fast:
+            cfg = HotPathConfig(graph_type=args.graph, feature_layout="hwc", volume_precision="exact", volume_store="encoder")
         if native:
             # lanes > 1: integer seeds = the driver's native per-lane MT19937 generators (bit-identical to torch.Generator(seed) +
             # torch.randperm; 32 host-side torch.randperm calls per step were the bound of the 32-lane configuration)
@@ -754,10 +774,10 @@ def main():
     last_period: dict = {}
     last_region: dict = {}
 
-    def measure(lanes, steps, warmup, seed, with_events, precision=None):
+    def measure(lanes, steps, warmup, seed, with_events, precision=None, fast=False):
         """W untimed + K timed steps of an L-lane pipe.  Returns (elapsed s, poses, per-launch GEMM ms, launches in region)."""
-        batches = lane_batches(lanes)
-        hot = make_pipe(lanes, seed, precision)
+        batches = lane_batches(lanes, fast)
+        hot = make_pipe(lanes, seed, precision, fast=fast)
         torch.manual_seed(seed)  # the selector consumes the global CPU generator (reference behaviour) when lanes == 1
         hot.initialize(batches[0])
         t_idx = 1
@@ -1141,6 +1161,26 @@ def main():
             except Exception as e:  # noqa: BLE001
                 parity = {"volume_and_lookups": {"error": repr(e)[:300]}, "within_north_star": False, "rte_vs_oracle": {"mean": None}}
 
+    # ---- Fast mode (MACVO_Fast.yaml:73-74: the encoder in fp16, so `einsum` returns — and the decoder reads — a 16-bit volume): the same frames as fp16 HWC
+    # feature maps through mv_corr_volume_out16 (2-byte cells, tiled) + mv_corr_lookup_tiled_vol16.  A second workload, not the headline's configuration.
+    # (Runs BEFORE the configs[4] leg: on this HIP stack a one-lane pipe — three normal-priority streams + one high-priority — created after a batched pipe —
+    # two + two — has been destroyed maps two of its streams onto one hardware queue and runs 3.7x slower: 2.3 k instead of 8.4 k frames/s, profiles/r06_fast_mode.log.)
+    fast_mode = None
+    if (rank == 0 and world == 1 and native and args.fast_mode_steps > 0 and args.lanes == 1 and (H, W) == (480, 640) and args.feat_dtype == "f32"
+            and C in (128, 256)):
+        try:
+            ef1 = measure(1, args.fast_mode_steps, 10, 2468, False, fast=True)[0]
+            ef32 = measure(32, max(args.fast_mode_steps // 5, 10), 10, 2469, False, fast=True)[0]
+            fast_mode = {"workload": "MACVO_Fast.yaml:73-74 arithmetic on the headline's frames: fp16 HWC feature maps, cost volume STORED in fp16 by the GEMM's epilogue "
+                                     "(mv_corr_volume_out16) in 4 x 4-cell tiles (mv_fmap_tile_rows16), lookups on the 2-byte cells (mv_corr_lookup_tiled_vol16)",
+                         "one_lane": {"value": round(args.fast_mode_steps / ef1, 2), "unit": "stereo frames/s", "steps": args.fast_mode_steps},
+                         "lanes_32": {"value": round(32 * max(args.fast_mode_steps // 5, 10) / ef32, 2), "unit": "stereo frames/s", "steps": max(args.fast_mode_steps // 5, 10)},
+                         "parity": "tests/test_gpu_fastmode.py (cells = the fp32 accumulators rounded once; tokens bit-equal to the fp32 lookup on the widened volume; "
+                                   "pipe vs the oracle's Fast-mode arithmetic)"}
+            frames16.clear()
+        except Exception as e:  # noqa: BLE001
+            fast_mode = {"error": repr(e)[:300]}
+
     # ---- configs[4]: batch-32 frames per GPU (B = 64 pairs per GEMM) — a short second measurement, N = 1 only
     config4 = None
     if rank == 0 and world == 1 and native and args.config4_steps > 0 and args.lanes == 1 and (H, W) == (480, 640):
@@ -1293,6 +1333,7 @@ def main():
             "cpu_baseline": cpu_baseline,
             "parity": parity,
             "config4": config4,
+            "fast_mode": fast_mode,
             "decoder_loop": decoder_loop,
             "patch_embed": patch_embed,
             "kernels": kernels,

@@ -760,6 +760,9 @@ int mv_randperm_heads_emulated(uint64_t seed, const int64_t* n, int calls, int k
  * itself.  Same keypoints, same poses as mv_frame_pipe_finish_seeded.  mv_frame_pipe_finished_counts: the counts of the age-th newest finished frame
  * (0 or 1), for whoever needs them on the host (blocks until that frame's front launch has run). */
 int mv_frame_pipe_device_draw(const mvFramePipe* p);
+/* 1 when the pipe's volume buffers (the VOLUME view) hold every query's slice in 4 x 4-cell tiles (mv_corr_lookup_tiled / _tiled_vol16 read them):
+ * Fast-mode pipes by default, split-precision pipes under MV_PIPE_TILED=1 */
+int mv_frame_pipe_volume_tiled(const mvFramePipe* p);
 int mv_frame_pipe_host_threads(const mvFramePipe* p);   /* 1: the caller issues everything; 2: + the backend launch thread (default where the process has >= 3 cores) */
 int mv_frame_pipe_finish_device(mvFramePipe* p, float* pose_sink);
 int mv_frame_pipe_finished_counts(mvFramePipe* p, int age, int32_t* n_cand, int32_t* n_sel);

@@ -188,6 +188,7 @@ SIGNATURES = {
     "mv_frame_pipe_time_detail": (C.c_int, [_P, C.c_int]),
     "mv_randperm_heads": (C.c_int, [C.c_uint64, _P, C.c_int, C.c_int, _P]),
     "mv_frame_pipe_device_draw": (C.c_int, [_P]),
+    "mv_frame_pipe_volume_tiled": (C.c_int, [_P]),
     "mv_frame_pipe_host_threads": (C.c_int, [_P]),
     "mv_frame_pipe_finish_device": (C.c_int, [_P, _P]),
     "mv_frame_pipe_finished_counts": (C.c_int, [_P, C.c_int, _P, _P]),

@@ -604,6 +604,8 @@ class NativeHotPath:
             # inside the backend's front launch, `finish` never waits for the GPU (csrc/frame_pipe.hip, csrc/randperm_dev.h; MV_PIPE_DEVICE_DRAW=0 restores
             # the host draw).  Same keypoints, same poses (tests/test_gpu_lanes.py).
             self.device_driven = bool(lib.mv_frame_pipe_device_draw(pipe))
+        # the volume buffers hold every query's slice in 4 x 4-cell tiles (Fast-mode pipes; MV_PIPE_TILED): read them with corr_lookup(tiled=True)
+        self.volume_tiled = bool(lib.mv_frame_pipe_volume_tiled(pipe))
         self.host_threads = int(lib.mv_frame_pipe_host_threads(pipe))      # 1, or 2 with the backend launch thread
         self._counts_cache: dict = {}
         self.host_issue_s = self.host_wait_s = 0.0

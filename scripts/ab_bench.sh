@@ -5,7 +5,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
-Q="--exact-steps 0 --config4-steps 0 --no-decoder-leg --end-to-end-frames 0 --plugin-frames 0 --no-cpu-baseline --no-kernel-events ${AB_EXTRA:-}"
+Q="--exact-steps 0 --config4-steps 0 --fast-mode-steps 0 --no-decoder-leg --end-to-end-frames 0 --plugin-frames 0 --no-cpu-baseline --no-kernel-events ${AB_EXTRA:-}"
 for spec in "$@"; do
   lab=${spec%%:*}; rest=${spec#*:}; st=${rest%%:*}; envs=${rest#*:}
   IFS=',' read -r -a kv <<< "$envs"

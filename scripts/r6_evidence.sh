@@ -21,7 +21,7 @@ import json
 d = json.loads([l for l in open("gpurun_out/${T}_bench_default_line.json") if l.startswith("{")][-1])
 print("default steps", d["steps"], "value", d["value"], "ms/step", d["ms_per_step"], "period", d.get("period_us_timed_pass"))
 PY
-Q="--exact-steps 0 --config4-steps 0 --no-decoder-leg --end-to-end-frames 0 --plugin-frames 0 --no-cpu-baseline"
+Q="--exact-steps 0 --config4-steps 0 --fast-mode-steps 0 --no-decoder-leg --end-to-end-frames 0 --plugin-frames 0 --no-cpu-baseline"
 OUT=gpurun_out/kprof_$T; rm -rf $OUT; mkdir -p $OUT
 ( cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT" -o trace -- python $R/bench.py --steps 20 --warmup 5 $Q ) > $OUT/run.log 2>&1
 cp $(find $OUT -name "*kernel_stats.csv" | head -1) gpurun_out/${T}_bench_kernel_stats.csv 2>/dev/null; grep '^{' $OUT/run.log | tail -1 > gpurun_out/${T}_bench_traced_line.json

@@ -2,7 +2,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 R=$PWD
-Q="--exact-steps 0 --config4-steps 0 --no-decoder-leg --end-to-end-frames 0 --plugin-frames 0 --no-cpu-baseline --no-kernel-events --no-ramp"
+Q="--exact-steps 0 --config4-steps 0 --fast-mode-steps 0 --no-decoder-leg --end-to-end-frames 0 --plugin-frames 0 --no-cpu-baseline --no-kernel-events --no-ramp"
 OUT=gpurun_out/ktrace_r06; rm -rf $OUT; mkdir -p $OUT
 ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d "$R/$OUT" -o trace -- python $R/bench.py --steps 120 --warmup 5 $Q ) > $OUT/run.log 2>&1
 F=$(find $OUT -name "*kernel_trace.csv" | head -1); echo $F; wc -l $F

@@ -13,7 +13,7 @@ import pytest
 from tests import refrun
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-QUICK = ["--no-ramp", "--exact-steps", "0", "--config4-steps", "0", "--no-decoder-leg", "--pool", "6", "--end-to-end-frames", "0", "--plugin-frames", "0"]
+QUICK = ["--no-ramp", "--exact-steps", "0", "--config4-steps", "0", "--fast-mode-steps", "0", "--no-decoder-leg", "--pool", "6", "--end-to-end-frames", "0", "--plugin-frames", "0"]
 
 
 def _line(p):
@@ -122,11 +122,13 @@ def test_bench_line_carries_a_roofline_per_kernel(gpu):
     """`kernels{}` — one entry per SURVEY §8(d) kernel, measured alone (HIP events, back to back) in the run itself, with the
     algorithmic bytes / FLOPs the fractions are computed from — and the patch-embedding leg with its Fast-mode (16-bit in / out) form."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--no-cpu-baseline", "--no-ramp", "--exact-steps", "0", "--config4-steps", "0",
-           "--pool", "6", "--end-to-end-frames", "0", "--plugin-frames", "0"]
+           "--fast-mode-steps", "20", "--pool", "6", "--end-to-end-frames", "0", "--plugin-frames", "0"]
     d = _line(subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT))
+    fm = d["fast_mode"]                                                  # the Fast-mode leg: fp16 features, tiled fp16-stored volume, one lane and 32
+    assert "error" not in fm and fm["one_lane"]["value"] > 0 and fm["lanes_32"]["value"] > 0, fm
     k = d["kernels"]
     assert "error" not in k, k
-    for name in ("volume", "lookup_B2", "lookup_B64", "volume_out16", "lookup_B2_vol16", "convex_upsample", "convex_upsample_bf16_mask", "patch_embed",
+    for name in ("volume", "lookup_B2", "lookup_B64", "volume_out16", "lookup_B2_vol16", "lookup_B2_vol16_tiled", "lookup_B64_vol16", "lookup_B64_vol16_tiled", "convex_upsample", "convex_upsample_bf16_mask", "patch_embed",
                  "patch_embed_fast_mode", "selector", "covariance", "solve"):
         assert name in k and "error" not in k[name], (name, k.get(name))
         assert k[name]["us"] > 0
