@@ -226,9 +226,10 @@ def volume_lookup_parity(ops, frames, cfr, args, n_q, C, dev, picks, make_pipe):
         hot.initialize(frames[(k - 1) % len(frames)])
         hot.step(fr)
         torch.cuda.synchronize()
-        vol_pipe = hot._view("VOLUME", 0, torch.float16 if enc16 else torch.float32, (P * n_q, 1, h8, w8))
-        tiled = bool(getattr(hot, "volume_tiled", False))     # Fast-mode pipes keep the slices in 4 x 4-cell tiles: the row-major view of the same cells for the checks
-        vol = vol_pipe.view(P * n_q, h8 // 4, w8 // 4, 4, 4).permute(0, 1, 3, 2, 4).reshape(P * n_q, 1, h8, w8) if tiled else vol_pipe
+        tiled = bool(getattr(hot, "volume_tiled", False))     # Fast-mode pipes keep the slices in 4 x 4-cell tiles (a padded last tile row when h8 % 4 != 0):
+        hp = -(-h8 // 4) * 4 if tiled else h8                 # ... the row-major view of the same cells for the checks
+        vol_pipe = hot._view("VOLUME", 0, torch.float16 if enc16 else torch.float32, (P * n_q, 1, hp, w8))
+        vol = vol_pipe.view(P * n_q, hp // 4, w8 // 4, 4, 4).permute(0, 1, 3, 2, 4).reshape(P * n_q, 1, hp, w8)[:, :, :h8].contiguous() if tiled else vol_pipe
         out["volume_tiled"] = tiled
         pipe_tok = hot.last_tokens.clone()
         out["volume_kernel"] = ops.last_volume_kernel()
@@ -257,7 +258,7 @@ def volume_lookup_parity(ops, frames, cfr, args, n_q, C, dev, picks, make_pipe):
         ok = ok and bool(torch.allclose(pipe_tok.cpu(), rlast, rtol=1e-5, atol=2e-4))     # the tokens the pipe's own last lookup wrote
         out["pipe_tokens_checked"] += 1
         for it in range(n_it):
-            tok = ops.corr_lookup(vol_pipe, fr.coords[it], 4, tiled=tiled).cpu()      # the same lookup kernel the pipe runs (fp16-cell / tiled form under enc16), on the pipe's buffer
+            tok = ops.corr_lookup(vol_pipe, fr.coords[it], 4, tiled=tiled, image_hw=(h8, w8) if (tiled and enc16) else None).cpu()      # the same lookup kernel the pipe runs (fp16-cell / tiled form under enc16), on the pipe's buffer
             rtok = rlast if it == n_it - 1 else ocorr.corr_lookup(volc, fc["coords"][it], 4)
             out["lookup_launches"] += 1
             out["lookup_max_abs_err"] = max(out["lookup_max_abs_err"], float((tok - rtok).abs().max()))

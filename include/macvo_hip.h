@@ -172,10 +172,13 @@ int mv_corr_lookup_tiled(const float* vol, const float* coords, float* out, int 
 
 /* Round 6: the tiled form for the Fast-mode volume's 2-byte cells.  mv_fmap_tile_rows16 writes the pixel rows of a 16-bit HWC feature map
  * [B, H, W, C] in 4 x 4-tile order (out[b][((y / 4) * (W / 4) + x / 4) * 16 + (y % 4) * 4 + x % 4][:] = f[b][y * W + x][:]; C % 8 == 0,
- * H % 4 == W % 4 == 0, out != f); as operand 2 of mv_corr_volume_out16 it makes the unchanged GEMM — the same `einsum` of
+ * W % 4 == 0, out != f; ceil(H / 4) tile rows, the rows y >= H of the last one zero pixels: out is [B, mv_tiled_slice_cells(H, W), C]);
+ * as operand 2 of mv_corr_volume_out16 (with N2 = mv_tiled_slice_cells) it makes the unchanged GEMM — the same `einsum` of
  * Module/Network/FlowFormerCov/flownet.py:26 — write every query's slice in the tile order above, where a tile is one aligned 32-byte
  * sector.  mv_corr_lookup_tiled_vol16 is mv_corr_lookup_vol16 (covhead.py:92 on `cost_maps.float()`) on that layout: ~338 B instead of
- * ~512 B per query, tokens bit-identical.  vol 32-byte aligned; radius == 4, H2 % 4 == W2 % 4 == 0 (MV_ERR_UNSUPPORTED otherwise). */
+ * ~512 B per query, tokens bit-identical; a slice is mv_tiled_slice_cells(H2, W2) cells (the padding cells are exact zeros = the lookup's zero
+ * padding).  vol 32-byte aligned; radius == 4, W2 % 4 == 0 (MV_ERR_UNSUPPORTED otherwise). */
+int mv_tiled_slice_cells(int H, int W);   /* ceil(H / 4) * 4 * W; 0 when W % 4 != 0 */
 int mv_fmap_tile_rows16(const void* f, void* out, int B, int C, int H, int W, mvStream_t stream);
 int mv_corr_lookup_tiled_vol16(const void* vol_f16, const float* coords, float* out, int B, int H1, int W1, int H2, int W2, int radius,
                                mvStream_t stream);

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * (QPB / QPW)) void corr_lookup_tiled_kernel(con
     const int b = blockIdx.y;
     const int q0 = blockIdx.x * QPB;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int slice = H2 * W2, tpr = W2 >> 2, tpc = H2 >> 2;
+    const int tpr = W2 >> 2, tpc = (H2 + 3) >> 2, slice = tpc * tpr * 16;   // (fp16 cells: H2 need not be a multiple of 4 — the last tile row is padded with zero cells)
 
     const int qmine = q0 + wave * QPW + (lane & (QPW - 1));
     float x = 0.f, y = 0.f;
@@ -431,7 +431,7 @@ extern "C" int mv_corr_lookup_tiled_vol16(const void* vol, const float* coords, 
     MV_CHECK_ARG(vol && coords && out);
     MV_CHECK_ARG(B > 0 && H1 > 0 && W1 > 0 && H2 > 1 && W2 > 1);
     MV_CHECK_ARG(((uintptr_t)vol & 31) == 0);                            // a tile = one 32-byte sector
-    if (radius != 4 || (H2 % 4) || (W2 % 4) || B > 65535) return MV_ERR_UNSUPPORTED;
+    if (radius != 4 || (W2 % 4) || B > 65535) return MV_ERR_UNSUPPORTED;
     const int N1 = H1 * W1;
     hipStream_t s = (hipStream_t)stream;
     const _Float16* v = reinterpret_cast<const _Float16*>(vol);
@@ -443,31 +443,36 @@ extern "C" int mv_corr_lookup_tiled_vol16(const void* vol, const float* coords, 
 }
 
 // The pixel rows of a 16-bit HWC feature map [B, H, W, C] in 4 x 4-tile order: out[b][(ty * W/4 + tx) * 16 + (y % 4) * 4 + x % 4][:] =
-// f[b][y * W + x][:].  As operand 2 of mv_corr_volume_out16 it makes the unchanged GEMM write every query's slice tiled (each output element
-// is the same k-ordered sum wherever its column sits) — the 16-bit twin of mv_volume_pack_tiled's permutation.  One 16-byte chunk per thread.
+// f[b][y * W + x][:], ceil(H / 4) tile rows — rows y >= H of the last one are ZERO pixels, so out is [B, mv_tiled_slice_cells(H, W), C].  As
+// operand 2 of mv_corr_volume_out16 (N2 = that many) it makes the unchanged GEMM write every query's slice tiled (each output element is the
+// same k-ordered sum wherever its column sits; the padding cells come out as exact zeros = the lookup's zero padding) — the 16-bit twin of
+// mv_volume_pack_tiled's permutation.  One 16-byte chunk per thread.
 namespace {
-__global__ __launch_bounds__(256) void fmap_tile_rows16_kernel(const uint4* __restrict__ f, uint4* __restrict__ out, int N, int W, int cpr, size_t total) {
+__global__ __launch_bounds__(256) void fmap_tile_rows16_kernel(const uint4* __restrict__ f, uint4* __restrict__ out, int H, int W, int n_out, int cpr, size_t total) {
     const int tpr = W >> 2;
+    const size_t n_in = (size_t)H * W;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t rowi = i / cpr;
         const int ch = (int)(i - rowi * cpr);
-        const size_t b = rowi / N;
-        const int j = (int)(rowi - b * N);
+        const size_t b = rowi / n_out;
+        const int j = (int)(rowi - b * n_out);
         const int tile = j >> 4, cell = j & 15;
         const int ty = tile / tpr, tx = tile - ty * tpr;
-        const int src = (4 * ty + (cell >> 2)) * W + 4 * tx + (cell & 3);
-        out[i] = f[(b * N + src) * cpr + ch];
+        const int y = 4 * ty + (cell >> 2);
+        out[i] = y < H ? f[(b * n_in + (size_t)y * W + 4 * tx + (cell & 3)) * cpr + ch] : make_uint4(0u, 0u, 0u, 0u);
     }
 }
 }  // namespace
 
+extern "C" int mv_tiled_slice_cells(int H, int W) { return (H > 0 && W > 0 && (W % 4) == 0) ? ((H + 3) / 4) * 4 * W : 0; }
+
 extern "C" int mv_fmap_tile_rows16(const void* f, void* out, int B, int C, int H, int W, mvStream_t stream) {
     MV_CHECK_ARG(f && out && f != out && B > 0 && C > 0 && H > 0 && W > 0);
     MV_CHECK_ARG(((uintptr_t)f & 15) == 0 && ((uintptr_t)out & 15) == 0);
-    if ((C % 8) || (H % 4) || (W % 4)) return MV_ERR_UNSUPPORTED;
-    const int cpr = C / 8;
-    const size_t total = (size_t)B * H * W * cpr;
+    if ((C % 8) || (W % 4)) return MV_ERR_UNSUPPORTED;
+    const int cpr = C / 8, n_out = mv_tiled_slice_cells(H, W);
+    const size_t total = (size_t)B * n_out * cpr;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(fmap_tile_rows16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)f, (uint4*)out, H * W, W, cpr, total);
+    hipLaunchKernelGGL(fmap_tile_rows16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)f, (uint4*)out, H, W, n_out, cpr, total);
     return mv_launch_status();
 }

@@ -146,6 +146,7 @@ struct mvFramePipe {
     // volume_split = MV_PACK_BF16X3: packed three-piece operands of the streaming split GEMM, two sets (the pack of frame f + 1 may
     // run beside the GEMM of frame f); `packed` = the shape is covered by the streaming kernel (exact fp32 kernel otherwise)
     void* pk[2][2];
+    int n2t;           // cells per volume slice: n8, or mv_tiled_slice_cells(h8, w8) for a tiled fp16 volume (a padded last tile row when h8 % 4 != 0)
     void* tile16;      // vol16 && tiled: operand 2 with its pixel rows in 4 x 4-tile order (mv_fmap_tile_rows16; written and read on the GEMM's stream)
     size_t pk_bytes;
     bool packed;
@@ -334,7 +335,7 @@ static size_t carve(mvFramePipe* p, char* base) {
     for (int k = 0; k < 2; ++k)
         for (int o = 0; o < 2; ++o) p->pk[k][o] = p->packed ? (void*)a.take<char>(p->pk_bytes) : nullptr;
     // (carved for every Fast-mode pipe whose shape the tiled form covers — the sizing call knows the configuration, not MV_PIPE_TILED: 2 % of the volume buffers)
-    p->tile16 = (c.volume_split == MV_VOL_ENC16 && c.radius == 4 && p->h8 % 4 == 0 && p->w8 % 4 == 0) ? (void*)a.take<uint16_t>(B * n8 * c.C) : nullptr;
+    p->tile16 = (c.volume_split == MV_VOL_ENC16 && c.radius == 4 && p->w8 % 4 == 0) ? (void*)a.take<uint16_t>(B * (size_t)mv_tiled_slice_cells(p->h8, p->w8) * c.C) : nullptr;
     p->up_flow = a.take<float>(B * 2 * plane);
     p->up_cov = a.take<float>(B * 2 * plane);
     for (int k = 0; k < N_MAPS; ++k) {   // every map is [lanes, ch, H, W]
@@ -602,7 +603,10 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
         const char* e = getenv("MV_PIPE_TILED");
         const bool want = e ? atoi(e) != 0 : p->vol16;
         // [r6] Fast mode's 2-byte cells: a tile is one 32-byte sector (mv_corr_lookup_tiled_vol16: B = 64 alone 115 -> 79 us)
-        p->tiled = want && (p->packed || p->vol16) && cfg->radius == 4 && (p->h8 % 4) == 0 && (p->w8 % 4) == 0;
+        p->tiled = want && cfg->radius == 4 && (p->w8 % 4) == 0 &&
+                   (p->vol16 ? mv_corr_volume_out16_supported(cfg->pairs, cfg->C, p->n8, mv_tiled_slice_cells(p->h8, p->w8), cfg->feat_dtype, cfg->layout) != 0
+                             : (p->packed && (p->h8 % 4) == 0));
+        p->n2t = (p->tiled && p->vol16) ? mv_tiled_slice_cells(p->h8, p->w8) : p->n8;    // (2-byte cells: a padded slice still fits the buffer's n8 * n8 * 4 bytes)
     }
     {
         // MV_PIPE_SELECTOR_ON=back: the selector segment of a frame (epilogue, NMS, finishing workgroup, count copy: ~60 us beside the
@@ -758,7 +762,7 @@ static int issue_volume(mvFramePipe* p, const mvFrameInputs* in, mvStream_t in_s
             MV_TRY(mv_fmap_tile_rows16(in->fmap2, p->tile16, B, c.C, p->h8, p->w8, p->s_vol));
             op2 = p->tile16;
         }
-        MV_TRY(mv_corr_volume_out16(in->fmap1, op2, p->vol[k], B, c.C, p->n8, p->n8, c.feat_dtype, c.layout, p->s_vol));
+        MV_TRY(mv_corr_volume_out16(in->fmap1, op2, p->vol[k], B, c.C, p->n8, p->n2t, c.feat_dtype, c.layout, p->s_vol));
     } else {
         MV_TRY(mv_corr_volume(in->fmap1, in->fmap2, p->vol[k], B, c.C, p->n8, p->n8, c.feat_dtype, c.layout, p->s_vol));
     }
@@ -1693,7 +1697,7 @@ extern "C" int mv_frame_pipe_buffer(mvFramePipe* p, int which, int age, void** p
         case MV_FB_VOLUME:
             // age limit: with a GEMM issued ahead (n_vol > n_enq) the buffer of frame f - 1 is being rewritten
             if (!front(p->n_vol > p->n_enq ? 1 : 2)) break;
-            *ptr = p->vol[f % p->n_volbuf]; *count = (size_t)c.pairs * p->n8 * p->n8; return MV_OK;
+            *ptr = p->vol[f % p->n_volbuf]; *count = (size_t)c.pairs * p->n8 * p->n2t; return MV_OK;   // (n2t cells per slice: padded for a tiled fp16 volume with h8 % 4 != 0)
         case MV_FB_TOKENS: if (!front(1) || c.iters == 0) break; *ptr = p->tok[2 * (f % p->n_lk) + ((c.iters - 1) & 1)]; *count = (size_t)c.pairs * p->KK * p->n8; return MV_OK;
         case MV_FB_DISPARITY: if (!front(N_MAPS)) break; *ptr = p->maps[f % N_MAPS].disparity; *count = plane; return MV_OK;
         case MV_FB_DISPARITY_COV: if (!front(N_MAPS)) break; *ptr = p->maps[f % N_MAPS].disparity_cov; *count = plane; return MV_OK;

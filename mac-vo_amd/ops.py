@@ -197,9 +197,11 @@ def local_corr81(first: torch.Tensor, second: torch.Tensor, out: torch.Tensor | 
 
 # ------------------------------------------------------------------------------------------- A6
 def corr_lookup(cost_maps: torch.Tensor, coords: torch.Tensor, radius: int = 4, out: torch.Tensor | None = None,
-                tiled: bool = False) -> torch.Tensor:
+                tiled: bool = False, image_hw: "tuple | None" = None) -> torch.Tensor:
     """``encode_flow_token(cost_maps, coords)`` (covhead.py:92): ``[B*N1,1,H2,W2]``, ``[B,2,H1,W1]`` -> ``[B,(2r+1)^2,H1,W1]``.
-    ``tiled``: the slices of ``cost_maps`` are stored in 4 x 4-cell tiles (``volume_pack(tiled_hw=...)`` + ``corr_volume_packed``)."""
+    ``tiled``: the slices of ``cost_maps`` are stored in 4 x 4-cell tiles (``volume_pack(tiled_hw=...)`` + ``corr_volume_packed``, or
+    ``corr_volume_out16(tiled=True)``); ``image_hw=(H2, W2)``: the image the slices cover when a tiled fp16 slice carries a padded
+    last tile row (H2 % 4 != 0: ``cost_maps`` is then ``[B*N1, 1, 4 * ceil(H2 / 4), W2]``)."""
     lib = L.load()
     vol16 = cost_maps.dtype == torch.float16                    # Fast mode: the volume as `corr_volume_out16` stores it
     cost_maps = _req(cost_maps, torch.float16 if vol16 else torch.float32, "cost_maps")
@@ -209,6 +211,10 @@ def corr_lookup(cost_maps: torch.Tensor, coords: torch.Tensor, radius: int = 4, 
     BN, _, H2, W2 = cost_maps.shape
     if BN != B * H1 * W1:
         raise L.MacvoHipError("corr_lookup: cost_maps / coords shape mismatch")
+    if image_hw is not None:
+        if not (tiled and vol16) or image_hw[1] != W2 or lib.mv_tiled_slice_cells(int(image_hw[0]), W2) != H2 * W2:
+            raise L.MacvoHipError("corr_lookup: image_hw belongs to a tiled fp16 volume of mv_tiled_slice_cells(H2, W2) cells per slice")
+        H2 = int(image_hw[0])
     K = 2 * radius + 1
     if out is None:
         out = torch.empty((B, K * K, H1, W1), dtype=torch.float32, device=coords.device)
@@ -225,8 +231,12 @@ def fmap_tile_rows16(f: torch.Tensor, out: torch.Tensor | None = None) -> torch.
         raise L.MacvoHipError("fmap_tile_rows16: a [B, H, W, C] float16 / bfloat16 feature map")
     f = _req(f, f.dtype, "f")
     B, H, W, Cc = f.shape
+    cells = lib.mv_tiled_slice_cells(H, W)
+    if cells == 0:
+        raise L.MacvoHipError("fmap_tile_rows16: W % 4 != 0")
     if out is None:
-        out = torch.empty_like(f)
+        out = torch.empty((B, cells // W, W, Cc), dtype=f.dtype, device=f.device)      # (rows >= H of the last tile row: zero pixels)
+    assert out.numel() >= B * cells * Cc and out.dtype == f.dtype
     L.check(lib.mv_fmap_tile_rows16(f.data_ptr(), out.data_ptr(), B, Cc, H, W, _stream()), "mv_fmap_tile_rows16")
     return out
 
@@ -246,10 +256,14 @@ def corr_volume_out16(f1: torch.Tensor, f2: torch.Tensor, out: torch.Tensor | No
     _, H2, W2, _ = f2.shape
     N1, N2 = H1 * W1, H2 * W2
     dt = _DT[f1.dtype]
+    if tiled:                                                             # slices of mv_tiled_slice_cells(H2, W2) cells: a padded last tile row when H2 % 4 != 0
+        N2 = lib.mv_tiled_slice_cells(H2, W2)
+        if N2 == 0:
+            return None
     if not lib.mv_corr_volume_out16_supported(B, Cc, N1, N2, dt, L.MV_LAYOUT_HWC):
         return None
     if out is None:
-        out = torch.empty((B * N1, 1, H2, W2), dtype=f1.dtype, device=f1.device)
+        out = torch.empty((B * N1, 1, N2 // W2, W2), dtype=f1.dtype, device=f1.device)
     if tiled:
         f2 = fmap_tile_rows16(f2, out=scratch)
     L.check(lib.mv_corr_volume_out16(f1.data_ptr(), f2.data_ptr(), out.data_ptr(), B, Cc, N1, N2, dt, L.MV_LAYOUT_HWC, _stream()),

@@ -69,31 +69,37 @@ def test_lookup_on_the_fp16_volume_equals_the_lookup_on_its_widened_copy(gpu, B,
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("B,H,W,C", [(2, 60, 80, 256), (3, 48, 64, 128), (1, 8, 8, 256)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 60, 80, 256), (3, 48, 64, 128), (1, 8, 8, 256), (1, 59, 64, 256), (2, 90, 160, 256)])
 def test_tiled_16bit_volume_is_the_row_major_one_permuted(gpu, dt, B, H, W, C):
-    """`mv_fmap_tile_rows16` puts operand 2's pixel rows in 4 x 4-tile order; the unchanged out16 GEMM then writes every query's slice tiled —
-    each cell the same k-ordered sum with the same one rounding, wherever its column sits: bit-equal to the row-major volume permuted."""
+    """`mv_fmap_tile_rows16` puts operand 2's pixel rows in 4 x 4-tile order (H % 4 != 0: the last tile row padded with zero pixels); the unchanged
+    out16 GEMM then writes every query's slice tiled — each cell the same k-ordered sum with the same one rounding, wherever its column sits:
+    bit-equal to the row-major volume permuted, the padding cells exact zeros."""
+    import torch.nn.functional as F
     from macvo_amd import ops
 
     f1, f2 = _feats(B, H, W, C, dt, seed=W)
     d1, d2 = f1.to(gpu), f2.to(gpu)
+    Hp = -(-H // 4) * 4
     t2 = ops.fmap_tile_rows16(d2)
-    want = f2.view(B, H // 4, 4, W // 4, 4, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)       # [b][ty][tx][4][4][C]
+    assert t2.shape == (B, Hp, W, C)
+    want = F.pad(f2, (0, 0, 0, 0, 0, Hp - H)).view(B, Hp // 4, 4, W // 4, 4, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, W, C)    # [b][ty][tx][4][4][C]
     assert torch.equal(t2.cpu(), want)
     v = ops.corr_volume_out16(d1, d2)
     vt = ops.corr_volume_out16(d1, d2, tiled=True)
     if v is None:                                                        # 8 x 8: outside the streaming kernel's domain
         assert vt is None
         return
-    unt = vt.view(B * H * W, H // 4, W // 4, 4, 4).permute(0, 1, 3, 2, 4).reshape(B * H * W, 1, H, W)
-    assert torch.equal(unt, v)
+    assert vt.shape == (B * H * W, 1, Hp, W)
+    unt = vt.view(B * H * W, Hp // 4, W // 4, 4, 4).permute(0, 1, 3, 2, 4).reshape(B * H * W, 1, Hp, W)
+    assert torch.equal(unt[:, :, :H], v) and not unt[:, :, H:].any()
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 60, 80), (4, 48, 64), (14, 60, 80)])
+@pytest.mark.parametrize("B,H,W", [(2, 60, 80), (4, 48, 64), (14, 60, 80), (2, 90, 160), (2, 59, 64)])
 def test_tiled_lookup_on_fp16_cells_equals_the_row_major_lookup(gpu, B, H, W):
     """`mv_corr_lookup_tiled_vol16` on the tiled fp16 volume returns `mv_corr_lookup_vol16`'s tokens on the row-major one bit
     for bit — coordinates inside, across the border, far outside, on / next to integers (the margin-tile predicate), both kernel variants
-    ((14, 60, 80) is above the small-launch threshold) — and so equals the fp32 lookup on the widened volume (flownet.py:27)."""
+    ((14, 60, 80) is above the small-launch threshold), slices with a padded last tile row (90 and 59 rows) — and so equals the fp32 lookup on
+    the widened volume (flownet.py:27)."""
     from macvo_amd import ops
     from oracle import corr
 
@@ -115,7 +121,7 @@ def test_tiled_lookup_on_fp16_cells_equals_the_row_major_lookup(gpu, B, H, W):
             coords[:, :, 2, 2] = float("nan")
         cd = coords.to(gpu)
         a = ops.corr_lookup(v, cd, 4)
-        b_ = ops.corr_lookup(vt, cd, 4, tiled=True)
+        b_ = ops.corr_lookup(vt, cd, 4, tiled=True, image_hw=(H, W))
         assert torch.equal(a, b_) or torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b_, nan=7.0)), it
         if it == 0:
             assert torch.equal(a, ops.corr_lookup(wide, cd, 4))
@@ -124,12 +130,14 @@ def test_tiled_lookup_on_fp16_cells_equals_the_row_major_lookup(gpu, B, H, W):
 def test_tiled_fp16_lookup_rejects_what_it_does_not_cover(gpu):
     from macvo_amd import _lib as L, ops
 
-    vol = torch.zeros(6 * 6, 1, 6, 6, dtype=torch.float16, device=gpu)    # 6 % 4 != 0
-    co = torch.zeros(1, 2, 6, 6, device=gpu)
+    vol = torch.zeros(8 * 6, 1, 8, 6, dtype=torch.float16, device=gpu)    # W2 = 6: 6 % 4 != 0
+    co = torch.zeros(1, 2, 8, 6, device=gpu)
     with pytest.raises(L.MacvoHipError):
         ops.corr_lookup(vol, co, 4, tiled=True)
     with pytest.raises(L.MacvoHipError):
-        ops.fmap_tile_rows16(torch.zeros(1, 6, 8, 16, dtype=torch.float16, device=gpu))
+        ops.fmap_tile_rows16(torch.zeros(1, 8, 6, 16, dtype=torch.float16, device=gpu))
+    with pytest.raises(L.MacvoHipError):                                  # image_hw that does not match the slices
+        ops.corr_lookup(torch.zeros(64, 1, 8, 8, dtype=torch.float16, device=gpu), torch.zeros(1, 2, 8, 8, device=gpu), 4, tiled=True, image_hw=(9, 8))
 
 
 def test_flowformer_hook_returns_the_16bit_volume_in_one_pass(gpu):
@@ -191,15 +199,16 @@ def test_frame_driver_with_the_volume_stored_in_the_encoder_dtype(gpu):
         assert dt <= 1e-4 and dr <= 1e-4, (t, dt, dr)
 
 
-@pytest.mark.parametrize("lanes", [1, 3])
-def test_frame_driver_tiled_fp16_volume_equals_the_row_major_one(gpu, monkeypatch, lanes):
-    """`MV_PIPE_TILED=1` on a Fast-mode pipe: operand 2's pixel rows go through `mv_fmap_tile_rows16` in front of the out16 GEMM and the lookups are
-    `mv_corr_lookup_tiled_vol16` — tokens, keypoints and poses of the same pipe with the row-major fp16 volume, bit for bit."""
+@pytest.mark.parametrize("lanes,H,W", [(1, 480, 640), (3, 480, 640), (1, 720, 1280)])
+def test_frame_driver_tiled_fp16_volume_equals_the_row_major_one(gpu, monkeypatch, lanes, H, W):
+    """`MV_PIPE_TILED=1` (the default) on a Fast-mode pipe: operand 2's pixel rows go through `mv_fmap_tile_rows16` in front of the out16 GEMM and the
+    lookups are `mv_corr_lookup_tiled_vol16` — tokens, keypoints and poses of the same pipe with the row-major fp16 volume, bit for bit; 1280x720: slices
+    of 90 rows = 22.5 tile rows, the last one padded."""
     from macvo_amd.pipeline import Camera, FrameInputs, HotPathConfig, NativeHotPath, stack_lanes
     from tests import synth
 
     n_frames = 4
-    seqs = [synth.make_sequence(n_frames, 480, 640, C=256, iters=3, seed=300 + l, pool=1) for l in range(lanes)]
+    seqs = [synth.make_sequence(n_frames, H, W, C=256, iters=3, seed=300 + l, pool=1) for l in range(lanes)]
     cam = seqs[0][0]
 
     def to16(fr):
@@ -215,6 +224,7 @@ def test_frame_driver_tiled_fp16_volume_equals_the_row_major_one(gpu, monkeypatc
         hot = NativeHotPath(Camera(**cam), HotPathConfig(num_point=100, feature_layout="hwc", volume_store="encoder"), gpu, lanes=lanes,
                             generators=list(range(5, 5 + lanes)))
         hot.initialize(batched[0])
+        assert hot.volume_tiled == (flag == "1")
         toks, kps, poses = [], [], []
         for t in range(1, n_frames):
             res = hot.step(batched[t])

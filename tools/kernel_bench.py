@@ -157,7 +157,7 @@ def main():
                         med, mn = timeit(lambda: ops.corr_lookup(v16, co, 4, out=tok), a.iters)
                         print(f"lookup_vol16 B={B} {med:8.1f} us (min {mn:.1f})")
                         vt = ops.corr_volume_out16(a1, a2, tiled=True)
-                        med, mn = timeit(lambda: ops.corr_lookup(vt, co, 4, out=tok, tiled=True), a.iters)
+                        med, mn = timeit(lambda: ops.corr_lookup(vt, co, 4, out=tok, tiled=True, image_hw=(h8, w8)), a.iters)
                         print(f"lookup_vol16_tiled B={B} {med:8.1f} us (min {mn:.1f})")
                         del vt
                         v32 = v16.float()
