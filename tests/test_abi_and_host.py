@@ -316,3 +316,20 @@ def test_bench_roofline_object_contract():
         else:
             b16 = bench.volume_work(1, n_q, C, 2)[1]
             assert abs(r["achieved"] - b16 / 1e-4 / 1e9) < 0.02 * r["achieved"] and r["unit"] == "GB/s"
+
+
+def test_tiled_slice_cells_host_arithmetic():
+    """`mv_tiled_slice_cells(H, W)` (include/macvo_hip.h): cells of one tiled fp16 volume slice = ceil(H / 4) tile rows of W / 4 tiles of 16 cells — the slice
+    height padded to a multiple of 4; 0 where the tiling does not apply (W % 4 != 0).  Pure host arithmetic: callers size operand 2 and the volume with it."""
+    from macvo_amd import _lib as L
+
+    lib = L.load()
+    assert lib.mv_tiled_slice_cells(60, 80) == 60 * 80                    # 640x480: no padding
+    assert lib.mv_tiled_slice_cells(90, 160) == 92 * 160                  # 1280x720: 22.5 tile rows -> 23
+    assert lib.mv_tiled_slice_cells(59, 64) == 60 * 64
+    assert lib.mv_tiled_slice_cells(1, 4) == 16
+    assert lib.mv_tiled_slice_cells(47, 156) == 48 * 156                  # KITTI-sized (1248x376) slices
+    assert lib.mv_tiled_slice_cells(60, 78) == 0 and lib.mv_tiled_slice_cells(0, 80) == 0 and lib.mv_tiled_slice_cells(60, 0) == 0
+    for h in range(1, 40):
+        c = lib.mv_tiled_slice_cells(h, 8)
+        assert c % 32 == 0 and h * 8 <= c < (h + 4) * 8
