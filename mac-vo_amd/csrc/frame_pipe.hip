@@ -657,6 +657,7 @@ extern "C" int mv_frame_pipe_create(const mvFramePipeConfig* cfg, void* arena, s
         // workgroup (496 registers + 77 KB of LDS) cannot sit beside a GEMM wave (300 registers, the LDS ring) — with no CU free it waited for the gap between two GEMMs (73 of its 127 us).  Measured
         // (profiles/r05_pipe_ab.log): 0 / 8 / 16 / 32 / 48 / 64 free = 6.26 / 6.34 / 6.68 / 6.84 / 6.87 / 6.82 k frames/s; in the classic layout no gain (r3, r5).
         p->free_cus = p->alt ? 32 : 0;
+        if (const char* e = getenv("MV_PIPE_FREE_CUS")) p->free_cus = atoi(e);   // A/B knob (multiples of 8: per XCD)
         p->alt_indep = p->alt;   // (ordered segments for every selector: -6 % on the 20-step line, profiles/r05_pipe_ab.log run 18)
         // Device-driven frames: the front launch (permutation draw + gathers + both covariance models) rides behind the frame's own selector segment on its
         // decoder-side stream — no cross-queue barrier in front of it — and the fourth stream carries the solves only.  With front + solve in order on one
