@@ -183,6 +183,39 @@ def _coords(B, H, W, seed, spread=8.0):
     return corr.coords_grid(B, H, W) + (torch.rand(B, 2, H, W, generator=g) * 2 - 1) * spread
 
 
+def test_corr_lookup_both_variants_agree_for_every_radius(gpu):
+    """The two launch shapes of the lookup (16-query / 32-query workgroups; B * N1 <= / > MV_LOOKUP_SMALL) deal a wave's (tap, query) pairs differently
+    (2 / 4 queries per wave, (2r+1)^2 taps each): for every radius the forced 4-queries-per-wave variant returns the default variant's tokens bit for bit
+    — coordinates inside, across the border and far outside; ragged N1 (not a multiple of 32)."""
+    import os, subprocess, sys
+
+    code = (
+        "import sys, torch; sys.path.insert(0, sys.argv[1])\n"
+        "from macvo_amd import ops\n"
+        "from oracle import corr\n"
+        "g = torch.Generator().manual_seed(3)\n"
+        "for r in (1, 2, 3, 4):\n"
+        "    for B, H, W in ((2, 13, 17), (1, 24, 32)):\n"
+        "        vol = (torch.randn(B * H * W, 1, H, W, generator=g) * 8).cuda()\n"
+        "        co = corr.coords_grid(B, H, W) + torch.rand(B, 2, H, W, generator=g) * 14 - 7\n"
+        "        co[:, :, 0, 0] = 500.0\n"
+        "        t = ops.corr_lookup(vol, co.cuda(), r)\n"
+        "        torch.save(t.cpu(), sys.argv[2] + f'/t_{r}_{B}_{H}.pt')\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+
+    outs = []
+    for thr in ("1000000000", "0"):
+        d = tempfile.mkdtemp()
+        r = subprocess.run([sys.executable, "-c", code, root, d], env=dict(os.environ, MV_LOOKUP_SMALL=thr), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append({f: torch.load(os.path.join(d, f)) for f in sorted(os.listdir(d))})
+    assert outs[0].keys() == outs[1].keys() and len(outs[0]) == 8
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+
+
 @pytest.mark.parametrize("shape,radius", [((2, 8, 12), 4), ((1, 16, 24), 4), ((1, 7, 9), 3), ((2, 5, 6), 1), ((1, 9, 5), 2)])
 def test_corr_lookup_small(gpu, shape, radius):
     from macvo_amd import ops
