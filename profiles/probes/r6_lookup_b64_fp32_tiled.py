@@ -4,14 +4,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import torch
 from macvo_amd import ops
-from oracle import corr
+from tools.synth import coords_grid
 
 dev = torch.device("cuda:0")
 B, C, H, W = 64, 256, 60, 80
 N = H * W
 g = torch.Generator().manual_seed(1)
 f1 = torch.randn(B, C, H, W, generator=g).to(dev); f2 = torch.randn(B, C, H, W, generator=g).to(dev)
-coords = (corr.coords_grid(B, H, W) + (torch.rand(B, 2, H, W, generator=g) * 2 - 1) * 8).to(dev)
+coords = (coords_grid(B, H, W) + (torch.rand(B, 2, H, W, generator=g) * 2 - 1) * 8).to(dev)
 tok = torch.empty(B, 81, H, W, device=dev)
 pk = ops.volume_pack(f1, f2, mode="f16x2")
 vol = ops.corr_volume_packed(pk[0], pk[1], B, C, N, N, mode="f16x2").view(B * N, 1, H, W)

@@ -170,9 +170,9 @@ def main():
                 print(f"volume_{str(dt)[6:]}_chw B={B} {med:8.1f} us (min {mn:.1f})  {byts / med / 1e3:7.1f} GB/s")
         elif w == "lookup":
             ops.corr_volume(f1, f2, "chw", out=vol)
-            from oracle import corr
+            from tools.synth import coords_grid
 
-            coords = (corr.coords_grid(B, h8, w8) + (torch.rand(B, 2, h8, w8, generator=g) * 2 - 1) * 8).to(dev)
+            coords = (coords_grid(B, h8, w8) + (torch.rand(B, 2, h8, w8, generator=g) * 2 - 1) * 8).to(dev)
             tok = torch.empty((B, 81, h8, w8), dtype=torch.float32, device=dev)
             byts = B * (n * 100 * 4 + n * 8 + n * 81 * 4.0)
             med, mn = timeit(lambda: ops.corr_lookup(vol, coords, 4, out=tok), a.iters)

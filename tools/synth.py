@@ -46,10 +46,82 @@ def keypoints(n=200, H=480, W=640, seed=5, border=32):
 # ----------------------------------------------------------------------------------------------------------
 # S-e2e: a geometrically consistent synthetic stereo stream (planar scene, known SE3 trajectory)
 # ----------------------------------------------------------------------------------------------------------
-def _se3_exp(xi):
-    from oracle import se3
+def coords_grid(B: int, H: int, W: int) -> torch.Tensor:
+    """Pixel-coordinate grid ``[B, 2, H, W]`` (channel 0 = x, channel 1 = y): the zero-flow lookup coordinates of an H x W map."""
+    ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    return torch.stack([xs, ys], dim=0).to(torch.float32)[None].repeat(B, 1, 1, 1)
 
-    return se3.se3_exp(xi)
+
+class _se3:
+    """The SE(3) arithmetic the generator needs (exponential map, composition, rotation matrix; poses are [tx, ty, tz, qx, qy, qz, qw], tangents
+    [rho, phi]) — textbook closed forms, self-contained: the input generator does not import the oracle."""
+
+    @staticmethod
+    def _skew(v):
+        z = torch.zeros_like(v[..., 0])
+        return torch.stack([torch.stack([z, -v[..., 2], v[..., 1]], dim=-1), torch.stack([v[..., 2], z, -v[..., 0]], dim=-1),
+                            torch.stack([-v[..., 1], v[..., 0], z], dim=-1)], dim=-2)
+
+    @staticmethod
+    def _so3_exp(phi):                                       # axis-angle -> unit quaternion (x, y, z, w)
+        eps = torch.finfo(phi.dtype).eps
+        theta = phi.norm(dim=-1, keepdim=True)
+        theta2 = theta * theta
+        theta4 = theta2 * theta2
+        half = 0.5 * theta
+        safe = torch.where(theta > eps, theta, torch.ones_like(theta))
+        imag = torch.where(theta > eps, half.sin() / safe, 0.5 - theta2 / 48.0 + theta4 / 3840.0)
+        real = torch.where(theta > eps, half.cos(), 1.0 - theta2 / 8.0 + theta4 / 384.0)
+        return torch.cat([phi * imag, real], dim=-1)
+
+    @staticmethod
+    def _so3_Jl(phi):                                        # left Jacobian I + c1 K + c2 K^2
+        eps = torch.finfo(phi.dtype).eps
+        K = _se3._skew(phi)
+        theta = phi.norm(dim=-1, keepdim=True).unsqueeze(-1)
+        theta2 = theta * theta
+        safe = torch.where(theta > eps, theta, torch.ones_like(theta))
+        safe2 = safe * safe
+        c1 = torch.where(theta > eps, (1.0 - safe.cos()) / safe2, 0.5 - theta2 / 24.0)
+        c2 = torch.where(theta > eps, (safe - safe.sin()) / (safe * safe2), 1.0 / 6.0 - theta2 / 120.0)
+        I = torch.eye(3, dtype=phi.dtype, device=phi.device).expand(K.shape)
+        return I + c1 * K + c2 * (K @ K)
+
+    @staticmethod
+    def _quat_mul(a, b):
+        av, aw, bv, bw = a[..., :3], a[..., 3:], b[..., :3], b[..., 3:]
+        v = aw * bv + bw * av + torch.linalg.cross(av, bv)
+        w = aw * bw - (av * bv).sum(dim=-1, keepdim=True)
+        return torch.cat([v, w], dim=-1)
+
+    @staticmethod
+    def _quat_act(q, p):
+        qv, qw = q[..., :3], q[..., 3:]
+        uv = torch.linalg.cross(qv.expand(p.shape), p)
+        uv = uv + uv
+        return p + qw * uv + torch.linalg.cross(qv.expand(p.shape), uv)
+
+    @staticmethod
+    def quat_to_matrix(q):
+        x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+        return torch.stack([torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], dim=-1),
+                            torch.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], dim=-1),
+                            torch.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], dim=-1)], dim=-2)
+
+    @staticmethod
+    def se3_exp(xi):                                         # [rho, phi] -> [Jl(phi) rho, exp(phi)]
+        rho, phi = xi[..., :3], xi[..., 3:6]
+        t = (_se3._so3_Jl(phi) @ rho.unsqueeze(-1)).squeeze(-1)
+        return torch.cat([t, _se3._so3_exp(phi)], dim=-1)
+
+    @staticmethod
+    def se3_mul(a, b):                                       # a * b (b first)
+        t = a[..., :3] + _se3._quat_act(a[..., 3:], b[..., :3])
+        return torch.cat([t, _se3._quat_mul(a[..., 3:], b[..., 3:])], dim=-1)
+
+
+def _se3_exp(xi):
+    return _se3.se3_exp(xi)
 
 
 def make_camera(H=480, W=640):
@@ -66,7 +138,7 @@ def make_sequence(n_frames=4, H=480, W=640, C=256, iters=12, seed=0, feat_dtype=
     The feature maps / lookup coordinates are random (their consumer, the GRU, is not part of the hot path); only
     `pool` distinct sets are generated and cycled.
     """
-    from oracle import se3
+    se3 = _se3
 
     dev = torch.device(device)
     g = torch.Generator().manual_seed(seed)
