@@ -412,12 +412,12 @@ def patch_embed_leg(ops, vol, dev, reps=10):
     Algorithmic work per slice: 2 x (1280x16x36 + 320x32x576 + 80x64x1152) = 25.07 MFLOP; HBM: the slice in + the tokens out."""
     import torch.nn.functional as F
 
-    from oracle import patch_embed as ope
+    from tools.synth import patch_embed_weights
 
     S, H2, W2 = vol.shape[0], vol.shape[-2], vol.shape[-1]
     if not ops.cost_patch_embed_supported(H2, W2):
         return None
-    Wt = [t.to(dev) for t in ope.make_weights(0)]
+    Wt = [t.to(dev) for t in patch_embed_weights(0)]
     pk = ops.PatchEmbedWeights(*Wt)                        # fp32 layers: IEEE-half operands (TF32's mantissa), the hook's choice for fp32 / fp16 encoders
     out = torch.empty((S, (H2 + 7) // 8 * ((W2 + 7) // 8), 64), dtype=torch.float32, device=dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -457,7 +457,9 @@ def patch_embed_leg(ops, vol, dev, reps=10):
     except Exception as e:  # noqa: BLE001
         leg["fast_mode"] = {"error": repr(e)[:200]}
     try:
-        # parity of what was just timed: a few slices against the conv2d chain in the same arithmetic (16-bit operands, fp32 accumulation)
+        # parity of what was just timed: a few slices against the conv2d chain in the same arithmetic (16-bit operands, fp32 accumulation) — the oracle as the checker
+        from oracle import patch_embed as ope
+
         idx = torch.tensor([0, S // 2, S - 1])
         ref = ope.to_tokens(ope.patch_embed_proj_16(vol[idx.to(dev)].cpu(), *[t.cpu() for t in Wt], dtype=torch.float16 if pk.operand == "f16" else torch.bfloat16))
         err = float((out[idx.to(dev)].cpu() - ref).abs().max())
@@ -585,10 +587,9 @@ def kernels_leg(ops, frames, cam, args, dev, volume_roofline, patch_embed, n_q, 
     hbm("covariance", period_us(lambda: ops.match_cov(depth, kp, fcv, None, *K)), 200 * (31 * 31 * 4 + 28 + 72.0), note="MatchCovariance, N = 200, 31 x 31 window: latency-bound",
         kernel="match_cov_kernel")
     try:
-        from oracle import pgo as opgo
-        from tools.synth import pgo_batch as _to_batch
+        from tools.synth import pgo_batch as _to_batch, pgo_problem
 
-        prob, _ = opgo.make_synthetic_problem(n=200, seed=6)
+        prob, _ = pgo_problem(n=200, seed=6)
         batch = _to_batch([prob], dev)
         us = period_us(lambda: ops.pgo_solve(batch, args.graph), 60, 10)
         pose, info = ops.pgo_solve(batch, args.graph)

@@ -333,3 +333,30 @@ def test_tiled_slice_cells_host_arithmetic():
     for h in range(1, 40):
         c = lib.mv_tiled_slice_cells(h, 8)
         assert c % 32 == 0 and h * 8 <= c < (h + 4) * 8
+
+
+def test_measurement_generators_equal_the_oracle_generators():
+    """`tools/synth.py` (input generators of bench.py / tools/kernel_bench.py; self-contained: the measurement legs do not import the oracle for their
+    inputs) produces the oracle generators' values bit for bit: SE(3) helpers via a sequence, the two-frame pose-graph problem, the patch-embed weights,
+    the coordinate grid."""
+    import torch
+    from oracle import corr, patch_embed, pgo, se3
+    from tools import synth
+
+    for n, seed in ((200, 6), (37, 1)):
+        a, Ta = synth.pgo_problem(n, seed)
+        b, Tb = pgo.make_synthetic_problem(n, seed)
+        assert torch.equal(Ta, Tb) and a.baseline == b.baseline
+        for f in ("init_pose", "K", "pos_Tw", "cov_Tw", "pixel2_uv", "pixel2_d", "pixel2_disp", "pixel2_disp_cov", "pixel2_uv_cov", "obs2_covTc"):
+            assert torch.equal(getattr(a, f), getattr(b, f)), f
+    for x, y in zip(synth.patch_embed_weights(3), patch_embed.make_weights(3)):
+        assert torch.equal(x, y)
+    assert torch.equal(synth.coords_grid(2, 5, 7), corr.coords_grid(2, 5, 7))
+    xi = torch.randn(9, 6, dtype=torch.float64, generator=torch.Generator().manual_seed(2)) * 0.3
+    xi[0] = 0
+    T = synth._se3.se3_exp(xi)
+    assert torch.equal(T, se3.se3_exp(xi)) and torch.equal(synth._se3.se3_mul(T, T.flip(0)), se3.se3_mul(T, T.flip(0)))
+    assert torch.equal(synth._se3.se3_inv(T), se3.se3_inv(T)) and torch.equal(synth._se3.quat_to_matrix(T[:, 3:]), se3.quat_to_matrix(T[:, 3:]))
+    import re
+
+    assert not re.search(r"^\s*(from|import)\s+oracle\b", open(synth.__file__).read(), flags=re.M)      # the generator stands alone

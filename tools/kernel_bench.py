@@ -79,11 +79,11 @@ def main():
                       f"16-bit MFMA peak executed ({'zero' if a.zeros else 'random'} operands)")
         elif w == "patch_embed":
             # (f)2: both volumes of a frame (S = B n slices) through the fused conv stack; 2 x (36 + 16*36*... ) MAC per output, see DESIGN
-            from oracle import patch_embed as ope
+            from tools.synth import patch_embed_weights
             if not ops.cost_patch_embed_supported(h8, w8):
                 print(f"patch_embed: no kernel for {h8}x{w8} slices")
                 continue
-            Wt = [t.to(dev) for t in ope.make_weights(0)]
+            Wt = [t.to(dev) for t in patch_embed_weights(0)]
             hp, wpd = (h8 + 7) // 8 * 8, (w8 + 7) // 8 * 8
             m1, m2, m3 = hp * wpd // 4, hp * wpd // 16, hp * wpd // 64
             volr = torch.randn(B * n, 1, h8, w8, device=dev) * 16
@@ -222,11 +222,10 @@ def main():
                 med, mn = timeit(lambda: ops.match_cov(depth, kp, fc, None, 320.0, 320.0, 320.0, 240.0), a.iters)
                 print(f"match_cov N={npt:5d}    {med:8.1f} us (min {mn:.1f})")
         elif w == "pgo":
-            from oracle import pgo
-            from tools.synth import pgo_batch as _to_batch
+            from tools.synth import pgo_batch as _to_batch, pgo_problem
 
             for nprob in (1, 8, 256, 4096):
-                base = [pgo.make_synthetic_problem(n=200, seed=6 + k)[0] for k in range(min(nprob, 8))]
+                base = [pgo_problem(n=200, seed=6 + k)[0] for k in range(min(nprob, 8))]
                 probs = [base[k % len(base)] for k in range(nprob)]
                 batch = _to_batch(probs, dev)
                 for gt in ("disp", "icp"):

@@ -119,6 +119,15 @@ class _se3:
         t = a[..., :3] + _se3._quat_act(a[..., 3:], b[..., :3])
         return torch.cat([t, _se3._quat_mul(a[..., 3:], b[..., 3:])], dim=-1)
 
+    @staticmethod
+    def se3_inv(a):
+        qi = torch.cat([-a[..., 3:6], a[..., 6:]], dim=-1)
+        return torch.cat([-_se3._quat_act(qi, a[..., :3]), qi], dim=-1)
+
+    @staticmethod
+    def se3_act(a, p):                                       # R p + t
+        return _se3._quat_act(a[..., 3:], p) + a[..., :3]
+
 
 def _se3_exp(xi):
     return _se3.se3_exp(xi)
@@ -318,3 +327,58 @@ def pgo_batch(probs, dev):
         pixel2_disp_cov=cat(lambda p: p.pixel2_disp_cov.squeeze(-1)), pixel2_uv_cov=cat(lambda p: p.pixel2_uv_cov),
         obs2_covTc=cat(lambda p: p.obs2_covTc),
     )
+
+
+# ----------------------------------------------------------------------------------------------------------
+# generators of the measurement legs (bench.py kernels{} / patch_embed, tools/kernel_bench.py): the same values as the oracle's own
+# generators (tests/test_abi_and_host.py pins the equality), without importing the oracle
+# ----------------------------------------------------------------------------------------------------------
+def patch_embed_weights(seed: int = 0, scale: float = 1.0):
+    """Conv2d-default-like weights (uniform +-1/sqrt(fan_in)) of the three 6 x 6 stride-2 layers of the cost patch embedding: (w1, b1, w2, b2, w3, b3), fp32."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for cout, cin in ((16, 1), (32, 16), (64, 32)):
+        bound = scale / (cin * 36) ** 0.5
+        out.append((torch.rand(cout, cin, 6, 6, generator=g) * 2 - 1) * bound)
+        out.append((torch.rand(cout, generator=g) * 2 - 1) * bound)
+    return tuple(out)
+
+
+def pgo_problem(n: int = 200, seed: int = 6, K=(320.0, 320.0, 320.0, 240.0), baseline: float = 0.25, W: int = 640, H: int = 480,
+                trans_sigma: float = 0.1, rot_sigma: float = 0.02):
+    """Seeded two-frame pose-graph problem ``(problem, T_true [7] float64)``: ``n`` points observed in camera 1 (identity prior) and, with pixel / disparity
+    noise, in camera 2 at ``T_true``; ``problem`` carries the fields ``pgo_batch`` reads (NED points: depth first)."""
+    from types import SimpleNamespace
+
+    g = torch.Generator().manual_seed(seed)
+    fx, fy, cx, cy = K
+    Km = torch.tensor([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], dtype=torch.float32)
+    depth = 2 + 18 * torch.rand(n, generator=g)
+    u = 32 + (W - 64) * torch.rand(n, generator=g)
+    v = 32 + (H - 64) * torch.rand(n, generator=g)
+    p_w = torch.stack([depth, ((u - Km[0, 2]) * depth) / Km[0, 0], ((v - Km[1, 2]) * depth) / Km[1, 1]], dim=-1)      # world == camera-1 frame
+    xi = torch.cat([trans_sigma * torch.randn(3, generator=g), rot_sigma * torch.randn(3, generator=g)]).double()
+    T_true = _se3.se3_exp(xi)
+    p_c2 = _se3.se3_act(_se3.se3_inv(T_true), p_w.double())
+    Kd = Km.double()
+    X, Y, Z = p_c2[..., 0], p_c2[..., 1], p_c2[..., 2]
+    den = X.abs().clamp(min=torch.finfo(p_c2.dtype).tiny)
+    den = torch.where(X >= 0, den, -den)
+    uv2 = torch.stack([(Kd[0, 0] * Y + Kd[0, 2] * X) / den, (Kd[1, 1] * Z + Kd[1, 2] * X) / den], dim=-1)
+    s_uu = torch.exp(2 * 0.5 * torch.randn(n, generator=g)).clamp(min=0.0625)
+    s_vv = torch.exp(2 * 0.5 * torch.randn(n, generator=g)).clamp(min=0.0625)
+    s_uv = torch.zeros(n)
+    s_disp = (0.05 + 0.2 * torch.rand(n, generator=g))
+    uv2n = uv2 + torch.stack([s_uu.sqrt() * torch.randn(n, generator=g), s_vv.sqrt() * torch.randn(n, generator=g)], -1) * 0.3
+    disp2 = (fx * baseline) / p_c2[:, 0] + s_disp.sqrt() * torch.randn(n, generator=g) * 0.3
+    d2 = (fx * baseline) / disp2
+    sig_d = (0.02 * depth ** 2 / 20.0 + 0.05)
+    A = torch.randn(n, 3, 3, generator=g, dtype=torch.float64) * 0.05
+    cov_Tw = A @ A.transpose(-1, -2) + torch.diag_embed(torch.stack([sig_d, 0.01 * sig_d + 1e-3, 0.01 * sig_d + 1e-3], -1).double())
+    Bm = torch.randn(n, 3, 3, generator=g, dtype=torch.float64) * 0.05
+    obs_cov = Bm @ Bm.transpose(-1, -2) + torch.diag_embed(torch.stack([sig_d, 0.01 * sig_d + 1e-3, 0.01 * sig_d + 1e-3], -1).double())
+    prob = SimpleNamespace(
+        init_pose=torch.tensor([0, 0, 0, 0, 0, 0, 1], dtype=torch.float32), K=Km, baseline=baseline, pos_Tw=p_w.float(), cov_Tw=cov_Tw,
+        pixel2_uv=uv2n.float(), pixel2_d=d2.float().unsqueeze(-1), pixel2_disp=disp2.float().unsqueeze(-1), pixel2_disp_cov=s_disp.float().unsqueeze(-1),
+        pixel2_uv_cov=torch.stack([s_uu, s_vv, s_uv], -1).float(), obs2_covTc=obs_cov)
+    return prob, T_true
