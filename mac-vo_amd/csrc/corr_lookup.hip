@@ -16,9 +16,11 @@
 //     a handful of VALU ops; all loads are issued before LDS is touched; out-of-image cells are zero (= zero padding).
 //   * per-AXIS coordinate math: RAFT's normalise + ATen's un-normalise + floor/weights depend only on (query, i) for x
 //     and (query, j) for y: 2K values per query instead of 2*K*K.  Lanes [0, 2K) of an "axis pass" evaluate them for one
-//     query, the next 2K lanes for the next query, ... (true division, same fp32 op order as grid_sample), and the tap
-//     phase fetches its (weight, cell) pair per axis with ds_bpermute.  Results are bit-identical to the per-tap form.
-//   * taps: lane = tap (K*K of them in ceil(K*K/64) rounds): 4 LDS reads + the ATen bilinear sum.
+//     query, the next 2K lanes for the next query, ... (true division, same fp32 op order as grid_sample) and write the
+//     (weight, cell) entries to LDS.  Results are bit-identical to the per-tap form.
+//   * taps (round 6): the wave's QPW * K*K (tap, query) PAIRS are dealt over its lanes (324 pairs = 6 rounds for four
+//     queries; "lane = tap, query after query" took 8, every second one with 17 live lanes); a pair reads its two axis
+//     entries (two 8-byte LDS reads; rounds 1-5: four ds_bpermute), 4 cells, and forms the ATen bilinear sum.
 //   * output [B, K*K, H1, W1] is channel-major: results are transposed through LDS (aliasing the staging buffer) so
 //     every channel row is written as one QPB*4-byte segment.
 #include "common.h"
